@@ -1,0 +1,245 @@
+"""NumPy stand-in for the handful of `cv2` calls the reference hot path makes.
+
+TEST INFRASTRUCTURE ONLY.  Nothing under ``pano360_amd/`` may import this file.
+
+Why it exists: ``/root/reference/stitcher.py`` does ``import cv2`` (line 12) and
+``features.py`` calls ``cv2.xfeatures2d.SIFT_create()`` at import time
+(features.py:255,286); OpenCV is not installed in this image and its source is
+not under ``/root/reference``.  ``oracle/gen_golden.py`` installs this module as
+``sys.modules['cv2']`` so the reference's *own* NumPy code can be executed
+unchanged and its intermediate / final arrays dumped as golden fixtures.
+
+PARITY UNPINNED at the OpenCV boundary: the reference (Readme.md:22-24) pins no
+OpenCV version and ships no golden image, so ``remap``, ``GaussianBlur``,
+``cvtColor`` and ``pyrDown`` below restate OpenCV's *documented / published*
+algorithms (OpenCV 3.4/4.x ``imgproc``: ``remap`` with ``INTER_BITS=5``
+fixed-point coordinates and the float bilinear table; ``getGaussianKernel`` +
+``sepFilter2D`` row/column engines; ``borderInterpolate``).  Every assumed
+semantic is spelled out next to the code.  Everything the reference computes in
+NumPy itself (stitcher.py:73-157, 160-327, 340-369) is exercised for real.
+
+Written vectorised NumPy, float32 arithmetic with one rounding per operation
+(no FMA), so that the independent C restatement in ``pano_oracle.c`` can be
+checked against it bit for bit.
+"""
+import numpy as np
+
+# constants the reference names (stitcher.py:56-57,259,315-316; features.py)
+INTER_NEAREST = 0
+INTER_LINEAR = 1
+BORDER_CONSTANT = 0
+BORDER_REPLICATE = 1
+BORDER_REFLECT = 2
+BORDER_WRAP = 3
+BORDER_REFLECT_101 = 4
+BORDER_DEFAULT = 4
+BORDER_TRANSPARENT = 5
+COLOR_RGB2RGBA = 0
+COLOR_BGR2GRAY = 6
+CV_32F = 5
+RANSAC = 8
+
+INTER_BITS = 5
+INTER_TAB_SIZE = 1 << INTER_BITS
+
+_I32_MIN = np.int64(-2 ** 31)
+
+
+def border_interpolate(p, length, border):
+    """OpenCV ``borderInterpolate`` for REFLECT / REFLECT_101 (any distance).
+
+    REFLECT:      ... c b a | a b c ... z | z y x ...   (period 2*len)
+    REFLECT_101:  ... c b | a b c ... z | y x ...       (period 2*len-2)
+    OpenCV iterates single reflections until the index is in range; that is
+    the periodic extension used here.  ``len == 1`` returns 0.
+    """
+    p = np.asarray(p, dtype=np.int64)
+    if length == 1:
+        return np.zeros_like(p)
+    if border == BORDER_REFLECT:
+        per = 2 * length
+        m = np.mod(p, per)
+        return np.where(m < length, m, per - 1 - m)
+    if border == BORDER_REFLECT_101:
+        per = 2 * length - 2
+        m = np.mod(p, per)
+        return np.where(m < length, m, per - m)
+    raise NotImplementedError(border)
+
+
+def cv_round_f32(val):
+    """``cvRound(float)`` on x86: cvtss2si, round-half-even, and the "integer
+    indefinite" 0x80000000 for NaN / out-of-range inputs."""
+    val = np.asarray(val, dtype=np.float32)
+    with np.errstate(invalid="ignore"):
+        r = np.rint(val.astype(np.float64))
+    ok = np.isfinite(r) & (r >= -2.0 ** 31) & (r < 2.0 ** 31)
+    out = np.where(ok, r, 0.0).astype(np.int64)
+    return np.where(ok, out, _I32_MIN)
+
+
+def cvtColor(img, code):
+    """Only RGB->RGBA on float images is needed (stitcher.py:259): alpha = 1."""
+    if code != COLOR_RGB2RGBA:
+        raise NotImplementedError(code)
+    out = np.empty(img.shape[:2] + (4,), dtype=img.dtype)
+    out[..., :3] = img
+    out[..., 3] = 1
+    return out
+
+
+def remap(src, map1, map2, interpolation, borderMode=BORDER_CONSTANT):
+    """``cv2.remap`` for float32 maps, INTER_LINEAR, BORDER_REFLECT
+    (call site stitcher.py:315-316).
+
+    Assumed OpenCV semantics:
+      * coordinates are converted to fixed point: ``s = cvRound(v * 32)``
+        (float32 multiply), integer part ``s >> 5`` saturated to int16,
+        fraction ``s & 31``;
+      * weights come from the float bilinear table: products of
+        ``(1 - f/32)`` and ``f/32`` rounded to float32 (they are exact);
+      * ``dst = v00*w00 + v01*w01 + v10*w10 + v11*w11`` evaluated left to
+        right in float32, one rounding per operation;
+      * out-of-range taps go through ``borderInterpolate`` per tap.
+    """
+    if interpolation != INTER_LINEAR or borderMode != BORDER_REFLECT:
+        raise NotImplementedError((interpolation, borderMode))
+    src = np.ascontiguousarray(src, dtype=np.float32)
+    squeeze = src.ndim == 2
+    if squeeze:
+        src = src[..., None]
+    sh, sw = src.shape[:2]
+    f32 = np.float32
+    sx = cv_round_f32(np.asarray(map1, f32) * f32(INTER_TAB_SIZE))
+    sy = cv_round_f32(np.asarray(map2, f32) * f32(INTER_TAB_SIZE))
+    fx = (sx & (INTER_TAB_SIZE - 1)).astype(np.int64)
+    fy = (sy & (INTER_TAB_SIZE - 1)).astype(np.int64)
+    ix = np.clip(sx >> INTER_BITS, -32768, 32767)
+    iy = np.clip(sy >> INTER_BITS, -32768, 32767)
+
+    x0 = border_interpolate(ix, sw, borderMode)
+    x1 = border_interpolate(ix + 1, sw, borderMode)
+    y0 = border_interpolate(iy, sh, borderMode)
+    y1 = border_interpolate(iy + 1, sh, borderMode)
+
+    one = f32(1.0)
+    ax = fx.astype(f32) * f32(1.0 / INTER_TAB_SIZE)
+    ay = fy.astype(f32) * f32(1.0 / INTER_TAB_SIZE)
+    w00 = ((one - ay) * (one - ax))[..., None]
+    w01 = ((one - ay) * ax)[..., None]
+    w10 = (ay * (one - ax))[..., None]
+    w11 = (ay * ax)[..., None]
+
+    acc = src[y0, x0] * w00
+    acc = acc + src[y0, x1] * w01
+    acc = acc + src[y1, x0] * w10
+    acc = acc + src[y1, x1] * w11
+    return acc[..., 0] if squeeze else acc
+
+
+def gaussian_ksize(sigma, depth_is_8u=False):
+    """Automatic aperture of ``GaussianBlur(ksize=(0,0))``:
+    ``cvRound(sigma * (3 if 8-bit else 4) * 2 + 1) | 1``."""
+    return int(np.rint(sigma * (3 if depth_is_8u else 4) * 2 + 1)) | 1
+
+
+def getGaussianKernel(ksize, sigma, ktype=CV_32F):
+    """``cv::getGaussianKernel`` for a float32 kernel: taps exp(-x^2/2s^2)
+    evaluated in double, stored as float32, summed in double, then each tap
+    multiplied by 1/sum in double and stored as float32."""
+    if sigma <= 0:
+        sigma = ((ksize - 1) * 0.5 - 1) * 0.3 + 0.8
+    x = np.arange(ksize, dtype=np.float64) - (ksize - 1) * 0.5
+    scale2x = -0.5 / (sigma * sigma)
+    taps = np.exp(scale2x * x * x).astype(np.float32)
+    total = 0.0
+    for t in taps:          # sequential double sum, as the C loop does
+        total += float(t)
+    inv = 1.0 / total
+    return (taps.astype(np.float64) * inv).astype(np.float32)
+
+
+def sep_filter_symm(src, taps, border=BORDER_REFLECT_101):
+    """Separable symmetric filter, float32, the two engines of sepFilter2D:
+
+    row pass   : s = k[0]*x[0]; s += k[j]*x[j]  (j ascending)       -> buffer
+    column pass: s = k[c]*y[c]; s += k[c+j]*(y[c+j] + y[c-j])  (j = 1..r)
+    """
+    src = np.ascontiguousarray(src, dtype=np.float32)
+    squeeze = src.ndim == 2
+    if squeeze:
+        src = src[..., None]
+    h, w = src.shape[:2]
+    n = len(taps)
+    r = n // 2
+    taps = np.asarray(taps, np.float32)
+
+    cols = border_interpolate(np.arange(-r, w + r), w, border)
+    padded = src[:, cols]
+    acc = padded[:, 0:w] * taps[0]
+    for j in range(1, n):
+        acc = acc + padded[:, j:j + w] * taps[j]
+
+    rows = border_interpolate(np.arange(-r, h + r), h, border)
+    padded = acc[rows]
+    out = padded[r:r + h] * taps[r]
+    for j in range(1, r + 1):
+        out = out + (padded[r + j:r + j + h] + padded[r - j:r - j + h]) * taps[r + j]
+    return out[..., 0] if squeeze else out
+
+
+def GaussianBlur(src, ksize, sigmaX, sigmaY=0, borderType=BORDER_DEFAULT):
+    """``cv2.GaussianBlur`` on float32 images (call sites stitcher.py:226,
+    features.py:24).  ksize (0,0) -> automatic aperture (4 sigma for float)."""
+    kx, ky = ksize
+    if sigmaY <= 0:
+        sigmaY = sigmaX
+    if kx <= 0 and sigmaX > 0:
+        kx = gaussian_ksize(sigmaX)
+    if ky <= 0 and sigmaY > 0:
+        ky = gaussian_ksize(sigmaY)
+    if kx != ky or sigmaX != sigmaY:
+        raise NotImplementedError("anisotropic blur is never requested")
+    return sep_filter_symm(src, getGaussianKernel(kx, sigmaX), borderType)
+
+
+def pyrDown(src):
+    """``cv2.pyrDown``: 5x5 separable [1 4 6 4 1]/16 (x1/256 overall),
+    REFLECT_101, keep even rows/cols, output ((w+1)//2, (h+1)//2).
+    Float path assumed: ``c*6 + (l1+r1)*4 + l2 + r2`` (left to right) along
+    rows, the same along columns, scaled by 1/256 at the end."""
+    src = np.ascontiguousarray(src, dtype=np.float32)
+    h, w = src.shape[:2]
+    oh, ow = (h + 1) // 2, (w + 1) // 2
+    f32 = np.float32
+    cx = border_interpolate(np.arange(-2, 2 * ow + 2), w, BORDER_REFLECT_101)
+    p = src[:, cx]
+    c = np.arange(ow) * 2
+    row = (p[:, c + 2] * f32(6) + (p[:, c + 1] + p[:, c + 3]) * f32(4)
+           + p[:, c] + p[:, c + 4])
+    ry = border_interpolate(np.arange(-2, 2 * oh + 2), h, BORDER_REFLECT_101)
+    q = row[ry]
+    r_ = np.arange(oh) * 2
+    out = (q[r_ + 2] * f32(6) + (q[r_ + 1] + q[r_ + 3]) * f32(4)
+           + q[r_] + q[r_ + 4])
+    return out * f32(1.0 / 256.0)
+
+
+class _NoSift:
+    """``features.py:255,286`` evaluates ``sift_detector()`` as a default
+    argument at import; the object only has to exist."""
+
+    def detectAndCompute(self, img, mask):
+        raise NotImplementedError("SIFT lives inside OpenCV; not restated here")
+
+
+class xfeatures2d:  # noqa: N801  (mirrors the cv2 attribute name)
+    @staticmethod
+    def SIFT_create(*args, **kwargs):
+        return _NoSift()
+
+
+def install():
+    """Register this module as ``cv2`` (used by gen_golden.py only)."""
+    import sys
+    sys.modules["cv2"] = sys.modules[__name__]

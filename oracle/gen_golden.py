@@ -1,0 +1,277 @@
+#!/usr/bin/env python3
+"""Generate golden vectors by RUNNING THE REFERENCE in this container.
+
+TEST INFRASTRUCTURE.  Run once here (``python oracle/gen_golden.py``); the
+``.npz`` files it writes under ``tests/golden/`` are committed, this script is
+committed, and nothing from ``/root/reference`` travels anywhere.
+
+How: ``oracle/cv2_shim.py`` is installed as ``cv2``, then the reference's own
+``stitcher.py`` / ``bundle_adj.py`` are imported from ``/root/reference`` and
+driven on small seeded scenes.  A spying ``remap`` and a spying blender capture
+the intermediate arrays.  Two classes of fixture result:
+
+* "pure" keys  - produced by the reference's NumPy code alone (projection
+  round trips, hat weights, ranges, resolution, mosaic shape, patch slices,
+  inverse maps, masks, valid mask, crop rectangle);
+* "shim" keys  - reference logic + the restated OpenCV primitives (warped
+  patches and the none / linear / multiband mosaics).  Parity at the OpenCV
+  boundary is unpinned (see cv2_shim.py header).
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(HERE)
+REF = "/root/reference"
+OUT = os.path.join(REPO, "tests", "golden")
+
+sys.path.insert(0, HERE)
+sys.path.insert(0, REPO)
+import cv2_shim  # noqa: E402
+
+cv2_shim.install()
+_REAL_REMAP = cv2_shim.remap
+sys.path.insert(0, REF)
+import bundle_adj as ref_ba  # noqa: E402  (the reference's)
+import stitcher as ref_st  # noqa: E402  (the reference's)
+
+from pano360_amd import synth  # noqa: E402  (scene recipe only; plain arrays)
+
+assert ref_st.__file__.startswith(REF), ref_st.__file__
+assert ref_ba.__file__.startswith(REF), ref_ba.__file__
+
+
+def regions_from(imgs, rots, intrs):
+    return [ref_ba.Image(img.copy(), rot.copy(), intr.copy())
+            for img, rot, intr in zip(imgs, rots, intrs)]
+
+
+class Spy:
+    """Captures remap inputs and what the blender is handed."""
+
+    def __init__(self):
+        self.maps = []
+        self.patches = None
+        self.shape = None
+
+    def remap(self, src, m1, m2, interp, borderMode=0):
+        self.maps.append((np.array(m1, copy=True), np.array(m2, copy=True)))
+        return _REAL_REMAP(src, m1, m2, interp, borderMode=borderMode)
+
+    def wrap(self, blender):
+        def _spy_blend(patches, shape):
+            self.patches = [(w.copy(), m.copy(),
+                             (ir[0].start, ir[0].stop, ir[1].start, ir[1].stop))
+                            for w, m, ir in patches]
+            self.shape = tuple(shape)
+            return blender(patches, shape)
+        return _spy_blend
+
+
+def run_stitch(imgs, rots, intrs, blend, crop=False, n_levels=None,
+               max_resolution=None):
+    """Drive reference stitch(); returns (mosaic, spy, regions)."""
+    spy = Spy()
+    saved = (ref_st.cv2.remap, ref_st.multiband_blend, ref_st.MAX_RESOLUTION,
+             ref_st.multiband_blend.__defaults__)
+    regions = regions_from(imgs, rots, intrs)
+    try:
+        ref_st.cv2.remap = spy.remap
+        if max_resolution is not None:
+            ref_st.MAX_RESOLUTION = max_resolution
+        if blend == "multiband":
+            if n_levels is not None:
+                saved[1].__defaults__ = (n_levels,)
+            # the 10 px padding is keyed on `blender == multiband_blend`
+            # (stitcher.py:295): rebind the module global to the spy wrapper
+            wrapped = spy.wrap(saved[1])
+            ref_st.multiband_blend = wrapped
+            blender = wrapped
+        else:
+            blender = spy.wrap(ref_st.BLENDERS[blend])
+        mosaic = ref_st.stitch(regions, blender=blender, crop=crop)
+    finally:
+        ref_st.cv2.remap = saved[0]
+        ref_st.multiband_blend = saved[1]
+        ref_st.MAX_RESOLUTION = saved[2]
+        saved[1].__defaults__ = saved[3]
+    return mosaic, spy, regions
+
+
+def crop_rect(valid):
+    """Rectangle picked by the reference crop_mosaic, as (y0, x0, h, w)."""
+    h, w = valid.shape
+    probe = np.zeros((h, w, 3), np.int32)
+    probe[..., 0] = np.arange(h)[:, None]
+    probe[..., 1] = np.arange(w)[None, :]
+    view = ref_st.crop_mosaic(probe, valid)
+    return np.array([view[0, 0, 0], view[0, 0, 1], view.shape[0], view.shape[1]],
+                    dtype=np.int64)
+
+
+def scene_fixture(name, n, width, height, sweep_deg, jitter, seed, kind,
+                  levels=(5,), max_resolution=None, keep_warped=True):
+    imgs, rots, intrs = synth.make_scene(n, width, height, sweep_deg=sweep_deg,
+                                         jitter=jitter, seed=seed, kind=kind)
+    out = dict(imgs=np.stack(imgs), rots=rots, intrs=intrs,
+               max_resolution=np.int64(-1 if max_resolution is None
+                                       else max_resolution))
+    # ---- multiband (padded patches) -------------------------------------
+    for lv in levels:
+        mosaic, spy, regions = run_stitch(imgs, rots, intrs, "multiband",
+                                          n_levels=lv,
+                                          max_resolution=max_resolution)
+        out[f"mb{lv}_mosaic"] = mosaic
+        if lv == levels[0]:
+            out["mb_shape"] = np.array(spy.shape, np.int64)
+            out["range_min"] = np.stack([r.range[0] for r in regions])
+            out["range_max"] = np.stack([r.range[1] for r in regions])
+            # estimate_resolution is pure: re-evaluate on the mutated regions
+            saved = ref_st.MAX_RESOLUTION
+            if max_resolution is not None:
+                ref_st.MAX_RESOLUTION = max_resolution
+            res, (mn, mx) = ref_st.estimate_resolution(regions)
+            ref_st.MAX_RESOLUTION = saved
+            out["resolution"], out["im_min"], out["im_max"] = res, mn, mx
+            out["alpha0"] = regions[0].img[..., 3].copy()   # _add_weights
+            for i, ((m1, m2), (warped, mask, ir)) in enumerate(
+                    zip(spy.maps, spy.patches)):
+                out[f"mb_irange_{i}"] = np.array(ir, np.int64)
+                out[f"mb_mapx_{i}"], out[f"mb_mapy_{i}"] = m1, m2
+                out[f"mb_mask_{i}"] = mask
+                if keep_warped:
+                    out[f"mb_warped_{i}"] = warped
+            valid = ref_st._valid(
+                [(w, m, np.s_[ir[0]:ir[1], ir[2]:ir[3]])
+                 for w, m, ir in spy.patches], spy.shape)
+            out["mb_valid"] = valid
+            out["mb_crop_rect"] = crop_rect(valid)
+    # ---- linear / none (unpadded patches) --------------------------------
+    for blend in ("linear", "none"):
+        mosaic, spy, _ = run_stitch(imgs, rots, intrs, blend,
+                                    max_resolution=max_resolution)
+        out[f"{blend}_mosaic"] = mosaic
+        if blend == "linear":
+            out["lin_shape"] = np.array(spy.shape, np.int64)
+            for i, ((m1, m2), (warped, mask, ir)) in enumerate(
+                    zip(spy.maps, spy.patches)):
+                out[f"lin_irange_{i}"] = np.array(ir, np.int64)
+                out[f"lin_mask_{i}"] = mask
+            valid = ref_st._valid(
+                [(w, m, np.s_[ir[0]:ir[1], ir[2]:ir[3]])
+                 for w, m, ir in spy.patches], spy.shape)
+            out["lin_valid"] = valid
+            out["lin_crop_rect"] = crop_rect(valid)
+            # cropped stitch straight through the reference entry point
+            cropped, _, _ = run_stitch(imgs, rots, intrs, "linear", crop=True,
+                                       max_resolution=max_resolution)
+            out["lin_cropped"] = cropped
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **out)
+    print(f"{name}: {os.path.getsize(path) / 1e6:.2f} MB, multiband mosaic "
+          f"{out['mb_shape']}, linear mosaic {out['lin_shape']}")
+
+
+def pure_fixture():
+    """Stage functions that need no OpenCV at all."""
+    rng = np.random.default_rng(1234)
+    out = {}
+    pts = rng.normal(size=(64, 3))
+    out["sph_pts"] = pts
+    out["sph_h2p"] = ref_st.SphProj.hom2proj(pts)
+    out["sph_p2h"] = ref_st.SphProj.proj2hom(out["sph_h2p"])
+    out["cyl_h2p"] = ref_st.CylProj.hom2proj(pts)
+    out["cyl_p2h"] = ref_st.CylProj.proj2hom(out["cyl_h2p"])
+    for size in (1, 2, 7, 64, 135):
+        out[f"hat_{size}"] = ref_st._hat(size)
+    rot = ref_ba.rotation_to_mat(np.array([0.05, -0.4, 0.02]))
+    cam = ref_ba.Image(None, rot, ref_ba.intrinsics(300.0))
+    out["cam_rot"], out["cam_intr"] = rot, cam.intr
+    out["cam_hom"], out["cam_proj"] = cam.hom(), cam.proj()
+    mn, mx = ref_st._proj_img_range_border((72, 128), cam.hom())
+    out["border_min"], out["border_max"] = mn, mx
+    mn, mx = ref_st._proj_img_range_corners((72, 128), cam.hom())
+    out["corners_min"], out["corners_max"] = mn, mx
+    out["rot_vecs"] = rng.normal(size=(5, 3))
+    out["rot_mats"] = np.stack([ref_ba.rotation_to_mat(v)
+                                for v in out["rot_vecs"]])
+    out["intr_pair"] = ref_ba.intrinsics((250.0, 999.0), (3.0, -4.0))
+
+    # crop_mosaic on hand-made masks, ties and the column-0 quirk included
+    masks = []
+    m = np.zeros((6, 7), bool); m[1:4, 2:6] = True; masks.append(m)
+    m = np.ones((5, 5), bool); masks.append(m)
+    m = np.zeros((6, 8), bool); m[0:2, 0:4] = True; m[3:5, 4:8] = True
+    masks.append(m)                                   # two equal areas
+    m = np.zeros((4, 6), bool); m[:, 0] = True; m[0:2, :] = True
+    masks.append(m)                                   # column 0 is the post
+    m = np.zeros((5, 6), bool); m[0:2, 0] = True; m[0:3, 1:3] = True
+    masks.append(m)                                   # heights [2,3,3]
+    m = np.zeros((3, 9), bool); m[1, 4] = True; masks.append(m)
+    for s in range(6):
+        r2 = np.random.default_rng(100 + s)
+        masks.append(r2.random((23, 37)) < (0.55 + 0.07 * s))
+    for s in range(3):
+        r2 = np.random.default_rng(200 + s)
+        m = r2.random((40, 64)) < 0.97
+        masks.append(m)
+    out["n_crop"] = np.int64(len(masks))
+    for i, m in enumerate(masks):
+        out[f"crop_mask_{i}"] = m
+        out[f"crop_rect_{i}"] = crop_rect(m)
+
+    # linear / none / multiband blenders on hand-made patches (stage API)
+    r3 = np.random.default_rng(77)
+    shape = (40, 70)
+    patches, meta = [], []
+    for y0, y1, x0, x1 in [(0, 30, 0, 40), (5, 40, 20, 70), (10, 35, 35, 60)]:
+        w = r3.random((y1 - y0, x1 - x0, 4)).astype(np.float32)
+        msk = r3.random((y1 - y0, x1 - x0)) < 0.15
+        w[..., 3] = w[..., 3] * (~msk)
+        patches.append((w, msk, np.s_[y0:y1, x0:x1]))
+        meta.append((y0, y1, x0, x1))
+    out["bl_shape"] = np.array(shape, np.int64)
+    out["bl_n"] = np.int64(len(patches))
+    for i, ((w, msk, _), ir) in enumerate(zip(patches, meta)):
+        out[f"bl_warped_{i}"], out[f"bl_mask_{i}"] = w.copy(), msk.copy()
+        out[f"bl_irange_{i}"] = np.array(ir, np.int64)
+
+    def fresh():
+        return [(w.copy(), m.copy(), ir) for w, m, ir in patches]
+    out["bl_none"] = ref_st.no_blend(fresh(), shape)
+    out["bl_linear"] = ref_st.linear_blend(fresh(), shape)
+    out["bl_mb5"] = ref_st.multiband_blend(fresh(), shape)
+    out["bl_mb3"] = ref_st.multiband_blend(fresh(), shape, n_levels=3)
+    out["bl_valid"] = ref_st._valid(fresh(), shape)
+
+    # blur / pyrDown / gaussian_filter vectors through the reference's
+    # features.gaussian_filter ksize rule (features.py:20-24)
+    import features as ref_ft
+    assert ref_ft.__file__.startswith(REF)
+    img = r3.random((37, 53)).astype(np.float32)
+    out["gf_img"] = img
+    out["gf_s1"] = ref_ft.gaussian_filter(img)            # sigma 1 -> 5 taps
+    out["gf_s2"] = ref_ft.gaussian_filter(img, 2.0)       # sigma 2 -> 11 taps
+    out["pyr_1"] = cv2_shim.pyrDown(img)
+    out["pyr_2"] = cv2_shim.pyrDown(out["pyr_1"])
+    path = os.path.join(OUT, "pure.npz")
+    np.savez_compressed(path, **out)
+    print(f"pure: {os.path.getsize(path) / 1e6:.2f} MB")
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    pure_fixture()
+    scene_fixture("scene_small_noise", n=4, width=96, height=64, sweep_deg=60.0,
+                  jitter=0.01, seed=0, kind="A", levels=(5, 6))
+    scene_fixture("scene_small_smooth", n=5, width=128, height=72,
+                  sweep_deg=100.0, jitter=0.01, seed=10, kind="B", levels=(5,))
+    scene_fixture("scene_capped", n=8, width=240, height=136, sweep_deg=140.0,
+                  jitter=0.0, seed=20, kind="B", levels=(5,),
+                  max_resolution=300, keep_warped=False)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,66 @@
+"""Camera record consumed by the warp/blend hot path.
+
+Only the *input type* of the path is mirrored here (reference
+``bundle_adj.py:18-33`` ``Image``, ``:82-87`` ``intrinsics``, ``:96-101``
+``rotation_to_mat``).  Feature matching and Levenberg-Marquardt bundle
+adjustment are registration, outside the accelerated path, and
+are not rebuilt.
+
+The class is importable as ``bundle_adj.Image`` through the top-level
+``bundle_adj.py`` re-export, so ``ba_<name>.pkl`` caches written by the
+reference CLI (stitcher.py:430-439) unpickle into it unchanged.
+"""
+from dataclasses import dataclass, field
+
+import numpy as np
+
+
+def _zero_range():
+    return (np.zeros(2), np.zeros(2))
+
+
+@dataclass
+class Image:
+    """One registered frame: pixels, rotation R, calibration K, angular range.
+
+    ``img``   uint8 [H, W, 3] on entry to ``stitch`` (channel order opaque).
+    ``rot``   float64 3x3 world->camera rotation.
+    ``intr``  float64 3x3 ``[[f,0,cx],[0,f,cy],[0,0,1]]``.
+    ``range`` (min, max) spherical angles, filled in by ``stitch``.
+    """
+
+    img: np.ndarray
+    rot: np.ndarray
+    intr: np.ndarray
+    range: tuple = field(default_factory=_zero_range)
+
+    def hom(self):
+        """Pixel -> ray: ``R^T K^-1`` (reference bundle_adj.py:27-29)."""
+        return self.rot.T.dot(np.linalg.inv(self.intr))
+
+    def proj(self):
+        """Ray -> pixel: ``K R`` (reference bundle_adj.py:31-33)."""
+        return self.intr.dot(self.rot)
+
+
+def intrinsics(focal, center=(0, 0)):
+    """Calibration matrix; like the reference (bundle_adj.py:82-87) a pair of
+    focals is accepted but only the first one is used for both axes."""
+    if not isinstance(focal, (list, tuple)):
+        focal = (focal, focal)
+    f = focal[0]
+    return np.array([[f, 0, center[0]],
+                     [0, f, center[1]],
+                     [0, 0, 1]])
+
+
+def rotation_to_mat(rad):
+    """Rodrigues formula, exponential map -> matrix (bundle_adj.py:96-101).
+    Unlike the reference there is no random default argument."""
+    rad = np.asarray(rad, dtype=np.float64)
+    ang = np.linalg.norm(rad)
+    axis = rad / ang if ang else rad
+    k = np.array([[0, -axis[2], axis[1]],
+                  [axis[2], 0, -axis[0]],
+                  [-axis[1], axis[0], 0]])
+    return np.eye(3) + k * np.sin(ang) + (1 - np.cos(ang)) * k.dot(k)
