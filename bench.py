@@ -1,0 +1,224 @@
+#!/usr/bin/env python3
+"""Headline benchmark: blended megapixels/s of warp + multiband blend.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = one full stitch of the workload: uint8 frames + cameras resident
+in HBM -> uint8 mosaic in HBM (the boundary of the reference's own timer,
+stitcher.py:441-444): host geometry, spherical warp, ownership, the L-1
+Gaussian blurs per frame, band-pass collapse.  value = sum of patch pixels the
+reference algorithm warps and blends ("P") / step time.
+
+Workload (BASELINE.json): the metric is quoted on N x 4K frames, so the default
+is config 3 - 32 synthetic 3840x2160 frames, 5 deg yaw steps, hfov 60 deg,
+native resolution, 5 levels - on however many GPUs are given (strong scaling:
+frames are split into contiguous blocks, one block per rank).  ``--workload
+cfg2`` runs the 8 x 1080p configuration instead.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+F32_PEAK_TFLOPS = 157.3         # f32 vector == f32 MFMA peak on gfx950
+NATIVE = 10 ** 9                # MAX_RESOLUTION that never caps
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="cfg3", choices=["cfg2", "cfg3", "tiny"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+def workload(name):
+    from pano360_amd import synth
+    if name == "tiny":
+        return dict(n=8, width=320, height=180, sweep_deg=140.0, n_levels=5)
+    return dict(synth.CONFIGS[name])
+
+
+def kernel_times(lib):
+    import ctypes as C
+    out = {}
+    for kid in range(lib.pano_kernel_count()):
+        ms, n = C.c_double(), C.c_int()
+        lib.pano_timing_read(kid, C.byref(ms), C.byref(n))
+        if n.value:
+            out[lib.pano_kernel_name(kid).decode()] = (ms.value, n.value)
+    return out
+
+
+def roofline_for(times, plan, n_levels, steps, source_px):
+    """Roofline entry of the kernel with the largest share of the timed region.
+    Algorithmic work per launch is derived from the plan."""
+    from pano360_amd import engine
+    name = max(times, key=lambda k: times[k][0])
+    total_ms, launches = times[name]
+    avg_s = total_ms / launches * 1e-3
+    P = plan.patch_pixels
+    M = plan.shape[0] * plan.shape[1]
+    taps = [engine.gaussian_ksize(s) for s in engine.level_sigmas(n_levels)]
+    if name in ("blur_rows_kernel", "blur_cols_kernel"):
+        # one launch = one level of one patch, 4 channels: taps FMAs per output
+        flop = steps * sum(2.0 * t * 4 * P for t in taps)
+        achieved = flop / launches / avg_s / 1e12
+        return dict(kernel=name, bound="mfma", achieved=achieved, peak=F32_PEAK_TFLOPS,
+                    unit="TFLOP/s", frac=achieved / F32_PEAK_TFLOPS, traffic=None,
+                    note="f32 FMA on the vector ALU; gfx950 f32 MFMA peak equals the "
+                         "f32 vector peak (157.3 TFLOP/s), no MFMA is issued",
+                    avg_launch_ms=avg_s * 1e3, launches=launches)
+    per_step = {
+        "warp_spherical_kernel": 17.0 * P + 3.0 * source_px,
+        "ownership_kernel": 5.0 * P + 3.0 * M,
+        "multiband_compose_kernel": (12.0 + 16.0 * (n_levels - 1)) * P + 6.0 * M,
+        "linear_blend_kernel": 17.0 * P + 3.0 * M,
+        "no_blend_kernel": 13.0 * P + 3.0 * M,
+    }.get(name, 0.0)
+    achieved = per_step * steps / launches / avg_s / 1e9
+    return dict(kernel=name, bound="hbm", achieved=achieved, peak=HBM_PEAK_GBPS,
+                unit="GB/s", frac=achieved / HBM_PEAK_GBPS, traffic=None,
+                avg_launch_ms=avg_s * 1e3, launches=launches)
+
+
+def cpu_baseline(cfg):
+    """The CPU oracle (C + OpenMP restatement of the reference path) timed on
+    this host on a bounded sample: the first 4 frames of the same sweep."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import pano_oracle as po
+    from pano360_amd import synth
+    n = min(4, cfg["n"])
+    step = cfg.get("step_deg") or cfg["sweep_deg"] / (cfg["n"] - 1)
+    imgs, rots, intrs = synth.make_scene(n, cfg["width"], cfg["height"], step_deg=step,
+                                         seed=0, kind="A")
+    plan = po.Plan([im.shape[:2] for im in imgs], rots, intrs, True, NATIVE)
+    px = sum((r[1] - r[0]) * (r[3] - r[2]) for r in plan.rects)
+    t0 = time.time()
+    po.stitch(imgs, rots, intrs, "multiband", cfg["n_levels"], max_resolution=NATIVE)
+    dt = time.time() - t0
+    return dict(value=px / dt / 1e6, unit="MP/s", cores=po.max_threads(), kind="port",
+                sample=f"first {n} of the {cfg['n']} frames ({cfg['width']}x{cfg['height']}, "
+                       f"{step:.2f} deg/step), multiband L={cfg['n_levels']}, native "
+                       f"resolution, {px / 1e6:.1f} MP of patches in {dt:.1f} s; oracle = "
+                       f"oracle/pano_oracle.c (gcc -O2 -fopenmp), {os.cpu_count()} host CPUs")
+
+
+def main():
+    args = parse()
+    import torch
+    from pano360_amd import _lib, engine, synth
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for N > 1")
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+
+    cfg = workload(args.workload)
+    n_levels = cfg["n_levels"]
+    rots, intrs = synth.make_cameras(cfg["n"], cfg["width"], cfg["height"],
+                                     sweep_deg=cfg.get("sweep_deg"),
+                                     step_deg=cfg.get("step_deg"))
+    shapes = [(cfg["height"], cfg["width"])] * cfg["n"]
+    eng = engine.Engine(f"cuda:{local}")
+
+    if world > 1:
+        from pano360_amd import dist as pdist
+        runner = pdist.ShardedStitcher(eng, shapes, rots, intrs, n_levels, rank, world)
+        mine = runner.my_frames
+    else:
+        runner = None
+        mine = range(cfg["n"])
+    frames = eng.upload_frames([synth.make_frame(i, cfg["width"], cfg["height"], "A")
+                                for i in mine])
+
+    def step():
+        if runner is not None:
+            return runner.step(frames)
+        plan = engine.Plan(shapes, rots, intrs, True, NATIVE)
+        mosaic, _, _, _ = eng.stitch(frames, plan, "multiband", n_levels)
+        return plan, mosaic
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    eng.lib.pano_timing_enable(1)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        plan, mosaic = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    times = kernel_times(eng.lib)
+    eng.lib.pano_timing_enable(0)
+    if dist is not None:
+        tt = torch.tensor([elapsed], device=eng.device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = tt.item()
+
+    if rank == 0:
+        ms = elapsed / args.steps * 1e3
+        P, M = plan.patch_pixels, plan.shape[0] * plan.shape[1]
+        S = cfg["n"] * cfg["width"] * cfg["height"]
+        algo_bytes = 3.0 * S + (33 + 64 * n_levels) * P + (16 * n_levels + 3) * M
+        out = {
+            "metric": "blended megapixels/sec (multiband)",
+            "value": P / (ms * 1e-3) / 1e6,
+            "unit": "MP/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"{args.workload}: {cfg['n']} synthetic {cfg['width']}x"
+                            f"{cfg['height']} frames, spherical warp + multiband blend "
+                            f"L={n_levels}, native resolution (MAX_RESOLUTION uncapped)",
+                "frames": cfg["n"], "mosaic": list(plan.shape),
+                "patch_megapixels": P / 1e6, "source_megapixels": S / 1e6,
+                "mosaic_megapixels": M / 1e6,
+                "parallelism": f"frames sharded in contiguous blocks over {world} GPU(s)",
+            },
+            "pipeline": {
+                "algorithmic_GB_per_step": algo_bytes / 1e9,
+                "algorithmic_GBps": algo_bytes / (ms * 1e-3) / 1e9,
+                "frac_of_hbm_peak": algo_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                "input_MPps": S / (ms * 1e-3) / 1e6, "mosaic_MPps": M / (ms * 1e-3) / 1e6,
+            },
+            "kernel_ms_per_step": {k: v[0] / args.steps for k, v in sorted(times.items())},
+            "roofline": roofline_for(times, plan, n_levels, args.steps, S),
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(cfg)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

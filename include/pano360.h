@@ -1,0 +1,154 @@
+/*
+ * pano360.h - C ABI of libpano360_hip.so (MI355X / gfx950).
+ *
+ * The reference (Banus/pano360) is pure Python and has no FFI; its boundary
+ * for the warp/blend hot path is the Python function surface of stitcher.py.
+ * Each entry point below names the reference function (file:line, relative to
+ * the reference repo) whose arithmetic it replaces.  pano360_amd/stitcher.py
+ * keeps those Python signatures and calls these symbols through ctypes
+ * (INTEGRATION.md shows the binding).
+ *
+ * Conventions
+ *   - every pointer marked "dev" is a device (HBM) pointer owned by the
+ *     caller; "host" pointers are ordinary host memory read before return;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); all
+ *     work is enqueued asynchronously on it, nothing synchronises;
+ *   - return value: 0 on success, a negative PANO_E* code otherwise, with a
+ *     thread-local message available from pano_last_error();
+ *   - no exceptions cross the boundary, no global mutable state.
+ *
+ * Layouts
+ *   frame      uint8  [H][W][3]      as cv2.imread hands it to the reference
+ *   planes     float  [4][h][pitch]  planar R,G,B,A of a warped patch,
+ *                                    pitch = pano_pitch(w) floats (16-B rows)
+ *   mask       uint8  [h][w]         1 = outside the source frame
+ *   owner      int16  [H][W]         patch index owning the pixel, -1 = none
+ *   mosaic     uint8  [H][W][3]
+ */
+#ifndef PANO360_H
+#define PANO360_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PANO_OK 0
+#define PANO_EINVAL (-1)   /* bad argument (shape, null pointer, limits)   */
+#define PANO_EHIP (-2)     /* a HIP runtime call failed                    */
+#define PANO_ELIMIT (-3)   /* size beyond a compiled-in limit              */
+
+#define PANO_MAX_TAPS 129      /* largest Gaussian aperture (sigma <= 16)  */
+#define PANO_MAX_LEVELS 8      /* n_levels of multiband_blend              */
+#define PANO_TAP_LEAD 7        /* zero taps in front of a padded tap table */
+#define PANO_TAP_PAD 40        /* padded table length = ntaps + this       */
+
+/* One warped patch as the blenders see it (reference: the tuples appended at
+ * stitcher.py:318-319).  All pointers dev.  `blurred` holds the n_levels-1
+ * Gaussian-blurred copies, [level][4][h][pitch]; may be NULL for the
+ * non-multiband blenders. */
+typedef struct pano_patch {
+    float *planes;
+    uint8_t *mask;
+    float *blurred;
+    int32_t y0, x0, h, w;      /* rectangle in mosaic coordinates          */
+    int32_t pitch;             /* floats per plane row                     */
+    int32_t reserved;
+} pano_patch;
+
+const char *pano_version(void);
+const char *pano_last_error(void);
+int pano_device_count(void);
+/* Row pitch (in floats) used for every float plane of width w. */
+int pano_pitch(int w);
+
+/* Instrumentation for bench.py (no reference counterpart): when enabled every
+ * kernel launch is bracketed by HIP events recorded on its own stream.
+ * pano_timing_read waits for kernel class `kid`'s events and returns the
+ * summed duration in ms and the number of launches since the last enable. */
+int pano_timing_enable(int on);
+int pano_kernel_count(void);
+const char *pano_kernel_name(int kid);
+int pano_timing_read(int kid, double *total_ms, int *launches);
+
+/* _add_weights                                        stitcher.py:251-263
+ * frame uint8 [h][w][3] -> rgba float32 [h][w][4] interleaved (the array the
+ * reference leaves in reg.img).  lut255: dev float[256] = float32(i)/255
+ * (built on the host with NumPy); hat_x / hat_y: dev double[w] / [h]. */
+int pano_add_weights(const uint8_t *frame, int h, int w, const float *lut255,
+                     const double *hat_x, const double *hat_y, float *rgba,
+                     void *stream);
+
+/* Inverse map + mask + bilinear REFLECT remap of one patch
+ *                                       stitcher.py:300-317 (+ cv2.remap)
+ * proj: host double[9] = K R row-major (bundle_adj.py:31-33).
+ * sin_t, cos_t: dev double tables over mosaic columns, tan_p over mosaic rows
+ * (angles = index*resolution + min, stitcher.py:301-303, NumPy on the host).
+ * (gx0, gy0) = patch origin in the mosaic, pw x ph = patch size.
+ * Outputs: planes [4][ph][pitch] (alpha already multiplied by ~mask, :317),
+ * mask [ph][pw]; map_x / map_y float [ph][pw] optional (NULL to skip). */
+int pano_warp_spherical(const uint8_t *frame, int sh, int sw,
+                        const double *proj, const double *sin_t,
+                        const double *cos_t, const double *tan_p,
+                        const float *lut255, const double *hat_x,
+                        const double *hat_y, int gx0, int gy0, int pw, int ph,
+                        float *planes, uint8_t *mask, float *map_x,
+                        float *map_y, void *stream);
+
+/* Ownership + validity                      stitcher.py:196-204, 266-271
+ * owner = first-index argmax of the patches' alpha, -1 where all are 0;
+ * valid = OR over patches of ~mask.  patches: dev array of n pano_patch. */
+int pano_ownership(const pano_patch *patches, int n, int H, int W,
+                   int16_t *owner, uint8_t *valid, void *stream);
+
+/* The n_levels-1 Gaussian blurs of one patch   stitcher.py:207-208, 218, 226
+ * (cv2.GaussianBlur(warped, (0,0), 4*sqrt(2k+1)) with the alpha channel
+ * replaced by the sharp mask owner == index).  patch: host struct.
+ * taps: dev float, n_blur tables laid out back to back, table k has
+ * ntaps[k] + PANO_TAP_PAD floats: PANO_TAP_LEAD zeros, the ntaps[k] taps,
+ * zeros.  ntaps: host int[n_blur].  scratch: dev float [4][h][pitch].
+ * Writes patch->blurred. */
+int pano_multiband_blur(const pano_patch *patch, int index,
+                        const int16_t *owner, int W, const float *taps,
+                        const int *ntaps, int n_blur, float *scratch,
+                        void *stream);
+
+/* Band-pass build + collapse                     stitcher.py:210-241
+ * Gathers, per mosaic pixel and in patch order, layer_k / wsum_k of every
+ * level, zeroes outside `valid`, sums the levels, clips, truncates to uint8.
+ * mosaic_f32 (optional) receives the clipped float mosaic [H][W][3]. */
+int pano_multiband_compose(const pano_patch *patches, int n, int H, int W,
+                           int n_levels, const int16_t *owner,
+                           const uint8_t *valid, uint8_t *mosaic,
+                           float *mosaic_f32, void *stream);
+
+/* linear_blend                                          stitcher.py:171-183 */
+int pano_linear_blend(const pano_patch *patches, int n, int H, int W,
+                      uint8_t *mosaic, void *stream);
+
+/* no_blend                                              stitcher.py:160-168 */
+int pano_no_blend(const pano_patch *patches, int n, int H, int W,
+                  uint8_t *mosaic, void *stream);
+
+/* crop_mosaic rectangle                                 stitcher.py:340-369
+ * valid: dev uint8 [H][W].  heights: dev int32 [H][W] workspace.
+ * result: dev int64[6] = {found, y0, x0, h, w, area}. */
+int pano_crop_rect(const uint8_t *valid, int H, int W, int32_t *heights,
+                   int64_t *result, void *stream);
+
+/* Separable symmetric filter on one float plane, BORDER_REFLECT_101
+ *                     cv2.GaussianBlur at features.py:24 / stitcher.py:226
+ * taps: dev padded table (see pano_multiband_blur); tmp: dev [h][pitch]. */
+int pano_blur_plane(const float *src, float *dst, float *tmp, int h, int w,
+                    int pitch, const float *taps, int ntaps, void *stream);
+
+/* cv2.pyrDown on one float plane                        features.py:155
+ * src [h][w] (dense) -> dst [(h+1)/2][(w+1)/2] (dense). */
+int pano_pyr_down(const float *src, int h, int w, float *dst, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PANO360_H */

@@ -1,0 +1,96 @@
+"""ctypes binding of ``libpano360_hip.so`` (declared in ``include/pano360.h``).
+
+There is no CPU fallback: if the library is missing or a call fails the caller
+gets an exception.  ``torch`` is imported first so that the HIP runtime torch
+ships is the one both sides use (the library is linked against the SONAME
+``libamdhip64.so.7``, which the loader then resolves to the already loaded
+copy); torch itself is only used for device memory, streams and
+``torch.distributed``.
+"""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpano360_hip.so")
+
+MAX_TAPS = 129
+MAX_LEVELS = 8
+TAP_LEAD = 7
+TAP_PAD = 40
+
+
+class PanoError(RuntimeError):
+    """A C-ABI call returned a negative status."""
+
+
+class Patch(C.Structure):
+    """``pano_patch`` of include/pano360.h (48 bytes)."""
+    _fields_ = [("planes", C.c_void_p), ("mask", C.c_void_p),
+                ("blurred", C.c_void_p),
+                ("y0", C.c_int32), ("x0", C.c_int32),
+                ("h", C.c_int32), ("w", C.c_int32),
+                ("pitch", C.c_int32), ("reserved", C.c_int32)]
+
+
+_vp, _i = C.c_void_p, C.c_int
+_SIGNATURES = {
+    "pano_version": (C.c_char_p, []),
+    "pano_last_error": (C.c_char_p, []),
+    "pano_device_count": (_i, []),
+    "pano_pitch": (_i, [_i]),
+    "pano_timing_enable": (_i, [_i]),
+    "pano_kernel_count": (_i, []),
+    "pano_kernel_name": (C.c_char_p, [_i]),
+    "pano_timing_read": (_i, [_i, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
+    "pano_add_weights": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "pano_warp_spherical": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                                 _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "pano_ownership": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp]),
+    "pano_multiband_blur": (_i, [C.POINTER(Patch), _i, _vp, _i, _vp,
+                                 C.POINTER(C.c_int), _i, _vp, _vp]),
+    "pano_multiband_compose": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "pano_linear_blend": (_i, [_vp, _i, _i, _i, _vp, _vp]),
+    "pano_no_blend": (_i, [_vp, _i, _i, _i, _vp, _vp]),
+    "pano_crop_rect": (_i, [_vp, _i, _i, _vp, _vp, _vp]),
+    "pano_blur_plane": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _i, _vp]),
+    "pano_pyr_down": (_i, [_vp, _i, _i, _vp, _vp]),
+}
+EXPORTS = tuple(_SIGNATURES)
+
+
+def build(force=False):
+    """Compile the HIP sources in-tree (hipcc cross-compiles without a GPU)."""
+    src = os.path.join(_HERE, "csrc")
+    cmd = ["make", "-C", src, "-s", "-j4"]
+    if force:
+        cmd.append("-B")
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    """Load (once) and return the bound library; raises if it is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise PanoError(
+                f"{LIB_PATH} is missing: build it with "
+                "`python -c 'import __graft_entry__ as g; g.build()'` "
+                "(there is no CPU fallback)")
+        import torch  # noqa: F401  (pins the HIP runtime, see module docstring)
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(handle, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = handle
+    return _lib
+
+
+def check(status, what):
+    if status != 0:
+        msg = lib().pano_last_error().decode("utf-8", "replace")
+        raise PanoError(f"{what} failed ({status}): {msg}")

@@ -43,6 +43,11 @@ class Image:
         return self.intr.dot(self.rot)
 
 
+# pickles name the class by module path: keep the reference's, so camera caches
+# move between the reference CLI and this build in both directions
+Image.__module__ = "bundle_adj"
+
+
 def intrinsics(focal, center=(0, 0)):
     """Calibration matrix; like the reference (bundle_adj.py:82-87) a pair of
     focals is accepted but only the first one is used for both axes."""

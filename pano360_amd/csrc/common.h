@@ -1,0 +1,101 @@
+// Shared host/device helpers for libpano360_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/pano360.h"
+
+// ---- error plumbing --------------------------------------------------------
+void pano_set_error(const char *fmt, ...);
+
+#define PANO_REQUIRE(cond, ...)          \
+    do {                                 \
+        if (!(cond)) {                   \
+            pano_set_error(__VA_ARGS__); \
+            return PANO_EINVAL;          \
+        }                                \
+    } while (0)
+
+#define PANO_HIP(call)                                                         \
+    do {                                                                       \
+        hipError_t e_ = (call);                                                \
+        if (e_ != hipSuccess) {                                                \
+            pano_set_error("%s failed: %s", #call, hipGetErrorString(e_));     \
+            return PANO_EHIP;                                                  \
+        }                                                                      \
+    } while (0)
+
+#define PANO_LAUNCH_CHECK(name)                                                \
+    do {                                                                       \
+        hipError_t e_ = hipGetLastError();                                     \
+        if (e_ != hipSuccess) {                                                \
+            pano_set_error("launch of %s failed: %s", name,                    \
+                           hipGetErrorString(e_));                             \
+            return PANO_EHIP;                                                  \
+        }                                                                      \
+    } while (0)
+
+// ---- per-kernel timing (HIP events on the launch stream; off by default) ----
+enum PanoKernelId {
+    PK_ADD_WEIGHTS = 0,
+    PK_WARP,
+    PK_OWNERSHIP,
+    PK_BLUR_ROWS,
+    PK_BLUR_COLS,
+    PK_COMPOSE,
+    PK_LINEAR,
+    PK_NOBLEND,
+    PK_CROP_HEIGHTS,
+    PK_CROP_ROWS,
+    PK_PYR_DOWN,
+    PK_COUNT
+};
+extern bool g_pano_timing_on;
+void pano_timing_edge(int kid, hipStream_t stream, bool begin);
+
+// Launch `...` on `stream`; when timing is enabled bracket it with events.
+#define PANO_TIMED(kid, stream, ...)                                 \
+    do {                                                             \
+        if (g_pano_timing_on) pano_timing_edge(kid, stream, true);   \
+        __VA_ARGS__;                                                 \
+        if (g_pano_timing_on) pano_timing_edge(kid, stream, false);  \
+    } while (0)
+
+static inline int pano_pitch_of(int w) { return (w + 3) & ~3; }
+static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+// ---- device helpers --------------------------------------------------------
+// Scalar-cache view of read-only global memory: loads through this pointer are
+// selected as s_load (SGPR operands for the FMA chains of the blur kernels).
+typedef const __attribute__((address_space(4))) float *kptr_f32;
+
+// cv2.BORDER_REFLECT      ... c b a | a b c ... z | z y x ...
+__device__ __forceinline__ int reflect_edge(int p, int len) {
+    if ((unsigned)p < (unsigned)len) return p;
+    int per = 2 * len;
+    int m = p % per;
+    if (m < 0) m += per;
+    return m < len ? m : per - 1 - m;
+}
+
+// cv2.BORDER_REFLECT_101  ... c b | a b c ... z | y x ...   (len 1 -> 0)
+__device__ __forceinline__ int reflect_101(int p, int len) {
+    if ((unsigned)p < (unsigned)len) return p;
+    if (len == 1) return 0;
+    int per = 2 * len - 2;
+    int m = p % per;
+    if (m < 0) m += per;
+    return m < len ? m : per - m;
+}
+
+// cvRound(float) the way x86 cvtss2si does it: ties to even, and the
+// "integer indefinite" 0x80000000 for NaN or anything outside int32.
+__device__ __forceinline__ int cv_round(float v) {
+    float r = rintf(v);
+    if (!(r >= -2147483648.0f && r < 2147483648.0f)) return (int)0x80000000;
+    return (int)r;
+}
+
+__device__ __forceinline__ int sat16(int v) {
+    return v < -32768 ? -32768 : (v > 32767 ? 32767 : v);
+}

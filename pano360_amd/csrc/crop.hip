@@ -1,0 +1,153 @@
+// Largest all-valid rectangle with the reference's exact tie-breaking.
+//
+// Reference arithmetic replaced: stitcher.py:340-369 (crop_mosaic).  For every
+// row i (as bottom row) and column j the reference's candidate is the widest
+// run around j whose column heights are >= heights[j]; it keeps the FIRST
+// candidate in (row, column) scan order whose area is strictly larger than
+// everything before.  Quirk kept: its right-extent loop never touches column 0
+// (range(width-1, 0, -1), :359), so column 0's candidate is one pixel wide.
+//
+// Integer work, bit-exact target.  Three kernels:
+//   1. column scan  : one thread per column walks the rows -> heights[H][W]
+//   2. row search   : one block per row; 64-column chunk minima in LDS let a
+//                     thread skip whole chunks while looking for the nearest
+//                     strictly smaller height on each side; candidates are
+//                     packed as (area << 32 | ~(i*W + j)) and max-reduced, so
+//                     the maximum key is the reference's winner
+//   3. finalise     : one thread re-derives the winner's extents.
+#include "common.h"
+
+__global__ __launch_bounds__(256) void crop_heights_kernel(
+    const uint8_t *__restrict__ valid, int H, int W, int32_t *__restrict__ heights) {
+    const int x = blockIdx.x * 256 + threadIdx.x;
+    if (x >= W) return;
+    int run = 0;
+    for (int y = 0; y < H; ++y) {
+        run = valid[(size_t)y * W + x] ? run + 1 : 0;                              // :354
+        heights[(size_t)y * W + x] = run;
+    }
+}
+
+#define CROP_CHUNK 64
+#define CROP_MAX_CHUNKS 1024       // mosaic width up to 65536
+
+// nearest index left of j with height < h, or -1
+__device__ __forceinline__ int smaller_left(const int32_t *row, const int32_t *cmin,
+                                            int j, int h) {
+    int idx = j - 1;
+    const int cstart = (j / CROP_CHUNK) * CROP_CHUNK;
+    while (idx >= cstart && row[idx] >= h) --idx;
+    if (idx >= cstart) return idx;
+    int c = j / CROP_CHUNK - 1;
+    while (c >= 0 && cmin[c] >= h) --c;
+    if (c < 0) return -1;
+    idx = c * CROP_CHUNK + CROP_CHUNK - 1;
+    while (row[idx] >= h) --idx;      // this chunk holds a smaller height
+    return idx;
+}
+
+// nearest index right of j with height < h, or W
+__device__ __forceinline__ int smaller_right(const int32_t *row, const int32_t *cmin,
+                                             int j, int h, int W, int nchunks) {
+    int idx = j + 1;
+    int cend = (j / CROP_CHUNK + 1) * CROP_CHUNK;
+    if (cend > W) cend = W;
+    while (idx < cend && row[idx] >= h) ++idx;
+    if (idx < cend) return idx;
+    int c = j / CROP_CHUNK + 1;
+    while (c < nchunks && cmin[c] >= h) ++c;
+    if (c >= nchunks) return W;
+    idx = c * CROP_CHUNK;
+    while (row[idx] >= h) ++idx;
+    return idx;
+}
+
+__global__ __launch_bounds__(256) void crop_rows_kernel(
+    const int32_t *__restrict__ heights, int H, int W,
+    unsigned long long *__restrict__ best) {
+    __shared__ int32_t s_cmin[CROP_MAX_CHUNKS];
+    __shared__ unsigned long long s_red[4];
+    const int i = blockIdx.x;
+    const int32_t *row = heights + (size_t)i * W;
+    const int nchunks = (W + CROP_CHUNK - 1) / CROP_CHUNK;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int c = wave; c < nchunks; c += 4) {
+        const int j = c * CROP_CHUNK + lane;
+        int v = j < W ? row[j] : 0x7fffffff;
+        for (int off = 32; off > 0; off >>= 1) {
+            int o = __shfl_xor(v, off);
+            v = o < v ? o : v;
+        }
+        if (lane == 0) s_cmin[c] = v;
+    }
+    __syncthreads();
+
+    unsigned long long key = 0;
+    for (int j = threadIdx.x; j < W; j += 256) {
+        const int h = row[j];
+        if (h == 0) continue;
+        const int l = smaller_left(row, s_cmin, j, h) + 1;
+        const int r = j == 0 ? 0 : smaller_right(row, s_cmin, j, h, W, nchunks) - 1;
+        const unsigned long long area = (unsigned long long)(r - l + 1) * (unsigned)h;
+        const unsigned long long pos = (unsigned long long)i * W + j;
+        const unsigned long long k = (area << 32) | (0xffffffffull - pos);
+        key = k > key ? k : key;
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        unsigned long long o = __shfl_xor(key, off);
+        key = o > key ? o : key;
+    }
+    if (lane == 0) s_red[wave] = key;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 1; k < 4; ++k) key = s_red[k] > key ? s_red[k] : key;
+        if (key) atomicMax(best, key);
+    }
+}
+
+__global__ void crop_finalize_kernel(const int32_t *__restrict__ heights, int H, int W,
+                                     const unsigned long long *__restrict__ best,
+                                     int64_t *__restrict__ result) {
+    const unsigned long long key = *best;
+    if (key == 0) {
+        for (int k = 0; k < 6; ++k) result[k] = 0;
+        return;
+    }
+    const unsigned long long pos = 0xffffffffull - (key & 0xffffffffull);
+    const int i = (int)(pos / (unsigned)W), j = (int)(pos % (unsigned)W);
+    const int32_t *row = heights + (size_t)i * W;
+    const int h = row[j];
+    int l = j, r = j;
+    while (l > 0 && row[l - 1] >= h) --l;
+    if (j != 0)
+        while (r < W - 1 && row[r + 1] >= h) ++r;
+    result[0] = 1;
+    result[1] = i - h + 1;                                                         // :369
+    result[2] = l;
+    result[3] = h;
+    result[4] = r - l + 1;
+    result[5] = (int64_t)(key >> 32);
+}
+
+extern "C" int pano_crop_rect(const uint8_t *valid, int H, int W, int32_t *heights,
+                              int64_t *result, void *stream) {
+    PANO_REQUIRE(valid && heights && result, "pano_crop_rect: null pointer");
+    PANO_REQUIRE(H > 0 && W > 0, "pano_crop_rect: bad shape %dx%d", H, W);
+    PANO_REQUIRE(W <= CROP_CHUNK * CROP_MAX_CHUNKS, "pano_crop_rect: width %d above %d", W,
+                 CROP_CHUNK * CROP_MAX_CHUNKS);
+    PANO_REQUIRE((unsigned long long)H * W < 0xffffffffull,
+                 "pano_crop_rect: %dx%d does not fit the 32-bit position key", H, W);
+    hipStream_t s = (hipStream_t)stream;
+    // result[5] doubles as the 64-bit max-reduction cell until finalise rewrites it
+    unsigned long long *best = (unsigned long long *)(result + 5);
+    PANO_HIP(hipMemsetAsync(best, 0, sizeof(unsigned long long), s));
+    PANO_TIMED(PK_CROP_HEIGHTS, s, hipLaunchKernelGGL(crop_heights_kernel, dim3(ceil_div(W, 256)), dim3(256), 0, s, valid,
+                       H, W, heights));
+    PANO_LAUNCH_CHECK("crop_heights_kernel");
+    PANO_TIMED(PK_CROP_ROWS, s, hipLaunchKernelGGL(crop_rows_kernel, dim3(H), dim3(256), 0, s, heights, H, W, best));
+    PANO_LAUNCH_CHECK("crop_rows_kernel");
+    hipLaunchKernelGGL(crop_finalize_kernel, dim3(1), dim3(1), 0, s, heights, H, W, best,
+                       result);
+    PANO_LAUNCH_CHECK("crop_finalize_kernel");
+    return PANO_OK;
+}

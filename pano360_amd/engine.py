@@ -1,0 +1,415 @@
+"""Device-resident warp/blend engine: host geometry + launches over the C ABI.
+
+Everything per-pixel runs in ``libpano360_hip.so``; this module only plans
+(float64 scalar geometry, as the reference does on the host) and sequences the
+launches.  torch supplies device memory and the stream, nothing else.
+
+Reference lines mirrored by the planning code: stitcher.py:107-157 (ranges,
+resolution), :283-302 (mosaic shape, patch rectangles, angle grids), :218
+(level sigmas); OpenCV's getGaussianKernel for the taps (host, 33..97 floats).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import Patch
+
+BORDER_SAMPLES = 100        # stitcher.py:109
+MULTIBAND_PAD = 10          # stitcher.py:296-297
+
+
+# --------------------------------------------------------------- projections
+class SphProj:
+    """Spherical projection pair (reference stitcher.py:73-87)."""
+
+    @staticmethod
+    def hom2proj(pts):
+        pts = np.asarray(pts)
+        xz = np.sqrt(pts[:, 0] ** 2 + pts[:, 2] ** 2)
+        theta = np.arctan2(pts[:, 0], pts[:, 2])
+        phi = np.arctan2(pts[:, 1], xz)
+        return np.stack([theta, phi], axis=-1)
+
+    @staticmethod
+    def proj2hom(pts):
+        pts = np.asarray(pts)
+        return np.stack([np.sin(pts[:, 0]), np.tan(pts[:, 1]),
+                         np.cos(pts[:, 0])], axis=-1)
+
+
+class CylProj:
+    """Cylindrical projection pair (reference stitcher.py:90-104)."""
+
+    @staticmethod
+    def hom2proj(pts):
+        pts = np.asarray(pts)
+        xz = np.sqrt(pts[:, 0] ** 2 + pts[:, 2] ** 2)
+        return np.stack([np.arctan2(pts[:, 0], pts[:, 2]), pts[:, 1] / xz],
+                        axis=-1)
+
+    @staticmethod
+    def proj2hom(pts):
+        pts = np.asarray(pts)
+        return np.stack([np.sin(pts[:, 0]), pts[:, 1], np.cos(pts[:, 0])],
+                        axis=-1)
+
+
+def hat(size):
+    """Triangular weight 0 .. 0.5 .. 1/size (reference stitcher.py:251-254)."""
+    centred = np.arange(size) - size / 2
+    return 0.5 - np.abs(centred / size)
+
+
+def range_from_border(shape, hom):
+    """Angular bounding box of a frame from 4x100 border points
+    (reference stitcher.py:107-122; no wrap-around handling there either)."""
+    height, width = shape
+    ticks_x = np.linspace(0, width, BORDER_SAMPLES)
+    ticks_y = np.linspace(0, height, BORDER_SAMPLES)
+    ones = np.ones(BORDER_SAMPLES)
+    left = np.stack([0 * ones, ticks_y, ones], axis=1)
+    right = np.stack([width * ones, ticks_y, ones], axis=1)
+    top = np.stack([ticks_x, 0 * ones, ones], axis=1)
+    bottom = np.stack([ticks_x, height * ones, ones], axis=1)
+    ring = np.concatenate([left, right, top, bottom])
+    ring = ring - np.array([width / 2, height / 2, 0])
+    angles = SphProj.hom2proj(hom.dot(ring.T).T)
+    return np.min(angles, axis=0), np.max(angles, axis=0)
+
+
+def range_from_corners(shape, hom):
+    """Angular box from the 4 corners with the +2pi / +pi wrap fixes
+    (reference stitcher.py:125-139)."""
+    height, width = shape
+    half_w, half_h = width / 2, height / 2
+    corners = np.array([[-half_w, -half_h, 1], [half_w, -half_h, 1],
+                        [-half_w, half_h, 1], [half_w, half_h, 1]])
+    ang = SphProj.hom2proj(hom.dot(corners.T).T)
+    xmin, xmax = min(ang[0, 0], ang[2, 0]), max(ang[1, 0], ang[3, 0])
+    ymin, ymax = min(ang[0, 1], ang[1, 1]), max(ang[2, 1], ang[3, 1])
+    if xmin > xmax:
+        xmax += 2 * np.pi
+    if ymin > ymax:
+        ymax += np.pi
+    return np.array([xmin, ymin]), np.array([xmax, ymax])
+
+
+def resolution_for(ranges, mid_shape, mid_hom, max_resolution):
+    """rad/px of the central frame, capped so the long mosaic side is at most
+    ``max_resolution`` pixels (reference stitcher.py:142-157)."""
+    lows, highs = zip(*ranges)
+    low, high = np.min(lows, axis=0), np.max(highs, axis=0)
+    c_low, c_high = range_from_corners(mid_shape, mid_hom)
+    res = (c_high - c_low) / np.array(mid_shape[::-1])
+    longest = np.max((high - low) / res)
+    if longest > max_resolution:
+        res *= longest / max_resolution
+    return res, (low, high)
+
+
+def gaussian_ksize(sigma):
+    """Aperture cv2.GaussianBlur picks for ksize=(0,0) on float images."""
+    return int(np.rint(sigma * 4 * 2 + 1)) | 1
+
+
+def gaussian_taps(ksize, sigma):
+    """cv::getGaussianKernel as float32: exp in double, float32 taps, double
+    sum of the rounded taps, rescale in double, round again."""
+    if sigma <= 0:
+        sigma = ((ksize - 1) * 0.5 - 1) * 0.3 + 0.8
+    offs = np.arange(ksize, dtype=np.float64) - (ksize - 1) * 0.5
+    raw = np.exp(offs * offs * (-0.5 / (sigma * sigma))).astype(np.float32)
+    total = 0.0
+    for tap in raw:
+        total += float(tap)
+    return (raw.astype(np.float64) * (1.0 / total)).astype(np.float32)
+
+
+def padded_taps(taps):
+    """Tap table layout of include/pano360.h: TAP_LEAD zeros, taps, zeros."""
+    out = np.zeros(len(taps) + _lib.TAP_PAD, np.float32)
+    out[_lib.TAP_LEAD:_lib.TAP_LEAD + len(taps)] = taps
+    return out
+
+
+def level_sigmas(n_levels):
+    """sigma_k = 4*sqrt(2k+1) for the n_levels-1 blurred levels (:218)."""
+    return [float(np.sqrt(2 * k + 1.0) * 4) for k in range(n_levels - 1)]
+
+
+class Plan:
+    """Host-side geometry of one stitch: everything stitcher.py:276-302
+    derives before a pixel is touched."""
+
+    def __init__(self, shapes, rots, intrs, padded, max_resolution):
+        self.shapes = [tuple(int(v) for v in s) for s in shapes]
+        self.n = len(self.shapes)
+        self.homs = [np.asarray(r).T.dot(np.linalg.inv(k)) for r, k in zip(rots, intrs)]
+        self.projs = [np.ascontiguousarray(np.asarray(k).dot(r), np.float64)
+                      for r, k in zip(rots, intrs)]
+        self.ranges = [range_from_border(s, h) for s, h in zip(self.shapes, self.homs)]
+        mid = self.n // 2
+        self.resolution, (self.low, self.high) = resolution_for(
+            self.ranges, self.shapes[mid], self.homs[mid], max_resolution)
+        target = (self.high - self.low) / self.resolution
+        self.shape = tuple(int(v) for v in np.round(target))[::-1]      # (H, W)
+        limit = target.astype(np.int32)
+        self.rects = []                                     # (y0, y1, x0, x1)
+        for low, high in self.ranges:
+            first = np.round((low - self.low) / self.resolution).astype(np.int32)
+            last = np.round((high - self.low) / self.resolution).astype(np.int32)
+            if padded:
+                first = np.maximum(first - MULTIBAND_PAD, np.int32([0, 0]))
+                last = np.minimum(last + MULTIBAND_PAD, limit)
+            self.rects.append((int(first[1]), int(last[1]), int(first[0]), int(last[0])))
+        for y0, y1, x0, x1 in self.rects:
+            if y1 <= y0 or x1 <= x0:
+                raise ValueError("a frame projects to an empty patch")
+        cols = max(self.shape[1], max(r[3] for r in self.rects))
+        rows = max(self.shape[0], max(r[1] for r in self.rects))
+        theta = np.arange(cols, dtype=np.int64) * self.resolution[0] + self.low[0]
+        phi = np.arange(rows, dtype=np.int64) * self.resolution[1] + self.low[1]
+        self.sin_t, self.cos_t, self.tan_p = np.sin(theta), np.cos(theta), np.tan(phi)
+
+    @property
+    def patch_pixels(self):
+        return sum((y1 - y0) * (x1 - x0) for y0, y1, x0, x1 in self.rects)
+
+
+# ------------------------------------------------------------------- device
+def _torch():
+    import torch
+    return torch
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+class DevicePatch:
+    """Device buffers of one warped patch + its ``pano_patch`` record."""
+
+    def __init__(self, rect, device, n_blur):
+        torch = _torch()
+        y0, y1, x0, x1 = rect
+        self.rect = rect
+        self.h, self.w = y1 - y0, x1 - x0
+        self.pitch = (self.w + 3) & ~3
+        self.planes = torch.empty((4, self.h, self.pitch), dtype=torch.float32, device=device)
+        self.mask = torch.empty((self.h, self.w), dtype=torch.uint8, device=device)
+        self.blurred = (torch.empty((n_blur, 4, self.h, self.pitch), dtype=torch.float32,
+                                    device=device) if n_blur else None)
+
+    def record(self):
+        y0, _, x0, _ = self.rect
+        return Patch(self.planes.data_ptr(), self.mask.data_ptr(),
+                     self.blurred.data_ptr() if self.blurred is not None else None,
+                     y0, x0, self.h, self.w, self.pitch, 0)
+
+
+def patch_table(patches, device):
+    """Pack ``pano_patch`` records and copy them to the device."""
+    torch = _torch()
+    raw = b"".join(bytes(p.record()) for p in patches)
+    host = torch.frombuffer(bytearray(raw), dtype=torch.uint8)
+    return host.to(device)
+
+
+class Engine:
+    """Sequences the HIP stages for one device.  One instance per process/GPU."""
+
+    def __init__(self, device=None):
+        torch = _torch()
+        self.lib = _lib.lib()
+        if not torch.cuda.is_available() or self.lib.pano_device_count() < 1:
+            raise _lib.PanoError("no MI355X visible: the HIP path has no CPU fallback")
+        self.device = torch.device(device if device is not None
+                                   else f"cuda:{torch.cuda.current_device()}")
+        lut = np.arange(256, dtype=np.float32) / np.float32(255)   # stitcher.py:259
+        self.lut255 = torch.from_numpy(lut).to(self.device)
+        self._hats = {}
+        self._taps = {}
+
+    # -- small cached tables ------------------------------------------------
+    def stream(self):
+        return C.c_void_p(_torch().cuda.current_stream(self.device).cuda_stream)
+
+    def hat_tables(self, shape):
+        torch = _torch()
+        if shape not in self._hats:
+            h, w = shape
+            self._hats[shape] = (torch.from_numpy(hat(w)).to(self.device),
+                                 torch.from_numpy(hat(h)).to(self.device))
+        return self._hats[shape]
+
+    def blur_tables(self, n_levels):
+        """Padded tap tables of the n_levels-1 blurs, back to back on device."""
+        torch = _torch()
+        if n_levels not in self._taps:
+            sig = level_sigmas(n_levels)
+            sizes = [gaussian_ksize(s) for s in sig]
+            flat = np.concatenate([padded_taps(gaussian_taps(k, s))
+                                   for k, s in zip(sizes, sig)]) if sig else np.zeros(1, np.float32)
+            self._taps[n_levels] = (torch.from_numpy(flat).to(self.device),
+                                    (C.c_int * max(len(sizes), 1))(*sizes), len(sizes))
+        return self._taps[n_levels]
+
+    def upload_frames(self, imgs):
+        torch = _torch()
+        return [torch.from_numpy(np.ascontiguousarray(im, np.uint8)).to(self.device)
+                for im in imgs]
+
+    def upload_plan(self, plan):
+        torch = _torch()
+        plan.dev = tuple(torch.from_numpy(t).to(self.device)
+                         for t in (plan.sin_t, plan.cos_t, plan.tan_p))
+        return plan
+
+    # -- stages ---------------------------------------------------------------
+    def add_weights(self, frame):
+        """_add_weights on device: uint8 [H,W,3] -> float32 [H,W,4]."""
+        torch = _torch()
+        h, w = frame.shape[:2]
+        hx, hy = self.hat_tables((h, w))
+        out = torch.empty((h, w, 4), dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.pano_add_weights(_ptr(frame), h, w, _ptr(self.lut255), _ptr(hx),
+                                             _ptr(hy), _ptr(out), self.stream()),
+                   "pano_add_weights")
+        return out
+
+    def warp(self, frame, plan, index, patch, want_maps=False):
+        torch = _torch()
+        sh, sw = frame.shape[:2]
+        hx, hy = self.hat_tables((sh, sw))
+        y0, _, x0, _ = plan.rects[index]
+        mx = my = None
+        if want_maps:
+            mx = torch.empty((patch.h, patch.w), dtype=torch.float32, device=self.device)
+            my = torch.empty_like(mx)
+        proj = plan.projs[index]
+        _lib.check(self.lib.pano_warp_spherical(
+            _ptr(frame), sh, sw, proj.ctypes.data_as(C.c_void_p), _ptr(plan.dev[0]),
+            _ptr(plan.dev[1]), _ptr(plan.dev[2]), _ptr(self.lut255), _ptr(hx), _ptr(hy),
+            x0, y0, patch.w, patch.h, _ptr(patch.planes), _ptr(patch.mask), _ptr(mx),
+            _ptr(my), self.stream()), "pano_warp_spherical")
+        return mx, my
+
+    def ownership(self, table, n, shape):
+        torch = _torch()
+        H, W = shape
+        owner = torch.empty((H, W), dtype=torch.int16, device=self.device)
+        valid = torch.empty((H, W), dtype=torch.uint8, device=self.device)
+        _lib.check(self.lib.pano_ownership(_ptr(table), n, H, W, _ptr(owner), _ptr(valid),
+                                           self.stream()), "pano_ownership")
+        return owner, valid
+
+    def multiband(self, patches, shape, n_levels, want_float=False, table=None):
+        """Ownership -> per-patch blurs -> collapse.  Returns
+        (mosaic u8, float mosaic or None, owner, valid)."""
+        torch = _torch()
+        H, W = shape
+        n = len(patches)
+        if table is None:
+            table = patch_table(patches, self.device)
+        owner, valid = self.ownership(table, n, shape)
+        taps, ntaps, n_blur = self.blur_tables(n_levels)
+        if n_blur:
+            biggest = max(p.h * p.pitch for p in patches)
+            scratch = torch.empty(4 * biggest, dtype=torch.float32, device=self.device)
+            for i, p in enumerate(patches):
+                rec = p.record()
+                _lib.check(self.lib.pano_multiband_blur(C.byref(rec), i, _ptr(owner), W,
+                                                        _ptr(taps), ntaps, n_blur,
+                                                        _ptr(scratch), self.stream()),
+                           "pano_multiband_blur")
+        mosaic = torch.empty((H, W, 3), dtype=torch.uint8, device=self.device)
+        fl = (torch.empty((H, W, 3), dtype=torch.float32, device=self.device)
+              if want_float else None)
+        _lib.check(self.lib.pano_multiband_compose(_ptr(table), n, H, W, n_levels,
+                                                   _ptr(owner), _ptr(valid), _ptr(mosaic),
+                                                   _ptr(fl), self.stream()),
+                   "pano_multiband_compose")
+        return mosaic, fl, owner, valid
+
+    def simple_blend(self, patches, shape, linear, table=None):
+        torch = _torch()
+        H, W = shape
+        if table is None:
+            table = patch_table(patches, self.device)
+        mosaic = torch.empty((H, W, 3), dtype=torch.uint8, device=self.device)
+        fn = self.lib.pano_linear_blend if linear else self.lib.pano_no_blend
+        _lib.check(fn(_ptr(table), len(patches), H, W, _ptr(mosaic), self.stream()),
+                   "pano_linear_blend" if linear else "pano_no_blend")
+        return mosaic
+
+    def crop_rect(self, valid):
+        """Rectangle (y0, x0, h, w) of crop_mosaic, or None when nothing is valid."""
+        torch = _torch()
+        H, W = valid.shape
+        heights = torch.empty((H, W), dtype=torch.int32, device=self.device)
+        result = torch.zeros(6, dtype=torch.int64, device=self.device)
+        _lib.check(self.lib.pano_crop_rect(_ptr(valid), H, W, _ptr(heights), _ptr(result),
+                                           self.stream()), "pano_crop_rect")
+        res = result.cpu().numpy()
+        if not res[0]:
+            return None
+        return tuple(int(v) for v in res[1:5])
+
+    def blur_plane(self, plane, ksize, sigma):
+        """cv2.GaussianBlur on one float32 plane [h][w] already on device."""
+        torch = _torch()
+        h, w = plane.shape
+        pitch = (w + 3) & ~3
+        src = torch.zeros((h, pitch), dtype=torch.float32, device=self.device)
+        src[:, :w] = plane
+        dst, tmp = torch.empty_like(src), torch.empty_like(src)
+        taps = torch.from_numpy(padded_taps(gaussian_taps(ksize, sigma))).to(self.device)
+        _lib.check(self.lib.pano_blur_plane(_ptr(src), _ptr(dst), _ptr(tmp), h, w, pitch,
+                                            _ptr(taps), ksize, self.stream()),
+                   "pano_blur_plane")
+        return dst[:, :w]
+
+    def pyr_down(self, plane):
+        torch = _torch()
+        plane = plane.contiguous()
+        h, w = plane.shape
+        out = torch.empty(((h + 1) // 2, (w + 1) // 2), dtype=torch.float32,
+                          device=self.device)
+        _lib.check(self.lib.pano_pyr_down(_ptr(plane), h, w, _ptr(out), self.stream()),
+                   "pano_pyr_down")
+        return out
+
+    # -- whole stitch -----------------------------------------------------------
+    def warp_all(self, frames, plan, n_blur=0, want_maps=False):
+        patches, maps = [], []
+        for i, frame in enumerate(frames):
+            patch = DevicePatch(plan.rects[i], self.device, n_blur)
+            maps.append(self.warp(frame, plan, i, patch, want_maps))
+            patches.append(patch)
+        return patches, maps
+
+    def stitch(self, frames, plan, blend="multiband", n_levels=5, want_float=False):
+        """uint8 frames on device -> (mosaic u8 on device, float mosaic, valid)."""
+        if not hasattr(plan, "dev"):
+            self.upload_plan(plan)
+        n_blur = n_levels - 1 if blend == "multiband" else 0
+        patches, _ = self.warp_all(frames, plan, n_blur)
+        table = patch_table(patches, self.device)
+        if blend == "multiband":
+            mosaic, fl, _, valid = self.multiband(patches, plan.shape, n_levels, want_float,
+                                                  table)
+            return mosaic, fl, valid, patches
+        mosaic = self.simple_blend(patches, plan.shape, blend == "linear", table)
+        return mosaic, None, None, patches
+
+
+_engine = None
+
+
+def engine():
+    """Process-wide engine on the current device."""
+    global _engine
+    if _engine is None:
+        _engine = Engine()
+    return _engine

@@ -1,0 +1,128 @@
+"""CPU: the product's host-side geometry against the golden vectors, and the
+C-ABI library: it loads and exports every symbol include/pano360.h declares
+(no compute calls - there is no GPU here)."""
+import ctypes
+import os
+import pickle
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, SCENES, load_golden, n_patches, scene_inputs
+
+
+def test_library_exports_every_declared_symbol():
+    from pano360_amd import _lib
+    _lib.build()
+    header = open(os.path.join(ROOT, "include", "pano360.h")).read()
+    declared = set(re.findall(r"\b(pano_[a-z0-9_]+)\s*\(", header))
+    assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
+    handle = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(handle, name), name
+    handle.pano_version.restype = ctypes.c_char_p
+    assert b"gfx950" in handle.pano_version()
+    assert handle.pano_pitch(1941) == 1944
+    assert ctypes.sizeof(_lib.Patch) == 48
+
+
+def test_header_constants_match_binding():
+    from pano360_amd import _lib
+    header = open(os.path.join(ROOT, "include", "pano360.h")).read()
+    for macro, value in (("PANO_MAX_TAPS", _lib.MAX_TAPS), ("PANO_MAX_LEVELS", _lib.MAX_LEVELS),
+                         ("PANO_TAP_LEAD", _lib.TAP_LEAD), ("PANO_TAP_PAD", _lib.TAP_PAD)):
+        assert int(re.search(rf"#define {macro} (\d+)", header).group(1)) == value
+
+
+def test_no_product_import_of_the_oracle():
+    """The product path must never route through oracle/ (the checker)."""
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "pano360_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "pano_oracle" not in text and "cv2_shim" not in text, f
+
+
+@pytest.mark.parametrize("name", SCENES)
+def test_plan_matches_reference(name):
+    from pano360_amd import engine
+    g = load_golden(name)
+    imgs, rots, intrs, mr = scene_inputs(g)
+    shapes = [im.shape[:2] for im in imgs]
+    plan = engine.Plan(shapes, rots, intrs, True, mr)
+    assert plan.shape == tuple(g["mb_shape"])
+    assert np.array_equal(plan.resolution, g["resolution"])
+    assert np.array_equal(plan.low, g["im_min"]) and np.array_equal(plan.high, g["im_max"])
+    for i in range(n_patches(g)):
+        assert plan.rects[i] == tuple(g[f"mb_irange_{i}"])
+        assert np.array_equal(plan.ranges[i][0], g["range_min"][i])
+        assert np.array_equal(plan.ranges[i][1], g["range_max"][i])
+    plan = engine.Plan(shapes, rots, intrs, False, mr)
+    assert plan.shape == tuple(g["lin_shape"])
+    for i in range(n_patches(g, "lin")):
+        assert plan.rects[i] == tuple(g[f"lin_irange_{i}"])
+
+
+def test_stage_functions_match_reference():
+    from pano360_amd import bundle_adj, engine
+    g = load_golden("pure")
+    assert np.array_equal(engine.SphProj.hom2proj(g["sph_pts"]), g["sph_h2p"])
+    assert np.array_equal(engine.SphProj.proj2hom(g["sph_h2p"]), g["sph_p2h"])
+    assert np.array_equal(engine.CylProj.hom2proj(g["sph_pts"]), g["cyl_h2p"])
+    assert np.array_equal(engine.CylProj.proj2hom(g["cyl_h2p"]), g["cyl_p2h"])
+    for size in (1, 2, 7, 64, 135):
+        assert np.array_equal(engine.hat(size), g[f"hat_{size}"])
+    cam = bundle_adj.Image(None, g["cam_rot"], g["cam_intr"])
+    assert np.array_equal(cam.hom(), g["cam_hom"]) and np.array_equal(cam.proj(), g["cam_proj"])
+    mn, mx = engine.range_from_border((72, 128), cam.hom())
+    assert np.array_equal(mn, g["border_min"]) and np.array_equal(mx, g["border_max"])
+    mn, mx = engine.range_from_corners((72, 128), cam.hom())
+    assert np.array_equal(mn, g["corners_min"]) and np.array_equal(mx, g["corners_max"])
+    for vec, mat in zip(g["rot_vecs"], g["rot_mats"]):
+        assert np.array_equal(bundle_adj.rotation_to_mat(vec), mat)
+    assert np.array_equal(bundle_adj.intrinsics((250.0, 999.0), (3.0, -4.0)), g["intr_pair"])
+    assert np.array_equal(bundle_adj.intrinsics(300.0), g["cam_intr"])
+
+
+def test_camera_inverse_and_projection_round_trip():
+    """The reference's own tests that touch the path (pano_tests.py:29-33,59-77)."""
+    from pano360_amd import bundle_adj, engine
+    rng = np.random.default_rng(42)
+    cam = bundle_adj.Image(None, bundle_adj.rotation_to_mat(rng.normal(size=3)),
+                           bundle_adj.intrinsics(1e3))
+    np.testing.assert_almost_equal(cam.hom().dot(cam.proj()), np.eye(3))
+    pts = rng.normal(size=(10, 3))
+    pts /= np.linalg.norm(pts, axis=1, keepdims=True)
+    for proj in (engine.SphProj, engine.CylProj):
+        back = proj.proj2hom(proj.hom2proj(pts))
+        back /= np.linalg.norm(back, axis=1, keepdims=True)
+        np.testing.assert_almost_equal(back, pts)
+
+
+def test_gaussian_taps_match_oracle(oracle):
+    from pano360_amd import engine
+    assert [engine.gaussian_ksize(s) for s in engine.level_sigmas(6)] == [33, 57, 73, 87, 97]
+    for sigma in engine.level_sigmas(6) + [1.0, 2.0]:
+        k = engine.gaussian_ksize(sigma)
+        assert np.array_equal(engine.gaussian_taps(k, sigma), oracle.gaussian_kernel(k, sigma))
+    padded = engine.padded_taps(engine.gaussian_taps(33, 4.0))
+    assert len(padded) == 33 + 40 and not padded[:7].any() and not padded[40:].any()
+
+
+def test_pickled_cameras_use_the_reference_module_path():
+    import bundle_adj as top
+    cam = top.Image(np.zeros((2, 2, 3), np.uint8), np.eye(3), top.intrinsics(10.0))
+    blob = pickle.dumps([cam])
+    assert b"bundle_adj" in blob and b"pano360_amd" not in blob.split(b"bundle_adj")[0]
+    back = pickle.loads(blob)[0]
+    assert isinstance(back, top.Image) and np.array_equal(back.intr, cam.intr)
+
+
+def test_product_fails_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    from pano360_amd import _lib, engine
+    with pytest.raises(_lib.PanoError):
+        engine.Engine()

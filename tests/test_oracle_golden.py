@@ -1,0 +1,149 @@
+"""CPU: the C oracle against the golden vectors produced by running the
+reference (oracle/gen_golden.py).  Everything here is bit-exact."""
+import numpy as np
+import pytest
+
+from conftest import SCENES, load_golden, n_patches, scene_inputs
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+@pytest.mark.parametrize("name", SCENES)
+def test_plan_and_warp(oracle, name):
+    g = load_golden(name)
+    imgs, rots, intrs, mr = scene_inputs(g)
+    plan, patches, maps = oracle.warp_all(imgs, rots, intrs, True, mr)
+    assert plan.shape == tuple(g["mb_shape"])
+    assert np.array_equal(plan.resolution, g["resolution"])
+    assert np.array_equal(plan.lo, g["im_min"]) and np.array_equal(plan.hi, g["im_max"])
+    for i, rng in enumerate(plan.ranges):
+        assert np.array_equal(rng[0], g["range_min"][i])
+        assert np.array_equal(rng[1], g["range_max"][i])
+    assert n_patches(g) == len(patches)
+    for i, ((warped, mask, _), (mx, my)) in enumerate(zip(patches, maps)):
+        assert plan.rects[i] == tuple(g[f"mb_irange_{i}"])
+        assert np.array_equal(bits(mx), bits(g[f"mb_mapx_{i}"]))
+        assert np.array_equal(bits(my), bits(g[f"mb_mapy_{i}"]))
+        assert np.array_equal(mask, g[f"mb_mask_{i}"])
+        if f"mb_warped_{i}" in g:
+            assert np.array_equal(bits(warped), bits(g[f"mb_warped_{i}"]))
+    assert np.array_equal(bits(oracle.add_weights(imgs[0])[..., 3]), bits(g["alpha0"]))
+
+
+@pytest.mark.parametrize("name", SCENES)
+def test_inverse_map_fma_choice_is_immaterial(oracle, name):
+    """The 3x3 product in double as FMA chain or as separate mul/add gives the
+    same float32 maps on these scenes (inverse map)."""
+    g = load_golden(name)
+    imgs, rots, intrs, mr = scene_inputs(g)
+    plan = oracle.Plan([im.shape[:2] for im in imgs], rots, intrs, True, mr)
+    for i in range(len(imgs)):
+        a = oracle.inverse_map(plan.projs[i], plan, plan.rects[i], imgs[i].shape[:2], True)
+        b = oracle.inverse_map(plan.projs[i], plan, plan.rects[i], imgs[i].shape[:2], False)
+        assert all(np.array_equal(x, y) for x, y in zip(a, b))
+
+
+@pytest.mark.parametrize("name", SCENES)
+def test_blenders_and_crop(oracle, name):
+    g = load_golden(name)
+    imgs, rots, intrs, mr = scene_inputs(g)
+    for lv in (5, 6):
+        if f"mb{lv}_mosaic" in g:
+            out = oracle.stitch(imgs, rots, intrs, "multiband", lv, max_resolution=mr)
+            assert np.array_equal(out, g[f"mb{lv}_mosaic"])
+    assert np.array_equal(oracle.stitch(imgs, rots, intrs, "linear", max_resolution=mr),
+                          g["linear_mosaic"])
+    assert np.array_equal(oracle.stitch(imgs, rots, intrs, "none", max_resolution=mr),
+                          g["none_mosaic"])
+    assert np.array_equal(
+        oracle.stitch(imgs, rots, intrs, "linear", crop=True, max_resolution=mr),
+        g["lin_cropped"])
+    plan, patches, _ = oracle.warp_all(imgs, rots, intrs, True, mr)
+    valid = oracle.valid(patches, plan.shape)
+    assert np.array_equal(valid, g["mb_valid"])
+    assert oracle.crop_rect(valid) == tuple(g["mb_crop_rect"])
+    plan, patches, _ = oracle.warp_all(imgs, rots, intrs, False, mr)
+    valid = oracle.valid(patches, plan.shape)
+    assert np.array_equal(valid, g["lin_valid"])
+    assert oracle.crop_rect(valid) == tuple(g["lin_crop_rect"])
+
+
+def test_pure_stage_functions(oracle):
+    g = load_golden("pure")
+    assert np.array_equal(oracle.sph_hom2proj(g["sph_pts"]), g["sph_h2p"])
+    assert np.array_equal(oracle.sph_proj2hom(g["sph_h2p"]), g["sph_p2h"])
+    assert np.array_equal(oracle.cyl_hom2proj(g["sph_pts"]), g["cyl_h2p"])
+    assert np.array_equal(oracle.cyl_proj2hom(g["cyl_h2p"]), g["cyl_p2h"])
+    for size in (1, 2, 7, 64, 135):
+        assert np.array_equal(oracle.hat(size), g[f"hat_{size}"])
+    mn, mx = oracle.range_border((72, 128), g["cam_hom"])
+    assert np.array_equal(mn, g["border_min"]) and np.array_equal(mx, g["border_max"])
+    mn, mx = oracle.range_corners((72, 128), g["cam_hom"])
+    assert np.array_equal(mn, g["corners_min"]) and np.array_equal(mx, g["corners_max"])
+
+
+def test_spherical_round_trip(oracle):
+    """The reference's own test of the path (pano_tests.py:59-67)."""
+    pts = np.random.default_rng(42).normal(size=(10, 3))
+    pts /= np.linalg.norm(pts, axis=1, keepdims=True)
+    back = oracle.sph_proj2hom(oracle.sph_hom2proj(pts))
+    back /= np.linalg.norm(back, axis=1, keepdims=True)
+    np.testing.assert_almost_equal(back, pts)
+    back = oracle.cyl_proj2hom(oracle.cyl_hom2proj(pts))
+    back /= np.linalg.norm(back, axis=1, keepdims=True)
+    np.testing.assert_almost_equal(back, pts)
+
+
+def test_crop_masks(oracle):
+    g = load_golden("pure")
+    for i in range(int(g["n_crop"])):
+        assert oracle.crop_rect(g[f"crop_mask_{i}"]) == tuple(g[f"crop_rect_{i}"]), i
+    with pytest.raises(UnboundLocalError):
+        oracle.crop_rect(np.zeros((4, 5), bool))
+
+
+def _bl_patches(g):
+    out = []
+    for i in range(int(g["bl_n"])):
+        y0, y1, x0, x1 = g[f"bl_irange_{i}"]
+        out.append((g[f"bl_warped_{i}"].copy(), g[f"bl_mask_{i}"].copy(),
+                    np.s_[int(y0):int(y1), int(x0):int(x1)]))
+    return out
+
+
+def test_stage_blenders(oracle):
+    g = load_golden("pure")
+    shape = tuple(int(v) for v in g["bl_shape"])
+    assert np.array_equal(oracle.no_blend(_bl_patches(g), shape), g["bl_none"])
+    assert np.array_equal(oracle.linear_blend(_bl_patches(g), shape), g["bl_linear"])
+    assert np.array_equal(oracle.multiband_blend(_bl_patches(g), shape), g["bl_mb5"])
+    assert np.array_equal(oracle.multiband_blend(_bl_patches(g), shape, 3), g["bl_mb3"])
+    assert np.array_equal(oracle.valid(_bl_patches(g), shape), g["bl_valid"])
+
+
+def test_filters(oracle):
+    g = load_golden("pure")
+    assert np.array_equal(bits(oracle.gaussian_filter(g["gf_img"])), bits(g["gf_s1"]))
+    assert np.array_equal(bits(oracle.gaussian_filter(g["gf_img"], 2.0)), bits(g["gf_s2"]))
+    p1 = oracle.pyr_down(g["gf_img"])
+    assert np.array_equal(bits(p1), bits(g["pyr_1"]))
+    assert np.array_equal(bits(oracle.pyr_down(p1)), bits(g["pyr_2"]))
+    assert [oracle.gaussian_ksize(4 * np.sqrt(2 * k + 1.0)) for k in range(5)] == \
+        [33, 57, 73, 87, 97]
+
+
+def test_border_rule(oracle):
+    lib = oracle.lib()
+    for length in (1, 2, 3, 7):
+        for p in range(-3 * length - 2, 3 * length + 3):
+            for mode in (2, 4):
+                want = p          # OpenCV's iterative rule, stated independently
+                if length == 1:
+                    want = 0
+                else:
+                    while not 0 <= want < length:
+                        d = 1 if mode == 4 else 0
+                        want = -want - 1 + d if want < 0 else length - 1 - (want - length) - d
+                assert lib.orc_border(p, length, mode) == want
