@@ -61,19 +61,26 @@ def kernel_times(lib):
     return out
 
 
-def roofline_for(times, plan, n_levels, steps, source_px):
+def roofline_for(times, plan, patches, n_levels, steps):
     """Roofline entry of the kernel with the largest share of the timed region.
-    Algorithmic work per launch is derived from the plan."""
+    Algorithmic work per launch counts the pixels that launch really produced
+    (windows V / rectangles A of the patches), not the
+    reference's whole-patch count P."""
     from pano360_amd import engine
     name = max(times, key=lambda k: times[k][0])
     total_ms, launches = times[name]
     avg_s = total_ms / launches * 1e-3
-    P = plan.patch_pixels
     M = plan.shape[0] * plan.shape[1]
+    win = [((p.window[1] - p.window[0]), (p.window[3] - p.window[2]),
+            (p.area[1] - p.area[0]), (p.area[3] - p.area[2])) for p in patches]
+    px_rows = sum(vh * aw for vh, vw, ah, aw in win)      # row pass: rows of V x cols of A
+    px_cols = sum(ah * aw for vh, vw, ah, aw in win)      # column pass / gather: A
+    px_warp = sum(vh * vw for vh, vw, ah, aw in win)      # warp: V
     taps = [engine.gaussian_ksize(s) for s in engine.level_sigmas(n_levels)]
     if name in ("blur_rows_kernel", "blur_cols_kernel"):
         # one launch = one level of one patch, 4 channels: taps FMAs per output
-        flop = steps * sum(2.0 * t * 4 * P for t in taps)
+        px = px_rows if name == "blur_rows_kernel" else px_cols
+        flop = steps * sum(2.0 * t * 4 * px for t in taps)
         achieved = flop / launches / avg_s / 1e12
         return dict(kernel=name, bound="mfma", achieved=achieved, peak=F32_PEAK_TFLOPS,
                     unit="TFLOP/s", frac=achieved / F32_PEAK_TFLOPS, traffic=None,
@@ -81,11 +88,13 @@ def roofline_for(times, plan, n_levels, steps, source_px):
                          "f32 vector peak (157.3 TFLOP/s), no MFMA is issued",
                     avg_launch_ms=avg_s * 1e3, launches=launches)
     per_step = {
-        "warp_spherical_kernel": 17.0 * P + 3.0 * source_px,
-        "ownership_kernel": 5.0 * P + 3.0 * M,
-        "multiband_compose_kernel": (12.0 + 16.0 * (n_levels - 1)) * P + 6.0 * M,
-        "linear_blend_kernel": 17.0 * P + 3.0 * M,
-        "no_blend_kernel": 13.0 * P + 3.0 * M,
+        # 3 float planes written + the frame bytes under the window (about 1:1 scale)
+        "warp_spherical_kernel": 12.0 * px_warp + 3.0 * px_warp,
+        # no pixel data read: owner (2 B) + valid (1 B) written per mosaic pixel
+        "ownership_cameras_kernel": 3.0 * M,
+        "owned_boxes_kernel": 2.0 * M,
+        # warped colour + L-1 blurred RGBA per gathered pixel; owner/valid read, u8 out
+        "multiband_compose_kernel": (12.0 + 16.0 * (n_levels - 1)) * px_cols + 6.0 * M,
     }.get(name, 0.0)
     achieved = per_step * steps / launches / avg_s / 1e9
     return dict(kernel=name, bound="hbm", achieved=achieved, peak=HBM_PEAK_GBPS,
@@ -154,8 +163,8 @@ def main():
         if runner is not None:
             return runner.step(frames)
         plan = engine.Plan(shapes, rots, intrs, True, NATIVE)
-        mosaic, _, _, _ = eng.stitch(frames, plan, "multiband", n_levels)
-        return plan, mosaic
+        mosaic, _, _, patches = eng.stitch(frames, plan, "multiband", n_levels)
+        return plan, mosaic, patches
 
     def fence():
         torch.cuda.synchronize()
@@ -169,7 +178,7 @@ def main():
     eng.lib.pano_timing_enable(1)
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        plan, mosaic = step()
+        plan, mosaic, patches = step()
     fence()
     elapsed = time.perf_counter() - t0
     times = kernel_times(eng.lib)
@@ -211,7 +220,12 @@ def main():
                 "input_MPps": S / (ms * 1e-3) / 1e6, "mosaic_MPps": M / (ms * 1e-3) / 1e6,
             },
             "kernel_ms_per_step": {k: v[0] / args.steps for k, v in sorted(times.items())},
-            "roofline": roofline_for(times, plan, n_levels, args.steps, S),
+            "roofline": roofline_for(times, plan, patches, n_levels, args.steps),
+            "active_megapixels": {
+                "warped": sum((p.window[1] - p.window[0]) * (p.window[3] - p.window[2])
+                              for p in patches) / 1e6,
+                "blurred": sum((p.area[1] - p.area[0]) * (p.area[3] - p.area[2])
+                               for p in patches) / 1e6},
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(cfg)

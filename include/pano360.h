@@ -15,15 +15,26 @@
  *     work is enqueued asynchronously on it, nothing synchronises;
  *   - return value: 0 on success, a negative PANO_E* code otherwise, with a
  *     thread-local message available from pano_last_error();
- *   - no exceptions cross the boundary, no global mutable state.
+ *   - no exceptions cross the boundary; the only global state is the
+ *     optional timing registry (pano_timing_*).
  *
  * Layouts
  *   frame      uint8  [H][W][3]      as cv2.imread hands it to the reference
- *   planes     float  [4][h][pitch]  planar R,G,B,A of a warped patch,
- *                                    pitch = pano_pitch(w) floats (16-B rows)
+ *   planes     float  [c][vh][vpitch] planar R,G,B(,A) of a warped patch
+ *                                    window, pitch = pano_pitch(width) floats
  *   mask       uint8  [h][w]         1 = outside the source frame
  *   owner      int16  [H][W]         patch index owning the pixel, -1 = none
  *   mosaic     uint8  [H][W][3]
+ *
+ * Windows.  Multiband blending only ever uses a patch near the pixels it owns:
+ * beyond the Gaussian radius of the last owned pixel every blurred alpha is an
+ * exact 0 and the patch contributes 0 to every sum (stitcher.py:231-232).  A
+ * patch therefore carries two sub-rectangles, in patch-local coordinates:
+ *   A = bounding box of its owned pixels grown by the largest radius R
+ *       (clipped to the patch): where blurred copies exist and are gathered;
+ *   V = A grown by R again (closed under the REFLECT_101 border rule): where
+ *       the warped colour is needed as blur input.
+ * Both default to the whole patch (the stage-level blender API).
  */
 #ifndef PANO360_H
 #define PANO360_H
@@ -46,17 +57,26 @@ extern "C" {
 #define PANO_TAP_PAD 40        /* padded table length = ntaps + this       */
 
 /* One warped patch as the blenders see it (reference: the tuples appended at
- * stitcher.py:318-319).  All pointers dev.  `blurred` holds the n_levels-1
- * Gaussian-blurred copies, [level][4][h][pitch]; may be NULL for the
- * non-multiband blenders. */
+ * stitcher.py:318-319).  All pointers dev. */
 typedef struct pano_patch {
-    float *planes;
-    uint8_t *mask;
-    float *blurred;
-    int32_t y0, x0, h, w;      /* rectangle in mosaic coordinates          */
-    int32_t pitch;             /* floats per plane row                     */
-    int32_t reserved;
+    float *planes;             /* [3 or 4][vh][vpitch] over window V        */
+    uint8_t *mask;             /* [h][w], full patch; NULL in the fused path */
+    float *blurred;            /* [n_levels-1][4][ah][apitch] over A; or NULL */
+    int32_t y0, x0, h, w;      /* patch rectangle in mosaic coordinates     */
+    int32_t vy0, vx0, vh, vw;  /* window V, patch-local                     */
+    int32_t ay0, ax0, ah, aw;  /* rectangle A, patch-local                  */
+    int32_t vpitch, apitch;    /* floats per row of planes / blurred        */
 } pano_patch;
+
+/* One registered frame for the analytic ownership kernel (reference:
+ * bundle_adj.Image, bundle_adj.py:18-33, plus its patch rectangle). */
+typedef struct pano_camera {
+    double proj[9];            /* K R, row-major (bundle_adj.py:31-33)      */
+    const double *hat_x;       /* dev double[sw] = _hat(sw) (stitcher.py:251) */
+    const double *hat_y;       /* dev double[sh]                            */
+    int32_t sh, sw;            /* frame size                                */
+    int32_t y0, x0, h, w;      /* patch rectangle in mosaic coordinates     */
+} pano_camera;
 
 const char *pano_version(void);
 const char *pano_last_error(void);
@@ -81,7 +101,7 @@ int pano_add_weights(const uint8_t *frame, int h, int w, const float *lut255,
                      const double *hat_x, const double *hat_y, float *rgba,
                      void *stream);
 
-/* Inverse map + mask + bilinear REFLECT remap of one patch
+/* Inverse map + mask + bilinear REFLECT remap of one whole patch
  *                                       stitcher.py:300-317 (+ cv2.remap)
  * proj: host double[9] = K R row-major (bundle_adj.py:31-33).
  * sin_t, cos_t: dev double tables over mosaic columns, tan_p over mosaic rows
@@ -97,18 +117,44 @@ int pano_warp_spherical(const uint8_t *frame, int sh, int sw,
                         float *planes, uint8_t *mask, float *map_x,
                         float *map_y, void *stream);
 
-/* Ownership + validity                      stitcher.py:196-204, 266-271
- * owner = first-index argmax of the patches' alpha, -1 where all are 0;
- * valid = OR over patches of ~mask.  patches: dev array of n pano_patch. */
+/* Same arithmetic, colour only, restricted to a window: (gx0, gy0) is the
+ * window origin in mosaic coordinates, vw x vh its size; writes planes
+ * [3][vh][pitch].  Alpha and mask are not produced: the fused path gets them
+ * from pano_ownership_cameras. */
+int pano_warp_window(const uint8_t *frame, int sh, int sw, const double *proj,
+                     const double *sin_t, const double *cos_t,
+                     const double *tan_p, const float *lut255, int gx0,
+                     int gy0, int vw, int vh, float *planes, void *stream);
+
+/* Ownership + validity from warped patches   stitcher.py:196-204, 266-271
+ * owner = first-index argmax of the patches' alpha plane (planes[3]), -1 where
+ * all are 0; valid = OR over patches of ~mask.  patches: dev array of n
+ * pano_patch with 4 planes and a mask, V = whole patch. */
 int pano_ownership(const pano_patch *patches, int n, int H, int W,
                    int16_t *owner, uint8_t *valid, void *stream);
 
+/* The same two maps straight from the cameras (no pixel data is read): for
+ * every mosaic pixel in columns [xs0, xs1) and every camera whose patch
+ * rectangle holds it, the inverse map, the mask and the bilinear alpha are
+ * re-evaluated exactly as pano_warp_spherical does.  cams: dev array. */
+int pano_ownership_cameras(const pano_camera *cams, int n, int H, int W,
+                           int xs0, int xs1, const double *sin_t,
+                           const double *cos_t, const double *tan_p,
+                           int16_t *owner, uint8_t *valid, void *stream);
+
+/* Bounding box of each patch's owned pixels: boxes dev int32 [n][4] =
+ * {ymin, ymax, xmin, xmax} inclusive, mosaic coordinates; ymax < ymin when the
+ * patch owns nothing. */
+int pano_owned_boxes(const int16_t *owner, int H, int W, int n, int32_t *boxes,
+                     void *stream);
+
 /* The n_levels-1 Gaussian blurs of one patch   stitcher.py:207-208, 218, 226
  * (cv2.GaussianBlur(warped, (0,0), 4*sqrt(2k+1)) with the alpha channel
- * replaced by the sharp mask owner == index).  patch: host struct.
+ * replaced by the sharp mask owner == index), evaluated on rectangle A from
+ * the colour planes over V.  patch: host struct.
  * taps: dev float, n_blur tables laid out back to back, table k has
  * ntaps[k] + PANO_TAP_PAD floats: PANO_TAP_LEAD zeros, the ntaps[k] taps,
- * zeros.  ntaps: host int[n_blur].  scratch: dev float [4][h][pitch].
+ * zeros.  ntaps: host int[n_blur].  scratch: dev float [4][vh][apitch].
  * Writes patch->blurred. */
 int pano_multiband_blur(const pano_patch *patch, int index,
                         const int16_t *owner, int W, const float *taps,
@@ -117,7 +163,8 @@ int pano_multiband_blur(const pano_patch *patch, int index,
 
 /* Band-pass build + collapse                     stitcher.py:210-241
  * Gathers, per mosaic pixel and in patch order, layer_k / wsum_k of every
- * level, zeroes outside `valid`, sums the levels, clips, truncates to uint8.
+ * level over the patches whose A holds the pixel, zeroes outside `valid`,
+ * sums the levels, clips, truncates to uint8.
  * mosaic_f32 (optional) receives the clipped float mosaic [H][W][3]. */
 int pano_multiband_compose(const pano_patch *patches, int n, int H, int W,
                            int n_levels, const int16_t *owner,

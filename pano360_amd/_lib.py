@@ -25,12 +25,20 @@ class PanoError(RuntimeError):
 
 
 class Patch(C.Structure):
-    """``pano_patch`` of include/pano360.h (48 bytes)."""
+    """``pano_patch`` of include/pano360.h (80 bytes)."""
     _fields_ = [("planes", C.c_void_p), ("mask", C.c_void_p),
                 ("blurred", C.c_void_p),
-                ("y0", C.c_int32), ("x0", C.c_int32),
-                ("h", C.c_int32), ("w", C.c_int32),
-                ("pitch", C.c_int32), ("reserved", C.c_int32)]
+                ("y0", C.c_int32), ("x0", C.c_int32), ("h", C.c_int32), ("w", C.c_int32),
+                ("vy0", C.c_int32), ("vx0", C.c_int32), ("vh", C.c_int32), ("vw", C.c_int32),
+                ("ay0", C.c_int32), ("ax0", C.c_int32), ("ah", C.c_int32), ("aw", C.c_int32),
+                ("vpitch", C.c_int32), ("apitch", C.c_int32)]
+
+
+class Camera(C.Structure):
+    """``pano_camera`` of include/pano360.h (112 bytes)."""
+    _fields_ = [("proj", C.c_double * 9), ("hat_x", C.c_void_p), ("hat_y", C.c_void_p),
+                ("sh", C.c_int32), ("sw", C.c_int32),
+                ("y0", C.c_int32), ("x0", C.c_int32), ("h", C.c_int32), ("w", C.c_int32)]
 
 
 _vp, _i = C.c_void_p, C.c_int
@@ -46,7 +54,10 @@ _SIGNATURES = {
     "pano_add_weights": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "pano_warp_spherical": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                  _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "pano_warp_window": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "pano_ownership": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp]),
+    "pano_ownership_cameras": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "pano_owned_boxes": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "pano_multiband_blur": (_i, [C.POINTER(Patch), _i, _vp, _i, _vp,
                                  C.POINTER(C.c_int), _i, _vp, _vp]),
     "pano_multiband_compose": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),

@@ -8,12 +8,17 @@
 // (linear_blend), :196-241 (multiband_blend minus the GaussianBlur calls),
 // :266-271 (_valid).
 //
-// Roofline: HBM.  Per covered (pixel, patch) pair the multiband collapse reads
+// Roofline: HBM.  Per gathered (pixel, patch) pair the multiband collapse reads
 // 3 + 4(L-1) floats (the warped colour and the L-1 blurred RGBA copies),
 // coalesced along x because every plane is planar; it writes 3 B (+12 B when
-// the float mosaic is requested) per mosaic pixel.
-#include "common.h"
+// the float mosaic is requested) per mosaic pixel.  The camera-driven ownership
+// kernel reads no pixel data at all: 3 B written per mosaic pixel, the rest is
+// arithmetic (about 120 instructions per covering camera).
+#include "geom.h"
 
+int pano_check_patch(const pano_patch *p, const char *who);   // blur.hip
+
+// ---- ownership from warped alpha planes (stage-level API) ---------------------
 __global__ __launch_bounds__(256) void ownership_kernel(
     const pano_patch *__restrict__ patches, int n, int H, int W,
     int16_t *__restrict__ owner, uint8_t *__restrict__ valid) {
@@ -26,7 +31,7 @@ __global__ __launch_bounds__(256) void ownership_kernel(
         const pano_patch p = patches[i];
         const int px = x - p.x0, py = y - p.y0;
         if ((unsigned)px >= (unsigned)p.w || (unsigned)py >= (unsigned)p.h) continue;
-        const float a = p.planes[3 * (size_t)p.h * p.pitch + (size_t)py * p.pitch + px];
+        const float a = p.planes[3 * (size_t)p.vh * p.vpitch + (size_t)py * p.vpitch + px];
         if (a > best) {          // strict: the first maximum keeps the pixel
             best = a;
             who = i;
@@ -35,6 +40,68 @@ __global__ __launch_bounds__(256) void ownership_kernel(
     }
     owner[(size_t)y * W + x] = (int16_t)who;
     valid[(size_t)y * W + x] = any ? 1 : 0;
+}
+
+// ---- ownership straight from the cameras (fused path) ---------------------------
+// alpha_i(pixel) is a closed form of camera i alone: the inverse map, the
+// bounds mask and the bilinear sample of hat_y (x) hat_x, all evaluated with
+// the operations pano_warp_spherical uses, so the owner map is identical to
+// the one computed from warped alpha planes.
+__global__ __launch_bounds__(256) void ownership_cameras_kernel(
+    const pano_camera *__restrict__ cams, int n, int H, int W, int xs0, int xs1,
+    const double *__restrict__ sin_t, const double *__restrict__ cos_t,
+    const double *__restrict__ tan_p, int16_t *__restrict__ owner,
+    uint8_t *__restrict__ valid) {
+    const int x = xs0 + blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+    if (x >= xs1 || y >= H) return;
+    const double s = sin_t[x], c = cos_t[x], t = tan_p[y];
+    float best = 0.0f;
+    int who = -1;
+    bool any = false;
+    for (int i = 0; i < n; ++i) {
+        const pano_camera *cam = cams + i;
+        const int px = x - cam->x0, py = y - cam->y0;
+        if ((unsigned)px >= (unsigned)cam->w || (unsigned)py >= (unsigned)cam->h) continue;
+        float fx, fy;
+        const int sw = cam->sw, sh = cam->sh;
+        if (map_pixel(cam->proj, s, c, t, sw, sh, fx, fy)) continue;   // alpha * 0
+        any = true;
+        const Taps tp = make_taps(fx, fy, sw, sh);
+        const float a = alpha_at(cam->hat_x, cam->hat_y, tp);
+        if (a > best) {
+            best = a;
+            who = i;
+        }
+    }
+    owner[(size_t)y * W + x] = (int16_t)who;
+    valid[(size_t)y * W + x] = any ? 1 : 0;
+}
+
+// Bounding boxes of the owned regions.  Only the ends of each horizontal run of
+// equal owners touch the atomics (a few runs per row), so contention is nil.
+__global__ __launch_bounds__(256) void owned_boxes_kernel(const int16_t *__restrict__ owner,
+                                                          int H, int W,
+                                                          int32_t *__restrict__ boxes) {
+    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+    if (x >= W || y >= H) return;
+    const int16_t *row = owner + (size_t)y * W;
+    const int o = row[x];
+    if (o < 0) return;
+    if (x == 0 || row[x - 1] != o) {
+        atomicMin(&boxes[4 * o + 0], y);
+        atomicMax(&boxes[4 * o + 1], y);
+        atomicMin(&boxes[4 * o + 2], x);
+    }
+    if (x == W - 1 || row[x + 1] != o) atomicMax(&boxes[4 * o + 3], x);
+}
+
+__global__ void init_boxes_kernel(int32_t *boxes, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    boxes[4 * i + 0] = 0x7fffffff;
+    boxes[4 * i + 1] = -1;
+    boxes[4 * i + 2] = 0x7fffffff;
+    boxes[4 * i + 3] = -1;
 }
 
 // uint8(255 * v) with C truncation; v is in [0, 1] up to rounding.
@@ -53,22 +120,25 @@ __global__ __launch_bounds__(256) void multiband_compose_kernel(
 
     for (int i = 0; i < n; ++i) {
         const pano_patch p = patches[i];
-        const int px = x - p.x0, py = y - p.y0;
-        if ((unsigned)px >= (unsigned)p.w || (unsigned)py >= (unsigned)p.h) continue;
-        const size_t plane = (size_t)p.h * p.pitch, o = (size_t)py * p.pitch + px;
+        // outside A every weight of this patch is an exact 0 (header, "Windows")
+        const int ax = x - p.x0 - p.ax0, ay = y - p.y0 - p.ay0;
+        if ((unsigned)ax >= (unsigned)p.aw || (unsigned)ay >= (unsigned)p.ah) continue;
+        const size_t vplane = (size_t)p.vh * p.vpitch;
+        const size_t vo = (size_t)(ay + p.ay0 - p.vy0) * p.vpitch + (ax + p.ax0 - p.vx0);
+        const size_t aplane = (size_t)p.ah * p.apitch, ao = (size_t)ay * p.apitch + ax;
         float hi[3], ha = 0.0f;                 // the copy that gets the minus
 #pragma unroll
-        for (int c = 0; c < 3; ++c) hi[c] = p.planes[c * plane + o];
+        for (int c = 0; c < 3; ++c) hi[c] = p.planes[c * vplane + vo];
         if (L == 1) ha = owner[(size_t)y * W + x] == i ? 1.0f : 0.0f;   // sharp alpha (:208)
 #pragma unroll
         for (int k = 0; k < L; ++k) {
             float rgb[3], a;
             if (k < L - 1) {
-                const float *b = p.blurred + (size_t)k * 4 * plane + o;
-                a = b[3 * plane];
+                const float *b = p.blurred + (size_t)k * 4 * aplane + ao;
+                a = b[3 * aplane];
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
-                    const float g = b[c * plane];
+                    const float g = b[c * aplane];
                     rgb[c] = hi[c] - g;          // tile.rgb -= blur.rgb   (:227)
                     hi[c] = g;                   // prevs[idx] = blur      (:229)
                 }
@@ -112,7 +182,7 @@ __global__ __launch_bounds__(256) void linear_blend_kernel(
         const pano_patch p = patches[i];
         const int px = x - p.x0, py = y - p.y0;
         if ((unsigned)px >= (unsigned)p.w || (unsigned)py >= (unsigned)p.h) continue;
-        const size_t plane = (size_t)p.h * p.pitch, o = (size_t)py * p.pitch + px;
+        const size_t plane = (size_t)p.vh * p.vpitch, o = (size_t)py * p.vpitch + px;
         const bool m = p.mask[(size_t)py * p.w + px] != 0;
         const float a = p.planes[3 * plane + o];
 #pragma unroll
@@ -139,7 +209,7 @@ __global__ __launch_bounds__(256) void no_blend_kernel(
         const int px = x - p.x0, py = y - p.y0;
         if ((unsigned)px >= (unsigned)p.w || (unsigned)py >= (unsigned)p.h) continue;
         if (p.mask[(size_t)py * p.w + px]) continue;
-        const size_t plane = (size_t)p.h * p.pitch, o = (size_t)py * p.pitch + px;
+        const size_t plane = (size_t)p.vh * p.vpitch, o = (size_t)py * p.vpitch + px;
 #pragma unroll
         for (int c = 0; c < 3; ++c) out[c] = quant255(p.planes[c * plane + o]);
     }
@@ -149,8 +219,8 @@ __global__ __launch_bounds__(256) void no_blend_kernel(
     mosaic[g + 2] = out[2];
 }
 
-static int check_table(const pano_patch *patches, int n, int H, int W, const char *who) {
-    PANO_REQUIRE(patches, "%s: null patch table", who);
+static int check_table(const void *table, int n, int H, int W, const char *who) {
+    PANO_REQUIRE(table, "%s: null table", who);
     PANO_REQUIRE(n >= 0 && n <= 32767, "%s: %d patches (int16 owner map holds 32767)", who, n);
     PANO_REQUIRE(H > 0 && W > 0, "%s: bad mosaic shape %dx%d", who, H, W);
     return PANO_OK;
@@ -158,14 +228,49 @@ static int check_table(const pano_patch *patches, int n, int H, int W, const cha
 
 #define MOSAIC_GRID dim3 block(64, 4), grid(ceil_div(W, 64), ceil_div(H, 4))
 
+// The stage-level kernels index whole-patch planes: V must be the patch.
 extern "C" int pano_ownership(const pano_patch *patches, int n, int H, int W,
                               int16_t *owner, uint8_t *valid, void *stream) {
     if (int rc = check_table(patches, n, H, W, "pano_ownership")) return rc;
     PANO_REQUIRE(owner && valid, "pano_ownership: null output");
     MOSAIC_GRID;
-    PANO_TIMED(PK_OWNERSHIP, (hipStream_t)stream, hipLaunchKernelGGL(ownership_kernel, grid, block, 0, (hipStream_t)stream, patches, n,
-                       H, W, owner, valid));
+    PANO_TIMED(PK_OWNERSHIP, (hipStream_t)stream,
+               hipLaunchKernelGGL(ownership_kernel, grid, block, 0, (hipStream_t)stream,
+                                  patches, n, H, W, owner, valid));
     PANO_LAUNCH_CHECK("ownership_kernel");
+    return PANO_OK;
+}
+
+extern "C" int pano_ownership_cameras(const pano_camera *cams, int n, int H, int W,
+                                      int xs0, int xs1, const double *sin_t,
+                                      const double *cos_t, const double *tan_p,
+                                      int16_t *owner, uint8_t *valid, void *stream) {
+    if (int rc = check_table(cams, n, H, W, "pano_ownership_cameras")) return rc;
+    PANO_REQUIRE(sin_t && cos_t && tan_p && owner && valid, "pano_ownership_cameras: null pointer");
+    PANO_REQUIRE(xs0 >= 0 && xs1 <= W && xs0 <= xs1, "pano_ownership_cameras: bad strip [%d, %d)", xs0, xs1);
+    if (xs0 == xs1) return PANO_OK;
+    dim3 block(64, 4), grid(ceil_div(xs1 - xs0, 64), ceil_div(H, 4));
+    PANO_TIMED(PK_OWNERSHIP_CAMS, (hipStream_t)stream,
+               hipLaunchKernelGGL(ownership_cameras_kernel, grid, block, 0,
+                                  (hipStream_t)stream, cams, n, H, W, xs0, xs1, sin_t, cos_t,
+                                  tan_p, owner, valid));
+    PANO_LAUNCH_CHECK("ownership_cameras_kernel");
+    return PANO_OK;
+}
+
+extern "C" int pano_owned_boxes(const int16_t *owner, int H, int W, int n, int32_t *boxes,
+                                void *stream) {
+    PANO_REQUIRE(owner && boxes, "pano_owned_boxes: null pointer");
+    PANO_REQUIRE(H > 0 && W > 0 && n >= 0 && n <= 32767, "pano_owned_boxes: bad argument");
+    if (n == 0) return PANO_OK;
+    hipLaunchKernelGGL(init_boxes_kernel, dim3(ceil_div(n, 256)), dim3(256), 0,
+                       (hipStream_t)stream, boxes, n);
+    PANO_LAUNCH_CHECK("init_boxes_kernel");
+    MOSAIC_GRID;
+    PANO_TIMED(PK_OWNED_BOXES, (hipStream_t)stream,
+               hipLaunchKernelGGL(owned_boxes_kernel, grid, block, 0, (hipStream_t)stream,
+                                  owner, H, W, boxes));
+    PANO_LAUNCH_CHECK("owned_boxes_kernel");
     return PANO_OK;
 }
 
@@ -199,8 +304,9 @@ extern "C" int pano_linear_blend(const pano_patch *patches, int n, int H, int W,
     if (int rc = check_table(patches, n, H, W, "pano_linear_blend")) return rc;
     PANO_REQUIRE(mosaic, "pano_linear_blend: null output");
     MOSAIC_GRID;
-    PANO_TIMED(PK_LINEAR, (hipStream_t)stream, hipLaunchKernelGGL(linear_blend_kernel, grid, block, 0, (hipStream_t)stream, patches,
-                       n, H, W, mosaic));
+    PANO_TIMED(PK_LINEAR, (hipStream_t)stream,
+               hipLaunchKernelGGL(linear_blend_kernel, grid, block, 0, (hipStream_t)stream,
+                                  patches, n, H, W, mosaic));
     PANO_LAUNCH_CHECK("linear_blend_kernel");
     return PANO_OK;
 }
@@ -210,8 +316,9 @@ extern "C" int pano_no_blend(const pano_patch *patches, int n, int H, int W,
     if (int rc = check_table(patches, n, H, W, "pano_no_blend")) return rc;
     PANO_REQUIRE(mosaic, "pano_no_blend: null output");
     MOSAIC_GRID;
-    PANO_TIMED(PK_NOBLEND, (hipStream_t)stream, hipLaunchKernelGGL(no_blend_kernel, grid, block, 0, (hipStream_t)stream, patches, n, H,
-                       W, mosaic));
+    PANO_TIMED(PK_NOBLEND, (hipStream_t)stream,
+               hipLaunchKernelGGL(no_blend_kernel, grid, block, 0, (hipStream_t)stream,
+                                  patches, n, H, W, mosaic));
     PANO_LAUNCH_CHECK("no_blend_kernel");
     return PANO_OK;
 }

@@ -21,6 +21,12 @@
 // input / output) is wz[p - o + 7], which is 0 outside the aperture, so the
 // inner loops need no edge cases.  Sums run in ascending tap order with one
 // FMA per tap.
+//
+// Windows (include/pano360.h): the passes only produce rectangle A of a patch.
+// The row pass reads the colour planes over window V and writes rows V x
+// columns A into scratch; the column pass reads that and writes A.  Border
+// reflection always uses the full patch size, so results equal blurring the
+// whole patch and cutting A out of it.
 #include "common.h"
 
 #define ROW_TW 512            // outputs per wave-row
@@ -31,39 +37,49 @@
 #define COL_TW 64
 #define COL_TH 128
 
-struct RowJob {
-    const float *src;     // plane [h][pitch]; NULL -> sharp alpha from owner
-    float *dst;           // plane [h][pitch]
+struct RowGeom {
+    int w;              // full patch width (reflection period)
+    int vx0, vw, vh;    // window V: x origin (patch-local), width, rows
+    int vpitch;         // source plane pitch
+    int ax0, aw;        // output columns: patch-local origin, count
+    int apitch;         // destination pitch
+    // sharp-alpha source: owner[(oy + row) * opitch + ox + patch_col] == oindex
+    int opitch, oy, ox, oindex;
 };
+
 struct RowJobs {
-    RowJob j[4];
+    const float *src[4];    // plane over V; NULL -> sharp alpha from the owner map
+    float *dst[4];          // [vh][apitch]
 };
 
 __device__ __forceinline__ int row_pos(int i) { return i + ((i >> 3) << 2); }
 
 __global__ __launch_bounds__(256) void blur_rows_kernel(
-    RowJobs jobs, int h, int w, int pitch, const float *wz_global, int ntaps,
-    const int16_t *__restrict__ owner, int owner_pitch, int owner_y0,
-    int owner_x0, int owner_index) {
+    RowJobs jobs, RowGeom g, const float *wz_global, int ntaps,
+    const int16_t *__restrict__ owner) {
     const kptr_f32 wz = (kptr_f32)(uintptr_t)wz_global;
     __shared__ __attribute__((aligned(16))) float s_row[4][ROW_LDS];
-    const RowJob job = jobs.j[blockIdx.z];
+    const float *__restrict__ src = jobs.src[blockIdx.z];
+    float *__restrict__ dst = jobs.dst[blockIdx.z];
     const int lane = threadIdx.x, wv = threadIdx.y;
     const int R = ntaps >> 1;
-    const int xt = blockIdx.x * ROW_TW;          // first output column
+    const int xt = blockIdx.x * ROW_TW;          // first output column, A-relative
     const int y = blockIdx.y * 4 + wv;
-    const int yc = y < h ? y : h - 1;
+    const int yc = y < g.vh ? y : g.vh - 1;
     float *tile = s_row[wv];
 
     const int steps = (ntaps + 7 + 3) >> 2;      // 4 inputs per step
     const int need = 8 * 63 + 4 * steps;         // tile entries read by lane 63
     for (int i = lane; i < need; i += 64) {
-        int col = reflect_101(xt - R + i, w);
+        const int pcol = reflect_101(g.ax0 + xt - R + i, g.w);
         float v;
-        if (job.src)
-            v = job.src[(size_t)yc * pitch + col];
-        else
-            v = owner[(size_t)(owner_y0 + yc) * owner_pitch + owner_x0 + col] == owner_index ? 1.0f : 0.0f;
+        if (src) {
+            int vc = pcol - g.vx0;               // inside V by construction; clamp anyway
+            vc = vc < 0 ? 0 : (vc >= g.vw ? g.vw - 1 : vc);
+            v = src[(size_t)yc * g.vpitch + vc];
+        } else {
+            v = owner[(size_t)(g.oy + yc) * g.opitch + g.ox + pcol] == g.oindex ? 1.0f : 0.0f;
+        }
         tile[row_pos(i)] = v;
     }
     __syncthreads();
@@ -86,46 +102,51 @@ __global__ __launch_bounds__(256) void blur_rows_kernel(
             acc[o] = __builtin_fmaf(wq[7 - o + 3], v.w, acc[o]);
         }
     }
-    if (y < h) {
+    if (y < g.vh) {
         const int x = xt + 8 * lane;
-        float *d = job.dst + (size_t)y * pitch + x;
-        if (x + 8 <= pitch) {
+        float *d = dst + (size_t)y * g.apitch + x;
+        if (x + 8 <= g.apitch) {
             *(float4 *)d = make_float4(acc[0], acc[1], acc[2], acc[3]);
             *(float4 *)(d + 4) = make_float4(acc[4], acc[5], acc[6], acc[7]);
         } else {
 #pragma unroll
             for (int o = 0; o < 8; ++o)
-                if (x + o < w) d[o] = acc[o];
+                if (x + o < g.aw) d[o] = acc[o];
         }
     }
 }
 
-struct ColJob {
-    const float *src;     // plane [h][pitch]
-    float *dst;           // plane [h][pitch]
-};
-struct ColJobs {
-    ColJob j[4];
+struct ColGeom {
+    int h;              // full patch height (reflection period)
+    int vy0, vh;        // rows held by the source: patch-local origin, count
+    int ay0, ah;        // output rows: patch-local origin, count
+    int aw, apitch;     // columns, pitch of source and destination
 };
 
-__global__ __launch_bounds__(256) void blur_cols_kernel(ColJobs jobs, int h,
-                                                        int w, int pitch,
+struct ColJobs {
+    const float *src[4];    // [vh][apitch]
+    float *dst[4];          // [ah][apitch]
+};
+
+__global__ __launch_bounds__(256) void blur_cols_kernel(ColJobs jobs, ColGeom g,
                                                         const float *wz_global,
                                                         int ntaps) {
     const kptr_f32 wz = (kptr_f32)(uintptr_t)wz_global;
     extern __shared__ __attribute__((aligned(16))) float s_col[];   // [rows][64]
-    const ColJob job = jobs.j[blockIdx.z];
+    const float *__restrict__ src = jobs.src[blockIdx.z];
+    float *__restrict__ dst = jobs.dst[blockIdx.z];
     const int tx = threadIdx.x, ty = threadIdx.y;           // 16 x 16
     const int R = ntaps >> 1;
-    const int x0 = blockIdx.x * COL_TW, y0 = blockIdx.y * COL_TH;
+    const int x0 = blockIdx.x * COL_TW, y0 = blockIdx.y * COL_TH;   // A-relative
     const int steps = ntaps + 7;
     const int rows = 8 * 15 + steps;                        // rows read by ty = 15
     const int x = x0 + 4 * tx;
 
     for (int r = ty; r < rows; r += 16) {
-        const int gy = reflect_101(y0 - R + r, h);
+        int vr = reflect_101(g.ay0 + y0 - R + r, g.h) - g.vy0;
+        vr = vr < 0 ? 0 : (vr >= g.vh ? g.vh - 1 : vr);     // inside by construction
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (x < pitch) v = *(const float4 *)(job.src + (size_t)gy * pitch + x);
+        if (x < g.apitch) v = *(const float4 *)(src + (size_t)vr * g.apitch + x);
         *(float4 *)(s_col + r * COL_TW + 4 * tx) = v;
     }
     __syncthreads();
@@ -148,39 +169,39 @@ __global__ __launch_bounds__(256) void blur_cols_kernel(ColJobs jobs, int h,
             acc[o].w = __builtin_fmaf(wgt, v.w, acc[o].w);
         }
     }
-    if (x < pitch) {
+    if (x < g.apitch) {
 #pragma unroll
         for (int o = 0; o < 8; ++o) {
             const int y = y0 + 8 * ty + o;
-            if (y < h) *(float4 *)(job.dst + (size_t)y * pitch + x) = acc[o];
+            if (y < g.ah) *(float4 *)(dst + (size_t)y * g.apitch + x) = acc[o];
         }
     }
 }
 
-static int launch_rows(const RowJobs &jobs, int njobs, int h, int w, int pitch,
-                       const float *wz, int ntaps, const int16_t *owner,
-                       int owner_pitch, int oy0, int ox0, int index,
-                       hipStream_t stream) {
-    dim3 block(64, 4), grid(ceil_div(w, ROW_TW), ceil_div(h, 4), njobs);
-    PANO_TIMED(PK_BLUR_ROWS, stream, hipLaunchKernelGGL(blur_rows_kernel, grid, block, 0, stream, jobs, h, w, pitch,
-                       wz, ntaps, owner, owner_pitch, oy0, ox0, index));
+static int launch_rows(const RowJobs &jobs, int njobs, const RowGeom &g, const float *wz,
+                       int ntaps, const int16_t *owner, hipStream_t stream) {
+    dim3 block(64, 4), grid(ceil_div(g.aw, ROW_TW), ceil_div(g.vh, 4), njobs);
+    PANO_TIMED(PK_BLUR_ROWS, stream,
+               hipLaunchKernelGGL(blur_rows_kernel, grid, block, 0, stream, jobs, g, wz,
+                                  ntaps, owner));
     PANO_LAUNCH_CHECK("blur_rows_kernel");
     return PANO_OK;
 }
 
-static int launch_cols(const ColJobs &jobs, int njobs, int h, int w, int pitch,
-                       const float *wz, int ntaps, hipStream_t stream) {
+static int launch_cols(const ColJobs &jobs, int njobs, const ColGeom &g, const float *wz,
+                       int ntaps, hipStream_t stream) {
     const int rows = 8 * 15 + ntaps + 7;
     const size_t lds = (size_t)rows * COL_TW * sizeof(float);
-    dim3 block(16, 16), grid(ceil_div(w, COL_TW), ceil_div(h, COL_TH), njobs);
+    dim3 block(16, 16), grid(ceil_div(g.aw, COL_TW), ceil_div(g.ah, COL_TH), njobs);
     static bool lds_opt_in = false;   // tiles above 64 KiB need the opt-in
     if (!lds_opt_in) {
         PANO_HIP(hipFuncSetAttribute((const void *)blur_cols_kernel,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         lds_opt_in = true;
     }
-    PANO_TIMED(PK_BLUR_COLS, stream, hipLaunchKernelGGL(blur_cols_kernel, grid, block, lds, stream, jobs, h, w, pitch,
-                       wz, ntaps));
+    PANO_TIMED(PK_BLUR_COLS, stream,
+               hipLaunchKernelGGL(blur_cols_kernel, grid, block, lds, stream, jobs, g, wz,
+                                  ntaps));
     PANO_LAUNCH_CHECK("blur_cols_kernel");
     return PANO_OK;
 }
@@ -199,15 +220,34 @@ extern "C" int pano_blur_plane(const float *src, float *dst, float *tmp, int h,
                  "pano_blur_plane: bad shape %dx%d pitch %d", h, w, pitch);
     if (int rc = check_taps(ntaps, "pano_blur_plane")) return rc;
     RowJobs rj = {};
-    rj.j[0].src = src;
-    rj.j[0].dst = tmp;
-    if (int rc = launch_rows(rj, 1, h, w, pitch, taps, ntaps, nullptr, 0, 0, 0, 0,
-                             (hipStream_t)stream))
-        return rc;
+    rj.src[0] = src;
+    rj.dst[0] = tmp;
+    RowGeom rg = {};
+    rg.w = w; rg.vx0 = 0; rg.vw = w; rg.vh = h; rg.vpitch = pitch;
+    rg.ax0 = 0; rg.aw = w; rg.apitch = pitch;
+    if (int rc = launch_rows(rj, 1, rg, taps, ntaps, nullptr, (hipStream_t)stream)) return rc;
     ColJobs cj = {};
-    cj.j[0].src = tmp;
-    cj.j[0].dst = dst;
-    return launch_cols(cj, 1, h, w, pitch, taps, ntaps, (hipStream_t)stream);
+    cj.src[0] = tmp;
+    cj.dst[0] = dst;
+    ColGeom cg = {};
+    cg.h = h; cg.vy0 = 0; cg.vh = h; cg.ay0 = 0; cg.ah = h; cg.aw = w; cg.apitch = pitch;
+    return launch_cols(cj, 1, cg, taps, ntaps, (hipStream_t)stream);
+}
+
+// Shared by blur.hip and blend.hip: structural checks of a patch record.
+int pano_check_patch(const pano_patch *p, const char *who) {
+    PANO_REQUIRE(p->h > 0 && p->w > 0, "%s: empty patch %dx%d", who, p->h, p->w);
+    PANO_REQUIRE(p->vy0 >= 0 && p->vx0 >= 0 && p->vh >= 0 && p->vw >= 0 &&
+                     p->vy0 + p->vh <= p->h && p->vx0 + p->vw <= p->w,
+                 "%s: window V outside the patch", who);
+    PANO_REQUIRE(p->ay0 >= p->vy0 && p->ax0 >= p->vx0 && p->ah >= 0 && p->aw >= 0 &&
+                     p->ay0 + p->ah <= p->vy0 + p->vh && p->ax0 + p->aw <= p->vx0 + p->vw,
+                 "%s: rectangle A outside window V", who);
+    PANO_REQUIRE(p->vpitch >= p->vw && (p->vpitch & 3) == 0 && p->apitch >= p->aw &&
+                     (p->apitch & 3) == 0,
+                 "%s: bad pitch (v %d for %d, a %d for %d)", who, p->vpitch, p->vw, p->apitch,
+                 p->aw);
+    return PANO_OK;
 }
 
 extern "C" int pano_multiband_blur(const pano_patch *patch, int index,
@@ -215,12 +255,23 @@ extern "C" int pano_multiband_blur(const pano_patch *patch, int index,
                                    const int *ntaps, int n_blur, float *scratch,
                                    void *stream) {
     PANO_REQUIRE(patch && owner && taps && ntaps && scratch, "pano_multiband_blur: null pointer");
-    PANO_REQUIRE(patch->planes && patch->blurred, "pano_multiband_blur: patch without planes/blurred");
     PANO_REQUIRE(n_blur >= 0 && n_blur < PANO_MAX_LEVELS, "pano_multiband_blur: %d blur levels", n_blur);
-    const int h = patch->h, w = patch->w, pitch = patch->pitch;
-    PANO_REQUIRE(h > 0 && w > 0 && pitch == pano_pitch_of(w) && W > 0,
-                 "pano_multiband_blur: bad patch shape %dx%d pitch %d", h, w, pitch);
-    const size_t plane = (size_t)h * pitch;
+    if (int rc = pano_check_patch(patch, "pano_multiband_blur")) return rc;
+    if (patch->ah == 0 || patch->aw == 0 || n_blur == 0) return PANO_OK;   // owns nothing
+    PANO_REQUIRE(patch->planes && patch->blurred, "pano_multiband_blur: patch without planes/blurred");
+    PANO_REQUIRE(W > 0, "pano_multiband_blur: bad mosaic width %d", W);
+
+    RowGeom rg = {};
+    rg.w = patch->w; rg.vx0 = patch->vx0; rg.vw = patch->vw; rg.vh = patch->vh;
+    rg.vpitch = patch->vpitch; rg.ax0 = patch->ax0; rg.aw = patch->aw; rg.apitch = patch->apitch;
+    rg.opitch = W; rg.oy = patch->y0 + patch->vy0; rg.ox = patch->x0; rg.oindex = index;
+    ColGeom cg = {};
+    cg.h = patch->h; cg.vy0 = patch->vy0; cg.vh = patch->vh; cg.ay0 = patch->ay0;
+    cg.ah = patch->ah; cg.aw = patch->aw; cg.apitch = patch->apitch;
+
+    const size_t vplane = (size_t)patch->vh * patch->vpitch;
+    const size_t splane = (size_t)patch->vh * patch->apitch;
+    const size_t aplane = (size_t)patch->ah * patch->apitch;
     size_t off = 0;
     for (int k = 0; k < n_blur; ++k) {
         if (int rc = check_taps(ntaps[k], "pano_multiband_blur")) return rc;
@@ -229,16 +280,13 @@ extern "C" int pano_multiband_blur(const pano_patch *patch, int index,
         RowJobs rj = {};
         ColJobs cj = {};
         for (int c = 0; c < 4; ++c) {
-            rj.j[c].src = c < 3 ? patch->planes + c * plane : nullptr;
-            rj.j[c].dst = scratch + c * plane;
-            cj.j[c].src = scratch + c * plane;
-            cj.j[c].dst = patch->blurred + ((size_t)k * 4 + c) * plane;
+            rj.src[c] = c < 3 ? patch->planes + c * vplane : nullptr;
+            rj.dst[c] = scratch + c * splane;
+            cj.src[c] = scratch + c * splane;
+            cj.dst[c] = patch->blurred + ((size_t)k * 4 + c) * aplane;
         }
-        if (int rc = launch_rows(rj, 4, h, w, pitch, wz, ntaps[k], owner, W, patch->y0,
-                                 patch->x0, index, (hipStream_t)stream))
-            return rc;
-        if (int rc = launch_cols(cj, 4, h, w, pitch, wz, ntaps[k], (hipStream_t)stream))
-            return rc;
+        if (int rc = launch_rows(rj, 4, rg, wz, ntaps[k], owner, (hipStream_t)stream)) return rc;
+        if (int rc = launch_cols(cj, 4, cg, wz, ntaps[k], (hipStream_t)stream)) return rc;
     }
     return PANO_OK;
 }
@@ -272,8 +320,9 @@ extern "C" int pano_pyr_down(const float *src, int h, int w, float *dst, void *s
     PANO_REQUIRE(h > 0 && w > 0, "pano_pyr_down: bad shape %dx%d", h, w);
     const int oh = (h + 1) / 2, ow = (w + 1) / 2;
     dim3 block(64, 4), grid(ceil_div(ow, 64), ceil_div(oh, 4));
-    PANO_TIMED(PK_PYR_DOWN, (hipStream_t)stream, hipLaunchKernelGGL(pyr_down_kernel, grid, block, 0, (hipStream_t)stream, src, h, w,
-                       dst, oh, ow));
+    PANO_TIMED(PK_PYR_DOWN, (hipStream_t)stream,
+               hipLaunchKernelGGL(pyr_down_kernel, grid, block, 0, (hipStream_t)stream, src,
+                                  h, w, dst, oh, ow));
     PANO_LAUNCH_CHECK("pyr_down_kernel");
     return PANO_OK;
 }

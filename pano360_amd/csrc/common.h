@@ -48,6 +48,8 @@ enum PanoKernelId {
     PK_CROP_HEIGHTS,
     PK_CROP_ROWS,
     PK_PYR_DOWN,
+    PK_OWNERSHIP_CAMS,
+    PK_OWNED_BOXES,
     PK_COUNT
 };
 extern bool g_pano_timing_on;

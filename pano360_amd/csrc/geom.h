@@ -1,0 +1,67 @@
+// Device-side geometry shared by the warp and ownership kernels: the inverse
+// map of stitcher.py:300-312, cv2.remap's fixed-point tap selection, and the
+// analytic alpha of _add_weights (stitcher.py:251-263).
+#pragma once
+#include "common.h"
+
+struct Taps {
+    int x0, x1, y0, y1;
+    float w00, w01, w10, w11;
+};
+
+// cv2.remap's coordinate handling (INTER_BITS = 5), see include/pano360.h.
+__device__ __forceinline__ Taps make_taps(float px, float py, int sw, int sh) {
+    int sx = cv_round(px * 32.0f), sy = cv_round(py * 32.0f);
+    int fx = sx & 31, fy = sy & 31;
+    int ix = sat16(sx >> 5), iy = sat16(sy >> 5);
+    Taps t;
+    t.x0 = reflect_edge(ix, sw);
+    t.x1 = reflect_edge(ix + 1, sw);
+    t.y0 = reflect_edge(iy, sh);
+    t.y1 = reflect_edge(iy + 1, sh);
+    float ax = (float)fx * (1.0f / 32.0f), ay = (float)fy * (1.0f / 32.0f);
+    t.w00 = (1.0f - ay) * (1.0f - ax);
+    t.w01 = (1.0f - ay) * ax;
+    t.w10 = ay * (1.0f - ax);
+    t.w11 = ay * ax;
+    return t;
+}
+
+// v00*w00 + v01*w01 + v10*w10 + v11*w11, left to right, one rounding per
+// operation (the library is built with -ffp-contract=off).
+__device__ __forceinline__ float lerp4(float v00, float v01, float v10, float v11,
+                                       const Taps &t) {
+    float a = v00 * t.w00;
+    a = a + v01 * t.w01;
+    a = a + v10 * t.w10;
+    a = a + v11 * t.w11;
+    return a;
+}
+
+// ray = (sin theta, tan phi, cos theta); pixel = K R ray in double as an FMA
+// chain over k, rounded to float32, divided and centred in float32 (:303-310);
+// mask = behind the camera or outside [0, w-1] x [0, h-1] (:308, :311-312).
+__device__ __forceinline__ bool map_pixel(const double *K, double s, double c, double t,
+                                          int sw, int sh, float &px, float &py) {
+    const double vx = fma(K[2], c, fma(K[1], t, K[0] * s));
+    const double vy = fma(K[5], c, fma(K[4], t, K[3] * s));
+    const double vz = fma(K[8], c, fma(K[7], t, K[6] * s));
+    const float fx = (float)vx, fy = (float)vy, fz = (float)vz;
+    const float cx = (float)((double)sw / 2.0), cy = (float)((double)sh / 2.0);
+    px = __fdiv_rn(fx, fz) + cx;
+    py = __fdiv_rn(fy, fz) + cy;
+    bool m = fz < 0.0f;
+    m |= (px < 0.0f) | (px > (float)(sw - 1)) | (py < 0.0f) | (py > (float)(sh - 1));
+    return m;
+}
+
+// Bilinear sample of the alpha plane _add_weights would have stored:
+// float32(hat_y[y] * hat_x[x]) with the product taken in double.
+__device__ __forceinline__ float alpha_at(const double *__restrict__ hat_x,
+                                          const double *__restrict__ hat_y,
+                                          const Taps &tp) {
+    const double hy0 = hat_y[tp.y0], hy1 = hat_y[tp.y1];
+    const double hx0 = hat_x[tp.x0], hx1 = hat_x[tp.x1];
+    return lerp4((float)(hy0 * hx0), (float)(hy0 * hx1), (float)(hy1 * hx0),
+                 (float)(hy1 * hx1), tp);
+}

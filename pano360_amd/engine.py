@@ -187,25 +187,93 @@ def _ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else None
 
 
-class DevicePatch:
-    """Device buffers of one warped patch + its ``pano_patch`` record."""
+def reflect_closed(lo, hi, n):
+    """Smallest [a, b) inside [0, n) that holds reflect_101(p, n) for every p in
+    [lo, hi) (cv2.BORDER_REFLECT_101: ... c b | a b c ... z | y x ...)."""
+    if n == 1:
+        return 0, 1
+    if lo < -(n - 1) or hi > 2 * n - 1:      # a second reflection could occur
+        return 0, n
+    a, b = max(lo, 0), min(hi, n)
+    if lo < 0:                               # p in [lo, 0) lands on [1, -lo]
+        a, b = min(a, 1), max(b, 1 - lo)
+    if hi > n:                               # p in [n, hi) lands on [2n-1-hi, n-2]
+        a, b = min(a, 2 * n - 1 - hi), max(b, n - 1)
+    return max(a, 0), min(b, n)
 
-    def __init__(self, rect, device, n_blur):
+
+def windows_for(box, rect, radius):
+    """Rectangles A and V of include/pano360.h ("Windows") for one patch.
+
+    box: (ymin, ymax, xmin, xmax) of the owned pixels, mosaic coordinates,
+    inclusive, empty when ymax < ymin.  Returns patch-local
+    ((ay0, ay1, ax0, ax1), (vy0, vy1, vx0, vx1)) or None for an empty box."""
+    ymin, ymax, xmin, xmax = box
+    if ymax < ymin or xmax < xmin:
+        return None
+    y0, y1, x0, x1 = rect
+    h, w = y1 - y0, x1 - x0
+    ay0, ay1 = max(ymin - y0 - radius, 0), min(ymax - y0 + 1 + radius, h)
+    ax0, ax1 = max(xmin - x0 - radius, 0), min(xmax - x0 + 1 + radius, w)
+    vy0, vy1 = reflect_closed(ay0 - radius, ay1 + radius, h)
+    vx0, vx1 = reflect_closed(ax0 - radius, ax1 + radius, w)
+    return (ay0, ay1, ax0, ax1), (min(vy0, ay0), max(vy1, ay1), min(vx0, ax0), max(vx1, ax1))
+
+
+class DevicePatch:
+    """Device buffers of one warped patch + its ``pano_patch`` record.
+
+    Stage-level form (default): four planes and a mask over the whole patch.
+    Fused form (``windows`` given): three colour planes over window V and the
+    blurred copies over rectangle A only; ``windows=None`` with ``empty=True``
+    is a patch that owns nothing and carries no buffers."""
+
+    def __init__(self, rect, device, n_blur, windows=None, empty=False):
         torch = _torch()
         y0, y1, x0, x1 = rect
         self.rect = rect
         self.h, self.w = y1 - y0, x1 - x0
-        self.pitch = (self.w + 3) & ~3
-        self.planes = torch.empty((4, self.h, self.pitch), dtype=torch.float32, device=device)
-        self.mask = torch.empty((self.h, self.w), dtype=torch.uint8, device=device)
-        self.blurred = (torch.empty((n_blur, 4, self.h, self.pitch), dtype=torch.float32,
-                                    device=device) if n_blur else None)
+        self.planes = self.mask = self.blurred = None
+        if empty:
+            self.area = self.window = (0, 0, 0, 0)
+            self.vpitch = self.apitch = 0
+            return
+        if windows is None:
+            self.area = self.window = (0, self.h, 0, self.w)
+            channels = 4
+            self.mask = torch.empty((self.h, self.w), dtype=torch.uint8, device=device)
+        else:
+            self.area, self.window = windows
+            channels = 3
+        vh, vw = self.window[1] - self.window[0], self.window[3] - self.window[2]
+        ah, aw = self.area[1] - self.area[0], self.area[3] - self.area[2]
+        self.vpitch, self.apitch = (vw + 3) & ~3, (aw + 3) & ~3
+        self.planes = torch.empty((channels, vh, self.vpitch), dtype=torch.float32,
+                                  device=device)
+        if n_blur:
+            self.blurred = torch.empty((n_blur, 4, ah, self.apitch), dtype=torch.float32,
+                                       device=device)
+
+    @property
+    def pitch(self):
+        return self.vpitch
 
     def record(self):
         y0, _, x0, _ = self.rect
-        return Patch(self.planes.data_ptr(), self.mask.data_ptr(),
+        ay0, ay1, ax0, ax1 = self.area
+        vy0, vy1, vx0, vx1 = self.window
+        return Patch(self.planes.data_ptr() if self.planes is not None else None,
+                     self.mask.data_ptr() if self.mask is not None else None,
                      self.blurred.data_ptr() if self.blurred is not None else None,
-                     y0, x0, self.h, self.w, self.pitch, 0)
+                     y0, x0, self.h, self.w,
+                     vy0, vx0, vy1 - vy0, vx1 - vx0,
+                     ay0, ax0, ay1 - ay0, ax1 - ax0,
+                     self.vpitch, self.apitch)
+
+    @property
+    def scratch_floats(self):
+        """Row-pass scratch: 4 channels x window rows x area pitch."""
+        return 4 * (self.window[1] - self.window[0]) * self.apitch
 
 
 def patch_table(patches, device):
@@ -313,11 +381,23 @@ class Engine:
         if table is None:
             table = patch_table(patches, self.device)
         owner, valid = self.ownership(table, n, shape)
+        mosaic, fl = self.blur_and_compose(patches, table, owner, valid, shape, n_levels,
+                                           want_float)
+        return mosaic, fl, owner, valid
+
+    def blur_and_compose(self, patches, table, owner, valid, shape, n_levels,
+                         want_float=False):
+        """Per-patch Gaussian levels on rectangle A, then the gather collapse."""
+        torch = _torch()
+        H, W = shape
+        n = len(patches)
         taps, ntaps, n_blur = self.blur_tables(n_levels)
         if n_blur:
-            biggest = max(p.h * p.pitch for p in patches)
-            scratch = torch.empty(4 * biggest, dtype=torch.float32, device=self.device)
+            biggest = max(max(p.scratch_floats for p in patches), 4)
+            scratch = torch.empty(biggest, dtype=torch.float32, device=self.device)
             for i, p in enumerate(patches):
+                if p.planes is None:
+                    continue                      # owns nothing: contributes exact zeros
                 rec = p.record()
                 _lib.check(self.lib.pano_multiband_blur(C.byref(rec), i, _ptr(owner), W,
                                                         _ptr(taps), ntaps, n_blur,
@@ -330,7 +410,86 @@ class Engine:
                                                    _ptr(owner), _ptr(valid), _ptr(mosaic),
                                                    _ptr(fl), self.stream()),
                    "pano_multiband_compose")
-        return mosaic, fl, owner, valid
+        return mosaic, fl
+
+    # -- fused path: ownership from the cameras, work only near owned pixels ----
+    def camera_table(self, plan):
+        torch = _torch()
+        recs = []
+        for i in range(plan.n):
+            sh, sw = plan.shapes[i]
+            hx, hy = self.hat_tables((sh, sw))
+            y0, y1, x0, x1 = plan.rects[i]
+            recs.append(_lib.Camera((C.c_double * 9)(*plan.projs[i].ravel()),
+                                    hx.data_ptr(), hy.data_ptr(), sh, sw,
+                                    y0, x0, y1 - y0, x1 - x0))
+        raw = b"".join(bytes(r) for r in recs)
+        return torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(self.device)
+
+    def ownership_cameras(self, plan, strip=None, out=None):
+        """owner / valid of the mosaic (or of the column strip [xs0, xs1)) from the
+        cameras alone (stitcher.py:196-204, 266-271 without any pixel data)."""
+        torch = _torch()
+        H, W = plan.shape
+        if out is None:
+            owner = torch.empty((H, W), dtype=torch.int16, device=self.device)
+            valid = torch.empty((H, W), dtype=torch.uint8, device=self.device)
+        else:
+            owner, valid = out
+        xs0, xs1 = strip if strip is not None else (0, W)
+        if not hasattr(plan, "cams"):
+            plan.cams = self.camera_table(plan)
+        _lib.check(self.lib.pano_ownership_cameras(
+            _ptr(plan.cams), plan.n, H, W, xs0, xs1, _ptr(plan.dev[0]), _ptr(plan.dev[1]),
+            _ptr(plan.dev[2]), _ptr(owner), _ptr(valid), self.stream()),
+            "pano_ownership_cameras")
+        return owner, valid
+
+    def owned_boxes(self, owner, n):
+        """Host array [n][4] = (ymin, ymax, xmin, xmax) of every patch's owned
+        pixels (one small device->host copy; the only sync of a stitch)."""
+        torch = _torch()
+        H, W = owner.shape
+        boxes = torch.empty((n, 4), dtype=torch.int32, device=self.device)
+        _lib.check(self.lib.pano_owned_boxes(_ptr(owner), H, W, n, _ptr(boxes), self.stream()),
+                   "pano_owned_boxes")
+        return boxes.cpu().numpy()
+
+    def warp_window(self, frame, plan, index, patch):
+        sh, sw = frame.shape[:2]
+        y0, _, x0, _ = plan.rects[index]
+        vy0, vy1, vx0, vx1 = patch.window
+        proj = plan.projs[index]
+        _lib.check(self.lib.pano_warp_window(
+            _ptr(frame), sh, sw, proj.ctypes.data_as(C.c_void_p), _ptr(plan.dev[0]),
+            _ptr(plan.dev[1]), _ptr(plan.dev[2]), _ptr(self.lut255), x0 + vx0, y0 + vy0,
+            vx1 - vx0, vy1 - vy0, _ptr(patch.planes), self.stream()), "pano_warp_window")
+
+    def multiband_fused(self, frames, plan, n_levels, want_float=False, frame_ids=None,
+                        owner_valid=None):
+        """The headline path.  ``frames[j]`` is the frame of camera
+        ``frame_ids[j]`` (default: all cameras in order)."""
+        if owner_valid is None:
+            owner_valid = self.ownership_cameras(plan)
+        owner, valid = owner_valid
+        boxes = self.owned_boxes(owner, plan.n)
+        _, ntaps, n_blur = self.blur_tables(n_levels)
+        radius = max([t // 2 for t in ntaps[:n_blur]], default=0)
+        ids = list(range(plan.n)) if frame_ids is None else list(frame_ids)
+        have = dict(zip(ids, frames))
+        patches = []
+        for i in range(plan.n):
+            win = windows_for(boxes[i], plan.rects[i], radius) if i in have else None
+            if win is None:
+                patches.append(DevicePatch(plan.rects[i], self.device, 0, empty=True))
+                continue
+            patch = DevicePatch(plan.rects[i], self.device, n_blur, windows=win)
+            self.warp_window(have[i], plan, i, patch)
+            patches.append(patch)
+        table = patch_table(patches, self.device)
+        mosaic, fl = self.blur_and_compose(patches, table, owner, valid, plan.shape, n_levels,
+                                           want_float)
+        return mosaic, fl, valid, patches
 
     def simple_blend(self, patches, shape, linear, table=None):
         torch = _torch()
@@ -389,10 +548,15 @@ class Engine:
             patches.append(patch)
         return patches, maps
 
-    def stitch(self, frames, plan, blend="multiband", n_levels=5, want_float=False):
-        """uint8 frames on device -> (mosaic u8 on device, float mosaic, valid)."""
+    def stitch(self, frames, plan, blend="multiband", n_levels=5, want_float=False,
+               fused=True):
+        """uint8 frames on device -> (mosaic u8 on device, float mosaic, valid,
+        patches).  ``fused=False`` runs multiband through whole-patch stage
+        buffers (what the blender protocol sees); both give the same mosaic."""
         if not hasattr(plan, "dev"):
             self.upload_plan(plan)
+        if blend == "multiband" and fused:
+            return self.multiband_fused(frames, plan, n_levels, want_float)
         n_blur = n_levels - 1 if blend == "multiband" else 0
         patches, _ = self.warp_all(frames, plan, n_blur)
         table = patch_table(patches, self.device)

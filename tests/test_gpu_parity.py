@@ -185,6 +185,74 @@ def test_ownership_bit_exact(eng, oracle):
     assert np.array_equal(valid.cpu().numpy().astype(bool), oracle.valid(ref_patches, plan.shape))
 
 
+@pytest.mark.parametrize("name", SCENES)
+def test_ownership_from_cameras_equals_ownership_from_planes(eng, name):
+    """pano_ownership_cameras (no pixel data) against pano_ownership (warped
+    alpha planes): integer maps, bit-exact."""
+    import torch
+    from pano360_amd import engine
+    g = load_golden(name)
+    imgs, rots, intrs, mr = scene_inputs(g)
+    plan = eng.upload_plan(engine.Plan([im.shape[:2] for im in imgs], rots, intrs, True, mr))
+    patches, _ = eng.warp_all(eng.upload_frames(imgs), plan)
+    owner_b, valid_b = eng.ownership(engine.patch_table(patches, eng.device), len(patches),
+                                     plan.shape)
+    owner_a, valid_a = eng.ownership_cameras(plan)
+    assert torch.equal(owner_a, owner_b) and torch.equal(valid_a, valid_b)
+    assert np.array_equal(valid_a.cpu().numpy().astype(bool), g["mb_valid"])
+    # column strips (the multi-GPU split) tile the same map
+    W = plan.shape[1]
+    out = (torch.full_like(owner_a, -7), torch.full_like(valid_a, 9))
+    for xs in ((0, W // 3), (W // 3, W // 3), (W // 3, W - 5), (W - 5, W)):
+        eng.ownership_cameras(plan, strip=xs, out=out)
+    assert torch.equal(out[0], owner_a) and torch.equal(out[1], valid_a)
+    boxes = eng.owned_boxes(owner_a, plan.n)
+    own = owner_a.cpu().numpy()
+    for i in range(plan.n):
+        ys, xs = np.nonzero(own == i)
+        if len(ys):
+            assert tuple(boxes[i]) == (ys.min(), ys.max(), xs.min(), xs.max())
+        else:
+            assert boxes[i][1] < boxes[i][0]
+
+
+@pytest.mark.parametrize("name", SCENES)
+@pytest.mark.parametrize("levels", [1, 2, 5, 6])
+def test_fused_windows_equal_whole_patch_path(eng, name, levels):
+    """Restricting warp/blur/gather to the windows near owned pixels changes
+    nothing: same uint8 and same float mosaic, bit for bit."""
+    import torch
+    from pano360_amd import engine
+    g = load_golden(name)
+    imgs, rots, intrs, mr = scene_inputs(g)
+    plan = engine.Plan([im.shape[:2] for im in imgs], rots, intrs, True, mr)
+    frames = eng.upload_frames(imgs)
+    m1, f1, v1, p1 = eng.stitch(frames, plan, "multiband", levels, want_float=True, fused=True)
+    m2, f2, v2, _ = eng.stitch(frames, plan, "multiband", levels, want_float=True, fused=False)
+    assert torch.equal(m1, m2) and torch.equal(v1, v2)
+    assert torch.equal(f1.view(torch.int32), f2.view(torch.int32))
+
+
+def test_fused_windows_on_a_wide_sweep(eng, oracle):
+    """Frames much wider than the blur radius, so the windows really cut work
+    (and the 64-column / 128-row tile seams fall inside them)."""
+    import torch
+    from pano360_amd import engine, synth
+    imgs, rots, intrs = synth.make_scene(6, 640, 360, sweep_deg=50.0, jitter=0.01, seed=31,
+                                         kind="B")
+    plan = engine.Plan([im.shape[:2] for im in imgs], rots, intrs, True, 10 ** 9)
+    frames = eng.upload_frames(imgs)
+    m1, f1, v1, patches = eng.stitch(frames, plan, "multiband", 5, want_float=True)
+    m2, f2, _, _ = eng.stitch(frames, plan, "multiband", 5, want_float=True, fused=False)
+    assert torch.equal(m1, m2) and torch.equal(f1.view(torch.int32), f2.view(torch.int32))
+    warped = sum((p.window[1] - p.window[0]) * (p.window[3] - p.window[2]) for p in patches)
+    assert warped < 0.7 * plan.patch_pixels          # the windows did skip work
+    ref_u8, ref_f = oracle.stitch(imgs, rots, intrs, "multiband", 5, max_resolution=10 ** 9,
+                                  return_float=True)
+    assert rel_l2(f1.cpu().numpy(), ref_f) <= REL_TOL
+    assert np.abs(m1.cpu().numpy().astype(int) - ref_u8.astype(int)).max() <= 1
+
+
 # ------------------------------------------------------------------- crop
 def test_crop_rectangles_bit_exact(eng, oracle):
     import torch

@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     handle.pano_version.restype = ctypes.c_char_p
     assert b"gfx950" in handle.pano_version()
     assert handle.pano_pitch(1941) == 1944
-    assert ctypes.sizeof(_lib.Patch) == 48
+    assert ctypes.sizeof(_lib.Patch) == 80 and ctypes.sizeof(_lib.Camera) == 112
 
 
 def test_header_constants_match_binding():
@@ -126,3 +126,41 @@ def test_product_fails_loudly_without_gpu():
     from pano360_amd import _lib, engine
     with pytest.raises(_lib.PanoError):
         engine.Engine()
+
+
+def _reflect_101(p, n):
+    if n == 1:
+        return 0
+    while not 0 <= p < n:
+        p = -p if p < 0 else 2 * (n - 1) - p
+    return p
+
+
+def test_reflect_closed_is_tight_and_safe():
+    """The window rule that lets the blur read only part of a patch: it must
+    hold every REFLECT_101 image of the requested range, and not be wasteful
+    when a single reflection suffices."""
+    from pano360_amd.engine import reflect_closed
+    for n in (1, 2, 3, 5, 17, 64):
+        for lo in range(-3 * n - 2, n + 2):
+            for hi in range(lo + 1, 3 * n + 3):
+                a, b = reflect_closed(lo, hi, n)
+                hit = {_reflect_101(p, n) for p in range(lo, hi)}
+                assert 0 <= a < b <= n
+                assert min(hit) >= a and max(hit) < b, (n, lo, hi, a, b)
+                if n > 1 and lo >= -(n - 1) and hi <= 2 * n - 1:
+                    assert (a, b) == (min(hit), max(hit) + 1), (n, lo, hi, a, b)
+
+
+def test_windows_for():
+    from pano360_amd.engine import windows_for
+    rect = (10, 110, 200, 500)                      # 100 x 300 patch
+    assert windows_for((5, 4, 0, 0), rect, 43) is None          # owns nothing
+    area, win = windows_for((10, 109, 300, 349), rect, 43)
+    assert area == (0, 100, 57, 193)
+    assert win == (0, 100, 14, 236)
+    area, win = windows_for((10, 109, 200, 230), rect, 43)      # touches the left edge
+    assert area == (0, 100, 0, 74) and win[2] == 0 and win[3] >= 74 + 43
+    # tiny patch: everything reflects several times -> whole patch
+    area, win = windows_for((0, 5, 0, 7), (0, 6, 0, 8), 43)
+    assert area == (0, 6, 0, 8) and win == (0, 6, 0, 8)
