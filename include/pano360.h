@@ -62,16 +62,19 @@ typedef struct pano_patch {
     float *planes;             /* [3 or 4][vh][vpitch] over window V        */
     uint8_t *mask;             /* [h][w], full patch; NULL in the fused path */
     float *blurred;            /* [n_levels-1][4][ah][apitch] over A; or NULL */
+    float *scratch;            /* [n_levels-1][4][vh][apitch] row-pass output */
     int32_t y0, x0, h, w;      /* patch rectangle in mosaic coordinates     */
     int32_t vy0, vx0, vh, vw;  /* window V, patch-local                     */
     int32_t ay0, ax0, ah, aw;  /* rectangle A, patch-local                  */
     int32_t vpitch, apitch;    /* floats per row of planes / blurred        */
 } pano_patch;
 
-/* One registered frame for the analytic ownership kernel (reference:
- * bundle_adj.Image, bundle_adj.py:18-33, plus its patch rectangle). */
+/* One registered frame (reference: bundle_adj.Image, bundle_adj.py:18-33,
+ * plus the patch rectangle stitch() derives for it). */
 typedef struct pano_camera {
     double proj[9];            /* K R, row-major (bundle_adj.py:31-33)      */
+    const uint8_t *frame;      /* dev uint8 [sh][sw][3]; may be NULL for the
+                                  ownership kernel, which reads no pixels   */
     const double *hat_x;       /* dev double[sw] = _hat(sw) (stitcher.py:251) */
     const double *hat_y;       /* dev double[sh]                            */
     int32_t sh, sw;            /* frame size                                */
@@ -117,14 +120,15 @@ int pano_warp_spherical(const uint8_t *frame, int sh, int sw,
                         float *planes, uint8_t *mask, float *map_x,
                         float *map_y, void *stream);
 
-/* Same arithmetic, colour only, restricted to a window: (gx0, gy0) is the
- * window origin in mosaic coordinates, vw x vh its size; writes planes
- * [3][vh][pitch].  Alpha and mask are not produced: the fused path gets them
- * from pano_ownership_cameras. */
-int pano_warp_window(const uint8_t *frame, int sh, int sw, const double *proj,
-                     const double *sin_t, const double *cos_t,
-                     const double *tan_p, const float *lut255, int gx0,
-                     int gy0, int vw, int vh, float *planes, void *stream);
+/* Same arithmetic, colour only, for window V of EVERY patch in one launch:
+ * cams[i].frame is warped into patches[i].planes ([3][vh][vpitch]).  Alpha and
+ * mask are not produced: the fused path gets them from
+ * pano_ownership_cameras.  cams, patches: dev arrays of n records;
+ * max_vw / max_vh: the largest window among them (sizes the grid). */
+int pano_warp_windows(const pano_camera *cams, const pano_patch *patches, int n,
+                      int max_vw, int max_vh, const double *sin_t,
+                      const double *cos_t, const double *tan_p,
+                      const float *lut255, void *stream);
 
 /* Ownership + validity from warped patches   stitcher.py:196-204, 266-271
  * owner = first-index argmax of the patches' alpha plane (planes[3]), -1 where
@@ -148,17 +152,21 @@ int pano_ownership_cameras(const pano_camera *cams, int n, int H, int W,
 int pano_owned_boxes(const int16_t *owner, int H, int W, int n, int32_t *boxes,
                      void *stream);
 
-/* The n_levels-1 Gaussian blurs of one patch   stitcher.py:207-208, 218, 226
+/* The n_levels-1 Gaussian blurs of every patch  stitcher.py:207-208, 218, 226
  * (cv2.GaussianBlur(warped, (0,0), 4*sqrt(2k+1)) with the alpha channel
- * replaced by the sharp mask owner == index), evaluated on rectangle A from
- * the colour planes over V.  patch: host struct.
- * taps: dev float, n_blur tables laid out back to back, table k has
- * ntaps[k] + PANO_TAP_PAD floats: PANO_TAP_LEAD zeros, the ntaps[k] taps,
- * zeros.  ntaps: host int[n_blur].  scratch: dev float [4][vh][apitch].
- * Writes patch->blurred. */
-int pano_multiband_blur(const pano_patch *patch, int index,
-                        const int16_t *owner, int W, const float *taps,
-                        const int *ntaps, int n_blur, float *scratch,
+ * replaced by the sharp mask owner == index), evaluated on rectangle A of each
+ * patch from its colour planes over V; n_blur + 1 launches in all (one row
+ * pass that serves every level from a single staged tile, one column pass per
+ * level).  patches: dev array of n records with planes, blurred and scratch
+ * set; max_aw / max_vh / max_ah: the largest extents among them.
+ * taps: dev float, n_blur tables laid out back to back; table k has
+ * ntaps[k] + PANO_TAP_PAD floats: PANO_TAP_LEAD + ((R - r_k) & 3) zeros, the
+ * ntaps[k] taps, zeros, where r_k = ntaps[k] / 2 and R = max r_k (the extra
+ * zeros keep the row pass's 16-byte LDS reads aligned for every level).
+ * ntaps: host int[n_blur].  Writes patches[i].blurred (and .scratch). */
+int pano_multiband_blur(const pano_patch *patches, int n, int max_aw,
+                        int max_vh, int max_ah, const int16_t *owner, int W,
+                        const float *taps, const int *ntaps, int n_blur,
                         void *stream);
 
 /* Band-pass build + collapse                     stitcher.py:210-241

@@ -25,9 +25,9 @@ class PanoError(RuntimeError):
 
 
 class Patch(C.Structure):
-    """``pano_patch`` of include/pano360.h (80 bytes)."""
+    """``pano_patch`` of include/pano360.h (88 bytes)."""
     _fields_ = [("planes", C.c_void_p), ("mask", C.c_void_p),
-                ("blurred", C.c_void_p),
+                ("blurred", C.c_void_p), ("scratch", C.c_void_p),
                 ("y0", C.c_int32), ("x0", C.c_int32), ("h", C.c_int32), ("w", C.c_int32),
                 ("vy0", C.c_int32), ("vx0", C.c_int32), ("vh", C.c_int32), ("vw", C.c_int32),
                 ("ay0", C.c_int32), ("ax0", C.c_int32), ("ah", C.c_int32), ("aw", C.c_int32),
@@ -35,8 +35,9 @@ class Patch(C.Structure):
 
 
 class Camera(C.Structure):
-    """``pano_camera`` of include/pano360.h (112 bytes)."""
-    _fields_ = [("proj", C.c_double * 9), ("hat_x", C.c_void_p), ("hat_y", C.c_void_p),
+    """``pano_camera`` of include/pano360.h (120 bytes)."""
+    _fields_ = [("proj", C.c_double * 9), ("frame", C.c_void_p),
+                ("hat_x", C.c_void_p), ("hat_y", C.c_void_p),
                 ("sh", C.c_int32), ("sw", C.c_int32),
                 ("y0", C.c_int32), ("x0", C.c_int32), ("h", C.c_int32), ("w", C.c_int32)]
 
@@ -54,12 +55,12 @@ _SIGNATURES = {
     "pano_add_weights": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "pano_warp_spherical": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                  _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
-    "pano_warp_window": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "pano_warp_windows": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "pano_ownership": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp]),
     "pano_ownership_cameras": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "pano_owned_boxes": (_i, [_vp, _i, _i, _i, _vp, _vp]),
-    "pano_multiband_blur": (_i, [C.POINTER(Patch), _i, _vp, _i, _vp,
-                                 C.POINTER(C.c_int), _i, _vp, _vp]),
+    "pano_multiband_blur": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _vp,
+                                 C.POINTER(C.c_int), _i, _vp]),
     "pano_multiband_compose": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "pano_linear_blend": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "pano_no_blend": (_i, [_vp, _i, _i, _i, _vp, _vp]),

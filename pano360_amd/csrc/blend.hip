@@ -16,8 +16,6 @@
 // arithmetic (about 120 instructions per covering camera).
 #include "geom.h"
 
-int pano_check_patch(const pano_patch *p, const char *who);   // blur.hip
-
 // ---- ownership from warped alpha planes (stage-level API) ---------------------
 __global__ __launch_bounds__(256) void ownership_kernel(
     const pano_patch *__restrict__ patches, int n, int H, int W,
@@ -77,8 +75,14 @@ __global__ __launch_bounds__(256) void ownership_cameras_kernel(
     valid[(size_t)y * W + x] = any ? 1 : 0;
 }
 
-// Bounding boxes of the owned regions.  Only the ends of each horizontal run of
-// equal owners touch the atomics (a few runs per row), so contention is nil.
+// Bounding boxes of the owned regions.  Same-address atomics serialise in L2,
+// so only "corner" pixels issue them: a pixel whose left AND upper neighbours
+// belong to someone else can be the first row / first column of its region, one
+// whose left and lower neighbours differ the last row, one whose right and upper
+// neighbours differ the last column.  Every extreme of a region is attained at
+// such a pixel (the topmost pixel of the leftmost column has a foreign left and
+// upper neighbour, and so on), and a region bounded by near-vertical seams has
+// only a handful of them.
 __global__ __launch_bounds__(256) void owned_boxes_kernel(const int16_t *__restrict__ owner,
                                                           int H, int W,
                                                           int32_t *__restrict__ boxes) {
@@ -87,12 +91,17 @@ __global__ __launch_bounds__(256) void owned_boxes_kernel(const int16_t *__restr
     const int16_t *row = owner + (size_t)y * W;
     const int o = row[x];
     if (o < 0) return;
-    if (x == 0 || row[x - 1] != o) {
+    const bool left = x == 0 || row[x - 1] != o;
+    const bool right = x == W - 1 || row[x + 1] != o;
+    if (!left && !right) return;
+    const bool up = y == 0 || row[x - W] != o;
+    const bool down = y == H - 1 || row[x + W] != o;
+    if (left && up) {
         atomicMin(&boxes[4 * o + 0], y);
-        atomicMax(&boxes[4 * o + 1], y);
         atomicMin(&boxes[4 * o + 2], x);
     }
-    if (x == W - 1 || row[x + 1] != o) atomicMax(&boxes[4 * o + 3], x);
+    if (left && down) atomicMax(&boxes[4 * o + 1], y);
+    if (right && up) atomicMax(&boxes[4 * o + 3], x);
 }
 
 __global__ void init_boxes_kernel(int32_t *boxes, int n) {

@@ -10,17 +10,22 @@
 // from HBM inside a tile.
 //
 //   row pass : wave = one image row, lane = 8 consecutive outputs; the row
-//              segment (512 + 2R px) is staged in LDS with 4 pad floats per 8
-//              so the lanes' 32-B-strided b128 reads hit 16 distinct slots.
+//              segment (512 + 2R px) is staged in LDS ONCE, with 4 pad floats
+//              per 8 so the lanes' 32-B-strided b128 reads hit 16 distinct
+//              slots, and every blur level is computed from that one tile.
 //   col pass : 16x16 threads, thread = 4 adjacent columns x 8 rows; the
-//              (128 + 2R) x 64 tile is staged in LDS, a b128 read gives one
+//              (128 + 2r) x 64 tile is staged in LDS, a b128 read gives one
 //              input row for 4 columns and feeds the 8 row-outputs above it.
+//              One launch per level so the tile is sized to that level.
 //
-// Taps come as a zero-padded table wz: PANO_TAP_LEAD zeros, the taps, zeros;
-// the weight of input p for output o (both relative to the thread's first
-// input / output) is wz[p - o + 7], which is 0 outside the aperture, so the
-// inner loops need no edge cases.  Sums run in ascending tap order with one
-// FMA per tap.
+// Every launch covers ALL patches (blockIdx.z = patch x channel): a stitch is
+// a dozen launches with tens of thousands of workgroups each, not hundreds of
+// small ones.
+//
+// Taps come as a zero-padded table wz (layout in include/pano360.h): the
+// weight of input p for output o (both relative to the thread's first input /
+// output) is wz[p - o + 7], which is 0 outside the aperture, so the inner
+// loops need no edge cases.  Sums run in ascending tap order, one FMA per tap.
 //
 // Windows (include/pano360.h): the passes only produce rectangle A of a patch.
 // The row pass reads the colour planes over window V and writes rows V x
@@ -37,116 +42,117 @@
 #define COL_TW 64
 #define COL_TH 128
 
-struct RowGeom {
-    int w;              // full patch width (reflection period)
-    int vx0, vw, vh;    // window V: x origin (patch-local), width, rows
-    int vpitch;         // source plane pitch
-    int ax0, aw;        // output columns: patch-local origin, count
-    int apitch;         // destination pitch
-    // sharp-alpha source: owner[(oy + row) * opitch + ox + patch_col] == oindex
-    int opitch, oy, ox, oindex;
+struct LevelDesc {
+    const float *wz;     // row-pass table: 7 + extra leading zeros
+    int ntaps;           // true aperture
+    int start;           // row pass: first tile entry of lane 0 = (R - r) - extra
+    int steps;           // row pass: 4-input steps = ceil((ntaps + extra + 7) / 4)
 };
 
-struct RowJobs {
-    const float *src[4];    // plane over V; NULL -> sharp alpha from the owner map
-    float *dst[4];          // [vh][apitch]
+struct Levels {
+    LevelDesc lv[PANO_MAX_LEVELS];
+    int n;               // number of blur levels
+    int rmax;            // largest radius: halo of the staged row tile
+    int need;            // tile entries the row pass reads (lane 63, widest level)
 };
 
 __device__ __forceinline__ int row_pos(int i) { return i + ((i >> 3) << 2); }
 
+// nch = channels per patch (4: R,G,B + sharp alpha from the owner map; 1: a
+// plain plane); alpha_ch = channel whose source is the owner map, or -1.
+template <bool TABLE>
 __global__ __launch_bounds__(256) void blur_rows_kernel(
-    RowJobs jobs, RowGeom g, const float *wz_global, int ntaps,
-    const int16_t *__restrict__ owner) {
-    const kptr_f32 wz = (kptr_f32)(uintptr_t)wz_global;
+    const pano_patch *__restrict__ table, pano_patch single, int nch, int alpha_ch,
+    Levels L, const int16_t *__restrict__ owner, int W) {
     __shared__ __attribute__((aligned(16))) float s_row[4][ROW_LDS];
-    const float *__restrict__ src = jobs.src[blockIdx.z];
-    float *__restrict__ dst = jobs.dst[blockIdx.z];
-    const int lane = threadIdx.x, wv = threadIdx.y;
-    const int R = ntaps >> 1;
+    const int pid = blockIdx.z / nch, c = blockIdx.z - pid * nch;
+    const pano_patch p = TABLE ? table[pid] : single;
     const int xt = blockIdx.x * ROW_TW;          // first output column, A-relative
-    const int y = blockIdx.y * 4 + wv;
-    const int yc = y < g.vh ? y : g.vh - 1;
-    float *tile = s_row[wv];
+    if (xt >= p.aw || (int)blockIdx.y * 4 >= p.vh) return;   // uniform per block
 
-    const int steps = (ntaps + 7 + 3) >> 2;      // 4 inputs per step
-    const int need = 8 * 63 + 4 * steps;         // tile entries read by lane 63
-    for (int i = lane; i < need; i += 64) {
-        const int pcol = reflect_101(g.ax0 + xt - R + i, g.w);
+    const int lane = threadIdx.x, wv = threadIdx.y;
+    const int y = blockIdx.y * 4 + wv;
+    const int yc = y < p.vh ? y : p.vh - 1;
+    float *tile = s_row[wv];
+    const float *__restrict__ src =
+        c == alpha_ch ? nullptr : p.planes + (size_t)c * p.vh * p.vpitch;
+    const int16_t *__restrict__ orow =
+        owner + (size_t)(p.y0 + p.vy0 + yc) * W + p.x0;      // sharp-alpha source row
+
+    for (int i = lane; i < L.need; i += 64) {
+        const int pcol = reflect_101(p.ax0 + xt - L.rmax + i, p.w);
         float v;
         if (src) {
-            int vc = pcol - g.vx0;               // inside V by construction; clamp anyway
-            vc = vc < 0 ? 0 : (vc >= g.vw ? g.vw - 1 : vc);
-            v = src[(size_t)yc * g.vpitch + vc];
+            int vc = pcol - p.vx0;               // inside V by construction; clamp anyway
+            vc = vc < 0 ? 0 : (vc >= p.vw ? p.vw - 1 : vc);
+            v = src[(size_t)yc * p.vpitch + vc];
         } else {
-            v = owner[(size_t)(g.oy + yc) * g.opitch + g.ox + pcol] == g.oindex ? 1.0f : 0.0f;
+            v = orow[pcol] == pid ? 1.0f : 0.0f;             // stitcher.py:208
         }
         tile[row_pos(i)] = v;
     }
     __syncthreads();
 
-    float acc[8];
+    const float *base = tile + 12 * lane;        // row_pos(8 * lane)
+    const int x = xt + 8 * lane;
+    for (int k = 0; k < L.n; ++k) {
+        const kptr_f32 wz = (kptr_f32)(uintptr_t)L.lv[k].wz;
+        const int start = L.lv[k].start, steps = L.lv[k].steps;
+        float acc[8];
 #pragma unroll
-    for (int o = 0; o < 8; ++o) acc[o] = 0.0f;
-    const float *base = tile + 12 * lane;        // row_pos(8*lane)
-    for (int s = 0; s < steps; ++s) {
-        const int p = 4 * s;
-        const float4 v = *(const float4 *)(base + p + ((p >> 3) << 2));
-        float wq[11];
+        for (int o = 0; o < 8; ++o) acc[o] = 0.0f;
+        for (int s = 0; s < steps; ++s) {
+            const int q = start + 4 * s;
+            const float4 v = *(const float4 *)(base + q + ((q >> 3) << 2));
+            float wq[11];
 #pragma unroll
-        for (int k = 0; k < 11; ++k) wq[k] = wz[p + k];
+            for (int j = 0; j < 11; ++j) wq[j] = wz[4 * s + j];
 #pragma unroll
-        for (int o = 0; o < 8; ++o) {
-            acc[o] = __builtin_fmaf(wq[7 - o + 0], v.x, acc[o]);
-            acc[o] = __builtin_fmaf(wq[7 - o + 1], v.y, acc[o]);
-            acc[o] = __builtin_fmaf(wq[7 - o + 2], v.z, acc[o]);
-            acc[o] = __builtin_fmaf(wq[7 - o + 3], v.w, acc[o]);
+            for (int o = 0; o < 8; ++o) {
+                acc[o] = __builtin_fmaf(wq[7 - o + 0], v.x, acc[o]);
+                acc[o] = __builtin_fmaf(wq[7 - o + 1], v.y, acc[o]);
+                acc[o] = __builtin_fmaf(wq[7 - o + 2], v.z, acc[o]);
+                acc[o] = __builtin_fmaf(wq[7 - o + 3], v.w, acc[o]);
+            }
         }
-    }
-    if (y < g.vh) {
-        const int x = xt + 8 * lane;
-        float *d = dst + (size_t)y * g.apitch + x;
-        if (x + 8 <= g.apitch) {
-            *(float4 *)d = make_float4(acc[0], acc[1], acc[2], acc[3]);
-            *(float4 *)(d + 4) = make_float4(acc[4], acc[5], acc[6], acc[7]);
-        } else {
+        if (y < p.vh) {
+            float *d = p.scratch + ((size_t)(k * nch + c) * p.vh + y) * p.apitch + x;
+            if (x + 8 <= p.apitch) {
+                *(float4 *)d = make_float4(acc[0], acc[1], acc[2], acc[3]);
+                *(float4 *)(d + 4) = make_float4(acc[4], acc[5], acc[6], acc[7]);
+            } else {
 #pragma unroll
-            for (int o = 0; o < 8; ++o)
-                if (x + o < g.aw) d[o] = acc[o];
+                for (int o = 0; o < 8; ++o)
+                    if (x + o < p.aw) d[o] = acc[o];
+            }
         }
     }
 }
 
-struct ColGeom {
-    int h;              // full patch height (reflection period)
-    int vy0, vh;        // rows held by the source: patch-local origin, count
-    int ay0, ah;        // output rows: patch-local origin, count
-    int aw, apitch;     // columns, pitch of source and destination
-};
-
-struct ColJobs {
-    const float *src[4];    // [vh][apitch]
-    float *dst[4];          // [ah][apitch]
-};
-
-__global__ __launch_bounds__(256) void blur_cols_kernel(ColJobs jobs, ColGeom g,
-                                                        const float *wz_global,
-                                                        int ntaps) {
+template <bool TABLE>
+__global__ __launch_bounds__(256) void blur_cols_kernel(
+    const pano_patch *__restrict__ table, pano_patch single, int nch, int level,
+    const float *wz_global, int ntaps) {
     const kptr_f32 wz = (kptr_f32)(uintptr_t)wz_global;
     extern __shared__ __attribute__((aligned(16))) float s_col[];   // [rows][64]
-    const float *__restrict__ src = jobs.src[blockIdx.z];
-    float *__restrict__ dst = jobs.dst[blockIdx.z];
+    const int pid = blockIdx.z / nch, c = blockIdx.z - pid * nch;
+    const pano_patch p = TABLE ? table[pid] : single;
+    const int x0 = blockIdx.x * COL_TW, y0 = blockIdx.y * COL_TH;   // A-relative
+    if (x0 >= p.aw || y0 >= p.ah) return;                           // uniform per block
+
+    const float *__restrict__ src = p.scratch + (size_t)(level * nch + c) * p.vh * p.apitch;
+    float *__restrict__ dst = p.blurred + (size_t)(level * nch + c) * p.ah * p.apitch;
     const int tx = threadIdx.x, ty = threadIdx.y;           // 16 x 16
     const int R = ntaps >> 1;
-    const int x0 = blockIdx.x * COL_TW, y0 = blockIdx.y * COL_TH;   // A-relative
     const int steps = ntaps + 7;
     const int rows = 8 * 15 + steps;                        // rows read by ty = 15
     const int x = x0 + 4 * tx;
 
     for (int r = ty; r < rows; r += 16) {
-        int vr = reflect_101(g.ay0 + y0 - R + r, g.h) - g.vy0;
-        vr = vr < 0 ? 0 : (vr >= g.vh ? g.vh - 1 : vr);     // inside by construction
+        int vr = reflect_101(p.ay0 + y0 - R + r, p.h) - p.vy0;
+        vr = vr < 0 ? 0 : (vr >= p.vh ? p.vh - 1 : vr);     // inside by construction
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (x < g.apitch) v = *(const float4 *)(src + (size_t)vr * g.apitch + x);
+        if (x < p.apitch) v = *(const float4 *)(src + (size_t)vr * p.apitch + x);
         *(float4 *)(s_col + r * COL_TW + 4 * tx) = v;
     }
     __syncthreads();
@@ -155,11 +161,11 @@ __global__ __launch_bounds__(256) void blur_cols_kernel(ColJobs jobs, ColGeom g,
 #pragma unroll
     for (int o = 0; o < 8; ++o) acc[o] = make_float4(0.f, 0.f, 0.f, 0.f);
     const float *base = s_col + (8 * ty) * COL_TW + 4 * tx;
-    for (int p = 0; p < steps; ++p) {
-        const float4 v = *(const float4 *)(base + p * COL_TW);
+    for (int q = 0; q < steps; ++q) {
+        const float4 v = *(const float4 *)(base + q * COL_TW);
         float wq[8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) wq[k] = wz[p + k];
+        for (int j = 0; j < 8; ++j) wq[j] = wz[q + j];
 #pragma unroll
         for (int o = 0; o < 8; ++o) {
             const float wgt = wq[7 - o];
@@ -169,46 +175,89 @@ __global__ __launch_bounds__(256) void blur_cols_kernel(ColJobs jobs, ColGeom g,
             acc[o].w = __builtin_fmaf(wgt, v.w, acc[o].w);
         }
     }
-    if (x < g.apitch) {
+    if (x < p.apitch) {
 #pragma unroll
         for (int o = 0; o < 8; ++o) {
             const int y = y0 + 8 * ty + o;
-            if (y < g.ah) *(float4 *)(dst + (size_t)y * g.apitch + x) = acc[o];
+            if (y < p.ah) *(float4 *)(dst + (size_t)y * p.apitch + x) = acc[o];
         }
     }
-}
-
-static int launch_rows(const RowJobs &jobs, int njobs, const RowGeom &g, const float *wz,
-                       int ntaps, const int16_t *owner, hipStream_t stream) {
-    dim3 block(64, 4), grid(ceil_div(g.aw, ROW_TW), ceil_div(g.vh, 4), njobs);
-    PANO_TIMED(PK_BLUR_ROWS, stream,
-               hipLaunchKernelGGL(blur_rows_kernel, grid, block, 0, stream, jobs, g, wz,
-                                  ntaps, owner));
-    PANO_LAUNCH_CHECK("blur_rows_kernel");
-    return PANO_OK;
-}
-
-static int launch_cols(const ColJobs &jobs, int njobs, const ColGeom &g, const float *wz,
-                       int ntaps, hipStream_t stream) {
-    const int rows = 8 * 15 + ntaps + 7;
-    const size_t lds = (size_t)rows * COL_TW * sizeof(float);
-    dim3 block(16, 16), grid(ceil_div(g.aw, COL_TW), ceil_div(g.ah, COL_TH), njobs);
-    static bool lds_opt_in = false;   // tiles above 64 KiB need the opt-in
-    if (!lds_opt_in) {
-        PANO_HIP(hipFuncSetAttribute((const void *)blur_cols_kernel,
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        lds_opt_in = true;
-    }
-    PANO_TIMED(PK_BLUR_COLS, stream,
-               hipLaunchKernelGGL(blur_cols_kernel, grid, block, lds, stream, jobs, g, wz,
-                                  ntaps));
-    PANO_LAUNCH_CHECK("blur_cols_kernel");
-    return PANO_OK;
 }
 
 static int check_taps(int ntaps, const char *who) {
     PANO_REQUIRE(ntaps >= 1 && (ntaps & 1) && ntaps <= PANO_MAX_TAPS,
                  "%s: aperture %d must be odd and within [1, %d]", who, ntaps, PANO_MAX_TAPS);
+    return PANO_OK;
+}
+
+// Level descriptors from the caller's tap tables (layout: include/pano360.h).
+static int make_levels(const float *taps, const int *ntaps, int n_blur, Levels *L,
+                       const float **col_wz, const char *who) {
+    PANO_REQUIRE(n_blur >= 1 && n_blur < PANO_MAX_LEVELS, "%s: %d blur levels", who, n_blur);
+    L->n = n_blur;
+    L->rmax = 0;
+    for (int k = 0; k < n_blur; ++k) {
+        if (int rc = check_taps(ntaps[k], who)) return rc;
+        if (ntaps[k] / 2 > L->rmax) L->rmax = ntaps[k] / 2;
+    }
+    L->need = 0;
+    size_t off = 0;
+    for (int k = 0; k < n_blur; ++k) {
+        const int delta = L->rmax - ntaps[k] / 2, extra = delta & 3;
+        L->lv[k].wz = taps + off;
+        L->lv[k].ntaps = ntaps[k];
+        L->lv[k].start = delta - extra;
+        L->lv[k].steps = (ntaps[k] + extra + 7 + 3) >> 2;
+        col_wz[k] = taps + off + extra;          // 7 leading zeros for the column pass
+        const int need = 8 * 63 + L->lv[k].start + 4 * L->lv[k].steps;
+        if (need > L->need) L->need = need;
+        off += (size_t)ntaps[k] + PANO_TAP_PAD;
+    }
+    PANO_REQUIRE(L->need <= ROW_TILE, "%s: row tile %d exceeds %d", who, L->need, ROW_TILE);
+    return PANO_OK;
+}
+
+static int launch_blur(const pano_patch *table, const pano_patch &single, int n, int nch,
+                       int alpha_ch, int max_aw, int max_vh, int max_ah,
+                       const int16_t *owner, int W, const float *taps, const int *ntaps,
+                       int n_blur, hipStream_t stream, const char *who) {
+    Levels L = {};
+    const float *col_wz[PANO_MAX_LEVELS];
+    if (int rc = make_levels(taps, ntaps, n_blur, &L, col_wz, who)) return rc;
+    static bool lds_opt_in = false;   // column tiles above 64 KiB need the opt-in
+    if (!lds_opt_in) {
+        PANO_HIP(hipFuncSetAttribute((const void *)blur_cols_kernel<true>,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        PANO_HIP(hipFuncSetAttribute((const void *)blur_cols_kernel<false>,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        lds_opt_in = true;
+    }
+    {
+        dim3 block(64, 4), grid(ceil_div(max_aw, ROW_TW), ceil_div(max_vh, 4), n * nch);
+        if (table)
+            PANO_TIMED(PK_BLUR_ROWS, stream,
+                       hipLaunchKernelGGL(blur_rows_kernel<true>, grid, block, 0, stream, table,
+                                          single, nch, alpha_ch, L, owner, W));
+        else
+            PANO_TIMED(PK_BLUR_ROWS, stream,
+                       hipLaunchKernelGGL(blur_rows_kernel<false>, grid, block, 0, stream, table,
+                                          single, nch, alpha_ch, L, owner, W));
+        PANO_LAUNCH_CHECK("blur_rows_kernel");
+    }
+    for (int k = 0; k < n_blur; ++k) {
+        const int rows = 8 * 15 + ntaps[k] + 7;
+        const size_t lds = (size_t)rows * COL_TW * sizeof(float);
+        dim3 block(16, 16), grid(ceil_div(max_aw, COL_TW), ceil_div(max_ah, COL_TH), n * nch);
+        if (table)
+            PANO_TIMED(PK_BLUR_COLS, stream,
+                       hipLaunchKernelGGL(blur_cols_kernel<true>, grid, block, lds, stream,
+                                          table, single, nch, k, col_wz[k], ntaps[k]));
+        else
+            PANO_TIMED(PK_BLUR_COLS, stream,
+                       hipLaunchKernelGGL(blur_cols_kernel<false>, grid, block, lds, stream,
+                                          table, single, nch, k, col_wz[k], ntaps[k]));
+        PANO_LAUNCH_CHECK("blur_cols_kernel");
+    }
     return PANO_OK;
 }
 
@@ -218,77 +267,28 @@ extern "C" int pano_blur_plane(const float *src, float *dst, float *tmp, int h,
     PANO_REQUIRE(src && dst && tmp && taps, "pano_blur_plane: null pointer");
     PANO_REQUIRE(h > 0 && w > 0 && pitch >= w && (pitch & 3) == 0,
                  "pano_blur_plane: bad shape %dx%d pitch %d", h, w, pitch);
-    if (int rc = check_taps(ntaps, "pano_blur_plane")) return rc;
-    RowJobs rj = {};
-    rj.src[0] = src;
-    rj.dst[0] = tmp;
-    RowGeom rg = {};
-    rg.w = w; rg.vx0 = 0; rg.vw = w; rg.vh = h; rg.vpitch = pitch;
-    rg.ax0 = 0; rg.aw = w; rg.apitch = pitch;
-    if (int rc = launch_rows(rj, 1, rg, taps, ntaps, nullptr, (hipStream_t)stream)) return rc;
-    ColJobs cj = {};
-    cj.src[0] = tmp;
-    cj.dst[0] = dst;
-    ColGeom cg = {};
-    cg.h = h; cg.vy0 = 0; cg.vh = h; cg.ay0 = 0; cg.ah = h; cg.aw = w; cg.apitch = pitch;
-    return launch_cols(cj, 1, cg, taps, ntaps, (hipStream_t)stream);
+    pano_patch p = {};
+    p.planes = const_cast<float *>(src);
+    p.scratch = tmp;
+    p.blurred = dst;
+    p.h = p.vh = p.ah = h;
+    p.w = p.vw = p.aw = w;
+    p.vpitch = p.apitch = pitch;
+    return launch_blur(nullptr, p, 1, 1, -1, w, h, h, nullptr, 0, taps, &ntaps, 1,
+                       (hipStream_t)stream, "pano_blur_plane");
 }
 
-// Shared by blur.hip and blend.hip: structural checks of a patch record.
-int pano_check_patch(const pano_patch *p, const char *who) {
-    PANO_REQUIRE(p->h > 0 && p->w > 0, "%s: empty patch %dx%d", who, p->h, p->w);
-    PANO_REQUIRE(p->vy0 >= 0 && p->vx0 >= 0 && p->vh >= 0 && p->vw >= 0 &&
-                     p->vy0 + p->vh <= p->h && p->vx0 + p->vw <= p->w,
-                 "%s: window V outside the patch", who);
-    PANO_REQUIRE(p->ay0 >= p->vy0 && p->ax0 >= p->vx0 && p->ah >= 0 && p->aw >= 0 &&
-                     p->ay0 + p->ah <= p->vy0 + p->vh && p->ax0 + p->aw <= p->vx0 + p->vw,
-                 "%s: rectangle A outside window V", who);
-    PANO_REQUIRE(p->vpitch >= p->vw && (p->vpitch & 3) == 0 && p->apitch >= p->aw &&
-                     (p->apitch & 3) == 0,
-                 "%s: bad pitch (v %d for %d, a %d for %d)", who, p->vpitch, p->vw, p->apitch,
-                 p->aw);
-    return PANO_OK;
-}
-
-extern "C" int pano_multiband_blur(const pano_patch *patch, int index,
-                                   const int16_t *owner, int W, const float *taps,
-                                   const int *ntaps, int n_blur, float *scratch,
+extern "C" int pano_multiband_blur(const pano_patch *patches, int n, int max_aw,
+                                   int max_vh, int max_ah, const int16_t *owner, int W,
+                                   const float *taps, const int *ntaps, int n_blur,
                                    void *stream) {
-    PANO_REQUIRE(patch && owner && taps && ntaps && scratch, "pano_multiband_blur: null pointer");
-    PANO_REQUIRE(n_blur >= 0 && n_blur < PANO_MAX_LEVELS, "pano_multiband_blur: %d blur levels", n_blur);
-    if (int rc = pano_check_patch(patch, "pano_multiband_blur")) return rc;
-    if (patch->ah == 0 || patch->aw == 0 || n_blur == 0) return PANO_OK;   // owns nothing
-    PANO_REQUIRE(patch->planes && patch->blurred, "pano_multiband_blur: patch without planes/blurred");
-    PANO_REQUIRE(W > 0, "pano_multiband_blur: bad mosaic width %d", W);
-
-    RowGeom rg = {};
-    rg.w = patch->w; rg.vx0 = patch->vx0; rg.vw = patch->vw; rg.vh = patch->vh;
-    rg.vpitch = patch->vpitch; rg.ax0 = patch->ax0; rg.aw = patch->aw; rg.apitch = patch->apitch;
-    rg.opitch = W; rg.oy = patch->y0 + patch->vy0; rg.ox = patch->x0; rg.oindex = index;
-    ColGeom cg = {};
-    cg.h = patch->h; cg.vy0 = patch->vy0; cg.vh = patch->vh; cg.ay0 = patch->ay0;
-    cg.ah = patch->ah; cg.aw = patch->aw; cg.apitch = patch->apitch;
-
-    const size_t vplane = (size_t)patch->vh * patch->vpitch;
-    const size_t splane = (size_t)patch->vh * patch->apitch;
-    const size_t aplane = (size_t)patch->ah * patch->apitch;
-    size_t off = 0;
-    for (int k = 0; k < n_blur; ++k) {
-        if (int rc = check_taps(ntaps[k], "pano_multiband_blur")) return rc;
-        const float *wz = taps + off;
-        off += (size_t)ntaps[k] + PANO_TAP_PAD;
-        RowJobs rj = {};
-        ColJobs cj = {};
-        for (int c = 0; c < 4; ++c) {
-            rj.src[c] = c < 3 ? patch->planes + c * vplane : nullptr;
-            rj.dst[c] = scratch + c * splane;
-            cj.src[c] = scratch + c * splane;
-            cj.dst[c] = patch->blurred + ((size_t)k * 4 + c) * aplane;
-        }
-        if (int rc = launch_rows(rj, 4, rg, wz, ntaps[k], owner, (hipStream_t)stream)) return rc;
-        if (int rc = launch_cols(cj, 4, cg, wz, ntaps[k], (hipStream_t)stream)) return rc;
-    }
-    return PANO_OK;
+    PANO_REQUIRE(patches && owner && taps && ntaps, "pano_multiband_blur: null pointer");
+    PANO_REQUIRE(n >= 0 && n <= 32767 && W > 0, "pano_multiband_blur: bad argument");
+    PANO_REQUIRE(max_aw >= 0 && max_vh >= 0 && max_ah >= 0, "pano_multiband_blur: bad extents");
+    if (n == 0 || n_blur == 0 || max_aw == 0 || max_vh == 0 || max_ah == 0) return PANO_OK;
+    pano_patch none = {};
+    return launch_blur(patches, none, n, 4, 3, max_aw, max_vh, max_ah, owner, W, taps, ntaps,
+                       n_blur, (hipStream_t)stream, "pano_multiband_blur");
 }
 
 // ---- cv2.pyrDown -----------------------------------------------------------

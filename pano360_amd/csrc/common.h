@@ -50,6 +50,7 @@ enum PanoKernelId {
     PK_PYR_DOWN,
     PK_OWNERSHIP_CAMS,
     PK_OWNED_BOXES,
+    PK_WARP_WINDOWS,
     PK_COUNT
 };
 extern bool g_pano_timing_on;

@@ -62,6 +62,39 @@ __global__ __launch_bounds__(256) void warp_spherical_kernel(
     }
 }
 
+// Colour planes of window V of every patch in one launch (blockIdx.z = patch).
+__global__ __launch_bounds__(256) void warp_windows_kernel(
+    const pano_camera *__restrict__ cams, const pano_patch *__restrict__ patches,
+    const double *__restrict__ sin_t, const double *__restrict__ cos_t,
+    const double *__restrict__ tan_p, const float *__restrict__ lut255) {
+    __shared__ float s_lut[256];
+    const pano_patch p = patches[blockIdx.z];
+    if ((int)blockIdx.x * 64 >= p.vw || (int)blockIdx.y * 4 >= p.vh) return;   // uniform
+    s_lut[threadIdx.y * 64 + threadIdx.x] = lut255[threadIdx.y * 64 + threadIdx.x];
+    __syncthreads();
+
+    const int x = blockIdx.x * 64 + threadIdx.x;
+    const int y = blockIdx.y * 4 + threadIdx.y;
+    if (x >= p.vw || y >= p.vh) return;
+    const pano_camera *cam = cams + blockIdx.z;
+    const int sw = cam->sw, sh = cam->sh;
+    const int gx = p.x0 + p.vx0 + x, gy = p.y0 + p.vy0 + y;
+    float px, py;
+    map_pixel(cam->proj, sin_t[gx], cos_t[gx], tan_p[gy], sw, sh, px, py);
+    const Taps tp = make_taps(px, py, sw, sh);
+    const uint8_t *__restrict__ frame = cam->frame;
+    const uint8_t *r0 = frame + (size_t)tp.y0 * sw * 3;
+    const uint8_t *r1 = frame + (size_t)tp.y1 * sw * 3;
+    const uint8_t *p00 = r0 + tp.x0 * 3, *p01 = r0 + tp.x1 * 3;
+    const uint8_t *p10 = r1 + tp.x0 * 3, *p11 = r1 + tp.x1 * 3;
+    const size_t plane = (size_t)p.vh * p.vpitch;
+    const size_t o = (size_t)y * p.vpitch + x;
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+        p.planes[k * plane + o] =
+            lerp4(s_lut[p00[k]], s_lut[p01[k]], s_lut[p10[k]], s_lut[p11[k]], tp);
+}
+
 __global__ __launch_bounds__(256) void add_weights_kernel(
     const uint8_t *__restrict__ frame, int h, int w,
     const float *__restrict__ lut255, const double *__restrict__ hat_x,
@@ -124,22 +157,19 @@ extern "C" int pano_warp_spherical(const uint8_t *frame, int sh, int sw,
     return PANO_OK;
 }
 
-extern "C" int pano_warp_window(const uint8_t *frame, int sh, int sw, const double *proj,
-                                const double *sin_t, const double *cos_t,
-                                const double *tan_p, const float *lut255, int gx0,
-                                int gy0, int vw, int vh, float *planes, void *stream) {
-    PANO_REQUIRE(frame && proj && sin_t && cos_t && tan_p && lut255 && planes,
-                 "pano_warp_window: null pointer");
-    if (int rc = check_frame("pano_warp_window", sh, sw, vw, vh, gx0, gy0)) return rc;
-    ProjK K;
-    for (int i = 0; i < 9; ++i) K.p[i] = proj[i];
-    dim3 block(64, 4), grid(ceil_div(vw, 64), ceil_div(vh, 4));
-    PANO_TIMED(PK_WARP, (hipStream_t)stream,
-               hipLaunchKernelGGL(warp_spherical_kernel<false>, grid, block, 0,
-                                  (hipStream_t)stream, frame, sh, sw, K, sin_t, cos_t, tan_p,
-                                  lut255, (const double *)nullptr, (const double *)nullptr,
-                                  gx0, gy0, vw, vh, pano_pitch_of(vw), planes,
-                                  (uint8_t *)nullptr, (float *)nullptr, (float *)nullptr));
-    PANO_LAUNCH_CHECK("warp_spherical_kernel");
+extern "C" int pano_warp_windows(const pano_camera *cams, const pano_patch *patches, int n,
+                                 int max_vw, int max_vh, const double *sin_t,
+                                 const double *cos_t, const double *tan_p,
+                                 const float *lut255, void *stream) {
+    PANO_REQUIRE(cams && patches && sin_t && cos_t && tan_p && lut255,
+                 "pano_warp_windows: null pointer");
+    PANO_REQUIRE(n >= 0 && n <= 65535 && max_vw >= 0 && max_vh >= 0,
+                 "pano_warp_windows: bad argument");
+    if (n == 0 || max_vw == 0 || max_vh == 0) return PANO_OK;
+    dim3 block(64, 4), grid(ceil_div(max_vw, 64), ceil_div(max_vh, 4), n);
+    PANO_TIMED(PK_WARP_WINDOWS, (hipStream_t)stream,
+               hipLaunchKernelGGL(warp_windows_kernel, grid, block, 0, (hipStream_t)stream,
+                                  cams, patches, sin_t, cos_t, tan_p, lut255));
+    PANO_LAUNCH_CHECK("warp_windows_kernel");
     return PANO_OK;
 }

@@ -126,10 +126,12 @@ def gaussian_taps(ksize, sigma):
     return (raw.astype(np.float64) * (1.0 / total)).astype(np.float32)
 
 
-def padded_taps(taps):
-    """Tap table layout of include/pano360.h: TAP_LEAD zeros, taps, zeros."""
+def padded_taps(taps, extra=0):
+    """Tap table layout of include/pano360.h: TAP_LEAD + extra zeros, taps, zeros
+    (extra = (R - r) & 3 when several levels share one staged row tile)."""
     out = np.zeros(len(taps) + _lib.TAP_PAD, np.float32)
-    out[_lib.TAP_LEAD:_lib.TAP_LEAD + len(taps)] = taps
+    lead = _lib.TAP_LEAD + extra
+    out[lead:lead + len(taps)] = taps
     return out
 
 
@@ -187,6 +189,22 @@ def _ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else None
 
 
+# numpy mirrors of the C records (include/pano360.h), for building tables in bulk
+PATCH_DTYPE = np.dtype([(k, "<u8") for k in ("planes", "mask", "blurred", "scratch")]
+                       + [(k, "<i4") for k in ("y0", "x0", "h", "w", "vy0", "vx0", "vh", "vw",
+                                               "ay0", "ax0", "ah", "aw", "vpitch", "apitch")])
+CAMERA_DTYPE = np.dtype([("proj", "<f8", (9,)), ("frame", "<u8"), ("hat_x", "<u8"),
+                         ("hat_y", "<u8")]
+                        + [(k, "<i4") for k in ("sh", "sw", "y0", "x0", "h", "w")])
+assert PATCH_DTYPE.itemsize == C.sizeof(Patch) == 88
+assert CAMERA_DTYPE.itemsize == C.sizeof(_lib.Camera) == 120
+
+
+def _to_device(array, device):
+    torch = _torch()
+    return torch.from_numpy(np.ascontiguousarray(array).view(np.uint8).reshape(-1)).to(device)
+
+
 def reflect_closed(lo, hi, n):
     """Smallest [a, b) inside [0, n) that holds reflect_101(p, n) for every p in
     [lo, hi) (cv2.BORDER_REFLECT_101: ... c b | a b c ... z | y x ...)."""
@@ -208,7 +226,7 @@ def windows_for(box, rect, radius):
     box: (ymin, ymax, xmin, xmax) of the owned pixels, mosaic coordinates,
     inclusive, empty when ymax < ymin.  Returns patch-local
     ((ay0, ay1, ax0, ax1), (vy0, vy1, vx0, vx1)) or None for an empty box."""
-    ymin, ymax, xmin, xmax = box
+    ymin, ymax, xmin, xmax = (int(v) for v in box)
     if ymax < ymin or xmax < xmin:
         return None
     y0, y1, x0, x1 = rect
@@ -221,67 +239,108 @@ def windows_for(box, rect, radius):
 
 
 class DevicePatch:
-    """Device buffers of one warped patch + its ``pano_patch`` record.
+    """Stage-level patch: four planes and a mask over the whole patch, as the
+    blender protocol hands them over (V = A = the patch)."""
 
-    Stage-level form (default): four planes and a mask over the whole patch.
-    Fused form (``windows`` given): three colour planes over window V and the
-    blurred copies over rectangle A only; ``windows=None`` with ``empty=True``
-    is a patch that owns nothing and carries no buffers."""
-
-    def __init__(self, rect, device, n_blur, windows=None, empty=False):
+    def __init__(self, rect, device, n_blur):
         torch = _torch()
         y0, y1, x0, x1 = rect
         self.rect = rect
         self.h, self.w = y1 - y0, x1 - x0
-        self.planes = self.mask = self.blurred = None
-        if empty:
-            self.area = self.window = (0, 0, 0, 0)
-            self.vpitch = self.apitch = 0
-            return
-        if windows is None:
-            self.area = self.window = (0, self.h, 0, self.w)
-            channels = 4
-            self.mask = torch.empty((self.h, self.w), dtype=torch.uint8, device=device)
-        else:
-            self.area, self.window = windows
-            channels = 3
-        vh, vw = self.window[1] - self.window[0], self.window[3] - self.window[2]
-        ah, aw = self.area[1] - self.area[0], self.area[3] - self.area[2]
-        self.vpitch, self.apitch = (vw + 3) & ~3, (aw + 3) & ~3
-        self.planes = torch.empty((channels, vh, self.vpitch), dtype=torch.float32,
-                                  device=device)
-        if n_blur:
-            self.blurred = torch.empty((n_blur, 4, ah, self.apitch), dtype=torch.float32,
-                                       device=device)
-
-    @property
-    def pitch(self):
-        return self.vpitch
+        self.area = self.window = (0, self.h, 0, self.w)
+        self.pitch = (self.w + 3) & ~3
+        f32 = dict(dtype=torch.float32, device=device)
+        self.planes = torch.empty((4, self.h, self.pitch), **f32)
+        self.mask = torch.empty((self.h, self.w), dtype=torch.uint8, device=device)
+        self.blurred = torch.empty((n_blur, 4, self.h, self.pitch), **f32) if n_blur else None
+        self.scratch = torch.empty((n_blur, 4, self.h, self.pitch), **f32) if n_blur else None
 
     def record(self):
         y0, _, x0, _ = self.rect
-        ay0, ay1, ax0, ax1 = self.area
-        vy0, vy1, vx0, vx1 = self.window
-        return Patch(self.planes.data_ptr() if self.planes is not None else None,
-                     self.mask.data_ptr() if self.mask is not None else None,
-                     self.blurred.data_ptr() if self.blurred is not None else None,
-                     y0, x0, self.h, self.w,
-                     vy0, vx0, vy1 - vy0, vx1 - vx0,
-                     ay0, ax0, ay1 - ay0, ax1 - ax0,
-                     self.vpitch, self.apitch)
+        opt = lambda t: t.data_ptr() if t is not None else 0   # noqa: E731
+        return (self.planes.data_ptr(), self.mask.data_ptr(), opt(self.blurred),
+                opt(self.scratch), y0, x0, self.h, self.w, 0, 0, self.h, self.w,
+                0, 0, self.h, self.w, self.pitch, self.pitch)
+
+
+class PatchTable:
+    """Device array of ``pano_patch`` records + the extents that size the grids."""
+
+    def __init__(self, records, device):
+        self.host = np.array(records, dtype=PATCH_DTYPE).reshape(-1)
+        self.n = len(self.host)
+        self.dev = _to_device(self.host, device)
+        mx = lambda k: int(self.host[k].max()) if self.n else 0   # noqa: E731
+        self.max_vw, self.max_vh, self.max_aw, self.max_ah = (mx("vw"), mx("vh"), mx("aw"),
+                                                              mx("ah"))
 
     @property
-    def scratch_floats(self):
-        """Row-pass scratch: 4 channels x window rows x area pitch."""
-        return 4 * (self.window[1] - self.window[0]) * self.apitch
+    def ptr(self):
+        return _ptr(self.dev)
 
 
 def patch_table(patches, device):
-    """Pack ``pano_patch`` records and copy them to the device."""
-    torch = _torch()
-    raw = b"".join(bytes(p.record()) for p in patches)
-    host = torch.frombuffer(bytearray(raw), dtype=torch.uint8)
-    return host.to(device)
+    """``pano_patch`` table of stage-level patches."""
+    return PatchTable([p.record() for p in patches], device)
+
+
+class WindowInfo:
+    """What callers may want to know about one fused patch."""
+
+    def __init__(self, area, window):
+        self.area, self.window = area, window
+
+
+class FusedPatches:
+    """Windows of every patch packed into three arenas (colour planes over V,
+    blurred copies over A, row-pass scratch) + the patch table pointing into
+    them.  ``windows[i]`` is ``windows_for`` output or None."""
+
+    def __init__(self, rects, windows, device, n_blur):
+        torch = _torch()
+        n = len(rects)
+        rec = np.zeros(n, dtype=PATCH_DTYPE)
+        self.info = []
+        for i, (rect, win) in enumerate(zip(rects, windows)):
+            y0, y1, x0, x1 = rect
+            rec[i]["y0"], rec[i]["x0"], rec[i]["h"], rec[i]["w"] = y0, x0, y1 - y0, x1 - x0
+            if win is None:
+                self.info.append(WindowInfo((0, 0, 0, 0), (0, 0, 0, 0)))
+                continue
+            (ay0, ay1, ax0, ax1), (vy0, vy1, vx0, vx1) = win
+            rec[i]["vy0"], rec[i]["vx0"], rec[i]["vh"], rec[i]["vw"] = vy0, vx0, vy1 - vy0, vx1 - vx0
+            rec[i]["ay0"], rec[i]["ax0"], rec[i]["ah"], rec[i]["aw"] = ay0, ax0, ay1 - ay0, ax1 - ax0
+            self.info.append(WindowInfo(win[0], win[1]))
+        rec["vpitch"] = (rec["vw"] + 3) & ~3
+        rec["apitch"] = (rec["aw"] + 3) & ~3
+        vh, ah = rec["vh"].astype(np.int64), rec["ah"].astype(np.int64)
+        planes_sz = 3 * vh * rec["vpitch"]
+        blurred_sz = n_blur * 4 * ah * rec["apitch"]
+        scratch_sz = n_blur * 4 * vh * rec["apitch"]
+        f32 = dict(dtype=torch.float32, device=device)
+        self.planes = torch.empty(max(int(planes_sz.sum()), 4), **f32)
+        self.blurred = torch.empty(max(int(blurred_sz.sum()), 4), **f32)
+        self.scratch = torch.empty(max(int(scratch_sz.sum()), 4), **f32)
+        for key, sizes, arena in (("planes", planes_sz, self.planes),
+                                  ("blurred", blurred_sz, self.blurred),
+                                  ("scratch", scratch_sz, self.scratch)):
+            offs = np.concatenate([[0], np.cumsum(sizes)[:-1]])
+            rec[key] = arena.data_ptr() + 4 * offs
+        self.table = PatchTable(rec, device)
+
+    def __iter__(self):
+        return iter(self.info)
+
+    def __len__(self):
+        return len(self.info)
+
+    @property
+    def warped_pixels(self):
+        return int((self.table.host["vh"].astype(np.int64) * self.table.host["vw"]).sum())
+
+    @property
+    def blurred_pixels(self):
+        return int((self.table.host["ah"].astype(np.int64) * self.table.host["aw"]).sum())
 
 
 class Engine:
@@ -312,15 +371,17 @@ class Engine:
         return self._hats[shape]
 
     def blur_tables(self, n_levels):
-        """Padded tap tables of the n_levels-1 blurs, back to back on device."""
+        """(taps on device, ntaps C array, n_blur, largest radius) of the
+        n_levels-1 blurs; tables back to back, padded as include/pano360.h says."""
         torch = _torch()
         if n_levels not in self._taps:
             sig = level_sigmas(n_levels)
             sizes = [gaussian_ksize(s) for s in sig]
-            flat = np.concatenate([padded_taps(gaussian_taps(k, s))
+            rmax = max([k // 2 for k in sizes], default=0)
+            flat = np.concatenate([padded_taps(gaussian_taps(k, s), (rmax - k // 2) & 3)
                                    for k, s in zip(sizes, sig)]) if sig else np.zeros(1, np.float32)
             self._taps[n_levels] = (torch.from_numpy(flat).to(self.device),
-                                    (C.c_int * max(len(sizes), 1))(*sizes), len(sizes))
+                                    (C.c_int * max(len(sizes), 1))(*sizes), len(sizes), rmax)
         return self._taps[n_levels]
 
     def upload_frames(self, imgs):
@@ -334,7 +395,7 @@ class Engine:
                          for t in (plan.sin_t, plan.cos_t, plan.tan_p))
         return plan
 
-    # -- stages ---------------------------------------------------------------
+    # -- stage-level calls (whole patches, the blender protocol) ------------------
     def add_weights(self, frame):
         """_add_weights on device: uint8 [H,W,3] -> float32 [H,W,4]."""
         torch = _torch()
@@ -363,70 +424,76 @@ class Engine:
             _ptr(my), self.stream()), "pano_warp_spherical")
         return mx, my
 
-    def ownership(self, table, n, shape):
+    def warp_all(self, frames, plan, n_blur=0, want_maps=False):
+        patches, maps = [], []
+        for i, frame in enumerate(frames):
+            patch = DevicePatch(plan.rects[i], self.device, n_blur)
+            maps.append(self.warp(frame, plan, i, patch, want_maps))
+            patches.append(patch)
+        return patches, maps
+
+    def ownership(self, table, shape):
         torch = _torch()
         H, W = shape
         owner = torch.empty((H, W), dtype=torch.int16, device=self.device)
         valid = torch.empty((H, W), dtype=torch.uint8, device=self.device)
-        _lib.check(self.lib.pano_ownership(_ptr(table), n, H, W, _ptr(owner), _ptr(valid),
+        _lib.check(self.lib.pano_ownership(table.ptr, table.n, H, W, _ptr(owner), _ptr(valid),
                                            self.stream()), "pano_ownership")
         return owner, valid
 
     def multiband(self, patches, shape, n_levels, want_float=False, table=None):
-        """Ownership -> per-patch blurs -> collapse.  Returns
-        (mosaic u8, float mosaic or None, owner, valid)."""
-        torch = _torch()
-        H, W = shape
-        n = len(patches)
+        """Stage-level multiband: ownership from the alpha planes -> blurs ->
+        collapse.  Returns (mosaic u8, float mosaic or None, owner, valid)."""
         if table is None:
             table = patch_table(patches, self.device)
-        owner, valid = self.ownership(table, n, shape)
-        mosaic, fl = self.blur_and_compose(patches, table, owner, valid, shape, n_levels,
-                                           want_float)
+        owner, valid = self.ownership(table, shape)
+        mosaic, fl = self.blur_and_compose(table, owner, valid, shape, n_levels, want_float)
         return mosaic, fl, owner, valid
 
-    def blur_and_compose(self, patches, table, owner, valid, shape, n_levels,
-                         want_float=False):
-        """Per-patch Gaussian levels on rectangle A, then the gather collapse."""
+    def blur_and_compose(self, table, owner, valid, shape, n_levels, want_float=False):
+        """All Gaussian levels of all patches (n_levels launches), then the gather."""
         torch = _torch()
         H, W = shape
-        n = len(patches)
-        taps, ntaps, n_blur = self.blur_tables(n_levels)
+        taps, ntaps, n_blur, _ = self.blur_tables(n_levels)
         if n_blur:
-            biggest = max(max(p.scratch_floats for p in patches), 4)
-            scratch = torch.empty(biggest, dtype=torch.float32, device=self.device)
-            for i, p in enumerate(patches):
-                if p.planes is None:
-                    continue                      # owns nothing: contributes exact zeros
-                rec = p.record()
-                _lib.check(self.lib.pano_multiband_blur(C.byref(rec), i, _ptr(owner), W,
-                                                        _ptr(taps), ntaps, n_blur,
-                                                        _ptr(scratch), self.stream()),
-                           "pano_multiband_blur")
+            _lib.check(self.lib.pano_multiband_blur(
+                table.ptr, table.n, table.max_aw, table.max_vh, table.max_ah, _ptr(owner), W,
+                _ptr(taps), ntaps, n_blur, self.stream()), "pano_multiband_blur")
         mosaic = torch.empty((H, W, 3), dtype=torch.uint8, device=self.device)
         fl = (torch.empty((H, W, 3), dtype=torch.float32, device=self.device)
               if want_float else None)
-        _lib.check(self.lib.pano_multiband_compose(_ptr(table), n, H, W, n_levels,
+        _lib.check(self.lib.pano_multiband_compose(table.ptr, table.n, H, W, n_levels,
                                                    _ptr(owner), _ptr(valid), _ptr(mosaic),
                                                    _ptr(fl), self.stream()),
                    "pano_multiband_compose")
         return mosaic, fl
 
-    # -- fused path: ownership from the cameras, work only near owned pixels ----
-    def camera_table(self, plan):
+    def simple_blend(self, patches, shape, linear, table=None):
         torch = _torch()
-        recs = []
+        H, W = shape
+        if table is None:
+            table = patch_table(patches, self.device)
+        mosaic = torch.empty((H, W, 3), dtype=torch.uint8, device=self.device)
+        fn = self.lib.pano_linear_blend if linear else self.lib.pano_no_blend
+        _lib.check(fn(table.ptr, table.n, H, W, _ptr(mosaic), self.stream()),
+                   "pano_linear_blend" if linear else "pano_no_blend")
+        return mosaic
+
+    # -- fused path: ownership from the cameras, work only near owned pixels ----
+    def camera_table(self, plan, frames=None):
+        """Device array of ``pano_camera``; ``frames`` maps camera index -> frame
+        tensor (cameras without a frame get a NULL pointer)."""
+        rec = np.zeros(plan.n, dtype=CAMERA_DTYPE)
         for i in range(plan.n):
             sh, sw = plan.shapes[i]
             hx, hy = self.hat_tables((sh, sw))
             y0, y1, x0, x1 = plan.rects[i]
-            recs.append(_lib.Camera((C.c_double * 9)(*plan.projs[i].ravel()),
-                                    hx.data_ptr(), hy.data_ptr(), sh, sw,
-                                    y0, x0, y1 - y0, x1 - x0))
-        raw = b"".join(bytes(r) for r in recs)
-        return torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(self.device)
+            frame = frames.get(i) if frames else None
+            rec[i] = (plan.projs[i].ravel(), frame.data_ptr() if frame is not None else 0,
+                      hx.data_ptr(), hy.data_ptr(), sh, sw, y0, x0, y1 - y0, x1 - x0)
+        return _to_device(rec, self.device)
 
-    def ownership_cameras(self, plan, strip=None, out=None):
+    def ownership_cameras(self, plan, strip=None, out=None, cams=None):
         """owner / valid of the mosaic (or of the column strip [xs0, xs1)) from the
         cameras alone (stitcher.py:196-204, 266-271 without any pixel data)."""
         torch = _torch()
@@ -437,10 +504,10 @@ class Engine:
         else:
             owner, valid = out
         xs0, xs1 = strip if strip is not None else (0, W)
-        if not hasattr(plan, "cams"):
-            plan.cams = self.camera_table(plan)
+        if cams is None:
+            cams = self.camera_table(plan)
         _lib.check(self.lib.pano_ownership_cameras(
-            _ptr(plan.cams), plan.n, H, W, xs0, xs1, _ptr(plan.dev[0]), _ptr(plan.dev[1]),
+            _ptr(cams), plan.n, H, W, xs0, xs1, _ptr(plan.dev[0]), _ptr(plan.dev[1]),
             _ptr(plan.dev[2]), _ptr(owner), _ptr(valid), self.stream()),
             "pano_ownership_cameras")
         return owner, valid
@@ -455,53 +522,31 @@ class Engine:
                    "pano_owned_boxes")
         return boxes.cpu().numpy()
 
-    def warp_window(self, frame, plan, index, patch):
-        sh, sw = frame.shape[:2]
-        y0, _, x0, _ = plan.rects[index]
-        vy0, vy1, vx0, vx1 = patch.window
-        proj = plan.projs[index]
-        _lib.check(self.lib.pano_warp_window(
-            _ptr(frame), sh, sw, proj.ctypes.data_as(C.c_void_p), _ptr(plan.dev[0]),
-            _ptr(plan.dev[1]), _ptr(plan.dev[2]), _ptr(self.lut255), x0 + vx0, y0 + vy0,
-            vx1 - vx0, vy1 - vy0, _ptr(patch.planes), self.stream()), "pano_warp_window")
-
     def multiband_fused(self, frames, plan, n_levels, want_float=False, frame_ids=None,
                         owner_valid=None):
         """The headline path.  ``frames[j]`` is the frame of camera
         ``frame_ids[j]`` (default: all cameras in order)."""
-        if owner_valid is None:
-            owner_valid = self.ownership_cameras(plan)
-        owner, valid = owner_valid
-        boxes = self.owned_boxes(owner, plan.n)
-        _, ntaps, n_blur = self.blur_tables(n_levels)
-        radius = max([t // 2 for t in ntaps[:n_blur]], default=0)
         ids = list(range(plan.n)) if frame_ids is None else list(frame_ids)
         have = dict(zip(ids, frames))
-        patches = []
-        for i in range(plan.n):
-            win = windows_for(boxes[i], plan.rects[i], radius) if i in have else None
-            if win is None:
-                patches.append(DevicePatch(plan.rects[i], self.device, 0, empty=True))
-                continue
-            patch = DevicePatch(plan.rects[i], self.device, n_blur, windows=win)
-            self.warp_window(have[i], plan, i, patch)
-            patches.append(patch)
-        table = patch_table(patches, self.device)
-        mosaic, fl = self.blur_and_compose(patches, table, owner, valid, plan.shape, n_levels,
+        cams = self.camera_table(plan, have)
+        if owner_valid is None:
+            owner_valid = self.ownership_cameras(plan, cams=cams)
+        owner, valid = owner_valid
+        boxes = self.owned_boxes(owner, plan.n)
+        taps, ntaps, n_blur, radius = self.blur_tables(n_levels)
+        windows = [windows_for(boxes[i], plan.rects[i], radius) if i in have else None
+                   for i in range(plan.n)]
+        patches = FusedPatches(plan.rects, windows, self.device, n_blur)
+        table = patches.table
+        _lib.check(self.lib.pano_warp_windows(
+            _ptr(cams), table.ptr, table.n, table.max_vw, table.max_vh, _ptr(plan.dev[0]),
+            _ptr(plan.dev[1]), _ptr(plan.dev[2]), _ptr(self.lut255), self.stream()),
+            "pano_warp_windows")
+        mosaic, fl = self.blur_and_compose(table, owner, valid, plan.shape, n_levels,
                                            want_float)
         return mosaic, fl, valid, patches
 
-    def simple_blend(self, patches, shape, linear, table=None):
-        torch = _torch()
-        H, W = shape
-        if table is None:
-            table = patch_table(patches, self.device)
-        mosaic = torch.empty((H, W, 3), dtype=torch.uint8, device=self.device)
-        fn = self.lib.pano_linear_blend if linear else self.lib.pano_no_blend
-        _lib.check(fn(_ptr(table), len(patches), H, W, _ptr(mosaic), self.stream()),
-                   "pano_linear_blend" if linear else "pano_no_blend")
-        return mosaic
-
+    # -- crop and filters -------------------------------------------------------------
     def crop_rect(self, valid):
         """Rectangle (y0, x0, h, w) of crop_mosaic, or None when nothing is valid."""
         torch = _torch()
@@ -540,14 +585,6 @@ class Engine:
         return out
 
     # -- whole stitch -----------------------------------------------------------
-    def warp_all(self, frames, plan, n_blur=0, want_maps=False):
-        patches, maps = [], []
-        for i, frame in enumerate(frames):
-            patch = DevicePatch(plan.rects[i], self.device, n_blur)
-            maps.append(self.warp(frame, plan, i, patch, want_maps))
-            patches.append(patch)
-        return patches, maps
-
     def stitch(self, frames, plan, blend="multiband", n_levels=5, want_float=False,
                fused=True):
         """uint8 frames on device -> (mosaic u8 on device, float mosaic, valid,

@@ -115,7 +115,7 @@ def _valid(patches, shape):
     eng = _eng.engine()
     dev = _upload_patches(eng, patches, 0)
     table = _eng.patch_table(dev, eng.device)
-    _, valid = eng.ownership(table, len(dev), tuple(shape))
+    _, valid = eng.ownership(table, tuple(shape))
     return valid.cpu().numpy().astype(bool)
 
 
@@ -184,7 +184,7 @@ def stitch(regions, blender=no_blend, equalize=False, crop=False):
         logging.debug("Cropping...")
         if valid is None:
             table = _eng.patch_table(patches, eng.device)
-            _, valid = eng.ownership(table, len(patches), plan.shape)
+            _, valid = eng.ownership(table, plan.shape)
         rect = eng.crop_rect(valid)
         if rect is None:
             raise UnboundLocalError("local variable 'last' referenced before assignment")

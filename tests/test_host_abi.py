@@ -24,7 +24,18 @@ def test_library_exports_every_declared_symbol():
     handle.pano_version.restype = ctypes.c_char_p
     assert b"gfx950" in handle.pano_version()
     assert handle.pano_pitch(1941) == 1944
-    assert ctypes.sizeof(_lib.Patch) == 80 and ctypes.sizeof(_lib.Camera) == 112
+    # record sizes against the C compiler's view of the header
+    import subprocess
+    import tempfile
+    with tempfile.TemporaryDirectory() as tmp:
+        src = os.path.join(tmp, "sz.c")
+        with open(src, "w") as fid:
+            fid.write('#include <stdio.h>\n#include "pano360.h"\nint main(void){'
+                      'printf("%zu %zu", sizeof(pano_patch), sizeof(pano_camera));return 0;}')
+        exe = os.path.join(tmp, "sz")
+        subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), src, "-o", exe])
+        sizes = [int(v) for v in subprocess.check_output([exe]).split()]
+    assert sizes == [ctypes.sizeof(_lib.Patch), ctypes.sizeof(_lib.Camera)] == [88, 120]
 
 
 def test_header_constants_match_binding():
@@ -148,7 +159,7 @@ def test_reflect_closed_is_tight_and_safe():
                 hit = {_reflect_101(p, n) for p in range(lo, hi)}
                 assert 0 <= a < b <= n
                 assert min(hit) >= a and max(hit) < b, (n, lo, hi, a, b)
-                if n > 1 and lo >= -(n - 1) and hi <= 2 * n - 1:
+                if n > 1 and lo >= -(n - 1) and hi <= 2 * n - 1 and hi > 0 and lo < n:
                     assert (a, b) == (min(hit), max(hit) + 1), (n, lo, hi, a, b)
 
 
