@@ -135,11 +135,18 @@ def main():
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for N > 1")
+    # PANO_DIST_BACKEND=gloo lets several ranks share one GPU for a dry run of the
+    # multi-rank path on a 1-GPU box; the real launch is one rank per GPU over RCCL
+    backend = os.environ.get("PANO_DIST_BACKEND", "nccl")
+    local = local % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+        else:
+            dist.init_process_group(backend)
 
     cfg = workload(args.workload)
     n_levels = cfg["n_levels"]
@@ -184,7 +191,8 @@ def main():
     times = kernel_times(eng.lib)
     eng.lib.pano_timing_enable(0)
     if dist is not None:
-        tt = torch.tensor([elapsed], device=eng.device, dtype=torch.float64)
+        tt = torch.tensor([elapsed], dtype=torch.float64,
+                          device=eng.device if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = tt.item()
 

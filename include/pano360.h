@@ -146,11 +146,11 @@ int pano_ownership_cameras(const pano_camera *cams, int n, int H, int W,
                            const double *cos_t, const double *tan_p,
                            int16_t *owner, uint8_t *valid, void *stream);
 
-/* Bounding box of each patch's owned pixels: boxes dev int32 [n][4] =
- * {ymin, ymax, xmin, xmax} inclusive, mosaic coordinates; ymax < ymin when the
- * patch owns nothing. */
-int pano_owned_boxes(const int16_t *owner, int H, int W, int n, int32_t *boxes,
-                     void *stream);
+/* Bounding box of each patch's owned pixels inside the column strip
+ * [xs0, xs1): boxes dev int32 [n][4] = {ymin, ymax, xmin, xmax} inclusive,
+ * mosaic coordinates; ymax < ymin when the patch owns nothing there. */
+int pano_owned_boxes(const int16_t *owner, int H, int W, int xs0, int xs1,
+                     int n, int32_t *boxes, void *stream);
 
 /* The n_levels-1 Gaussian blurs of every patch  stitcher.py:207-208, 218, 226
  * (cv2.GaussianBlur(warped, (0,0), 4*sqrt(2k+1)) with the alpha channel
@@ -172,12 +172,14 @@ int pano_multiband_blur(const pano_patch *patches, int n, int max_aw,
 /* Band-pass build + collapse                     stitcher.py:210-241
  * Gathers, per mosaic pixel and in patch order, layer_k / wsum_k of every
  * level over the patches whose A holds the pixel, zeroes outside `valid`,
- * sums the levels, clips, truncates to uint8.
- * mosaic_f32 (optional) receives the clipped float mosaic [H][W][3]. */
+ * sums the levels, clips, truncates to uint8 - for the mosaic columns
+ * [xs0, xs1) (the whole mosaic: 0, W; one GPU's share when the mosaic is split
+ * into column strips).  mosaic / mosaic_f32 are full-size [H][W][3] buffers,
+ * only the strip is written; mosaic_f32 is optional. */
 int pano_multiband_compose(const pano_patch *patches, int n, int H, int W,
-                           int n_levels, const int16_t *owner,
-                           const uint8_t *valid, uint8_t *mosaic,
-                           float *mosaic_f32, void *stream);
+                           int xs0, int xs1, int n_levels,
+                           const int16_t *owner, const uint8_t *valid,
+                           uint8_t *mosaic, float *mosaic_f32, void *stream);
 
 /* linear_blend                                          stitcher.py:171-183 */
 int pano_linear_blend(const pano_patch *patches, int n, int H, int W,

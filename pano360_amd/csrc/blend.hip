@@ -84,15 +84,15 @@ __global__ __launch_bounds__(256) void ownership_cameras_kernel(
 // upper neighbour, and so on), and a region bounded by near-vertical seams has
 // only a handful of them.
 __global__ __launch_bounds__(256) void owned_boxes_kernel(const int16_t *__restrict__ owner,
-                                                          int H, int W,
+                                                          int H, int W, int xs0, int xs1,
                                                           int32_t *__restrict__ boxes) {
-    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
-    if (x >= W || y >= H) return;
+    const int x = xs0 + blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+    if (x >= xs1 || y >= H) return;
     const int16_t *row = owner + (size_t)y * W;
     const int o = row[x];
     if (o < 0) return;
-    const bool left = x == 0 || row[x - 1] != o;
-    const bool right = x == W - 1 || row[x + 1] != o;
+    const bool left = x == xs0 || row[x - 1] != o;      // the strip's edge counts as foreign
+    const bool right = x == xs1 - 1 || row[x + 1] != o;
     if (!left && !right) return;
     const bool up = y == 0 || row[x - W] != o;
     const bool down = y == H - 1 || row[x + W] != o;
@@ -118,11 +118,11 @@ __device__ __forceinline__ uint8_t quant255(float v) { return (uint8_t)(int)(255
 
 template <int L>
 __global__ __launch_bounds__(256) void multiband_compose_kernel(
-    const pano_patch *__restrict__ patches, int n, int H, int W,
+    const pano_patch *__restrict__ patches, int n, int H, int W, int xs0, int xs1,
     const int16_t *__restrict__ owner, const uint8_t *__restrict__ valid,
     uint8_t *__restrict__ mosaic, float *__restrict__ mosaic_f32) {
-    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
-    if (x >= W || y >= H) return;
+    const int x = xs0 + blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+    if (x >= xs1 || y >= H) return;
     float layer[L][3], wsum[L];
 #pragma unroll
     for (int k = 0; k < L; ++k) layer[k][0] = layer[k][1] = layer[k][2] = wsum[k] = 0.0f;
@@ -267,38 +267,43 @@ extern "C" int pano_ownership_cameras(const pano_camera *cams, int n, int H, int
     return PANO_OK;
 }
 
-extern "C" int pano_owned_boxes(const int16_t *owner, int H, int W, int n, int32_t *boxes,
-                                void *stream) {
+extern "C" int pano_owned_boxes(const int16_t *owner, int H, int W, int xs0, int xs1, int n,
+                                int32_t *boxes, void *stream) {
     PANO_REQUIRE(owner && boxes, "pano_owned_boxes: null pointer");
     PANO_REQUIRE(H > 0 && W > 0 && n >= 0 && n <= 32767, "pano_owned_boxes: bad argument");
+    PANO_REQUIRE(xs0 >= 0 && xs1 <= W && xs0 <= xs1, "pano_owned_boxes: bad strip [%d, %d)", xs0, xs1);
     if (n == 0) return PANO_OK;
     hipLaunchKernelGGL(init_boxes_kernel, dim3(ceil_div(n, 256)), dim3(256), 0,
                        (hipStream_t)stream, boxes, n);
     PANO_LAUNCH_CHECK("init_boxes_kernel");
-    MOSAIC_GRID;
+    if (xs0 == xs1) return PANO_OK;
+    dim3 block(64, 4), grid(ceil_div(xs1 - xs0, 64), ceil_div(H, 4));
     PANO_TIMED(PK_OWNED_BOXES, (hipStream_t)stream,
                hipLaunchKernelGGL(owned_boxes_kernel, grid, block, 0, (hipStream_t)stream,
-                                  owner, H, W, boxes));
+                                  owner, H, W, xs0, xs1, boxes));
     PANO_LAUNCH_CHECK("owned_boxes_kernel");
     return PANO_OK;
 }
 
 extern "C" int pano_multiband_compose(const pano_patch *patches, int n, int H, int W,
-                                      int n_levels, const int16_t *owner,
-                                      const uint8_t *valid, uint8_t *mosaic,
-                                      float *mosaic_f32, void *stream) {
+                                      int xs0, int xs1, int n_levels,
+                                      const int16_t *owner, const uint8_t *valid,
+                                      uint8_t *mosaic, float *mosaic_f32, void *stream) {
     if (int rc = check_table(patches, n, H, W, "pano_multiband_compose")) return rc;
     PANO_REQUIRE(owner && valid && mosaic, "pano_multiband_compose: null pointer");
     PANO_REQUIRE(n_levels >= 1 && n_levels <= PANO_MAX_LEVELS,
                  "pano_multiband_compose: n_levels %d outside [1, %d]", n_levels, PANO_MAX_LEVELS);
-    MOSAIC_GRID;
+    PANO_REQUIRE(xs0 >= 0 && xs1 <= W && xs0 <= xs1,
+                 "pano_multiband_compose: bad strip [%d, %d)", xs0, xs1);
+    if (xs0 == xs1) return PANO_OK;
+    dim3 block(64, 4), grid(ceil_div(xs1 - xs0, 64), ceil_div(H, 4));
     hipStream_t s = (hipStream_t)stream;
 #define COMPOSE(L)                                                                   \
     case L:                                                                          \
         PANO_TIMED(PK_COMPOSE, s,                                                    \
                    hipLaunchKernelGGL(multiband_compose_kernel<L>, grid, block, 0,   \
-                                      s, patches, n, H, W, owner, valid, mosaic,     \
-                                      mosaic_f32));                                  \
+                                      s, patches, n, H, W, xs0, xs1, owner, valid,   \
+                                      mosaic, mosaic_f32));                          \
         break;
     switch (n_levels) {
         COMPOSE(1) COMPOSE(2) COMPOSE(3) COMPOSE(4) COMPOSE(5) COMPOSE(6) COMPOSE(7) COMPOSE(8)

@@ -220,12 +220,14 @@ def reflect_closed(lo, hi, n):
     return max(a, 0), min(b, n)
 
 
-def windows_for(box, rect, radius):
+def windows_for(box, rect, radius, strip=None):
     """Rectangles A and V of include/pano360.h ("Windows") for one patch.
 
     box: (ymin, ymax, xmin, xmax) of the owned pixels, mosaic coordinates,
-    inclusive, empty when ymax < ymin.  Returns patch-local
-    ((ay0, ay1, ax0, ax1), (vy0, vy1, vx0, vx1)) or None for an empty box."""
+    inclusive, empty when ymax < ymin.  ``strip`` = (c0, c1) keeps only the
+    part of A inside those mosaic columns (one GPU's share of the mosaic).
+    Returns patch-local ((ay0, ay1, ax0, ax1), (vy0, vy1, vx0, vx1)) or None
+    when nothing is left."""
     ymin, ymax, xmin, xmax = (int(v) for v in box)
     if ymax < ymin or xmax < xmin:
         return None
@@ -233,6 +235,10 @@ def windows_for(box, rect, radius):
     h, w = y1 - y0, x1 - x0
     ay0, ay1 = max(ymin - y0 - radius, 0), min(ymax - y0 + 1 + radius, h)
     ax0, ax1 = max(xmin - x0 - radius, 0), min(xmax - x0 + 1 + radius, w)
+    if strip is not None:
+        ax0, ax1 = max(ax0, strip[0] - x0), min(ax1, strip[1] - x0)
+        if ax1 <= ax0:
+            return None
     vy0, vy1 = reflect_closed(ay0 - radius, ay1 + radius, h)
     vx0, vx1 = reflect_closed(ax0 - radius, ax1 + radius, w)
     return (ay0, ay1, ax0, ax1), (min(vy0, ay0), max(vy1, ay1), min(vx0, ax0), max(vx1, ax1))
@@ -450,10 +456,13 @@ class Engine:
         mosaic, fl = self.blur_and_compose(table, owner, valid, shape, n_levels, want_float)
         return mosaic, fl, owner, valid
 
-    def blur_and_compose(self, table, owner, valid, shape, n_levels, want_float=False):
-        """All Gaussian levels of all patches (n_levels launches), then the gather."""
+    def blur_and_compose(self, table, owner, valid, shape, n_levels, want_float=False,
+                         strip=None):
+        """All Gaussian levels of all patches (n_levels launches), then the gather
+        over the mosaic columns ``strip`` (default: all of them)."""
         torch = _torch()
         H, W = shape
+        c0, c1 = strip if strip is not None else (0, W)
         taps, ntaps, n_blur, _ = self.blur_tables(n_levels)
         if n_blur:
             _lib.check(self.lib.pano_multiband_blur(
@@ -462,7 +471,7 @@ class Engine:
         mosaic = torch.empty((H, W, 3), dtype=torch.uint8, device=self.device)
         fl = (torch.empty((H, W, 3), dtype=torch.float32, device=self.device)
               if want_float else None)
-        _lib.check(self.lib.pano_multiband_compose(table.ptr, table.n, H, W, n_levels,
+        _lib.check(self.lib.pano_multiband_compose(table.ptr, table.n, H, W, c0, c1, n_levels,
                                                    _ptr(owner), _ptr(valid), _ptr(mosaic),
                                                    _ptr(fl), self.stream()),
                    "pano_multiband_compose")
@@ -512,30 +521,46 @@ class Engine:
             "pano_ownership_cameras")
         return owner, valid
 
-    def owned_boxes(self, owner, n):
+    def owned_boxes(self, owner, n, strip=None):
         """Host array [n][4] = (ymin, ymax, xmin, xmax) of every patch's owned
-        pixels (one small device->host copy; the only sync of a stitch)."""
+        pixels within the column strip (one small device->host copy; the only
+        sync of a stitch)."""
         torch = _torch()
         H, W = owner.shape
+        c0, c1 = strip if strip is not None else (0, W)
         boxes = torch.empty((n, 4), dtype=torch.int32, device=self.device)
-        _lib.check(self.lib.pano_owned_boxes(_ptr(owner), H, W, n, _ptr(boxes), self.stream()),
-                   "pano_owned_boxes")
+        _lib.check(self.lib.pano_owned_boxes(_ptr(owner), H, W, c0, c1, n, _ptr(boxes),
+                                             self.stream()), "pano_owned_boxes")
         return boxes.cpu().numpy()
 
     def multiband_fused(self, frames, plan, n_levels, want_float=False, frame_ids=None,
-                        owner_valid=None):
-        """The headline path.  ``frames[j]`` is the frame of camera
-        ``frame_ids[j]`` (default: all cameras in order)."""
+                        strip=None):
+        """The headline path, for the mosaic columns ``strip`` = (c0, c1) (default:
+        the whole mosaic).  ``frames[j]`` is the frame of camera ``frame_ids[j]``
+        (default: all cameras in order); every camera whose patch reaches within
+        two blur radii of the strip must be among them.
+
+        Column strips are independent: the owner map is evaluated on the strip
+        grown by the blur radius R (every owned pixel that can reach the strip is
+        in there), each patch's rectangle A is cut to the strip and its window V
+        grows from that.  Strips therefore shard a stitch over GPUs with no
+        exchange inside the blend, and the union of the strips' columns is the
+        single-GPU mosaic bit for bit."""
+        H, W = plan.shape
+        c0, c1 = strip if strip is not None else (0, W)
+        taps, ntaps, n_blur, radius = self.blur_tables(n_levels)
+        ext = (max(c0 - radius, 0), min(c1 + radius, W))
         ids = list(range(plan.n)) if frame_ids is None else list(frame_ids)
         have = dict(zip(ids, frames))
         cams = self.camera_table(plan, have)
-        if owner_valid is None:
-            owner_valid = self.ownership_cameras(plan, cams=cams)
-        owner, valid = owner_valid
-        boxes = self.owned_boxes(owner, plan.n)
-        taps, ntaps, n_blur, radius = self.blur_tables(n_levels)
-        windows = [windows_for(boxes[i], plan.rects[i], radius) if i in have else None
+        owner, valid = self.ownership_cameras(plan, strip=ext, cams=cams)
+        boxes = self.owned_boxes(owner, plan.n, ext)
+        windows = [windows_for(boxes[i], plan.rects[i], radius, (c0, c1))
                    for i in range(plan.n)]
+        missing = [i for i, w in enumerate(windows) if w is not None and i not in have]
+        if missing:
+            raise _lib.PanoError(f"frames {missing} are needed for columns [{c0}, {c1}) "
+                                 "but are not resident on this device")
         patches = FusedPatches(plan.rects, windows, self.device, n_blur)
         table = patches.table
         _lib.check(self.lib.pano_warp_windows(
@@ -543,7 +568,7 @@ class Engine:
             _ptr(plan.dev[1]), _ptr(plan.dev[2]), _ptr(self.lut255), self.stream()),
             "pano_warp_windows")
         mosaic, fl = self.blur_and_compose(table, owner, valid, plan.shape, n_levels,
-                                           want_float)
+                                           want_float, (c0, c1))
         return mosaic, fl, valid, patches
 
     # -- crop and filters -------------------------------------------------------------

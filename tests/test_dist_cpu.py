@@ -1,0 +1,104 @@
+"""CPU, world_size 2 over gloo: the only exchange of the multi-GPU path (strip
+gather onto rank 0) and the host-side sharding logic.  The kernels themselves
+need a GPU; their strip-restricted form is checked against the whole-mosaic run
+in tests/test_gpu_parity.py::test_column_strips_compose_the_single_gpu_mosaic."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from pano360_amd import dist as pdist
+from pano360_amd import engine, synth
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, H, W, result):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        bounds = pdist.strip_bounds(W, world)
+        truth = torch.arange(H * W * 3, dtype=torch.int64).reshape(H, W, 3).remainder(251)
+        truth = truth.to(torch.uint8)
+        # this rank only "computed" its own columns; everything else is junk
+        mine = torch.full((H, W, 3), 200 + rank, dtype=torch.uint8)
+        c0, c1 = bounds[rank], bounds[rank + 1]
+        mine[:, c0:c1] = truth[:, c0:c1]
+        width = max(b - a for a, b in zip(bounds[:-1], bounds[1:]))
+        packed = pdist.pack_strip(mine, (c0, c1), width)
+        full = pdist.gather_strips(packed, bounds, rank, world)
+        if rank == 0:
+            result.put(bool(torch.equal(full, truth)))
+        else:
+            assert full is None
+        # max-over-ranks timing reduction used by bench.py
+        t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        assert t.item() == world
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("W", [64, 37])
+def test_strip_gather_world_2(W):
+    ctx = mp.get_context("spawn")
+    result = ctx.SimpleQueue()
+    mp.spawn(_worker, args=(2, _free_port(), 9, W, result), nprocs=2, join=True)
+    assert result.get() is True
+
+
+def test_strip_bounds_cover_the_mosaic():
+    for width in (1, 7, 64, 13760):
+        for world in (1, 2, 3, 8):
+            b = pdist.strip_bounds(width, world)
+            assert b[0] == 0 and b[-1] == width and len(b) == world + 1
+            assert all(x <= y for x, y in zip(b[:-1], b[1:]))
+            if width >= world:
+                widths = [y - x for x, y in zip(b[:-1], b[1:])]
+                assert max(widths) - min(widths) <= 1
+
+
+def test_frames_for_strip_is_a_superset_of_what_windows_touch():
+    """Every frame whose patch can contribute to a strip (its rectangle reaches
+    the strip grown by the radius) is selected, for every rank; together the
+    ranks hold every frame."""
+    cfg = synth.CONFIGS["cfg3"]
+    rots, intrs = synth.make_cameras(cfg["n"], cfg["width"], cfg["height"],
+                                     sweep_deg=cfg["sweep_deg"])
+    shapes = [(cfg["height"], cfg["width"])] * cfg["n"]
+    plan = engine.Plan(shapes, rots, intrs, True, 10 ** 9)
+    radius = 43
+    for world in (2, 8):
+        bounds = pdist.strip_bounds(plan.shape[1], world)
+        seen = set()
+        for r in range(world):
+            strip = (bounds[r], bounds[r + 1])
+            got = pdist.frames_for_strip(plan.rects, strip, 2 * radius)
+            for i, (_, _, x0, x1) in enumerate(plan.rects):
+                touches = x0 < strip[1] + radius and x1 > strip[0] - radius
+                assert (i in got) or not touches
+            assert got == list(range(got[0], got[-1] + 1))      # a contiguous run
+            assert len(got) < cfg["n"] or world == 1
+            seen.update(got)
+        assert seen == set(range(cfg["n"]))
+
+
+def test_windows_for_strip_clipping():
+    rect = (0, 100, 1000, 1400)                     # patch columns 1000..1399
+    box = (0, 99, 1100, 1199)                       # owns columns 1100..1199
+    area, win = engine.windows_for(box, rect, 43)
+    assert area == (0, 100, 57, 243)
+    area, win = engine.windows_for(box, rect, 43, strip=(1150, 1300))
+    assert area == (0, 100, 150, 243) and win[2] == 150 - 43 and win[3] == 243 + 43
+    assert engine.windows_for(box, rect, 43, strip=(1243, 2000)) is None
+    assert engine.windows_for(box, rect, 43, strip=(0, 1057)) is None
+    area, _ = engine.windows_for(box, rect, 43, strip=(0, 1058))
+    assert area == (0, 100, 57, 58)

@@ -251,6 +251,45 @@ def test_fused_windows_on_a_wide_sweep(eng, oracle):
     assert np.abs(m1.cpu().numpy().astype(int) - ref_u8.astype(int)).max() <= 1
 
 
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_column_strips_compose_the_single_gpu_mosaic(eng, world):
+    """The multi-GPU decomposition, every rank emulated in turn on this one GPU:
+    each rank holds only the frames near its strip, evaluates ownership only
+    around its strip, and the concatenated strips are the single-GPU mosaic bit
+    for bit (tests/test_dist_cpu.py covers the gather itself over gloo)."""
+    import torch
+    from pano360_amd import dist as pdist
+    from pano360_amd import engine, synth
+    imgs, rots, intrs = synth.make_scene(10, 480, 270, sweep_deg=120.0, jitter=0.01, seed=41,
+                                         kind="A")
+    plan = engine.Plan([im.shape[:2] for im in imgs], rots, intrs, True, 10 ** 9)
+    whole, _, _, _ = eng.stitch(eng.upload_frames(imgs), plan, "multiband", 5)
+    strips, bounds = pdist.emulate_on_one_device(eng, imgs, rots, intrs, 5, world)
+    assert bounds[-1] == plan.shape[1]
+    assert torch.equal(strips, whole)
+    # the ranks did not all need all frames
+    shapes = [im.shape[:2] for im in imgs]
+    held = [len(pdist.ShardedStitcher(eng, shapes, rots, intrs, 5, r, world).my_frames)
+            for r in range(world)]
+    assert min(held) < len(imgs)
+
+
+def test_sharded_stitcher_world_1_equals_stitch(eng):
+    import torch
+    from pano360_amd import dist as pdist
+    from pano360_amd import engine, synth
+    imgs, rots, intrs = synth.make_scene(5, 320, 180, sweep_deg=70.0, seed=43, kind="B")
+    shapes = [im.shape[:2] for im in imgs]
+    st = pdist.ShardedStitcher(eng, shapes, rots, intrs, 5, 0, 1)
+    assert st.my_frames == list(range(5))
+    plan, mosaic, _ = st.step(eng.upload_frames(imgs))
+    whole, _, _, _ = eng.stitch(eng.upload_frames(imgs), plan, "multiband", 5)
+    assert torch.equal(mosaic, whole)
+    with pytest.raises(Exception):       # a needed frame that is not resident
+        eng.multiband_fused(eng.upload_frames(imgs[:2]), eng.upload_plan(plan), 5,
+                            frame_ids=[0, 1])
+
+
 # ------------------------------------------------------------------- crop
 def test_crop_rectangles_bit_exact(eng, oracle):
     import torch
