@@ -41,6 +41,9 @@
 
 #define COL_TW 64
 #define COL_TH 128
+// input rows a column-pass thread walks: aperture + its 8 outputs - 1, rounded
+// up to the 8-row trip of the inner loop
+#define COL_STEPS(ntaps) (((ntaps) + 7 + 7) & ~7)
 
 struct LevelDesc {
     const float *wz;     // row-pass table: 7 + extra leading zeros
@@ -79,17 +82,24 @@ __global__ __launch_bounds__(256) void blur_rows_kernel(
     const int16_t *__restrict__ orow =
         owner + (size_t)(p.y0 + p.vy0 + yc) * W + p.x0;      // sharp-alpha source row
 
-    for (int i = lane; i < L.need; i += 64) {
-        const int pcol = reflect_101(p.ax0 + xt - L.rmax + i, p.w);
-        float v;
-        if (src) {
-            int vc = pcol - p.vx0;               // inside V by construction; clamp anyway
-            vc = vc < 0 ? 0 : (vc >= p.vw ? p.vw - 1 : vc);
-            v = src[(size_t)yc * p.vpitch + vc];
-        } else {
-            v = orow[pcol] == pid ? 1.0f : 0.0f;             // stitcher.py:208
+    // stage the row segment, four loads in flight per lane
+    for (int i0 = lane; i0 < L.need; i0 += 256) {
+        float v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + 64 * u < L.need ? i0 + 64 * u : L.need - 1;
+            const int pcol = reflect_101(p.ax0 + xt - L.rmax + i, p.w);
+            if (src) {
+                int vc = pcol - p.vx0;           // inside V by construction; clamp anyway
+                vc = vc < 0 ? 0 : (vc >= p.vw ? p.vw - 1 : vc);
+                v[u] = src[(size_t)yc * p.vpitch + vc];
+            } else {
+                v[u] = orow[pcol] == pid ? 1.0f : 0.0f;      // stitcher.py:208
+            }
         }
-        tile[row_pos(i)] = v;
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (i0 + 64 * u < L.need) tile[row_pos(i0 + 64 * u)] = v[u];
     }
     __syncthreads();
 
@@ -101,18 +111,20 @@ __global__ __launch_bounds__(256) void blur_rows_kernel(
         float acc[8];
 #pragma unroll
         for (int o = 0; o < 8; ++o) acc[o] = 0.0f;
-        for (int s = 0; s < steps; ++s) {
-            const int q = start + 4 * s;
-            const float4 v = *(const float4 *)(base + q + ((q >> 3) << 2));
-            float wq[11];
+        // 8 inputs (two 16-B LDS reads) per trip against 15 consecutive taps
+        for (int s = 0; s < steps; s += 2) {
+            const int q0 = start + 4 * s, q1 = q0 + 4;
+            const float4 va = *(const float4 *)(base + q0 + ((q0 >> 3) << 2));
+            const float4 vb = *(const float4 *)(base + q1 + ((q1 >> 3) << 2));
+            float wq[15];
 #pragma unroll
-            for (int j = 0; j < 11; ++j) wq[j] = wz[4 * s + j];
+            for (int j = 0; j < 15; ++j) wq[j] = wz[4 * s + j];
+            const float in[8] = {va.x, va.y, va.z, va.w, vb.x, vb.y, vb.z, vb.w};
 #pragma unroll
-            for (int o = 0; o < 8; ++o) {
-                acc[o] = __builtin_fmaf(wq[7 - o + 0], v.x, acc[o]);
-                acc[o] = __builtin_fmaf(wq[7 - o + 1], v.y, acc[o]);
-                acc[o] = __builtin_fmaf(wq[7 - o + 2], v.z, acc[o]);
-                acc[o] = __builtin_fmaf(wq[7 - o + 3], v.w, acc[o]);
+            for (int i = 0; i < 8; ++i) {
+#pragma unroll
+                for (int o = 0; o < 8; ++o)
+                    acc[o] = __builtin_fmaf(wq[i + 7 - o], in[i], acc[o]);
             }
         }
         if (y < p.vh) {
@@ -144,16 +156,29 @@ __global__ __launch_bounds__(256) void blur_cols_kernel(
     float *__restrict__ dst = p.blurred + (size_t)(level * nch + c) * p.ah * p.apitch;
     const int tx = threadIdx.x, ty = threadIdx.y;           // 16 x 16
     const int R = ntaps >> 1;
-    const int steps = ntaps + 7;
+    const int steps = COL_STEPS(ntaps);                     // input rows per thread, x8
     const int rows = 8 * 15 + steps;                        // rows read by ty = 15
     const int x = x0 + 4 * tx;
 
-    for (int r = ty; r < rows; r += 16) {
-        int vr = reflect_101(p.ay0 + y0 - R + r, p.h) - p.vy0;
-        vr = vr < 0 ? 0 : (vr >= p.vh ? p.vh - 1 : vr);     // inside by construction
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (x < p.apitch) v = *(const float4 *)(src + (size_t)vr * p.apitch + x);
-        *(float4 *)(s_col + r * COL_TW + 4 * tx) = v;
+    // rows past the aperture only meet zero taps, but must hold finite numbers:
+    // they are staged like any other row (reflection keeps them inside the patch)
+    // four loads in flight per thread; columns past the pitch re-read the last
+    // valid 16 bytes (their results are never stored)
+    const int xl = x < p.apitch ? x : p.apitch - 4;
+    for (int r0 = ty; r0 < rows; r0 += 64) {
+        float4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int r = r0 + 16 * u;
+            int vr = reflect_101(p.ay0 + y0 - R + (r < rows ? r : rows - 1), p.h) - p.vy0;
+            vr = vr < 0 ? 0 : (vr >= p.vh ? p.vh - 1 : vr); // inside by construction
+            v[u] = *(const float4 *)(src + (size_t)vr * p.apitch + xl);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int r = r0 + 16 * u;
+            if (r < rows) *(float4 *)(s_col + r * COL_TW + 4 * tx) = v[u];
+        }
     }
     __syncthreads();
 
@@ -161,18 +186,26 @@ __global__ __launch_bounds__(256) void blur_cols_kernel(
 #pragma unroll
     for (int o = 0; o < 8; ++o) acc[o] = make_float4(0.f, 0.f, 0.f, 0.f);
     const float *base = s_col + (8 * ty) * COL_TW + 4 * tx;
-    for (int q = 0; q < steps; ++q) {
-        const float4 v = *(const float4 *)(base + q * COL_TW);
-        float wq[8];
+    // 8 input rows per trip: 15 consecutive taps serve all 8 x 8 (row, output)
+    // pairs, so the scalar loads and the LDS reads of a trip are issued up
+    // front and 256 FMAs run behind them.
+    for (int q = 0; q < steps; q += 8) {
+        float wq[15];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) wq[j] = wz[q + j];
+        for (int j = 0; j < 15; ++j) wq[j] = wz[q + j];
+        float4 v[8];
 #pragma unroll
-        for (int o = 0; o < 8; ++o) {
-            const float wgt = wq[7 - o];
-            acc[o].x = __builtin_fmaf(wgt, v.x, acc[o].x);
-            acc[o].y = __builtin_fmaf(wgt, v.y, acc[o].y);
-            acc[o].z = __builtin_fmaf(wgt, v.z, acc[o].z);
-            acc[o].w = __builtin_fmaf(wgt, v.w, acc[o].w);
+        for (int s = 0; s < 8; ++s) v[s] = *(const float4 *)(base + (q + s) * COL_TW);
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+#pragma unroll
+            for (int o = 0; o < 8; ++o) {
+                const float wgt = wq[s + 7 - o];
+                acc[o].x = __builtin_fmaf(wgt, v[s].x, acc[o].x);
+                acc[o].y = __builtin_fmaf(wgt, v[s].y, acc[o].y);
+                acc[o].z = __builtin_fmaf(wgt, v[s].z, acc[o].z);
+                acc[o].w = __builtin_fmaf(wgt, v[s].w, acc[o].w);
+            }
         }
     }
     if (x < p.apitch) {
@@ -207,7 +240,7 @@ static int make_levels(const float *taps, const int *ntaps, int n_blur, Levels *
         L->lv[k].wz = taps + off;
         L->lv[k].ntaps = ntaps[k];
         L->lv[k].start = delta - extra;
-        L->lv[k].steps = (ntaps[k] + extra + 7 + 3) >> 2;
+        L->lv[k].steps = (((ntaps[k] + extra + 7 + 3) >> 2) + 1) & ~1;   // even: 2 per trip
         col_wz[k] = taps + off + extra;          // 7 leading zeros for the column pass
         const int need = 8 * 63 + L->lv[k].start + 4 * L->lv[k].steps;
         if (need > L->need) L->need = need;
@@ -245,7 +278,7 @@ static int launch_blur(const pano_patch *table, const pano_patch &single, int n,
         PANO_LAUNCH_CHECK("blur_rows_kernel");
     }
     for (int k = 0; k < n_blur; ++k) {
-        const int rows = 8 * 15 + ntaps[k] + 7;
+        const int rows = 8 * 15 + COL_STEPS(ntaps[k]);
         const size_t lds = (size_t)rows * COL_TW * sizeof(float);
         dim3 block(16, 16), grid(ceil_div(max_aw, COL_TW), ceil_div(max_ah, COL_TH), n * nch);
         if (table)
