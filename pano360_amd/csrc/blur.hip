@@ -160,25 +160,24 @@ __global__ __launch_bounds__(256) void blur_cols_kernel(
     const int rows = 8 * 15 + steps;                        // rows read by ty = 15
     const int x = x0 + 4 * tx;
 
-    // rows past the aperture only meet zero taps, but must hold finite numbers:
-    // they are staged like any other row (reflection keeps them inside the patch)
-    // four loads in flight per thread; columns past the pitch re-read the last
-    // valid 16 bytes (their results are never stored)
+    // Stage the tile with direct-to-LDS loads (global_load_lds_dwordx4): a wave
+    // owns 4 consecutive tile rows per trip - 64 lanes x 16 B = 1 KiB contiguous
+    // in LDS, which is what the instruction's "wave base + lane * 16" addressing
+    // needs - while every lane fetches from its own (reflected) source row.  No
+    // VGPRs are held, so the whole tile (14-16 KiB per wave) is in flight at
+    // once; the tile load was latency-bound when it went through registers
+    // (profiles/r01/notes.md).  Rows past the aperture only meet zero taps but
+    // must hold finite numbers: they are staged like any other row.  Columns
+    // past the pitch re-read the last valid 16 bytes (never stored).
     const int xl = x < p.apitch ? x : p.apitch - 4;
-    for (int r0 = ty; r0 < rows; r0 += 64) {
-        float4 v[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int r = r0 + 16 * u;
-            int vr = reflect_101(p.ay0 + y0 - R + (r < rows ? r : rows - 1), p.h) - p.vy0;
-            vr = vr < 0 ? 0 : (vr >= p.vh ? p.vh - 1 : vr); // inside by construction
-            v[u] = *(const float4 *)(src + (size_t)vr * p.apitch + xl);
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int r = r0 + 16 * u;
-            if (r < rows) *(float4 *)(s_col + r * COL_TW + 4 * tx) = v[u];
-        }
+    const int wave4 = (ty >> 2) << 2;                       // first row of this wave's group
+    for (int r0 = 0; r0 < rows; r0 += 16) {
+        const int r = r0 + ty;
+        int vr = reflect_101(p.ay0 + y0 - R + (r < rows ? r : rows - 1), p.h) - p.vy0;
+        vr = vr < 0 ? 0 : (vr >= p.vh ? p.vh - 1 : vr);     // inside by construction
+        __builtin_amdgcn_global_load_lds(
+            (const __attribute__((address_space(1))) void *)(src + (size_t)vr * p.apitch + xl),
+            (__attribute__((address_space(3))) void *)(s_col + (r0 + wave4) * COL_TW), 16, 0, 0);
     }
     __syncthreads();
 
@@ -278,7 +277,7 @@ static int launch_blur(const pano_patch *table, const pano_patch &single, int n,
         PANO_LAUNCH_CHECK("blur_rows_kernel");
     }
     for (int k = 0; k < n_blur; ++k) {
-        const int rows = 8 * 15 + COL_STEPS(ntaps[k]);
+        const int rows = (8 * 15 + COL_STEPS(ntaps[k]) + 15) & ~15;   // staged 16 at a time
         const size_t lds = (size_t)rows * COL_TW * sizeof(float);
         dim3 block(16, 16), grid(ceil_div(max_aw, COL_TW), ceil_div(max_ah, COL_TH), n * nch);
         if (table)
