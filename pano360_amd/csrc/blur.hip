@@ -141,7 +141,36 @@ __global__ __launch_bounds__(256) void blur_rows_kernel(
     }
 }
 
-template <bool TABLE>
+// One trip of the column pass: 8 tile rows and the 15 taps they meet.
+struct ColTrip {
+    float w[15];
+    float4 v[8];
+};
+
+__device__ __forceinline__ void col_trip_load(ColTrip &t, const float *base, kptr_f32 wz, int q) {
+#pragma unroll
+    for (int j = 0; j < 15; ++j) t.w[j] = wz[q + j];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) t.v[s] = *(const float4 *)(base + (q + s) * COL_TW);
+}
+
+__device__ __forceinline__ void col_trip_fma(const ColTrip &t, float4 (&acc)[8]) {
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+#pragma unroll
+        for (int o = 0; o < 8; ++o) {
+            const float wgt = t.w[s + 7 - o];
+            acc[o].x = __builtin_fmaf(wgt, t.v[s].x, acc[o].x);
+            acc[o].y = __builtin_fmaf(wgt, t.v[s].y, acc[o].y);
+            acc[o].z = __builtin_fmaf(wgt, t.v[s].z, acc[o].z);
+            acc[o].w = __builtin_fmaf(wgt, t.v[s].w, acc[o].w);
+        }
+    }
+}
+
+// PIPE: issue trip t+1's LDS reads and scalar tap loads before trip t's 256
+// FMAs, so the wait in front of a trip's arithmetic finds its operands landed.
+template <bool TABLE, bool PIPE>
 __global__ __launch_bounds__(256) void blur_cols_kernel(
     const pano_patch *__restrict__ table, pano_patch single, int nch, int level,
     const float *wz_global, int ntaps) {
@@ -186,25 +215,25 @@ __global__ __launch_bounds__(256) void blur_cols_kernel(
     for (int o = 0; o < 8; ++o) acc[o] = make_float4(0.f, 0.f, 0.f, 0.f);
     const float *base = s_col + (8 * ty) * COL_TW + 4 * tx;
     // 8 input rows per trip: 15 consecutive taps serve all 8 x 8 (row, output)
-    // pairs, so the scalar loads and the LDS reads of a trip are issued up
-    // front and 256 FMAs run behind them.
-    for (int q = 0; q < steps; q += 8) {
-        float wq[15];
-#pragma unroll
-        for (int j = 0; j < 15; ++j) wq[j] = wz[q + j];
-        float4 v[8];
-#pragma unroll
-        for (int s = 0; s < 8; ++s) v[s] = *(const float4 *)(base + (q + s) * COL_TW);
-#pragma unroll
-        for (int s = 0; s < 8; ++s) {
-#pragma unroll
-            for (int o = 0; o < 8; ++o) {
-                const float wgt = wq[s + 7 - o];
-                acc[o].x = __builtin_fmaf(wgt, v[s].x, acc[o].x);
-                acc[o].y = __builtin_fmaf(wgt, v[s].y, acc[o].y);
-                acc[o].z = __builtin_fmaf(wgt, v[s].z, acc[o].z);
-                acc[o].w = __builtin_fmaf(wgt, v[s].w, acc[o].w);
-            }
+    // pairs; a trip is 8 LDS reads + 15 scalar loads feeding 256 FMAs.
+    if (PIPE) {
+        ColTrip a, b;
+        col_trip_load(a, base, wz, 0);
+        for (int q = 0;;) {
+            if (q + 8 < steps) col_trip_load(b, base, wz, q + 8);
+            col_trip_fma(a, acc);
+            q += 8;
+            if (q >= steps) break;
+            if (q + 8 < steps) col_trip_load(a, base, wz, q + 8);
+            col_trip_fma(b, acc);
+            q += 8;
+            if (q >= steps) break;
+        }
+    } else {
+        for (int q = 0; q < steps; q += 8) {
+            ColTrip a;
+            col_trip_load(a, base, wz, q);
+            col_trip_fma(a, acc);
         }
     }
     if (x < p.apitch) {
@@ -258,12 +287,18 @@ static int launch_blur(const pano_patch *table, const pano_patch &single, int n,
     if (int rc = make_levels(taps, ntaps, n_blur, &L, col_wz, who)) return rc;
     static bool lds_opt_in = false;   // column tiles above 64 KiB need the opt-in
     if (!lds_opt_in) {
-        PANO_HIP(hipFuncSetAttribute((const void *)blur_cols_kernel<true>,
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        PANO_HIP(hipFuncSetAttribute((const void *)blur_cols_kernel<false>,
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        const void *fns[] = {(const void *)blur_cols_kernel<true, true>,
+                             (const void *)blur_cols_kernel<true, false>,
+                             (const void *)blur_cols_kernel<false, true>,
+                             (const void *)blur_cols_kernel<false, false>};
+        for (const void *fn : fns)
+            PANO_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         160 * 1024));
         lds_opt_in = true;
     }
+    // A/B switch for tools/ab_bench.py; the default is the measured-faster form
+    const char *env = getenv("PANO_COLS_PIPE");
+    const bool pipe = env ? env[0] != '0' : true;
     {
         dim3 block(64, 4), grid(ceil_div(max_aw, ROW_TW), ceil_div(max_vh, 4), n * nch);
         if (table)
@@ -280,14 +315,16 @@ static int launch_blur(const pano_patch *table, const pano_patch &single, int n,
         const int rows = (8 * 15 + COL_STEPS(ntaps[k]) + 15) & ~15;   // staged 16 at a time
         const size_t lds = (size_t)rows * COL_TW * sizeof(float);
         dim3 block(16, 16), grid(ceil_div(max_aw, COL_TW), ceil_div(max_ah, COL_TH), n * nch);
-        if (table)
-            PANO_TIMED(PK_BLUR_COLS, stream,
-                       hipLaunchKernelGGL(blur_cols_kernel<true>, grid, block, lds, stream,
-                                          table, single, nch, k, col_wz[k], ntaps[k]));
-        else
-            PANO_TIMED(PK_BLUR_COLS, stream,
-                       hipLaunchKernelGGL(blur_cols_kernel<false>, grid, block, lds, stream,
-                                          table, single, nch, k, col_wz[k], ntaps[k]));
+#define LAUNCH_COLS(T, P)                                                              \
+    PANO_TIMED(PK_BLUR_COLS, stream,                                                   \
+               hipLaunchKernelGGL((blur_cols_kernel<T, P>), grid, block, lds, stream,  \
+                                  table, single, nch, k, col_wz[k], ntaps[k]))
+        if (table) {
+            if (pipe) LAUNCH_COLS(true, true); else LAUNCH_COLS(true, false);
+        } else {
+            if (pipe) LAUNCH_COLS(false, true); else LAUNCH_COLS(false, false);
+        }
+#undef LAUNCH_COLS
         PANO_LAUNCH_CHECK("blur_cols_kernel");
     }
     return PANO_OK;
