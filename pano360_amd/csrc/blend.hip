@@ -45,17 +45,51 @@ __global__ __launch_bounds__(256) void ownership_kernel(
 // bounds mask and the bilinear sample of hat_y (x) hat_x, all evaluated with
 // the operations pano_warp_spherical uses, so the owner map is identical to
 // the one computed from warped alpha planes.
+//
+// Cost is arithmetic (about 110 instructions per pixel and covering camera, a
+// third of it the exact inverse map, the rest the taps and the alpha sample).
+// Only the winner's alpha matters, so the second part is pruned exactly: the
+// taps lie within 1 + 1/64 px of the mapped point (1/32-px rounding, then the
+// two neighbours), hence hat(tap) <= 0.5 - (|p - n/2| - 1.1)/n on each axis and
+// the product of the two bounds (x 1.00001 for float32 rounding) is an upper
+// bound of alpha.  Pass 1 maps every covering camera (exact, also settles
+// `valid`) and parks (px, py, index) in LDS; the camera with the largest bound
+// is sampled first and the others only if their bound reaches the running
+// maximum.  First-index tie-breaking is kept by comparing indices on equality.
+#define OWN_SLOTS 12
+
+__device__ __forceinline__ float hat_bound(float p, int n, float inv_n_lo) {
+    float d = fabsf(p - 0.5f * (float)n) - 1.1f;
+    d = d > 0.0f ? d : 0.0f;
+    return 0.5f - d * inv_n_lo;
+}
+
+__device__ __forceinline__ float alpha_bound(float fx, float fy, int sw, int sh) {
+    const float ub = hat_bound(fx, sw, (1.0f - 1e-6f) / (float)sw) *
+                     hat_bound(fy, sh, (1.0f - 1e-6f) / (float)sh) * 1.00001f;
+    return ub == ub ? ub : 1.0f;             // NaN coordinates: never prune
+}
+
+__device__ __forceinline__ void own_update(float a, int i, float &best, int &who) {
+    if (a > best || (a == best && a > 0.0f && i < who)) {
+        best = a;
+        who = i;
+    }
+}
+
 __global__ __launch_bounds__(256) void ownership_cameras_kernel(
     const pano_camera *__restrict__ cams, int n, int H, int W, int xs0, int xs1,
     const double *__restrict__ sin_t, const double *__restrict__ cos_t,
     const double *__restrict__ tan_p, int16_t *__restrict__ owner,
     uint8_t *__restrict__ valid) {
+    __shared__ float s_fx[OWN_SLOTS][256], s_fy[OWN_SLOTS][256];
+    __shared__ int16_t s_id[OWN_SLOTS][256];
+    const int tid = threadIdx.y * 64 + threadIdx.x;
     const int x = xs0 + blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
     if (x >= xs1 || y >= H) return;
     const double s = sin_t[x], c = cos_t[x], t = tan_p[y];
-    float best = 0.0f;
-    int who = -1;
-    bool any = false;
+    float best = 0.0f, ubmax = -1.0f;
+    int who = -1, cnt = 0, top = -1;
     for (int i = 0; i < n; ++i) {
         const pano_camera *cam = cams + i;
         const int px = x - cam->x0, py = y - cam->y0;
@@ -63,13 +97,38 @@ __global__ __launch_bounds__(256) void ownership_cameras_kernel(
         float fx, fy;
         const int sw = cam->sw, sh = cam->sh;
         if (map_pixel(cam->proj, s, c, t, sw, sh, fx, fy)) continue;   // alpha * 0
-        any = true;
-        const Taps tp = make_taps(fx, fy, sw, sh);
-        const float a = alpha_at(cam->hat_x, cam->hat_y, tp);
-        if (a > best) {
-            best = a;
-            who = i;
+        if (cnt < OWN_SLOTS) {
+            s_fx[cnt][tid] = fx;
+            s_fy[cnt][tid] = fy;
+            s_id[cnt][tid] = (int16_t)i;
+            const float ub = alpha_bound(fx, fy, sw, sh);
+            if (ub > ubmax) {
+                ubmax = ub;
+                top = cnt;
+            }
+            ++cnt;
+        } else {                              // more cameras than slots: sample now
+            const Taps tp = make_taps(fx, fy, sw, sh);
+            own_update(alpha_at(cam->hat_x, cam->hat_y, tp), i, best, who);
+            cnt = OWN_SLOTS + 1;
         }
+    }
+    const bool any = cnt > 0;
+    if (cnt > OWN_SLOTS) cnt = OWN_SLOTS;
+    if (top >= 0) {
+        const int i = s_id[top][tid];
+        const pano_camera *cam = cams + i;
+        const Taps tp = make_taps(s_fx[top][tid], s_fy[top][tid], cam->sw, cam->sh);
+        own_update(alpha_at(cam->hat_x, cam->hat_y, tp), i, best, who);
+    }
+    for (int j = 0; j < cnt; ++j) {
+        if (j == top) continue;
+        const int i = s_id[j][tid];
+        const pano_camera *cam = cams + i;
+        const float fx = s_fx[j][tid], fy = s_fy[j][tid];
+        if (!(alpha_bound(fx, fy, cam->sw, cam->sh) >= best)) continue;   // cannot win or tie
+        const Taps tp = make_taps(fx, fy, cam->sw, cam->sh);
+        own_update(alpha_at(cam->hat_x, cam->hat_y, tp), i, best, who);
     }
     owner[(size_t)y * W + x] = (int16_t)who;
     valid[(size_t)y * W + x] = any ? 1 : 0;

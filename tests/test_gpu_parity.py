@@ -214,6 +214,47 @@ def test_ownership_from_cameras_equals_ownership_from_planes(eng, name):
             assert boxes[i][1] < boxes[i][0]
 
 
+@pytest.mark.parametrize("case", ["dense", "tilted", "wide", "identical"])
+def test_ownership_pruning_is_exact(eng, case):
+    """The camera-driven kernel samples alpha only where an upper bound says the
+    camera can still win; whatever the geometry, the map must equal the
+    exhaustive argmax over warped alpha planes (first index on ties)."""
+    import torch
+    from pano360_amd import bundle_adj, engine, synth
+    rng = np.random.default_rng(5)
+    if case == "dense":          # 40 cameras 2 deg apart: > 12 cover a pixel (slot overflow)
+        n, w, h = 40, 96, 64
+        rots, intrs = synth.make_cameras(n, w, h, step_deg=2.0, jitter=0.003, seed=1)
+    elif case == "tilted":       # pitch / roll up to ~15 deg
+        n, w, h = 9, 160, 120
+        rots = np.stack([bundle_adj.rotation_to_mat(
+            [rng.normal(0, 0.15), 0.3 * (i - 4), rng.normal(0, 0.15)]) for i in range(n)])
+        intrs = np.stack([bundle_adj.intrinsics(synth.focal_for(w))] * n).astype(np.float64)
+    elif case == "wide":         # 120 deg lenses, off-centre principal points
+        n, w, h = 5, 200, 100
+        rots, _ = synth.make_cameras(n, w, h, step_deg=35.0, jitter=0.02, seed=2)
+        intrs = np.stack([bundle_adj.intrinsics(synth.focal_for(w, 120.0), (3.0 * i, -2.0))
+                          for i in range(n)]).astype(np.float64)
+    else:                        # the same camera four times: every pixel is a 4-way tie
+        n, w, h = 4, 120, 80
+        rots, intrs = synth.make_cameras(1, w, h, step_deg=0.0)
+        rots, intrs = np.repeat(rots, n, 0), np.repeat(intrs, n, 0)
+    imgs = [synth.make_frame(i, w, h, "A") for i in range(n)]
+    plan = eng.upload_plan(engine.Plan([(h, w)] * n, rots, intrs, True, 10 ** 9))
+    patches, _ = eng.warp_all(eng.upload_frames(imgs), plan)
+    owner_b, valid_b = eng.ownership(engine.patch_table(patches, eng.device), plan.shape)
+    owner_a, valid_a = eng.ownership_cameras(plan)
+    assert torch.equal(owner_a, owner_b) and torch.equal(valid_a, valid_b)
+    if case == "identical":
+        assert int(owner_a.max()) == 0           # ties go to the first index
+    if case == "dense":
+        cover = sum((torch.zeros(plan.shape, device=eng.device)
+                     .index_put_((torch.arange(r[0], r[1], device=eng.device)[:, None],
+                                  torch.arange(r[2], r[3], device=eng.device)[None, :]),
+                                 torch.ones((), device=eng.device))) for r in plan.rects)
+        assert int(cover.max()) > 12             # the slot overflow path really ran
+
+
 @pytest.mark.parametrize("name", SCENES)
 @pytest.mark.parametrize("levels", [1, 2, 5, 6])
 def test_fused_windows_equal_whole_patch_path(eng, name, levels):
