@@ -46,35 +46,27 @@ __global__ __launch_bounds__(256) void ownership_kernel(
 // the operations pano_warp_spherical uses, so the owner map is identical to
 // the one computed from warped alpha planes.
 //
-// Cost is arithmetic (about 110 instructions per pixel and covering camera, a
-// third of it the exact inverse map, the rest the taps and the alpha sample).
-// Only the winner's alpha matters, so the second part is pruned exactly: the
-// taps lie within 1 + 1/64 px of the mapped point (1/32-px rounding, then the
-// two neighbours), hence hat(tap) <= 0.5 - (|p - n/2| - 1.1)/n on each axis and
-// the product of the two bounds (x 1.00001 for float32 rounding) is an upper
-// bound of alpha.  Pass 1 maps every covering camera (exact, also settles
-// `valid`) and parks (px, py, index) in LDS; the camera with the largest bound
-// is sampled first and the others only if their bound reaches the running
-// maximum.  First-index tie-breaking is kept by comparing indices on equality.
-#define OWN_SLOTS 12
+// Cost is arithmetic (about 110 instructions per pixel and covering camera: 40
+// for the exact inverse map, the rest for the taps and the alpha sample).  Only
+// the winner's alpha matters, so the sampling is pruned - exactly: the taps lie
+// within 1 + 1/64 px of the mapped point (1/32-px rounding, then the two
+// neighbours), so on each axis 0.5 - (|p - n/2| + 1.1)/n <= hat(tap) <=
+// 0.5 - (|p - n/2| - 1.1)/n, and the products of the two lower / upper bounds
+// (with a 1e-5 allowance for float32 rounding) bracket alpha.  Pass 1 maps every
+// covering camera (exact; settles `valid`), parks (px, py) in LDS and keeps the
+// largest LOWER bound; pass 2 walks the cameras again in index order - camera
+// records stay scalar - and samples alpha only where the upper bound reaches
+// that floor and the running maximum.  A camera that could win or tie is
+// therefore always sampled, and index order keeps the first-maximum rule.
+#define OWN_SLOTS 16
 
-__device__ __forceinline__ float hat_bound(float p, int n, float inv_n_lo) {
-    float d = fabsf(p - 0.5f * (float)n) - 1.1f;
-    d = d > 0.0f ? d : 0.0f;
-    return 0.5f - d * inv_n_lo;
-}
-
-__device__ __forceinline__ float alpha_bound(float fx, float fy, int sw, int sh) {
-    const float ub = hat_bound(fx, sw, (1.0f - 1e-6f) / (float)sw) *
-                     hat_bound(fy, sh, (1.0f - 1e-6f) / (float)sh) * 1.00001f;
-    return ub == ub ? ub : 1.0f;             // NaN coordinates: never prune
-}
-
-__device__ __forceinline__ void own_update(float a, int i, float &best, int &who) {
-    if (a > best || (a == best && a > 0.0f && i < who)) {
-        best = a;
-        who = i;
-    }
+__device__ __forceinline__ void hat_bounds(float p, int n, float &lo, float &hi) {
+    const float d = fabsf(p - 0.5f * (float)n), inv = 1.0f / (float)n;
+    float dl = d - 1.1f;
+    dl = dl > 0.0f ? dl : 0.0f;
+    hi = 0.5f - dl * (inv * (1.0f - 1e-6f));
+    lo = 0.5f - (d + 1.1f) * (inv * (1.0f + 1e-6f));
+    lo = lo > 0.0f ? lo : 0.0f;
 }
 
 __global__ __launch_bounds__(256) void ownership_cameras_kernel(
@@ -83,52 +75,65 @@ __global__ __launch_bounds__(256) void ownership_cameras_kernel(
     const double *__restrict__ tan_p, int16_t *__restrict__ owner,
     uint8_t *__restrict__ valid) {
     __shared__ float s_fx[OWN_SLOTS][256], s_fy[OWN_SLOTS][256];
-    __shared__ int16_t s_id[OWN_SLOTS][256];
     const int tid = threadIdx.y * 64 + threadIdx.x;
     const int x = xs0 + blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
     if (x >= xs1 || y >= H) return;
     const double s = sin_t[x], c = cos_t[x], t = tan_p[y];
-    float best = 0.0f, ubmax = -1.0f;
-    int who = -1, cnt = 0, top = -1;
+    const float masked = __int_as_float(0x7fc00001);   // slot marker: alpha * 0
+    float floor_a = 0.0f;        // some camera's alpha is at least this
+    bool any = false;
+    int slot = 0;
     for (int i = 0; i < n; ++i) {
         const pano_camera *cam = cams + i;
         const int px = x - cam->x0, py = y - cam->y0;
         if ((unsigned)px >= (unsigned)cam->w || (unsigned)py >= (unsigned)cam->h) continue;
         float fx, fy;
         const int sw = cam->sw, sh = cam->sh;
-        if (map_pixel(cam->proj, s, c, t, sw, sh, fx, fy)) continue;   // alpha * 0
-        if (cnt < OWN_SLOTS) {
-            s_fx[cnt][tid] = fx;
-            s_fy[cnt][tid] = fy;
-            s_id[cnt][tid] = (int16_t)i;
-            const float ub = alpha_bound(fx, fy, sw, sh);
-            if (ub > ubmax) {
-                ubmax = ub;
-                top = cnt;
-            }
-            ++cnt;
-        } else {                              // more cameras than slots: sample now
-            const Taps tp = make_taps(fx, fy, sw, sh);
-            own_update(alpha_at(cam->hat_x, cam->hat_y, tp), i, best, who);
-            cnt = OWN_SLOTS + 1;
+        const bool m = map_pixel(cam->proj, s, c, t, sw, sh, fx, fy);
+        if (!m) {
+            any = true;
+            float xl, xh, yl, yh;
+            hat_bounds(fx, sw, xl, xh);
+            hat_bounds(fy, sh, yl, yh);
+            const float lb = xl * yl * 0.99999f;
+            if (lb > floor_a) floor_a = lb;
         }
+        if (slot < OWN_SLOTS) {
+            s_fx[slot][tid] = m ? masked : fx;
+            s_fy[slot][tid] = fy;
+        }
+        ++slot;
     }
-    const bool any = cnt > 0;
-    if (cnt > OWN_SLOTS) cnt = OWN_SLOTS;
-    if (top >= 0) {
-        const int i = s_id[top][tid];
+    float best = 0.0f;
+    int who = -1;
+    slot = 0;
+    for (int i = 0; i < n; ++i) {
         const pano_camera *cam = cams + i;
-        const Taps tp = make_taps(s_fx[top][tid], s_fy[top][tid], cam->sw, cam->sh);
-        own_update(alpha_at(cam->hat_x, cam->hat_y, tp), i, best, who);
-    }
-    for (int j = 0; j < cnt; ++j) {
-        if (j == top) continue;
-        const int i = s_id[j][tid];
-        const pano_camera *cam = cams + i;
-        const float fx = s_fx[j][tid], fy = s_fy[j][tid];
-        if (!(alpha_bound(fx, fy, cam->sw, cam->sh) >= best)) continue;   // cannot win or tie
-        const Taps tp = make_taps(fx, fy, cam->sw, cam->sh);
-        own_update(alpha_at(cam->hat_x, cam->hat_y, tp), i, best, who);
+        const int px = x - cam->x0, py = y - cam->y0;
+        if ((unsigned)px >= (unsigned)cam->w || (unsigned)py >= (unsigned)cam->h) continue;
+        const int sw = cam->sw, sh = cam->sh;
+        float fx, fy;
+        const int j = slot++;
+        if (j < OWN_SLOTS) {
+            fx = s_fx[j][tid];
+            fy = s_fy[j][tid];
+            if (__float_as_int(fx) == 0x7fc00001) continue;
+            float xl, xh, yl, yh;
+            hat_bounds(fx, sw, xl, xh);
+            hat_bounds(fy, sh, yl, yh);
+            const float ub = xh * yh * 1.00001f;
+            // ub < floor: another camera beats it; ub < best: an earlier one does.
+            // (NaN coordinates make ub NaN: never pruned.)
+            if (ub < floor_a || ub < best) continue;
+        } else if (map_pixel(cam->proj, s, c, t, sw, sh, fx, fy)) {   // out of slots
+            continue;
+        }
+        const Taps tp = make_taps(fx, fy, sw, sh);
+        const float a = alpha_at(cam->hat_x, cam->hat_y, tp);
+        if (a > best) {          // strict: the first maximum keeps the pixel
+            best = a;
+            who = i;
+        }
     }
     owner[(size_t)y * W + x] = (int16_t)who;
     valid[(size_t)y * W + x] = any ? 1 : 0;
