@@ -46,88 +46,65 @@ __global__ __launch_bounds__(256) void ownership_kernel(
 // the operations pano_warp_spherical uses, so the owner map is identical to
 // the one computed from warped alpha planes.
 //
-// Cost is arithmetic (about 110 instructions per pixel and covering camera: 40
-// for the exact inverse map, the rest for the taps and the alpha sample).  Only
-// the winner's alpha matters, so the sampling is pruned - exactly: the taps lie
-// within 1 + 1/64 px of the mapped point (1/32-px rounding, then the two
-// neighbours), so on each axis 0.5 - (|p - n/2| + 1.1)/n <= hat(tap) <=
-// 0.5 - (|p - n/2| - 1.1)/n, and the products of the two lower / upper bounds
-// (with a 1e-5 allowance for float32 rounding) bracket alpha.  Pass 1 maps every
-// covering camera (exact; settles `valid`), parks (px, py) in LDS and keeps the
-// largest LOWER bound; pass 2 walks the cameras again in index order - camera
-// records stay scalar - and samples alpha only where the upper bound reaches
-// that floor and the running maximum.  A camera that could win or tie is
-// therefore always sampled, and index order keeps the first-maximum rule.
-#define OWN_SLOTS 16
-
-__device__ __forceinline__ void hat_bounds(float p, int n, float &lo, float &hi) {
-    const float d = fabsf(p - 0.5f * (float)n), inv = 1.0f / (float)n;
-    float dl = d - 1.1f;
-    dl = dl > 0.0f ? dl : 0.0f;
-    hi = 0.5f - dl * (inv * (1.0f - 1e-6f));
-    lo = 0.5f - (d + 1.1f) * (inv * (1.0f + 1e-6f));
-    lo = lo > 0.0f ? lo : 0.0f;
-}
+// About 110 vector instructions per (pixel, covering camera) - but the walk over
+// the camera table is what a naive loop pays for: ~20 scalar instructions and a
+// dependent scalar load per camera and wave, for all n cameras, when only the
+// ~10 whose patch rectangle meets this 64 x 4 block matter.  The block therefore
+// first builds that short list (ordered, so the first-maximum rule survives) in
+// LDS with a ballot compaction, and every wave walks only the list.
+#define OWN_LIST 256
 
 __global__ __launch_bounds__(256) void ownership_cameras_kernel(
     const pano_camera *__restrict__ cams, int n, int H, int W, int xs0, int xs1,
     const double *__restrict__ sin_t, const double *__restrict__ cos_t,
     const double *__restrict__ tan_p, int16_t *__restrict__ owner,
     uint8_t *__restrict__ valid) {
-    __shared__ float s_fx[OWN_SLOTS][256], s_fy[OWN_SLOTS][256];
-    const int tid = threadIdx.y * 64 + threadIdx.x;
-    const int x = xs0 + blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+    __shared__ int s_list[OWN_LIST];
+    __shared__ int s_wave[4];
+    __shared__ int s_count;
+    const int tid = threadIdx.y * 64 + threadIdx.x, lane = threadIdx.x, wave = threadIdx.y;
+    const int bx0 = xs0 + blockIdx.x * 64, by0 = blockIdx.y * 4;
+    const int bx1 = min(bx0 + 64, xs1), by1 = min(by0 + 4, H);       // block pixels [.., ..)
+    if (tid == 0) s_count = 0;
+    __syncthreads();
+    bool overflow = false;
+    for (int base = 0; base < n; base += 256) {
+        const int i = base + tid;
+        bool hit = false;
+        if (i < n) {
+            const pano_camera *cam = cams + i;
+            hit = cam->x0 < bx1 && cam->x0 + cam->w > bx0 && cam->y0 < by1 && cam->y0 + cam->h > by0;
+        }
+        const unsigned long long bal = __ballot(hit);
+        if (lane == 0) s_wave[wave] = __popcll(bal);
+        __syncthreads();
+        int off = s_count;
+        for (int w = 0; w < wave; ++w) off += s_wave[w];
+        const int total = s_count + s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+        off += __popcll(bal & ((1ull << lane) - 1ull));
+        if (hit && off < OWN_LIST) s_list[off] = i;
+        __syncthreads();
+        if (tid == 0) s_count = total;
+        if (total > OWN_LIST) overflow = true;                       // uniform across the block
+        __syncthreads();
+    }
+    const int ncand = overflow ? n : s_count;
+
+    const int x = bx0 + threadIdx.x, y = by0 + threadIdx.y;
     if (x >= xs1 || y >= H) return;
     const double s = sin_t[x], c = cos_t[x], t = tan_p[y];
-    const float masked = __int_as_float(0x7fc00001);   // slot marker: alpha * 0
-    float floor_a = 0.0f;        // some camera's alpha is at least this
-    bool any = false;
-    int slot = 0;
-    for (int i = 0; i < n; ++i) {
-        const pano_camera *cam = cams + i;
-        const int px = x - cam->x0, py = y - cam->y0;
-        if ((unsigned)px >= (unsigned)cam->w || (unsigned)py >= (unsigned)cam->h) continue;
-        float fx, fy;
-        const int sw = cam->sw, sh = cam->sh;
-        const bool m = map_pixel(cam->proj, s, c, t, sw, sh, fx, fy);
-        if (!m) {
-            any = true;
-            float xl, xh, yl, yh;
-            hat_bounds(fx, sw, xl, xh);
-            hat_bounds(fy, sh, yl, yh);
-            const float lb = xl * yl * 0.99999f;
-            if (lb > floor_a) floor_a = lb;
-        }
-        if (slot < OWN_SLOTS) {
-            s_fx[slot][tid] = m ? masked : fx;
-            s_fy[slot][tid] = fy;
-        }
-        ++slot;
-    }
     float best = 0.0f;
     int who = -1;
-    slot = 0;
-    for (int i = 0; i < n; ++i) {
+    bool any = false;
+    for (int k = 0; k < ncand; ++k) {
+        const int i = overflow ? k : __builtin_amdgcn_readfirstlane(s_list[k]);
         const pano_camera *cam = cams + i;
         const int px = x - cam->x0, py = y - cam->y0;
         if ((unsigned)px >= (unsigned)cam->w || (unsigned)py >= (unsigned)cam->h) continue;
-        const int sw = cam->sw, sh = cam->sh;
         float fx, fy;
-        const int j = slot++;
-        if (j < OWN_SLOTS) {
-            fx = s_fx[j][tid];
-            fy = s_fy[j][tid];
-            if (__float_as_int(fx) == 0x7fc00001) continue;
-            float xl, xh, yl, yh;
-            hat_bounds(fx, sw, xl, xh);
-            hat_bounds(fy, sh, yl, yh);
-            const float ub = xh * yh * 1.00001f;
-            // ub < floor: another camera beats it; ub < best: an earlier one does.
-            // (NaN coordinates make ub NaN: never pruned.)
-            if (ub < floor_a || ub < best) continue;
-        } else if (map_pixel(cam->proj, s, c, t, sw, sh, fx, fy)) {   // out of slots
-            continue;
-        }
+        const int sw = cam->sw, sh = cam->sh;
+        if (map_pixel(cam->proj, s, c, t, sw, sh, fx, fy)) continue;   // alpha * 0
+        any = true;
         const Taps tp = make_taps(fx, fy, sw, sh);
         const float a = alpha_at(cam->hat_x, cam->hat_y, tp);
         if (a > best) {          // strict: the first maximum keeps the pixel
