@@ -181,7 +181,19 @@ int pano_multiband_compose(const pano_patch *patches, int n, int H, int W,
                            const int16_t *owner, const uint8_t *valid,
                            uint8_t *mosaic, float *mosaic_f32, void *stream);
 
-/* linear_blend                                          stitcher.py:171-183 */
+/* linear_blend (linear != 0) or no_blend (linear == 0) of the mosaic columns
+ * [xs0, xs1) straight from the frames         stitcher.py:160-183 + :300-317
+ * No patch is materialised: per mosaic pixel the covering cameras (UNPADDED
+ * patch rectangles, stitcher.py:289-291) are mapped, sampled and combined in
+ * index order.  cams: dev array with frame pointers set.  valid (optional,
+ * dev uint8 [H][W]) receives _valid (stitcher.py:266-271) for the strip. */
+int pano_blend_cameras(const pano_camera *cams, int n, int H, int W, int xs0,
+                       int xs1, int linear, const double *sin_t,
+                       const double *cos_t, const double *tan_p,
+                       const float *lut255, uint8_t *mosaic, uint8_t *valid,
+                       void *stream);
+
+/* linear_blend on warped patches                        stitcher.py:171-183 */
 int pano_linear_blend(const pano_patch *patches, int n, int H, int W,
                       uint8_t *mosaic, void *stream);
 

@@ -62,6 +62,7 @@ _SIGNATURES = {
     "pano_multiband_blur": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _vp,
                                  C.POINTER(C.c_int), _i, _vp]),
     "pano_multiband_compose": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "pano_blend_cameras": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "pano_linear_blend": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "pano_no_blend": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "pano_crop_rect": (_i, [_vp, _i, _i, _vp, _vp, _vp]),

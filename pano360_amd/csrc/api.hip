@@ -40,7 +40,8 @@ static const char *const g_kernel_names[PK_COUNT] = {
     "add_weights_kernel", "warp_spherical_kernel", "ownership_kernel", "blur_rows_kernel",
     "blur_cols_kernel",   "multiband_compose_kernel", "linear_blend_kernel",
     "no_blend_kernel",    "crop_heights_kernel", "crop_rows_kernel", "pyr_down_kernel",
-    "ownership_cameras_kernel", "owned_boxes_kernel", "warp_windows_kernel"};
+    "ownership_cameras_kernel", "owned_boxes_kernel", "warp_windows_kernel",
+    "blend_cameras_kernel"};
 
 void pano_timing_edge(int kid, hipStream_t stream, bool begin) {
     hipEvent_t ev;

@@ -54,18 +54,19 @@ __global__ __launch_bounds__(256) void ownership_kernel(
 // LDS with a ballot compaction, and every wave walks only the list.
 #define OWN_LIST 256
 
-__global__ __launch_bounds__(256) void ownership_cameras_kernel(
-    const pano_camera *__restrict__ cams, int n, int H, int W, int xs0, int xs1,
-    const double *__restrict__ sin_t, const double *__restrict__ cos_t,
-    const double *__restrict__ tan_p, int16_t *__restrict__ owner,
-    uint8_t *__restrict__ valid) {
-    __shared__ int s_list[OWN_LIST];
-    __shared__ int s_wave[4];
-    __shared__ int s_count;
+struct CamList {
+    int list[OWN_LIST];
+    int wave[4];
+    int count;
+};
+
+// Ordered list of the cameras whose patch rectangle meets the block's pixels
+// [bx0, bx1) x [by0, by1); returns its length, or -1 when it does not fit (the
+// caller then walks all n cameras).  Every thread of the 256-thread block calls it.
+__device__ __forceinline__ int build_camera_list(CamList &sh, const pano_camera *__restrict__ cams,
+                                                 int n, int bx0, int bx1, int by0, int by1) {
     const int tid = threadIdx.y * 64 + threadIdx.x, lane = threadIdx.x, wave = threadIdx.y;
-    const int bx0 = xs0 + blockIdx.x * 64, by0 = blockIdx.y * 4;
-    const int bx1 = min(bx0 + 64, xs1), by1 = min(by0 + 4, H);       // block pixels [.., ..)
-    if (tid == 0) s_count = 0;
+    if (tid == 0) sh.count = 0;
     __syncthreads();
     bool overflow = false;
     for (int base = 0; base < n; base += 256) {
@@ -76,19 +77,31 @@ __global__ __launch_bounds__(256) void ownership_cameras_kernel(
             hit = cam->x0 < bx1 && cam->x0 + cam->w > bx0 && cam->y0 < by1 && cam->y0 + cam->h > by0;
         }
         const unsigned long long bal = __ballot(hit);
-        if (lane == 0) s_wave[wave] = __popcll(bal);
+        if (lane == 0) sh.wave[wave] = __popcll(bal);
         __syncthreads();
-        int off = s_count;
-        for (int w = 0; w < wave; ++w) off += s_wave[w];
-        const int total = s_count + s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+        int off = sh.count;
+        for (int w = 0; w < wave; ++w) off += sh.wave[w];
+        const int total = sh.count + sh.wave[0] + sh.wave[1] + sh.wave[2] + sh.wave[3];
         off += __popcll(bal & ((1ull << lane) - 1ull));
-        if (hit && off < OWN_LIST) s_list[off] = i;
+        if (hit && off < OWN_LIST) sh.list[off] = i;
         __syncthreads();
-        if (tid == 0) s_count = total;
+        if (tid == 0) sh.count = total;
         if (total > OWN_LIST) overflow = true;                       // uniform across the block
         __syncthreads();
     }
-    const int ncand = overflow ? n : s_count;
+    return overflow ? -1 : sh.count;
+}
+
+__global__ __launch_bounds__(256) void ownership_cameras_kernel(
+    const pano_camera *__restrict__ cams, int n, int H, int W, int xs0, int xs1,
+    const double *__restrict__ sin_t, const double *__restrict__ cos_t,
+    const double *__restrict__ tan_p, int16_t *__restrict__ owner,
+    uint8_t *__restrict__ valid) {
+    __shared__ CamList sh;
+    const int bx0 = xs0 + blockIdx.x * 64, by0 = blockIdx.y * 4;
+    const int listed = build_camera_list(sh, cams, n, bx0, min(bx0 + 64, xs1), by0,
+                                         min(by0 + 4, H));
+    const int ncand = listed < 0 ? n : listed;
 
     const int x = bx0 + threadIdx.x, y = by0 + threadIdx.y;
     if (x >= xs1 || y >= H) return;
@@ -97,15 +110,15 @@ __global__ __launch_bounds__(256) void ownership_cameras_kernel(
     int who = -1;
     bool any = false;
     for (int k = 0; k < ncand; ++k) {
-        const int i = overflow ? k : __builtin_amdgcn_readfirstlane(s_list[k]);
+        const int i = listed < 0 ? k : __builtin_amdgcn_readfirstlane(sh.list[k]);
         const pano_camera *cam = cams + i;
         const int px = x - cam->x0, py = y - cam->y0;
         if ((unsigned)px >= (unsigned)cam->w || (unsigned)py >= (unsigned)cam->h) continue;
         float fx, fy;
-        const int sw = cam->sw, sh = cam->sh;
-        if (map_pixel(cam->proj, s, c, t, sw, sh, fx, fy)) continue;   // alpha * 0
+        const int sw = cam->sw, sh_ = cam->sh;
+        if (map_pixel(cam->proj, s, c, t, sw, sh_, fx, fy)) continue;   // alpha * 0
         any = true;
-        const Taps tp = make_taps(fx, fy, sw, sh);
+        const Taps tp = make_taps(fx, fy, sw, sh_);
         const float a = alpha_at(cam->hat_x, cam->hat_y, tp);
         if (a > best) {          // strict: the first maximum keeps the pixel
             best = a;
@@ -114,6 +127,76 @@ __global__ __launch_bounds__(256) void ownership_cameras_kernel(
     }
     owner[(size_t)y * W + x] = (int16_t)who;
     valid[(size_t)y * W + x] = any ? 1 : 0;
+}
+
+// ---- linear_blend / no_blend straight from the frames (fused path) --------------
+// stitcher.py:160-183 without materialising any patch: per mosaic pixel the
+// covering cameras are mapped, unmasked ones sampled (same taps, LUT and alpha as
+// the warp kernel) and combined in index order, exactly the reference's sums.
+// A masked sample contributes tile = 0 and alpha = 0 (stitcher.py:176, 317), i.e.
+// nothing, so it is skipped; no_blend keeps the LAST unmasked camera (:164-166).
+// Reads 3 bytes of frame per sampled tap (L1/L2 absorb the 4-tap overlap),
+// writes 3 B per mosaic pixel: HBM-light, bound by the per-sample arithmetic.
+template <bool LINEAR>
+__global__ __launch_bounds__(256) void blend_cameras_kernel(
+    const pano_camera *__restrict__ cams, int n, int H, int W, int xs0, int xs1,
+    const double *__restrict__ sin_t, const double *__restrict__ cos_t,
+    const double *__restrict__ tan_p, const float *__restrict__ lut255,
+    uint8_t *__restrict__ mosaic, uint8_t *__restrict__ valid) {
+    __shared__ CamList sh;
+    __shared__ float s_lut[256];
+    s_lut[threadIdx.y * 64 + threadIdx.x] = lut255[threadIdx.y * 64 + threadIdx.x];
+    const int bx0 = xs0 + blockIdx.x * 64, by0 = blockIdx.y * 4;
+    const int listed = build_camera_list(sh, cams, n, bx0, min(bx0 + 64, xs1), by0,
+                                         min(by0 + 4, H));     // has the barriers s_lut needs
+    const int ncand = listed < 0 ? n : listed;
+
+    const int x = bx0 + threadIdx.x, y = by0 + threadIdx.y;
+    if (x >= xs1 || y >= H) return;
+    const double s = sin_t[x], c = cos_t[x], t = tan_p[y];
+    float acc[3] = {0.0f, 0.0f, 0.0f}, wsum = 0.0f;
+    uint8_t last[3] = {0, 0, 0};
+    bool any = false;
+    for (int k = 0; k < ncand; ++k) {
+        const int i = listed < 0 ? k : __builtin_amdgcn_readfirstlane(sh.list[k]);
+        const pano_camera *cam = cams + i;
+        const int px = x - cam->x0, py = y - cam->y0;
+        if ((unsigned)px >= (unsigned)cam->w || (unsigned)py >= (unsigned)cam->h) continue;
+        float fx, fy;
+        const int sw = cam->sw, sh_ = cam->sh;
+        if (map_pixel(cam->proj, s, c, t, sw, sh_, fx, fy)) continue;
+        any = true;
+        const Taps tp = make_taps(fx, fy, sw, sh_);
+        const uint8_t *__restrict__ frame = cam->frame;
+        const uint8_t *r0 = frame + (size_t)tp.y0 * sw * 3, *r1 = frame + (size_t)tp.y1 * sw * 3;
+        const uint8_t *p00 = r0 + tp.x0 * 3, *p01 = r0 + tp.x1 * 3;
+        const uint8_t *p10 = r1 + tp.x0 * 3, *p11 = r1 + tp.x1 * 3;
+        float rgb[3];
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch)
+            rgb[ch] = lerp4(s_lut[p00[ch]], s_lut[p01[ch]], s_lut[p10[ch]], s_lut[p11[ch]], tp);
+        if (LINEAR) {
+            const float a = alpha_at(cam->hat_x, cam->hat_y, tp);
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) acc[ch] = acc[ch] + rgb[ch] * a;         // :177
+            wsum = wsum + a;                                                         // :178
+        } else {
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) last[ch] = (uint8_t)(int)(255.0f * rgb[ch]);   // :166
+        }
+    }
+    const size_t g = ((size_t)y * W + x) * 3;
+    if (LINEAR) {
+        const float ws = wsum == 0.0f ? 1.0f : wsum;                                 // :180
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch)
+            mosaic[g + ch] = (uint8_t)(int)(255.0f * __fdiv_rn(acc[ch], ws));         // :181-183
+    } else {
+        mosaic[g] = last[0];
+        mosaic[g + 1] = last[1];
+        mosaic[g + 2] = last[2];
+    }
+    if (valid) valid[(size_t)y * W + x] = any ? 1 : 0;
 }
 
 // Bounding boxes of the owned regions.  Same-address atomics serialise in L2,
@@ -305,6 +388,29 @@ extern "C" int pano_ownership_cameras(const pano_camera *cams, int n, int H, int
                                   (hipStream_t)stream, cams, n, H, W, xs0, xs1, sin_t, cos_t,
                                   tan_p, owner, valid));
     PANO_LAUNCH_CHECK("ownership_cameras_kernel");
+    return PANO_OK;
+}
+
+extern "C" int pano_blend_cameras(const pano_camera *cams, int n, int H, int W, int xs0,
+                                  int xs1, int linear, const double *sin_t,
+                                  const double *cos_t, const double *tan_p,
+                                  const float *lut255, uint8_t *mosaic, uint8_t *valid,
+                                  void *stream) {
+    if (int rc = check_table(cams, n, H, W, "pano_blend_cameras")) return rc;
+    PANO_REQUIRE(sin_t && cos_t && tan_p && lut255 && mosaic, "pano_blend_cameras: null pointer");
+    PANO_REQUIRE(xs0 >= 0 && xs1 <= W && xs0 <= xs1, "pano_blend_cameras: bad strip [%d, %d)", xs0, xs1);
+    if (xs0 == xs1) return PANO_OK;
+    dim3 block(64, 4), grid(ceil_div(xs1 - xs0, 64), ceil_div(H, 4));
+    hipStream_t s = (hipStream_t)stream;
+    if (linear)
+        PANO_TIMED(PK_BLEND_CAMERAS, s,
+                   hipLaunchKernelGGL(blend_cameras_kernel<true>, grid, block, 0, s, cams, n, H, W,
+                                      xs0, xs1, sin_t, cos_t, tan_p, lut255, mosaic, valid));
+    else
+        PANO_TIMED(PK_BLEND_CAMERAS, s,
+                   hipLaunchKernelGGL(blend_cameras_kernel<false>, grid, block, 0, s, cams, n, H, W,
+                                      xs0, xs1, sin_t, cos_t, tan_p, lut255, mosaic, valid));
+    PANO_LAUNCH_CHECK("blend_cameras_kernel");
     return PANO_OK;
 }
 

@@ -51,6 +51,7 @@ enum PanoKernelId {
     PK_OWNERSHIP_CAMS,
     PK_OWNED_BOXES,
     PK_WARP_WINDOWS,
+    PK_BLEND_CAMERAS,
     PK_COUNT
 };
 extern bool g_pano_timing_on;

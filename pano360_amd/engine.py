@@ -571,6 +571,28 @@ class Engine:
                                            want_float, (c0, c1))
         return mosaic, fl, valid, patches
 
+    def blend_fused(self, frames, plan, linear, frame_ids=None, strip=None):
+        """linear_blend / no_blend of the mosaic columns ``strip`` straight from
+        the frames (no patch buffers).  Returns (mosaic u8, valid u8)."""
+        torch = _torch()
+        H, W = plan.shape
+        c0, c1 = strip if strip is not None else (0, W)
+        ids = list(range(plan.n)) if frame_ids is None else list(frame_ids)
+        have = dict(zip(ids, frames))
+        missing = [i for i, (_, _, x0, x1) in enumerate(plan.rects)
+                   if x0 < c1 and x1 > c0 and i not in have]
+        if missing:
+            raise _lib.PanoError(f"frames {missing} are needed for columns [{c0}, {c1}) "
+                                 "but are not resident on this device")
+        cams = self.camera_table(plan, have)
+        mosaic = torch.empty((H, W, 3), dtype=torch.uint8, device=self.device)
+        valid = torch.empty((H, W), dtype=torch.uint8, device=self.device)
+        _lib.check(self.lib.pano_blend_cameras(
+            _ptr(cams), plan.n, H, W, c0, c1, 1 if linear else 0, _ptr(plan.dev[0]),
+            _ptr(plan.dev[1]), _ptr(plan.dev[2]), _ptr(self.lut255), _ptr(mosaic), _ptr(valid),
+            self.stream()), "pano_blend_cameras")
+        return mosaic, valid
+
     # -- crop and filters -------------------------------------------------------------
     def crop_rect(self, valid):
         """Rectangle (y0, x0, h, w) of crop_mosaic, or None when nothing is valid."""
@@ -619,6 +641,9 @@ class Engine:
             self.upload_plan(plan)
         if blend == "multiband" and fused:
             return self.multiband_fused(frames, plan, n_levels, want_float)
+        if fused:
+            mosaic, valid = self.blend_fused(frames, plan, blend == "linear")
+            return mosaic, None, valid, []
         n_blur = n_levels - 1 if blend == "multiband" else 0
         patches, _ = self.warp_all(frames, plan, n_blur)
         table = patch_table(patches, self.device)

@@ -331,6 +331,37 @@ def test_sharded_stitcher_world_1_equals_stitch(eng):
                             frame_ids=[0, 1])
 
 
+def test_cli_plumbing_config_1(eng, oracle, tmp_path, monkeypatch):
+    """BASELINE config 1 (`stitcher.py DIR --shrink 4 --blend linear`): the CMU2
+    images are not redistributable, so the plumbing runs on a synthetic directory
+    plus the `ba_<name>_s<shrink>.pkl` camera cache the reference CLI writes
+    (stitcher.py:414, 430-439).  The written image must equal the oracle's
+    linear mosaic."""
+    import pickle
+    from PIL import Image as PilImage
+    import bundle_adj
+    import stitcher as top
+    from pano360_amd import synth
+    imgs, rots, intrs = synth.make_scene(5, 200, 120, sweep_deg=80.0, jitter=0.01, seed=9,
+                                         kind="B")
+    data = tmp_path / "CMU2"
+    data.mkdir()
+    for i, im in enumerate(imgs):
+        PilImage.fromarray(im).save(data / f"frame{i}.png")
+    regions = [bundle_adj.Image(im, r, k) for im, r, k in zip(imgs, rots, intrs)]
+    with open(tmp_path / "ba_CMU2_s4.0.pkl", "wb") as fid:
+        pickle.dump(regions, fid, protocol=pickle.HIGHEST_PROTOCOL)
+    monkeypatch.chdir(tmp_path)
+    out = tmp_path / "mosaic.png"
+    got = top.main([str(data), "--shrink", "4", "--blend", "linear", "-c", "-o", str(out)])
+    want = oracle.stitch(imgs, rots, intrs, "linear", crop=True)
+    assert np.array_equal(got, want)
+    # cv2.imwrite stores BGR; the file holds the same pixels, channels reversed
+    assert np.array_equal(np.asarray(PilImage.open(out))[..., ::-1], want)
+    with pytest.raises(SystemExit):      # no camera cache: registration is out of scope
+        top.main([str(tmp_path / "nowhere"), "-b", "linear"])
+
+
 # ------------------------------------------------------------------- crop
 def test_crop_rectangles_bit_exact(eng, oracle):
     import torch
@@ -409,6 +440,11 @@ def test_full_size_properties_1080p(eng):
     # the paste blender covers exactly the valid area of the unpadded plan
     plan_l = eng.upload_plan(engine.Plan([im.shape[:2] for im in imgs], rots, intrs, False,
                                          10 ** 9))
-    non, _, _, patches = eng.stitch(frames, plan_l, "none")
+    non, _, valid_f, _ = eng.stitch(frames, plan_l, "none")
+    non_staged, _, _, patches = eng.stitch(frames, plan_l, "none", fused=False)
     _, valid_l = eng.ownership(engine.patch_table(patches, eng.device), plan_l.shape)
+    assert torch.equal(non, non_staged) and torch.equal(valid_f, valid_l)
     assert torch.equal(non.any(-1), valid_l.bool())
+    lin, _, _, _ = eng.stitch(frames, plan_l, "linear")
+    lin_staged, _, _, _ = eng.stitch(frames, plan_l, "linear", fused=False)
+    assert torch.equal(lin, lin_staged)
