@@ -413,6 +413,35 @@ def test_gaussian_filter_and_pyr_down(eng, oracle):
     assert np.array_equal(bits(features.pyr_down(p1)), bits(g["pyr_2"]))
 
 
+@pytest.mark.parametrize("shape", [(48, 64), (61, 35)])
+def test_sift_scale_space_matches_oracle(eng, shape):
+    """Gaussian / DoG pyramid of the SIFT front end (features.py:192-201 via
+    OpenCV; restated, parity unpinned): grey conversion, 2x bilinear base and
+    nearest halving are exact, the blurred layers agree to float tolerance
+    (values are on the 0..255 scale, one FMA per tap vs mul+add)."""
+    import sift_pyramid as ref
+    from pano360_amd import features
+    img = np.random.default_rng(3).integers(0, 256, shape + (3,), dtype=np.uint8)
+    gauss, dog = features.sift_pyramid(img)
+    want_g, want_d = ref.sift_pyramid(img)
+    assert len(gauss) == len(want_g) == features.sift_octaves(*shape) == ref.n_octaves(*shape)
+    for o, (go, wo) in enumerate(zip(gauss, want_g)):
+        assert len(go) == len(wo) == 6 and len(dog[o]) == 5
+        for layer, (a, b) in enumerate(zip(go, wo)):
+            assert a.shape == b.shape, (o, layer)
+            assert np.abs(a - b).max() <= 2e-4, (o, layer)
+        for layer, (a, b) in enumerate(zip(dog[o], want_d[o])):
+            assert np.abs(a - b).max() <= 4e-4, (o, layer)
+    # the exact pieces, bit for bit
+    dev = features._Dev(eng)
+    frame = eng.upload_frames([img])[0]
+    gray = dev.gray(frame)
+    assert np.array_equal(gray.cpu().numpy(), ref.gray_u8(img))
+    assert np.array_equal(bits(dev.up2(gray).cpu().numpy()), bits(ref.resize_up2(ref.gray_u8(img))))
+    assert np.array_equal(dev.half(gray).cpu().numpy(), ref.decimate2(ref.gray_u8(img)))
+    assert features.sift_sigmas() == ref.sigmas()
+
+
 # ------------------------------------------- size-independent properties
 def test_full_size_properties_1080p(eng):
     """BASELINE config 2 at full size (8 x 1080p, native resolution), checked
