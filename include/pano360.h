@@ -67,6 +67,12 @@ typedef struct pano_patch {
     int32_t vy0, vx0, vh, vw;  /* window V, patch-local                     */
     int32_t ay0, ax0, ah, aw;  /* rectangle A, patch-local                  */
     int32_t vpitch, apitch;    /* floats per row of planes / blurred        */
+    int32_t index;             /* camera / owner-map index this record belongs
+                                  to: a patch whose owned pixels fall into
+                                  several far-apart column spans (a frame that
+                                  straddles the +-pi seam of a 360 degree sweep)
+                                  is split into one record per span           */
+    int32_t reserved;
 } pano_patch;
 
 /* One registered frame (reference: bundle_adj.Image, bundle_adj.py:18-33,
@@ -151,6 +157,16 @@ int pano_ownership_cameras(const pano_camera *cams, int n, int H, int W,
  * mosaic coordinates; ymax < ymin when the patch owns nothing there. */
 int pano_owned_boxes(const int16_t *owner, int H, int W, int xs0, int xs1,
                      int n, int32_t *boxes, void *stream);
+
+/* Column spans of each patch's owned pixels inside the strip [xs0, xs1): runs
+ * of columns in which the patch owns at least one pixel, runs closer than
+ * min_gap columns merged (so that the spans' A rectangles stay disjoint), at
+ * most max_spans per patch (later runs are folded into the last span).
+ * marks: dev uint8 [n][W] workspace; spans: dev int32 [n][max_spans][2]
+ * inclusive column ranges; counts: dev int32 [n]. */
+int pano_owned_spans(const int16_t *owner, int H, int W, int xs0, int xs1,
+                     int n, int min_gap, int max_spans, uint8_t *marks,
+                     int32_t *spans, int32_t *counts, void *stream);
 
 /* The n_levels-1 Gaussian blurs of every patch  stitcher.py:207-208, 218, 226
  * (cv2.GaussianBlur(warped, (0,0), 4*sqrt(2k+1)) with the alpha channel

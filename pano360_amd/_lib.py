@@ -25,13 +25,14 @@ class PanoError(RuntimeError):
 
 
 class Patch(C.Structure):
-    """``pano_patch`` of include/pano360.h (88 bytes)."""
+    """``pano_patch`` of include/pano360.h (96 bytes)."""
     _fields_ = [("planes", C.c_void_p), ("mask", C.c_void_p),
                 ("blurred", C.c_void_p), ("scratch", C.c_void_p),
                 ("y0", C.c_int32), ("x0", C.c_int32), ("h", C.c_int32), ("w", C.c_int32),
                 ("vy0", C.c_int32), ("vx0", C.c_int32), ("vh", C.c_int32), ("vw", C.c_int32),
                 ("ay0", C.c_int32), ("ax0", C.c_int32), ("ah", C.c_int32), ("aw", C.c_int32),
-                ("vpitch", C.c_int32), ("apitch", C.c_int32)]
+                ("vpitch", C.c_int32), ("apitch", C.c_int32),
+                ("index", C.c_int32), ("reserved", C.c_int32)]
 
 
 class Camera(C.Structure):
@@ -59,6 +60,7 @@ _SIGNATURES = {
     "pano_ownership": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp]),
     "pano_ownership_cameras": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "pano_owned_boxes": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    "pano_owned_spans": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "pano_multiband_blur": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _vp,
                                  C.POINTER(C.c_int), _i, _vp]),
     "pano_multiband_compose": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),

@@ -262,7 +262,7 @@ __global__ __launch_bounds__(256) void multiband_compose_kernel(
         float hi[3], ha = 0.0f;                 // the copy that gets the minus
 #pragma unroll
         for (int c = 0; c < 3; ++c) hi[c] = p.planes[c * vplane + vo];
-        if (L == 1) ha = owner[(size_t)y * W + x] == i ? 1.0f : 0.0f;   // sharp alpha (:208)
+        if (L == 1) ha = owner[(size_t)y * W + x] == p.index ? 1.0f : 0.0f;   // sharp alpha (:208)
 #pragma unroll
         for (int k = 0; k < L; ++k) {
             float rgb[3], a;
@@ -429,6 +429,66 @@ extern "C" int pano_owned_boxes(const int16_t *owner, int H, int W, int xs0, int
                hipLaunchKernelGGL(owned_boxes_kernel, grid, block, 0, (hipStream_t)stream,
                                   owner, H, W, xs0, xs1, boxes));
     PANO_LAUNCH_CHECK("owned_boxes_kernel");
+    return PANO_OK;
+}
+
+// Column spans of the owned regions: one thread per mosaic column marks, per
+// owner change down the column, (owner, column); one thread per patch then turns
+// its marks into merged runs.  Both walks are short (H, W steps) and coalesced.
+__global__ __launch_bounds__(256) void owned_marks_kernel(const int16_t *__restrict__ owner,
+                                                          int H, int W, int xs0, int xs1,
+                                                          uint8_t *__restrict__ marks) {
+    const int x = xs0 + blockIdx.x * 256 + threadIdx.x;
+    if (x >= xs1) return;
+    int prev = -1;
+    for (int y = 0; y < H; ++y) {
+        const int o = owner[(size_t)y * W + x];
+        if (o != prev && o >= 0) marks[(size_t)o * W + x] = 1;
+        prev = o;
+    }
+}
+
+__global__ void owned_spans_kernel(const uint8_t *__restrict__ marks, int W, int xs0, int xs1,
+                                   int n, int min_gap, int max_spans,
+                                   int32_t *__restrict__ spans, int32_t *__restrict__ counts) {
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= n) return;
+    const uint8_t *row = marks + (size_t)i * W;
+    int32_t *out = spans + (size_t)i * max_spans * 2;
+    int cnt = 0, last = -1;
+    for (int x = xs0; x < xs1; ++x) {
+        if (!row[x]) continue;
+        if (cnt && (x - last - 1 < min_gap || cnt == max_spans)) {
+            out[2 * (cnt - 1) + 1] = x;               // extend the current span
+        } else {
+            out[2 * cnt] = x;
+            out[2 * cnt + 1] = x;
+            ++cnt;
+        }
+        last = x;
+    }
+    counts[i] = cnt;
+}
+
+extern "C" int pano_owned_spans(const int16_t *owner, int H, int W, int xs0, int xs1, int n,
+                                int min_gap, int max_spans, uint8_t *marks, int32_t *spans,
+                                int32_t *counts, void *stream) {
+    PANO_REQUIRE(owner && marks && spans && counts, "pano_owned_spans: null pointer");
+    PANO_REQUIRE(H > 0 && W > 0 && n >= 0 && n <= 32767 && max_spans >= 1 && min_gap >= 0,
+                 "pano_owned_spans: bad argument");
+    PANO_REQUIRE(xs0 >= 0 && xs1 <= W && xs0 <= xs1, "pano_owned_spans: bad strip [%d, %d)", xs0, xs1);
+    if (n == 0) return PANO_OK;
+    hipStream_t s = (hipStream_t)stream;
+    PANO_HIP(hipMemsetAsync(marks, 0, (size_t)n * W, s));
+    if (xs1 > xs0) {
+        PANO_TIMED(PK_OWNED_SPANS, s,
+                   hipLaunchKernelGGL(owned_marks_kernel, dim3(ceil_div(xs1 - xs0, 256)), dim3(256),
+                                      0, s, owner, H, W, xs0, xs1, marks));
+        PANO_LAUNCH_CHECK("owned_marks_kernel");
+    }
+    hipLaunchKernelGGL(owned_spans_kernel, dim3(ceil_div(n, 64)), dim3(64), 0, s, marks, W, xs0,
+                       xs1, n, min_gap, max_spans, spans, counts);
+    PANO_LAUNCH_CHECK("owned_spans_kernel");
     return PANO_OK;
 }
 

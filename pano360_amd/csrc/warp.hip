@@ -76,7 +76,7 @@ __global__ __launch_bounds__(256) void warp_windows_kernel(
     const int x = blockIdx.x * 64 + threadIdx.x;
     const int y = blockIdx.y * 4 + threadIdx.y;
     if (x >= p.vw || y >= p.vh) return;
-    const pano_camera *cam = cams + blockIdx.z;
+    const pano_camera *cam = cams + p.index;
     const int sw = cam->sw, sh = cam->sh;
     const int gx = p.x0 + p.vx0 + x, gy = p.y0 + p.vy0 + y;
     float px, py;

@@ -192,11 +192,12 @@ def _ptr(t):
 # numpy mirrors of the C records (include/pano360.h), for building tables in bulk
 PATCH_DTYPE = np.dtype([(k, "<u8") for k in ("planes", "mask", "blurred", "scratch")]
                        + [(k, "<i4") for k in ("y0", "x0", "h", "w", "vy0", "vx0", "vh", "vw",
-                                               "ay0", "ax0", "ah", "aw", "vpitch", "apitch")])
+                                               "ay0", "ax0", "ah", "aw", "vpitch", "apitch",
+                                               "index", "reserved")])
 CAMERA_DTYPE = np.dtype([("proj", "<f8", (9,)), ("frame", "<u8"), ("hat_x", "<u8"),
                          ("hat_y", "<u8")]
                         + [(k, "<i4") for k in ("sh", "sw", "y0", "x0", "h", "w")])
-assert PATCH_DTYPE.itemsize == C.sizeof(Patch) == 88
+assert PATCH_DTYPE.itemsize == C.sizeof(Patch) == 96
 assert CAMERA_DTYPE.itemsize == C.sizeof(_lib.Camera) == 120
 
 
@@ -261,12 +262,12 @@ class DevicePatch:
         self.blurred = torch.empty((n_blur, 4, self.h, self.pitch), **f32) if n_blur else None
         self.scratch = torch.empty((n_blur, 4, self.h, self.pitch), **f32) if n_blur else None
 
-    def record(self):
+    def record(self, index):
         y0, _, x0, _ = self.rect
         opt = lambda t: t.data_ptr() if t is not None else 0   # noqa: E731
         return (self.planes.data_ptr(), self.mask.data_ptr(), opt(self.blurred),
                 opt(self.scratch), y0, x0, self.h, self.w, 0, 0, self.h, self.w,
-                0, 0, self.h, self.w, self.pitch, self.pitch)
+                0, 0, self.h, self.w, self.pitch, self.pitch, index, 0)
 
 
 class PatchTable:
@@ -287,7 +288,7 @@ class PatchTable:
 
 def patch_table(patches, device):
     """``pano_patch`` table of stage-level patches."""
-    return PatchTable([p.record() for p in patches], device)
+    return PatchTable([p.record(i) for i, p in enumerate(patches)], device)
 
 
 class WindowInfo:
@@ -300,19 +301,18 @@ class WindowInfo:
 class FusedPatches:
     """Windows of every patch packed into three arenas (colour planes over V,
     blurred copies over A, row-pass scratch) + the patch table pointing into
-    them.  ``windows[i]`` is ``windows_for`` output or None."""
+    them.  ``entries`` = [(camera index, patch rect, ``windows_for`` output)], one
+    per owned column span, in camera order."""
 
-    def __init__(self, rects, windows, device, n_blur):
+    def __init__(self, entries, device, n_blur):
         torch = _torch()
-        n = len(rects)
+        n = len(entries)
         rec = np.zeros(n, dtype=PATCH_DTYPE)
         self.info = []
-        for i, (rect, win) in enumerate(zip(rects, windows)):
+        for i, (index, rect, win) in enumerate(entries):
             y0, y1, x0, x1 = rect
             rec[i]["y0"], rec[i]["x0"], rec[i]["h"], rec[i]["w"] = y0, x0, y1 - y0, x1 - x0
-            if win is None:
-                self.info.append(WindowInfo((0, 0, 0, 0), (0, 0, 0, 0)))
-                continue
+            rec[i]["index"] = index
             (ay0, ay1, ax0, ax1), (vy0, vy1, vx0, vx1) = win
             rec[i]["vy0"], rec[i]["vx0"], rec[i]["vh"], rec[i]["vw"] = vy0, vx0, vy1 - vy0, vx1 - vx0
             rec[i]["ay0"], rec[i]["ax0"], rec[i]["ah"], rec[i]["aw"] = ay0, ax0, ay1 - ay0, ax1 - ax0
@@ -533,6 +533,19 @@ class Engine:
                                              self.stream()), "pano_owned_boxes")
         return boxes.cpu().numpy()
 
+    def owned_spans(self, owner, n, strip, min_gap, max_spans=4):
+        """Per patch, the column runs in which it owns pixels (runs closer than
+        ``min_gap`` merged): host lists of inclusive (xa, xb)."""
+        torch = _torch()
+        H, W = owner.shape
+        marks = torch.empty((n, W), dtype=torch.uint8, device=self.device)
+        spans = torch.empty((n, max_spans, 2), dtype=torch.int32, device=self.device)
+        counts = torch.empty((n,), dtype=torch.int32, device=self.device)
+        _lib.check(self.lib.pano_owned_spans(_ptr(owner), H, W, strip[0], strip[1], n, min_gap,
+                                             max_spans, _ptr(marks), _ptr(spans), _ptr(counts),
+                                             self.stream()), "pano_owned_spans")
+        return spans, counts
+
     def multiband_fused(self, frames, plan, n_levels, want_float=False, frame_ids=None,
                         strip=None):
         """The headline path, for the mosaic columns ``strip`` = (c0, c1) (default:
@@ -554,14 +567,23 @@ class Engine:
         have = dict(zip(ids, frames))
         cams = self.camera_table(plan, have)
         owner, valid = self.ownership_cameras(plan, strip=ext, cams=cams)
-        boxes = self.owned_boxes(owner, plan.n, ext)
-        windows = [windows_for(boxes[i], plan.rects[i], radius, (c0, c1))
-                   for i in range(plan.n)]
-        missing = [i for i, w in enumerate(windows) if w is not None and i not in have]
+        # one record per (patch, span of columns it owns): spans farther apart than
+        # 2R keep disjoint rectangles A, so a pixel still meets a patch at most once
+        spans_d, counts_d = self.owned_spans(owner, plan.n, ext, 2 * radius + 2)
+        boxes = self.owned_boxes(owner, plan.n, ext)              # row extents (and the sync)
+        spans, counts = spans_d.cpu().numpy(), counts_d.cpu().numpy()
+        entries = []
+        for i in range(plan.n):
+            for xa, xb in spans[i, :counts[i]]:
+                win = windows_for((boxes[i][0], boxes[i][1], xa, xb), plan.rects[i], radius,
+                                  (c0, c1))
+                if win is not None:
+                    entries.append((i, plan.rects[i], win))
+        missing = sorted({i for i, _, _ in entries if i not in have})
         if missing:
             raise _lib.PanoError(f"frames {missing} are needed for columns [{c0}, {c1}) "
                                  "but are not resident on this device")
-        patches = FusedPatches(plan.rects, windows, self.device, n_blur)
+        patches = FusedPatches(entries, self.device, n_blur)
         table = patches.table
         _lib.check(self.lib.pano_warp_windows(
             _ptr(cams), table.ptr, table.n, table.max_vw, table.max_vh, _ptr(plan.dev[0]),

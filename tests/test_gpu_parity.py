@@ -292,6 +292,40 @@ def test_fused_windows_on_a_wide_sweep(eng, oracle):
     assert np.abs(m1.cpu().numpy().astype(int) - ref_u8.astype(int)).max() <= 1
 
 
+def test_closed_360_sweep_with_seam_straddling_frames(eng, oracle):
+    """BASELINE config 5 in miniature: a closed 360 degree sweep.  Frames that
+    straddle the +-pi seam get full-width patches (the reference has no
+    wrap-around handling, stitcher.py:107-122) and own pixels at BOTH ends of the
+    mosaic; they are split into one record per column span so that only the
+    neighbourhood of what they own is warped and blurred."""
+    import torch
+    from pano360_amd import engine, synth
+    n, w, h = 24, 160, 90
+    imgs, rots, intrs = synth.make_scene(n, w, h, step_deg=15.0, jitter=0.004, seed=77, kind="B",
+                                         n_levels=6)
+    plan = engine.Plan([(h, w)] * n, rots, intrs, True, 10 ** 9)
+    widths = [r[3] - r[2] for r in plan.rects]
+    assert max(widths) > 0.9 * plan.shape[1] and min(widths) < 0.3 * plan.shape[1]
+    frames = eng.upload_frames(imgs)
+    m1, f1, v1, patches = eng.stitch(frames, plan, "multiband", 6, want_float=True)
+    m2, f2, v2, _ = eng.stitch(frames, plan, "multiband", 6, want_float=True, fused=False)
+    assert torch.equal(m1, m2) and torch.equal(v1, v2)
+    assert torch.equal(f1.view(torch.int32), f2.view(torch.int32))
+    assert len(patches) > n                          # some frame was split into spans
+    assert patches.warped_pixels < 0.6 * plan.patch_pixels
+    ref_u8, ref_f = oracle.stitch(imgs, rots, intrs, "multiband", 6, max_resolution=10 ** 9,
+                                  return_float=True)
+    assert rel_l2(f1.cpu().numpy(), ref_f) <= REL_TOL
+    assert np.abs(m1.cpu().numpy().astype(int) - ref_u8.astype(int)).max() <= 1
+    _, ref_patches, _ = oracle.warp_all(imgs, rots, intrs, True, 10 ** 9)
+    assert np.array_equal(v1.cpu().numpy().astype(bool), oracle.valid(ref_patches, plan.shape))
+    for kind in ("linear", "none"):
+        plan_l = engine.Plan([(h, w)] * n, rots, intrs, False, 10 ** 9)
+        got, _, _, _ = eng.stitch(frames, plan_l, kind)
+        assert np.array_equal(got.cpu().numpy(),
+                              oracle.stitch(imgs, rots, intrs, kind, max_resolution=10 ** 9))
+
+
 @pytest.mark.parametrize("world", [2, 3, 8])
 def test_column_strips_compose_the_single_gpu_mosaic(eng, world):
     """The multi-GPU decomposition, every rank emulated in turn on this one GPU:
