@@ -152,21 +152,17 @@ int pano_ownership_cameras(const pano_camera *cams, int n, int H, int W,
                            const double *cos_t, const double *tan_p,
                            int16_t *owner, uint8_t *valid, void *stream);
 
-/* Bounding box of each patch's owned pixels inside the column strip
- * [xs0, xs1): boxes dev int32 [n][4] = {ymin, ymax, xmin, xmax} inclusive,
- * mosaic coordinates; ymax < ymin when the patch owns nothing there. */
-int pano_owned_boxes(const int16_t *owner, int H, int W, int xs0, int xs1,
-                     int n, int32_t *boxes, void *stream);
-
-/* Column spans of each patch's owned pixels inside the strip [xs0, xs1): runs
- * of columns in which the patch owns at least one pixel, runs closer than
- * min_gap columns merged (so that the spans' A rectangles stay disjoint), at
- * most max_spans per patch (later runs are folded into the last span).
- * marks: dev uint8 [n][W] workspace; spans: dev int32 [n][max_spans][2]
- * inclusive column ranges; counts: dev int32 [n]. */
-int pano_owned_spans(const int16_t *owner, int H, int W, int xs0, int xs1,
-                     int n, int min_gap, int max_spans, uint8_t *marks,
-                     int32_t *spans, int32_t *counts, void *stream);
+/* Where each patch owns pixels inside the column strip [xs0, xs1), one record
+ * of 5 + 2*max_spans int32 per patch:
+ *   {ymin, ymax, xmin, xmax, count, xa_0, xb_0, xa_1, xb_1, ...}
+ * bounding box (inclusive, mosaic coordinates; ymax < ymin when the patch owns
+ * nothing there) and `count` column spans [xa, xb]: runs of columns in which
+ * the patch owns at least one pixel, runs closer than min_gap columns merged
+ * (so that the spans' rectangles A stay disjoint), at most max_spans (later
+ * runs are folded into the last span).  marks: dev uint8 [n][W] workspace. */
+int pano_owned_regions(const int16_t *owner, int H, int W, int xs0, int xs1,
+                       int n, int min_gap, int max_spans, uint8_t *marks,
+                       int32_t *regions, void *stream);
 
 /* The n_levels-1 Gaussian blurs of every patch  stitcher.py:207-208, 218, 226
  * (cv2.GaussianBlur(warped, (0,0), 4*sqrt(2k+1)) with the alpha channel

@@ -59,8 +59,7 @@ _SIGNATURES = {
     "pano_warp_windows": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "pano_ownership": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp]),
     "pano_ownership_cameras": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
-    "pano_owned_boxes": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
-    "pano_owned_spans": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "pano_owned_regions": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "pano_multiband_blur": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _vp,
                                  C.POINTER(C.c_int), _i, _vp]),
     "pano_multiband_compose": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),

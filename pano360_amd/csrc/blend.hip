@@ -207,34 +207,31 @@ __global__ __launch_bounds__(256) void blend_cameras_kernel(
 // such a pixel (the topmost pixel of the leftmost column has a foreign left and
 // upper neighbour, and so on), and a region bounded by near-vertical seams has
 // only a handful of them.
+//
+// The same pass marks, per patch, the columns in which it owns anything
+// (marks[o][x] = 1 at the top pixel of every vertical run - idempotent plain
+// stores); owned_spans_kernel turns the marks into column spans.
 __global__ __launch_bounds__(256) void owned_boxes_kernel(const int16_t *__restrict__ owner,
                                                           int H, int W, int xs0, int xs1,
-                                                          int32_t *__restrict__ boxes) {
+                                                          int32_t *__restrict__ boxes, int stride,
+                                                          uint8_t *__restrict__ marks) {
     const int x = xs0 + blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
     if (x >= xs1 || y >= H) return;
     const int16_t *row = owner + (size_t)y * W;
     const int o = row[x];
     if (o < 0) return;
+    const bool up = y == 0 || row[x - W] != o;
+    if (up && marks) marks[(size_t)o * W + x] = 1;
     const bool left = x == xs0 || row[x - 1] != o;      // the strip's edge counts as foreign
     const bool right = x == xs1 - 1 || row[x + 1] != o;
     if (!left && !right) return;
-    const bool up = y == 0 || row[x - W] != o;
     const bool down = y == H - 1 || row[x + W] != o;
     if (left && up) {
-        atomicMin(&boxes[4 * o + 0], y);
-        atomicMin(&boxes[4 * o + 2], x);
+        atomicMin(&boxes[(size_t)stride * o + 0], y);
+        atomicMin(&boxes[(size_t)stride * o + 2], x);
     }
-    if (left && down) atomicMax(&boxes[4 * o + 1], y);
-    if (right && up) atomicMax(&boxes[4 * o + 3], x);
-}
-
-__global__ void init_boxes_kernel(int32_t *boxes, int n) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    boxes[4 * i + 0] = 0x7fffffff;
-    boxes[4 * i + 1] = -1;
-    boxes[4 * i + 2] = 0x7fffffff;
-    boxes[4 * i + 3] = -1;
+    if (left && down) atomicMax(&boxes[(size_t)stride * o + 1], y);
+    if (right && up) atomicMax(&boxes[(size_t)stride * o + 3], x);
 }
 
 // uint8(255 * v) with C truncation; v is in [0, 1] up to rounding.
@@ -414,80 +411,77 @@ extern "C" int pano_blend_cameras(const pano_camera *cams, int n, int H, int W, 
     return PANO_OK;
 }
 
-extern "C" int pano_owned_boxes(const int16_t *owner, int H, int W, int xs0, int xs1, int n,
-                                int32_t *boxes, void *stream) {
-    PANO_REQUIRE(owner && boxes, "pano_owned_boxes: null pointer");
-    PANO_REQUIRE(H > 0 && W > 0 && n >= 0 && n <= 32767, "pano_owned_boxes: bad argument");
-    PANO_REQUIRE(xs0 >= 0 && xs1 <= W && xs0 <= xs1, "pano_owned_boxes: bad strip [%d, %d)", xs0, xs1);
-    if (n == 0) return PANO_OK;
-    hipLaunchKernelGGL(init_boxes_kernel, dim3(ceil_div(n, 256)), dim3(256), 0,
-                       (hipStream_t)stream, boxes, n);
-    PANO_LAUNCH_CHECK("init_boxes_kernel");
-    if (xs0 == xs1) return PANO_OK;
-    dim3 block(64, 4), grid(ceil_div(xs1 - xs0, 64), ceil_div(H, 4));
-    PANO_TIMED(PK_OWNED_BOXES, (hipStream_t)stream,
-               hipLaunchKernelGGL(owned_boxes_kernel, grid, block, 0, (hipStream_t)stream,
-                                  owner, H, W, xs0, xs1, boxes));
-    PANO_LAUNCH_CHECK("owned_boxes_kernel");
-    return PANO_OK;
-}
-
-// Column spans of the owned regions: one thread per mosaic column marks, per
-// owner change down the column, (owner, column); one thread per patch then turns
-// its marks into merged runs.  Both walks are short (H, W steps) and coalesced.
-__global__ __launch_bounds__(256) void owned_marks_kernel(const int16_t *__restrict__ owner,
-                                                          int H, int W, int xs0, int xs1,
-                                                          uint8_t *__restrict__ marks) {
-    const int x = xs0 + blockIdx.x * 256 + threadIdx.x;
-    if (x >= xs1) return;
-    int prev = -1;
-    for (int y = 0; y < H; ++y) {
-        const int o = owner[(size_t)y * W + x];
-        if (o != prev && o >= 0) marks[(size_t)o * W + x] = 1;
-        prev = o;
-    }
-}
-
-__global__ void owned_spans_kernel(const uint8_t *__restrict__ marks, int W, int xs0, int xs1,
-                                   int n, int min_gap, int max_spans,
-                                   int32_t *__restrict__ spans, int32_t *__restrict__ counts) {
-    const int i = blockIdx.x * 64 + threadIdx.x;
-    if (i >= n) return;
-    const uint8_t *row = marks + (size_t)i * W;
-    int32_t *out = spans + (size_t)i * max_spans * 2;
-    int cnt = 0, last = -1;
-    for (int x = xs0; x < xs1; ++x) {
-        if (!row[x]) continue;
-        if (cnt && (x - last - 1 < min_gap || cnt == max_spans)) {
-            out[2 * (cnt - 1) + 1] = x;               // extend the current span
-        } else {
-            out[2 * cnt] = x;
-            out[2 * cnt + 1] = x;
-            ++cnt;
+// One wave per patch turns its column marks into merged runs: 64 columns per
+// ballot, the runs inside a ballot peeled off with bit scans (all lanes run the
+// same scalar bookkeeping, lane 0 writes).
+//   regions[i] = {ymin, ymax, xmin, xmax, count, xa_0, xb_0, xa_1, xb_1, ...}
+__global__ __launch_bounds__(64) void owned_spans_kernel(const uint8_t *__restrict__ marks,
+                                                         int W, int xs0, int xs1, int min_gap,
+                                                         int max_spans, int stride,
+                                                         int32_t *__restrict__ regions) {
+    const int lane = threadIdx.x;
+    const uint8_t *row = marks + (size_t)blockIdx.x * W;
+    int32_t *out = regions + (size_t)blockIdx.x * stride + 5;
+    int cnt = 0, last = 0;
+    for (int base = xs0; base < xs1; base += 64) {
+        const int x = base + lane;
+        unsigned long long bal = __ballot(x < xs1 && row[x] != 0);
+        while (bal) {
+            const int s = __ffsll((long long)bal) - 1;
+            const unsigned long long rest = ~(bal >> s);          // 0 bits = the run
+            const int len = rest ? __ffsll((long long)rest) - 1 : 64 - s;
+            const int xa = base + s, xb = xa + len - 1;
+            if (cnt && (xa - last - 1 < min_gap || cnt == max_spans)) {
+                if (lane == 0) out[2 * (cnt - 1) + 1] = xb;       // extend the current span
+            } else {
+                if (lane == 0) {
+                    out[2 * cnt] = xa;
+                    out[2 * cnt + 1] = xb;
+                }
+                ++cnt;
+            }
+            last = xb;
+            bal = s + len >= 64 ? 0ull : bal & ~((1ull << (s + len)) - 1ull);
         }
-        last = x;
     }
-    counts[i] = cnt;
+    if (lane == 0) regions[(size_t)blockIdx.x * stride + 4] = cnt;
 }
 
-extern "C" int pano_owned_spans(const int16_t *owner, int H, int W, int xs0, int xs1, int n,
-                                int min_gap, int max_spans, uint8_t *marks, int32_t *spans,
-                                int32_t *counts, void *stream) {
-    PANO_REQUIRE(owner && marks && spans && counts, "pano_owned_spans: null pointer");
+__global__ void init_regions_kernel(int32_t *regions, int n, int stride) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    int32_t *r = regions + (size_t)i * stride;
+    r[0] = 0x7fffffff;
+    r[1] = -1;
+    r[2] = 0x7fffffff;
+    r[3] = -1;
+    r[4] = 0;
+}
+
+extern "C" int pano_owned_regions(const int16_t *owner, int H, int W, int xs0, int xs1, int n,
+                                  int min_gap, int max_spans, uint8_t *marks,
+                                  int32_t *regions, void *stream) {
+    PANO_REQUIRE(owner && marks && regions, "pano_owned_regions: null pointer");
     PANO_REQUIRE(H > 0 && W > 0 && n >= 0 && n <= 32767 && max_spans >= 1 && min_gap >= 0,
-                 "pano_owned_spans: bad argument");
-    PANO_REQUIRE(xs0 >= 0 && xs1 <= W && xs0 <= xs1, "pano_owned_spans: bad strip [%d, %d)", xs0, xs1);
+                 "pano_owned_regions: bad argument");
+    PANO_REQUIRE(xs0 >= 0 && xs1 <= W && xs0 <= xs1, "pano_owned_regions: bad strip [%d, %d)", xs0, xs1);
     if (n == 0) return PANO_OK;
     hipStream_t s = (hipStream_t)stream;
+    const int stride = 5 + 2 * max_spans;
     PANO_HIP(hipMemsetAsync(marks, 0, (size_t)n * W, s));
-    if (xs1 > xs0) {
-        PANO_TIMED(PK_OWNED_SPANS, s,
-                   hipLaunchKernelGGL(owned_marks_kernel, dim3(ceil_div(xs1 - xs0, 256)), dim3(256),
-                                      0, s, owner, H, W, xs0, xs1, marks));
-        PANO_LAUNCH_CHECK("owned_marks_kernel");
-    }
-    hipLaunchKernelGGL(owned_spans_kernel, dim3(ceil_div(n, 64)), dim3(64), 0, s, marks, W, xs0,
-                       xs1, n, min_gap, max_spans, spans, counts);
+    hipLaunchKernelGGL(init_regions_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, s, regions, n,
+                       stride);
+    PANO_LAUNCH_CHECK("init_regions_kernel");
+    if (xs0 == xs1) return PANO_OK;
+    dim3 block(64, 4), grid(ceil_div(xs1 - xs0, 64), ceil_div(H, 4));
+    // the box fields are the first four ints of each record: stride-aware view
+    PANO_TIMED(PK_OWNED_BOXES, s,
+               hipLaunchKernelGGL(owned_boxes_kernel, grid, block, 0, s, owner, H, W, xs0, xs1,
+                                  regions, stride, marks));
+    PANO_LAUNCH_CHECK("owned_boxes_kernel");
+    PANO_TIMED(PK_OWNED_SPANS, s,
+               hipLaunchKernelGGL(owned_spans_kernel, dim3(n), dim3(64), 0, s, marks, W, xs0, xs1,
+                                  min_gap, max_spans, stride, regions));
     PANO_LAUNCH_CHECK("owned_spans_kernel");
     return PANO_OK;
 }

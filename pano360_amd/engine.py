@@ -521,30 +521,25 @@ class Engine:
             "pano_ownership_cameras")
         return owner, valid
 
-    def owned_boxes(self, owner, n, strip=None):
-        """Host array [n][4] = (ymin, ymax, xmin, xmax) of every patch's owned
-        pixels within the column strip (one small device->host copy; the only
-        sync of a stitch)."""
+    def owned_regions(self, owner, n, strip=None, min_gap=0, max_spans=4):
+        """Where every patch owns pixels within the column strip: host arrays
+        boxes [n][4] = (ymin, ymax, xmin, xmax) and a list, per patch, of the
+        inclusive column spans (xa, xb) (runs closer than ``min_gap`` merged).
+        One small device->host copy: the only sync of a stitch."""
         torch = _torch()
         H, W = owner.shape
         c0, c1 = strip if strip is not None else (0, W)
-        boxes = torch.empty((n, 4), dtype=torch.int32, device=self.device)
-        _lib.check(self.lib.pano_owned_boxes(_ptr(owner), H, W, c0, c1, n, _ptr(boxes),
-                                             self.stream()), "pano_owned_boxes")
-        return boxes.cpu().numpy()
-
-    def owned_spans(self, owner, n, strip, min_gap, max_spans=4):
-        """Per patch, the column runs in which it owns pixels (runs closer than
-        ``min_gap`` merged): host lists of inclusive (xa, xb)."""
-        torch = _torch()
-        H, W = owner.shape
         marks = torch.empty((n, W), dtype=torch.uint8, device=self.device)
-        spans = torch.empty((n, max_spans, 2), dtype=torch.int32, device=self.device)
-        counts = torch.empty((n,), dtype=torch.int32, device=self.device)
-        _lib.check(self.lib.pano_owned_spans(_ptr(owner), H, W, strip[0], strip[1], n, min_gap,
-                                             max_spans, _ptr(marks), _ptr(spans), _ptr(counts),
-                                             self.stream()), "pano_owned_spans")
-        return spans, counts
+        regions = torch.empty((n, 5 + 2 * max_spans), dtype=torch.int32, device=self.device)
+        _lib.check(self.lib.pano_owned_regions(_ptr(owner), H, W, c0, c1, n, min_gap, max_spans,
+                                               _ptr(marks), _ptr(regions), self.stream()),
+                   "pano_owned_regions")
+        host = regions.cpu().numpy()
+        spans = [host[i, 5:5 + 2 * host[i, 4]].reshape(-1, 2) for i in range(n)]
+        return host[:, :4], spans
+
+    def owned_boxes(self, owner, n, strip=None):
+        return self.owned_regions(owner, n, strip)[0]
 
     def multiband_fused(self, frames, plan, n_levels, want_float=False, frame_ids=None,
                         strip=None):
@@ -569,12 +564,10 @@ class Engine:
         owner, valid = self.ownership_cameras(plan, strip=ext, cams=cams)
         # one record per (patch, span of columns it owns): spans farther apart than
         # 2R keep disjoint rectangles A, so a pixel still meets a patch at most once
-        spans_d, counts_d = self.owned_spans(owner, plan.n, ext, 2 * radius + 2)
-        boxes = self.owned_boxes(owner, plan.n, ext)              # row extents (and the sync)
-        spans, counts = spans_d.cpu().numpy(), counts_d.cpu().numpy()
+        boxes, spans = self.owned_regions(owner, plan.n, ext, 2 * radius + 2)
         entries = []
         for i in range(plan.n):
-            for xa, xb in spans[i, :counts[i]]:
+            for xa, xb in spans[i]:
                 win = windows_for((boxes[i][0], boxes[i][1], xa, xb), plan.rects[i], radius,
                                   (c0, c1))
                 if win is not None:
