@@ -38,7 +38,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="cfg3", choices=["cfg2", "cfg3", "tiny"])
+    ap.add_argument("--workload", default="cfg3", choices=["cfg2", "cfg3", "cfg5", "tiny"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     return ap.parse_args()
 
@@ -163,8 +163,8 @@ def main():
     else:
         runner = None
         mine = range(cfg["n"])
-    frames = eng.upload_frames([synth.make_frame(i, cfg["width"], cfg["height"], "A")
-                                for i in mine])
+    frames = [eng.upload_frames([synth.make_frame(i, cfg["width"], cfg["height"], "A")])[0]
+              for i in mine]             # one frame at a time: 120 x 8K is 12 GB
 
     def step():
         if runner is not None:
