@@ -224,9 +224,46 @@ assert PATCH_DTYPE.itemsize == C.sizeof(Patch) == 96
 assert CAMERA_DTYPE.itemsize == C.sizeof(_lib.Camera) == 120
 
 
+class _PinnedRing:
+    """Small host->device uploads (record tables, trig tables) without blocking
+    the host: a pageable copy waits for everything already queued on the stream,
+    i.e. for the previous stitch, and serialises host and GPU.  Slots are pinned,
+    reused round-robin, each guarded by an event recorded after its copy."""
+
+    SLOTS = 8
+
+    def __init__(self, device):
+        self.device, self.slots, self.events, self.next = device, [], [], 0
+
+    def upload(self, array):
+        torch = _torch()
+        raw = np.ascontiguousarray(array).view(np.uint8).reshape(-1)
+        if len(self.slots) < self.SLOTS:
+            self.slots.append(torch.empty(max(raw.size, 1 << 16), dtype=torch.uint8).pin_memory())
+            self.events.append(torch.cuda.Event())
+            k = len(self.slots) - 1
+        else:
+            k = self.next
+            self.next = (self.next + 1) % self.SLOTS
+            self.events[k].synchronize()             # its previous copy has landed
+            if self.slots[k].numel() < raw.size:
+                self.slots[k] = torch.empty(raw.size, dtype=torch.uint8).pin_memory()
+        self.slots[k].numpy()[:raw.size] = raw
+        dev = self.slots[k][:raw.size].to(self.device, non_blocking=True)
+        self.events[k].record(torch.cuda.current_stream(self.device))
+        return dev
+
+
+_rings = {}
+
+
 def _to_device(array, device):
+    """Bytes of a NumPy array as a uint8 device tensor (asynchronous copy)."""
     torch = _torch()
-    return torch.from_numpy(np.ascontiguousarray(array).view(np.uint8).reshape(-1)).to(device)
+    key = str(torch.device(device))
+    if key not in _rings:
+        _rings[key] = _PinnedRing(device)
+    return _rings[key].upload(array)
 
 
 def reflect_closed(lo, hi, n):
@@ -423,18 +460,9 @@ class Engine:
         buffer (three pageable copies cost 1.5 ms of host time per stitch)."""
         torch = _torch()
         nx, ny = len(plan.sin_t), len(plan.tan_p)
-        total = 2 * nx + ny
-        stage = getattr(self, "_stage", None)
-        if stage is None or stage.numel() < total:
-            stage = self._stage = torch.empty(total, dtype=torch.float64).pin_memory()
-            self._stage_free = torch.cuda.Event()
-        else:
-            self._stage_free.synchronize()       # the previous copy out of it has landed
-        host = stage.numpy()
-        host[:nx], host[nx:2 * nx], host[2 * nx:total] = plan.sin_t, plan.cos_t, plan.tan_p
-        dev = stage[:total].to(self.device, non_blocking=True)
-        self._stage_free.record(torch.cuda.current_stream(self.device))
-        plan.dev = (dev[:nx], dev[nx:2 * nx], dev[2 * nx:total])
+        dev = _to_device(np.concatenate([plan.sin_t, plan.cos_t, plan.tan_p]),
+                         self.device).view(torch.float64)
+        plan.dev = (dev[:nx], dev[nx:2 * nx], dev[2 * nx:2 * nx + ny])
         return plan
 
     # -- stage-level calls (whole patches, the blender protocol) ------------------
