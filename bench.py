@@ -171,7 +171,9 @@ def main():
             return runner.step(frames)
         plan = engine.Plan(shapes, rots, intrs, True, NATIVE)
         mosaic, _, _, patches = eng.stitch(frames, plan, "multiband", n_levels)
-        return plan, mosaic, patches
+        # keep only the window geometry: holding the arenas across steps would make
+        # the allocator carve out fresh gigabytes every step
+        return plan, mosaic, list(patches)
 
     def fence():
         torch.cuda.synchronize()

@@ -94,7 +94,7 @@ class ShardedStitcher:
             frames, plan, self.n_levels, frame_ids=self.my_frames, strip=self.strip)
         packed = pack_strip(mosaic, self.strip, self.pack_width)
         full = gather_strips(packed, self.bounds, self.rank, self.world, self.group)
-        return plan, full, patches
+        return plan, full, list(patches)          # window geometry only, not the arenas
 
 
 def emulate_on_one_device(eng, imgs, rots, intrs, n_levels, world, max_resolution=10 ** 9):
