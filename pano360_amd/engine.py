@@ -231,26 +231,31 @@ class _PinnedRing:
     reused round-robin, each guarded by an event recorded after its copy."""
 
     SLOTS = 8
+    SLOT_BYTES = 1 << 20
 
     def __init__(self, device):
-        self.device, self.slots, self.events, self.next = device, [], [], 0
+        torch = _torch()
+        self.device, self.next = device, 0
+        # one pinning call for the whole ring (each costs tens of milliseconds)
+        self.store = torch.empty(self.SLOTS * self.SLOT_BYTES, dtype=torch.uint8).pin_memory()
+        self.slots = [self.store[k * self.SLOT_BYTES:(k + 1) * self.SLOT_BYTES]
+                      for k in range(self.SLOTS)]
+        self.events = [torch.cuda.Event() for _ in range(self.SLOTS)]
+        self.used = [False] * self.SLOTS
 
     def upload(self, array):
         torch = _torch()
         raw = np.ascontiguousarray(array).view(np.uint8).reshape(-1)
-        if len(self.slots) < self.SLOTS:
-            self.slots.append(torch.empty(max(raw.size, 1 << 16), dtype=torch.uint8).pin_memory())
-            self.events.append(torch.cuda.Event())
-            k = len(self.slots) - 1
-        else:
-            k = self.next
-            self.next = (self.next + 1) % self.SLOTS
+        if raw.size > self.SLOT_BYTES:               # rare: larger than a slot
+            return torch.from_numpy(raw.copy()).to(self.device)
+        k = self.next
+        self.next = (self.next + 1) % self.SLOTS
+        if self.used[k]:
             self.events[k].synchronize()             # its previous copy has landed
-            if self.slots[k].numel() < raw.size:
-                self.slots[k] = torch.empty(raw.size, dtype=torch.uint8).pin_memory()
         self.slots[k].numpy()[:raw.size] = raw
         dev = self.slots[k][:raw.size].to(self.device, non_blocking=True)
         self.events[k].record(torch.cuda.current_stream(self.device))
+        self.used[k] = True
         return dev
 
 
