@@ -72,7 +72,9 @@ typedef struct pano_patch {
                                   several far-apart column spans (a frame that
                                   straddles the +-pi seam of a 360 degree sweep)
                                   is split into one record per span           */
-    int32_t reserved;
+    int32_t tiles_off;         /* first entry of this record's 64 x 128 column
+                                  tiles in the tile_flags array (row-major,
+                                  ceil(aw/64) per row)                        */
 } pano_patch;
 
 /* One registered frame (reference: bundle_adj.Image, bundle_adj.py:18-33,
@@ -175,11 +177,29 @@ int pano_owned_regions(const int16_t *owner, int H, int W, int xs0, int xs1,
  * ntaps[k] + PANO_TAP_PAD floats: PANO_TAP_LEAD + ((R - r_k) & 3) zeros, the
  * ntaps[k] taps, zeros, where r_k = ntaps[k] / 2 and R = max r_k (the extra
  * zeros keep the row pass's 16-byte LDS reads aligned for every level).
- * ntaps: host int[n_blur].  Writes patches[i].blurred (and .scratch). */
+ * ntaps: host int[n_blur].  Writes patches[i].blurred (and .scratch).
+ * interior (optional, with tile_flags): the map of pano_interior_map; tiles
+ * that hold only interior pixels, and the scratch rows only they would read,
+ * are skipped.  tile_flags: dev uint8, one entry per 64 x 128 column tile of
+ * every record (patches[i].tiles_off), written here. */
 int pano_multiband_blur(const pano_patch *patches, int n, int max_aw,
                         int max_vh, int max_ah, const int16_t *owner, int W,
                         const float *taps, const int *ntaps, int n_blur,
+                        const uint8_t *interior, uint8_t *tile_flags,
                         void *stream);
+
+/* Interior map (no reference counterpart: an exact-in-real-arithmetic property
+ * of stitcher.py:210-241).  Where every pixel within `radius` (the largest
+ * Gaussian radius) of p is owned by one patch, the band-pass stack telescopes:
+ * all of that patch's blurred alphas equal the full tap sum, every other
+ * patch's are exact zeros, and the multiband mosaic at p is the patch's warped
+ * colour (to float32 rounding, <= 6e-8 absolute).  interior: dev uint8
+ * [ceil(H/8)][ceil(W/8)], 1 = every pixel of the 8 x 8 block is such a pixel
+ * (conservative: tested on whole blocks); block_owner: dev int16 workspace of
+ * the same shape.  Only columns [xs0, xs1) of owner are read. */
+int pano_interior_map(const int16_t *owner, int H, int W, int xs0, int xs1,
+                      int radius, int16_t *block_owner, uint8_t *interior,
+                      void *stream);
 
 /* Band-pass build + collapse                     stitcher.py:210-241
  * Gathers, per mosaic pixel and in patch order, layer_k / wsum_k of every
@@ -187,10 +207,16 @@ int pano_multiband_blur(const pano_patch *patches, int n, int max_aw,
  * sums the levels, clips, truncates to uint8 - for the mosaic columns
  * [xs0, xs1) (the whole mosaic: 0, W; one GPU's share when the mosaic is split
  * into column strips).  mosaic / mosaic_f32 are full-size [H][W][3] buffers,
- * only the strip is written; mosaic_f32 is optional. */
+ * only the strip is written; mosaic_f32 is optional.
+ * interior (optional): pixels of interior blocks are not gathered; the owner's
+ * frame (cams[owner].frame) is sampled there exactly as the warp samples it,
+ * which needs cams, the trig tables and lut255 (all NULL otherwise). */
 int pano_multiband_compose(const pano_patch *patches, int n, int H, int W,
                            int xs0, int xs1, int n_levels,
                            const int16_t *owner, const uint8_t *valid,
+                           const uint8_t *interior, const pano_camera *cams,
+                           const double *sin_t, const double *cos_t,
+                           const double *tan_p, const float *lut255,
                            uint8_t *mosaic, float *mosaic_f32, void *stream);
 
 /* linear_blend (linear != 0) or no_blend (linear == 0) of the mosaic columns

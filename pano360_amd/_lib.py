@@ -32,7 +32,7 @@ class Patch(C.Structure):
                 ("vy0", C.c_int32), ("vx0", C.c_int32), ("vh", C.c_int32), ("vw", C.c_int32),
                 ("ay0", C.c_int32), ("ax0", C.c_int32), ("ah", C.c_int32), ("aw", C.c_int32),
                 ("vpitch", C.c_int32), ("apitch", C.c_int32),
-                ("index", C.c_int32), ("reserved", C.c_int32)]
+                ("index", C.c_int32), ("tiles_off", C.c_int32)]
 
 
 class Camera(C.Structure):
@@ -61,8 +61,10 @@ _SIGNATURES = {
     "pano_ownership_cameras": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "pano_owned_regions": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "pano_multiband_blur": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _vp,
-                                 C.POINTER(C.c_int), _i, _vp]),
-    "pano_multiband_compose": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+                                 C.POINTER(C.c_int), _i, _vp, _vp, _vp]),
+    "pano_interior_map": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "pano_multiband_compose": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp,
+                                    _vp, _vp, _vp, _vp, _vp]),
     "pano_blend_cameras": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "pano_linear_blend": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "pano_no_blend": (_i, [_vp, _i, _i, _i, _vp, _vp]),

@@ -41,7 +41,8 @@ static const char *const g_kernel_names[PK_COUNT] = {
     "blur_cols_kernel",   "multiband_compose_kernel", "linear_blend_kernel",
     "no_blend_kernel",    "crop_heights_kernel", "crop_rows_kernel", "pyr_down_kernel",
     "ownership_cameras_kernel", "owned_boxes_kernel", "warp_windows_kernel",
-    "blend_cameras_kernel", "owned_spans_kernel"};
+    "blend_cameras_kernel", "owned_spans_kernel",
+    "block_owner_kernel", "tile_flags_kernel"};
 
 void pano_timing_edge(int kid, hipStream_t stream, bool begin) {
     hipEvent_t ev;

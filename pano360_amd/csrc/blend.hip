@@ -237,13 +237,109 @@ __global__ __launch_bounds__(256) void owned_boxes_kernel(const int16_t *__restr
 // uint8(255 * v) with C truncation; v is in [0, 1] up to rounding.
 __device__ __forceinline__ uint8_t quant255(float v) { return (uint8_t)(int)(255.0f * v); }
 
+// ---- interior map ---------------------------------------------------------------
+// The band-pass stack is a partition of unity: where every pixel within the
+// largest Gaussian radius R of p (a (2R+1)^2 window) is owned by the same patch
+// i, all of i's blurred alphas equal the full tap sum s_k, every other patch's
+// are exact zeros, and  sum_k (band_k * s_k) / s_k  telescopes to the warped
+// colour itself (|difference| <= 6e-8 measured against the oracle).  Such
+// "interior" pixels need no blur at all; multiband blending only happens within
+// R of a seam or of the border of the covered area.  The test runs on 8 x 8
+// blocks (conservative): a block is interior when all blocks within
+// ceil((R + 7) / 8) of it are uniformly owned by the same patch.
+#define IB 8
+
+__global__ __launch_bounds__(256) void block_owner_kernel(const int16_t *__restrict__ owner,
+                                                          int H, int W, int xs0, int xs1,
+                                                          int H8, int W8,
+                                                          int16_t *__restrict__ bown) {
+    const int bx = blockIdx.x * 64 + threadIdx.x, by = blockIdx.y * 4 + threadIdx.y;
+    if (bx >= W8 || by >= H8) return;
+    const int x0 = bx * IB, y0 = by * IB;
+    int o = -2;                                  // -2: mixed, or not inside the strip
+    if (x0 >= xs0 && (x0 + IB < W ? x0 + IB : W) <= xs1) {
+        o = owner[(size_t)y0 * W + x0];
+        for (int dy = 0; dy < IB && o != -2; ++dy) {
+            const int y = y0 + dy;
+            if (y >= H) break;
+            for (int dx = 0; dx < IB; ++dx) {
+                const int x = x0 + dx;
+                if (x >= W) break;
+                if (owner[(size_t)y * W + x] != o) {
+                    o = -2;
+                    break;
+                }
+            }
+        }
+    }
+    bown[(size_t)by * W8 + bx] = (int16_t)o;
+}
+
+__global__ __launch_bounds__(256) void interior_blocks_kernel(const int16_t *__restrict__ bown,
+                                                              int H8, int W8, int reach,
+                                                              uint8_t *__restrict__ interior) {
+    const int bx = blockIdx.x * 64 + threadIdx.x, by = blockIdx.y * 4 + threadIdx.y;
+    if (bx >= W8 || by >= H8) return;
+    const int o = bown[(size_t)by * W8 + bx];
+    bool in = o >= 0;
+    for (int dy = -reach; dy <= reach && in; ++dy) {
+        const int y = by + dy;
+        if (y < 0 || y >= H8) continue;          // beyond the mosaic: nothing there
+        for (int dx = -reach; dx <= reach; ++dx) {
+            const int x = bx + dx;
+            if (x < 0 || x >= W8) continue;
+            if (bown[(size_t)y * W8 + x] != o) {
+                in = false;
+                break;
+            }
+        }
+    }
+    interior[(size_t)by * W8 + bx] = in ? 1 : 0;
+}
+
+// What the collapse needs to finish an interior pixel on its own: the owner's
+// frame is sampled exactly as the warp kernel samples it.
+struct InteriorArgs {
+    const uint8_t *interior;     // [H8][W8], NULL = no shortcut
+    int W8;
+    const pano_camera *cams;
+    const double *sin_t, *cos_t, *tan_p;
+    const float *lut255;
+};
+
 template <int L>
 __global__ __launch_bounds__(256) void multiband_compose_kernel(
     const pano_patch *__restrict__ patches, int n, int H, int W, int xs0, int xs1,
     const int16_t *__restrict__ owner, const uint8_t *__restrict__ valid,
-    uint8_t *__restrict__ mosaic, float *__restrict__ mosaic_f32) {
+    uint8_t *__restrict__ mosaic, float *__restrict__ mosaic_f32, InteriorArgs ia) {
+    __shared__ float s_lut[256];
+    if (ia.interior) {
+        s_lut[threadIdx.y * 64 + threadIdx.x] = ia.lut255[threadIdx.y * 64 + threadIdx.x];
+        __syncthreads();
+    }
     const int x = xs0 + blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
     if (x >= xs1 || y >= H) return;
+    if (ia.interior && ia.interior[(size_t)(y / IB) * ia.W8 + x / IB]) {
+        // interior pixel: the mosaic is the owner's warped colour, clipped, quantised
+        const pano_camera *cam = ia.cams + owner[(size_t)y * W + x];
+        const int sw = cam->sw, sh = cam->sh;
+        float fx, fy;
+        map_pixel(cam->proj, ia.sin_t[x], ia.cos_t[x], ia.tan_p[y], sw, sh, fx, fy);
+        const Taps tp = make_taps(fx, fy, sw, sh);
+        const uint8_t *__restrict__ frame = cam->frame;
+        const uint8_t *r0 = frame + (size_t)tp.y0 * sw * 3, *r1 = frame + (size_t)tp.y1 * sw * 3;
+        const uint8_t *p00 = r0 + tp.x0 * 3, *p01 = r0 + tp.x1 * 3;
+        const uint8_t *p10 = r1 + tp.x0 * 3, *p11 = r1 + tp.x1 * 3;
+        const size_t g = ((size_t)y * W + x) * 3;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float v = lerp4(s_lut[p00[c]], s_lut[p01[c]], s_lut[p10[c]], s_lut[p11[c]], tp);
+            v = v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v);
+            if (mosaic_f32) mosaic_f32[g + c] = v;
+            mosaic[g + c] = (uint8_t)(int)(255.0f * v);
+        }
+        return;
+    }
     float layer[L][3], wsum[L];
 #pragma unroll
     for (int k = 0; k < L; ++k) layer[k][0] = layer[k][1] = layer[k][2] = wsum[k] = 0.0f;
@@ -486,9 +582,31 @@ extern "C" int pano_owned_regions(const int16_t *owner, int H, int W, int xs0, i
     return PANO_OK;
 }
 
+extern "C" int pano_interior_map(const int16_t *owner, int H, int W, int xs0, int xs1,
+                                 int radius, int16_t *block_owner, uint8_t *interior,
+                                 void *stream) {
+    PANO_REQUIRE(owner && block_owner && interior, "pano_interior_map: null pointer");
+    PANO_REQUIRE(H > 0 && W > 0 && radius >= 0, "pano_interior_map: bad argument");
+    PANO_REQUIRE(xs0 >= 0 && xs1 <= W && xs0 <= xs1, "pano_interior_map: bad strip [%d, %d)", xs0, xs1);
+    const int H8 = ceil_div(H, IB), W8 = ceil_div(W, IB), reach = ceil_div(radius + IB - 1, IB);
+    dim3 block(64, 4), grid(ceil_div(W8, 64), ceil_div(H8, 4));
+    hipStream_t s = (hipStream_t)stream;
+    PANO_TIMED(PK_INTERIOR, s,
+               hipLaunchKernelGGL(block_owner_kernel, grid, block, 0, s, owner, H, W, xs0, xs1,
+                                  H8, W8, block_owner));
+    PANO_LAUNCH_CHECK("block_owner_kernel");
+    hipLaunchKernelGGL(interior_blocks_kernel, grid, block, 0, s, block_owner, H8, W8, reach,
+                       interior);
+    PANO_LAUNCH_CHECK("interior_blocks_kernel");
+    return PANO_OK;
+}
+
 extern "C" int pano_multiband_compose(const pano_patch *patches, int n, int H, int W,
                                       int xs0, int xs1, int n_levels,
                                       const int16_t *owner, const uint8_t *valid,
+                                      const uint8_t *interior, const pano_camera *cams,
+                                      const double *sin_t, const double *cos_t,
+                                      const double *tan_p, const float *lut255,
                                       uint8_t *mosaic, float *mosaic_f32, void *stream) {
     if (int rc = check_table(patches, n, H, W, "pano_multiband_compose")) return rc;
     PANO_REQUIRE(owner && valid && mosaic, "pano_multiband_compose: null pointer");
@@ -496,7 +614,10 @@ extern "C" int pano_multiband_compose(const pano_patch *patches, int n, int H, i
                  "pano_multiband_compose: n_levels %d outside [1, %d]", n_levels, PANO_MAX_LEVELS);
     PANO_REQUIRE(xs0 >= 0 && xs1 <= W && xs0 <= xs1,
                  "pano_multiband_compose: bad strip [%d, %d)", xs0, xs1);
+    PANO_REQUIRE(!interior || (cams && sin_t && cos_t && tan_p && lut255),
+                 "pano_multiband_compose: the interior map needs cameras, tables and LUT");
     if (xs0 == xs1) return PANO_OK;
+    InteriorArgs ia = {interior, ceil_div(W, IB), cams, sin_t, cos_t, tan_p, lut255};
     dim3 block(64, 4), grid(ceil_div(xs1 - xs0, 64), ceil_div(H, 4));
     hipStream_t s = (hipStream_t)stream;
 #define COMPOSE(L)                                                                   \
@@ -504,7 +625,7 @@ extern "C" int pano_multiband_compose(const pano_patch *patches, int n, int H, i
         PANO_TIMED(PK_COMPOSE, s,                                                    \
                    hipLaunchKernelGGL(multiband_compose_kernel<L>, grid, block, 0,   \
                                       s, patches, n, H, W, xs0, xs1, owner, valid,   \
-                                      mosaic, mosaic_f32));                          \
+                                      mosaic, mosaic_f32, ia));                      \
         break;
     switch (n_levels) {
         COMPOSE(1) COMPOSE(2) COMPOSE(3) COMPOSE(4) COMPOSE(5) COMPOSE(6) COMPOSE(7) COMPOSE(8)

@@ -63,15 +63,42 @@ __device__ __forceinline__ int row_pos(int i) { return i + ((i >> 3) << 2); }
 
 // nch = channels per patch (4: R,G,B + sharp alpha from the owner map; 1: a
 // plain plane); alpha_ch = channel whose source is the owner map, or -1.
+// Column tile (tx, ty) of a record is "active" when it holds a pixel that is not
+// interior (blend.hip: interior map): only those tiles are ever gathered, so only
+// they - and the scratch rows they read - are computed.  flags == NULL: all active.
+__device__ __forceinline__ bool col_tile_active(const uint8_t *__restrict__ flags,
+                                                const pano_patch &p, int tx, int ty) {
+    return !flags || flags[p.tiles_off + ty * ((p.aw + COL_TW - 1) / COL_TW) + tx] != 0;
+}
+
 template <bool TABLE>
 __global__ __launch_bounds__(256) void blur_rows_kernel(
     const pano_patch *__restrict__ table, pano_patch single, int nch, int alpha_ch,
-    Levels L, const int16_t *__restrict__ owner, int W) {
+    Levels L, const int16_t *__restrict__ owner, int W, const uint8_t *__restrict__ flags) {
     __shared__ __attribute__((aligned(16))) float s_row[4][ROW_LDS];
     const int pid = blockIdx.z / nch, c = blockIdx.z - pid * nch;
     const pano_patch p = TABLE ? table[pid] : single;
     const int xt = blockIdx.x * ROW_TW;          // first output column, A-relative
     if (xt >= p.aw || (int)blockIdx.y * 4 >= p.vh) return;   // uniform per block
+    if (flags && p.h > 2 * L.rmax + 2) {
+        // these 4 rows x 512 columns are needed iff an active column tile over the
+        // same columns reads them: its own 128 rows grown by the radius (the
+        // REFLECT_101 images of rows beyond the patch fall inside that range)
+        const int ntx = (p.aw + COL_TW - 1) / COL_TW, nty = (p.ah + COL_TH - 1) / COL_TH;
+        const int ry0 = p.vy0 + (int)blockIdx.y * 4 - p.ay0;      // A-relative first row
+        const int t = threadIdx.y * 64 + threadIdx.x;             // 24 candidates: 8 x 3
+        bool need = false;
+        if (t < 24) {
+            const int tx = xt / COL_TW + (t & 7);
+            int t0 = ry0 / COL_TH;
+            t0 = t0 < 0 ? 0 : (t0 >= nty ? nty - 1 : t0);
+            const int ty = t0 - 1 + (t >> 3);
+            if (tx < ntx && ty >= 0 && ty < nty && ty * COL_TH - L.rmax <= ry0 + 3 &&
+                ty * COL_TH + COL_TH + L.rmax > ry0)
+                need = flags[p.tiles_off + ty * ntx + tx] != 0;
+        }
+        if (!__syncthreads_or(need)) return;
+    }
 
     const int lane = threadIdx.x, wv = threadIdx.y;
     const int y = blockIdx.y * 4 + wv;
@@ -173,13 +200,14 @@ __device__ __forceinline__ void col_trip_fma(const ColTrip &t, float4 (&acc)[8])
 template <bool TABLE, bool PIPE>
 __global__ __launch_bounds__(256) void blur_cols_kernel(
     const pano_patch *__restrict__ table, pano_patch single, int nch, int level,
-    const float *wz_global, int ntaps) {
+    const float *wz_global, int ntaps, const uint8_t *__restrict__ flags) {
     const kptr_f32 wz = (kptr_f32)(uintptr_t)wz_global;
     extern __shared__ __attribute__((aligned(16))) float s_col[];   // [rows][64]
     const int pid = blockIdx.z / nch, c = blockIdx.z - pid * nch;
     const pano_patch p = TABLE ? table[pid] : single;
     const int x0 = blockIdx.x * COL_TW, y0 = blockIdx.y * COL_TH;   // A-relative
     if (x0 >= p.aw || y0 >= p.ah) return;                           // uniform per block
+    if (p.h > 2 * (ntaps >> 1) + 2 && !col_tile_active(flags, p, blockIdx.x, blockIdx.y)) return;
 
     const float *__restrict__ src = p.scratch + (size_t)(level * nch + c) * p.vh * p.apitch;
     float *__restrict__ dst = p.blurred + (size_t)(level * nch + c) * p.ah * p.apitch;
@@ -245,6 +273,29 @@ __global__ __launch_bounds__(256) void blur_cols_kernel(
     }
 }
 
+// One wave per column tile of every record: active = some 8 x 8 block under the
+// tile is not interior.
+__global__ __launch_bounds__(64) void tile_flags_kernel(const pano_patch *__restrict__ table,
+                                                        const uint8_t *__restrict__ interior,
+                                                        int W8, uint8_t *__restrict__ flags) {
+    const pano_patch p = table[blockIdx.z];
+    const int ntx = (p.aw + COL_TW - 1) / COL_TW, nty = (p.ah + COL_TH - 1) / COL_TH;
+    const int tx = blockIdx.x, ty = blockIdx.y;
+    if (tx >= ntx || ty >= nty) return;
+    const int gx0 = p.x0 + p.ax0 + tx * COL_TW, gy0 = p.y0 + p.ay0 + ty * COL_TH;
+    int gx1 = gx0 + COL_TW, gy1 = gy0 + COL_TH;
+    const int ax1 = p.x0 + p.ax0 + p.aw, ay1 = p.y0 + p.ay0 + p.ah;
+    gx1 = gx1 < ax1 ? gx1 : ax1;
+    gy1 = gy1 < ay1 ? gy1 : ay1;
+    const int bx0 = gx0 >> 3, bx1 = (gx1 - 1) >> 3, by0 = gy0 >> 3, by1 = (gy1 - 1) >> 3;
+    const int nbx = bx1 - bx0 + 1, total = nbx * (by1 - by0 + 1);
+    bool active = false;
+    for (int i = threadIdx.x; i < total; i += 64)
+        active |= interior[(size_t)(by0 + i / nbx) * W8 + bx0 + i % nbx] == 0;
+    if (__ballot(active) && threadIdx.x == 0) flags[p.tiles_off + ty * ntx + tx] = 1;
+    if (!__ballot(active) && threadIdx.x == 0) flags[p.tiles_off + ty * ntx + tx] = 0;
+}
+
 static int check_taps(int ntaps, const char *who) {
     PANO_REQUIRE(ntaps >= 1 && (ntaps & 1) && ntaps <= PANO_MAX_TAPS,
                  "%s: aperture %d must be odd and within [1, %d]", who, ntaps, PANO_MAX_TAPS);
@@ -281,7 +332,8 @@ static int make_levels(const float *taps, const int *ntaps, int n_blur, Levels *
 static int launch_blur(const pano_patch *table, const pano_patch &single, int n, int nch,
                        int alpha_ch, int max_aw, int max_vh, int max_ah,
                        const int16_t *owner, int W, const float *taps, const int *ntaps,
-                       int n_blur, hipStream_t stream, const char *who) {
+                       int n_blur, const uint8_t *interior, uint8_t *tile_flags,
+                       hipStream_t stream, const char *who) {
     Levels L = {};
     const float *col_wz[PANO_MAX_LEVELS];
     if (int rc = make_levels(taps, ntaps, n_blur, &L, col_wz, who)) return rc;
@@ -299,16 +351,25 @@ static int launch_blur(const pano_patch *table, const pano_patch &single, int n,
     // A/B switch for tools/ab_bench.py; the default is the measured-faster form
     const char *env = getenv("PANO_COLS_PIPE");
     const bool pipe = env ? env[0] != '0' : false;   // measured: 1.78 vs 1.92 ms (cfg3)
+    const uint8_t *flags = nullptr;
+    if (interior && table) {
+        dim3 grid(ceil_div(max_aw, COL_TW), ceil_div(max_ah, COL_TH), n);
+        PANO_TIMED(PK_TILE_FLAGS, stream,
+                   hipLaunchKernelGGL(tile_flags_kernel, grid, dim3(64), 0, stream, table, interior,
+                                      ceil_div(W, 8), tile_flags));
+        PANO_LAUNCH_CHECK("tile_flags_kernel");
+        flags = tile_flags;
+    }
     {
         dim3 block(64, 4), grid(ceil_div(max_aw, ROW_TW), ceil_div(max_vh, 4), n * nch);
         if (table)
             PANO_TIMED(PK_BLUR_ROWS, stream,
                        hipLaunchKernelGGL(blur_rows_kernel<true>, grid, block, 0, stream, table,
-                                          single, nch, alpha_ch, L, owner, W));
+                                          single, nch, alpha_ch, L, owner, W, flags));
         else
             PANO_TIMED(PK_BLUR_ROWS, stream,
                        hipLaunchKernelGGL(blur_rows_kernel<false>, grid, block, 0, stream, table,
-                                          single, nch, alpha_ch, L, owner, W));
+                                          single, nch, alpha_ch, L, owner, W, flags));
         PANO_LAUNCH_CHECK("blur_rows_kernel");
     }
     for (int k = 0; k < n_blur; ++k) {
@@ -318,7 +379,7 @@ static int launch_blur(const pano_patch *table, const pano_patch &single, int n,
 #define LAUNCH_COLS(T, P)                                                              \
     PANO_TIMED(PK_BLUR_COLS, stream,                                                   \
                hipLaunchKernelGGL((blur_cols_kernel<T, P>), grid, block, lds, stream,  \
-                                  table, single, nch, k, col_wz[k], ntaps[k]))
+                                  table, single, nch, k, col_wz[k], ntaps[k], flags))
         if (table) {
             if (pipe) LAUNCH_COLS(true, true); else LAUNCH_COLS(true, false);
         } else {
@@ -343,21 +404,23 @@ extern "C" int pano_blur_plane(const float *src, float *dst, float *tmp, int h,
     p.h = p.vh = p.ah = h;
     p.w = p.vw = p.aw = w;
     p.vpitch = p.apitch = pitch;
-    return launch_blur(nullptr, p, 1, 1, -1, w, h, h, nullptr, 0, taps, &ntaps, 1,
-                       (hipStream_t)stream, "pano_blur_plane");
+    return launch_blur(nullptr, p, 1, 1, -1, w, h, h, nullptr, 0, taps, &ntaps, 1, nullptr,
+                       nullptr, (hipStream_t)stream, "pano_blur_plane");
 }
 
 extern "C" int pano_multiband_blur(const pano_patch *patches, int n, int max_aw,
                                    int max_vh, int max_ah, const int16_t *owner, int W,
                                    const float *taps, const int *ntaps, int n_blur,
+                                   const uint8_t *interior, uint8_t *tile_flags,
                                    void *stream) {
     PANO_REQUIRE(patches && owner && taps && ntaps, "pano_multiband_blur: null pointer");
     PANO_REQUIRE(n >= 0 && n <= 32767 && W > 0, "pano_multiband_blur: bad argument");
     PANO_REQUIRE(max_aw >= 0 && max_vh >= 0 && max_ah >= 0, "pano_multiband_blur: bad extents");
+    PANO_REQUIRE(!interior || tile_flags, "pano_multiband_blur: interior map without tile_flags");
     if (n == 0 || n_blur == 0 || max_aw == 0 || max_vh == 0 || max_ah == 0) return PANO_OK;
     pano_patch none = {};
     return launch_blur(patches, none, n, 4, 3, max_aw, max_vh, max_ah, owner, W, taps, ntaps,
-                       n_blur, (hipStream_t)stream, "pano_multiband_blur");
+                       n_blur, interior, tile_flags, (hipStream_t)stream, "pano_multiband_blur");
 }
 
 // ---- cv2.pyrDown -----------------------------------------------------------

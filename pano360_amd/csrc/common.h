@@ -53,6 +53,8 @@ enum PanoKernelId {
     PK_WARP_WINDOWS,
     PK_BLEND_CAMERAS,
     PK_OWNED_SPANS,
+    PK_INTERIOR,
+    PK_TILE_FLAGS,
     PK_COUNT
 };
 extern bool g_pano_timing_on;

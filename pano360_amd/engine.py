@@ -216,7 +216,7 @@ def _ptr(t):
 PATCH_DTYPE = np.dtype([(k, "<u8") for k in ("planes", "mask", "blurred", "scratch")]
                        + [(k, "<i4") for k in ("y0", "x0", "h", "w", "vy0", "vx0", "vh", "vw",
                                                "ay0", "ax0", "ah", "aw", "vpitch", "apitch",
-                                               "index", "reserved")])
+                                               "index", "tiles_off")])
 CAMERA_DTYPE = np.dtype([("proj", "<f8", (9,)), ("frame", "<u8"), ("hat_x", "<u8"),
                          ("hat_y", "<u8")]
                         + [(k, "<i4") for k in ("sh", "sw", "y0", "x0", "h", "w")])
@@ -341,6 +341,10 @@ class PatchTable:
     def __init__(self, records, device):
         self.host = np.array(records, dtype=PATCH_DTYPE).reshape(-1)
         self.n = len(self.host)
+        tiles = ((self.host["aw"].astype(np.int64) + 63) // 64) * \
+            ((self.host["ah"].astype(np.int64) + 127) // 128)        # 64 x 128 column tiles
+        self.host["tiles_off"] = np.concatenate([[0], np.cumsum(tiles)[:-1]]) if self.n else 0
+        self.n_tiles = int(tiles.sum())
         self.dev = _to_device(self.host, device)
         mx = lambda k: int(self.host[k].max()) if self.n else 0   # noqa: E731
         self.max_vw, self.max_vh, self.max_aw, self.max_ah = (mx("vw"), mx("vh"), mx("aw"),
@@ -538,25 +542,46 @@ class Engine:
         mosaic, fl = self.blur_and_compose(table, owner, valid, shape, n_levels, want_float)
         return mosaic, fl, owner, valid
 
+    def interior_map(self, owner, radius, strip=None):
+        """uint8 [ceil(H/8)][ceil(W/8)]: 8 x 8 blocks whose pixels all have a single
+        owner within ``radius`` - there the multiband mosaic is the owner's colour."""
+        torch = _torch()
+        H, W = owner.shape
+        c0, c1 = strip if strip is not None else (0, W)
+        shape8 = ((H + 7) // 8, (W + 7) // 8)
+        bown = torch.empty(shape8, dtype=torch.int16, device=self.device)
+        interior = torch.empty(shape8, dtype=torch.uint8, device=self.device)
+        _lib.check(self.lib.pano_interior_map(_ptr(owner), H, W, c0, c1, radius, _ptr(bown),
+                                              _ptr(interior), self.stream()),
+                   "pano_interior_map")
+        return interior
+
     def blur_and_compose(self, table, owner, valid, shape, n_levels, want_float=False,
-                         strip=None):
+                         strip=None, interior=None, cams=None, plan=None):
         """All Gaussian levels of all patches (n_levels launches), then the gather
-        over the mosaic columns ``strip`` (default: all of them)."""
+        over the mosaic columns ``strip`` (default: all of them).  With an
+        ``interior`` map, blur tiles and gathers are skipped where the result is
+        the owner's colour (needs ``cams`` with frame pointers and ``plan``)."""
         torch = _torch()
         H, W = shape
         c0, c1 = strip if strip is not None else (0, W)
         taps, ntaps, n_blur, _ = self.blur_tables(n_levels)
         if n_blur:
+            flags = (torch.empty(max(table.n_tiles, 1), dtype=torch.uint8, device=self.device)
+                     if interior is not None else None)
             _lib.check(self.lib.pano_multiband_blur(
                 table.ptr, table.n, table.max_aw, table.max_vh, table.max_ah, _ptr(owner), W,
-                _ptr(taps), ntaps, n_blur, self.stream()), "pano_multiband_blur")
+                _ptr(taps), ntaps, n_blur, _ptr(interior), _ptr(flags), self.stream()),
+                "pano_multiband_blur")
         mosaic = torch.empty((H, W, 3), dtype=torch.uint8, device=self.device)
         fl = (torch.empty((H, W, 3), dtype=torch.float32, device=self.device)
               if want_float else None)
-        _lib.check(self.lib.pano_multiband_compose(table.ptr, table.n, H, W, c0, c1, n_levels,
-                                                   _ptr(owner), _ptr(valid), _ptr(mosaic),
-                                                   _ptr(fl), self.stream()),
-                   "pano_multiband_compose")
+        tabs = plan.dev if interior is not None else (None, None, None)
+        _lib.check(self.lib.pano_multiband_compose(
+            table.ptr, table.n, H, W, c0, c1, n_levels, _ptr(owner), _ptr(valid),
+            _ptr(interior), _ptr(cams) if interior is not None else None, _ptr(tabs[0]),
+            _ptr(tabs[1]), _ptr(tabs[2]), _ptr(self.lut255) if interior is not None else None,
+            _ptr(mosaic), _ptr(fl), self.stream()), "pano_multiband_compose")
         return mosaic, fl
 
     def simple_blend(self, patches, shape, linear, table=None):
@@ -624,7 +649,7 @@ class Engine:
         return self.owned_regions(owner, n, strip)[0]
 
     def multiband_fused(self, frames, plan, n_levels, want_float=False, frame_ids=None,
-                        strip=None):
+                        strip=None, shortcut=True):
         """The headline path, for the mosaic columns ``strip`` = (c0, c1) (default:
         the whole mosaic).  ``frames[j]`` is the frame of camera ``frame_ids[j]``
         (default: all cameras in order); every camera whose patch reaches within
@@ -639,7 +664,11 @@ class Engine:
         H, W = plan.shape
         c0, c1 = strip if strip is not None else (0, W)
         taps, ntaps, n_blur, radius = self.blur_tables(n_levels)
-        ext = (max(c0 - radius, 0), min(c1 + radius, W))
+        # the owner map is needed one radius past the strip for the windows, and as
+        # far as the 8 x 8-block interior test looks, so that every strip classifies
+        # its pixels exactly as the whole mosaic would
+        margin = max(radius, 8 * ((radius + 14) // 8) + 7) if shortcut and n_blur else radius
+        ext = (max(c0 - margin, 0), min(c1 + margin, W))
         ids = list(range(plan.n)) if frame_ids is None else list(frame_ids)
         have = dict(zip(ids, frames))
         cams = self.camera_table(plan, have)
@@ -664,8 +693,9 @@ class Engine:
             _ptr(cams), table.ptr, table.n, table.max_vw, table.max_vh, _ptr(plan.dev[0]),
             _ptr(plan.dev[1]), _ptr(plan.dev[2]), _ptr(self.lut255), self.stream()),
             "pano_warp_windows")
+        interior = self.interior_map(owner, radius, ext) if shortcut and n_blur else None
         mosaic, fl = self.blur_and_compose(table, owner, valid, plan.shape, n_levels,
-                                           want_float, (c0, c1))
+                                           want_float, (c0, c1), interior, cams, plan)
         return mosaic, fl, valid, patches
 
     def blend_fused(self, frames, plan, linear, frame_ids=None, strip=None):
@@ -730,14 +760,14 @@ class Engine:
 
     # -- whole stitch -----------------------------------------------------------
     def stitch(self, frames, plan, blend="multiband", n_levels=5, want_float=False,
-               fused=True):
+               fused=True, shortcut=True):
         """uint8 frames on device -> (mosaic u8 on device, float mosaic, valid,
         patches).  ``fused=False`` runs multiband through whole-patch stage
         buffers (what the blender protocol sees); both give the same mosaic."""
         if not hasattr(plan, "dev"):
             self.upload_plan(plan)
         if blend == "multiband" and fused:
-            return self.multiband_fused(frames, plan, n_levels, want_float)
+            return self.multiband_fused(frames, plan, n_levels, want_float, shortcut=shortcut)
         if fused:
             mosaic, valid = self.blend_fused(frames, plan, blend == "linear")
             return mosaic, None, valid, []
