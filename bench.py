@@ -61,11 +61,25 @@ def kernel_times(lib):
     return out
 
 
-def roofline_for(times, plan, patches, n_levels, steps):
+def pmc_traffic(name):
+    """HBM bytes per launch of kernel `name` from the committed PMC summary of this
+    same command (profiles/<round>/pmc_traffic.json, written from tools/pmc.sh
+    output: FETCH_SIZE x 2 + WRITE_SIZE, KiB -> bytes, per MI355X_MICROARCH.md)."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "pmc_traffic.json")))[::-1]:
+        with open(path) as fid:
+            table = json.load(fid)
+        if name in table.get("bytes_per_launch", {}):
+            return table["bytes_per_launch"][name], os.path.relpath(path, ROOT)
+    return None, None
+
+
+def roofline_for(times, plan, patches, n_levels, steps, px_active):
     """Roofline entry of the kernel with the largest share of the timed region.
     Algorithmic work per launch counts the pixels that launch really produced
-    (windows V / rectangles A of the patches), not the
-    reference's whole-patch count P."""
+    (windows V / rectangles A of the patches, only the column tiles that were
+    not skipped as interior - DESIGN.md §Kernels), not the reference's
+    whole-patch count P."""
     from pano360_amd import engine
     name = max(times, key=lambda k: times[k][0])
     total_ms, launches = times[name]
@@ -74,7 +88,7 @@ def roofline_for(times, plan, patches, n_levels, steps):
     win = [((p.window[1] - p.window[0]), (p.window[3] - p.window[2]),
             (p.area[1] - p.area[0]), (p.area[3] - p.area[2])) for p in patches]
     px_rows = sum(vh * aw for vh, vw, ah, aw in win)      # row pass: rows of V x cols of A
-    px_cols = sum(ah * aw for vh, vw, ah, aw in win)      # column pass / gather: A
+    px_cols = px_active or sum(ah * aw for vh, vw, ah, aw in win)   # column pass / gather
     px_warp = sum(vh * vw for vh, vw, ah, aw in win)      # warp: V
     taps = [engine.gaussian_ksize(s) for s in engine.level_sigmas(n_levels)]
     if name in ("blur_rows_kernel", "blur_cols_kernel"):
@@ -82,8 +96,10 @@ def roofline_for(times, plan, patches, n_levels, steps):
         px = px_rows if name == "blur_rows_kernel" else px_cols
         flop = steps * sum(2.0 * t * 4 * px for t in taps)
         achieved = flop / launches / avg_s / 1e12
+        traffic, source = pmc_traffic(name)
         return dict(kernel=name, bound="mfma", achieved=achieved, peak=F32_PEAK_TFLOPS,
-                    unit="TFLOP/s", frac=achieved / F32_PEAK_TFLOPS, traffic=None,
+                    unit="TFLOP/s", frac=achieved / F32_PEAK_TFLOPS, traffic=traffic,
+                    traffic_source=source,
                     note="f32 FMA on the vector ALU; gfx950 f32 MFMA peak equals the "
                          "f32 vector peak (157.3 TFLOP/s), no MFMA is issued",
                     avg_launch_ms=avg_s * 1e3, launches=launches)
@@ -97,9 +113,10 @@ def roofline_for(times, plan, patches, n_levels, steps):
         "multiband_compose_kernel": (12.0 + 16.0 * (n_levels - 1)) * px_cols + 6.0 * M,
     }.get(name, 0.0)
     achieved = per_step * steps / launches / avg_s / 1e9
+    traffic, source = pmc_traffic(name)
     return dict(kernel=name, bound="hbm", achieved=achieved, peak=HBM_PEAK_GBPS,
-                unit="GB/s", frac=achieved / HBM_PEAK_GBPS, traffic=None,
-                avg_launch_ms=avg_s * 1e3, launches=launches)
+                unit="GB/s", frac=achieved / HBM_PEAK_GBPS, traffic=traffic,
+                traffic_source=source, avg_launch_ms=avg_s * 1e3, launches=launches)
 
 
 def cpu_baseline(cfg):
@@ -233,7 +250,8 @@ def main():
                 "input_MPps": S / (ms * 1e-3) / 1e6, "mosaic_MPps": M / (ms * 1e-3) / 1e6,
             },
             "kernel_ms_per_step": {k: v[0] / args.steps for k, v in sorted(times.items())},
-            "roofline": roofline_for(times, plan, patches, n_levels, args.steps),
+            "roofline": roofline_for(times, plan, patches, n_levels, args.steps,
+                                     eng.active_tile_pixels()),
             "active_megapixels": {
                 "warped": sum((p.window[1] - p.window[0]) * (p.window[3] - p.window[2])
                               for p in patches) / 1e6,

@@ -556,6 +556,27 @@ class Engine:
                    "pano_interior_map")
         return interior
 
+    def active_tile_pixels(self):
+        """Pixels of the 64 x 128 column tiles the last blur really computed (all of
+        every rectangle A when no interior map was in use).  Synchronises."""
+        table, flags = getattr(self, "last_tiles", (None, None))
+        if table is None:
+            return 0
+        host = table.host
+        if flags is None:
+            return int((host["ah"].astype(np.int64) * host["aw"]).sum())
+        on = flags.cpu().numpy()
+        total = 0
+        for rec in host:
+            ntx, nty = (int(rec["aw"]) + 63) // 64, (int(rec["ah"]) + 127) // 128
+            if ntx * nty == 0:
+                continue
+            grid = on[int(rec["tiles_off"]):int(rec["tiles_off"]) + ntx * nty].reshape(nty, ntx)
+            wx = np.minimum(64, int(rec["aw"]) - 64 * np.arange(ntx))
+            wy = np.minimum(128, int(rec["ah"]) - 128 * np.arange(nty))
+            total += int((grid.astype(np.int64) * wy[:, None] * wx[None, :]).sum())
+        return total
+
     def blur_and_compose(self, table, owner, valid, shape, n_levels, want_float=False,
                          strip=None, interior=None, cams=None, plan=None):
         """All Gaussian levels of all patches (n_levels launches), then the gather
@@ -573,6 +594,7 @@ class Engine:
                 table.ptr, table.n, table.max_aw, table.max_vh, table.max_ah, _ptr(owner), W,
                 _ptr(taps), ntaps, n_blur, _ptr(interior), _ptr(flags), self.stream()),
                 "pano_multiband_blur")
+            self.last_tiles = (table, flags)        # for active_tile_pixels (reporting)
         mosaic = torch.empty((H, W, 3), dtype=torch.uint8, device=self.device)
         fl = (torch.empty((H, W, 3), dtype=torch.float32, device=self.device)
               if want_float else None)

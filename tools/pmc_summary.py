@@ -1,9 +1,14 @@
 #!/usr/bin/env python3
-"""Per-kernel averages of the rocprofv3 --pmc CSVs written by tools/pmc.sh."""
+"""Per-kernel averages of the rocprofv3 --pmc CSVs written by tools/pmc.sh, and
+pmc_traffic.json: HBM bytes per launch = (FETCH_SIZE x 2 + WRITE_SIZE) x 1024
+(FETCH_SIZE counts half the bytes of wide coalesced reads on gfx950 and both
+counters are in KiB: MI355X_MICROARCH.md, "HBM")."""
 import collections
 import csv
 import glob
+import json
 import os
+import re
 import sys
 
 
@@ -12,15 +17,24 @@ def main(root):
     for path in glob.glob(os.path.join(root, "*", "**", "*counter_collection.csv"), recursive=True):
         with open(path) as fid:
             for row in csv.DictReader(fid):
-                name = row["Kernel_Name"].split("(")[0].replace("void ", "")[:40]
+                name = row["Kernel_Name"].split("(")[0].replace("void ", "")
+                name = re.sub(r"<.*", "", name)[:40]
                 acc[name][row["Counter_Name"]].append(float(row["Counter_Value"]))
     counters = sorted({c for k in acc.values() for c in k})
+    traffic = {}
     for name in sorted(acc):
         print(f"== {name}  (dispatches: {max(len(v) for v in acc[name].values())})")
         for c in counters:
             vals = acc[name].get(c)
             if vals:
                 print(f"   {c:24s} avg {sum(vals) / len(vals):16.1f}   sum {sum(vals):18.1f}")
+        f, w = acc[name].get("FETCH_SIZE"), acc[name].get("WRITE_SIZE")
+        if f and w:
+            traffic[name] = (2.0 * sum(f) / len(f) + sum(w) / len(w)) * 1024.0
+    with open(os.path.join(root, "pmc_traffic.json"), "w") as fid:
+        json.dump({"command": "bench.py (see tools/pmc.sh)", "unit": "bytes per launch",
+                   "formula": "(2 x FETCH_SIZE + WRITE_SIZE) x 1024",
+                   "bytes_per_launch": traffic}, fid, indent=1)
 
 
 if __name__ == "__main__":
