@@ -137,6 +137,100 @@ def remap(src, map1, map2, interpolation, borderMode=BORDER_CONSTANT):
     return acc[..., 0] if squeeze else acc
 
 
+def invert3x3(m):
+    """``cv::invert`` on a 3x3 CV_64F matrix: adjugate times 1/det, one rounding
+    per operation (OpenCV special-cases small matrices instead of running LU)."""
+    m = np.asarray(m, dtype=np.float64)
+    det = (m[0, 0] * (m[1, 1] * m[2, 2] - m[1, 2] * m[2, 1])
+           - m[0, 1] * (m[1, 0] * m[2, 2] - m[1, 2] * m[2, 0])
+           + m[0, 2] * (m[1, 0] * m[2, 1] - m[1, 1] * m[2, 0]))
+    if det == 0.0:
+        return np.zeros((3, 3))
+    d = 1.0 / det
+    return np.array([
+        [(m[1, 1] * m[2, 2] - m[1, 2] * m[2, 1]) * d, (m[0, 2] * m[2, 1] - m[0, 1] * m[2, 2]) * d,
+         (m[0, 1] * m[1, 2] - m[0, 2] * m[1, 1]) * d],
+        [(m[1, 2] * m[2, 0] - m[1, 0] * m[2, 2]) * d, (m[0, 0] * m[2, 2] - m[0, 2] * m[2, 0]) * d,
+         (m[0, 2] * m[1, 0] - m[0, 0] * m[1, 2]) * d],
+        [(m[1, 0] * m[2, 1] - m[1, 1] * m[2, 0]) * d, (m[0, 1] * m[2, 0] - m[0, 0] * m[2, 1]) * d,
+         (m[0, 0] * m[1, 1] - m[0, 1] * m[1, 0]) * d]])
+
+
+def warp_block_width(width, height):
+    """Column-block width of ``WarpPerspectiveInvoker`` (BLOCK_SZ = 32): the
+    x coordinate enters as block start + offset, which fixes the rounding of
+    the double-precision numerators."""
+    bh0 = min(16, height)
+    return min(1024 // bh0, width)
+
+
+def warpPerspective(src, M, dsize, flags=INTER_LINEAR, borderMode=BORDER_CONSTANT):
+    """``cv2.warpPerspective`` for a float32 multi-channel source, INTER_LINEAR,
+    BORDER_TRANSPARENT, no WARP_INVERSE_MAP (call site stitcher.py:56-57).
+
+    Assumed OpenCV semantics:
+      * ``M`` (src -> dst) is inverted with ``cv::invert`` (adjugate / det);
+      * per destination pixel, in double, with x = block start + x1:
+        ``W = 32 / (W0 + M6*x1)`` (0 when the denominator is 0),
+        ``fX = (X0 + M0*x1) * W`` clamped to the int range, ``X = cvRound(fX)``;
+        integer part ``X >> 5`` saturated to int16, fraction ``X & 31``;
+      * ``remap`` with those fixed-point maps: a pixel is written only when all
+        four taps are inside the source (``0 <= sx < w-1``, ``0 <= sy < h-1``;
+        the BORDER_TRANSPARENT shortcut of ``remapBilinear`` for cn != 3), as
+        ``v00*w00 + v01*w01 + v10*w10 + v11*w11`` left to right in float32;
+      * pixels not written keep the destination's previous content.  The Python
+        binding hands OpenCV a freshly allocated array; the reference reads its
+        alpha channel as "0 = not written" (stitcher.py:58), so the
+        destination is taken to start as zeros.
+    """
+    if flags != INTER_LINEAR or borderMode != BORDER_TRANSPARENT:
+        raise NotImplementedError((flags, borderMode))
+    src = np.ascontiguousarray(src, dtype=np.float32)
+    sh, sw = src.shape[:2]
+    width, height = dsize
+    m = invert3x3(M).ravel()
+    bw0 = warp_block_width(width, height)
+
+    col = np.arange(width, dtype=np.int64)
+    xb = ((col // bw0) * bw0).astype(np.float64)[None, :]
+    x1 = (col % bw0).astype(np.float64)[None, :]
+    yy = np.arange(height, dtype=np.float64)[:, None]
+    x0_ = m[0] * xb + m[1] * yy + m[2]
+    y0_ = m[3] * xb + m[4] * yy + m[5]
+    w0_ = m[6] * xb + m[7] * yy + m[8]
+    den = w0_ + m[6] * x1
+    with np.errstate(divide="ignore", invalid="ignore"):
+        wgt = np.where(den != 0.0, float(INTER_TAB_SIZE) / den, 0.0)
+    lo, hi = float(-2 ** 31), float(2 ** 31 - 1)
+    fx_ = np.maximum(lo, np.minimum(hi, (x0_ + m[0] * x1) * wgt))
+    fy_ = np.maximum(lo, np.minimum(hi, (y0_ + m[3] * x1) * wgt))
+    big_x = np.rint(fx_).astype(np.int64)
+    big_y = np.rint(fy_).astype(np.int64)
+    sx = np.clip(big_x >> INTER_BITS, -32768, 32767)
+    sy = np.clip(big_y >> INTER_BITS, -32768, 32767)
+    fx = big_x & (INTER_TAB_SIZE - 1)
+    fy = big_y & (INTER_TAB_SIZE - 1)
+
+    inside = (sx >= 0) & (sx < max(sw - 1, 0)) & (sy >= 0) & (sy < max(sh - 1, 0))
+    sx = np.where(inside, sx, 0)
+    sy = np.where(inside, sy, 0)
+    f32 = np.float32
+    one = f32(1.0)
+    ax = fx.astype(f32) * f32(1.0 / INTER_TAB_SIZE)
+    ay = fy.astype(f32) * f32(1.0 / INTER_TAB_SIZE)
+    w00 = ((one - ay) * (one - ax))[..., None]
+    w01 = ((one - ay) * ax)[..., None]
+    w10 = (ay * (one - ax))[..., None]
+    w11 = (ay * ax)[..., None]
+    x1i = np.minimum(sx + 1, sw - 1)
+    y1i = np.minimum(sy + 1, sh - 1)
+    acc = src[sy, sx] * w00
+    acc = acc + src[sy, x1i] * w01
+    acc = acc + src[y1i, sx] * w10
+    acc = acc + src[y1i, x1i] * w11
+    return np.where(inside[..., None], acc, f32(0.0)).astype(f32)
+
+
 def gaussian_ksize(sigma, depth_is_8u=False):
     """Automatic aperture of ``GaussianBlur(ksize=(0,0))``:
     ``cvRound(sigma * (3 if 8-bit else 4) * 2 + 1) | 1``."""

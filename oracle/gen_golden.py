@@ -71,14 +71,20 @@ class Spy:
 
 
 def run_stitch(imgs, rots, intrs, blend, crop=False, n_levels=None,
-               max_resolution=None):
+               max_resolution=None, equalize=False):
     """Drive reference stitch(); returns (mosaic, spy, regions)."""
     spy = Spy()
     saved = (ref_st.cv2.remap, ref_st.multiband_blend, ref_st.MAX_RESOLUTION,
-             ref_st.multiband_blend.__defaults__)
+             ref_st.multiband_blend.__defaults__, ref_st.find_gains)
     regions = regions_from(imgs, rots, intrs)
+
+    def _spy_gains(overlaps, sizes, *args, **kwargs):
+        spy.overlaps, spy.sizes = overlaps.copy(), sizes.copy()
+        spy.gains = saved[4](overlaps, sizes, *args, **kwargs)
+        return spy.gains
     try:
         ref_st.cv2.remap = spy.remap
+        ref_st.find_gains = _spy_gains
         if max_resolution is not None:
             ref_st.MAX_RESOLUTION = max_resolution
         if blend == "multiband":
@@ -91,9 +97,11 @@ def run_stitch(imgs, rots, intrs, blend, crop=False, n_levels=None,
             blender = wrapped
         else:
             blender = spy.wrap(ref_st.BLENDERS[blend])
-        mosaic = ref_st.stitch(regions, blender=blender, crop=crop)
+        mosaic = ref_st.stitch(regions, blender=blender, crop=crop,
+                               equalize=equalize)
     finally:
         ref_st.cv2.remap = saved[0]
+        ref_st.find_gains = saved[4]
         ref_st.multiband_blend = saved[1]
         ref_st.MAX_RESOLUTION = saved[2]
         saved[1].__defaults__ = saved[3]
@@ -172,6 +180,52 @@ def scene_fixture(name, n, width, height, sweep_deg, jitter, seed, kind,
     np.savez_compressed(path, **out)
     print(f"{name}: {os.path.getsize(path) / 1e6:.2f} MB, multiband mosaic "
           f"{out['mb_shape']}, linear mosaic {out['lin_shape']}")
+
+
+def equalize_fixture(name, n, width, height, sweep_deg, jitter, seed,
+                     exposures, max_resolution=None):
+    """stitch(equalize=True) (stitcher.py:24-66, 280-281) on a smooth scene whose
+    frames were shot with different exposures.  "shim" keys throughout: the
+    overlap statistics go through the restated cv2.warpPerspective."""
+    imgs, rots, intrs = synth.make_scene(n, width, height, sweep_deg=sweep_deg,
+                                         jitter=jitter, seed=seed, kind="B")
+    imgs = [np.clip(np.rint(im.astype(np.float64) * e), 0, 255).astype(np.uint8)
+            for im, e in zip(imgs, exposures)]
+    out = dict(imgs=np.stack(imgs), rots=rots, intrs=intrs,
+               max_resolution=np.int64(-1 if max_resolution is None
+                                       else max_resolution))
+    for blend, key in (("linear", "lin"), ("multiband", "mb5")):
+        mosaic, spy, regions = run_stitch(imgs, rots, intrs, blend,
+                                          max_resolution=max_resolution,
+                                          equalize=True)
+        out[f"{key}_mosaic"] = mosaic
+        if blend == "linear":
+            out["overlaps"], out["sizes"], out["gains"] = (spy.overlaps, spy.sizes,
+                                                          spy.gains)
+            # equalised frames as the reference leaves them in reg.img
+            out["eq_rgb_0"] = regions[0].img[..., :3].copy()
+            out["eq_rgb_last"] = regions[-1].img[..., :3].copy()
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **out)
+    print(f"{name}: {os.path.getsize(path) / 1e6:.2f} MB, gains {out['gains']}")
+
+
+def gains_fixture():
+    """find_gains (stitcher.py:24-33) on the construction of the reference's own
+    test (pano_tests.py:79-96): overlaps consistent with known gains."""
+    rng = np.random.default_rng(42)
+    size = 10
+    gains = 1 + 0.1 * rng.standard_normal(size)
+    overlaps = 100 + 10 * rng.standard_normal((size, size))
+    for i in range(size):
+        for j in range(i + 1, size):
+            overlaps[i, j] = overlaps[j, i] * gains[j] / gains[i]
+    sizes = rng.standard_normal((size, size)) + 10
+    found = ref_st.find_gains(overlaps, sizes)
+    ratio = found / gains
+    assert np.allclose(ratio, ratio[0])        # the property pano_tests.py checks
+    return dict(fg_true=gains, fg_overlaps=overlaps, fg_sizes=sizes, fg_gains=found,
+                fg_gains_wide=ref_st.find_gains(overlaps, sizes, stdn=0.5, stdg=1.0))
 
 
 def pure_fixture():
@@ -263,14 +317,26 @@ def pure_fixture():
 
 def main():
     os.makedirs(OUT, exist_ok=True)
-    pure_fixture()
-    scene_fixture("scene_small_noise", n=4, width=96, height=64, sweep_deg=60.0,
-                  jitter=0.01, seed=0, kind="A", levels=(5, 6))
-    scene_fixture("scene_small_smooth", n=5, width=128, height=72,
-                  sweep_deg=100.0, jitter=0.01, seed=10, kind="B", levels=(5,))
-    scene_fixture("scene_capped", n=8, width=240, height=136, sweep_deg=140.0,
-                  jitter=0.0, seed=20, kind="B", levels=(5,),
-                  max_resolution=300, keep_warped=False)
+    jobs = {
+        "pure": pure_fixture,
+        "gains": lambda: np.savez_compressed(os.path.join(OUT, "gains.npz"),
+                                             **gains_fixture()),
+        "scene_small_noise": lambda: scene_fixture(
+            "scene_small_noise", n=4, width=96, height=64, sweep_deg=60.0,
+            jitter=0.01, seed=0, kind="A", levels=(5, 6)),
+        "scene_small_smooth": lambda: scene_fixture(
+            "scene_small_smooth", n=5, width=128, height=72, sweep_deg=100.0,
+            jitter=0.01, seed=10, kind="B", levels=(5,)),
+        "scene_equalize": lambda: equalize_fixture(
+            "scene_equalize", n=5, width=128, height=72, sweep_deg=70.0,
+            jitter=0.01, seed=21, exposures=(0.8, 1.1, 1.0, 1.25, 0.9)),
+        "scene_capped": lambda: scene_fixture(
+            "scene_capped", n=8, width=240, height=136, sweep_deg=140.0,
+            jitter=0.0, seed=20, kind="B", levels=(5,), max_resolution=300,
+            keep_warped=False),
+    }
+    for name in (sys.argv[1:] or list(jobs)):       # default: regenerate everything
+        jobs[name]()
 
 
 if __name__ == "__main__":

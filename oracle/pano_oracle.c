@@ -530,3 +530,105 @@ void orc_pyr_down(const float *src, int h, int w, float *tmp, float *dst) {
             dst[(size_t)y * ow + x] = (m[x] * 6.0f + (l1[x] + r1[x]) * 4.0f + l2[x] + r2[x]) * (1.0f / 256.0f);
     }
 }
+
+/* ------------------------------------------------------------------------
+ * Overlap statistics of equalize_gains for one pair (i, j)
+ *                                                       stitcher.py:44-63
+ * overlap = cv2.warpPerspective(img_j, hom, (w, h), BORDER_TRANSPARENT);
+ * mask = overlap[..., 3] != 0; size = sum(mask);
+ * mean_i = np.mean(img_i[mask, :3]); mean_j = np.mean(overlap[mask, :3]).
+ *
+ * OpenCV semantics restated (unpinned, see cv2_shim.warpPerspective): minv =
+ * cv::invert(hom) is passed in; per pixel, in double, with x = block start +
+ * x1 (block width bw0): W = 32 / (W0 + m6*x1) (0 if the denominator is 0),
+ * X = cvRound(clamp((X0 + m0*x1) * W)), tap = X >> 5 saturated to int16,
+ * frac = X & 31; a pixel is written only when all four taps are inside
+ * (BORDER_TRANSPARENT, cn = 4) and the destination starts as zeros.
+ *
+ * NumPy semantics restated (checked against NumPy 2.2 in this container):
+ * np.mean over float32 = float32 sum / float32(count); the sum runs over the
+ * row-major (pixel, channel) sequence in chunks of 8192 values (the ufunc
+ * buffer size), chunk results added left to right, each chunk by pairwise
+ * summation (8 interleaved partial sums below 128 values, halves above).
+ *
+ * img_i, img_j: [h][w][4] float32 (RGBA as _add_weights leaves them).
+ * out: size (pixel count), mean_i, mean_j.
+ * --------------------------------------------------------------------- */
+static float np_pairwise_f32(const float *a, size_t n) {
+    if (n < 8) {
+        float res = 0.0f;
+        for (size_t i = 0; i < n; ++i) res = res + a[i];
+        return res;
+    }
+    if (n <= 128) {
+        float r[8];
+        size_t i;
+        for (i = 0; i < 8; ++i) r[i] = a[i];
+        for (i = 8; i < n - (n % 8); i += 8)
+            for (int k = 0; k < 8; ++k) r[k] = r[k] + a[i + k];
+        float res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        for (; i < n; ++i) res = res + a[i];
+        return res;
+    }
+    size_t n2 = n / 2;
+    n2 -= n2 % 8;
+    return np_pairwise_f32(a, n2) + np_pairwise_f32(a + n2, n - n2);
+}
+
+static float np_sum_f32(const float *a, size_t n) {
+    float total = 0.0f;
+    for (size_t s = 0; s < n; s += 8192) {
+        size_t len = n - s < 8192 ? n - s : 8192;
+        float part = np_pairwise_f32(a + s, len);
+        total = s == 0 ? part : total + part;
+    }
+    return total;
+}
+
+void orc_overlap_stats(const float *img_i, const float *img_j, int h, int w,
+                       const double *m, int bw0, double *size_out,
+                       float *mean_i, float *mean_j) {
+    float *gi = (float *)malloc((size_t)h * w * 3 * sizeof(float));
+    float *gj = (float *)malloc((size_t)h * w * 3 * sizeof(float));
+    size_t n = 0;
+    for (int y = 0; y < h; ++y) {
+        for (int x = 0; x < w; ++x) {
+            double xb = (double)((x / bw0) * bw0), x1 = (double)(x % bw0);
+            double X0 = m[0] * xb + m[1] * (double)y + m[2];
+            double Y0 = m[3] * xb + m[4] * (double)y + m[5];
+            double W0 = m[6] * xb + m[7] * (double)y + m[8];
+            double W = W0 + m[6] * x1;
+            W = W != 0.0 ? 32.0 / W : 0.0;
+            double fX = fmax(-2147483648.0, fmin(2147483647.0, (X0 + m[0] * x1) * W));
+            double fY = fmax(-2147483648.0, fmin(2147483647.0, (Y0 + m[3] * x1) * W));
+            long X = lrint(fX), Y = lrint(fY);
+            int sx = sat16((int)(X >> 5)), sy = sat16((int)(Y >> 5));
+            if (sx < 0 || sx >= w - 1 || sy < 0 || sy >= h - 1) continue;
+            float ax = (float)(X & 31) * (1.0f / 32.0f), ay = (float)(Y & 31) * (1.0f / 32.0f);
+            float w00 = (1.0f - ay) * (1.0f - ax), w01 = (1.0f - ay) * ax;
+            float w10 = ay * (1.0f - ax), w11 = ay * ax;
+            const float *p00 = img_j + ((size_t)sy * w + sx) * 4;
+            const float *p01 = p00 + 4, *p10 = p00 + (size_t)w * 4, *p11 = p10 + 4;
+            float v[4];
+            for (int k = 0; k < 4; ++k) {
+                float a = p00[k] * w00;
+                a = a + p01[k] * w01;
+                a = a + p10[k] * w10;
+                a = a + p11[k] * w11;
+                v[k] = a;
+            }
+            if (v[3] == 0.0f) continue;
+            const float *pi = img_i + ((size_t)y * w + x) * 4;
+            for (int k = 0; k < 3; ++k) {
+                gi[n * 3 + k] = pi[k];
+                gj[n * 3 + k] = v[k];
+            }
+            ++n;
+        }
+    }
+    *size_out = (double)n;
+    *mean_i = n ? np_sum_f32(gi, n * 3) / (float)(n * 3) : 0.0f;
+    *mean_j = n ? np_sum_f32(gj, n * 3) / (float)(n * 3) : 0.0f;
+    free(gi);
+    free(gj);
+}

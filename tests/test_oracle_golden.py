@@ -10,6 +10,12 @@ def bits(a):
     return np.ascontiguousarray(a, np.float32).view(np.uint32)
 
 
+def same64(a, b):
+    """Bit equality of float64 arrays."""
+    a, b = np.ascontiguousarray(a, np.float64), np.ascontiguousarray(b, np.float64)
+    return a.shape == b.shape and np.array_equal(a.view(np.uint64), b.view(np.uint64))
+
+
 @pytest.mark.parametrize("name", SCENES)
 def test_plan_and_warp(oracle, name):
     g = load_golden(name)
@@ -147,3 +153,49 @@ def test_border_rule(oracle):
                         d = 1 if mode == 4 else 0
                         want = -want - 1 + d if want < 0 else length - 1 - (want - length) - d
                 assert lib.orc_border(p, length, mode) == want
+
+
+def test_find_gains_golden(oracle):
+    """find_gains against the reference on the construction of its own test
+    (pano_tests.py:79-96), and the property that test checks."""
+    g = load_golden("gains")
+    found = oracle.find_gains(g["fg_overlaps"], g["fg_sizes"])
+    assert same64(found, g["fg_gains"])
+    assert same64(oracle.find_gains(g["fg_overlaps"], g["fg_sizes"], stdn=0.5, stdg=1.0),
+                  g["fg_gains_wide"])
+    ratio = found / g["fg_true"]
+    np.testing.assert_almost_equal(ratio, np.full(len(ratio), ratio[0]))
+
+
+def test_equalize_gains_golden(oracle):
+    """stitch(equalize=True): overlap sizes / means, gains, equalised frames and
+    both mosaics equal the reference's, bit for bit."""
+    g = load_golden("scene_equalize")
+    imgs, rots, intrs, _ = scene_inputs(g)
+    rgbas = [oracle.add_weights(im) for im in imgs]
+    overlaps, sizes, gains = oracle.equalize_gains(rgbas, rots, intrs)
+    assert np.array_equal(sizes, g["sizes"])
+    assert same64(overlaps, g["overlaps"])
+    assert same64(gains, g["gains"])
+    assert np.array_equal(bits(rgbas[0][..., :3]), bits(g["eq_rgb_0"]))
+    assert np.array_equal(bits(rgbas[-1][..., :3]), bits(g["eq_rgb_last"]))
+    for blend, key in (("linear", "lin"), ("multiband", "mb5")):
+        mosaic = oracle.stitch(imgs, rots, intrs, blend=blend, equalize=True)
+        assert np.array_equal(mosaic, g[f"{key}_mosaic"]), blend
+
+
+def test_warp_perspective_shim_matches_oracle(oracle):
+    """The two independent restatements of cv2.warpPerspective(BORDER_TRANSPARENT)
+    agree on a pair with a strong perspective component."""
+    import cv2_shim
+    rng = np.random.default_rng(5)
+    h, w = 40, 72
+    a = oracle.add_weights(rng.integers(0, 256, (h, w, 3), dtype=np.uint8))
+    b = oracle.add_weights(rng.integers(0, 256, (h, w, 3), dtype=np.uint8))
+    hom = np.array([[0.9, 0.05, 6.0], [-0.04, 1.1, -3.0], [4e-4, -3e-4, 1.0]])
+    warped = cv2_shim.warpPerspective(b, hom, (w, h), borderMode=cv2_shim.BORDER_TRANSPARENT)
+    mask = warped[..., 3] != 0
+    size, mean_i, mean_j = oracle.overlap_stats(a, b, hom)
+    assert size == mask.sum() and 0 < size < h * w
+    assert np.float32(mean_i) == np.mean(a[mask, :3])
+    assert np.float32(mean_j) == np.mean(warped[mask, :3])
