@@ -89,6 +89,21 @@ typedef struct pano_camera {
     int32_t y0, x0, h, w;      /* patch rectangle in mosaic coordinates     */
 } pano_camera;
 
+/* One (i, j) iteration of equalize_gains (stitcher.py:44-63). */
+typedef struct pano_pair {
+    double minv[9];            /* cv::invert of the pixel homography j -> i
+                                  (stitcher.py:48), row-major                */
+    int32_t i, j;              /* camera indices, frame i is the destination */
+} pano_pair;
+
+/* Colour tables.  The reference turns a frame into float32(u8)/255
+ * (stitcher.py:259) and, with equalize=True, into clip(gain * that, 0, 1)
+ * (stitcher.py:66): either way a function of the uint8 value alone, so the
+ * kernels sample uint8 frames through a 256-entry float table built on the
+ * host with NumPy.  Entry points that sample several cameras take
+ * (lut, lut_stride): camera k uses lut + k * lut_stride; stride 0 = one table
+ * for all (no equalisation), stride 256 = one table per camera. */
+
 const char *pano_version(void);
 const char *pano_last_error(void);
 int pano_device_count(void);
@@ -136,7 +151,7 @@ int pano_warp_spherical(const uint8_t *frame, int sh, int sw,
 int pano_warp_windows(const pano_camera *cams, const pano_patch *patches, int n,
                       int max_vw, int max_vh, const double *sin_t,
                       const double *cos_t, const double *tan_p,
-                      const float *lut255, void *stream);
+                      const float *lut, int lut_stride, void *stream);
 
 /* Ownership + validity from warped patches   stitcher.py:196-204, 266-271
  * owner = first-index argmax of the patches' alpha plane (planes[3]), -1 where
@@ -210,14 +225,16 @@ int pano_interior_map(const int16_t *owner, int H, int W, int xs0, int xs1,
  * only the strip is written; mosaic_f32 is optional.
  * interior (optional): pixels of interior blocks are not gathered; the owner's
  * frame (cams[owner].frame) is sampled there exactly as the warp samples it,
- * which needs cams, the trig tables and lut255 (all NULL otherwise). */
+ * which needs cams, the trig tables and the colour tables (all NULL
+ * otherwise). */
 int pano_multiband_compose(const pano_patch *patches, int n, int H, int W,
                            int xs0, int xs1, int n_levels,
                            const int16_t *owner, const uint8_t *valid,
                            const uint8_t *interior, const pano_camera *cams,
                            const double *sin_t, const double *cos_t,
-                           const double *tan_p, const float *lut255,
-                           uint8_t *mosaic, float *mosaic_f32, void *stream);
+                           const double *tan_p, const float *lut,
+                           int lut_stride, uint8_t *mosaic, float *mosaic_f32,
+                           void *stream);
 
 /* linear_blend (linear != 0) or no_blend (linear == 0) of the mosaic columns
  * [xs0, xs1) straight from the frames         stitcher.py:160-183 + :300-317
@@ -228,8 +245,33 @@ int pano_multiband_compose(const pano_patch *patches, int n, int H, int W,
 int pano_blend_cameras(const pano_camera *cams, int n, int H, int W, int xs0,
                        int xs1, int linear, const double *sin_t,
                        const double *cos_t, const double *tan_p,
-                       const float *lut255, uint8_t *mosaic, uint8_t *valid,
-                       void *stream);
+                       const float *lut, int lut_stride, uint8_t *mosaic,
+                       uint8_t *valid, void *stream);
+
+/* Overlap statistics of equalize_gains           stitcher.py:36-63
+ * For each pair, every pixel (x, y) of frame i is looked up in frame j as
+ * cv2.warpPerspective(img_j, hom, (w, h), INTER_LINEAR, BORDER_TRANSPARENT)
+ * does on the float32 RGBA image (OpenCV semantics restated, parity unpinned):
+ * in double, with x = xb + x1, xb = (x / bw0) * bw0 the column-block start,
+ *   W = 32 / (m6*xb + m7*y + m8 + m6*x1)          (0 if the denominator is 0)
+ *   X = cvRound(clamp_int((m0*xb + m1*y + m2 + m0*x1) * W)),  Y likewise,
+ * taps (X >> 5, Y >> 5) saturated to int16, fractions X & 31, Y & 31; the pixel
+ * is written only if all four taps lie inside frame j; the bilinear sum runs
+ * left to right in float32.  A pixel counts where the sampled alpha (analytic,
+ * float32(hat_y*hat_x) per tap) is non-zero (stitcher.py:58).
+ * All frames must be h x w (the reference sizes everything by regions[0],
+ * stitcher.py:41).  bw0 = min(1024 / min(16, h), w) (WarpPerspectiveInvoker's
+ * block width).  lut255: dev float[256], float32(u8)/255.
+ * partials: dev double [n_pairs][pano_overlap_blocks(h, w)][3] workspace.
+ * stats: dev double [n_pairs][3] = {pixel count (stitcher.py:59), sum of
+ * frame i's colours over those pixels and the 3 channels, sum of the sampled
+ * colours of frame j}; the means of stitcher.py:62-63 are sum / (3 count).
+ * Sums are taken in double in a fixed order (the reference's np.mean sums in
+ * float32 pairwise; the two agree to ~1e-7 relative). */
+int pano_overlap_blocks(int h, int w);
+int pano_overlap_stats(const pano_camera *cams, const pano_pair *pairs,
+                       int n_pairs, int h, int w, int bw0, const float *lut255,
+                       double *partials, double *stats, void *stream);
 
 /* linear_blend on warped patches                        stitcher.py:171-183 */
 int pano_linear_blend(const pano_patch *patches, int n, int H, int W,

@@ -35,6 +35,11 @@ class Patch(C.Structure):
                 ("index", C.c_int32), ("tiles_off", C.c_int32)]
 
 
+class Pair(C.Structure):
+    """``pano_pair`` of include/pano360.h (80 bytes)."""
+    _fields_ = [("minv", C.c_double * 9), ("i", C.c_int32), ("j", C.c_int32)]
+
+
 class Camera(C.Structure):
     """``pano_camera`` of include/pano360.h (120 bytes)."""
     _fields_ = [("proj", C.c_double * 9), ("frame", C.c_void_p),
@@ -56,7 +61,7 @@ _SIGNATURES = {
     "pano_add_weights": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "pano_warp_spherical": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                  _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
-    "pano_warp_windows": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "pano_warp_windows": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp]),
     "pano_ownership": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp]),
     "pano_ownership_cameras": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "pano_owned_regions": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
@@ -64,8 +69,11 @@ _SIGNATURES = {
                                  C.POINTER(C.c_int), _i, _vp, _vp, _vp]),
     "pano_interior_map": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "pano_multiband_compose": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp,
-                                    _vp, _vp, _vp, _vp, _vp]),
-    "pano_blend_cameras": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+                                    _vp, _vp, _i, _vp, _vp, _vp]),
+    "pano_blend_cameras": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp,
+                                _vp]),
+    "pano_overlap_blocks": (_i, [_i, _i]),
+    "pano_overlap_stats": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "pano_linear_blend": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "pano_no_blend": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "pano_crop_rect": (_i, [_vp, _i, _i, _vp, _vp, _vp]),

@@ -137,15 +137,17 @@ __global__ __launch_bounds__(256) void ownership_cameras_kernel(
 // nothing, so it is skipped; no_blend keeps the LAST unmasked camera (:164-166).
 // Reads 3 bytes of frame per sampled tap (L1/L2 absorb the 4-tap overlap),
 // writes 3 B per mosaic pixel: HBM-light, bound by the per-sample arithmetic.
-template <bool LINEAR>
+// PERCAM: every camera has its own colour table (equalised exposures); the
+// tables then stay in global memory (1 KiB each, L1-resident) instead of LDS.
+template <bool LINEAR, bool PERCAM>
 __global__ __launch_bounds__(256) void blend_cameras_kernel(
     const pano_camera *__restrict__ cams, int n, int H, int W, int xs0, int xs1,
     const double *__restrict__ sin_t, const double *__restrict__ cos_t,
-    const double *__restrict__ tan_p, const float *__restrict__ lut255,
+    const double *__restrict__ tan_p, const float *__restrict__ lut,
     uint8_t *__restrict__ mosaic, uint8_t *__restrict__ valid) {
     __shared__ CamList sh;
     __shared__ float s_lut[256];
-    s_lut[threadIdx.y * 64 + threadIdx.x] = lut255[threadIdx.y * 64 + threadIdx.x];
+    if (!PERCAM) s_lut[threadIdx.y * 64 + threadIdx.x] = lut[threadIdx.y * 64 + threadIdx.x];
     const int bx0 = xs0 + blockIdx.x * 64, by0 = blockIdx.y * 4;
     const int listed = build_camera_list(sh, cams, n, bx0, min(bx0 + 64, xs1), by0,
                                          min(by0 + 4, H));     // has the barriers s_lut needs
@@ -172,9 +174,12 @@ __global__ __launch_bounds__(256) void blend_cameras_kernel(
         const uint8_t *p00 = r0 + tp.x0 * 3, *p01 = r0 + tp.x1 * 3;
         const uint8_t *p10 = r1 + tp.x0 * 3, *p11 = r1 + tp.x1 * 3;
         float rgb[3];
+        const float *__restrict__ gl = lut + (size_t)i * 256;
 #pragma unroll
         for (int ch = 0; ch < 3; ++ch)
-            rgb[ch] = lerp4(s_lut[p00[ch]], s_lut[p01[ch]], s_lut[p10[ch]], s_lut[p11[ch]], tp);
+            rgb[ch] = PERCAM ? lerp4(gl[p00[ch]], gl[p01[ch]], gl[p10[ch]], gl[p11[ch]], tp)
+                             : lerp4(s_lut[p00[ch]], s_lut[p01[ch]], s_lut[p10[ch]],
+                                     s_lut[p11[ch]], tp);
         if (LINEAR) {
             const float a = alpha_at(cam->hat_x, cam->hat_y, tp);
 #pragma unroll
@@ -304,24 +309,26 @@ struct InteriorArgs {
     int W8;
     const pano_camera *cams;
     const double *sin_t, *cos_t, *tan_p;
-    const float *lut255;
+    const float *lut;            // [256], or [n][256] when PERCAM
 };
 
-template <int L>
+template <int L, bool PERCAM>
 __global__ __launch_bounds__(256) void multiband_compose_kernel(
     const pano_patch *__restrict__ patches, int n, int H, int W, int xs0, int xs1,
     const int16_t *__restrict__ owner, const uint8_t *__restrict__ valid,
     uint8_t *__restrict__ mosaic, float *__restrict__ mosaic_f32, InteriorArgs ia) {
     __shared__ float s_lut[256];
-    if (ia.interior) {
-        s_lut[threadIdx.y * 64 + threadIdx.x] = ia.lut255[threadIdx.y * 64 + threadIdx.x];
+    if (ia.interior && !PERCAM) {
+        s_lut[threadIdx.y * 64 + threadIdx.x] = ia.lut[threadIdx.y * 64 + threadIdx.x];
         __syncthreads();
     }
     const int x = xs0 + blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
     if (x >= xs1 || y >= H) return;
     if (ia.interior && ia.interior[(size_t)(y / IB) * ia.W8 + x / IB]) {
         // interior pixel: the mosaic is the owner's warped colour, clipped, quantised
-        const pano_camera *cam = ia.cams + owner[(size_t)y * W + x];
+        const int own = owner[(size_t)y * W + x];
+        const pano_camera *cam = ia.cams + own;
+        const float *__restrict__ gl = ia.lut + (size_t)own * 256;
         const int sw = cam->sw, sh = cam->sh;
         float fx, fy;
         map_pixel(cam->proj, ia.sin_t[x], ia.cos_t[x], ia.tan_p[y], sw, sh, fx, fy);
@@ -333,7 +340,8 @@ __global__ __launch_bounds__(256) void multiband_compose_kernel(
         const size_t g = ((size_t)y * W + x) * 3;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            float v = lerp4(s_lut[p00[c]], s_lut[p01[c]], s_lut[p10[c]], s_lut[p11[c]], tp);
+            float v = PERCAM ? lerp4(gl[p00[c]], gl[p01[c]], gl[p10[c]], gl[p11[c]], tp)
+                             : lerp4(s_lut[p00[c]], s_lut[p01[c]], s_lut[p10[c]], s_lut[p11[c]], tp);
             v = v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v);
             if (mosaic_f32) mosaic_f32[g + c] = v;
             mosaic[g + c] = (uint8_t)(int)(255.0f * v);
@@ -487,22 +495,25 @@ extern "C" int pano_ownership_cameras(const pano_camera *cams, int n, int H, int
 extern "C" int pano_blend_cameras(const pano_camera *cams, int n, int H, int W, int xs0,
                                   int xs1, int linear, const double *sin_t,
                                   const double *cos_t, const double *tan_p,
-                                  const float *lut255, uint8_t *mosaic, uint8_t *valid,
-                                  void *stream) {
+                                  const float *lut, int lut_stride, uint8_t *mosaic,
+                                  uint8_t *valid, void *stream) {
     if (int rc = check_table(cams, n, H, W, "pano_blend_cameras")) return rc;
-    PANO_REQUIRE(sin_t && cos_t && tan_p && lut255 && mosaic, "pano_blend_cameras: null pointer");
+    PANO_REQUIRE(sin_t && cos_t && tan_p && lut && mosaic, "pano_blend_cameras: null pointer");
+    PANO_REQUIRE(lut_stride == 0 || lut_stride == 256,
+                 "pano_blend_cameras: lut_stride %d (0 = shared table, 256 = per camera)", lut_stride);
     PANO_REQUIRE(xs0 >= 0 && xs1 <= W && xs0 <= xs1, "pano_blend_cameras: bad strip [%d, %d)", xs0, xs1);
     if (xs0 == xs1) return PANO_OK;
     dim3 block(64, 4), grid(ceil_div(xs1 - xs0, 64), ceil_div(H, 4));
     hipStream_t s = (hipStream_t)stream;
-    if (linear)
-        PANO_TIMED(PK_BLEND_CAMERAS, s,
-                   hipLaunchKernelGGL(blend_cameras_kernel<true>, grid, block, 0, s, cams, n, H, W,
-                                      xs0, xs1, sin_t, cos_t, tan_p, lut255, mosaic, valid));
-    else
-        PANO_TIMED(PK_BLEND_CAMERAS, s,
-                   hipLaunchKernelGGL(blend_cameras_kernel<false>, grid, block, 0, s, cams, n, H, W,
-                                      xs0, xs1, sin_t, cos_t, tan_p, lut255, mosaic, valid));
+#define BLEND(LIN, PC)                                                                        \
+    PANO_TIMED(PK_BLEND_CAMERAS, s,                                                           \
+               hipLaunchKernelGGL((blend_cameras_kernel<LIN, PC>), grid, block, 0, s, cams, n, \
+                                  H, W, xs0, xs1, sin_t, cos_t, tan_p, lut, mosaic, valid))
+    if (linear && lut_stride) BLEND(true, true);
+    else if (linear) BLEND(true, false);
+    else if (lut_stride) BLEND(false, true);
+    else BLEND(false, false);
+#undef BLEND
     PANO_LAUNCH_CHECK("blend_cameras_kernel");
     return PANO_OK;
 }
@@ -606,26 +617,37 @@ extern "C" int pano_multiband_compose(const pano_patch *patches, int n, int H, i
                                       const int16_t *owner, const uint8_t *valid,
                                       const uint8_t *interior, const pano_camera *cams,
                                       const double *sin_t, const double *cos_t,
-                                      const double *tan_p, const float *lut255,
-                                      uint8_t *mosaic, float *mosaic_f32, void *stream) {
+                                      const double *tan_p, const float *lut,
+                                      int lut_stride, uint8_t *mosaic, float *mosaic_f32,
+                                      void *stream) {
     if (int rc = check_table(patches, n, H, W, "pano_multiband_compose")) return rc;
     PANO_REQUIRE(owner && valid && mosaic, "pano_multiband_compose: null pointer");
     PANO_REQUIRE(n_levels >= 1 && n_levels <= PANO_MAX_LEVELS,
                  "pano_multiband_compose: n_levels %d outside [1, %d]", n_levels, PANO_MAX_LEVELS);
     PANO_REQUIRE(xs0 >= 0 && xs1 <= W && xs0 <= xs1,
                  "pano_multiband_compose: bad strip [%d, %d)", xs0, xs1);
-    PANO_REQUIRE(!interior || (cams && sin_t && cos_t && tan_p && lut255),
+    PANO_REQUIRE(!interior || (cams && sin_t && cos_t && tan_p && lut),
                  "pano_multiband_compose: the interior map needs cameras, tables and LUT");
+    PANO_REQUIRE(lut_stride == 0 || lut_stride == 256,
+                 "pano_multiband_compose: lut_stride %d (0 = shared table, 256 = per camera)",
+                 lut_stride);
     if (xs0 == xs1) return PANO_OK;
-    InteriorArgs ia = {interior, ceil_div(W, IB), cams, sin_t, cos_t, tan_p, lut255};
+    InteriorArgs ia = {interior, ceil_div(W, IB), cams, sin_t, cos_t, tan_p, lut};
+    const bool percam = interior && lut_stride != 0;
     dim3 block(64, 4), grid(ceil_div(xs1 - xs0, 64), ceil_div(H, 4));
     hipStream_t s = (hipStream_t)stream;
-#define COMPOSE(L)                                                                   \
-    case L:                                                                          \
-        PANO_TIMED(PK_COMPOSE, s,                                                    \
-                   hipLaunchKernelGGL(multiband_compose_kernel<L>, grid, block, 0,   \
-                                      s, patches, n, H, W, xs0, xs1, owner, valid,   \
-                                      mosaic, mosaic_f32, ia));                      \
+#define COMPOSE(L)                                                                      \
+    case L:                                                                             \
+        if (percam)                                                                     \
+            PANO_TIMED(PK_COMPOSE, s,                                                   \
+                       hipLaunchKernelGGL((multiband_compose_kernel<L, true>), grid,    \
+                                          block, 0, s, patches, n, H, W, xs0, xs1,      \
+                                          owner, valid, mosaic, mosaic_f32, ia));       \
+        else                                                                            \
+            PANO_TIMED(PK_COMPOSE, s,                                                   \
+                       hipLaunchKernelGGL((multiband_compose_kernel<L, false>), grid,   \
+                                          block, 0, s, patches, n, H, W, xs0, xs1,      \
+                                          owner, valid, mosaic, mosaic_f32, ia));       \
         break;
     switch (n_levels) {
         COMPOSE(1) COMPOSE(2) COMPOSE(3) COMPOSE(4) COMPOSE(5) COMPOSE(6) COMPOSE(7) COMPOSE(8)

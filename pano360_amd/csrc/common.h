@@ -55,6 +55,7 @@ enum PanoKernelId {
     PK_OWNED_SPANS,
     PK_INTERIOR,
     PK_TILE_FLAGS,
+    PK_OVERLAP,
     PK_COUNT
 };
 extern bool g_pano_timing_on;

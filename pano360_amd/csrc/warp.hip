@@ -66,11 +66,12 @@ __global__ __launch_bounds__(256) void warp_spherical_kernel(
 __global__ __launch_bounds__(256) void warp_windows_kernel(
     const pano_camera *__restrict__ cams, const pano_patch *__restrict__ patches,
     const double *__restrict__ sin_t, const double *__restrict__ cos_t,
-    const double *__restrict__ tan_p, const float *__restrict__ lut255) {
+    const double *__restrict__ tan_p, const float *__restrict__ lut, int lut_stride) {
     __shared__ float s_lut[256];
     const pano_patch p = patches[blockIdx.z];
     if ((int)blockIdx.x * 64 >= p.vw || (int)blockIdx.y * 4 >= p.vh) return;   // uniform
-    s_lut[threadIdx.y * 64 + threadIdx.x] = lut255[threadIdx.y * 64 + threadIdx.x];
+    s_lut[threadIdx.y * 64 + threadIdx.x] =
+        lut[(size_t)p.index * lut_stride + threadIdx.y * 64 + threadIdx.x];
     __syncthreads();
 
     const int x = blockIdx.x * 64 + threadIdx.x;
@@ -160,8 +161,8 @@ extern "C" int pano_warp_spherical(const uint8_t *frame, int sh, int sw,
 extern "C" int pano_warp_windows(const pano_camera *cams, const pano_patch *patches, int n,
                                  int max_vw, int max_vh, const double *sin_t,
                                  const double *cos_t, const double *tan_p,
-                                 const float *lut255, void *stream) {
-    PANO_REQUIRE(cams && patches && sin_t && cos_t && tan_p && lut255,
+                                 const float *lut, int lut_stride, void *stream) {
+    PANO_REQUIRE(cams && patches && sin_t && cos_t && tan_p && lut && lut_stride >= 0,
                  "pano_warp_windows: null pointer");
     PANO_REQUIRE(n >= 0 && n <= 65535 && max_vw >= 0 && max_vh >= 0,
                  "pano_warp_windows: bad argument");
@@ -169,7 +170,7 @@ extern "C" int pano_warp_windows(const pano_camera *cams, const pano_patch *patc
     dim3 block(64, 4), grid(ceil_div(max_vw, 64), ceil_div(max_vh, 4), n);
     PANO_TIMED(PK_WARP_WINDOWS, (hipStream_t)stream,
                hipLaunchKernelGGL(warp_windows_kernel, grid, block, 0, (hipStream_t)stream,
-                                  cams, patches, sin_t, cos_t, tan_p, lut255));
+                                  cams, patches, sin_t, cos_t, tan_p, lut, lut_stride));
     PANO_LAUNCH_CHECK("warp_windows_kernel");
     return PANO_OK;
 }

@@ -202,6 +202,66 @@ class Plan:
         return sum((y1 - y0) * (x1 - x0) for y0, y1, x0, x1 in self.rects)
 
 
+# ------------------------------------------------------------------ exposure
+def find_gains(overlaps, sizes, stdn=0.1, stdg=2):
+    """Gains minimising the mean-intensity discrepancies on the overlaps
+    (stitcher.py:24-33, eq. (29) of Brown & Lowe): N x N normal equations, host
+    float64, ``np.linalg.solve`` like the reference."""
+    pair_w = (sizes + sizes.T) / (stdn * stdn)
+    prior_w = sizes / (stdg * stdg)
+    lhs = np.diag(np.sum(pair_w * overlaps * overlaps + prior_w, axis=1))
+    lhs -= pair_w * overlaps * overlaps.T
+    return np.linalg.solve(lhs, np.sum(prior_w, axis=1))
+
+
+def invert3x3(m):
+    """``cv::invert`` on 3 x 3 doubles (what cv2.warpPerspective applies to its
+    matrix): adjugate times 1/det, one rounding per operation."""
+    a, b, c, d, e, f, g, h, i = np.asarray(m, np.float64).ravel()
+    det = a * (e * i - f * h) - b * (d * i - f * g) + c * (d * h - e * g)
+    if det == 0.0:
+        return np.zeros((3, 3))
+    r = 1.0 / det
+    return np.array([[(e * i - f * h) * r, (c * h - b * i) * r, (b * f - c * e) * r],
+                     [(f * g - d * i) * r, (a * i - c * g) * r, (c * d - a * f) * r],
+                     [(d * h - e * g) * r, (b * g - a * h) * r, (a * e - b * d) * r]])
+
+
+def overlap_pairs(rots, intrs, width, height):
+    """The (i, j) pairs equalize_gains samples (stitcher.py:44-55) as a
+    ``pano_pair`` table: pixel homography j -> i = T (K_i R_i)(R_j^T K_j^-1) T^-1
+    with the reference's association of the products (stitcher.py:48,
+    bundle_adj.py:36-38), pairs with a corner of frame j behind frame i
+    dropped (:51-52), inverted as OpenCV inverts it."""
+    shift = np.array([[1, 0, width / 2], [0, 1, height / 2], [0, 0, 1]])
+    unshift = np.array([[1, 0, -width / 2], [0, 1, -height / 2], [0, 0, 1]])
+    corners = np.array([[0, 0, 1], [width, 0, 1], [width, height, 1], [0, height, 1]])
+    fwd = [intr.dot(rot) for rot, intr in zip(rots, intrs)]
+    back = [rot.T.dot(np.linalg.inv(intr)) for rot, intr in zip(rots, intrs)]
+    out = []
+    for i in range(len(rots)):
+        for j in range(i + 1, len(rots)):
+            hom = shift.dot(fwd[i].dot(back[j])).dot(unshift)
+            if np.any(hom.dot(corners.T).T[:, 2] < 0):
+                continue
+            out.append((invert3x3(hom).ravel(), i, j))
+    table = np.zeros(len(out), dtype=PAIR_DTYPE)
+    for k, rec in enumerate(out):
+        table[k] = rec
+    return table
+
+
+def gain_tables(gains):
+    """Per-camera colour tables of the equalised frames: the reference's
+    ``np.clip(gain * img, 0, 1)`` stored back into the float32 image
+    (stitcher.py:66) applied to the 256 values float32(u8)/255 can take."""
+    base = np.arange(256, dtype=np.float32) / np.float32(255)
+    luts = np.empty((len(gains), 256), np.float32)
+    for k, gain in enumerate(gains):
+        luts[k] = np.clip(gain * base, 0, 1)
+    return luts
+
+
 # ------------------------------------------------------------------- device
 def _torch():
     import torch
@@ -220,6 +280,8 @@ PATCH_DTYPE = np.dtype([(k, "<u8") for k in ("planes", "mask", "blurred", "scrat
 CAMERA_DTYPE = np.dtype([("proj", "<f8", (9,)), ("frame", "<u8"), ("hat_x", "<u8"),
                          ("hat_y", "<u8")]
                         + [(k, "<i4") for k in ("sh", "sw", "y0", "x0", "h", "w")])
+PAIR_DTYPE = np.dtype([("minv", "<f8", (9,)), ("i", "<i4"), ("j", "<i4")])
+assert PAIR_DTYPE.itemsize == C.sizeof(_lib.Pair) == 80
 assert PATCH_DTYPE.itemsize == C.sizeof(Patch) == 96
 assert CAMERA_DTYPE.itemsize == C.sizeof(_lib.Camera) == 120
 
@@ -488,19 +550,22 @@ class Engine:
         return plan
 
     # -- stage-level calls (whole patches, the blender protocol) ------------------
-    def add_weights(self, frame):
-        """_add_weights on device: uint8 [H,W,3] -> float32 [H,W,4]."""
+    def add_weights(self, frame, lut=None):
+        """_add_weights on device: uint8 [H,W,3] -> float32 [H,W,4]; ``lut`` = the
+        camera's colour table when the exposures were equalised."""
         torch = _torch()
         h, w = frame.shape[:2]
         hx, hy = self.hat_tables((h, w))
         out = torch.empty((h, w, 4), dtype=torch.float32, device=self.device)
-        _lib.check(self.lib.pano_add_weights(_ptr(frame), h, w, _ptr(self.lut255), _ptr(hx),
+        lut = self.lut255 if lut is None else lut
+        _lib.check(self.lib.pano_add_weights(_ptr(frame), h, w, _ptr(lut), _ptr(hx),
                                              _ptr(hy), _ptr(out), self.stream()),
                    "pano_add_weights")
         return out
 
-    def warp(self, frame, plan, index, patch, want_maps=False):
+    def warp(self, frame, plan, index, patch, want_maps=False, lut=None):
         torch = _torch()
+        lut = self.lut255 if lut is None else lut
         sh, sw = frame.shape[:2]
         hx, hy = self.hat_tables((sh, sw))
         y0, _, x0, _ = plan.rects[index]
@@ -511,16 +576,17 @@ class Engine:
         proj = plan.projs[index]
         _lib.check(self.lib.pano_warp_spherical(
             _ptr(frame), sh, sw, proj.ctypes.data_as(C.c_void_p), _ptr(plan.dev[0]),
-            _ptr(plan.dev[1]), _ptr(plan.dev[2]), _ptr(self.lut255), _ptr(hx), _ptr(hy),
+            _ptr(plan.dev[1]), _ptr(plan.dev[2]), _ptr(lut), _ptr(hx), _ptr(hy),
             x0, y0, patch.w, patch.h, _ptr(patch.planes), _ptr(patch.mask), _ptr(mx),
             _ptr(my), self.stream()), "pano_warp_spherical")
         return mx, my
 
-    def warp_all(self, frames, plan, n_blur=0, want_maps=False):
+    def warp_all(self, frames, plan, n_blur=0, want_maps=False, luts=None):
         patches, maps = [], []
         for i, frame in enumerate(frames):
             patch = DevicePatch(plan.rects[i], self.device, n_blur)
-            maps.append(self.warp(frame, plan, i, patch, want_maps))
+            maps.append(self.warp(frame, plan, i, patch, want_maps,
+                                  None if luts is None else luts[i]))
             patches.append(patch)
         return patches, maps
 
@@ -578,7 +644,7 @@ class Engine:
         return total
 
     def blur_and_compose(self, table, owner, valid, shape, n_levels, want_float=False,
-                         strip=None, interior=None, cams=None, plan=None):
+                         strip=None, interior=None, cams=None, plan=None, luts=None):
         """All Gaussian levels of all patches (n_levels launches), then the gather
         over the mosaic columns ``strip`` (default: all of them).  With an
         ``interior`` map, blur tiles and gathers are skipped where the result is
@@ -602,8 +668,8 @@ class Engine:
         _lib.check(self.lib.pano_multiband_compose(
             table.ptr, table.n, H, W, c0, c1, n_levels, _ptr(owner), _ptr(valid),
             _ptr(interior), _ptr(cams) if interior is not None else None, _ptr(tabs[0]),
-            _ptr(tabs[1]), _ptr(tabs[2]), _ptr(self.lut255) if interior is not None else None,
-            _ptr(mosaic), _ptr(fl), self.stream()), "pano_multiband_compose")
+            _ptr(tabs[1]), _ptr(tabs[2]), *self._lut_args(luts), _ptr(mosaic), _ptr(fl),
+            self.stream()), "pano_multiband_compose")
         return mosaic, fl
 
     def simple_blend(self, patches, shape, linear, table=None):
@@ -616,6 +682,57 @@ class Engine:
         _lib.check(fn(table.ptr, table.n, H, W, _ptr(mosaic), self.stream()),
                    "pano_linear_blend" if linear else "pano_no_blend")
         return mosaic
+
+    def _lut_args(self, luts):
+        """(lut, lut_stride) of include/pano360.h: one shared table, or one per camera."""
+        if luts is None:
+            return _ptr(self.lut255), 0
+        return _ptr(luts), 256
+
+    # -- exposure ---------------------------------------------------------------
+    def equalize_gains(self, frames, rots, intrs, chunk_bytes=256 << 20):
+        """equalize_gains up to the gains (stitcher.py:36-65): overlap sizes and
+        mean intensities of every camera pair on device, the N x N solve on the
+        host.  ``frames``: uint8 [H,W,3] tensors on this device, one size.
+        Returns (overlaps, sizes, gains, luts): the reference's two N x N arrays,
+        the gains, and the per-camera colour tables (device float32 [N][256])
+        that stand for the equalised images of stitcher.py:66."""
+        torch = _torch()
+        n = len(frames)
+        h, w = (int(v) for v in frames[0].shape[:2])
+        if any(tuple(f.shape[:2]) != (h, w) for f in frames):
+            raise ValueError("equalize_gains: every overlap is sized by regions[0] "
+                             "(stitcher.py:41); frames of different sizes cannot be indexed")
+        pairs = overlap_pairs(rots, intrs, w, h)
+        overlaps, sizes = np.zeros((n, n)), np.zeros((n, n))
+        if len(pairs):
+            hx, hy = self.hat_tables((h, w))
+            rec = np.zeros(n, dtype=CAMERA_DTYPE)
+            for k, frame in enumerate(frames):
+                rec[k] = (np.zeros(9), frame.data_ptr(), hx.data_ptr(), hy.data_ptr(), h, w,
+                          0, 0, 0, 0)
+            cams = _to_device(rec, self.device)
+            nblk = int(self.lib.pano_overlap_blocks(h, w))
+            bw0 = min(1024 // min(16, h), w)
+            step = max(1, chunk_bytes // (nblk * 24))
+            stats = torch.empty((len(pairs), 3), dtype=torch.float64, device=self.device)
+            partials = torch.empty((min(step, len(pairs)), nblk, 3), dtype=torch.float64,
+                                   device=self.device)
+            for a in range(0, len(pairs), step):
+                part = pairs[a:a + step]
+                dev_pairs = torch.from_numpy(part.view(np.uint8).reshape(-1)).to(self.device)
+                _lib.check(self.lib.pano_overlap_stats(
+                    _ptr(cams), _ptr(dev_pairs), len(part), h, w, bw0, _ptr(self.lut255),
+                    _ptr(partials), _ptr(stats[a:]), self.stream()), "pano_overlap_stats")
+            host = stats.cpu().numpy()
+            for (_, i, j), (count, sum_i, sum_j) in zip(pairs, host):
+                sizes[i, j] = sizes[j, i] = count                       # stitcher.py:59
+                if count:                                               # :62-63 (float32 means)
+                    overlaps[i, j] = np.float32(sum_i / (3.0 * count))
+                    overlaps[j, i] = np.float32(sum_j / (3.0 * count))
+        gains = find_gains(overlaps, sizes)
+        luts = torch.from_numpy(gain_tables(gains)).to(self.device)
+        return overlaps, sizes, gains, luts
 
     # -- fused path: ownership from the cameras, work only near owned pixels ----
     def camera_table(self, plan, frames=None):
@@ -671,7 +788,7 @@ class Engine:
         return self.owned_regions(owner, n, strip)[0]
 
     def multiband_fused(self, frames, plan, n_levels, want_float=False, frame_ids=None,
-                        strip=None, shortcut=True):
+                        strip=None, shortcut=True, luts=None):
         """The headline path, for the mosaic columns ``strip`` = (c0, c1) (default:
         the whole mosaic).  ``frames[j]`` is the frame of camera ``frame_ids[j]``
         (default: all cameras in order); every camera whose patch reaches within
@@ -713,14 +830,14 @@ class Engine:
         table = patches.table
         _lib.check(self.lib.pano_warp_windows(
             _ptr(cams), table.ptr, table.n, table.max_vw, table.max_vh, _ptr(plan.dev[0]),
-            _ptr(plan.dev[1]), _ptr(plan.dev[2]), _ptr(self.lut255), self.stream()),
+            _ptr(plan.dev[1]), _ptr(plan.dev[2]), *self._lut_args(luts), self.stream()),
             "pano_warp_windows")
         interior = self.interior_map(owner, radius, ext) if shortcut and n_blur else None
         mosaic, fl = self.blur_and_compose(table, owner, valid, plan.shape, n_levels,
-                                           want_float, (c0, c1), interior, cams, plan)
+                                           want_float, (c0, c1), interior, cams, plan, luts)
         return mosaic, fl, valid, patches
 
-    def blend_fused(self, frames, plan, linear, frame_ids=None, strip=None):
+    def blend_fused(self, frames, plan, linear, frame_ids=None, strip=None, luts=None):
         """linear_blend / no_blend of the mosaic columns ``strip`` straight from
         the frames (no patch buffers).  Returns (mosaic u8, valid u8)."""
         torch = _torch()
@@ -738,8 +855,8 @@ class Engine:
         valid = torch.empty((H, W), dtype=torch.uint8, device=self.device)
         _lib.check(self.lib.pano_blend_cameras(
             _ptr(cams), plan.n, H, W, c0, c1, 1 if linear else 0, _ptr(plan.dev[0]),
-            _ptr(plan.dev[1]), _ptr(plan.dev[2]), _ptr(self.lut255), _ptr(mosaic), _ptr(valid),
-            self.stream()), "pano_blend_cameras")
+            _ptr(plan.dev[1]), _ptr(plan.dev[2]), *self._lut_args(luts), _ptr(mosaic),
+            _ptr(valid), self.stream()), "pano_blend_cameras")
         return mosaic, valid
 
     # -- crop and filters -------------------------------------------------------------
@@ -782,19 +899,20 @@ class Engine:
 
     # -- whole stitch -----------------------------------------------------------
     def stitch(self, frames, plan, blend="multiband", n_levels=5, want_float=False,
-               fused=True, shortcut=True):
+               fused=True, shortcut=True, luts=None):
         """uint8 frames on device -> (mosaic u8 on device, float mosaic, valid,
         patches).  ``fused=False`` runs multiband through whole-patch stage
         buffers (what the blender protocol sees); both give the same mosaic."""
         if not hasattr(plan, "dev"):
             self.upload_plan(plan)
         if blend == "multiband" and fused:
-            return self.multiband_fused(frames, plan, n_levels, want_float, shortcut=shortcut)
+            return self.multiband_fused(frames, plan, n_levels, want_float, shortcut=shortcut,
+                                        luts=luts)
         if fused:
-            mosaic, valid = self.blend_fused(frames, plan, blend == "linear")
+            mosaic, valid = self.blend_fused(frames, plan, blend == "linear", luts=luts)
             return mosaic, None, valid, []
         n_blur = n_levels - 1 if blend == "multiband" else 0
-        patches, _ = self.warp_all(frames, plan, n_blur)
+        patches, _ = self.warp_all(frames, plan, n_blur, luts=luts)
         table = patch_table(patches, self.device)
         if blend == "multiband":
             mosaic, fl, _, valid = self.multiband(patches, plan.shape, n_levels, want_float,

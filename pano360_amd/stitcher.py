@@ -5,13 +5,14 @@ reference: ``stitch``, ``no_blend`` / ``linear_blend`` /
 ``multiband_blend`` (the ``blender(patches, shape)`` protocol), ``SphProj``,
 ``CylProj``, ``_proj_img_range_border``, ``_proj_img_range_corners``,
 ``estimate_resolution``, ``_hat``, ``_add_weights``, ``_valid``,
-``crop_mosaic``, ``BLENDERS``, ``MAX_RESOLUTION`` and the CLI ``main``.
+``crop_mosaic``, ``find_gains``, ``equalize_gains``, ``BLENDERS``,
+``MAX_RESOLUTION`` and the CLI ``main``.
 Per-pixel work goes to hand-written HIP kernels through ``_lib`` (ctypes over
 ``libpano360_hip.so``); there is no CPU fallback for it.
 
 Out of scope here: feature matching and bundle adjustment - the
 CLI therefore needs the ``ba_<name>.pkl`` camera cache the reference CLI writes
-(stitcher.py:430-439) - and ``equalize_gains`` (§8f, "next").
+(stitcher.py:430-439).
 """
 import argparse
 import logging
@@ -25,6 +26,46 @@ from . import engine as _eng
 from .engine import CylProj, SphProj  # noqa: F401  (re-exported API)
 
 MAX_RESOLUTION = 1400       # read at call time, like the reference (stitcher.py:17,154)
+
+
+# ------------------------------------------------------------------ exposure
+def find_gains(overlaps, sizes, stdn=0.1, stdg=2):
+    """Find the gains minimizing discrepancies between mean intensities
+    (stitcher.py:24-33)."""
+    return _eng.find_gains(overlaps, sizes, stdn, stdg)
+
+
+def _frames_of(regions):
+    """uint8 frames behind ``reg.img``: either still uint8 (before
+    ``_add_weights``) or the float32 RGBA image ``_add_weights`` made of one, whose
+    colours are float32(u8)/255 and convert back exactly."""
+    base = np.arange(256, dtype=np.float32) / np.float32(255)
+    frames = []
+    for reg in regions:
+        img = reg.img
+        if img.dtype != np.uint8:
+            back = np.clip(np.rint(img[..., :3] * np.float32(255)), 0, 255).astype(np.uint8)
+            if not np.array_equal(base[back], img[..., :3]):
+                raise ValueError("equalize_gains works on frames that came from uint8 images "
+                                 "(reg.img as _add_weights leaves it, stitcher.py:257-263)")
+            img = back
+        frames.append(np.ascontiguousarray(img[..., :3]))
+    return frames
+
+
+def equalize_gains(regions):
+    """Equalize the exposures by minimizing differences on overlaps
+    (stitcher.py:36-66).  Like the reference it rescales ``reg.img[..., :3]`` of
+    float32 RGBA regions in place; the pair statistics run on the GPU
+    (``pano_overlap_stats``).  Returns the gains (the reference returns None)."""
+    eng = _eng.engine()
+    frames = eng.upload_frames(_frames_of(regions))
+    _, _, gains, _ = eng.equalize_gains(frames, [r.rot for r in regions],
+                                        [r.intr for r in regions])
+    for reg, gain in zip(regions, gains):
+        if reg.img.dtype != np.uint8:
+            reg.img[..., :3] = np.clip(gain * reg.img[..., :3], 0, 1)      # stitcher.py:66
+    return gains
 
 
 # ------------------------------------------------------------ host geometry
@@ -156,26 +197,28 @@ def stitch(regions, blender=no_blend, equalize=False, crop=False):
     one of this module's three is called with host patches, exactly as the
     reference would call it.
     """
-    if equalize:
-        raise NotImplementedError(
-            "equalize_gains (stitcher.py:36-66) is outside the accelerated path")
     eng = _eng.engine()
     frames_host = [reg.img for reg in regions]
     padded = blender == multiband_blend                     # stitcher.py:295
     plan = _eng.Plan([im.shape[:2] for im in frames_host], [r.rot for r in regions],
                      [r.intr for r in regions], padded, MAX_RESOLUTION)
     frames = eng.upload_frames(frames_host)
-    for reg, rng, frame in zip(regions, plan.ranges, frames):
+    luts = None
+    if equalize:                                            # stitcher.py:280-281
+        logging.debug("Equalizing gain...")
+        luts = eng.equalize_gains(frames, [r.rot for r in regions],
+                                  [r.intr for r in regions])[3]
+    for i, (reg, rng, frame) in enumerate(zip(regions, plan.ranges, frames)):
         reg.range = rng
-        reg.img = eng.add_weights(frame).cpu().numpy()
+        reg.img = eng.add_weights(frame, None if luts is None else luts[i]).cpu().numpy()
     eng.upload_plan(plan)
 
     kind = _FUSED.get(blender)
     if kind is not None:
         n_levels = multiband_blend.__defaults__[0]
-        mosaic, _, valid, patches = eng.stitch(frames, plan, kind, n_levels)
+        mosaic, _, valid, patches = eng.stitch(frames, plan, kind, n_levels, luts=luts)
     else:
-        patches, _ = eng.warp_all(frames, plan)
+        patches, _ = eng.warp_all(frames, plan, luts=luts)
         valid = None
         mosaic = blender(_download_patches(patches), plan.shape)
     if hasattr(mosaic, "cpu"):

@@ -155,6 +155,70 @@ def test_stitch_entry_point_against_reference_mosaics(eng, name):
         stitcher.MAX_RESOLUTION = saved
 
 
+def test_equalize_gains_against_reference(eng, oracle):
+    """stitch(..., equalize=True) (stitcher.py:36-66, 280-281): overlap sizes bit
+    exact, means / gains to the accuracy of the reference's float32 np.mean,
+    mosaics within one level of the reference's."""
+    import bundle_adj
+    from pano360_amd import stitcher
+    g = load_golden("scene_equalize")
+    imgs, rots, intrs, _ = scene_inputs(g)
+    frames = eng.upload_frames(imgs)
+    overlaps, sizes, gains, luts = eng.equalize_gains(frames, rots, intrs)
+    assert np.array_equal(sizes, g["sizes"])
+    np.testing.assert_allclose(overlaps, g["overlaps"], rtol=2e-6, atol=0)
+    np.testing.assert_allclose(gains, g["gains"], rtol=2e-5, atol=0)
+    assert np.abs(luts.cpu().numpy()[0][imgs[0]] - g["eq_rgb_0"]).max() <= 2e-5
+    # deterministic: fixed-order double sums
+    again = eng.equalize_gains(frames, rots, intrs)
+    assert np.array_equal(again[0], overlaps) and np.array_equal(again[2], gains)
+
+    def regions():
+        return [bundle_adj.Image(im.copy(), r.copy(), k.copy())
+                for im, r, k in zip(imgs, rots, intrs)]
+    for blender, key in ((stitcher.linear_blend, "lin"), (stitcher.multiband_blend, "mb5")):
+        regs = regions()
+        got = stitcher.stitch(regs, blender, equalize=True)
+        assert got.shape == g[f"{key}_mosaic"].shape
+        assert np.abs(got.astype(int) - g[f"{key}_mosaic"].astype(int)).max() <= 1, key
+        # reg.img is the equalised float32 RGBA image (stitcher.py:66)
+        assert np.abs(regs[0].img[..., :3] - g["eq_rgb_0"]).max() <= 2e-5
+    # the blender protocol (host patches) sees equalised patches too
+    via_stage = stitcher.stitch(regions(), lambda p, s: stitcher.linear_blend(p, s), equalize=True)
+    assert np.abs(via_stage.astype(int) - g["lin_mosaic"].astype(int)).max() <= 1
+    # equalize_gains(regions) on float32 RGBA regions, as the reference is called
+    regs = regions()
+    for reg in regs:
+        reg.img = stitcher._add_weights(reg.img)
+    found = stitcher.equalize_gains(regs)
+    np.testing.assert_allclose(found, g["gains"], rtol=2e-5, atol=0)
+    assert np.abs(regs[-1].img[..., :3] - g["eq_rgb_last"]).max() <= 2e-5
+
+
+@pytest.mark.parametrize("case", ["sweep", "tilted", "perspective"])
+def test_overlap_stats_match_oracle(eng, oracle, case):
+    """pano_overlap_stats against the C oracle on larger frames: counts bit exact
+    (tile culling and the fixed-point taps included), means to float32 accuracy."""
+    from pano360_amd import synth
+    n, w, h = 6, 333, 187
+    imgs, rots, intrs = synth.make_scene(n, w, h, sweep_deg=150.0, jitter=0.02, seed=3, kind="B")
+    if case == "tilted":
+        rots = [synth.rotation_to_mat(np.array([0.3 * (-1) ** i, 0.25 * i - 0.6, 0.2 * i]))
+                for i in range(n)]
+    elif case == "perspective":
+        intrs = [k * np.array([[1 + 0.15 * i, 1, 1], [1, 1 + 0.15 * i, 1], [1, 1, 1]])
+                 for i, k in enumerate(intrs)]
+    frames = eng.upload_frames(imgs)
+    overlaps, sizes, gains, _ = eng.equalize_gains(frames, rots, intrs, chunk_bytes=1 << 16)
+    rgbas = [oracle.add_weights(im) for im in imgs]
+    want_o, want_s, want_g = oracle.equalize_gains(rgbas, rots, intrs)
+    assert np.array_equal(sizes, want_s) and sizes.max() > 0
+    if case == "sweep":
+        assert (sizes == 0).sum() > n          # pairs without overlap are in the batch too
+    np.testing.assert_allclose(overlaps, want_o, rtol=2e-6, atol=0)
+    np.testing.assert_allclose(gains, want_g, rtol=2e-5, atol=0)
+
+
 @pytest.mark.parametrize("name", SCENES)
 def test_multiband_float_mosaic_and_valid(eng, oracle, name):
     from pano360_amd import engine

@@ -31,11 +31,13 @@ def test_library_exports_every_declared_symbol():
         src = os.path.join(tmp, "sz.c")
         with open(src, "w") as fid:
             fid.write('#include <stdio.h>\n#include "pano360.h"\nint main(void){'
-                      'printf("%zu %zu", sizeof(pano_patch), sizeof(pano_camera));return 0;}')
+                      'printf("%zu %zu %zu", sizeof(pano_patch), sizeof(pano_camera), '
+                      'sizeof(pano_pair));return 0;}')
         exe = os.path.join(tmp, "sz")
         subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), src, "-o", exe])
         sizes = [int(v) for v in subprocess.check_output([exe]).split()]
-    assert sizes == [ctypes.sizeof(_lib.Patch), ctypes.sizeof(_lib.Camera)] == [96, 120]
+    assert sizes == [ctypes.sizeof(_lib.Patch), ctypes.sizeof(_lib.Camera),
+                     ctypes.sizeof(_lib.Pair)] == [96, 120, 80]
 
 
 def test_header_constants_match_binding():
@@ -175,3 +177,53 @@ def test_windows_for():
     # tiny patch: everything reflects several times -> whole patch
     area, win = windows_for((0, 5, 0, 7), (0, 6, 0, 8), 43)
     assert area == (0, 6, 0, 8) and win == (0, 6, 0, 8)
+
+
+def same64(a, b):
+    a, b = np.ascontiguousarray(a, np.float64), np.ascontiguousarray(b, np.float64)
+    return a.shape == b.shape and np.array_equal(a.view(np.uint64), b.view(np.uint64))
+
+
+def test_find_gains_reference_vectors():
+    """Host side of equalize_gains: find_gains equals the reference bit for bit on
+    the construction of pano_tests.py:79-96 and recovers consistent gains."""
+    from pano360_amd import stitcher
+    g = load_golden("gains")
+    found = stitcher.find_gains(g["fg_overlaps"], g["fg_sizes"])
+    assert same64(found, g["fg_gains"])
+    assert same64(stitcher.find_gains(g["fg_overlaps"], g["fg_sizes"], stdn=0.5, stdg=1.0),
+                  g["fg_gains_wide"])
+    ratio = found / g["fg_true"]
+    np.testing.assert_almost_equal(ratio, np.full(len(ratio), ratio[0]))
+    # the reference's own test, re-drawn
+    rng = np.random.default_rng(7)
+    gains = 1 + 0.1 * rng.standard_normal(10)
+    overlaps = 100 + 10 * rng.standard_normal((10, 10))
+    for i in range(10):
+        for j in range(i + 1, 10):
+            overlaps[i, j] = overlaps[j, i] * gains[j] / gains[i]
+    ratio = stitcher.find_gains(overlaps, rng.standard_normal((10, 10)) + 10) / gains
+    np.testing.assert_almost_equal(ratio, np.full(10, ratio[0]))
+
+
+def test_gain_tables_and_pairs_match_reference(oracle):
+    """The per-camera colour tables stand for the reference's equalised images
+    exactly, and the pair table holds the reference's homographies."""
+    from pano360_amd import engine
+    g = load_golden("scene_equalize")
+    imgs, rots, intrs, _ = scene_inputs(g)
+    luts = engine.gain_tables(g["gains"])
+    assert np.array_equal(luts[0][imgs[0]].view(np.uint32), g["eq_rgb_0"].view(np.uint32))
+    assert np.array_equal(luts[-1][imgs[-1]].view(np.uint32), g["eq_rgb_last"].view(np.uint32))
+    h, w = imgs[0].shape[:2]
+    pairs = engine.overlap_pairs(rots, intrs, w, h)
+    # every pair the reference found an overlap for is in the table
+    listed = {(int(p["i"]), int(p["j"])) for p in pairs}
+    assert {(i, j) for i, j in zip(*np.nonzero(g["sizes"])) if i < j} <= listed
+    for p in pairs:
+        hom, behind = oracle.pair_homography(rots[p["i"]], intrs[p["i"]], rots[p["j"]],
+                                             intrs[p["j"]], w, h)
+        assert not behind and same64(p["minv"].reshape(3, 3), oracle.invert3x3(hom))
+    # a camera looking backwards drops out (stitcher.py:51-52)
+    back = engine.overlap_pairs([np.eye(3), np.diag([-1.0, 1.0, -1.0])], [intrs[0], intrs[0]], w, h)
+    assert len(back) == 0
