@@ -194,9 +194,18 @@ int pano_owned_regions(const int16_t *owner, int H, int W, int xs0, int xs1,
  * zeros keep the row pass's 16-byte LDS reads aligned for every level).
  * ntaps: host int[n_blur].  Writes patches[i].blurred (and .scratch).
  * interior (optional, with tile_flags): the map of pano_interior_map; tiles
- * that hold only interior pixels, and the scratch rows only they would read,
- * are skipped.  tile_flags: dev uint8, one entry per 64 x 128 column tile of
- * every record (patches[i].tiles_off), written here. */
+ * that hold only interior pixels (and the intermediate rows only they would
+ * read) are skipped.  tile_flags: dev uint8, one entry per tile of every record,
+ * record i's entries starting at patches[i].tiles_off, written here.  The tile
+ * grid is the library's choice, reported by pano_blur_tile_grid():
+ *   32: 32 x 32 tiles anchored at multiples of 32 in patch coordinates, i.e.
+ *       ((ax0+aw-1)>>5) - (ax0>>5) + 1 per row, ((ay0+ah-1)>>5) - (ay0>>5) + 1
+ *       rows (the matrix-core kernel, default);
+ *    0: 64-column x 128-row tiles relative to A, ceil(aw/64) per row,
+ *       ceil(ah/128) rows (the vector-ALU kernels, PANO_BLUR=valu).
+ * The matrix-core kernel computes in split float16 (hi + lo, three products)
+ * with float32 accumulation and does not use patches[i].scratch. */
+int pano_blur_tile_grid(void);
 int pano_multiband_blur(const pano_patch *patches, int n, int max_aw,
                         int max_vh, int max_ah, const int16_t *owner, int W,
                         const float *taps, const int *ntaps, int n_blur,

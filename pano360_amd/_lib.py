@@ -72,6 +72,7 @@ _SIGNATURES = {
                                     _vp, _vp, _i, _vp, _vp, _vp]),
     "pano_blend_cameras": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp,
                                 _vp]),
+    "pano_blur_tile_grid": (_i, []),
     "pano_overlap_blocks": (_i, [_i, _i]),
     "pano_overlap_stats": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "pano_linear_blend": (_i, [_vp, _i, _i, _i, _vp, _vp]),

@@ -42,7 +42,8 @@ static const char *const g_kernel_names[PK_COUNT] = {
     "no_blend_kernel",    "crop_heights_kernel", "crop_rows_kernel", "pyr_down_kernel",
     "ownership_cameras_kernel", "owned_boxes_kernel", "warp_windows_kernel",
     "blend_cameras_kernel", "owned_spans_kernel",
-    "block_owner_kernel", "tile_flags_kernel", "overlap_stats_kernel"};
+    "block_owner_kernel", "tile_flags_kernel", "overlap_stats_kernel",
+    "blur_mfma_kernel"};
 
 void pano_timing_edge(int kid, hipStream_t stream, bool begin) {
     hipEvent_t ev;

@@ -408,6 +408,19 @@ extern "C" int pano_blur_plane(const float *src, float *dst, float *tmp, int h,
                        nullptr, (hipStream_t)stream, "pano_blur_plane");
 }
 
+// PANO_BLUR=mfma selects the matrix-core kernel of blur_mfma.hip for the multiband
+// levels, PANO_BLUR=valu (default) the vector-ALU kernels above.
+bool pano_blur_uses_mfma() {
+    static int mode = -1;
+    if (mode < 0) {
+        const char *env = getenv("PANO_BLUR");
+        mode = env && env[0] == 'm';          // opt-in (PANO_BLUR=mfma) until it is the faster one
+    }
+    return mode == 1;
+}
+
+extern "C" int pano_blur_tile_grid(void) { return pano_blur_uses_mfma() ? 32 : 0; }
+
 extern "C" int pano_multiband_blur(const pano_patch *patches, int n, int max_aw,
                                    int max_vh, int max_ah, const int16_t *owner, int W,
                                    const float *taps, const int *ntaps, int n_blur,
@@ -418,6 +431,12 @@ extern "C" int pano_multiband_blur(const pano_patch *patches, int n, int max_aw,
     PANO_REQUIRE(max_aw >= 0 && max_vh >= 0 && max_ah >= 0, "pano_multiband_blur: bad extents");
     PANO_REQUIRE(!interior || tile_flags, "pano_multiband_blur: interior map without tile_flags");
     if (n == 0 || n_blur == 0 || max_aw == 0 || max_vh == 0 || max_ah == 0) return PANO_OK;
+    for (int k = 0; k < n_blur; ++k)
+        if (int rc = check_taps(ntaps[k], "pano_multiband_blur")) return rc;
+    PANO_REQUIRE(n_blur < PANO_MAX_LEVELS, "pano_multiband_blur: %d blur levels", n_blur);
+    if (pano_blur_uses_mfma())
+        return pano_launch_blur_mfma(patches, n, max_aw, max_ah, owner, W, taps, ntaps, n_blur,
+                                     interior, tile_flags, (hipStream_t)stream);
     pano_patch none = {};
     return launch_blur(patches, none, n, 4, 3, max_aw, max_vh, max_ah, owner, W, taps, ntaps,
                        n_blur, interior, tile_flags, (hipStream_t)stream, "pano_multiband_blur");

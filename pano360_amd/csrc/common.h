@@ -56,6 +56,7 @@ enum PanoKernelId {
     PK_INTERIOR,
     PK_TILE_FLAGS,
     PK_OVERLAP,
+    PK_BLUR_MFMA,
     PK_COUNT
 };
 extern bool g_pano_timing_on;
@@ -70,6 +71,13 @@ void pano_timing_edge(int kid, hipStream_t stream, bool begin);
     } while (0)
 
 static inline int pano_pitch_of(int w) { return (w + 3) & ~3; }
+
+// blur_mfma.hip: all multiband levels of all records on the matrix cores
+int pano_launch_blur_mfma(const pano_patch *table, int n, int max_aw, int max_ah,
+                          const int16_t *owner, int W, const float *taps, const int *ntaps,
+                          int n_blur, const uint8_t *interior, uint8_t *tile_flags,
+                          hipStream_t stream);
+bool pano_blur_uses_mfma();
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
 // ---- device helpers --------------------------------------------------------

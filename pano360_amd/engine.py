@@ -403,8 +403,14 @@ class PatchTable:
     def __init__(self, records, device):
         self.host = np.array(records, dtype=PATCH_DTYPE).reshape(-1)
         self.n = len(self.host)
-        tiles = ((self.host["aw"].astype(np.int64) + 63) // 64) * \
-            ((self.host["ah"].astype(np.int64) + 127) // 128)        # 64 x 128 column tiles
+        aw, ah = self.host["aw"].astype(np.int64), self.host["ah"].astype(np.int64)
+        if _lib.lib().pano_blur_tile_grid() == 32:
+            # 32 x 32 tiles anchored at multiples of 32 in patch coordinates
+            ax0, ay0 = self.host["ax0"].astype(np.int64), self.host["ay0"].astype(np.int64)
+            tiles = (((ax0 + aw - 1) >> 5) - (ax0 >> 5) + 1) * (((ay0 + ah - 1) >> 5) - (ay0 >> 5) + 1)
+            tiles = np.where((aw > 0) & (ah > 0), tiles, 0)
+        else:
+            tiles = ((aw + 63) // 64) * ((ah + 127) // 128)          # 64 x 128 column tiles
         self.host["tiles_off"] = np.concatenate([[0], np.cumsum(tiles)[:-1]]) if self.n else 0
         self.n_tiles = int(tiles.sum())
         self.dev = _to_device(self.host, device)
@@ -632,6 +638,8 @@ class Engine:
         if flags is None:
             return int((host["ah"].astype(np.int64) * host["aw"]).sum())
         on = flags.cpu().numpy()
+        if self.lib.pano_blur_tile_grid() == 32:
+            return int(on[:table.n_tiles].astype(np.int64).sum()) * 1024      # upper bound: whole tiles
         total = 0
         for rec in host:
             ntx, nty = (int(rec["aw"]) + 63) // 64, (int(rec["ah"]) + 127) // 128

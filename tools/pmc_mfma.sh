@@ -1,0 +1,21 @@
+#!/bin/bash
+# PMC passes focused on the matrix-core blur kernel.  tools/pmc_mfma.sh <tag>
+set -u
+cd "${GRAFT_REPO_ROOT:-/root/repo}"
+HERE=$PWD
+OUT=$HERE/gpurun_out/${1:-pmcm}
+mkdir -p "$OUT"
+export TMPDIR=/tmp
+cd /tmp
+run() {
+  name=$1; shift
+  timeout 600 rocprofv3 --pmc "$@" --output-format csv -d "$OUT/$name" -- \
+      python3 "$HERE/bench.py" --steps 2 --warmup 1 --no-cpu-baseline > "$OUT/$name.log" 2>&1
+  echo "pass $name rc=$?"
+}
+run sq1 SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY
+run sq2 SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_INSTS_SMEM SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR
+run sq3 SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_SCA SQ_INSTS_BRANCH SQ_IFETCH SQ_ACTIVE_INST_MISC GRBM_GUI_ACTIVE
+cd "$HERE"
+python3 tools/pmc_summary.py "$OUT" | grep -A 30 "blur_mfma" | tee "$OUT/summary.txt"
+find "$OUT" -name "*.csv" -size +8M -delete
