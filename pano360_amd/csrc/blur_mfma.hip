@@ -33,6 +33,9 @@
 // Activity: with an interior map only the 32 x 32 tiles that hold a pixel the
 // collapse will gather are produced (flags, one byte per tile).
 #include <stdlib.h>
+#include <string.h>
+
+#include <type_traits>
 
 #include "common.h"
 
@@ -48,19 +51,53 @@ typedef GLOBAL_AS float *gf32;
 typedef const GLOBAL_AS int16_t *gci16;
 typedef const GLOBAL_AS float4u *gcf32x4;
 
-#define MB_XT 128                   // output columns per workgroup
-#define MB_PITCH 264                // halfs per band row (128 + 2*64 + 8): 528 B, conflict-free b128
-#define MB_CMAX 4                   // ceil(64 / 16): radius up to 64
+#define MB_XT 64                    // output columns per workgroup: two 32-column tiles
+#define MB_PITCH 200                // halfs per band row (64 + 2*64 + 8): 400 B, conflict-free b128
+#define MB_GROUP 4                  // levels per workgroup: one pair of waves each
+#define MB_THREADS (128 * MB_GROUP)
 #define MB_IN_SCALE 2048.0f         // inputs in [0, 1] -> hi/lo normal in f16
 #define MB_TAP_SCALE 256.0f         // taps <= 0.1
 #define MB_MID_SCALE (1.0f / 256.0f)            // Mid back to input scale before its split
 #define MB_OUT_SCALE (1.0f / (2048.0f * 256.0f))
+#define MB_NEED_PAD 8               // slack entries either side of a strip's need flags
+#define MB_NEED_MAX 1024            // 32-row tiles of the tallest patch (rows < 32768)
+#define MB_NEED_LEN (MB_NEED_MAX + 2 * MB_NEED_PAD)
+#define MB_WLEN (PANO_MAX_TAPS + 3)
 
 struct MbLevels {
     const float *w[PANO_MAX_LEVELS];    // first tap of each level
     int ntaps[PANO_MAX_LEVELS];
+    int tab_off[PANO_MAX_LEVELS];       // byte offset of each level's Toeplitz tables
     int n;
 };
+
+__host__ __device__ static inline int mb_c_of(int ntaps) {       // K-steps either side = ceil(r / 16)
+    const int c = ((ntaps >> 1) + 15) >> 4;
+    return c < 1 ? 1 : c;
+}
+// which of a group's levels the wave pair q works on: waves w and w + 4 share a SIMD, so
+// pairs q and q + 2 do: heavy levels (large radius) sit next to light ones
+__host__ __device__ static inline int mb_level_of_pair(int nl, int q) {
+    const int order[4][4] = {{0, -1, -1, -1}, {1, 0, -1, -1}, {2, 1, 0, -1}, {3, 2, 0, 1}};
+    return order[nl - 1][q];
+}
+// dynamic LDS: band (hi, lo), need flags of the two tile columns, any flags, column map,
+// then each pair's two Toeplitz tables
+#define MB_FIXED_BYTES (2 * 32 * MB_PITCH * 2 + 2 * MB_NEED_LEN + MB_NEED_LEN + 4 * MB_NEED_LEN + \
+                        (MB_PITCH + 8) * 2)
+__host__ __device__ static inline int mb_table_bytes(int ntaps) {
+    const int c = mb_c_of(ntaps), ks = 2 + 2 * c, nb = 2 * ((c + 1) / 2) + 1;
+    return ks * 2 * 1024 + nb * 4 * 1024;
+}
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for every
+// outstanding global load and store of the wave (release fence), which would put the
+// latency of the prefetched bands and of the output stores into every step.
+__device__ __forceinline__ void lds_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
 
 __device__ __forceinline__ void split16(float v, _Float16 &hi, _Float16 &lo) {
     hi = (_Float16)v;
@@ -84,15 +121,14 @@ __device__ __forceinline__ MbGeom mb_geom(const pano_patch &p) {
     return g;
 }
 
-#define MB_NEED_PAD 8               // slack entries either side of a strip's need flags
-#define MB_NEED_MAX 1024            // 32-row tiles of the tallest patch (rows < 32768)
-
-// Column pass of one step.  U = t mod NB fixes which accumulator belongs to which output
-// tile, so the roles are compile-time constants.
-template <int C, int U>
+// Column pass of one step.  Accumulator k belongs to the output tile o with o mod NB == k;
+// at step t (u = t mod NB) that is tile t - d with d = (u - k) folded into [-DMAX, DMAX].
+// The accumulators are addressed statically; what varies with u - the Toeplitz block and
+// the need flag - is an LDS address.
+template <int C>
 __device__ __forceinline__ void mb_colpass(f32x16 (&acc)[2 * ((C + 1) / 2) + 1], const f32x16 &mid,
-                                           const half8 *s_ty, const uint8_t *need_t,
-                                           const int lane) {
+                                           const half8 *s_ty, const unsigned inf,
+                                           const int lane, const int u) {
     constexpr int DMAX = (C + 1) / 2, NB = 2 * DMAX + 1;
     // Mid as the B operand: registers 8s..8s+7 are k-step s
     half8 m_hi[2], m_lo[2];
@@ -106,17 +142,18 @@ __device__ __forceinline__ void mb_colpass(f32x16 (&acc)[2 * ((C + 1) / 2) + 1],
             m_lo[s][j] = b;
         }
 #pragma unroll
-    for (int di = 0; di < NB; ++di) {
-        if (!need_t[-(di - DMAX)]) continue;                        // tile t - d, wave-uniform
-        constexpr int NB2 = 2 * NB;
-        const int slot = (U - (di - DMAX) + NB2) % NB;
+    for (int k = 0; k < NB; ++k) {
+        int d = u - k;
+        d = d > DMAX ? d - NB : (d < -DMAX ? d + NB : d);
+        if (!((inf >> (d + 2)) & 1u)) continue;                     // tile t - d, wave-uniform
+        const half8 *ty = s_ty + (d + DMAX) * 4 * 64 + lane;        // [d][s][hi, lo][lane]
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-            const half8 t_hi = s_ty[((di * 2 + s) * 2) * 64 + lane];
-            const half8 t_lo = s_ty[((di * 2 + s) * 2 + 1) * 64 + lane];
-            acc[slot] = __builtin_amdgcn_mfma_f32_32x32x16_f16(t_hi, m_hi[s], acc[slot], 0, 0, 0);
-            acc[slot] = __builtin_amdgcn_mfma_f32_32x32x16_f16(t_lo, m_hi[s], acc[slot], 0, 0, 0);
-            acc[slot] = __builtin_amdgcn_mfma_f32_32x32x16_f16(t_hi, m_lo[s], acc[slot], 0, 0, 0);
+            const half8 t_hi = ty[(s * 2) * 64];
+            const half8 t_lo = ty[(s * 2 + 1) * 64];
+            acc[k] = __builtin_amdgcn_mfma_f32_32x32x16_f16(t_hi, m_hi[s], acc[k], 0, 0, 0);
+            acc[k] = __builtin_amdgcn_mfma_f32_32x32x16_f16(t_lo, m_hi[s], acc[k], 0, 0, 0);
+            acc[k] = __builtin_amdgcn_mfma_f32_32x32x16_f16(t_hi, m_lo[s], acc[k], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);           // keep the operand reads next to their use
         }
     }
@@ -124,106 +161,61 @@ __device__ __forceinline__ void mb_colpass(f32x16 (&acc)[2 * ((C + 1) / 2) + 1],
 
 // After step t, output tile t - DMAX has all its contributions: store it, clear the
 // accumulator for the tile that takes its place.
-template <int C, int U>
+template <int C>
 __device__ __forceinline__ void mb_store(f32x16 (&acc)[2 * ((C + 1) / 2) + 1],
-                                         const uint8_t *need_t, const int t, const int lane,
-                                         const pano_patch &p, const gf32 dst, const int px0) {
+                                         const bool wanted, const int t, const int lane,
+                                         const pano_patch &p, const gf32 dst, const int px0,
+                                         const int u) {
     constexpr int DMAX = (C + 1) / 2, NB = 2 * DMAX + 1;
-    constexpr int slot = (U + DMAX + 1) % NB;
+    const int slot = (u + DMAX + 1) % NB;
     const int n = lane & 31, h = lane >> 5;
-    if (need_t[-DMAX]) {
-        const int o = t - DMAX, ax = px0 + n - p.ax0;
+    const int o = t - DMAX, ax = px0 + n - p.ax0;
 #pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const int ay = 32 * o + (q & 3) + 8 * (q >> 2) + 4 * h - p.ay0;
-            if ((unsigned)ay < (unsigned)p.ah && (unsigned)ax < (unsigned)p.aw)
-                dst[(size_t)ay * p.apitch + ax] = acc[slot][q] * MB_OUT_SCALE;
+    for (int k = 0; k < NB; ++k) {
+        if (k != slot) continue;                                    // wave-uniform
+        if (wanted) {
+            const int ay0 = 32 * o + 4 * h - p.ay0;                 // row of register 0
+            const unsigned base = (unsigned)(ay0 * p.apitch + ax);  // uniform dst + 32-bit offset
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int dy = (q & 3) + 8 * (q >> 2);
+                if ((unsigned)(ay0 + dy) < (unsigned)p.ah && (unsigned)ax < (unsigned)p.aw)
+                    dst[base + (unsigned)(dy * p.apitch)] = acc[k][q] * MB_OUT_SCALE;
+                __builtin_amdgcn_sched_barrier(0);       // one address / value pair live at a time
+            }
         }
-    }
 #pragma unroll
-    for (int q = 0; q < 16; ++q) acc[slot][q] = 0.0f;
+        for (int q = 0; q < 16; ++q) acc[k][q] = 0.0f;
+    }
 }
+
+// What every wave of the workgroup shares.
+struct MbShared {
+    _Float16 *hi, *lo;              // band, [32][MB_PITCH]
+    uint8_t *need;                  // [2][MB_NEED_LEN]: output tile o of tile column 0 / 1 is wanted
+    uint8_t *any;                   // [MB_NEED_LEN]: band t is wanted by some wave
+    // [2][MB_NEED_LEN], one word per band t and tile column: bit d + 2 = tile t - d is wanted
+    // (d = -2 .. 2), bit 8 = band t is wanted by some wave, bit 9 = band t + 1 is
+    uint16_t *info;
+    short *col;                     // band column -> column of V, or -1
+    int CM;                         // largest C of the group: the band reaches 16 CM columns out
+    int t_lo, t_hi;                 // bands any wave may want
+    int dbg;
+};
 
 template <int C>
 __device__ __forceinline__ void mb_body(const pano_patch &p, const int ch, const int level,
-                                        const float *__restrict__ w_global, const int ntaps,
-                                        const int16_t *__restrict__ owner_, const int W,
-                                        const uint8_t *__restrict__ flags, _Float16 *s_hi,
-                                        _Float16 *s_lo, half8 *s_tx, half8 *s_ty,
-                                        uint8_t *s_need, uint8_t *s_any, short *s_col,
-                                        float *s_w, const int dbg) {
-    constexpr int KS = 2 + 2 * C, DMAX = (C + 1) / 2, NB = 2 * DMAX + 1, BW = MB_XT + 32 * C;
-    constexpr int GPR = BW / 8, NGRP = 32 * GPR, NPF = (NGRP + 255) / 256;   // groups of 8 columns
+                                        const bool live, const half8 *s_tx,
+                                        const half8 *s_ty, const MbShared &sh,
+                                        const int16_t *__restrict__ owner_, const int W) {
+    constexpr int KS = 2 + 2 * C, DMAX = (C + 1) / 2, NB = 2 * DMAX + 1;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, n = lane & 31, h = lane >> 5;
-    const int r = ntaps >> 1;
+    const int tile = wv & 1;
     const bool alpha = ch == 3;
     const MbGeom g = mb_geom(p);
     const int X0 = g.gx0 + MB_XT * (int)blockIdx.x;     // first output column of the workgroup
-    const int px0 = X0 + 32 * wv;                       // ... of this wave
-    const int nty = g.O1 - g.O0 + 1;
-
-    // need flags of this wave's tile column, zero-padded so that o - O0 in [-PAD, nty + PAD)
-    // needs no range check; any[] = OR over the waves (is band t staged at all)
-    {
-        const int txg = (px0 - g.gx0) >> 5;
-        uint8_t *mine = s_need + wv * (MB_NEED_MAX + 2 * MB_NEED_PAD);
-        for (int i = lane; i < nty + 2 * MB_NEED_PAD; i += 64) {
-            const int o = i - MB_NEED_PAD;
-            bool v = txg < g.ntx && o >= 0 && o < nty;
-            if (v && flags) v = flags[p.tiles_off + o * g.ntx + txg] != 0;
-            mine[i] = v ? 1 : 0;
-        }
-    }
-    for (int i = tid; i <= ntaps; i += 256) s_w[i] = i < ntaps ? w_global[i] : 0.0f;
-    const float *w = s_w;
-    __syncthreads();
-    for (int bc = tid; bc < 256 + 8; bc += 256) {        // band column -> column of V, or -1
-        const int vc = reflect_101(X0 - 16 * C + bc, p.w) - p.vx0;
-        s_col[bc] = bc < BW && (unsigned)vc < (unsigned)p.vw ? (short)vc : (short)-1;
-    }
-    // Toeplitz operand of the row pass, shared: B[k][n] = tap[16 (s - C) + k - n + r]
-    for (int idx = tid; idx < KS * 64; idx += 256) {
-        const int s = idx >> 6, l = idx & 63, nn = l & 31, hh = l >> 5;
-        half8 hi, lo;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            _Float16 a, b;
-            split16(tap_at(w, ntaps, 16 * (s - C) + 8 * hh + j - nn + r), a, b);
-            hi[j] = a;
-            lo[j] = b;
-        }
-        s_tx[(s * 2) * 64 + l] = hi;
-        s_tx[(s * 2 + 1) * 64 + l] = lo;
-    }
-    // Toeplitz operand of the column pass, shared: A[m][k] = tap[32 d + k - m + r] with k in
-    // the order the row pass's accumulator registers hold Mid's rows
-    for (int idx = tid; idx < NB * 2 * 64; idx += 256) {
-        const int ds = idx >> 6, l = idx & 63, mm = l & 31, hh = l >> 5;
-        const int di = ds >> 1, s = ds & 1;
-        half8 hi, lo;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int kk = 16 * s + 8 * (j >> 2) + 4 * hh + (j & 3);
-            _Float16 a, b;
-            split16(tap_at(w, ntaps, 32 * (di - DMAX) + kk - mm + r), a, b);
-            hi[j] = a;
-            lo[j] = b;
-        }
-        s_ty[(ds * 2) * 64 + l] = hi;
-        s_ty[(ds * 2 + 1) * 64 + l] = lo;
-    }
-    __syncthreads();
-    const int t_first = g.O0 - DMAX, t_last = g.O1 + DMAX;
-    // any[i]: some wave wants Mid tile t = t_first + i, i.e. needs an output tile within DMAX
-    for (int i = tid; i <= t_last - t_first + 1; i += 256) {
-        bool v = false;
-        for (int wq = 0; wq < 4; ++wq)
-            for (int d = -DMAX; d <= DMAX; ++d)
-                v |= s_need[wq * (MB_NEED_MAX + 2 * MB_NEED_PAD) + (t_first + i - d - g.O0) +
-                            MB_NEED_PAD] != 0;
-        s_any[i] = v ? 1 : 0;
-    }
-    __syncthreads();
+    const int px0 = X0 + 32 * tile;                     // ... of this wave
+    const int BW = MB_XT + 32 * sh.CM, GPR = BW >> 3, NGRP = 32 * GPR;
 
     f32x16 acc[NB];
 #pragma unroll
@@ -234,130 +226,136 @@ __device__ __forceinline__ void mb_body(const pano_patch &p, const int ch, const
     const gcf32 src = alpha ? nullptr : (gcf32)(p.planes + (size_t)ch * p.vh * p.vpitch);
     const gf32 dst = (gf32)(p.blurred + (size_t)(level * 4 + ch) * p.ah * p.apitch);
     const gci16 owner = (gci16)owner_;
-    const int bx0 = X0 - 16 * C;                        // patch column of band column 0
-    const uint8_t *need_w = s_need + wv * (MB_NEED_MAX + 2 * MB_NEED_PAD) + MB_NEED_PAD - g.O0;
+    // need flags of this wave's tile column; a wave without a level wants nothing
+    const uint16_t *info_w = sh.info + (live ? tile * MB_NEED_LEN : 0) + MB_NEED_PAD - g.O0;
+    const unsigned keep = live ? 0xffffu : 0xff00u;      // a wave without a level wants no tile
+    auto info_at = [&](const int t) -> unsigned {
+        return (unsigned)__builtin_amdgcn_readfirstlane(info_w[t]) & keep;
+    };
+    const int my_lo = g.O0 - DMAX, my_hi = g.O1 + DMAX;             // bands this wave can use
 
-    // band t (rows 32 t .. 32 t + 31) into registers, 8 consecutive columns per group.
-    // s_col[bc] = column of window V behind band column bc, or -1 (beyond V: only zero
-    // taps reach it); the same for every step, so the reflection is worked out once.
-    float pf[NPF][8];
+    // Band t (rows 32 t .. 32 t + 31) into registers, 8 consecutive columns per group; two
+    // bands in flight.  Every load is unconditional (clamped address, value selected
+    // afterwards): a load under a divergent branch is waited for on the spot.
+    // The registers keep what the loads return, untouched, plus a validity mask: anything
+    // computed from a loaded value here would be a wait right behind the load.
+    float pf[2][2][8];
+    unsigned pm[2][2];                                   // bit j: element j is a real sample
     const bool vec_ok = p.vw >= 8;                       // uniform
-    auto fetch = [&](const int t) {
-        // every load is unconditional (clamped address, value selected afterwards): a
-        // load under a divergent branch is waited for on the spot, one round trip each
+    auto fetch = [&](auto slot_c, const int t) {
+        constexpr int S = decltype(slot_c)::value;
 #pragma unroll
-        for (int it = 0; it < NPF; ++it) {
-            const int grp = tid + 256 * it;
+        for (int it = 0; it < 2; ++it) {
+            const int grp = tid + MB_THREADS * it;
             const int rr = grp / GPR, bc0 = (grp - rr * GPR) * 8;
             const int ry = reflect_101(32 * t + rr, p.h);
             const int vr = ry - p.vy0;
             const bool row_ok = grp < NGRP && (unsigned)vr < (unsigned)p.vh;
-            const short8 cm = *(const short8 *)(s_col + (grp < NGRP ? bc0 : 0));
+            const short8 cm = *(const short8 *)(sh.col + (grp < NGRP ? bc0 : 0));
+            unsigned each = 0;                           // per-element validity
+#pragma unroll
+            for (int j = 0; j < 8; ++j) each |= (row_ok && cm[j] >= 0 ? 1u : 0u) << j;
+            // uniform base + 32-bit per-lane offset: one address register per load
             if (src) {
-                const gcf32 q = src + (size_t)(row_ok ? vr : 0) * p.vpitch;
+                const unsigned rowoff = (unsigned)(row_ok ? vr : 0) * (unsigned)p.vpitch;
                 const bool contig = cm[0] >= 0 && cm[7] - cm[0] == 7;
                 if (vec_ok) {
-                    const gcf32 qb = q + (contig ? cm[0] : 0);
-                    const float4u lo4 = *(gcf32x4)qb;
-                    const float4u hi4 = *(gcf32x4)(qb + 4);
+                    const unsigned o = rowoff + (unsigned)(contig ? cm[0] : 0);
+                    const float4u lo4 = *(gcf32x4)(src + o);
+                    const float4u hi4 = *(gcf32x4)(src + o + 4);
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        pf[it][j] = row_ok && contig ? lo4[j] : 0.0f;
-                        pf[it][4 + j] = row_ok && contig ? hi4[j] : 0.0f;
+                        pf[S][it][j] = lo4[j];
+                        pf[S][it][4 + j] = hi4[j];
                     }
-                } else {
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) pf[it][j] = 0.0f;
                 }
-                const bool ragged = row_ok && !(contig && vec_ok) &&
-                                    (cm[0] | cm[1] | cm[2] | cm[3] | cm[4] | cm[5] | cm[6] | cm[7]) >= 0
-                                    ? true
-                                    : (row_ok && !(contig && vec_ok) &&
-                                       (cm[0] >= 0 || cm[1] >= 0 || cm[2] >= 0 || cm[3] >= 0 ||
-                                        cm[4] >= 0 || cm[5] >= 0 || cm[6] >= 0 || cm[7] >= 0));
+                pm[S][it] = row_ok && contig && vec_ok ? 0xffu : 0u;
+                const bool ragged = each != 0 && !(contig && vec_ok);
                 if (__any(ragged)) {                     // a patch / window edge inside the group: rare
-                    float e[8];
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) e[j] = q[cm[j] >= 0 ? cm[j] : 0];
-#pragma unroll
-                    for (int j = 0; j < 8; ++j)
-                        if (ragged) pf[it][j] = cm[j] >= 0 ? e[j] : 0.0f;
+                    for (int j = 0; j < 8; ++j) {
+                        const float e = src[rowoff + (unsigned)(cm[j] >= 0 ? cm[j] : 0)];
+                        if (ragged) pf[S][it][j] = e;
+                    }
+                    if (ragged) pm[S][it] = each;
                 }
             } else {
-                const gci16 q = owner + (size_t)(p.y0 + (row_ok ? ry : 0)) * W + p.x0 + p.vx0;
-                int16_t e[8];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) e[j] = q[cm[j] >= 0 ? cm[j] : 0];
+                const unsigned rowoff = (unsigned)(p.y0 + (row_ok ? ry : 0)) * (unsigned)W +
+                                        (unsigned)(p.x0 + p.vx0);
 #pragma unroll
                 for (int j = 0; j < 8; ++j)
-                    pf[it][j] = row_ok && cm[j] >= 0 && e[j] == p.index ? 1.0f : 0.0f;
+                    pf[S][it][j] = __int_as_float(
+                        (int)owner[rowoff + (unsigned)(cm[j] >= 0 ? cm[j] : 0)]);
+                pm[S][it] = each;
             }
         }
     };
-    auto commit = [&]() {                                // registers -> hi / lo float16 in LDS
+    auto commit = [&](auto slot_c) {                     // registers -> hi / lo float16 in LDS
+        constexpr int S = decltype(slot_c)::value;
 #pragma unroll
-        for (int it = 0; it < NPF; ++it) {
-            const int grp = tid + 256 * it;
+        for (int it = 0; it < 2; ++it) {
+            const int grp = tid + MB_THREADS * it;
             if (grp >= NGRP) break;
             const int rr = grp / GPR, bc0 = (grp - rr * GPR) * 8;
             half8 hi, lo;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
+                float v = pf[S][it][j];
+                if (alpha) v = __float_as_int(v) == p.index ? 1.0f : 0.0f;   // stitcher.py:208
+                v = (pm[S][it] >> j) & 1u ? v : 0.0f;    // beyond V: only zero taps reach it
                 _Float16 a, b;
-                split16(pf[it][j] * MB_IN_SCALE, a, b);
+                split16(v * MB_IN_SCALE, a, b);
                 hi[j] = a;
                 lo[j] = b;
             }
-            *(half8 *)(s_hi + rr * MB_PITCH + bc0) = hi;
-            *(half8 *)(s_lo + rr * MB_PITCH + bc0) = lo;
+            *(half8 *)(sh.hi + rr * MB_PITCH + bc0) = hi;
+            *(half8 *)(sh.lo + rr * MB_PITCH + bc0) = lo;
         }
     };
-
-    int rem = t_first % NB;
-    if (rem < 0) rem += NB;
-    int u = rem;                                         // t mod NB
-    int t = t_first;
-    while (t <= t_last && !s_any[t - t_first]) {         // leading steps nobody wants
+    auto next_wanted = [&](int t) {                      // first band after t that any wave wants
         ++t;
-        u = u + 1 == NB ? 0 : u + 1;
-    }
-    if (t <= t_last) fetch(t);
-    // steps [done_t, done_end) have had their column pass; the tiles they completed are
+        while (t <= sh.t_hi && !sh.any[t - sh.t_lo]) ++t;
+        return t;
+    };
+
+    // Steps [done_t, done_end) have had their column pass; the tiles they completed are
     // stored at the start of the NEXT step's arithmetic, not before its barriers: a
-    // barrier waits for every outstanding store, which put the full write latency of
-    // the output into each step
-    int done_t = t, done_end = t, done_u = u;
+    // barrier waits for every outstanding store.
+    int done_t = my_lo, done_end = my_lo;
     auto flush = [&]() {
+        int uu = done_t % NB;
+        if (uu < 0) uu += NB;
         for (int tt = done_t; tt < done_end; ++tt) {
-            switch (done_u) {                            // wave-uniform
-                case 0: mb_store<C, 0>(acc, need_w + tt, tt, lane, p, dst, px0); break;
-                case 1: mb_store<C, 1>(acc, need_w + tt, tt, lane, p, dst, px0); break;
-                case 2: mb_store<C, 2>(acc, need_w + tt, tt, lane, p, dst, px0); break;
-                case 3: mb_store<C, 3 % NB>(acc, need_w + tt, tt, lane, p, dst, px0); break;
-                default: mb_store<C, 4 % NB>(acc, need_w + tt, tt, lane, p, dst, px0); break;
-            }
-            done_u = done_u + 1 == NB ? 0 : done_u + 1;
+            mb_store<C>(acc, (info_at(tt) >> (DMAX + 2)) & 1u, tt, lane, p, dst, px0, uu);
+            uu = uu + 1 == NB ? 0 : uu + 1;
         }
         done_t = done_end;
     };
-    while (t <= t_last) {
-        // pf holds band t, which somebody wants
-        __syncthreads();                                 // everybody finished reading the band
-        if (!(dbg & 4)) commit();
-        __syncthreads();
-        if (!(dbg & 1)) flush(); else done_t = done_end;
-        int tn = t + 1;                                  // next band anybody wants: its loads
-        while (tn <= t_last && !s_any[tn - t_first]) ++tn;   // fly during this step's MFMAs
-        if (tn <= t_last && !(dbg & 2)) fetch(tn);
-        bool want = false;
-#pragma unroll
-        for (int d = -DMAX; d <= DMAX; ++d) want |= need_w[t - d] != 0;
-        if (want && !(dbg & 8)) {
+
+    // the sequence of wanted bands t, t1, t2, ...: band t is committed from slot S while t1
+    // is in flight in the other slot and t2 is fetched into S
+    int t = next_wanted(sh.t_lo - 1), t1 = next_wanted(t);
+    if (t <= sh.t_hi) fetch(std::integral_constant<int, 0>{}, t);
+    if (t1 <= sh.t_hi) fetch(std::integral_constant<int, 1>{}, t1);
+    unsigned inf = t <= sh.t_hi ? info_at(t) : 0u;       // flags of band t
+    auto step = [&](auto slot_c) {
+        const unsigned inf1 = t1 <= sh.t_hi ? info_at(t1) : 0u;    // one flag word per step
+        lds_barrier();                                   // everybody finished reading the band
+        if (!(sh.dbg & 4)) commit(slot_c);
+        lds_barrier();
+#ifndef MB_NO_STORE
+        if (live && !(sh.dbg & 1)) flush();
+#endif
+        const int t2 = (inf1 >> 9) & 1u ? t1 + 1 : next_wanted(t1);
+#ifndef MB_NO_FETCH
+        if (t2 <= sh.t_hi && !(sh.dbg & 2)) fetch(slot_c, t2);
+#endif
+        if (t >= my_lo && t <= my_hi && (inf & (DMAX == 1 ? 0x0eu : 0x1fu)) && !(sh.dbg & 8)) {
             f32x16 mid;
 #pragma unroll
             for (int q = 0; q < 16; ++q) mid[q] = 0.0f;
-            const _Float16 *arow = s_hi + n * MB_PITCH + 32 * wv + 8 * h;
-            const _Float16 *brow = s_lo + n * MB_PITCH + 32 * wv + 8 * h;
+            const int o = n * MB_PITCH + 16 * (sh.CM - C) + 32 * tile + 8 * h;
+            const _Float16 *arow = sh.hi + o, *brow = sh.lo + o;
 #pragma unroll
             for (int s = 0; s < KS; ++s) {
                 const half8 a_hi = *(const half8 *)(arow + 16 * s);
@@ -371,54 +369,171 @@ __device__ __forceinline__ void mb_body(const pano_patch &p, const int ch, const
                 }
                 if (s & 1) __builtin_amdgcn_sched_barrier(0);
             }
-            switch (u) {                                 // wave-uniform
-                case 0: mb_colpass<C, 0>(acc, mid, s_ty, need_w + t, lane); break;
-                case 1: mb_colpass<C, 1>(acc, mid, s_ty, need_w + t, lane); break;
-                case 2: mb_colpass<C, 2>(acc, mid, s_ty, need_w + t, lane); break;
-                case 3: mb_colpass<C, 3 % NB>(acc, mid, s_ty, need_w + t, lane); break;
-                default: mb_colpass<C, 4 % NB>(acc, mid, s_ty, need_w + t, lane); break;
-            }
+            int u = t % NB;
+            if (u < 0) u += NB;
+            mb_colpass<C>(acc, mid, s_ty, inf, lane, u);
         }
-        done_end = tn;                                   // the gap steps only complete tiles
-        u = (u + (tn - t)) % NB;
-        t = tn;
+        // bands up to the next wanted one only complete tiles
+        const int upto = t1 < my_hi + 1 ? t1 : my_hi + 1;
+        if (upto > done_end) done_end = upto;
+        t = t1;
+        t1 = t2;
+        inf = inf1;
+    };
+    while (t <= sh.t_hi) {
+        step(std::integral_constant<int, 0>{});
+        if (t > sh.t_hi) break;
+        step(std::integral_constant<int, 1>{});
     }
-    flush();
+    if (live) {
+        if (my_hi + 1 > done_end) done_end = my_hi + 1;
+        if (!(sh.dbg & 1)) flush();
+    }
 }
 
-__global__ __launch_bounds__(256, 2) void blur_mfma_kernel(
-    const pano_patch *__restrict__ table, MbLevels L, const int16_t *__restrict__ owner, int W,
-    const uint8_t *__restrict__ flags, int dbg) {
-    __shared__ __attribute__((aligned(16))) _Float16 s_hi[32 * MB_PITCH];
-    __shared__ __attribute__((aligned(16))) _Float16 s_lo[32 * MB_PITCH];
-    __shared__ half8 s_tx[(2 + 2 * MB_CMAX) * 2 * 64];
-    __shared__ half8 s_ty[5 * 2 * 2 * 64];
-    __shared__ uint8_t s_need[4 * (MB_NEED_MAX + 2 * MB_NEED_PAD)];
-    __shared__ uint8_t s_any[MB_NEED_MAX + 2 * MB_NEED_PAD];
-    __shared__ __attribute__((aligned(16))) short s_col[256 + 8];
-    __shared__ float s_w[PANO_MAX_TAPS + 1];
-    // heavy levels first: z = ((n_levels - 1 - level) * n_records + record) * 4 + channel
+// The two Toeplitz operands of every level, in the lane order the MFMAs read them
+// (built once per tap set; the workgroups copy their levels' tables into LDS):
+//   row pass     B[k][n] = tap[16 (s - C) + k - n + r],      s = 0 .. KS-1
+//   column pass  A[m][k] = tap[32 d + k - m + r], d = -DMAX .. DMAX, k in the order the
+//                row pass's accumulator registers hold Mid's rows
+// Layout per level: [s][hi, lo][lane] half8, then [d][s][hi, lo][lane] half8.
+__global__ __launch_bounds__(128) void mb_tables_kernel(MbLevels L, unsigned char *out) {
+    __shared__ float w[MB_WLEN];
+    const int level = blockIdx.x, ntaps = L.ntaps[level], r = ntaps >> 1;
+    const int c = mb_c_of(ntaps), KS = 2 + 2 * c, DMAX = (c + 1) / 2, NB = 2 * DMAX + 1;
+    for (int i = threadIdx.x; i <= ntaps; i += 128) w[i] = i < ntaps ? L.w[level][i] : 0.0f;
+    __syncthreads();
+    half8 *tx = (half8 *)(out + L.tab_off[level]), *ty = tx + KS * 2 * 64;
+    for (int idx = threadIdx.x; idx < KS * 64; idx += 128) {
+        const int s = idx >> 6, l = idx & 63, nn = l & 31, hh = l >> 5;
+        half8 hi, lo;
+        for (int j = 0; j < 8; ++j) {
+            _Float16 a, b;
+            split16(tap_at(w, ntaps, 16 * (s - c) + 8 * hh + j - nn + r), a, b);
+            hi[j] = a;
+            lo[j] = b;
+        }
+        tx[(s * 2) * 64 + l] = hi;
+        tx[(s * 2 + 1) * 64 + l] = lo;
+    }
+    for (int idx = threadIdx.x; idx < NB * 2 * 64; idx += 128) {
+        const int ds = idx >> 6, l = idx & 63, mm = l & 31, hh = l >> 5;
+        const int di = ds >> 1, s = ds & 1;
+        half8 hi, lo;
+        for (int j = 0; j < 8; ++j) {
+            const int kk = 16 * s + 8 * (j >> 2) + 4 * hh + (j & 3);
+            _Float16 a, b;
+            split16(tap_at(w, ntaps, 32 * (di - DMAX) + kk - mm + r), a, b);
+            hi[j] = a;
+            lo[j] = b;
+        }
+        ty[(ds * 2) * 64 + l] = hi;
+        ty[(ds * 2 + 1) * 64 + l] = lo;
+    }
+}
+
+__global__ __launch_bounds__(MB_THREADS, 1) void blur_mfma_kernel(
+    const pano_patch *__restrict__ table, MbLevels L, const unsigned char *__restrict__ tables,
+    const int16_t *__restrict__ owner, int W, const uint8_t *__restrict__ flags, int dbg) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
+    // z = ((level group * records) + record) * 4 + channel
+    const int ngroups = (L.n + MB_GROUP - 1) / MB_GROUP;
     const int ch = blockIdx.z & 3, rest = blockIdx.z >> 2;
-    const int nrec = gridDim.z / (4 * L.n);
-    const int level = L.n - 1 - rest / nrec, pid = rest % nrec;
+    const int nrec = gridDim.z / (4 * ngroups);
+    const int grp = rest / nrec, pid = rest - grp * nrec;
     const pano_patch p = table[pid];
     const MbGeom g = mb_geom(p);
-    if (p.aw <= 0 || p.ah <= 0 || (int)blockIdx.x * 4 >= g.ntx) return;       // uniform
-    const int ntaps = L.ntaps[level], c = ((ntaps >> 1) + 15) >> 4;
-#define MB_CALL(CC) \
-    mb_body<CC>(p, ch, level, L.w[level], ntaps, owner, W, flags, s_hi, s_lo, s_tx, s_ty, s_need, s_any, s_col, s_w, dbg)
-#ifdef MB_ONLY
-    MB_CALL(MB_ONLY);
-#else
-    switch (c) {
-        case 0:
-        case 1: MB_CALL(1); break;
-        case 2: MB_CALL(2); break;
-        case 3: MB_CALL(3); break;
-        default: MB_CALL(4); break;
+    if (p.aw <= 0 || p.ah <= 0 || (int)blockIdx.x * 2 >= g.ntx) return;       // uniform
+    const int l0 = MB_GROUP * grp, nl = L.n - l0 < MB_GROUP ? L.n - l0 : MB_GROUP;
+    const int q = __builtin_amdgcn_readfirstlane(wv >> 1);
+    const int lv = mb_level_of_pair(nl, q);
+    const bool live = lv >= 0;
+    const int level = l0 + (live ? lv : 0);
+    const int ntaps = L.ntaps[level], c = mb_c_of(ntaps);
+
+    MbShared sh;
+    sh.hi = (_Float16 *)smem;
+    sh.lo = sh.hi + 32 * MB_PITCH;
+    sh.need = (uint8_t *)(sh.lo + 32 * MB_PITCH);
+    sh.any = sh.need + 2 * MB_NEED_LEN;
+    sh.info = (uint16_t *)(sh.any + MB_NEED_LEN);
+    sh.col = (short *)(sh.info + 2 * MB_NEED_LEN);
+    int off = MB_FIXED_BYTES, my_tx = 0, my_ty = 0;
+    sh.CM = 1;
+    int dmax_of[MB_GROUP];
+    for (int k = 0; k < MB_GROUP; ++k) {
+        const int lk = mb_level_of_pair(nl, k);
+        dmax_of[k] = -1;
+        if (lk < 0) continue;
+        const int ck = mb_c_of(L.ntaps[l0 + lk]);
+        sh.CM = ck > sh.CM ? ck : sh.CM;
+        dmax_of[k] = (ck + 1) / 2;
+        if (k == q) {
+            my_tx = off;
+            my_ty = off + (2 + 2 * ck) * 2 * 1024;
+        }
+        off += mb_table_bytes(L.ntaps[l0 + lk]);
     }
+    sh.dbg = dbg;
+    const int dmaxm = (sh.CM + 1) / 2;
+    sh.t_lo = g.O0 - dmaxm;
+    sh.t_hi = g.O1 + dmaxm;
+
+    // this pair's Toeplitz tables (row pass, then column pass), column map, need flags
+    if (live) {
+        const uint4 *from = (const uint4 *)(tables + L.tab_off[level]);
+        uint4 *to = (uint4 *)(smem + my_tx);
+        const int n16 = mb_table_bytes(ntaps) >> 4;
+        for (int i = tid & 127; i < n16; i += 128) to[i] = from[i];
+    }
+    const int X0 = g.gx0 + MB_XT * (int)blockIdx.x, BW = MB_XT + 32 * sh.CM;
+    for (int bc = tid; bc < MB_PITCH + 8; bc += MB_THREADS) {
+        const int vc = reflect_101(X0 - 16 * sh.CM + bc, p.w) - p.vx0;
+        sh.col[bc] = bc < BW && (unsigned)vc < (unsigned)p.vw ? (short)vc : (short)-1;
+    }
+    const int nty = g.O1 - g.O0 + 1;
+    if (wv < 2) {
+        const int txg = ((X0 - g.gx0) >> 5) + wv;
+        for (int i = lane; i < nty + 2 * MB_NEED_PAD; i += 64) {
+            const int o = i - MB_NEED_PAD;
+            bool v = txg < g.ntx && o >= 0 && o < nty;
+            if (v && flags) v = flags[p.tiles_off + o * g.ntx + txg] != 0;
+            sh.need[wv * MB_NEED_LEN + i] = v ? 1 : 0;
+        }
+    }
+    __syncthreads();
+    // any[i]: band t_lo + i is within reach (its own DMAX) of a wanted tile of some pair
+    for (int i = tid; i <= sh.t_hi - sh.t_lo; i += MB_THREADS) {
+        const int o = sh.t_lo + i - g.O0 + MB_NEED_PAD;         // index of tile t into need[]
+        bool v = false;
+        for (int k = 0; k < MB_GROUP; ++k)
+            for (int d = -dmax_of[k]; d <= dmax_of[k]; ++d)
+                v |= (sh.need[o - d] | sh.need[MB_NEED_LEN + o - d]) != 0;
+        sh.any[i] = v ? 1 : 0;
+    }
+    __syncthreads();
+    for (int i = tid; i < 2 * (sh.t_hi - sh.t_lo + 1); i += MB_THREADS) {
+        const int col = i & 1, k = i >> 1, t = sh.t_lo + k;
+        const int o = t - g.O0 + MB_NEED_PAD;                   // index of tile t into need[]
+        unsigned v = 0;
+        for (int d = -2; d <= 2; ++d) v |= (sh.need[col * MB_NEED_LEN + o - d] ? 1u : 0u) << (d + 2);
+        v |= sh.any[k] ? 0x100u : 0u;
+        v |= t < sh.t_hi && sh.any[k + 1] ? 0x200u : 0u;
+        sh.info[col * MB_NEED_LEN + o] = (uint16_t)v;
+    }
+    __syncthreads();
+    const half8 *s_tx = (const half8 *)(smem + my_tx), *s_ty = (const half8 *)(smem + my_ty);
+#ifdef MB_ONLY
+    mb_body<MB_ONLY>(p, ch, level, live, s_tx, s_ty, sh, owner, W);
+    return;
 #endif
-#undef MB_CALL
+    switch (c) {                                         // wave-uniform
+        case 1: mb_body<1>(p, ch, level, live, s_tx, s_ty, sh, owner, W); break;
+        case 2: mb_body<2>(p, ch, level, live, s_tx, s_ty, sh, owner, W); break;
+        case 3: mb_body<3>(p, ch, level, live, s_tx, s_ty, sh, owner, W); break;
+        default: mb_body<4>(p, ch, level, live, s_tx, s_ty, sh, owner, W); break;
+    }
 }
 
 // One thread per 32 x 32 tile of every record: active = some 8 x 8 block under the
@@ -462,6 +577,8 @@ int pano_launch_blur_mfma(const pano_patch *table, int n, int max_aw, int max_ah
         off += (size_t)ntaps[k] + PANO_TAP_PAD;
     }
     const int ntx_max = (max_aw + 62) / 32, nty_max = (max_ah + 62) / 32;
+    PANO_REQUIRE(nty_max <= MB_NEED_MAX, "pano_multiband_blur: %d rows of tiles exceed %d", nty_max,
+                 MB_NEED_MAX);
     const uint8_t *flags = nullptr;
     if (interior) {
         dim3 grid(ceil_div(ntx_max, 32), ceil_div(nty_max, 8), n);
@@ -473,10 +590,52 @@ int pano_launch_blur_mfma(const pano_patch *table, int n, int max_aw, int max_ah
     }
     static int dbg = -1;                  // PANO_MFMA_DBG: switch parts off (timing experiments)
     if (dbg < 0) dbg = getenv("PANO_MFMA_DBG") ? atoi(getenv("PANO_MFMA_DBG")) : 0;
-    dim3 grid(ceil_div(ntx_max, 4), 1, n * 4 * n_blur);
+    // Toeplitz tables of this tap set: one small device buffer per distinct (table pointer,
+    // apertures), built on first use in stream order and kept
+    struct TableSet { const float *taps; int n; int ntaps[PANO_MAX_LEVELS]; unsigned char *dev; };
+    static TableSet sets[8];
+    static int n_sets = 0;
+    int total = 0;
+    for (int k = 0; k < n_blur; ++k) {
+        L.tab_off[k] = total;
+        total += mb_table_bytes(ntaps[k]);
+    }
+    unsigned char *tables = nullptr;
+    for (int i = 0; i < n_sets && !tables; ++i)
+        if (sets[i].taps == taps && sets[i].n == n_blur &&
+            !memcmp(sets[i].ntaps, ntaps, n_blur * sizeof(int)))
+            tables = sets[i].dev;
+    if (!tables) {
+        PANO_REQUIRE(n_sets < 8, "pano_multiband_blur: more than 8 distinct tap tables in one process");
+        PANO_HIP(hipMalloc((void **)&tables, total));
+        TableSet &ts = sets[n_sets++];
+        ts.taps = taps;
+        ts.n = n_blur;
+        memcpy(ts.ntaps, ntaps, n_blur * sizeof(int));
+        ts.dev = tables;
+        hipLaunchKernelGGL(mb_tables_kernel, dim3(n_blur), dim3(128), 0, stream, L, tables);
+        PANO_LAUNCH_CHECK("mb_tables_kernel");
+    }
+    // dynamic LDS: the largest level group's tables
+    const int ngroups = ceil_div(n_blur, MB_GROUP);
+    int lds = 0;
+    for (int gidx = 0; gidx < ngroups; ++gidx) {
+        int bytes = MB_FIXED_BYTES;
+        for (int k = MB_GROUP * gidx; k < n_blur && k < MB_GROUP * (gidx + 1); ++k)
+            bytes += mb_table_bytes(ntaps[k]);
+        lds = bytes > lds ? bytes : lds;
+    }
+    PANO_REQUIRE(lds <= 160 * 1024, "pano_multiband_blur: %d bytes of LDS tables", lds);
+    static bool lds_opt_in = false;
+    if (!lds_opt_in) {
+        PANO_HIP(hipFuncSetAttribute((const void *)blur_mfma_kernel,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        lds_opt_in = true;
+    }
+    dim3 grid(ceil_div(ntx_max, 2), 1, n * 4 * ngroups);
     PANO_TIMED(PK_BLUR_MFMA, stream,
-               hipLaunchKernelGGL(blur_mfma_kernel, grid, dim3(256), 0, stream, table, L, owner, W,
-                                  flags, dbg));
+               hipLaunchKernelGGL(blur_mfma_kernel, grid, dim3(MB_THREADS), lds, stream, table, L,
+                                  tables, owner, W, flags, dbg));
     PANO_LAUNCH_CHECK("blur_mfma_kernel");
     return PANO_OK;
 }
