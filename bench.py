@@ -111,12 +111,22 @@ def roofline_for(times, plan, patches, n_levels, steps, px_active):
         "owned_boxes_kernel": 2.0 * M,
         # warped colour + L-1 blurred RGBA per gathered pixel; owner/valid read, u8 out
         "multiband_compose_kernel": (12.0 + 16.0 * (n_levels - 1)) * px_cols + 6.0 * M,
+        # fused row + column pass of every level on the matrix cores: colour planes (12 B)
+        # and owner map (2 B) read over V, L-1 blurred RGBA copies written over the active
+        # tiles; the intermediate image never reaches memory
+        "blur_mfma_kernel": 14.0 * px_warp + 16.0 * (n_levels - 1) * px_cols,
     }.get(name, 0.0)
     achieved = per_step * steps / launches / avg_s / 1e9
     traffic, source = pmc_traffic(name)
-    return dict(kernel=name, bound="hbm", achieved=achieved, peak=HBM_PEAK_GBPS,
-                unit="GB/s", frac=achieved / HBM_PEAK_GBPS, traffic=traffic,
-                traffic_source=source, avg_launch_ms=avg_s * 1e3, launches=launches)
+    out = dict(kernel=name, bound="hbm", achieved=achieved, peak=HBM_PEAK_GBPS,
+               unit="GB/s", frac=achieved / HBM_PEAK_GBPS, traffic=traffic,
+               traffic_source=source, avg_launch_ms=avg_s * 1e3, launches=launches)
+    if name == "blur_mfma_kernel":
+        flop = steps * sum(2.0 * t * 4 * (px_rows + px_cols) for t in taps)
+        out["note"] = ("split-float16 Toeplitz products on the matrix cores (3 MFMAs per "
+                       "float32-accurate product); %.1f TFLOP/s of useful float32-equivalent "
+                       "FMA work" % (flop / launches / avg_s / 1e12))
+    return out
 
 
 def cpu_baseline(cfg):
