@@ -167,21 +167,30 @@ __device__ __forceinline__ void mb_store(f32x16 (&acc)[2 * ((C + 1) / 2) + 1],
                                          const pano_patch &p, const gf32 dst, const int px0,
                                          const int u) {
     constexpr int DMAX = (C + 1) / 2, NB = 2 * DMAX + 1;
-    const int slot = (u + DMAX + 1) % NB;
+    const int slot = __builtin_amdgcn_readfirstlane((u + DMAX + 1) % NB);
     const int n = lane & 31, h = lane >> 5;
     const int o = t - DMAX, ax = px0 + n - p.ax0;
+    const bool inside = 32 * o >= p.ay0 && 32 * o + 32 <= p.ay0 + p.ah && px0 >= p.ax0 &&
+                        px0 + 32 <= p.ax0 + p.aw;             // wave-uniform
 #pragma unroll
     for (int k = 0; k < NB; ++k) {
         if (k != slot) continue;                                    // wave-uniform
         if (wanted) {
             const int ay0 = 32 * o + 4 * h - p.ay0;                 // row of register 0
             const unsigned base = (unsigned)(ay0 * p.apitch + ax);  // uniform dst + 32-bit offset
+            if (inside) {                                // the whole tile lies in A: no masks
 #pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                const int dy = (q & 3) + 8 * (q >> 2);
-                if ((unsigned)(ay0 + dy) < (unsigned)p.ah && (unsigned)ax < (unsigned)p.aw)
-                    dst[base + (unsigned)(dy * p.apitch)] = acc[k][q] * MB_OUT_SCALE;
-                __builtin_amdgcn_sched_barrier(0);       // one address / value pair live at a time
+                for (int q = 0; q < 16; ++q)
+                    dst[base + (unsigned)(((q & 3) + 8 * (q >> 2)) * p.apitch)] =
+                        acc[k][q] * MB_OUT_SCALE;
+            } else {
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const int dy = (q & 3) + 8 * (q >> 2);
+                    if ((unsigned)(ay0 + dy) < (unsigned)p.ah && (unsigned)ax < (unsigned)p.aw)
+                        dst[base + (unsigned)(dy * p.apitch)] = acc[k][q] * MB_OUT_SCALE;
+                    __builtin_amdgcn_sched_barrier(0);   // one address / value pair live at a time
+                }
             }
         }
 #pragma unroll

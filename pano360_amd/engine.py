@@ -469,19 +469,33 @@ class FusedPatches:
             rec[i]["ay0"], rec[i]["ax0"], rec[i]["ah"], rec[i]["aw"] = ay0, ax0, ay1 - ay0, ax1 - ax0
             self.info.append(WindowInfo(win[0], win[1]))
         rec["vpitch"] = (rec["vw"] + 3) & ~3
-        rec["apitch"] = (rec["aw"] + 3) & ~3
         vh, ah = rec["vh"].astype(np.int64), rec["ah"].astype(np.int64)
         planes_sz = 3 * vh * rec["vpitch"]
-        blurred_sz = n_blur * 4 * ah * rec["apitch"]
-        scratch_sz = n_blur * 4 * vh * rec["apitch"]
+        lead = np.zeros(n, np.int64)
+        if _lib.lib().pano_blur_tile_grid() == 32:
+            # the matrix-core blur writes 32-column tile rows anchored at multiples of 32 in
+            # patch coordinates: 128-byte rows, and the anchor column on a 128-byte boundary,
+            # make each such row one cache line instead of two; no row-pass scratch
+            rec["apitch"] = (rec["aw"] + 31) & ~31
+            lead = rec["ax0"].astype(np.int64) & 31
+            blurred_sz = n_blur * 4 * ah * rec["apitch"] + 32
+            scratch_sz = np.zeros(n, np.int64)
+        else:
+            rec["apitch"] = (rec["aw"] + 3) & ~3
+            blurred_sz = n_blur * 4 * ah * rec["apitch"]
+            scratch_sz = n_blur * 4 * vh * rec["apitch"]
         self.planes = self._arena(device, "planes", int(planes_sz.sum()))
-        self.blurred = self._arena(device, "blurred", int(blurred_sz.sum()))
+        self.blurred = self._arena(device, "blurred", int(blurred_sz.sum()) + 32)
         self.scratch = self._arena(device, "scratch", int(scratch_sz.sum()))
         for key, sizes, arena in (("planes", planes_sz, self.planes),
                                   ("blurred", blurred_sz, self.blurred),
                                   ("scratch", scratch_sz, self.scratch)):
             offs = np.concatenate([[0], np.cumsum(sizes)[:-1]])
-            rec[key] = arena.data_ptr() + 4 * offs
+            base = arena.data_ptr()
+            if key == "blurred":
+                base += -base % 128                         # arenas come 512-byte aligned anyway
+                offs = offs + lead
+            rec[key] = base + 4 * offs
         self.table = PatchTable(rec, device)
 
     def __iter__(self):
