@@ -14,6 +14,8 @@
 // the float mosaic is requested) per mosaic pixel.  The camera-driven ownership
 // kernel reads no pixel data at all: 3 B written per mosaic pixel, the rest is
 // arithmetic (about 120 instructions per covering camera).
+#include <stdlib.h>
+
 #include "geom.h"
 
 // ---- ownership from warped alpha planes (stage-level API) ---------------------
@@ -92,41 +94,186 @@ __device__ __forceinline__ int build_camera_list(CamList &sh, const pano_camera 
     return overflow ? -1 : sh.count;
 }
 
+// Pruning (exact).  Before any pixel is evaluated, one thread per listed camera bounds
+// that camera's alpha over the whole 64 x 16 tile: interval arithmetic, in double, on
+// the ray components (the ranges of sin / cos over the tile's columns and of tan over
+// its rows), through K R and the perspective divide, gives a box of source coordinates
+// that holds every pixel's sample position; the box is grown by 2 px - far more than
+// the float32 rounding of the exact path, its 1/32 px fixed-point coordinates and the
+// one-sample reach of the bilinear taps - and hat_y (x) hat_x, concave and piecewise
+// linear, is bounded on it from above (its value nearest the frame centre; bilinear
+// interpolation of a concave function never exceeds it) and from below (its smaller
+// end value, when the box lies inside the frame and in front of the camera, so that
+// no pixel is masked; else 0).  A camera whose upper bound is below the largest lower
+// bound L loses every pixel of the tile to the camera that attains L, strictly, so it
+// can be skipped: neither the argmax nor - since that winner is unmasked everywhere
+// when L > 0 - the valid flag depends on it.  With L = 0 only cameras that are masked
+// on the whole tile go.  Far from seams one camera survives, near a seam two; the
+// pixels then run the exact evaluation on the survivors only, in index order.
+struct AlphaBound {
+    float lo, hi;      // hi < 0: masked on the whole tile
+};
+
+__device__ __forceinline__ void hat_range(double a, double b, int n, double &lo, double &hi) {
+    // hat(x) = 0.5 - |x - n/2| / n on [a, b]
+    const double mid = 0.5 * n, peak = fmin(fmax(mid, a), b);
+    hi = 0.5 - fabs(peak - mid) / n;
+    lo = fmin(0.5 - fabs(a - mid) / n, 0.5 - fabs(b - mid) / n);
+}
+
+__device__ __forceinline__ void iv_axpy(double k, double lo, double hi, double &alo, double &ahi) {
+    alo += k >= 0.0 ? k * lo : k * hi;
+    ahi += k >= 0.0 ? k * hi : k * lo;
+}
+
+__device__ __forceinline__ AlphaBound alpha_bound(const pano_camera *cam, const double *r) {
+    // r = {s_lo, s_hi, t_lo, t_hi, c_lo, c_hi}
+    const double *K = cam->proj;
+    double v[3][2];
+#pragma unroll
+    for (int row = 0; row < 3; ++row) {
+        double lo = 0.0, hi = 0.0;
+        iv_axpy(K[3 * row + 0], r[0], r[1], lo, hi);
+        iv_axpy(K[3 * row + 1], r[2], r[3], lo, hi);
+        iv_axpy(K[3 * row + 2], r[4], r[5], lo, hi);
+        const double slack = 1e-9 * (fabs(lo) + fabs(hi)) + 1e-300;
+        v[row][0] = lo - slack;
+        v[row][1] = hi + slack;
+    }
+    AlphaBound out;
+    if (v[2][1] <= 0.0) {                    // behind the camera everywhere: mask (stitcher.py:308)
+        out.lo = 0.0f;
+        out.hi = -1.0f;
+        return out;
+    }
+    if (v[2][0] <= 1e-6 * (fabs(v[0][0]) + fabs(v[0][1]) + fabs(v[1][0]) + fabs(v[1][1]) + 1.0)) {
+        out.lo = 0.0f;                       // the tile touches the camera's horizon: no bound
+        out.hi = 1.0f;
+        return out;
+    }
+    const int sw = cam->sw, sh = cam->sh;
+    double box[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+        const double q0 = v[a][0] / v[2][0], q1 = v[a][0] / v[2][1];
+        const double q2 = v[a][1] / v[2][0], q3 = v[a][1] / v[2][1];
+        const double half = 0.5 * (a == 0 ? sw : sh);
+        box[a][0] = fmin(fmin(q0, q1), fmin(q2, q3)) + half - 2.0;
+        box[a][1] = fmax(fmax(q0, q1), fmax(q2, q3)) + half + 2.0;
+    }
+    if (box[0][1] < 0.0 || box[0][0] > sw - 1.0 || box[1][1] < 0.0 || box[1][0] > sh - 1.0) {
+        out.lo = 0.0f;                       // outside the frame everywhere (stitcher.py:311-312)
+        out.hi = -1.0f;
+        return out;
+    }
+    const bool inside = box[0][0] >= 0.0 && box[0][1] <= sw - 1.0 && box[1][0] >= 0.0 &&
+                        box[1][1] <= sh - 1.0;
+    double xlo, xhi, ylo, yhi;
+    hat_range(fmax(box[0][0], 0.0), fmin(box[0][1], sw - 1.0), sw, xlo, xhi);
+    hat_range(fmax(box[1][0], 0.0), fmin(box[1][1], sh - 1.0), sh, ylo, yhi);
+    out.hi = (float)(fmax(xhi, 0.0) * fmax(yhi, 0.0) * (1.0 + 1e-6)) + 1e-7f;
+    out.lo = inside ? fmaxf((float)(fmax(xlo, 0.0) * fmax(ylo, 0.0) * (1.0 - 1e-6)) - 1e-7f, 0.0f)
+                    : 0.0f;
+    return out;
+}
+
+#define OWN_ROWS 16
+
 __global__ __launch_bounds__(256) void ownership_cameras_kernel(
     const pano_camera *__restrict__ cams, int n, int H, int W, int xs0, int xs1,
     const double *__restrict__ sin_t, const double *__restrict__ cos_t,
     const double *__restrict__ tan_p, int16_t *__restrict__ owner,
-    uint8_t *__restrict__ valid) {
+    uint8_t *__restrict__ valid, int prune) {
     __shared__ CamList sh;
-    const int bx0 = xs0 + blockIdx.x * 64, by0 = blockIdx.y * 4;
-    const int listed = build_camera_list(sh, cams, n, bx0, min(bx0 + 64, xs1), by0,
-                                         min(by0 + 4, H));
-    const int ncand = listed < 0 ? n : listed;
+    __shared__ double s_rng[6];
+    __shared__ float s_wmax[4];
+    __shared__ int s_keep[OWN_LIST];
+    const int tid = threadIdx.y * 64 + threadIdx.x, lane = threadIdx.x, wave = threadIdx.y;
+    const int bx0 = xs0 + blockIdx.x * 64, by0 = blockIdx.y * OWN_ROWS;
+    const int bx1 = min(bx0 + 64, xs1), by1 = min(by0 + OWN_ROWS, H);
+    const int listed = build_camera_list(sh, cams, n, bx0, bx1, by0, by1);
+    int ncand = listed < 0 ? n : listed;
+    const int *list = sh.list;
 
-    const int x = bx0 + threadIdx.x, y = by0 + threadIdx.y;
-    if (x >= xs1 || y >= H) return;
-    const double s = sin_t[x], c = cos_t[x], t = tan_p[y];
-    float best = 0.0f;
-    int who = -1;
-    bool any = false;
-    for (int k = 0; k < ncand; ++k) {
-        const int i = listed < 0 ? k : __builtin_amdgcn_readfirstlane(sh.list[k]);
-        const pano_camera *cam = cams + i;
-        const int px = x - cam->x0, py = y - cam->y0;
-        if ((unsigned)px >= (unsigned)cam->w || (unsigned)py >= (unsigned)cam->h) continue;
-        float fx, fy;
-        const int sw = cam->sw, sh_ = cam->sh;
-        if (map_pixel(cam->proj, s, c, t, sw, sh_, fx, fy)) continue;   // alpha * 0
-        any = true;
-        const Taps tp = make_taps(fx, fy, sw, sh_);
-        const float a = alpha_at(cam->hat_x, cam->hat_y, tp);
-        if (a > best) {          // strict: the first maximum keeps the pixel
-            best = a;
-            who = i;
+    if (listed > 1 && prune) {
+        // ranges of the ray components over the tile (wave 0: columns, wave 1: rows)
+        if (wave == 0) {
+            const int xc = min(bx0 + lane, bx1 - 1);
+            double lo_s = sin_t[xc], hi_s = lo_s, lo_c = cos_t[xc], hi_c = lo_c;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                lo_s = fmin(lo_s, __shfl_xor(lo_s, off, 64));
+                hi_s = fmax(hi_s, __shfl_xor(hi_s, off, 64));
+                lo_c = fmin(lo_c, __shfl_xor(lo_c, off, 64));
+                hi_c = fmax(hi_c, __shfl_xor(hi_c, off, 64));
+            }
+            if (lane == 0) {
+                s_rng[0] = lo_s; s_rng[1] = hi_s; s_rng[4] = lo_c; s_rng[5] = hi_c;
+            }
+        } else if (wave == 1) {
+            const double tv = tan_p[min(by0 + (lane & (OWN_ROWS - 1)), by1 - 1)];
+            double lo_t = tv, hi_t = tv;
+#pragma unroll
+            for (int off = OWN_ROWS / 2; off > 0; off >>= 1) {
+                lo_t = fmin(lo_t, __shfl_xor(lo_t, off, 64));
+                hi_t = fmax(hi_t, __shfl_xor(hi_t, off, 64));
+            }
+            if (lane == 0) {
+                s_rng[2] = lo_t; s_rng[3] = hi_t;
+            }
         }
+        __syncthreads();
+        AlphaBound bnd = {0.0f, -1.0f};
+        if (tid < listed) bnd = alpha_bound(cams + sh.list[tid], s_rng);
+        float wmax = bnd.lo;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) wmax = fmaxf(wmax, __shfl_xor(wmax, off, 64));
+        if (lane == 0) s_wmax[wave] = wmax;
+        __syncthreads();
+        const float L = fmaxf(fmaxf(s_wmax[0], s_wmax[1]), fmaxf(s_wmax[2], s_wmax[3]));
+        const bool keep = tid < listed && bnd.hi >= L;
+        const unsigned long long bal = __ballot(keep);
+        if (lane == 0) sh.wave[wave] = __popcll(bal);
+        __syncthreads();
+        int off = 0;
+        for (int w = 0; w < wave; ++w) off += sh.wave[w];
+        off += __popcll(bal & ((1ull << lane) - 1ull));
+        if (keep) s_keep[off] = sh.list[tid];                 // order preserved: first maximum wins
+        ncand = sh.wave[0] + sh.wave[1] + sh.wave[2] + sh.wave[3];
+        list = s_keep;
+        __syncthreads();
     }
-    owner[(size_t)y * W + x] = (int16_t)who;
-    valid[(size_t)y * W + x] = any ? 1 : 0;
+
+    const int x = bx0 + lane;
+    if (x >= xs1) return;
+    const double s = sin_t[x], c = cos_t[x];
+#pragma unroll 1
+    for (int r = 0; r < OWN_ROWS / 4; ++r) {
+        const int y = by0 + 4 * r + wave;
+        if (y >= H) break;
+        const double t = tan_p[y];
+        float best = 0.0f;
+        int who = -1;
+        bool any = false;
+        for (int k = 0; k < ncand; ++k) {
+            const int i = listed < 0 ? k : __builtin_amdgcn_readfirstlane(list[k]);
+            const pano_camera *cam = cams + i;
+            const int px = x - cam->x0, py = y - cam->y0;
+            if ((unsigned)px >= (unsigned)cam->w || (unsigned)py >= (unsigned)cam->h) continue;
+            float fx, fy;
+            const int sw = cam->sw, sh_ = cam->sh;
+            if (map_pixel(cam->proj, s, c, t, sw, sh_, fx, fy)) continue;   // alpha * 0
+            any = true;
+            const Taps tp = make_taps(fx, fy, sw, sh_);
+            const float a = alpha_at(cam->hat_x, cam->hat_y, tp);
+            if (a > best) {          // strict: the first maximum keeps the pixel
+                best = a;
+                who = i;
+            }
+        }
+        owner[(size_t)y * W + x] = (int16_t)who;
+        valid[(size_t)y * W + x] = any ? 1 : 0;
+    }
 }
 
 // ---- linear_blend / no_blend straight from the frames (fused path) --------------
@@ -483,11 +630,15 @@ extern "C" int pano_ownership_cameras(const pano_camera *cams, int n, int H, int
     PANO_REQUIRE(sin_t && cos_t && tan_p && owner && valid, "pano_ownership_cameras: null pointer");
     PANO_REQUIRE(xs0 >= 0 && xs1 <= W && xs0 <= xs1, "pano_ownership_cameras: bad strip [%d, %d)", xs0, xs1);
     if (xs0 == xs1) return PANO_OK;
-    dim3 block(64, 4), grid(ceil_div(xs1 - xs0, 64), ceil_div(H, 4));
+    // PANO_OWN_PRUNE=0 evaluates every listed camera at every pixel (A/B and the
+    // exactness tests compare the two)
+    const char *env = getenv("PANO_OWN_PRUNE");
+    const int prune = !(env && env[0] == '0');
+    dim3 block(64, 4), grid(ceil_div(xs1 - xs0, 64), ceil_div(H, OWN_ROWS));
     PANO_TIMED(PK_OWNERSHIP_CAMS, (hipStream_t)stream,
                hipLaunchKernelGGL(ownership_cameras_kernel, grid, block, 0,
                                   (hipStream_t)stream, cams, n, H, W, xs0, xs1, sin_t, cos_t,
-                                  tan_p, owner, valid));
+                                  tan_p, owner, valid, prune));
     PANO_LAUNCH_CHECK("ownership_cameras_kernel");
     return PANO_OK;
 }

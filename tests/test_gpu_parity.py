@@ -278,6 +278,33 @@ def test_ownership_from_cameras_equals_ownership_from_planes(eng, name):
             assert boxes[i][1] < boxes[i][0]
 
 
+@pytest.mark.parametrize("seed", range(6))
+def test_ownership_bounds_against_exhaustive_evaluation(eng, seed, monkeypatch):
+    """The interval bounds that prune cameras per 64 x 16 tile never change the
+    owner / valid maps: random rotations (roll and pitch included), mixed focal
+    lengths, native and capped resolutions, a camera looking away."""
+    import torch
+    from pano360_amd import bundle_adj, engine, synth
+    rng = np.random.default_rng(100 + seed)
+    n, w, h = 10, 320, 200
+    rots = np.stack([bundle_adj.rotation_to_mat(
+        [rng.normal(0, 0.2), rng.uniform(-1.1, 1.1), rng.normal(0, 0.35)]) for _ in range(n)])
+    if seed == 0:
+        rots[3] = bundle_adj.rotation_to_mat([0.0, np.pi * 0.97, 0.0])     # faces backwards
+    intrs = np.stack([bundle_adj.intrinsics(synth.focal_for(w, rng.uniform(45, 100)),
+                                            (rng.normal(0, 4), rng.normal(0, 4)))
+                      for _ in range(n)]).astype(np.float64)
+    cap = (10 ** 9, 700, 180)[seed % 3]
+    plan = eng.upload_plan(engine.Plan([(h, w)] * n, rots, intrs, seed % 2 == 0, cap))
+    monkeypatch.setenv("PANO_OWN_PRUNE", "0")
+    owner_all, valid_all = eng.ownership_cameras(plan)
+    torch.cuda.synchronize()
+    monkeypatch.setenv("PANO_OWN_PRUNE", "1")
+    owner, valid = eng.ownership_cameras(plan)
+    assert torch.equal(owner, owner_all) and torch.equal(valid, valid_all)
+    assert (owner_all >= 0).any() and (owner_all < 0).any()
+
+
 @pytest.mark.parametrize("case", ["dense", "tilted", "wide", "identical"])
 def test_ownership_pruning_is_exact(eng, case):
     """The camera-driven kernel samples alpha only where an upper bound says the
