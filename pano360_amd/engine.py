@@ -527,6 +527,7 @@ class Engine:
         self.lut255 = torch.from_numpy(lut).to(self.device)
         self._hats = {}
         self._taps = {}
+        self._region_bufs = {}
 
     # -- small cached tables ------------------------------------------------
     def stream(self):
@@ -789,11 +790,11 @@ class Engine:
             "pano_ownership_cameras")
         return owner, valid
 
-    def owned_regions(self, owner, n, strip=None, min_gap=0, max_spans=4):
-        """Where every patch owns pixels within the column strip: host arrays
-        boxes [n][4] = (ymin, ymax, xmin, xmax) and a list, per patch, of the
-        inclusive column spans (xa, xb) (runs closer than ``min_gap`` merged).
-        One small device->host copy: the only sync of a stitch."""
+    def owned_regions_async(self, owner, n, strip=None, min_gap=0, max_spans=4):
+        """Queues the region search and its device->host copy (pinned), returns a function
+        that waits for it: host arrays boxes [n][4] = (ymin, ymax, xmin, xmax) and a list,
+        per patch, of the inclusive column spans (xa, xb) (runs closer than ``min_gap``
+        merged).  That wait is the only sync of a stitch."""
         torch = _torch()
         H, W = owner.shape
         c0, c1 = strip if strip is not None else (0, W)
@@ -802,9 +803,24 @@ class Engine:
         _lib.check(self.lib.pano_owned_regions(_ptr(owner), H, W, c0, c1, n, min_gap, max_spans,
                                                _ptr(marks), _ptr(regions), self.stream()),
                    "pano_owned_regions")
-        host = regions.cpu().numpy()
-        spans = [host[i, 5:5 + 2 * host[i, 4]].reshape(-1, 2) for i in range(n)]
-        return host[:, :4], spans
+        key = (n, max_spans)
+        host_buf = self._region_bufs.get(key)
+        if host_buf is None:
+            host_buf = self._region_bufs[key] = torch.empty(
+                (n, 5 + 2 * max_spans), dtype=torch.int32).pin_memory()
+        host_buf.copy_(regions, non_blocking=True)
+        done = torch.cuda.Event()
+        done.record(torch.cuda.current_stream(self.device))
+
+        def wait():
+            done.synchronize()
+            host = host_buf.numpy().copy()
+            spans = [host[i, 5:5 + 2 * host[i, 4]].reshape(-1, 2) for i in range(n)]
+            return host[:, :4], spans
+        return wait
+
+    def owned_regions(self, owner, n, strip=None, min_gap=0, max_spans=4):
+        return self.owned_regions_async(owner, n, strip, min_gap, max_spans)()
 
     def owned_boxes(self, owner, n, strip=None):
         return self.owned_regions(owner, n, strip)[0]
@@ -835,8 +851,12 @@ class Engine:
         cams = self.camera_table(plan, have)
         owner, valid = self.ownership_cameras(plan, strip=ext, cams=cams)
         # one record per (patch, span of columns it owns): spans farther apart than
-        # 2R keep disjoint rectangles A, so a pixel still meets a patch at most once
-        boxes, spans = self.owned_regions(owner, plan.n, ext, 2 * radius + 2)
+        # 2R keep disjoint rectangles A, so a pixel still meets a patch at most once.
+        # The interior map needs the owner map only: queued first, it keeps the GPU busy
+        # while the host waits for the regions and lays out the windows.
+        regions = self.owned_regions_async(owner, plan.n, ext, 2 * radius + 2)
+        interior = self.interior_map(owner, radius, ext) if shortcut and n_blur else None
+        boxes, spans = regions()
         entries = []
         for i in range(plan.n):
             for xa, xb in spans[i]:
@@ -854,7 +874,6 @@ class Engine:
             _ptr(cams), table.ptr, table.n, table.max_vw, table.max_vh, _ptr(plan.dev[0]),
             _ptr(plan.dev[1]), _ptr(plan.dev[2]), *self._lut_args(luts), self.stream()),
             "pano_warp_windows")
-        interior = self.interior_map(owner, radius, ext) if shortcut and n_blur else None
         mosaic, fl = self.blur_and_compose(table, owner, valid, plan.shape, n_levels,
                                            want_float, (c0, c1), interior, cams, plan, luts)
         return mosaic, fl, valid, patches
