@@ -170,7 +170,10 @@ class Plan:
     def __init__(self, shapes, rots, intrs, padded, max_resolution):
         self.shapes = [tuple(int(v) for v in s) for s in shapes]
         self.n = len(self.shapes)
-        self.homs = [np.asarray(r).T.dot(np.linalg.inv(k)) for r, k in zip(rots, intrs)]
+        # one LAPACK call per matrix either way: the stacked inverse has the same bits as
+        # np.linalg.inv per camera (bundle_adj.py:28-29) at a thirtieth of the call overhead
+        kinv = np.linalg.inv(np.asarray(intrs, np.float64).reshape(-1, 3, 3))
+        self.homs = [np.asarray(r).T.dot(ki) for r, ki in zip(rots, kinv)]
         self.projs = [np.ascontiguousarray(np.asarray(k).dot(r), np.float64)
                       for r, k in zip(rots, intrs)]
         self.ranges = ranges_from_border(self.shapes, self.homs)
@@ -914,18 +917,31 @@ class Engine:
             return None
         return tuple(int(v) for v in res[1:5])
 
-    def blur_plane(self, plane, ksize, sigma):
-        """cv2.GaussianBlur on one float32 plane [h][w] already on device."""
+    def plane_taps(self, ksize, sigma):
+        """Padded tap table of one Gaussian on the device, cached per (ksize, sigma)."""
+        torch = _torch()
+        key = ("plane", int(ksize), float(sigma))
+        if key not in self._taps:
+            self._taps[key] = torch.from_numpy(padded_taps(gaussian_taps(ksize, sigma))).to(
+                self.device)
+        return self._taps[key]
+
+    def blur_plane(self, plane, ksize, sigma, out=None):
+        """cv2.GaussianBlur on one float32 plane [h][w] already on device.  Rows that
+        are a multiple of 4 floats are filtered in place of any padded copy."""
         torch = _torch()
         h, w = plane.shape
         pitch = (w + 3) & ~3
-        src = torch.zeros((h, pitch), dtype=torch.float32, device=self.device)
-        src[:, :w] = plane
-        dst, tmp = torch.empty_like(src), torch.empty_like(src)
-        taps = torch.from_numpy(padded_taps(gaussian_taps(ksize, sigma))).to(self.device)
+        if pitch == w and plane.is_contiguous():
+            src = plane
+        else:
+            src = torch.zeros((h, pitch), dtype=torch.float32, device=self.device)
+            src[:, :w] = plane
+        dst = out if out is not None and pitch == w else torch.empty_like(src)
+        tmp = torch.empty_like(src)
         _lib.check(self.lib.pano_blur_plane(_ptr(src), _ptr(dst), _ptr(tmp), h, w, pitch,
-                                            _ptr(taps), ksize, self.stream()),
-                   "pano_blur_plane")
+                                            _ptr(self.plane_taps(ksize, sigma)), ksize,
+                                            self.stream()), "pano_blur_plane")
         return dst[:, :w]
 
     def pyr_down(self, plane):
