@@ -96,6 +96,16 @@ typedef struct pano_pair {
     int32_t i, j;              /* camera indices, frame i is the destination */
 } pano_pair;
 
+/* One SIFT keypoint (reference: the cv2.KeyPoint objects of features.py:197). */
+typedef struct pano_sift_keypoint {
+    float x, y;                /* position                                   */
+    float size;                /* diameter of the meaningful neighbourhood    */
+    float angle;               /* degrees, [0, 360)                           */
+    float response;            /* |contrast| of the refined extremum          */
+    int32_t octave;            /* octave | layer << 8 | round((xi+0.5)*255) << 16 */
+    int32_t r, c;              /* refined sample in the octave's own grid     */
+} pano_sift_keypoint;
+
 /* Colour tables.  The reference turns a frame into float32(u8)/255
  * (stitcher.py:259) and, with equalize=True, into clip(gain * that, 0, 1)
  * (stitcher.py:66): either way a function of the uint8 value alone, so the
@@ -319,6 +329,36 @@ int pano_resize_up2(const float *src, int h, int w, float *dst, void *stream);
 int pano_decimate2(const float *src, int h, int w, float *dst, void *stream);
 int pano_subtract(const float *a, const float *b, size_t n, float *out,
                   void *stream);
+
+/* Keypoints and descriptors of SIFT_create().detectAndCompute  features.py:192-198
+ * (the arithmetic lives in OpenCV's xfeatures2d/sift.cpp, restated with the
+ * SIFT_create() defaults; parity unpinned).  The scale space comes from the
+ * building blocks above, one contiguous stack per octave:
+ * gauss[o] = dev float [n_layers+3][rows_o][cols_o], dog likewise with n_layers+2;
+ * dims = dev int32 {rows_0, cols_0, rows_1, cols_1, ...}.
+ *   pano_sift_extrema   findScaleSpaceExtrema + adjustLocalExtrema of one octave:
+ *                       refined extrema (angle 0, coordinates of the doubled base
+ *                       image, octave index not yet shifted) appended at
+ *                       cands[atomicAdd(count)] while below max_cands.
+ *   pano_sift_orient    calcOrientationHist: every candidate becomes one keypoint
+ *                       per dominant orientation, appended to kpts.  n_cands: dev.
+ *   pano_sift_describe  calcSIFTDescriptor of n keypoints as detectAndCompute
+ *                       returns them (full-resolution coordinates, octave field
+ *                       shifted by first_octave): desc dev float [n][128], values
+ *                       0..255.  RootSIFT (features.py:198) is left to the caller.
+ * List order is arbitrary (atomics); sort as KeyPointsFilter::removeDuplicatedSorted
+ * does before describing. */
+int pano_sift_extrema(const float *dog, int rows, int cols, int octave,
+                      int n_layers, float contrast_thr, float edge_thr,
+                      float sigma, pano_sift_keypoint *cands, int *count,
+                      int max_cands, void *stream);
+int pano_sift_orient(const float *const *gauss, const int *dims, int n_layers,
+                     const pano_sift_keypoint *cands, const int *n_cands,
+                     int max_cands, pano_sift_keypoint *kpts, int *count,
+                     int max_kpts, void *stream);
+int pano_sift_describe(const float *const *gauss, const int *dims,
+                       int first_octave, const pano_sift_keypoint *kpts, int n,
+                       float *desc, void *stream);
 
 #ifdef __cplusplus
 }

@@ -40,6 +40,12 @@ class Pair(C.Structure):
     _fields_ = [("minv", C.c_double * 9), ("i", C.c_int32), ("j", C.c_int32)]
 
 
+class SiftKeypoint(C.Structure):
+    """``pano_sift_keypoint`` of include/pano360.h (32 bytes)."""
+    _fields_ = [("x", C.c_float), ("y", C.c_float), ("size", C.c_float), ("angle", C.c_float),
+                ("response", C.c_float), ("octave", C.c_int32), ("r", C.c_int32), ("c", C.c_int32)]
+
+
 class Camera(C.Structure):
     """``pano_camera`` of include/pano360.h (120 bytes)."""
     _fields_ = [("proj", C.c_double * 9), ("frame", C.c_void_p),
@@ -84,6 +90,10 @@ _SIGNATURES = {
     "pano_resize_up2": (_i, [_vp, _i, _i, _vp, _vp]),
     "pano_decimate2": (_i, [_vp, _i, _i, _vp, _vp]),
     "pano_subtract": (_i, [_vp, _vp, C.c_size_t, _vp, _vp]),
+    "pano_sift_extrema": (_i, [_vp, _i, _i, _i, _i, C.c_float, C.c_float, C.c_float, _vp, _vp, _i,
+                               _vp]),
+    "pano_sift_orient": (_i, [_vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _vp]),
+    "pano_sift_describe": (_i, [_vp, _vp, _i, _vp, _i, _vp, _vp]),
 }
 EXPORTS = tuple(_SIGNATURES)
 

@@ -57,6 +57,9 @@ enum PanoKernelId {
     PK_TILE_FLAGS,
     PK_OVERLAP,
     PK_BLUR_MFMA,
+    PK_SIFT_EXTREMA,
+    PK_SIFT_ORIENT,
+    PK_SIFT_DESCRIBE,
     PK_COUNT
 };
 extern bool g_pano_timing_on;

@@ -1,0 +1,398 @@
+// Keypoints and descriptors of OpenCV's SIFT on the scale space of pyramid.hip
+// (features.py:192-201: cv2.xfeatures2d.SIFT_create().detectAndCompute).
+// The arithmetic is inside OpenCV, not in the reference repository: OpenCV 3.4 / 4.x
+// xfeatures2d/src/sift.cpp is restated with the SIFT_create() defaults - parity
+// unpinned, checked against oracle/sift_oracle.py (an independent NumPy restatement).
+//
+//   sift_extrema_kernel   findScaleSpaceExtrema + adjustLocalExtrema: one thread per DoG
+//                         pixel and layer; the 26-neighbour test first, the (rare) Newton
+//                         refinement, contrast and edge tests in the same thread;
+//                         survivors are appended to a candidate list.
+//   sift_orient_kernel    calcOrientationHist: one wave per candidate, the lanes walk the
+//                         (2r+1)^2 window and add into a 36-bin LDS histogram; smoothing
+//                         and peak picking emit one keypoint per dominant orientation.
+//   sift_describe_kernel  calcSIFTDescriptor: one wave per keypoint, trilinear votes into
+//                         the 6 x 6 x 10 LDS histogram, then clip / scale / saturate.
+//
+// Lists are filled with atomics, so their order varies from run to run; the host sorts
+// keypoints the way KeyPointsFilter::removeDuplicatedSorted does before describing them.
+// LDS float atomics make the order of a histogram's additions vary as well: sums agree
+// to float32 rounding, a saturated descriptor entry can differ by one level.
+#include "common.h"
+
+#define SIFT_BORDER 5
+#define SIFT_MAX_STEPS 5
+#define SIFT_ORI_BINS 36
+#define SIFT_D 4
+#define SIFT_N 8
+
+// cv::fastAtan2: degrees in [0, 360), 0.3 degree accuracy
+__device__ __forceinline__ float fast_atan2(float y, float x) {
+    const float p1 = (float)(0.9997878412794807 * 57.29577951308232);
+    const float p3 = (float)(-0.3258083974640975 * 57.29577951308232);
+    const float p5 = (float)(0.1555786518463281 * 57.29577951308232);
+    const float p7 = (float)(-0.04432655554792128 * 57.29577951308232);
+    const float ax = fabsf(x), ay = fabsf(y);
+    float a, c, c2;
+    if (ax >= ay) {
+        c = __fdiv_rn(ay, ax + 2.220446049250313e-16f);
+        c2 = c * c;
+        a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    } else {
+        c = __fdiv_rn(ax, ay + 2.220446049250313e-16f);
+        c2 = c * c;
+        a = 90.0f - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    }
+    if (x < 0.0f) a = 180.0f - a;
+    if (y < 0.0f) a = 360.0f - a;
+    return a;
+}
+
+// Matx33f::solve(b, DECOMP_LU): float Gaussian elimination with partial pivoting
+__device__ __forceinline__ bool solve3(float a[3][3], float b[3], float x[3]) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        int k = i;
+#pragma unroll
+        for (int j = i + 1; j < 3; ++j)
+            if (fabsf(a[j][i]) > fabsf(a[k][i])) k = j;
+        if (fabsf(a[k][i]) < 1.1920929e-06f) return false;          // FLT_EPSILON * 10
+        if (k != i) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const float t = a[i][j];
+                a[i][j] = a[k][j];
+                a[k][j] = t;
+            }
+            const float t = b[i];
+            b[i] = b[k];
+            b[k] = t;
+        }
+        const float d = __fdiv_rn(-1.0f, a[i][i]);
+#pragma unroll
+        for (int j = i + 1; j < 3; ++j) {
+            const float alpha = a[j][i] * d;
+#pragma unroll
+            for (int c = i + 1; c < 3; ++c) a[j][c] = a[j][c] + alpha * a[i][c];
+            b[j] = b[j] + alpha * b[i];
+        }
+    }
+#pragma unroll
+    for (int i = 2; i >= 0; --i) {
+        float s = b[i];
+#pragma unroll
+        for (int k = i + 1; k < 3; ++k) s = s - a[i][k] * x[k];
+        x[i] = __fdiv_rn(s, a[i][i]);
+    }
+    return true;
+}
+
+__global__ __launch_bounds__(256) void sift_extrema_kernel(
+    const float *__restrict__ dog, int rows, int cols, int octv, int n_layers, int threshold,
+    float contrast_thr, float edge_thr, float sigma, pano_sift_keypoint *__restrict__ cands,
+    int *__restrict__ count, int max_cands) {
+    const int c0 = blockIdx.x * 64 + threadIdx.x + SIFT_BORDER;
+    const int r0 = blockIdx.y * 4 + threadIdx.y + SIFT_BORDER;
+    const int layer0 = blockIdx.z + 1;
+    if (c0 >= cols - SIFT_BORDER || r0 >= rows - SIFT_BORDER) return;
+    const size_t plane = (size_t)rows * cols;
+#define DOG(l, r, c) dog[(size_t)(l) * plane + (size_t)(r) * cols + (c)]
+    const float val = DOG(layer0, r0, c0);
+    if (!(fabsf(val) > (float)threshold)) return;
+    bool is_max = val > 0.0f, is_min = val < 0.0f;
+    for (int dl = -1; dl <= 1; ++dl)
+        for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+            for (int dx = -1; dx <= 1; ++dx) {
+                const float v = DOG(layer0 + dl, r0 + dy, c0 + dx);
+                is_max &= val >= v;
+                is_min &= val <= v;
+            }
+    if (!(is_max || is_min)) return;
+
+    // adjustLocalExtrema
+    const float img_scale = 1.0f / 255.0f, deriv_scale = img_scale * 0.5f;
+    const float second_scale = img_scale, cross_scale = img_scale * 0.25f;
+    int r = r0, c = c0, layer = layer0;
+    float xi = 0.0f, xr = 0.0f, xc = 0.0f;
+    int step = 0;
+    for (; step < SIFT_MAX_STEPS; ++step) {
+        float dd[3] = {(DOG(layer, r, c + 1) - DOG(layer, r, c - 1)) * deriv_scale,
+                       (DOG(layer, r + 1, c) - DOG(layer, r - 1, c)) * deriv_scale,
+                       (DOG(layer + 1, r, c) - DOG(layer - 1, r, c)) * deriv_scale};
+        const float v2 = DOG(layer, r, c) * 2.0f;
+        const float dxx = (DOG(layer, r, c + 1) + DOG(layer, r, c - 1) - v2) * second_scale;
+        const float dyy = (DOG(layer, r + 1, c) + DOG(layer, r - 1, c) - v2) * second_scale;
+        const float dss = (DOG(layer + 1, r, c) + DOG(layer - 1, r, c) - v2) * second_scale;
+        const float dxy = (DOG(layer, r + 1, c + 1) - DOG(layer, r + 1, c - 1) -
+                           DOG(layer, r - 1, c + 1) + DOG(layer, r - 1, c - 1)) * cross_scale;
+        const float dxs = (DOG(layer + 1, r, c + 1) - DOG(layer + 1, r, c - 1) -
+                           DOG(layer - 1, r, c + 1) + DOG(layer - 1, r, c - 1)) * cross_scale;
+        const float dys = (DOG(layer + 1, r + 1, c) - DOG(layer + 1, r - 1, c) -
+                           DOG(layer - 1, r + 1, c) + DOG(layer - 1, r - 1, c)) * cross_scale;
+        float h[3][3] = {{dxx, dxy, dxs}, {dxy, dyy, dys}, {dxs, dys, dss}};
+        float x[3] = {0.0f, 0.0f, 0.0f};
+        if (!solve3(h, dd, x)) x[0] = x[1] = x[2] = 0.0f;
+        xi = -x[2];
+        xr = -x[1];
+        xc = -x[0];
+        if (fabsf(xi) < 0.5f && fabsf(xr) < 0.5f && fabsf(xc) < 0.5f) break;
+        const float big = (float)(2147483647 / 3);
+        if (fabsf(xi) > big || fabsf(xr) > big || fabsf(xc) > big) return;
+        c += (int)rintf(xc);
+        r += (int)rintf(xr);
+        layer += (int)rintf(xi);
+        if (layer < 1 || layer > n_layers || c < SIFT_BORDER || c >= cols - SIFT_BORDER ||
+            r < SIFT_BORDER || r >= rows - SIFT_BORDER)
+            return;
+    }
+    if (step >= SIFT_MAX_STEPS) return;
+    {
+        const float d0 = (DOG(layer, r, c + 1) - DOG(layer, r, c - 1)) * deriv_scale;
+        const float d1 = (DOG(layer, r + 1, c) - DOG(layer, r - 1, c)) * deriv_scale;
+        const float d2 = (DOG(layer + 1, r, c) - DOG(layer - 1, r, c)) * deriv_scale;
+        const float t = d0 * xc + d1 * xr + d2 * xi;
+        const float contr = DOG(layer, r, c) * img_scale + t * 0.5f;
+        if (fabsf(contr) * n_layers < contrast_thr) return;
+        const float v2 = DOG(layer, r, c) * 2.0f;
+        const float dxx = (DOG(layer, r, c + 1) + DOG(layer, r, c - 1) - v2) * second_scale;
+        const float dyy = (DOG(layer, r + 1, c) + DOG(layer, r - 1, c) - v2) * second_scale;
+        const float dxy = (DOG(layer, r + 1, c + 1) - DOG(layer, r + 1, c - 1) -
+                           DOG(layer, r - 1, c + 1) + DOG(layer, r - 1, c - 1)) * cross_scale;
+        const float tr = dxx + dyy, det = dxx * dyy - dxy * dxy;
+        if (det <= 0.0f || tr * tr * edge_thr >= (edge_thr + 1.0f) * (edge_thr + 1.0f) * det) return;
+        const int slot = atomicAdd(count, 1);
+        if (slot >= max_cands) return;
+        const float scale = (float)(1 << octv);
+        pano_sift_keypoint k;
+        k.x = ((float)c + xc) * scale;
+        k.y = ((float)r + xr) * scale;
+        k.size = sigma * powf(2.0f, __fdiv_rn((float)layer + xi, (float)n_layers)) * scale * 2.0f;
+        k.angle = 0.0f;
+        k.response = fabsf(contr);
+        k.octave = octv + (layer << 8) + ((int)rintf((xi + 0.5f) * 255.0f) << 16);
+        k.r = r;
+        k.c = c;
+        cands[slot] = k;
+    }
+#undef DOG
+}
+
+// One wave per candidate (blockDim 64).
+__global__ __launch_bounds__(64) void sift_orient_kernel(
+    const float *const *__restrict__ gauss, const int *__restrict__ dims, int n_layers,
+    const pano_sift_keypoint *__restrict__ cands, const int *__restrict__ n_cands, int max_cands,
+    pano_sift_keypoint *__restrict__ kpts, int *__restrict__ count, int max_kpts) {
+    __shared__ float temp[SIFT_ORI_BINS + 4];
+    __shared__ float hist[SIFT_ORI_BINS];
+    const int total = min(*n_cands, max_cands);
+    const int lane = threadIdx.x;
+    for (int idx = blockIdx.x; idx < total; idx += gridDim.x) {
+        const pano_sift_keypoint k = cands[idx];
+        const int octv = k.octave & 255, layer = (k.octave >> 8) & 255;
+        const int rows = dims[2 * octv], cols = dims[2 * octv + 1];
+        const float *__restrict__ img = gauss[octv] + (size_t)layer * rows * cols;
+        const float scl = __fdiv_rn(k.size * 0.5f, (float)(1 << octv));
+        const int radius = (int)rintf(4.5f * scl);
+        const float sig = 1.5f * scl, expf_scale = __fdiv_rn(-1.0f, 2.0f * sig * sig);
+        if (lane < SIFT_ORI_BINS + 4) temp[lane] = 0.0f;
+        __syncthreads();
+        const int side = 2 * radius + 1;
+        for (int t = lane; t < side * side; t += 64) {
+            const int i = t / side - radius, j = t % side - radius;
+            const int y = k.r + i, x = k.c + j;
+            if (y <= 0 || y >= rows - 1 || x <= 0 || x >= cols - 1) continue;
+            const float dx = img[(size_t)y * cols + x + 1] - img[(size_t)y * cols + x - 1];
+            const float dy = img[(size_t)(y - 1) * cols + x] - img[(size_t)(y + 1) * cols + x];
+            const float w = expf((float)(i * i + j * j) * expf_scale);
+            const float ori = fast_atan2(dy, dx), mag = sqrtf(dx * dx + dy * dy);
+            int bin = (int)rintf((SIFT_ORI_BINS / 360.0f) * ori);
+            if (bin >= SIFT_ORI_BINS) bin -= SIFT_ORI_BINS;
+            if (bin < 0) bin += SIFT_ORI_BINS;
+            atomicAdd(&temp[2 + bin], w * mag);
+        }
+        __syncthreads();
+        if (lane == 0) {
+            temp[0] = temp[SIFT_ORI_BINS];
+            temp[1] = temp[SIFT_ORI_BINS + 1];
+            temp[SIFT_ORI_BINS + 2] = temp[2];
+            temp[SIFT_ORI_BINS + 3] = temp[3];
+        }
+        __syncthreads();
+        float h = 0.0f;
+        if (lane < SIFT_ORI_BINS) {
+            const int t = lane + 2;
+            h = (temp[t - 2] + temp[t + 2]) * (1.0f / 16.0f) +
+                (temp[t - 1] + temp[t + 1]) * (4.0f / 16.0f) + temp[t] * (6.0f / 16.0f);
+            hist[lane] = h;
+        }
+        float omax = h;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) omax = fmaxf(omax, __shfl_xor(omax, off, 64));
+        __syncthreads();
+        if (lane < SIFT_ORI_BINS) {
+            const int l = lane > 0 ? lane - 1 : SIFT_ORI_BINS - 1;
+            const int r2 = lane < SIFT_ORI_BINS - 1 ? lane + 1 : 0;
+            const float hl = hist[l], hr = hist[r2];
+            if (h > hl && h > hr && h >= omax * 0.8f) {
+                float bin = (float)lane + __fdiv_rn(0.5f * (hl - hr), hl - 2.0f * h + hr);
+                bin = bin < 0.0f ? SIFT_ORI_BINS + bin : (bin >= SIFT_ORI_BINS ? bin - SIFT_ORI_BINS : bin);
+                float angle = 360.0f - (360.0f / SIFT_ORI_BINS) * bin;
+                if (fabsf(angle - 360.0f) < 1.1920929e-07f) angle = 0.0f;
+                const int slot = atomicAdd(count, 1);
+                if (slot < max_kpts) {
+                    pano_sift_keypoint out = k;
+                    out.angle = angle;
+                    kpts[slot] = out;
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// One wave per keypoint.  kpts hold full-resolution coordinates (after the halving for
+// first octave -1) and the adjusted packed octave, as SIFT::detectAndCompute returns them.
+__global__ __launch_bounds__(64) void sift_describe_kernel(
+    const float *const *__restrict__ gauss, const int *__restrict__ dims, int first_octave,
+    const pano_sift_keypoint *__restrict__ kpts, int n, float *__restrict__ desc) {
+    constexpr int d = SIFT_D, nb = SIFT_N, HL = (d + 2) * (d + 2) * (nb + 2);
+    __shared__ float hist[HL];
+    const int lane = threadIdx.x;
+    for (int idx = blockIdx.x; idx < n; idx += gridDim.x) {
+        const pano_sift_keypoint k = kpts[idx];
+        int octave = k.octave & 255;
+        const int layer = (k.octave >> 8) & 255;
+        octave = octave < 128 ? octave : (-128 | octave);
+        const float scale = octave >= 0 ? __fdiv_rn(1.0f, (float)(1 << octave)) : (float)(1 << -octave);
+        const int o = octave - first_octave;
+        const int rows = dims[2 * o], cols = dims[2 * o + 1];
+        const float *__restrict__ img = gauss[o] + (size_t)layer * rows * cols;
+        float ori = 360.0f - k.angle;
+        if (fabsf(ori - 360.0f) < 1.1920929e-07f) ori = 0.0f;
+        const float scl = k.size * scale * 0.5f;
+        const int px = (int)rintf(k.x * scale), py = (int)rintf(k.y * scale);
+        float cos_t = cosf(ori * (float)(3.141592653589793 / 180.0));
+        float sin_t = sinf(ori * (float)(3.141592653589793 / 180.0));
+        const float bins_per_rad = nb / 360.0f, exp_scale = -1.0f / (d * d * 0.5f);
+        const float hist_width = 3.0f * scl;
+        int radius = (int)rintf(hist_width * 1.4142135623730951f * (d + 1) * 0.5f);
+        radius = min(radius, (int)sqrt((double)cols * cols + (double)rows * rows));
+        cos_t = __fdiv_rn(cos_t, hist_width);
+        sin_t = __fdiv_rn(sin_t, hist_width);
+        for (int t = lane; t < HL; t += 64) hist[t] = 0.0f;
+        __syncthreads();
+        const int side = 2 * radius + 1;
+        for (int t = lane; t < side * side; t += 64) {
+            const int i = t / side - radius, j = t % side - radius;
+            const float c_rot = j * cos_t - i * sin_t, r_rot = j * sin_t + i * cos_t;
+            float rbin = r_rot + d / 2 - 0.5f, cbin = c_rot + d / 2 - 0.5f;
+            const int r = py + i, c = px + j;
+            if (!(rbin > -1.0f && rbin < d && cbin > -1.0f && cbin < d && r > 0 && r < rows - 1 &&
+                  c > 0 && c < cols - 1))
+                continue;
+            const float dx = img[(size_t)r * cols + c + 1] - img[(size_t)r * cols + c - 1];
+            const float dy = img[(size_t)(r - 1) * cols + c] - img[(size_t)(r + 1) * cols + c];
+            const float w = expf((c_rot * c_rot + r_rot * r_rot) * exp_scale);
+            float obin = (fast_atan2(dy, dx) - ori) * bins_per_rad;
+            const float mag = sqrtf(dx * dx + dy * dy) * w;
+            const int r0 = (int)floorf(rbin), c0 = (int)floorf(cbin);
+            int o0 = (int)floorf(obin);
+            rbin -= r0;
+            cbin -= c0;
+            obin -= o0;
+            if (o0 < 0) o0 += nb;
+            if (o0 >= nb) o0 -= nb;
+            const float v_r1 = mag * rbin, v_r0 = mag - v_r1;
+            const float v_rc11 = v_r1 * cbin, v_rc10 = v_r1 - v_rc11;
+            const float v_rc01 = v_r0 * cbin, v_rc00 = v_r0 - v_rc01;
+            const float v111 = v_rc11 * obin, v110 = v_rc11 - v111;
+            const float v101 = v_rc10 * obin, v100 = v_rc10 - v101;
+            const float v011 = v_rc01 * obin, v010 = v_rc01 - v011;
+            const float v001 = v_rc00 * obin, v000 = v_rc00 - v001;
+            const int at = ((r0 + 1) * (d + 2) + c0 + 1) * (nb + 2) + o0;
+            atomicAdd(&hist[at], v000);
+            atomicAdd(&hist[at + 1], v001);
+            atomicAdd(&hist[at + (nb + 2)], v010);
+            atomicAdd(&hist[at + (nb + 3)], v011);
+            atomicAdd(&hist[at + (d + 2) * (nb + 2)], v100);
+            atomicAdd(&hist[at + (d + 2) * (nb + 2) + 1], v101);
+            atomicAdd(&hist[at + (d + 3) * (nb + 2)], v110);
+            atomicAdd(&hist[at + (d + 3) * (nb + 2) + 1], v111);
+        }
+        __syncthreads();
+        // circular orientation bins, then the 4 x 4 x 8 vector (two entries per lane)
+        float v[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int q = lane + 64 * e, cell = q / nb, kk = q % nb;
+            const int i = cell / d, j = cell % d;
+            const int at = ((i + 1) * (d + 2) + (j + 1)) * (nb + 2);
+            float val = hist[at + kk];
+            if (kk < 2) val += hist[at + nb + kk];
+            v[e] = val;
+        }
+        float nrm2 = v[0] * v[0] + v[1] * v[1];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) nrm2 += __shfl_xor(nrm2, off, 64);
+        const float thr = sqrtf(nrm2) * 0.2f;
+        v[0] = fminf(v[0], thr);
+        v[1] = fminf(v[1], thr);
+        nrm2 = v[0] * v[0] + v[1] * v[1];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) nrm2 += __shfl_xor(nrm2, off, 64);
+        const float s = __fdiv_rn(512.0f, fmaxf(sqrtf(nrm2), 1.1920929e-07f));
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const float q = rintf(v[e] * s);
+            desc[(size_t)idx * (d * d * nb) + lane + 64 * e] = fminf(fmaxf(q, 0.0f), 255.0f);
+        }
+        __syncthreads();
+    }
+}
+
+extern "C" int pano_sift_extrema(const float *dog, int rows, int cols, int octave, int n_layers,
+                                 float contrast_thr, float edge_thr, float sigma,
+                                 pano_sift_keypoint *cands, int *count, int max_cands,
+                                 void *stream) {
+    PANO_REQUIRE(dog && cands && count, "pano_sift_extrema: null pointer");
+    PANO_REQUIRE(rows > 0 && cols > 0 && n_layers >= 1 && octave >= 0 && octave < 32 && max_cands > 0,
+                 "pano_sift_extrema: bad argument");
+    if (rows <= 2 * SIFT_BORDER || cols <= 2 * SIFT_BORDER) return PANO_OK;
+    const int threshold = (int)floor(0.5 * contrast_thr / n_layers * 255.0);
+    dim3 block(64, 4), grid(ceil_div(cols - 2 * SIFT_BORDER, 64), ceil_div(rows - 2 * SIFT_BORDER, 4),
+                            n_layers);
+    PANO_TIMED(PK_SIFT_EXTREMA, (hipStream_t)stream,
+               hipLaunchKernelGGL(sift_extrema_kernel, grid, block, 0, (hipStream_t)stream, dog, rows,
+                                  cols, octave, n_layers, threshold, contrast_thr, edge_thr, sigma,
+                                  cands, count, max_cands));
+    PANO_LAUNCH_CHECK("sift_extrema_kernel");
+    return PANO_OK;
+}
+
+extern "C" int pano_sift_orient(const float *const *gauss, const int *dims, int n_layers,
+                                const pano_sift_keypoint *cands, const int *n_cands, int max_cands,
+                                pano_sift_keypoint *kpts, int *count, int max_kpts, void *stream) {
+    PANO_REQUIRE(gauss && dims && cands && n_cands && kpts && count, "pano_sift_orient: null pointer");
+    PANO_REQUIRE(max_cands > 0 && max_kpts > 0 && n_layers >= 1, "pano_sift_orient: bad argument");
+    const int blocks = max_cands < 16384 ? max_cands : 16384;
+    PANO_TIMED(PK_SIFT_ORIENT, (hipStream_t)stream,
+               hipLaunchKernelGGL(sift_orient_kernel, dim3(blocks), dim3(64), 0, (hipStream_t)stream,
+                                  gauss, dims, n_layers, cands, n_cands, max_cands, kpts, count,
+                                  max_kpts));
+    PANO_LAUNCH_CHECK("sift_orient_kernel");
+    return PANO_OK;
+}
+
+extern "C" int pano_sift_describe(const float *const *gauss, const int *dims, int first_octave,
+                                  const pano_sift_keypoint *kpts, int n, float *desc, void *stream) {
+    PANO_REQUIRE(gauss && dims && (n == 0 || (kpts && desc)), "pano_sift_describe: null pointer");
+    PANO_REQUIRE(n >= 0, "pano_sift_describe: bad count");
+    if (n == 0) return PANO_OK;
+    const int blocks = n < 65535 ? n : 65535;
+    PANO_TIMED(PK_SIFT_DESCRIBE, (hipStream_t)stream,
+               hipLaunchKernelGGL(sift_describe_kernel, dim3(blocks), dim3(64), 0,
+                                  (hipStream_t)stream, gauss, dims, first_octave, kpts, n, desc));
+    PANO_LAUNCH_CHECK("sift_describe_kernel");
+    return PANO_OK;
+}

@@ -11,8 +11,10 @@ All filters run in ``libpano360_hip.so`` (``pano_blur_plane``, ``pano_pyr_down``
 ``pano_gray_u8``, ``pano_resize_up2``, ``pano_decimate2``, ``pano_subtract``).
 The SIFT arithmetic is inside OpenCV, not in the reference repo: its published
 algorithm (SIFT defaults: sigma 1.6, 3 layers per octave, first octave -1) is
-restated, parity unpinned.  Keypoint detection, description and matching stay
-outside this build's scope: ``sift_detector`` is not provided.
+restated, parity unpinned.
+* ``sift_detector()``                   - features.py:192-201: keypoints, 128-d
+  descriptors (``pano_sift_extrema`` / ``_orient`` / ``_describe``) and the RootSIFT
+  normalisation.  Matching stays outside this build's scope.
 """
 import ctypes as C
 
@@ -121,29 +123,144 @@ class _Dev:
 
 def sift_pyramid_device(frame, n_octaves=None, sigma=SIFT_SIGMA, layers=SIFT_LAYERS):
     """Gaussian and DoG pyramids of a uint8 BGR frame already on the device.
-    Returns (gauss, dog): lists over octaves of lists of float32 planes."""
-    dev = _Dev(_eng.engine())
+    Returns (gauss, dog): lists over octaves of contiguous stacks
+    [layers+3][h][w] / [layers+2][h][w] (index them like lists of planes)."""
+    import torch
+    eng = _eng.engine()
+    dev = _Dev(eng)
     h, w = frame.shape[:2]
     if n_octaves is None:
         n_octaves = sift_octaves(h, w)
     # createInitialImage: grey -> float -> 2x bilinear -> blur to sigma
     sig_diff = float(np.sqrt(max(np.float32(sigma) ** 2 - np.float32(SIFT_INIT_SIGMA) ** 2 * 4,
                                  np.float32(0.01))))
-    base = dev.blur(dev.up2(dev.gray(frame)), sig_diff)
     sig = sift_sigmas(sigma, layers)
     gauss, dog = [], []
+
+    def blur_into(dst, src, s):
+        res = eng.blur_plane(src, _eng.gaussian_ksize(s), s, out=dst)
+        if res.data_ptr() != dst.data_ptr():
+            dst.copy_(res)
+
     for o in range(n_octaves):
-        if o:
+        if o == 0:
+            first = dev.up2(dev.gray(frame))
+        else:
             prev = gauss[-1][layers]
             if min(prev.shape) < 2:
                 break
-            base = dev.half(prev)
-        octave = [base]
+            first = dev.half(prev)
+        oh, ow = first.shape
+        stack = torch.empty((layers + 3, oh, ow), dtype=torch.float32, device=eng.device)
+        if o == 0:
+            blur_into(stack[0], first, sig_diff)
+        else:
+            stack[0].copy_(first)
         for i in range(1, layers + 3):
-            octave.append(dev.blur(octave[-1], sig[i]))
-        gauss.append(octave)
-        dog.append([dev.sub(octave[i + 1], octave[i]) for i in range(layers + 2)])
+            blur_into(stack[i], stack[i - 1], sig[i])
+        diff = torch.empty((layers + 2, oh, ow), dtype=torch.float32, device=eng.device)
+        for i in range(layers + 2):
+            _lib.check(eng.lib.pano_subtract(_eng._ptr(stack[i + 1]), _eng._ptr(stack[i]),
+                                             C.c_size_t(oh * ow), _eng._ptr(diff[i]), eng.stream()),
+                       "pano_subtract")
+        gauss.append(stack)
+        dog.append(diff)
     return gauss, dog
+
+
+# ------------------------------------------------------- SIFT keypoints, descriptors
+SIFT_CONTRAST = 0.04        # cv2.xfeatures2d.SIFT_create() defaults
+SIFT_EDGE = 10.0
+SIFT_FIRST_OCTAVE = -1
+KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"),
+                     ("response", "<f4"), ("octave", "<i4"), ("r", "<i4"), ("c", "<i4")])
+assert KP_DTYPE.itemsize == C.sizeof(_lib.SiftKeypoint) == 32
+
+
+class KeyPoint:
+    """The fields of ``cv2.KeyPoint`` the reference reads (features.py:223-232: ``pt``)."""
+    __slots__ = ("pt", "size", "angle", "response", "octave", "class_id")
+
+    def __init__(self, x, y, size, angle=-1.0, response=0.0, octave=0, class_id=-1):
+        self.pt = (float(x), float(y))
+        self.size, self.angle, self.response = float(size), float(angle), float(response)
+        self.octave, self.class_id = int(octave), int(class_id)
+
+    def __repr__(self):
+        return (f"KeyPoint(pt=({self.pt[0]:.2f}, {self.pt[1]:.2f}), size={self.size:.2f}, "
+                f"angle={self.angle:.1f}, octave={self.octave})")
+
+
+def sift_sort_unique(kps):
+    """KeyPointsFilter::removeDuplicatedSorted on a KP_DTYPE array: order by x, y,
+    size (descending), angle, response (descending), octave (descending); keep the
+    first of keypoints that share x, y, size and angle."""
+    order = np.lexsort((-kps["octave"].astype(np.int64), -kps["response"], kps["angle"],
+                        -kps["size"], kps["y"], kps["x"]))
+    kps = kps[order]
+    if len(kps) > 1:
+        same = ((kps["x"][1:] == kps["x"][:-1]) & (kps["y"][1:] == kps["y"][:-1]) &
+                (kps["size"][1:] == kps["size"][:-1]) & (kps["angle"][1:] == kps["angle"][:-1]))
+        kps = kps[np.concatenate([[True], ~same])]
+    return kps
+
+
+def sift_detect_device(frame, max_keypoints=1 << 18, pyramid=None):
+    """detectAndCompute on a uint8 BGR frame on the device.  Returns (keypoints as a
+    KP_DTYPE array in OpenCV's order, descriptors float32 [K][128] with values 0..255).
+    ``pyramid`` = (gauss, dog) device stacks replaces the scale space of ``frame``."""
+    import torch
+    eng = _eng.engine()
+    lib = eng.lib
+    gauss, dog = pyramid if pyramid is not None else sift_pyramid_device(frame)
+    dev = eng.device
+    dims = torch.tensor([v for g in gauss for v in g.shape[1:]], dtype=torch.int32, device=dev)
+    gptr = torch.tensor([g.data_ptr() for g in gauss], dtype=torch.int64, device=dev)
+    cands = torch.empty(max_keypoints * 32, dtype=torch.uint8, device=dev)
+    kpts = torch.empty(max_keypoints * 32, dtype=torch.uint8, device=dev)
+    counts = torch.zeros(2, dtype=torch.int32, device=dev)
+    for o, diff in enumerate(dog):
+        _, oh, ow = diff.shape
+        _lib.check(lib.pano_sift_extrema(_eng._ptr(diff), oh, ow, o, SIFT_LAYERS, SIFT_CONTRAST,
+                                         SIFT_EDGE, SIFT_SIGMA, _eng._ptr(cands),
+                                         _eng._ptr(counts[0:]), max_keypoints, eng.stream()),
+                   "pano_sift_extrema")
+    _lib.check(lib.pano_sift_orient(_eng._ptr(gptr), _eng._ptr(dims), SIFT_LAYERS, _eng._ptr(cands),
+                                    _eng._ptr(counts[0:]), max_keypoints, _eng._ptr(kpts),
+                                    _eng._ptr(counts[1:]), max_keypoints, eng.stream()),
+               "pano_sift_orient")
+    n_cand, n_kp = (int(v) for v in counts.cpu().numpy())
+    if max(n_cand, n_kp) > max_keypoints:
+        raise _lib.PanoError(f"sift: {max(n_cand, n_kp)} keypoints exceed max_keypoints")
+    host = kpts[:n_kp * 32].cpu().numpy().view(KP_DTYPE).copy()
+    host = sift_sort_unique(host)
+    # first octave -1: halve positions and sizes, shift the octave byte (sift.cpp, detectAndCompute)
+    host["octave"] = (host["octave"] & ~255) | ((host["octave"] + SIFT_FIRST_OCTAVE) & 255)
+    for key in ("x", "y", "size"):
+        host[key] = host[key] * np.float32(0.5)
+    desc = torch.empty((len(host), 128), dtype=torch.float32, device=dev)
+    if len(host):
+        dkp = torch.from_numpy(host.view(np.uint8).reshape(-1)).to(dev)
+        _lib.check(lib.pano_sift_describe(_eng._ptr(gptr), _eng._ptr(dims), SIFT_FIRST_OCTAVE,
+                                          _eng._ptr(dkp), len(host), _eng._ptr(desc), eng.stream()),
+                   "pano_sift_describe")
+    return host, desc
+
+
+def sift_detector():
+    """Closure, return a SIFT detecting function (features.py:192-201):
+    ``_detect(img) -> (keypoints, RootSIFT descriptors)``."""
+    def _detect(img):
+        eng = _eng.engine()
+        frame = eng.upload_frames([img])[0]
+        kps, desc = sift_detect_device(frame)
+        des = desc.cpu().numpy()
+        des = np.sqrt(des / (des.sum(axis=1, keepdims=True) + 1e-7))  # RootSIFT
+        kp_ = [KeyPoint(k["x"], k["y"], k["size"], k["angle"], k["response"], k["octave"])
+               for k in kps]
+        return kp_, des
+
+    return _detect
 
 
 def sift_pyramid(img, n_octaves=None):
@@ -151,5 +268,5 @@ def sift_pyramid(img, n_octaves=None):
     eng = _eng.engine()
     frame = eng.upload_frames([img])[0]
     gauss, dog = sift_pyramid_device(frame, n_octaves)
-    to_np = lambda pyr: [[p.cpu().numpy() for p in octave] for octave in pyr]   # noqa: E731
+    to_np = lambda pyr: [[p.cpu().numpy() for p in octave] for octave in pyr]   # noqa: E731  (stacks iterate as planes)
     return to_np(gauss), to_np(dog)

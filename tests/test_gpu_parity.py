@@ -609,6 +609,75 @@ def test_sift_scale_space_matches_oracle(eng, shape):
 
 
 # ------------------------------------------- size-independent properties
+def _match_keypoints(got, want):
+    """Greedy one-to-one matching on (x, y, size, angle); returns index pairs."""
+    pairs, used = [], set()
+    for i, k in enumerate(want):
+        d = (np.abs(got["x"] - k["x"]) + np.abs(got["y"] - k["y"]) + np.abs(got["size"] - k["size"])
+             + np.minimum(np.abs(got["angle"] - k["angle"]), 360 - np.abs(got["angle"] - k["angle"])) / 90)
+        for j in np.argsort(d)[:3]:
+            if d[j] < 0.05 and int(j) not in used:
+                used.add(int(j))
+                pairs.append((int(j), i))
+                break
+    return pairs
+
+
+@pytest.mark.parametrize("kind,seed", [("B", 3), ("blobs", 0)])
+def test_sift_keypoints_and_descriptors_match_oracle(eng, kind, seed):
+    """features.sift_detector's keypoints and descriptors (OpenCV SIFT restated, parity
+    unpinned) against the NumPy restatement: (1) on the oracle's own scale space the
+    kernels reproduce every keypoint and descriptor (LDS-atomic summation order aside);
+    (2) end to end, the few extrema that sit on a threshold may come or go."""
+    import torch
+    import sift_oracle
+    import sift_pyramid as sp
+    from pano360_amd import features, synth
+    w, h = 144, 104
+    if kind == "blobs":
+        rng = np.random.default_rng(seed)
+        yy, xx = np.mgrid[:h, :w]
+        img = np.zeros((h, w), np.float64)
+        for _ in range(25):
+            cx, cy, s = rng.uniform(8, w - 8), rng.uniform(8, h - 8), rng.uniform(1.5, 6)
+            img += rng.uniform(-1, 1) * np.exp(-((xx - cx) ** 2 + (yy - cy) ** 2) / (2 * s * s))
+        img = np.clip(128 + 100 * img, 0, 255).astype(np.uint8)
+        img = np.stack([img, np.roll(img, 1, 0), np.roll(img, 1, 1)], axis=-1)
+    else:
+        img = synth.make_frame(seed, w, h, kind)
+    g_or, d_or = sp.sift_pyramid(img)
+    want_k, want_d = sift_oracle.detect_and_compute(g_or, d_or)
+    want = np.zeros(len(want_k), features.KP_DTYPE)
+    for i, k in enumerate(want_k):
+        want[i] = (k["x"], k["y"], k["size"], k["angle"], k["response"], k["octave"], k["r"], k["c"])
+    assert len(want) > 15
+    frame = eng.upload_frames([img])[0]
+    # (1) same scale space
+    stacks = ([torch.from_numpy(np.stack(o)).to(eng.device) for o in g_or],
+              [torch.from_numpy(np.stack(o)).to(eng.device) for o in d_or])
+    got, desc = features.sift_detect_device(frame, pyramid=stacks)
+    desc = desc.cpu().numpy()
+    assert len(got) == len(want)
+    assert np.array_equal(got["octave"], want["octave"])
+    for key, tol in (("x", 2e-3), ("y", 2e-3), ("size", 2e-3), ("response", 1e-5)):
+        assert np.abs(got[key] - want[key]).max() <= tol, key
+    dang = np.abs(got["angle"] - want["angle"])
+    assert np.minimum(dang, 360 - dang).max() <= 0.05
+    diff = np.abs(desc - want_d)
+    assert diff.max() <= 2 and (diff > 0).mean() < 0.02
+    # (2) end to end
+    got2, desc2 = features.sift_detect_device(frame)
+    pairs = _match_keypoints(got2, want)
+    assert len(pairs) >= 0.97 * len(want) and abs(len(got2) - len(want)) <= 0.03 * len(want) + 2
+    gi, wi = np.array(pairs).T
+    assert np.abs(desc2.cpu().numpy()[gi] - want_d[wi]).mean() < 0.5
+    # the reference-facing closure: keypoint objects + RootSIFT rows of unit L2 norm
+    kp, des = features.sift_detector()(img)
+    assert len(kp) == len(got2) and des.shape == (len(kp), 128)
+    np.testing.assert_allclose((des ** 2).sum(axis=1), 1.0, atol=1e-5)
+    assert abs(kp[0].pt[0] - got2["x"][0]) < 1e-6 and kp[0].octave == got2["octave"][0]
+
+
 def test_full_size_properties_1080p(eng):
     """BASELINE config 2 at full size (8 x 1080p, native resolution), checked
     through properties that need no oracle: a constant-colour scene must come

@@ -199,3 +199,32 @@ def test_warp_perspective_shim_matches_oracle(oracle):
     assert size == mask.sum() and 0 < size < h * w
     assert np.float32(mean_i) == np.mean(a[mask, :3])
     assert np.float32(mean_j) == np.mean(warped[mask, :3])
+
+
+def test_sift_oracle_building_blocks():
+    """Pieces of the SIFT restatement that can be checked without OpenCV: fastAtan2
+    stays within its documented 0.3 degrees of atan2, the float LU solve agrees
+    with LAPACK, the keypoint sort is the one removeDuplicatedSorted specifies."""
+    import sift_oracle as so
+    rng = np.random.default_rng(2)
+    y, x = rng.normal(size=4000).astype(np.float32), rng.normal(size=4000).astype(np.float32)
+    want = np.degrees(np.arctan2(y.astype(np.float64), x.astype(np.float64))) % 360
+    err = np.abs(so.fast_atan2(y, x) - want)
+    assert np.minimum(err, 360 - err).max() < 0.3
+    assert so.fast_atan2(np.float32(0), np.float32(0)) == 0
+    for _ in range(50):
+        a = rng.normal(size=(3, 3)).astype(np.float32)
+        b = rng.normal(size=3).astype(np.float32)
+        np.testing.assert_allclose(so._solve3(a, b), np.linalg.solve(a.astype(np.float64), b),
+                                   rtol=2e-3, atol=2e-4)
+    assert so._solve3(np.zeros((3, 3)), np.ones(3)) is None
+    kp = [dict(x=2.0, y=1.0, size=3.0, angle=10.0, response=0.1, octave=5),
+          dict(x=1.0, y=5.0, size=3.0, angle=10.0, response=0.1, octave=5),
+          dict(x=2.0, y=1.0, size=4.0, angle=10.0, response=0.1, octave=5),
+          dict(x=2.0, y=1.0, size=3.0, angle=10.0, response=0.3, octave=7)]
+    out = so.sort_unique(kp)
+    assert [(k["x"], k["size"], k["response"]) for k in out] == [(1.0, 3.0, 0.1), (2.0, 4.0, 0.1),
+                                                                 (2.0, 3.0, 0.3)]
+    assert so.unpack_octave(255 | (2 << 8)) == (-1, 2, 2.0)
+    des = so.root_sift(np.array([[4.0, 0.0, 12.0]]))
+    np.testing.assert_allclose((des ** 2).sum(), 1.0, atol=1e-6)
