@@ -173,7 +173,11 @@ int pano_ownership(const pano_patch *patches, int n, int H, int W,
 /* The same two maps straight from the cameras (no pixel data is read): for
  * every mosaic pixel in columns [xs0, xs1) and every camera whose patch
  * rectangle holds it, the inverse map, the mask and the bilinear alpha are
- * re-evaluated exactly as pano_warp_spherical does.  cams: dev array. */
+ * re-evaluated exactly as pano_warp_spherical does - but only for the cameras
+ * that can still win: per 64 x 16 tile, cameras whose alpha is bounded (interval
+ * arithmetic on the ray, rigorous) below another camera's lower bound are
+ * skipped, which changes neither map (PANO_OWN_PRUNE=0 disables it).
+ * cams: dev array. */
 int pano_ownership_cameras(const pano_camera *cams, int n, int H, int W,
                            int xs0, int xs1, const double *sin_t,
                            const double *cos_t, const double *tan_p,
@@ -194,15 +198,18 @@ int pano_owned_regions(const int16_t *owner, int H, int W, int xs0, int xs1,
 /* The n_levels-1 Gaussian blurs of every patch  stitcher.py:207-208, 218, 226
  * (cv2.GaussianBlur(warped, (0,0), 4*sqrt(2k+1)) with the alpha channel
  * replaced by the sharp mask owner == index), evaluated on rectangle A of each
- * patch from its colour planes over V; n_blur + 1 launches in all (one row
- * pass that serves every level from a single staged tile, one column pass per
- * level).  patches: dev array of n records with planes, blurred and scratch
- * set; max_aw / max_vh / max_ah: the largest extents among them.
+ * patch from its colour planes over V, all levels, records and channels in one
+ * launch (matrix-core kernel; the vector-ALU alternative runs one row pass for
+ * all levels and one column pass per level through patches[i].scratch).
+ * patches: dev array of n records with planes and blurred set (scratch only for
+ * the vector-ALU kernels); max_aw / max_vh / max_ah: the largest extents.
  * taps: dev float, n_blur tables laid out back to back; table k has
  * ntaps[k] + PANO_TAP_PAD floats: PANO_TAP_LEAD + ((R - r_k) & 3) zeros, the
  * ntaps[k] taps, zeros, where r_k = ntaps[k] / 2 and R = max r_k (the extra
  * zeros keep the row pass's 16-byte LDS reads aligned for every level).
- * ntaps: host int[n_blur].  Writes patches[i].blurred (and .scratch).
+ * ntaps: host int[n_blur].  Writes patches[i].blurred.  The first call with a
+ * given (taps pointer, apertures) builds that tap set's operand tables on the
+ * device and keeps them (at most 8 distinct sets per process).
  * interior (optional, with tile_flags): the map of pano_interior_map; tiles
  * that hold only interior pixels (and the intermediate rows only they would
  * read) are skipped.  tile_flags: dev uint8, one entry per tile of every record,
