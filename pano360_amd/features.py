@@ -14,7 +14,11 @@ algorithm (SIFT defaults: sigma 1.6, 3 layers per octave, first octave -1) is
 restated, parity unpinned.
 * ``sift_detector()``                   - features.py:192-201: keypoints, 128-d
   descriptors (``pano_sift_extrema`` / ``_orient`` / ``_describe``) and the RootSIFT
-  normalisation.  Matching stays outside this build's scope.
+  normalisation.
+* ``flann_matching(des1, des2)``        - features.py:222-232: the 2-nearest-neighbour
+  search and Lowe's 0.7 ratio test, exhaustive on the GPU (a library GEMM for the
+  cross terms + top-2) where the reference asks FLANN's randomised kd-trees for an
+  approximate answer; homography estimation (RANSAC) stays outside.
 """
 import ctypes as C
 
@@ -270,3 +274,48 @@ def sift_pyramid(img, n_octaves=None):
     gauss, dog = sift_pyramid_device(frame, n_octaves)
     to_np = lambda pyr: [[p.cpu().numpy() for p in octave] for octave in pyr]   # noqa: E731  (stacks iterate as planes)
     return to_np(gauss), to_np(dog)
+
+
+# ------------------------------------------------------------------ matching
+class DMatch:
+    """The fields of ``cv2.DMatch`` the reference reads (features.py:238)."""
+    __slots__ = ("queryIdx", "trainIdx", "distance")
+
+    def __init__(self, query, train, distance):
+        self.queryIdx, self.trainIdx, self.distance = int(query), int(train), float(distance)
+
+
+def knn2_device(des1, des2, chunk=8192):
+    """Two nearest rows of ``des2`` (Euclidean) for every row of ``des1``; both device
+    float32 [K][D].  Returns (indices int64 [K1][2], distances float32 [K1][2]).
+    |a - b|^2 = |a|^2 + |b|^2 - 2 a.b with the cross terms from one hipBLASLt GEMM per
+    chunk of queries; the two winners' distances are then recomputed directly, so the
+    ratio test does not see the cancellation error of that expansion."""
+    import torch
+    n2 = (des2 * des2).sum(dim=1)
+    idx_out, dist_out = [], []
+    for a in range(0, des1.shape[0], chunk):
+        q = des1[a:a + chunk]
+        d2 = (q * q).sum(dim=1, keepdim=True) + n2[None, :] - 2.0 * (q @ des2.T)
+        _, idx = torch.topk(d2, k=2, dim=1, largest=False)
+        near = des2[idx]                                          # [k][2][D]
+        dist = torch.sqrt(((near - q[:, None, :]) ** 2).sum(dim=2))
+        order = torch.argsort(dist, dim=1, stable=True)
+        idx_out.append(torch.gather(idx, 1, order))
+        dist_out.append(torch.gather(dist, 1, order))
+    return torch.cat(idx_out), torch.cat(dist_out)
+
+
+def flann_matching(des1, des2, ratio=0.7):
+    """Given 2 lists of descriptors, match them (features.py:222-232): 2-NN + Lowe's
+    ratio test.  Exact search instead of FLANN's approximate one."""
+    import torch
+    eng = _eng.engine()
+    if len(des1) == 0 or len(des2) < 2:
+        return []
+    d1 = torch.from_numpy(np.ascontiguousarray(des1, np.float32)).to(eng.device)
+    d2 = torch.from_numpy(np.ascontiguousarray(des2, np.float32)).to(eng.device)
+    idx, dist = knn2_device(d1, d2)
+    idx, dist = idx.cpu().numpy(), dist.cpu().numpy()
+    keep = np.nonzero(dist[:, 0] < ratio * dist[:, 1])[0]
+    return [DMatch(q, idx[q, 0], dist[q, 0]) for q in keep]

@@ -678,6 +678,30 @@ def test_sift_keypoints_and_descriptors_match_oracle(eng, kind, seed):
     assert abs(kp[0].pt[0] - got2["x"][0]) < 1e-6 and kp[0].octave == got2["octave"][0]
 
 
+def test_exhaustive_two_nearest_neighbour_matching(eng):
+    """flann_matching (features.py:222-232) as an exact search: every match the ratio
+    test keeps equals the brute-force answer; the same frame matched against a shifted
+    copy of itself finds the shift."""
+    from pano360_amd import features, synth
+    rng = np.random.default_rng(9)
+    a = rng.random((700, 128)).astype(np.float32)
+    b = np.concatenate([a[rng.permutation(700)[:400]] + 0.01 * rng.random((400, 128)).astype(np.float32),
+                        rng.random((900, 128)).astype(np.float32)])
+    got = features.flann_matching(a, b)
+    d = np.sqrt(((a[:, None, :].astype(np.float64) - b[None, :, :]) ** 2).sum(-1))
+    order = np.argsort(d, axis=1)[:, :2]
+    best, second = d[np.arange(700), order[:, 0]], d[np.arange(700), order[:, 1]]
+    want = {int(q): int(order[q, 0]) for q in np.nonzero(best < 0.7 * second)[0]}
+    assert {m.queryIdx: m.trainIdx for m in got} == want and len(want) >= 390
+    assert max(abs(m.distance - best[m.queryIdx]) for m in got) < 1e-4
+    img = synth.make_frame(5, 320, 200, "B")
+    det = features.sift_detector()
+    (k1, d1), (k2, d2) = det(img), det(np.roll(img, 7, axis=1))
+    good = features.flann_matching(d1, d2)
+    shift = np.array([k2[m.trainIdx].pt[0] - k1[m.queryIdx].pt[0] for m in good])
+    assert len(good) > 50 and np.median(np.abs(shift - 7)) < 0.05
+
+
 def test_full_size_properties_1080p(eng):
     """BASELINE config 2 at full size (8 x 1080p, native resolution), checked
     through properties that need no oracle: a constant-colour scene must come
