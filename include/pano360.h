@@ -236,8 +236,9 @@ int pano_multiband_blur(const pano_patch *patches, int n, int max_aw,
  * patch's are exact zeros, and the multiband mosaic at p is the patch's warped
  * colour (to float32 rounding, <= 6e-8 absolute).  interior: dev uint8
  * [ceil(H/8)][ceil(W/8)], 1 = every pixel of the 8 x 8 block is such a pixel
- * (conservative: tested on whole blocks); block_owner: dev int16 workspace of
- * the same shape.  Only columns [xs0, xs1) of owner are read. */
+ * (conservative: tested on whole blocks); block_owner: dev int16 workspace,
+ * twice that shape ([2][ceil(H/8)][ceil(W/8)]).  Only columns [xs0, xs1) of
+ * owner are read. */
 int pano_interior_map(const int16_t *owner, int H, int W, int xs0, int xs1,
                       int radius, int16_t *block_owner, uint8_t *interior,
                       void *stream);

@@ -411,15 +411,22 @@ __global__ __launch_bounds__(256) void block_owner_kernel(const int16_t *__restr
     int o = -2;                                  // -2: mixed, or not inside the strip
     if (x0 >= xs0 && (x0 + IB < W ? x0 + IB : W) <= xs1) {
         o = owner[(size_t)y0 * W + x0];
+        const bool whole = x0 + IB <= W && (W & 1) == 0;      // rows 4-byte aligned, 8 in range
         for (int dy = 0; dy < IB && o != -2; ++dy) {
             const int y = y0 + dy;
             if (y >= H) break;
-            for (int dx = 0; dx < IB; ++dx) {
-                const int x = x0 + dx;
-                if (x >= W) break;
-                if (owner[(size_t)y * W + x] != o) {
-                    o = -2;
-                    break;
+            if (whole) {                         // one row of the block = four 32-bit words
+                const uint32_t *q = (const uint32_t *)(owner + (size_t)y * W + x0);
+                const uint32_t both = ((uint32_t)(uint16_t)o << 16) | (uint16_t)o;
+                if ((q[0] ^ both) | (q[1] ^ both) | (q[2] ^ both) | (q[3] ^ both)) o = -2;
+            } else {
+                for (int dx = 0; dx < IB; ++dx) {
+                    const int x = x0 + dx;
+                    if (x >= W) break;
+                    if (owner[(size_t)y * W + x] != o) {
+                        o = -2;
+                        break;
+                    }
                 }
             }
         }
@@ -427,25 +434,31 @@ __global__ __launch_bounds__(256) void block_owner_kernel(const int16_t *__restr
     bown[(size_t)by * W8 + bx] = (int16_t)o;
 }
 
-__global__ __launch_bounds__(256) void interior_blocks_kernel(const int16_t *__restrict__ bown,
-                                                              int H8, int W8, int reach,
-                                                              uint8_t *__restrict__ interior) {
+// interior = the block's owner o >= 0 fills the (2 reach + 1)^2 neighbourhood of blocks.
+// Separable: first down the columns (col[by][bx] = o if the blocks above and below
+// within reach all belong to o, else -2), then along the rows of that.
+__global__ __launch_bounds__(256) void interior_cols_kernel(const int16_t *__restrict__ bown,
+                                                            int H8, int W8, int reach,
+                                                            int16_t *__restrict__ col) {
     const int bx = blockIdx.x * 64 + threadIdx.x, by = blockIdx.y * 4 + threadIdx.y;
     if (bx >= W8 || by >= H8) return;
-    const int o = bown[(size_t)by * W8 + bx];
+    int o = bown[(size_t)by * W8 + bx];
+    const int y0 = by - reach < 0 ? 0 : by - reach, y1 = by + reach >= H8 ? H8 - 1 : by + reach;
+    for (int y = y0; y <= y1 && o >= 0; ++y)     // beyond the mosaic: nothing there
+        if (bown[(size_t)y * W8 + bx] != o) o = -2;
+    col[(size_t)by * W8 + bx] = (int16_t)o;
+}
+
+__global__ __launch_bounds__(256) void interior_rows_kernel(const int16_t *__restrict__ col,
+                                                            int H8, int W8, int reach,
+                                                            uint8_t *__restrict__ interior) {
+    const int bx = blockIdx.x * 64 + threadIdx.x, by = blockIdx.y * 4 + threadIdx.y;
+    if (bx >= W8 || by >= H8) return;
+    const int16_t *row = col + (size_t)by * W8;
+    const int o = row[bx];
     bool in = o >= 0;
-    for (int dy = -reach; dy <= reach && in; ++dy) {
-        const int y = by + dy;
-        if (y < 0 || y >= H8) continue;          // beyond the mosaic: nothing there
-        for (int dx = -reach; dx <= reach; ++dx) {
-            const int x = bx + dx;
-            if (x < 0 || x >= W8) continue;
-            if (bown[(size_t)y * W8 + x] != o) {
-                in = false;
-                break;
-            }
-        }
-    }
+    const int x0 = bx - reach < 0 ? 0 : bx - reach, x1 = bx + reach >= W8 ? W8 - 1 : bx + reach;
+    for (int x = x0; x <= x1 && in; ++x) in = row[x] == o;
     interior[(size_t)by * W8 + bx] = in ? 1 : 0;
 }
 
@@ -681,25 +694,36 @@ __global__ __launch_bounds__(64) void owned_spans_kernel(const uint8_t *__restri
     const uint8_t *row = marks + (size_t)blockIdx.x * W;
     int32_t *out = regions + (size_t)blockIdx.x * stride + 5;
     int cnt = 0, last = 0;
-    for (int base = xs0; base < xs1; base += 64) {
-        const int x = base + lane;
-        unsigned long long bal = __ballot(x < xs1 && row[x] != 0);
-        while (bal) {
-            const int s = __ffsll((long long)bal) - 1;
-            const unsigned long long rest = ~(bal >> s);          // 0 bits = the run
-            const int len = rest ? __ffsll((long long)rest) - 1 : 64 - s;
-            const int xa = base + s, xb = xa + len - 1;
-            if (cnt && (xa - last - 1 < min_gap || cnt == max_spans)) {
-                if (lane == 0) out[2 * (cnt - 1) + 1] = xb;       // extend the current span
-            } else {
-                if (lane == 0) {
-                    out[2 * cnt] = xa;
-                    out[2 * cnt + 1] = xb;
+    // four 64-column groups per trip: their loads are issued together, the run extraction
+    // (a serial chain through cnt / last) then works on the four ballots in order
+    for (int base0 = xs0; base0 < xs1; base0 += 256) {
+        uint8_t m[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int x = base0 + 64 * g + lane;
+            m[g] = x < xs1 ? row[x] : 0;
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int base = base0 + 64 * g;
+            unsigned long long bal = __ballot(m[g] != 0);
+            while (bal) {
+                const int s = __ffsll((long long)bal) - 1;
+                const unsigned long long rest = ~(bal >> s);      // 0 bits = the run
+                const int len = rest ? __ffsll((long long)rest) - 1 : 64 - s;
+                const int xa = base + s, xb = xa + len - 1;
+                if (cnt && (xa - last - 1 < min_gap || cnt == max_spans)) {
+                    if (lane == 0) out[2 * (cnt - 1) + 1] = xb;   // extend the current span
+                } else {
+                    if (lane == 0) {
+                        out[2 * cnt] = xa;
+                        out[2 * cnt + 1] = xb;
+                    }
+                    ++cnt;
                 }
-                ++cnt;
+                last = xb;
+                bal = s + len >= 64 ? 0ull : bal & ~((1ull << (s + len)) - 1ull);
             }
-            last = xb;
-            bal = s + len >= 64 ? 0ull : bal & ~((1ull << (s + len)) - 1ull);
         }
     }
     if (lane == 0) regions[(size_t)blockIdx.x * stride + 4] = cnt;
@@ -757,9 +781,11 @@ extern "C" int pano_interior_map(const int16_t *owner, int H, int W, int xs0, in
                hipLaunchKernelGGL(block_owner_kernel, grid, block, 0, s, owner, H, W, xs0, xs1,
                                   H8, W8, block_owner));
     PANO_LAUNCH_CHECK("block_owner_kernel");
-    hipLaunchKernelGGL(interior_blocks_kernel, grid, block, 0, s, block_owner, H8, W8, reach,
-                       interior);
-    PANO_LAUNCH_CHECK("interior_blocks_kernel");
+    int16_t *col = block_owner + (size_t)H8 * W8;
+    hipLaunchKernelGGL(interior_cols_kernel, grid, block, 0, s, block_owner, H8, W8, reach, col);
+    PANO_LAUNCH_CHECK("interior_cols_kernel");
+    hipLaunchKernelGGL(interior_rows_kernel, grid, block, 0, s, col, H8, W8, reach, interior);
+    PANO_LAUNCH_CHECK("interior_rows_kernel");
     return PANO_OK;
 }
 

@@ -639,7 +639,7 @@ class Engine:
         H, W = owner.shape
         c0, c1 = strip if strip is not None else (0, W)
         shape8 = ((H + 7) // 8, (W + 7) // 8)
-        bown = torch.empty(shape8, dtype=torch.int16, device=self.device)
+        bown = torch.empty((2,) + shape8, dtype=torch.int16, device=self.device)
         interior = torch.empty(shape8, dtype=torch.uint8, device=self.device)
         _lib.check(self.lib.pano_interior_map(_ptr(owner), H, W, c0, c1, radius, _ptr(bown),
                                               _ptr(interior), self.stream()),
