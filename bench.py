@@ -211,6 +211,12 @@ def main():
     for _ in range(3):            # setup: first-touch allocations of the workspaces
         step()
     fence()
+    # Python's cyclic collector walks every live object (all of torch and numpy) when its
+    # oldest generation comes due - 37 ms, ten stitches, in the middle of a timed step.
+    # Everything alive after setup is long-lived: park it where the collector does not look.
+    import gc
+    gc.collect()
+    gc.freeze()
     for _ in range(args.warmup):
         step()
     fence()

@@ -375,6 +375,43 @@ def windows_for(box, rect, radius, strip=None):
     return (ay0, ay1, ax0, ax1), (min(vy0, ay0), max(vy1, ay1), min(vx0, ax0), max(vx1, ax1))
 
 
+def _reflect_closed_many(lo, hi, n):
+    """reflect_closed on int64 arrays."""
+    a, b = np.maximum(lo, 0), np.minimum(hi, n)
+    neg, over = lo < 0, hi > n
+    a = np.where(neg, np.minimum(a, 1), a)
+    b = np.where(neg, np.maximum(b, 1 - lo), b)
+    a = np.where(over, np.minimum(a, 2 * n - 1 - hi), a)
+    b = np.where(over, np.maximum(b, n - 1), b)
+    a, b = np.maximum(a, 0), np.minimum(b, n)
+    full = (lo < -(n - 1)) | (hi > 2 * n - 1)
+    a, b = np.where(full, 0, a), np.where(full, n, b)
+    one = n == 1
+    return np.where(one, 0, a), np.where(one, 1, b)
+
+
+def windows_for_many(boxes, rects, radius, strip=None):
+    """``windows_for`` for k records at once (the host sits between two GPU stages
+    while it lays these out).  boxes, rects: int arrays [k][4].  Returns
+    (keep [k] bool, A [k][4], V [k][4]) with A, V patch-local (y0, y1, x0, x1)."""
+    boxes, rects = np.asarray(boxes, np.int64).reshape(-1, 4), np.asarray(rects, np.int64).reshape(-1, 4)
+    ymin, ymax, xmin, xmax = boxes.T
+    y0, y1, x0, x1 = rects.T
+    h, w = y1 - y0, x1 - x0
+    keep = (ymax >= ymin) & (xmax >= xmin)
+    ay0, ay1 = np.maximum(ymin - y0 - radius, 0), np.minimum(ymax - y0 + 1 + radius, h)
+    ax0, ax1 = np.maximum(xmin - x0 - radius, 0), np.minimum(xmax - x0 + 1 + radius, w)
+    if strip is not None:
+        ax0, ax1 = np.maximum(ax0, strip[0] - x0), np.minimum(ax1, strip[1] - x0)
+        keep &= ax1 > ax0
+    vy0, vy1 = _reflect_closed_many(ay0 - radius, ay1 + radius, h)
+    vx0, vx1 = _reflect_closed_many(ax0 - radius, ax1 + radius, w)
+    area = np.stack([ay0, ay1, ax0, ax1], axis=1)
+    window = np.stack([np.minimum(vy0, ay0), np.maximum(vy1, ay1), np.minimum(vx0, ax0),
+                       np.maximum(vx1, ax1)], axis=1)
+    return keep, area, window
+
+
 class DevicePatch:
     """Stage-level patch: four planes and a mask over the whole patch, as the
     blender protocol hands them over (V = A = the patch)."""
@@ -460,17 +497,23 @@ class FusedPatches:
         return have
 
     def __init__(self, entries, device, n_blur):
-        n = len(entries)
+        if isinstance(entries, tuple):                   # (index [k], rects [k][4], A [k][4], V [k][4])
+            index, rects, area, window = (np.asarray(v, np.int64) for v in entries)
+        else:
+            index = np.array([e[0] for e in entries], np.int64)
+            rects = np.array([e[1] for e in entries], np.int64).reshape(-1, 4)
+            area = np.array([e[2][0] for e in entries], np.int64).reshape(-1, 4)
+            window = np.array([e[2][1] for e in entries], np.int64).reshape(-1, 4)
+        n = len(index)
         rec = np.zeros(n, dtype=PATCH_DTYPE)
-        self.info = []
-        for i, (index, rect, win) in enumerate(entries):
-            y0, y1, x0, x1 = rect
-            rec[i]["y0"], rec[i]["x0"], rec[i]["h"], rec[i]["w"] = y0, x0, y1 - y0, x1 - x0
-            rec[i]["index"] = index
-            (ay0, ay1, ax0, ax1), (vy0, vy1, vx0, vx1) = win
-            rec[i]["vy0"], rec[i]["vx0"], rec[i]["vh"], rec[i]["vw"] = vy0, vx0, vy1 - vy0, vx1 - vx0
-            rec[i]["ay0"], rec[i]["ax0"], rec[i]["ah"], rec[i]["aw"] = ay0, ax0, ay1 - ay0, ax1 - ax0
-            self.info.append(WindowInfo(win[0], win[1]))
+        self._area, self._window = area, window
+        rec["y0"], rec["x0"] = rects[:, 0], rects[:, 2]
+        rec["h"], rec["w"] = rects[:, 1] - rects[:, 0], rects[:, 3] - rects[:, 2]
+        rec["index"] = index
+        rec["vy0"], rec["vx0"] = window[:, 0], window[:, 2]
+        rec["vh"], rec["vw"] = window[:, 1] - window[:, 0], window[:, 3] - window[:, 2]
+        rec["ay0"], rec["ax0"] = area[:, 0], area[:, 2]
+        rec["ah"], rec["aw"] = area[:, 1] - area[:, 0], area[:, 3] - area[:, 2]
         rec["vpitch"] = (rec["vw"] + 3) & ~3
         vh, ah = rec["vh"].astype(np.int64), rec["ah"].astype(np.int64)
         planes_sz = 3 * vh * rec["vpitch"]
@@ -501,11 +544,16 @@ class FusedPatches:
             rec[key] = base + 4 * offs
         self.table = PatchTable(rec, device)
 
+    @property
+    def info(self):
+        return [WindowInfo(tuple(int(v) for v in a), tuple(int(v) for v in w))
+                for a, w in zip(self._area, self._window)]
+
     def __iter__(self):
         return iter(self.info)
 
     def __len__(self):
-        return len(self.info)
+        return len(self._area)
 
     @property
     def warped_pixels(self):
@@ -820,6 +868,7 @@ class Engine:
             host = host_buf.numpy().copy()
             spans = [host[i, 5:5 + 2 * host[i, 4]].reshape(-1, 2) for i in range(n)]
             return host[:, :4], spans
+        wait.raw = lambda: (done.synchronize(), host_buf.numpy().copy())[1]
         return wait
 
     def owned_regions(self, owner, n, strip=None, min_gap=0, max_spans=4):
@@ -859,18 +908,20 @@ class Engine:
         # while the host waits for the regions and lays out the windows.
         regions = self.owned_regions_async(owner, plan.n, ext, 2 * radius + 2)
         interior = self.interior_map(owner, radius, ext) if shortcut and n_blur else None
-        boxes, spans = regions()
-        entries = []
-        for i in range(plan.n):
-            for xa, xb in spans[i]:
-                win = windows_for((boxes[i][0], boxes[i][1], xa, xb), plan.rects[i], radius,
-                                  (c0, c1))
-                if win is not None:
-                    entries.append((i, plan.rects[i], win))
-        missing = sorted({i for i, _, _ in entries if i not in have})
+        raw = regions.raw().astype(np.int64)             # [n][5 + 2 max_spans]
+        counts = raw[:, 4]
+        index = np.repeat(np.arange(plan.n), counts)
+        nth = np.arange(len(index)) - np.repeat(np.cumsum(counts) - counts, counts)
+        xa, xb = raw[index, 5 + 2 * nth], raw[index, 6 + 2 * nth]
+        rects = np.asarray(plan.rects, np.int64)[index]
+        keep, area, window = windows_for_many(
+            np.stack([raw[index, 0], raw[index, 1], xa, xb], axis=1), rects, radius, (c0, c1))
+        index, rects, area, window = index[keep], rects[keep], area[keep], window[keep]
+        missing = sorted({int(i) for i in index if int(i) not in have})
         if missing:
             raise _lib.PanoError(f"frames {missing} are needed for columns [{c0}, {c1}) "
                                  "but are not resident on this device")
+        entries = (index, rects, area, window)
         patches = FusedPatches(entries, self.device, n_blur)
         table = patches.table
         _lib.check(self.lib.pano_warp_windows(

@@ -227,3 +227,23 @@ def test_gain_tables_and_pairs_match_reference(oracle):
     # a camera looking backwards drops out (stitcher.py:51-52)
     back = engine.overlap_pairs([np.eye(3), np.diag([-1.0, 1.0, -1.0])], [intrs[0], intrs[0]], w, h)
     assert len(back) == 0
+
+
+def test_windows_for_many_equals_windows_for():
+    """The vectorised window layout used between the two GPU stages is the scalar one."""
+    from pano360_amd.engine import windows_for, windows_for_many
+    rng = np.random.default_rng(11)
+    boxes, rects = [], []
+    for _ in range(400):
+        h, w = int(rng.integers(1, 300)), int(rng.integers(1, 500))
+        y0, x0 = int(rng.integers(0, 50)), int(rng.integers(0, 900))
+        ya, xa = int(rng.integers(y0 - 3, y0 + h + 3)), int(rng.integers(x0 - 3, x0 + w + 3))
+        boxes.append((ya, int(rng.integers(ya - 2, y0 + h + 5)), xa, int(rng.integers(xa - 2, x0 + w + 5))))
+        rects.append((y0, y0 + h, x0, x0 + w))
+    for radius, strip in ((43, None), (5, (300, 700)), (48, (0, 400)), (0, None)):
+        keep, area, window = windows_for_many(boxes, rects, radius, strip)
+        for i, (box, rect) in enumerate(zip(boxes, rects)):
+            want = windows_for(box, rect, radius, strip)
+            assert bool(keep[i]) == (want is not None)
+            if want is not None:
+                assert tuple(area[i]) == want[0] and tuple(window[i]) == want[1], (box, rect, radius)
