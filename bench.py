@@ -11,9 +11,12 @@ reference algorithm warps and blends ("P") / step time.
 
 Workload (BASELINE.json): the metric is quoted on N x 4K frames, so the default
 is config 3 - 32 synthetic 3840x2160 frames, 5 deg yaw steps, hfov 60 deg,
-native resolution, 5 levels - on however many GPUs are given (strong scaling:
-frames are split into contiguous blocks, one block per rank).  ``--workload
-cfg2`` runs the 8 x 1080p configuration instead.
+native resolution, 5 levels.  With N GPUs a step stitches N such image sets,
+one per GPU (independent panoramas: weak scaling, no data-path collective);
+the same launch then also times ONE image set split into column strips over
+the N GPUs (strong scaling, strips gathered over RCCL) and reports it under
+"strips".  ``--mode strips`` makes that the headline instead; ``--workload
+cfg2`` runs the 8 x 1080p configuration.
 
 Prints ONE JSON line on rank 0.
 """
@@ -40,6 +43,13 @@ def parse():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="cfg3", choices=["cfg2", "cfg3", "cfg5", "tiny"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--mode", default="sets", choices=["sets", "strips"],
+                    help="N > 1: 'sets' = one independent image set per GPU and step "
+                         "(default, weak scaling); 'strips' = one image set, its mosaic "
+                         "split into column strips (strong scaling)")
+    ap.add_argument("--no-strips", action="store_true",
+                    help="N > 1, mode sets: skip the secondary column-strip measurement")
+    ap.add_argument("--strips-timeout", type=float, default=120.0)
     return ap.parse_args()
 
 
@@ -151,10 +161,28 @@ def cpu_baseline(cfg):
                        f"oracle/pano_oracle.c (gcc -O2 -fopenmp), {os.cpu_count()} host CPUs")
 
 
+def timed_steps(eng, step, steps, warmup, fence):
+    """W untimed steps, then exactly K steps between two fences.  Returns
+    (seconds on this rank, last step's result, per-kernel HIP-event times)."""
+    for _ in range(warmup):
+        step()
+    fence()
+    eng.lib.pano_timing_enable(1)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        result = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    times = kernel_times(eng.lib)
+    eng.lib.pano_timing_enable(0)
+    return elapsed, result, times
+
+
 def main():
     args = parse()
     import torch
-    from pano360_amd import _lib, engine, synth
+    from pano360_amd import dist as pdist
+    from pano360_amd import engine, synth
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -182,31 +210,39 @@ def main():
                                      step_deg=cfg.get("step_deg"))
     shapes = [(cfg["height"], cfg["width"])] * cfg["n"]
     eng = engine.Engine(f"cuda:{local}")
+    reduce_device = eng.device if backend == "nccl" else "cpu"
 
-    if world > 1:
-        from pano360_amd import dist as pdist
-        runner = pdist.ShardedStitcher(eng, shapes, rots, intrs, n_levels, rank, world)
-        mine = runner.my_frames
-    else:
-        runner = None
-        mine = range(cfg["n"])
-    frames = [eng.upload_frames([synth.make_frame(i, cfg["width"], cfg["height"], "A")])[0]
-              for i in mine]             # one frame at a time: 120 x 8K is 12 GB
-
-    def step():
-        if runner is not None:
-            return runner.step(frames)
-        plan = engine.Plan(shapes, rots, intrs, True, NATIVE)
-        mosaic, _, _, patches = eng.stitch(frames, plan, "multiband", n_levels)
-        # keep only the window geometry: holding the arenas across steps would make
-        # the allocator carve out fresh gigabytes every step
-        return plan, mosaic, list(patches)
+    def upload(set_id, which):      # one frame at a time: 120 x 8K is 12 GB
+        return [eng.upload_frames([synth.make_frame(set_id * cfg["n"] + i, cfg["width"],
+                                                    cfg["height"], "A")])[0] for i in which]
 
     def fence():
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
             torch.cuda.synchronize()
+
+    strips = args.mode == "strips" and world > 1
+    if strips:
+        # ONE panorama (image set 0) split into column strips, one per rank; the
+        # finished strips are gathered on rank 0 (strong scaling)
+        runner = pdist.ShardedStitcher(eng, shapes, rots, intrs, n_levels, rank, world)
+        frames = upload(0, runner.my_frames)
+
+        def step():
+            return runner.step(frames)
+    else:
+        # one image set per rank and step (rank r holds set r): the sets of a step
+        # are independent panoramas, nothing crosses a GPU (weak scaling)
+        my_set = pdist.assign_sets(world, rank, world)[0]
+        frames = upload(my_set, range(cfg["n"]))
+
+        def step():
+            plan = engine.Plan(shapes, rots, intrs, True, NATIVE)
+            mosaic, _, _, patches = eng.stitch(frames, plan, "multiband", n_levels)
+            # keep only the window geometry: holding the arenas across steps would make
+            # the allocator carve out fresh gigabytes every step
+            return plan, mosaic, list(patches)
 
     for _ in range(3):            # setup: first-touch allocations of the workspaces
         step()
@@ -217,53 +253,55 @@ def main():
     import gc
     gc.collect()
     gc.freeze()
-    for _ in range(args.warmup):
-        step()
-    fence()
-    eng.lib.pano_timing_enable(1)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        plan, mosaic, patches = step()
-    fence()
-    elapsed = time.perf_counter() - t0
-    times = kernel_times(eng.lib)
-    eng.lib.pano_timing_enable(0)
-    if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64,
-                          device=eng.device if backend == "nccl" else "cpu")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = tt.item()
+    elapsed, (plan, mosaic, patches), times = timed_steps(eng, step, args.steps, args.warmup,
+                                                          fence)
+    elapsed = pdist.max_over_ranks(elapsed, reduce_device)
+    sets_per_step = 1 if strips else world
 
+    out = None
     if rank == 0:
         ms = elapsed / args.steps * 1e3
         P, M = plan.patch_pixels, plan.shape[0] * plan.shape[1]
         S = cfg["n"] * cfg["width"] * cfg["height"]
-        algo_bytes = 3.0 * S + (33 + 64 * n_levels) * P + (16 * n_levels + 3) * M
+        algo_bytes = sets_per_step * (3.0 * S + (33 + 64 * n_levels) * P
+                                      + (16 * n_levels + 3) * M)
+        if strips:
+            how = (f"one image set per step, its mosaic split into {world} column strips "
+                   f"(one per GPU), finished uint8 strips gathered on rank 0 over RCCL")
+        elif world > 1:
+            how = (f"{world} independent image sets per step, one per GPU, no data-path "
+                   f"collective (the column-strip split of ONE mosaic is timed under 'strips')")
+        else:
+            how = "one image set per step on one GPU"
         out = {
             "metric": "blended megapixels/sec (multiband)",
-            "value": P / (ms * 1e-3) / 1e6,
+            "value": sets_per_step * P / (ms * 1e-3) / 1e6,
             "unit": "MP/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms,
             "higher_is_better": True,
-            "scaling": "strong",
+            "scaling": "strong" if strips else "weak",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
             "config": {
                 "workload": f"{args.workload}: {cfg['n']} synthetic {cfg['width']}x"
-                            f"{cfg['height']} frames, spherical warp + multiband blend "
-                            f"L={n_levels}, native resolution (MAX_RESOLUTION uncapped)",
+                            f"{cfg['height']} frames per image set, spherical warp + "
+                            f"multiband blend L={n_levels}, native resolution "
+                            f"(MAX_RESOLUTION uncapped)",
+                "image_sets_per_step": sets_per_step,
                 "frames": cfg["n"], "mosaic": list(plan.shape),
                 "patch_megapixels": P / 1e6, "source_megapixels": S / 1e6,
                 "mosaic_megapixels": M / 1e6,
-                "parallelism": f"frames sharded in contiguous blocks over {world} GPU(s)",
+                "parallelism": how,
             },
             "pipeline": {
                 "algorithmic_GB_per_step": algo_bytes / 1e9,
                 "algorithmic_GBps": algo_bytes / (ms * 1e-3) / 1e9,
-                "frac_of_hbm_peak": algo_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-                "input_MPps": S / (ms * 1e-3) / 1e6, "mosaic_MPps": M / (ms * 1e-3) / 1e6,
+                "frac_of_hbm_peak_all_gpus": algo_bytes / (ms * 1e-3) / 1e9
+                                             / (HBM_PEAK_GBPS * world),
+                "input_MPps": sets_per_step * S / (ms * 1e-3) / 1e6,
+                "mosaic_MPps": sets_per_step * M / (ms * 1e-3) / 1e6,
             },
             "kernel_ms_per_step": {k: v[0] / args.steps for k, v in sorted(times.items())},
             "roofline": roofline_for(times, plan, patches, n_levels, args.steps,
@@ -276,7 +314,49 @@ def main():
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(cfg)
-        print(json.dumps(out))
+
+    if world > 1 and not strips and not args.no_strips:
+        # Secondary measurement, same launch: ONE panorama over all GPUs (latency mode).
+        # It is the only part of this program with a data exchange, so a watchdog makes
+        # sure the headline line above is printed whatever happens here.
+        import threading
+
+        def give_up():
+            if rank == 0:
+                out["strips"] = {"error": f"no result within {args.strips_timeout} s"}
+                print(json.dumps(out), flush=True)
+            os._exit(0)
+
+        dog = threading.Timer(args.strips_timeout, give_up)
+        dog.daemon = True
+        dog.start()
+        try:
+            runner = pdist.ShardedStitcher(eng, shapes, rots, intrs, n_levels, rank, world)
+            sframes = upload(0, runner.my_frames)
+            for _ in range(3):
+                runner.step(sframes)
+            fence()
+            s_elapsed, (splan, _, _), s_times = timed_steps(
+                eng, lambda: runner.step(sframes), args.steps, args.warmup, fence)
+            s_elapsed = pdist.max_over_ranks(s_elapsed, reduce_device)
+            if rank == 0:
+                s_ms = s_elapsed / args.steps * 1e3
+                out["strips"] = {
+                    "what": f"one {cfg['n']}-frame image set per step, mosaic split into "
+                            f"{world} column strips, uint8 strips gathered on rank 0 "
+                            f"({backend}); strong scaling",
+                    "ms_per_step": s_ms,
+                    "value": splan.patch_pixels / (s_ms * 1e-3) / 1e6, "unit": "MP/s",
+                    "frames_on_rank0": len(runner.my_frames),
+                    "kernel_ms_per_step_rank0": {k: v[0] / args.steps
+                                                 for k, v in sorted(s_times.items())}}
+        except Exception as err:       # noqa: BLE001 - reported, the headline stands
+            if rank == 0:
+                out["strips"] = {"error": repr(err)[:300]}
+        dog.cancel()
+
+    if rank == 0:
+        print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
 

@@ -1,4 +1,14 @@
-"""Multi-GPU stitching: one process per GPU, the mosaic split into column strips.
+"""Multi-GPU stitching: one process per GPU.
+
+Two ways to use N GPUs, both driven by ``bench.py --gpus N``:
+
+* **image sets** (throughput; ``assign_sets``): a stitching service sees a stream of
+  independent image sets (one panorama per time step of a camera rig).  Sets are
+  dealt out round-robin, every rank stitches its own sets with the single-GPU path
+  and nothing crosses a GPU - the path partitions by object, so there is no
+  data-path collective (weak scaling: per-GPU work is fixed as N grows).
+* **column strips** (latency of ONE panorama; ``ShardedStitcher``): the mosaic is
+  split into column strips, described below.
 
 The reference is single-process; this is new design.  What
 shards: the *mosaic*, by columns.  Rank r produces columns [c_r, c_{r+1}) of
@@ -17,6 +27,23 @@ neighbouring ranks both hold the few frames that straddle their boundary.
 """
 
 from . import engine as _eng
+
+
+def assign_sets(n_sets, rank, world):
+    """Indices of the image sets rank ``rank`` stitches: round-robin, so that a
+    stream of sets keeps every GPU equally busy whatever its length."""
+    return list(range(rank, n_sets, world))
+
+
+def max_over_ranks(seconds, device="cpu", group=None):
+    """The slowest rank's time: what a job that waits for every rank took."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return float(seconds)
+    t = torch.tensor([float(seconds)], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    return t.item()
 
 
 def strip_bounds(width, world):

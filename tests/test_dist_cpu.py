@@ -40,9 +40,12 @@ def _worker(rank, world, port, H, W, result):
         else:
             assert full is None
         # max-over-ranks timing reduction used by bench.py
-        t = torch.tensor([float(rank + 1)], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        assert t.item() == world
+        assert pdist.max_over_ranks(float(rank + 1)) == world
+        # image sets of a stream, dealt out over the ranks: each set exactly once
+        mine = torch.zeros(7, dtype=torch.int64)
+        mine[pdist.assign_sets(7, rank, world)] = 1
+        dist.all_reduce(mine)
+        assert mine.tolist() == [1] * 7
     finally:
         dist.destroy_process_group()
 
@@ -102,3 +105,12 @@ def test_windows_for_strip_clipping():
     assert engine.windows_for(box, rect, 43, strip=(0, 1057)) is None
     area, _ = engine.windows_for(box, rect, 43, strip=(0, 1058))
     assert area == (0, 100, 57, 58)
+
+
+def test_assign_sets_round_robin():
+    for n_sets in (0, 1, 8, 13):
+        for world in (1, 2, 8):
+            got = [pdist.assign_sets(n_sets, r, world) for r in range(world)]
+            assert sorted(i for g in got for i in g) == list(range(n_sets))
+            assert max(map(len, got)) - min(map(len, got)) <= 1
+    assert pdist.max_over_ranks(1.25) == 1.25          # no process group: identity
