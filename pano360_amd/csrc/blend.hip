@@ -316,17 +316,15 @@ __global__ __launch_bounds__(256) void blend_cameras_kernel(
         if (map_pixel(cam->proj, s, c, t, sw, sh_, fx, fy)) continue;
         any = true;
         const Taps tp = make_taps(fx, fy, sw, sh_);
-        const uint8_t *__restrict__ frame = cam->frame;
-        const uint8_t *r0 = frame + (size_t)tp.y0 * sw * 3, *r1 = frame + (size_t)tp.y1 * sw * 3;
-        const uint8_t *p00 = r0 + tp.x0 * 3, *p01 = r0 + tp.x1 * 3;
-        const uint8_t *p10 = r1 + tp.x0 * 3, *p11 = r1 + tp.x1 * 3;
+        const TapBytes tb = load_taps(cam->frame, sw, tp);
         float rgb[3];
         const float *__restrict__ gl = lut + (size_t)i * 256;
 #pragma unroll
         for (int ch = 0; ch < 3; ++ch)
-            rgb[ch] = PERCAM ? lerp4(gl[p00[ch]], gl[p01[ch]], gl[p10[ch]], gl[p11[ch]], tp)
-                             : lerp4(s_lut[p00[ch]], s_lut[p01[ch]], s_lut[p10[ch]],
-                                     s_lut[p11[ch]], tp);
+            rgb[ch] = PERCAM ? lerp4(gl[tb.v[0][ch]], gl[tb.v[1][ch]], gl[tb.v[2][ch]],
+                                     gl[tb.v[3][ch]], tp)
+                             : lerp4(s_lut[tb.v[0][ch]], s_lut[tb.v[1][ch]], s_lut[tb.v[2][ch]],
+                                     s_lut[tb.v[3][ch]], tp);
         if (LINEAR) {
             const float a = alpha_at(cam->hat_x, cam->hat_y, tp);
 #pragma unroll
@@ -493,15 +491,14 @@ __global__ __launch_bounds__(256) void multiband_compose_kernel(
         float fx, fy;
         map_pixel(cam->proj, ia.sin_t[x], ia.cos_t[x], ia.tan_p[y], sw, sh, fx, fy);
         const Taps tp = make_taps(fx, fy, sw, sh);
-        const uint8_t *__restrict__ frame = cam->frame;
-        const uint8_t *r0 = frame + (size_t)tp.y0 * sw * 3, *r1 = frame + (size_t)tp.y1 * sw * 3;
-        const uint8_t *p00 = r0 + tp.x0 * 3, *p01 = r0 + tp.x1 * 3;
-        const uint8_t *p10 = r1 + tp.x0 * 3, *p11 = r1 + tp.x1 * 3;
+        const TapBytes tb = load_taps(cam->frame, sw, tp);
         const size_t g = ((size_t)y * W + x) * 3;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            float v = PERCAM ? lerp4(gl[p00[c]], gl[p01[c]], gl[p10[c]], gl[p11[c]], tp)
-                             : lerp4(s_lut[p00[c]], s_lut[p01[c]], s_lut[p10[c]], s_lut[p11[c]], tp);
+            float v = PERCAM ? lerp4(gl[tb.v[0][c]], gl[tb.v[1][c]], gl[tb.v[2][c]],
+                                     gl[tb.v[3][c]], tp)
+                             : lerp4(s_lut[tb.v[0][c]], s_lut[tb.v[1][c]], s_lut[tb.v[2][c]],
+                                     s_lut[tb.v[3][c]], tp);
             v = v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v);
             if (mosaic_f32) mosaic_f32[g + c] = v;
             mosaic[g + c] = (uint8_t)(int)(255.0f * v);

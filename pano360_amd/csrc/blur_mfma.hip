@@ -128,7 +128,7 @@ __device__ __forceinline__ MbGeom mb_geom(const pano_patch &p) {
 template <int C>
 __device__ __forceinline__ void mb_colpass(f32x16 (&acc)[2 * ((C + 1) / 2) + 1], const f32x16 &mid,
                                            const half8 *s_ty, const unsigned inf,
-                                           const int lane, const int u) {
+                                           const int lane, const int u, const int r) {
     constexpr int DMAX = (C + 1) / 2, NB = 2 * DMAX + 1;
     // Mid as the B operand: registers 8s..8s+7 are k-step s
     half8 m_hi[2], m_lo[2];
@@ -149,6 +149,9 @@ __device__ __forceinline__ void mb_colpass(f32x16 (&acc)[2 * ((C + 1) / 2) + 1],
         const half8 *ty = s_ty + (d + DMAX) * 4 * 64 + lane;        // [d][s][hi, lo][lane]
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
+            // Toeplitz block (d, s) holds tap[32 d + k - m + r], k in [16 s, 16 s + 16),
+            // m in [0, 32): all zeros when the whole block lies beyond the radius
+            if (32 * d + 16 * s - 31 > r || 32 * d + 16 * s + 15 < -r) continue;   // uniform
             const half8 t_hi = ty[(s * 2) * 64];
             const half8 t_lo = ty[(s * 2 + 1) * 64];
             acc[k] = __builtin_amdgcn_mfma_f32_32x32x16_f16(t_hi, m_hi[s], acc[k], 0, 0, 0);
@@ -216,7 +219,8 @@ template <int C>
 __device__ __forceinline__ void mb_body(const pano_patch &p, const int ch, const int level,
                                         const bool live, const half8 *s_tx,
                                         const half8 *s_ty, const MbShared &sh,
-                                        const int16_t *__restrict__ owner_, const int W) {
+                                        const int16_t *__restrict__ owner_, const int W,
+                                        const int r) {
     constexpr int KS = 2 + 2 * C, DMAX = (C + 1) / 2, NB = 2 * DMAX + 1;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, n = lane & 31, h = lane >> 5;
     const int tile = wv & 1;
@@ -380,7 +384,7 @@ __device__ __forceinline__ void mb_body(const pano_patch &p, const int ch, const
             }
             int u = t % NB;
             if (u < 0) u += NB;
-            mb_colpass<C>(acc, mid, s_ty, inf, lane, u);
+            mb_colpass<C>(acc, mid, s_ty, inf, lane, u, r);
         }
         // bands up to the next wanted one only complete tiles
         const int upto = t1 < my_hi + 1 ? t1 : my_hi + 1;
@@ -534,14 +538,14 @@ __global__ __launch_bounds__(MB_THREADS, 1) void blur_mfma_kernel(
     __syncthreads();
     const half8 *s_tx = (const half8 *)(smem + my_tx), *s_ty = (const half8 *)(smem + my_ty);
 #ifdef MB_ONLY
-    mb_body<MB_ONLY>(p, ch, level, live, s_tx, s_ty, sh, owner, W);
+    mb_body<MB_ONLY>(p, ch, level, live, s_tx, s_ty, sh, owner, W, ntaps >> 1);
     return;
 #endif
     switch (c) {                                         // wave-uniform
-        case 1: mb_body<1>(p, ch, level, live, s_tx, s_ty, sh, owner, W); break;
-        case 2: mb_body<2>(p, ch, level, live, s_tx, s_ty, sh, owner, W); break;
-        case 3: mb_body<3>(p, ch, level, live, s_tx, s_ty, sh, owner, W); break;
-        default: mb_body<4>(p, ch, level, live, s_tx, s_ty, sh, owner, W); break;
+        case 1: mb_body<1>(p, ch, level, live, s_tx, s_ty, sh, owner, W, ntaps >> 1); break;
+        case 2: mb_body<2>(p, ch, level, live, s_tx, s_ty, sh, owner, W, ntaps >> 1); break;
+        case 3: mb_body<3>(p, ch, level, live, s_tx, s_ty, sh, owner, W, ntaps >> 1); break;
+        default: mb_body<4>(p, ch, level, live, s_tx, s_ty, sh, owner, W, ntaps >> 1); break;
     }
 }
 

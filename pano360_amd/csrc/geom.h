@@ -38,6 +38,51 @@ __device__ __forceinline__ float lerp4(float v00, float v01, float v10, float v1
     return a;
 }
 
+// The four taps' uint8 RGB triples.  Away from the frame border the two taps of a
+// row are neighbours (x1 == x0 + 1): their six bytes are fetched with one 4-byte and
+// one 2-byte load (any alignment) instead of six byte loads - the sampling kernels are
+// bound by the number of memory instructions, not by bytes.
+struct TapBytes {
+    uint32_t v[4][3];               // [tap 00, 01, 10, 11][channel]
+};
+typedef uint32_t u32_any __attribute__((aligned(1)));
+typedef uint16_t u16_any __attribute__((aligned(1)));
+// a frame pointer taken out of a camera record is generic to the compiler (flat_load);
+// frames live in global memory
+typedef const __attribute__((address_space(1))) uint8_t *frame_ptr;
+typedef const __attribute__((address_space(1))) u32_any *frame_ptr32;
+typedef const __attribute__((address_space(1))) u16_any *frame_ptr16;
+
+__device__ __forceinline__ TapBytes load_taps(const uint8_t *__restrict__ frame, int sw,
+                                              const Taps &tp) {
+    TapBytes t;
+    const frame_ptr base = (frame_ptr)frame;
+    const frame_ptr rows[2] = {base + (size_t)tp.y0 * sw * 3, base + (size_t)tp.y1 * sw * 3};
+    const bool pair = tp.x1 == tp.x0 + 1;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const frame_ptr a = rows[r] + tp.x0 * 3;
+        if (pair) {
+            const uint32_t lo = *(frame_ptr32)a;
+            const uint32_t hi = *(frame_ptr16)(a + 4);
+            t.v[2 * r][0] = lo & 255u;
+            t.v[2 * r][1] = (lo >> 8) & 255u;
+            t.v[2 * r][2] = (lo >> 16) & 255u;
+            t.v[2 * r + 1][0] = lo >> 24;
+            t.v[2 * r + 1][1] = hi & 255u;
+            t.v[2 * r + 1][2] = hi >> 8;
+        } else {
+            const frame_ptr b = rows[r] + tp.x1 * 3;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                t.v[2 * r][k] = a[k];
+                t.v[2 * r + 1][k] = b[k];
+            }
+        }
+    }
+    return t;
+}
+
 // ray = (sin theta, tan phi, cos theta); pixel = K R ray in double as an FMA
 // chain over k, rounded to float32, divided and centred in float32 (:303-310);
 // mask = behind the camera or outside [0, w-1] x [0, h-1] (:308, :311-312).

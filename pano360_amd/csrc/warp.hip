@@ -83,17 +83,13 @@ __global__ __launch_bounds__(256) void warp_windows_kernel(
     float px, py;
     map_pixel(cam->proj, sin_t[gx], cos_t[gx], tan_p[gy], sw, sh, px, py);
     const Taps tp = make_taps(px, py, sw, sh);
-    const uint8_t *__restrict__ frame = cam->frame;
-    const uint8_t *r0 = frame + (size_t)tp.y0 * sw * 3;
-    const uint8_t *r1 = frame + (size_t)tp.y1 * sw * 3;
-    const uint8_t *p00 = r0 + tp.x0 * 3, *p01 = r0 + tp.x1 * 3;
-    const uint8_t *p10 = r1 + tp.x0 * 3, *p11 = r1 + tp.x1 * 3;
+    const TapBytes tb = load_taps(cam->frame, sw, tp);
     const size_t plane = (size_t)p.vh * p.vpitch;
     const size_t o = (size_t)y * p.vpitch + x;
 #pragma unroll
     for (int k = 0; k < 3; ++k)
-        p.planes[k * plane + o] =
-            lerp4(s_lut[p00[k]], s_lut[p01[k]], s_lut[p10[k]], s_lut[p11[k]], tp);
+        p.planes[k * plane + o] = lerp4(s_lut[tb.v[0][k]], s_lut[tb.v[1][k]], s_lut[tb.v[2][k]],
+                                        s_lut[tb.v[3][k]], tp);
 }
 
 __global__ __launch_bounds__(256) void add_weights_kernel(
