@@ -338,6 +338,38 @@ int pano_decimate2(const float *src, int h, int w, float *dst, void *stream);
 int pano_subtract(const float *a, const float *b, size_t n, float *out,
                   void *stream);
 
+/* Decimated Laplacian-pyramid blending of two images     blend.py:105-140
+ * (blend.laplacian_blending: cv2.pyrDown / cv2.pyrUp pyramids of two float32
+ * images and a float64 mask, la*gm + lb*(1-gm) per level in float64, collapse,
+ * clip, uint8).  Images are interleaved [h][w][c], c <= 4, dense; is_f64 selects
+ * double (the mask and everything after the mix) or float (the image pyramids).
+ * OpenCV's pyrDown / pyrUp restated, parity unpinned (csrc/laplacian.hip).
+ *   pano_pyr_down_image  cv2.pyrDown: [h][w][c] -> [(h+1)/2][(w+1)/2][c]
+ *   pano_pyr_up_image    cv2.pyrUp(src)[:oh, :ow] (blend.py:126,138), combined with
+ *                        `other` [oh][ow][c]: mode 0 = the up-sampled image,
+ *                        1 = other - up (a Laplacian level), 2 = other + up (collapse)
+ *   pano_u8_to_f32       img.astype("float32")                        blend.py:132-133
+ *   pano_laplacian_mix   out = la*gm + lb*(1.0 - gm), float64           blend.py:136
+ *   pano_clip_u8         np.clip(x, 0, 255).astype("uint8")             blend.py:140 */
+int pano_pyr_down_image(const void *src, int h, int w, int c, int is_f64, void *dst,
+                        void *stream);
+int pano_pyr_up_image(const void *src, int sh, int sw, int c, int is_f64,
+                      const void *other, int mode, void *dst, int oh, int ow,
+                      void *stream);
+int pano_u8_to_f32(const uint8_t *src, size_t n, float *dst, void *stream);
+int pano_laplacian_mix(const float *la, const float *lb, const double *gm, size_t n,
+                       double *out, void *stream);
+int pano_clip_u8(const double *src, size_t n, uint8_t *dst, void *stream);
+
+/* cv2.resize(im, None, fx=1/shrink, fy=1/shrink) on a uint8 image   stitcher.py:419-420
+ * (INTER_LINEAR, OpenCV's 8-bit fixed-point path restated; parity unpinned).
+ * xtab / ytab: dev int32 [ow][4] / [oh][4] = (first tap, second tap, coefficient of
+ * the first, of the second; 11-bit fixed point), built by the host exactly as the
+ * oracle builds them.  Both NULL: the exact 2:1 reduction, which cv2.resize takes by
+ * rounded 2 x 2 box means (sh == 2 oh, sw == 2 ow). */
+int pano_resize_u8(const uint8_t *src, int sh, int sw, int c, const int32_t *xtab,
+                   const int32_t *ytab, uint8_t *dst, int oh, int ow, void *stream);
+
 /* Keypoints and descriptors of SIFT_create().detectAndCompute  features.py:192-198
  * (the arithmetic lives in OpenCV's xfeatures2d/sift.cpp, restated with the
  * SIFT_create() defaults; parity unpinned).  The scale space comes from the

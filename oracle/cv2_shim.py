@@ -297,26 +297,119 @@ def GaussianBlur(src, ksize, sigmaX, sigmaY=0, borderType=BORDER_DEFAULT):
     return sep_filter_symm(src, getGaussianKernel(kx, sigmaX), borderType)
 
 
+def _pyr_dtype(src):
+    """pyrDown / pyrUp keep CV_32F and CV_64F (working type = the same type)."""
+    src = np.asarray(src)
+    if src.dtype not in (np.float32, np.float64):
+        raise NotImplementedError(f"pyramids of {src.dtype} are never requested by the path")
+    return np.ascontiguousarray(src), src.dtype.type
+
+
 def pyrDown(src):
     """``cv2.pyrDown``: 5x5 separable [1 4 6 4 1]/16 (x1/256 overall),
     REFLECT_101, keep even rows/cols, output ((w+1)//2, (h+1)//2).
     Float path assumed: ``c*6 + (l1+r1)*4 + l2 + r2`` (left to right) along
-    rows, the same along columns, scaled by 1/256 at the end."""
-    src = np.ascontiguousarray(src, dtype=np.float32)
+    rows, the same along columns, scaled by 1/256 at the end.  float32 and
+    float64 images keep their type (blend.py:113-117 feeds it a float64 mask)."""
+    src, ft = _pyr_dtype(src)
     h, w = src.shape[:2]
     oh, ow = (h + 1) // 2, (w + 1) // 2
-    f32 = np.float32
     cx = border_interpolate(np.arange(-2, 2 * ow + 2), w, BORDER_REFLECT_101)
     p = src[:, cx]
     c = np.arange(ow) * 2
-    row = (p[:, c + 2] * f32(6) + (p[:, c + 1] + p[:, c + 3]) * f32(4)
+    row = (p[:, c + 2] * ft(6) + (p[:, c + 1] + p[:, c + 3]) * ft(4)
            + p[:, c] + p[:, c + 4])
     ry = border_interpolate(np.arange(-2, 2 * oh + 2), h, BORDER_REFLECT_101)
     q = row[ry]
     r_ = np.arange(oh) * 2
-    out = (q[r_ + 2] * f32(6) + (q[r_ + 1] + q[r_ + 3]) * f32(4)
+    out = (q[r_ + 2] * ft(6) + (q[r_ + 1] + q[r_ + 3]) * ft(4)
            + q[r_] + q[r_ + 4])
-    return out * f32(1.0 / 256.0)
+    return out * ft(1.0 / 256.0)
+
+
+def pyrUp(src):
+    """``cv2.pyrUp`` to the default size (2w, 2h): zero-stuffed source filtered with
+    [1 4 6 4 1]/8 per axis (x1/64 overall).  Per axis, from source samples s:
+    even outputs ``s[i-1] + s[i]*6 + s[i+1]``, odd outputs ``(s[i] + s[i+1])*4``;
+    at the first sample ``s[-1] := s[1]`` (REFLECT_101), past the last one
+    ``s[n] := s[n-1]``.  Rows first (OpenCV's pyrUp_ writes the two edge pairs of a row
+    in closed form: ``s[0]*6 + s[1]*2``, ``s[n-2] + s[n-1]*7``, ``s[n-1]*8``), then columns
+    (three buffered rows chosen by borderInterpolate), scaled by 1/64 at the end."""
+    src, ft = _pyr_dtype(src)
+    h, w = src.shape[:2]
+    if h < 2 or w < 2:
+        raise NotImplementedError("pyrUp of a one-pixel-wide image is never requested")
+
+    def up(a, axis, edge_forms):
+        a = np.moveaxis(a, axis, 0)
+        n = a.shape[0]
+        prev = a[np.r_[1, 0:n - 1]]              # s[-1] := s[1]
+        nxt = a[np.r_[1:n, n - 1]]               # s[n] := s[n-1]
+        even = prev + a * ft(6) + nxt
+        odd = (a + nxt) * ft(4)
+        if edge_forms:
+            # the row pass writes its first and last sample pairs in closed form; the
+            # column pass (rows picked by borderInterpolate) keeps the three-term sum
+            even[0] = a[0] * ft(6) + a[1] * ft(2)
+            even[n - 1] = a[n - 2] + a[n - 1] * ft(7)
+            odd[n - 1] = a[n - 1] * ft(8)
+        out = np.empty((2 * n,) + a.shape[1:], dtype=a.dtype)
+        out[0::2] = even
+        out[1::2] = odd
+        return np.moveaxis(out, 0, axis)
+
+    return up(up(src, 1, True), 0, False) * ft(1.0 / 64.0)
+
+
+INTER_AREA = 3
+
+
+def resize(src, dsize, fx=0.0, fy=0.0, interpolation=INTER_LINEAR):
+    """``cv2.resize`` of an 8-bit image by scale factors (stitcher.py:419-420 calls it
+    with ``dsize=None, fx=fy=1/shrink``), INTER_LINEAR.  OpenCV's 8-bit path, restated:
+
+    * output size ``cvRound(w * fx) x cvRound(h * fy)``; source coordinate of output d is
+      ``float((d + 0.5) / fx - 0.5)``, split into floor and fraction, clamped to the first /
+      last sample with fraction 0;
+    * coefficients in 11-bit fixed point (``cvRound(c * 2048)`` as int16), horizontal pass
+      ``s0*a0 + s1*a1`` in int32, vertical pass
+      ``((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2``;
+    * an exact 2:1 reduction is taken by the area path instead (``resize`` switches
+      INTER_LINEAR to INTER_AREA when both scales are exactly 2): rounded 2 x 2 box means.
+    """
+    src = np.ascontiguousarray(src)
+    if src.dtype != np.uint8 or dsize is not None or interpolation != INTER_LINEAR:
+        raise NotImplementedError("only the call of stitcher.py:419 is restated")
+    h, w = src.shape[:2]
+    ow, oh = int(np.rint(w * fx)), int(np.rint(h * fy))
+    sx_, sy_ = 1.0 / fx, 1.0 / fy
+    if abs(sx_ - 2.0) < np.finfo(float).eps and abs(sy_ - 2.0) < np.finfo(float).eps \
+            and w % 2 == 0 and h % 2 == 0:
+        a = src.astype(np.int32)
+        box = a[0::2, 0::2] + a[0::2, 1::2] + a[1::2, 0::2] + a[1::2, 1::2]
+        return ((box + 2) >> 2).astype(np.uint8)
+
+    def taps(n_out, n_in, scale):
+        f = ((np.arange(n_out) + 0.5) * scale - 0.5).astype(np.float32)
+        s = np.floor(f).astype(np.int64)
+        f = f - s.astype(np.float32)
+        f[s < 0] = 0
+        s[s < 0] = 0
+        f[s >= n_in - 1] = 0
+        s[s >= n_in - 1] = n_in - 1
+        c0 = np.rint((np.float32(1.0) - f) * np.float32(2048.0)).astype(np.int32)
+        c1 = np.rint(f * np.float32(2048.0)).astype(np.int32)
+        return s, np.minimum(s + 1, n_in - 1), c0, c1
+
+    x0, x1, a0, a1 = taps(ow, w, sx_)
+    y0, y1, b0, b1 = taps(oh, h, sy_)
+    a = src.astype(np.int32)
+    shape = (1, ow) + (1,) * (a.ndim - 2)
+    rows = a[:, x0] * a0.reshape(shape) + a[:, x1] * a1.reshape(shape)
+    shape = (oh,) + (1,) * (a.ndim - 1)
+    out = (((b0.reshape(shape) * (rows[y0] >> 4)) >> 16)
+           + ((b1.reshape(shape) * (rows[y1] >> 4)) >> 16) + 2) >> 2
+    return np.clip(out, 0, 255).astype(np.uint8)
 
 
 class _NoSift:

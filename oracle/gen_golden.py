@@ -315,9 +315,32 @@ def pure_fixture():
     print(f"pure: {os.path.getsize(path) / 1e6:.2f} MB")
 
 
+def laplacian_fixture():
+    """blend.laplacian_blending (blend.py:105-140) run from the reference on seeded
+    images: default sigmoid mask at 3 and 6 levels (odd sizes: the pyrUp crops of
+    blend.py:126,137 are exercised), and a caller-supplied one-channel float64 mask."""
+    import blend as ref_blend                       # the reference's
+    assert ref_blend.__file__.startswith(REF), ref_blend.__file__
+    out = {}
+    cases = {"a": (45, 70, 3, None), "b": (130, 203, 6, None), "c": (64, 96, 4, "ramp")}
+    for key, (h, w, levels, mask_kind) in cases.items():
+        img1 = synth.make_frame(100 + len(out), w, h, "B")
+        img2 = synth.make_frame(200 + len(out), w, h, "A")
+        mask = None
+        if mask_kind == "ramp":
+            yy, xx = np.mgrid[0:h, 0:w]
+            mask = (((xx + 0.5 * yy) / (w + 0.5 * h)) ** 2)[..., None].astype(np.float64)
+            out[f"{key}_mask"] = mask
+        out[f"{key}_img1"], out[f"{key}_img2"] = img1, img2
+        out[f"{key}_levels"] = np.int64(levels)
+        out[f"{key}_blended"] = ref_blend.laplacian_blending(img1, img2, mask, n_levels=levels)
+    np.savez_compressed(os.path.join(OUT, "laplacian.npz"), **out)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     jobs = {
+        "laplacian": laplacian_fixture,
         "pure": pure_fixture,
         "gains": lambda: np.savez_compressed(os.path.join(OUT, "gains.npz"),
                                              **gains_fixture()),

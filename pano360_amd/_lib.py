@@ -90,6 +90,12 @@ _SIGNATURES = {
     "pano_resize_up2": (_i, [_vp, _i, _i, _vp, _vp]),
     "pano_decimate2": (_i, [_vp, _i, _i, _vp, _vp]),
     "pano_subtract": (_i, [_vp, _vp, C.c_size_t, _vp, _vp]),
+    "pano_pyr_down_image": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
+    "pano_pyr_up_image": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _vp, _i, _i, _vp]),
+    "pano_u8_to_f32": (_i, [_vp, C.c_size_t, _vp, _vp]),
+    "pano_laplacian_mix": (_i, [_vp, _vp, _vp, C.c_size_t, _vp, _vp]),
+    "pano_clip_u8": (_i, [_vp, C.c_size_t, _vp, _vp]),
+    "pano_resize_u8": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _i, _i, _vp]),
     "pano_sift_extrema": (_i, [_vp, _i, _i, _i, _i, C.c_float, C.c_float, C.c_float, _vp, _vp, _i,
                                _vp]),
     "pano_sift_orient": (_i, [_vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _vp]),

@@ -2,7 +2,7 @@
 // (features.py:192-201: cv2.xfeatures2d.SIFT_create().detectAndCompute).
 // The arithmetic is inside OpenCV, not in the reference repository: OpenCV 3.4 / 4.x
 // xfeatures2d/src/sift.cpp is restated with the SIFT_create() defaults - parity
-// unpinned, checked against oracle/sift_oracle.py (an independent NumPy restatement).
+// unpinned, checked against the SIFT oracle under oracle/ (an independent NumPy restatement).
 //
 //   sift_extrema_kernel   findScaleSpaceExtrema + adjustLocalExtrema: one thread per DoG
 //                         pixel and layer; the 26-neighbour test first, the (rare) Newton

@@ -736,3 +736,66 @@ def test_full_size_properties_1080p(eng):
     lin, _, _, _ = eng.stitch(frames, plan_l, "linear")
     lin_staged, _, _, _ = eng.stitch(frames, plan_l, "linear", fused=False)
     assert torch.equal(lin, lin_staged)
+
+
+# ------------------------------------------------------------------ laplacian / ingest
+@pytest.mark.parametrize("case", ["a", "b", "c"])
+def test_laplacian_blending_matches_reference_golden(eng, case):
+    """blend.laplacian_blending on the GPU against the mosaic the reference produced."""
+    from pano360_amd import blend
+    g = load_golden("laplacian")
+    mask = g[f"{case}_mask"] if f"{case}_mask" in g else None
+    out = blend.laplacian_blending(g[f"{case}_img1"], g[f"{case}_img2"], mask,
+                                   int(g[f"{case}_levels"]))
+    assert out.dtype == np.uint8 and np.array_equal(out, g[f"{case}_blended"])
+
+
+def test_laplacian_pyramid_levels_bit_exact(eng):
+    """Every pyramid primitive against the oracle, float32 and float64, odd sizes,
+    1 to 4 channels; then a 1080p blend end to end."""
+    import torch
+    import cv2_shim as cv
+    import laplacian_oracle as lo
+    from pano360_amd import blend, synth
+    pyr = blend._Pyr(eng)
+    rng = np.random.default_rng(5)
+    for (h, w, c), dtype in [((37, 53, 3), np.float32), ((64, 64, 1), np.float64),
+                             ((4, 3, 4), np.float32), ((9, 130, 2), np.float64)]:
+        a = (rng.random((h, w, c)) * 255).astype(dtype)
+        dev = torch.from_numpy(a).to(eng.device)
+        down = pyr.down(dev)
+        ref_down = cv.pyrDown(a)
+        assert np.array_equal(down.cpu().numpy(), ref_down), (h, w, c, dtype)
+        up = pyr.up(down, dev, 0).cpu().numpy()
+        assert np.array_equal(up, cv.pyrUp(ref_down)[:h, :w]), (h, w, c, dtype)
+        lap = pyr.up(down, dev, 1).cpu().numpy()
+        assert np.array_equal(lap, a - cv.pyrUp(ref_down)[:h, :w])
+    img1 = synth.make_frame(1, 1920, 1080, "A")
+    img2 = synth.make_frame(2, 1920, 1080, "A")
+    assert np.array_equal(blend.laplacian_blending(img1, img2),
+                          lo.laplacian_blending(img1, img2))
+
+
+def test_laplacian_blending_argument_errors(eng):
+    from pano360_amd import blend
+    img = np.zeros((8, 8, 3), np.uint8)
+    with pytest.raises(ValueError):
+        blend.laplacian_blending(img, np.zeros((8, 9, 3), np.uint8))
+    with pytest.raises(ValueError):
+        blend.laplacian_blending(img, img, n_levels=6)            # 8 px cannot take 6 levels
+    with pytest.raises(NotImplementedError):
+        blend.laplacian_blending(img, img, np.ones((8, 8, 1), np.uint8), n_levels=1)
+
+
+@pytest.mark.parametrize("shrink", [2, 4, 3, 2.5, 1.5])
+def test_shrink_matches_resize_oracle(eng, shrink):
+    """The CLI's cv2.resize(im, None, fx=1/shrink, fy=1/shrink) (stitcher.py:419-420):
+    bit-exact against the restated 8-bit path, even and odd sizes."""
+    import laplacian_oracle as lo
+    from pano360_amd import blend
+    rng = np.random.default_rng(int(shrink * 10))
+    for h, w in ((270, 480), (135, 241), (64, 96)):
+        img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        got = blend.shrink_images([img], shrink)[0].cpu().numpy()
+        assert np.array_equal(got, lo.shrink(img, shrink)), (h, w, shrink)
+    assert blend.shrink_images([img], 1)[0].shape == img.shape

@@ -228,3 +228,50 @@ def test_sift_oracle_building_blocks():
     assert so.unpack_octave(255 | (2 << 8)) == (-1, 2, 2.0)
     des = so.root_sift(np.array([[4.0, 0.0, 12.0]]))
     np.testing.assert_allclose((des ** 2).sum(), 1.0, atol=1e-6)
+
+
+# ------------------------------------------------------------------ laplacian / resize
+@pytest.mark.parametrize("case", ["a", "b", "c"])
+def test_laplacian_oracle_reproduces_the_reference(case):
+    """blend.laplacian_blending run from the reference (gen_golden.py) against the
+    restatement the GPU tests use as their checker."""
+    import laplacian_oracle as lo
+    g = load_golden("laplacian")
+    mask = g[f"{case}_mask"] if f"{case}_mask" in g else None
+    out = lo.laplacian_blending(g[f"{case}_img1"], g[f"{case}_img2"], mask,
+                                int(g[f"{case}_levels"]))
+    assert out.dtype == np.uint8 and np.array_equal(out, g[f"{case}_blended"])
+
+
+def test_pyr_up_properties():
+    """pyrUp of a constant is that constant (the filter has unit gain, borders
+    included), the output is twice the input, float64 stays float64."""
+    import cv2_shim as cv
+    for dtype in (np.float32, np.float64):
+        const = np.full((5, 7, 3), 3.25, dtype)
+        up = cv.pyrUp(const)
+        assert up.shape == (10, 14, 3) and up.dtype == dtype and np.ptp(up) == 0 and up[0, 0, 0] == 3.25
+        assert np.ptp(cv.pyrDown(const)) == 0
+    rng = np.random.default_rng(0)
+    a = rng.random((6, 9)).astype(np.float32)
+    # linear in the image: exact for power-of-two factors
+    assert np.array_equal(cv.pyrUp(a * np.float32(4)), cv.pyrUp(a) * np.float32(4))
+
+
+def test_resize_u8_oracle_properties():
+    import cv2_shim as cv
+    rng = np.random.default_rng(1)
+    img = rng.integers(0, 256, (48, 64, 3), dtype=np.uint8)
+    half = cv.resize(img, None, fx=0.5, fy=0.5)
+    box = img.astype(int).reshape(24, 2, 32, 2, 3).sum(axis=(1, 3))
+    assert np.array_equal(half, (box + 2) >> 2)
+    # 4:1: source coordinate 4 d + 1.5 -> the mean of samples 4 d + 1 and 4 d + 2 per axis
+    quarter = cv.resize(img, None, fx=0.25, fy=0.25)
+    assert quarter.shape == (12, 16, 3)
+    mid = img.astype(float)
+    mid = (mid[:, 1::4] + mid[:, 2::4]) / 2
+    mid = (mid[1::4] + mid[2::4]) / 2
+    assert np.abs(quarter.astype(float) - mid).max() <= 1.0
+    flat = np.full((30, 50, 3), 201, np.uint8)
+    for shrink in (2, 3, 4, 2.5):
+        assert np.all(cv.resize(flat, None, fx=1 / shrink, fy=1 / shrink) == 201)
