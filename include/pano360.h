@@ -253,7 +253,11 @@ int pano_interior_map(const int16_t *owner, int H, int W, int xs0, int xs1,
  * interior (optional): pixels of interior blocks are not gathered; the owner's
  * frame (cams[owner].frame) is sampled there exactly as the warp samples it,
  * which needs cams, the trig tables and the colour tables (all NULL
- * otherwise). */
+ * otherwise).
+ * part: 0 = every pixel of the strip; 1 = the interior pixels only - they depend
+ * on the owner map and the frames, not on the patches (patches / valid may be
+ * NULL), so this part can be queued on another stream beside the warp and the
+ * blur; 2 = the remaining pixels only. */
 int pano_multiband_compose(const pano_patch *patches, int n, int H, int W,
                            int xs0, int xs1, int n_levels,
                            const int16_t *owner, const uint8_t *valid,
@@ -261,7 +265,7 @@ int pano_multiband_compose(const pano_patch *patches, int n, int H, int W,
                            const double *sin_t, const double *cos_t,
                            const double *tan_p, const float *lut,
                            int lut_stride, uint8_t *mosaic, float *mosaic_f32,
-                           void *stream);
+                           int part, void *stream);
 
 /* linear_blend (linear != 0) or no_blend (linear == 0) of the mosaic columns
  * [xs0, xs1) straight from the frames         stitcher.py:160-183 + :300-317

@@ -75,7 +75,7 @@ _SIGNATURES = {
                                  C.POINTER(C.c_int), _i, _vp, _vp, _vp]),
     "pano_interior_map": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "pano_multiband_compose": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp,
-                                    _vp, _vp, _i, _vp, _vp, _vp]),
+                                    _vp, _vp, _i, _vp, _vp, _i, _vp]),
     "pano_blend_cameras": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp,
                                 _vp]),
     "pano_blur_tile_grid": (_i, []),

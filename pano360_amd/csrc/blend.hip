@@ -468,7 +468,46 @@ struct InteriorArgs {
     const pano_camera *cams;
     const double *sin_t, *cos_t, *tan_p;
     const float *lut;            // [256], or [n][256] when PERCAM
+    int part;                    // 0 every pixel, 2 only the pixels the interior pass left
 };
+
+// The interior pixels alone (part 1 of the collapse): they need the owner map and the
+// frames, not the blurred planes, so this runs on a second stream beside the warp and the
+// blur.  Few registers on purpose: its waves fit on a CU next to the blur's workgroup.
+template <bool PERCAM>
+__global__ __launch_bounds__(256) void compose_interior_kernel(
+    int H, int W, int xs0, int xs1, const int16_t *__restrict__ owner,
+    uint8_t *__restrict__ mosaic, float *__restrict__ mosaic_f32, InteriorArgs ia) {
+    __shared__ float s_lut[256];
+    if (!PERCAM) {
+        s_lut[threadIdx.y * 64 + threadIdx.x] = ia.lut[threadIdx.y * 64 + threadIdx.x];
+        __syncthreads();
+    }
+    const int x = xs0 + blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+    if (x >= xs1 || y >= H) return;
+    if (!ia.interior[(size_t)(y / IB) * ia.W8 + x / IB]) return;
+    const int own = owner[(size_t)y * W + x];
+    const pano_camera *cam = ia.cams + own;
+    // queued before the host has checked which frames the strip needs: a camera whose
+    // frame is not resident is skipped here and reported by the caller
+    if (!cam->frame) return;
+    const float *__restrict__ gl = ia.lut + (size_t)own * 256;
+    const int sw = cam->sw, sh = cam->sh;
+    float fx, fy;
+    map_pixel(cam->proj, ia.sin_t[x], ia.cos_t[x], ia.tan_p[y], sw, sh, fx, fy);
+    const Taps tp = make_taps(fx, fy, sw, sh);
+    const TapBytes tb = load_taps(cam->frame, sw, tp);
+    const size_t g = ((size_t)y * W + x) * 3;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        float v = PERCAM ? lerp4(gl[tb.v[0][c]], gl[tb.v[1][c]], gl[tb.v[2][c]], gl[tb.v[3][c]], tp)
+                         : lerp4(s_lut[tb.v[0][c]], s_lut[tb.v[1][c]], s_lut[tb.v[2][c]],
+                                 s_lut[tb.v[3][c]], tp);
+        v = v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v);
+        if (mosaic_f32) mosaic_f32[g + c] = v;
+        mosaic[g + c] = (uint8_t)(int)(255.0f * v);
+    }
+}
 
 template <int L, bool PERCAM>
 __global__ __launch_bounds__(256) void multiband_compose_kernel(
@@ -484,6 +523,7 @@ __global__ __launch_bounds__(256) void multiband_compose_kernel(
     if (x >= xs1 || y >= H) return;
     if (ia.interior && ia.interior[(size_t)(y / IB) * ia.W8 + x / IB]) {
         // interior pixel: the mosaic is the owner's warped colour, clipped, quantised
+        if (ia.part == 2) return;                // compose_interior_kernel wrote it
         const int own = owner[(size_t)y * W + x];
         const pano_camera *cam = ia.cams + own;
         const float *__restrict__ gl = ia.lut + (size_t)own * 256;
@@ -793,9 +833,13 @@ extern "C" int pano_multiband_compose(const pano_patch *patches, int n, int H, i
                                       const double *sin_t, const double *cos_t,
                                       const double *tan_p, const float *lut,
                                       int lut_stride, uint8_t *mosaic, float *mosaic_f32,
-                                      void *stream) {
-    if (int rc = check_table(patches, n, H, W, "pano_multiband_compose")) return rc;
-    PANO_REQUIRE(owner && valid && mosaic, "pano_multiband_compose: null pointer");
+                                      int part, void *stream) {
+    PANO_REQUIRE(part >= 0 && part <= 2, "pano_multiband_compose: part %d outside 0..2", part);
+    PANO_REQUIRE(part == 0 || interior, "pano_multiband_compose: parts need the interior map");
+    if (part != 1)
+        if (int rc = check_table(patches, n, H, W, "pano_multiband_compose")) return rc;
+    PANO_REQUIRE(H > 0 && W > 0, "pano_multiband_compose: bad mosaic shape %dx%d", H, W);
+    PANO_REQUIRE(owner && mosaic && (valid || part == 1), "pano_multiband_compose: null pointer");
     PANO_REQUIRE(n_levels >= 1 && n_levels <= PANO_MAX_LEVELS,
                  "pano_multiband_compose: n_levels %d outside [1, %d]", n_levels, PANO_MAX_LEVELS);
     PANO_REQUIRE(xs0 >= 0 && xs1 <= W && xs0 <= xs1,
@@ -806,10 +850,22 @@ extern "C" int pano_multiband_compose(const pano_patch *patches, int n, int H, i
                  "pano_multiband_compose: lut_stride %d (0 = shared table, 256 = per camera)",
                  lut_stride);
     if (xs0 == xs1) return PANO_OK;
-    InteriorArgs ia = {interior, ceil_div(W, IB), cams, sin_t, cos_t, tan_p, lut};
+    InteriorArgs ia = {interior, ceil_div(W, IB), cams, sin_t, cos_t, tan_p, lut, part};
     const bool percam = interior && lut_stride != 0;
     dim3 block(64, 4), grid(ceil_div(xs1 - xs0, 64), ceil_div(H, 4));
     hipStream_t s = (hipStream_t)stream;
+    if (part == 1) {
+        if (percam)
+            PANO_TIMED(PK_COMPOSE_INTERIOR, s,
+                       hipLaunchKernelGGL(compose_interior_kernel<true>, grid, block, 0, s, H, W,
+                                          xs0, xs1, owner, mosaic, mosaic_f32, ia));
+        else
+            PANO_TIMED(PK_COMPOSE_INTERIOR, s,
+                       hipLaunchKernelGGL(compose_interior_kernel<false>, grid, block, 0, s, H, W,
+                                          xs0, xs1, owner, mosaic, mosaic_f32, ia));
+        PANO_LAUNCH_CHECK("compose_interior_kernel");
+        return PANO_OK;
+    }
 #define COMPOSE(L)                                                                      \
     case L:                                                                             \
         if (percam)                                                                     \

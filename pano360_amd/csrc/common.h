@@ -60,6 +60,7 @@ enum PanoKernelId {
     PK_SIFT_EXTREMA,
     PK_SIFT_ORIENT,
     PK_SIFT_DESCRIBE,
+    PK_COMPOSE_INTERIOR,
     PK_COUNT
 };
 extern bool g_pano_timing_on;

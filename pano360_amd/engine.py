@@ -9,6 +9,7 @@ resolution), :283-302 (mosaic shape, patch rectangles, angle grids), :218
 (level sigmas); OpenCV's getGaussianKernel for the taps (host, 33..97 floats).
 """
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -579,6 +580,9 @@ class Engine:
         self._hats = {}
         self._taps = {}
         self._region_bufs = {}
+        # second stream for the part of the collapse that needs no blurred planes
+        self.side = torch.cuda.Stream(self.device)
+        self.overlap_interior = os.environ.get("PANO_SIDE_STREAM", "1") != "0"
 
     # -- small cached tables ------------------------------------------------
     def stream(self):
@@ -717,8 +721,34 @@ class Engine:
             total += int((grid.astype(np.int64) * wy[:, None] * wx[None, :]).sum())
         return total
 
+    def compose_interior_async(self, owner, shape, strip, interior, cams, plan, luts,
+                               want_float=False):
+        """Part 1 of the collapse - the interior pixels, which need the owner map and
+        the frames only - queued on the side stream behind everything queued so far.
+        Returns (mosaic, float mosaic, event) for ``blur_and_compose(out=...)``."""
+        torch = _torch()
+        H, W = shape
+        main = torch.cuda.current_stream(self.device)
+        mosaic = torch.empty((H, W, 3), dtype=torch.uint8, device=self.device)
+        fl = (torch.empty((H, W, 3), dtype=torch.float32, device=self.device)
+              if want_float else None)
+        ready = torch.cuda.Event()
+        ready.record(main)
+        self.side.wait_event(ready)
+        for t in (mosaic, fl, owner, interior, cams):
+            if t is not None:
+                t.record_stream(self.side)
+        _lib.check(self.lib.pano_multiband_compose(
+            None, 0, H, W, strip[0], strip[1], 1, _ptr(owner), None, _ptr(interior), _ptr(cams),
+            _ptr(plan.dev[0]), _ptr(plan.dev[1]), _ptr(plan.dev[2]), *self._lut_args(luts),
+            _ptr(mosaic), _ptr(fl), 1, C.c_void_p(self.side.cuda_stream)),
+            "pano_multiband_compose")
+        done = torch.cuda.Event()
+        done.record(self.side)
+        return mosaic, fl, done
+
     def blur_and_compose(self, table, owner, valid, shape, n_levels, want_float=False,
-                         strip=None, interior=None, cams=None, plan=None, luts=None):
+                         strip=None, interior=None, cams=None, plan=None, luts=None, out=None):
         """All Gaussian levels of all patches (n_levels launches), then the gather
         over the mosaic columns ``strip`` (default: all of them).  With an
         ``interior`` map, blur tiles and gathers are skipped where the result is
@@ -735,15 +765,22 @@ class Engine:
                 _ptr(taps), ntaps, n_blur, _ptr(interior), _ptr(flags), self.stream()),
                 "pano_multiband_blur")
             self.last_tiles = (table, flags)        # for active_tile_pixels (reporting)
-        mosaic = torch.empty((H, W, 3), dtype=torch.uint8, device=self.device)
-        fl = (torch.empty((H, W, 3), dtype=torch.float32, device=self.device)
-              if want_float else None)
+        if out is None:
+            mosaic = torch.empty((H, W, 3), dtype=torch.uint8, device=self.device)
+            fl = (torch.empty((H, W, 3), dtype=torch.float32, device=self.device)
+                  if want_float else None)
+            part = 0
+        else:                       # the interior pixels are being written on the side stream
+            mosaic, fl, done = out
+            part = 2
         tabs = plan.dev if interior is not None else (None, None, None)
         _lib.check(self.lib.pano_multiband_compose(
             table.ptr, table.n, H, W, c0, c1, n_levels, _ptr(owner), _ptr(valid),
             _ptr(interior), _ptr(cams) if interior is not None else None, _ptr(tabs[0]),
             _ptr(tabs[1]), _ptr(tabs[2]), *self._lut_args(luts), _ptr(mosaic), _ptr(fl),
-            self.stream()), "pano_multiband_compose")
+            part, self.stream()), "pano_multiband_compose")
+        if out is not None:
+            torch.cuda.current_stream(self.device).wait_event(done)
         return mosaic, fl
 
     def simple_blend(self, patches, shape, linear, table=None):
@@ -908,6 +945,13 @@ class Engine:
         # while the host waits for the regions and lays out the windows.
         regions = self.owned_regions_async(owner, plan.n, ext, 2 * radius + 2)
         interior = self.interior_map(owner, radius, ext) if shortcut and n_blur else None
+        # The interior pixels of the mosaic need nothing but the owner map: queued now, on
+        # the side stream, they fill the GPU while the host waits for the regions and lays
+        # out the windows, and run beside the warp.  (Queued behind the warp instead they
+        # share the CUs with the blur and slow it by as much as they take: measured.)
+        early = (self.compose_interior_async(owner, plan.shape, (c0, c1), interior, cams, plan,
+                                             luts, want_float)
+                 if interior is not None and self.overlap_interior else None)
         raw = regions.raw().astype(np.int64)             # [n][5 + 2 max_spans]
         counts = raw[:, 4]
         index = np.repeat(np.arange(plan.n), counts)
@@ -929,7 +973,8 @@ class Engine:
             _ptr(plan.dev[1]), _ptr(plan.dev[2]), *self._lut_args(luts), self.stream()),
             "pano_warp_windows")
         mosaic, fl = self.blur_and_compose(table, owner, valid, plan.shape, n_levels,
-                                           want_float, (c0, c1), interior, cams, plan, luts)
+                                           want_float, (c0, c1), interior, cams, plan, luts,
+                                           out=early)
         return mosaic, fl, valid, patches
 
     def blend_fused(self, frames, plan, linear, frame_ids=None, strip=None, luts=None):
