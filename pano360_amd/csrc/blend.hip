@@ -242,6 +242,24 @@ __global__ __launch_bounds__(256) void ownership_cameras_kernel(
         ncand = sh.wave[0] + sh.wave[1] + sh.wave[2] + sh.wave[3];
         list = s_keep;
         __syncthreads();
+        // One survivor with a positive lower bound: its alpha is positive on every pixel
+        // of the tile and above every other camera's, so it owns the whole tile and no
+        // pixel needs evaluating - provided the tile lies inside its patch rectangle
+        // (outside it the camera is no candidate, stitcher.py:289-297).
+        if (ncand == 1 && L > 0.0f) {
+            const int i = s_keep[0];
+            const pano_camera *cam = cams + i;
+            if (bx0 >= cam->x0 && bx1 <= cam->x0 + cam->w && by0 >= cam->y0 &&
+                by1 <= cam->y0 + cam->h) {
+                const int x = bx0 + lane;
+                if (x < xs1)
+                    for (int y = by0 + wave; y < by1; y += 4) {
+                        owner[(size_t)y * W + x] = (int16_t)i;
+                        valid[(size_t)y * W + x] = 1;
+                    }
+                return;
+            }
+        }
     }
 
     const int x = bx0 + lane;

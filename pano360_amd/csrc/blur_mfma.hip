@@ -220,13 +220,13 @@ __device__ __forceinline__ void mb_body(const pano_patch &p, const int ch, const
                                         const bool live, const half8 *s_tx,
                                         const half8 *s_ty, const MbShared &sh,
                                         const int16_t *__restrict__ owner_, const int W,
-                                        const int r) {
+                                        const int r, const int tx0) {
     constexpr int KS = 2 + 2 * C, DMAX = (C + 1) / 2, NB = 2 * DMAX + 1;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, n = lane & 31, h = lane >> 5;
     const int tile = wv & 1;
     const bool alpha = ch == 3;
     const MbGeom g = mb_geom(p);
-    const int X0 = g.gx0 + MB_XT * (int)blockIdx.x;     // first output column of the workgroup
+    const int X0 = g.gx0 + 32 * tx0;                    // first output column of the workgroup
     const int px0 = X0 + 32 * tile;                     // ... of this wave
     const int BW = MB_XT + 32 * sh.CM, GPR = BW >> 3, NGRP = 32 * GPR;
 
@@ -447,17 +447,21 @@ __global__ __launch_bounds__(128) void mb_tables_kernel(MbLevels L, unsigned cha
 
 __global__ __launch_bounds__(MB_THREADS, 1) void blur_mfma_kernel(
     const pano_patch *__restrict__ table, MbLevels L, const unsigned char *__restrict__ tables,
-    const int16_t *__restrict__ owner, int W, const uint8_t *__restrict__ flags, int dbg) {
+    const int16_t *__restrict__ owner, int W, const uint8_t *__restrict__ flags,
+    const int2 *__restrict__ items, int dbg) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
-    // z = ((level group * records) + record) * 4 + channel
+    // x = (work item * level groups + level group) * 4 + channel; the items - (record, first
+    // tile column of a pair) - are sorted by decreasing length (mb_sort_kernel), so the
+    // hardware's in-order dispatch starts the long strips first
     const int ngroups = (L.n + MB_GROUP - 1) / MB_GROUP;
-    const int ch = blockIdx.z & 3, rest = blockIdx.z >> 2;
-    const int nrec = gridDim.z / (4 * ngroups);
-    const int grp = rest / nrec, pid = rest - grp * nrec;
+    const int ch = blockIdx.x & 3, rest = blockIdx.x >> 2;
+    const int slot = rest / ngroups, grp = rest - slot * ngroups;
+    const int2 item = items[slot];
+    if (item.x < 0) return;                                                     // uniform
+    const int pid = item.x & 0xffff, tx0 = item.x >> 16;
     const pano_patch p = table[pid];
     const MbGeom g = mb_geom(p);
-    if (p.aw <= 0 || p.ah <= 0 || (int)blockIdx.x * 2 >= g.ntx) return;       // uniform
     const int l0 = MB_GROUP * grp, nl = L.n - l0 < MB_GROUP ? L.n - l0 : MB_GROUP;
     const int q = __builtin_amdgcn_readfirstlane(wv >> 1);
     const int lv = mb_level_of_pair(nl, q);
@@ -500,7 +504,7 @@ __global__ __launch_bounds__(MB_THREADS, 1) void blur_mfma_kernel(
         const int n16 = mb_table_bytes(ntaps) >> 4;
         for (int i = tid & 127; i < n16; i += 128) to[i] = from[i];
     }
-    const int X0 = g.gx0 + MB_XT * (int)blockIdx.x, BW = MB_XT + 32 * sh.CM;
+    const int X0 = g.gx0 + 32 * tx0, BW = MB_XT + 32 * sh.CM;
     for (int bc = tid; bc < MB_PITCH + 8; bc += MB_THREADS) {
         const int vc = reflect_101(X0 - 16 * sh.CM + bc, p.w) - p.vx0;
         sh.col[bc] = bc < BW && (unsigned)vc < (unsigned)p.vw ? (short)vc : (short)-1;
@@ -538,14 +542,14 @@ __global__ __launch_bounds__(MB_THREADS, 1) void blur_mfma_kernel(
     __syncthreads();
     const half8 *s_tx = (const half8 *)(smem + my_tx), *s_ty = (const half8 *)(smem + my_ty);
 #ifdef MB_ONLY
-    mb_body<MB_ONLY>(p, ch, level, live, s_tx, s_ty, sh, owner, W, ntaps >> 1);
+    mb_body<MB_ONLY>(p, ch, level, live, s_tx, s_ty, sh, owner, W, ntaps >> 1, tx0);
     return;
 #endif
     switch (c) {                                         // wave-uniform
-        case 1: mb_body<1>(p, ch, level, live, s_tx, s_ty, sh, owner, W, ntaps >> 1); break;
-        case 2: mb_body<2>(p, ch, level, live, s_tx, s_ty, sh, owner, W, ntaps >> 1); break;
-        case 3: mb_body<3>(p, ch, level, live, s_tx, s_ty, sh, owner, W, ntaps >> 1); break;
-        default: mb_body<4>(p, ch, level, live, s_tx, s_ty, sh, owner, W, ntaps >> 1); break;
+        case 1: mb_body<1>(p, ch, level, live, s_tx, s_ty, sh, owner, W, ntaps >> 1, tx0); break;
+        case 2: mb_body<2>(p, ch, level, live, s_tx, s_ty, sh, owner, W, ntaps >> 1, tx0); break;
+        case 3: mb_body<3>(p, ch, level, live, s_tx, s_ty, sh, owner, W, ntaps >> 1, tx0); break;
+        default: mb_body<4>(p, ch, level, live, s_tx, s_ty, sh, owner, W, ntaps >> 1, tx0); break;
     }
 }
 
@@ -570,6 +574,97 @@ __global__ __launch_bounds__(256) void tile_flags32_kernel(const pano_patch *__r
     for (int by = by0; by <= by1; ++by)
         for (int bx = bx0; bx <= bx1; ++bx) active |= interior[(size_t)by * W8 + bx] == 0;
     flags[p.tiles_off + ty * g.ntx + tx] = active ? 1 : 0;
+}
+
+// The work list.  An item = (record, pair of adjacent tile columns); every item becomes one
+// workgroup per channel and level group.  A seam's active tiles span a few tile columns that
+// start at any parity and drift with the row, so (a) pairs open at every active column not
+// yet covered, not at fixed even positions, and (b) items differ a lot in length (cfg3: 13 to
+// 82 bands), which is why they are sorted: dispatched longest first, the strips pack the CUs
+// (in blockIdx order of a (pairs, records) grid the kernel ran at 60 % occupancy).
+//   item.x = record | first tile column << 16,  item.y = bands the workgroup will process
+#define MB_SORT_BINS 2048
+__global__ __launch_bounds__(64) void mb_items_kernel(const pano_patch *__restrict__ table,
+                                                      const uint8_t *__restrict__ flags,
+                                                      int2 *__restrict__ items,
+                                                      int *__restrict__ counter, int cap) {
+    __shared__ int16_t s_start[1024];
+    const pano_patch p = table[blockIdx.x];
+    const int lane = threadIdx.x;
+    if (p.aw <= 0 || p.ah <= 0) return;
+    const MbGeom g = mb_geom(p);
+    const int nty = g.O1 - g.O0 + 1;
+    int count = 0;
+    bool covered = false;                                // column 0 of this chunk is in a pair
+    for (int c0 = 0; c0 < g.ntx; c0 += 64) {
+        const int tx = c0 + lane;
+        bool any = false;
+        if (tx < g.ntx) {
+            any = flags == nullptr;
+            for (int ty = 0; ty < nty && !any; ++ty)
+                any = flags[p.tiles_off + ty * g.ntx + tx] != 0;
+        }
+        unsigned long long m = __ballot(any);
+        if (covered) m &= ~1ull;
+        covered = false;
+        while (m) {                                      // uniform
+            const int b = __ffsll((long long)m) - 1;
+            if (lane == 0 && count < 1024) s_start[count] = (int16_t)(c0 + b);
+            ++count;
+            m &= ~(3ull << b);
+            covered = b == 63;
+        }
+    }
+    count = count < 1024 ? count : 1024;                 // 65536 columns: beyond any mosaic
+    __syncthreads();
+    int base = 0;
+    if (lane == 0) base = atomicAdd(counter, count);
+    base = __shfl(base, 0, 64);
+    for (int k = lane; k < count; k += 64) {
+        const int tx0 = s_start[k];
+        // bands within two tiles of a wanted tile of the pair (what the kernel steps through)
+        int bands = 0, last = -1000;
+        for (int ty = 0; ty < nty; ++ty) {
+            bool want = flags == nullptr || flags[p.tiles_off + ty * g.ntx + tx0] != 0;
+            if (!want && tx0 + 1 < g.ntx) want = flags[p.tiles_off + ty * g.ntx + tx0 + 1] != 0;
+            if (!want) continue;
+            const int lo = ty - 2 > last + 1 ? ty - 2 : last + 1;
+            bands += ty + 2 - lo + 1;
+            last = ty + 2;
+        }
+        if (base + k < cap) items[base + k] = make_int2((int)blockIdx.x | (tx0 << 16), bands);
+    }
+}
+
+// Counting sort of the items by decreasing length (one workgroup); slots past the last item
+// get record -1.  Resets the counter for the next launch.
+__global__ __launch_bounds__(256) void mb_sort_kernel(const int2 *__restrict__ items,
+                                                      int *__restrict__ counter, int cap,
+                                                      int2 *__restrict__ sorted) {
+    __shared__ int s_hist[MB_SORT_BINS];
+    const int tid = threadIdx.x;
+    const int n = min(*counter, cap);
+    for (int i = tid; i < MB_SORT_BINS; i += 256) s_hist[i] = 0;
+    __syncthreads();
+    for (int i = tid; i < n; i += 256)
+        atomicAdd(&s_hist[MB_SORT_BINS - 1 - min(items[i].y, MB_SORT_BINS - 1)], 1);   // long first
+    __syncthreads();
+    if (tid == 0) {
+        int run = 0;
+        for (int i = 0; i < MB_SORT_BINS; ++i) {
+            const int c = s_hist[i];
+            s_hist[i] = run;
+            run += c;
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < n; i += 256) {
+        const int2 it = items[i];
+        sorted[atomicAdd(&s_hist[MB_SORT_BINS - 1 - min(it.y, MB_SORT_BINS - 1)], 1)] = it;
+    }
+    for (int i = n + tid; i < cap; i += 256) sorted[i] = make_int2(-1, 0);
+    __syncthreads();
+    if (tid == 0) *counter = 0;
 }
 
 // Host side: called by pano_multiband_blur (blur.hip).  taps / ntaps: the caller's
@@ -601,6 +696,27 @@ int pano_launch_blur_mfma(const pano_patch *table, int n, int max_aw, int max_ah
         PANO_LAUNCH_CHECK("tile_flags32_kernel");
         flags = tile_flags;
     }
+    // work list: at most ceil(ntx / 2) pairs per record (grow-only device buffers, kept)
+    const int cap = n * ceil_div(ntx_max, 2);
+    static int2 *item_buf = nullptr;           // [2][item_cap]: unsorted, sorted
+    static int *item_counter = nullptr;
+    static int item_cap = 0;
+    if (cap > item_cap) {
+        if (item_buf) PANO_HIP(hipFree(item_buf));
+        item_cap = cap * 2;
+        PANO_HIP(hipMalloc((void **)&item_buf, (size_t)item_cap * 2 * sizeof(int2)));
+    }
+    if (!item_counter) {
+        PANO_HIP(hipMalloc((void **)&item_counter, sizeof(int)));
+        PANO_HIP(hipMemsetAsync(item_counter, 0, sizeof(int), stream));
+    }
+    int2 *sorted = item_buf + item_cap;
+    hipLaunchKernelGGL(mb_items_kernel, dim3(n), dim3(64), 0, stream, table, flags, item_buf,
+                       item_counter, cap);
+    PANO_LAUNCH_CHECK("mb_items_kernel");
+    hipLaunchKernelGGL(mb_sort_kernel, dim3(1), dim3(256), 0, stream, item_buf, item_counter, cap,
+                       sorted);
+    PANO_LAUNCH_CHECK("mb_sort_kernel");
     static int dbg = -1;                  // PANO_MFMA_DBG: switch parts off (timing experiments)
     if (dbg < 0) dbg = getenv("PANO_MFMA_DBG") ? atoi(getenv("PANO_MFMA_DBG")) : 0;
     // Toeplitz tables of this tap set: one small device buffer per distinct (table pointer,
@@ -645,10 +761,12 @@ int pano_launch_blur_mfma(const pano_patch *table, int n, int max_aw, int max_ah
                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         lds_opt_in = true;
     }
-    dim3 grid(ceil_div(ntx_max, 2), 1, n * 4 * ngroups);
+    PANO_REQUIRE((long long)cap * 4 * ngroups < (1ll << 31), "pano_multiband_blur: %d work items",
+                 cap);
+    dim3 grid((unsigned)cap * 4 * ngroups, 1, 1);
     PANO_TIMED(PK_BLUR_MFMA, stream,
                hipLaunchKernelGGL(blur_mfma_kernel, grid, dim3(MB_THREADS), lds, stream, table, L,
-                                  tables, owner, W, flags, dbg));
+                                  tables, owner, W, flags, sorted, dbg));
     PANO_LAUNCH_CHECK("blur_mfma_kernel");
     return PANO_OK;
 }

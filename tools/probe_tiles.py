@@ -30,13 +30,27 @@ for rec in table.host:
     x0 = gx0 + 32 * tx; y0 = 32 * (O0 + ty)
     inside = (y0 >= ay0) & (y0 + 32 <= ay0 + ah) & (x0 >= ax0) & (x0 + 32 <= ax0 + aw)
     tot += len(tx); ins += int(inside.sum())
-    for wx in range((ntx + 1) // 2):
-        cols = g[:, 2 * wx:2 * wx + 2]
+    colany = g.any(axis=0)
+    starts, tx_ = [], 0
+    while tx_ < ntx:                      # the greedy pairing of mb_columns_kernel
+        if colany[tx_]:
+            starts.append(tx_)
+            tx_ += 2
+        else:
+            tx_ += 1
+    for tx0 in starts:
+        cols = g[:, tx0:tx0 + 2]
         wgs += 1
-        if cols.any():
-            live += 1
-            rows = np.nonzero(cols.any(axis=1))[0]
-            steps.append(rows[-1] - rows[0] + 1 + 4)
+        live += 1
+        want = cols.any(axis=1)
+        reach = np.convolve(want.astype(int), np.ones(5, int), "same") > 0   # +-2 bands
+        steps.append(int(reach.sum()) + 4)
+        both = getattr(np, "_both", [])
+    if not hasattr(np, "_stat"):
+        np._stat = [0, 0]
+    np._stat[0] += int(g.sum())
+    np._stat[1] += sum(int(g[:, t:t + 2].any(axis=1).sum()) * 2 for t in starts)
 print("records", len(table.host), "active tiles", tot, "inside A", ins, "(%.1f%%)" % (100.0 * ins / tot))
 print("workgroups per channel", wgs, "live", live, "steps per live WG: mean %.1f min %d max %d" % (np.mean(steps), min(steps), max(steps)))
+print("wanted tiles", np._stat[0], "tile slots in wanted bands of the pairs", np._stat[1])
 print("total WG-steps x4 channels", 4 * sum(steps), " per CU (256):", 4 * sum(steps) / 256.0)
