@@ -221,8 +221,17 @@ int pano_owned_regions(const int16_t *owner, int H, int W, int xs0, int xs1,
  *    0: 64-column x 128-row tiles relative to A, ceil(aw/64) per row,
  *       ceil(ah/128) rows (the vector-ALU kernels, PANO_BLUR=valu).
  * The matrix-core kernel computes in split float16 (hi + lo, three products)
- * with float32 accumulation and does not use patches[i].scratch. */
+ * with float32 accumulation and does not use patches[i].scratch.
+ * pano_multiband_blur_prepare (optional): the part of the call that depends on the
+ * records' geometry and the interior map only (tile flags and the sorted work list of
+ * the matrix-core kernel).  It may be queued on another stream while the warp fills the
+ * planes; the caller orders it before the pano_multiband_blur call on the same table
+ * (same patches pointer and n) with an event.  Without it pano_multiband_blur does
+ * the same work itself. */
 int pano_blur_tile_grid(void);
+int pano_multiband_blur_prepare(const pano_patch *patches, int n, int max_aw, int max_ah,
+                                int W, const uint8_t *interior, uint8_t *tile_flags,
+                                void *stream);
 int pano_multiband_blur(const pano_patch *patches, int n, int max_aw,
                         int max_vh, int max_ah, const int16_t *owner, int W,
                         const float *taps, const int *ntaps, int n_blur,

@@ -73,6 +73,7 @@ _SIGNATURES = {
     "pano_owned_regions": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "pano_multiband_blur": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _vp,
                                  C.POINTER(C.c_int), _i, _vp, _vp, _vp]),
+    "pano_multiband_blur_prepare": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     "pano_interior_map": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "pano_multiband_compose": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp,
                                     _vp, _vp, _i, _vp, _vp, _i, _vp]),

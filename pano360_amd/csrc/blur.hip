@@ -443,6 +443,19 @@ extern "C" int pano_multiband_blur(const pano_patch *patches, int n, int max_aw,
                        n_blur, interior, tile_flags, (hipStream_t)stream, "pano_multiband_blur");
 }
 
+extern "C" int pano_multiband_blur_prepare(const pano_patch *patches, int n, int max_aw,
+                                           int max_ah, int W, const uint8_t *interior,
+                                           uint8_t *tile_flags, void *stream) {
+    PANO_REQUIRE(patches, "pano_multiband_blur_prepare: null pointer");
+    PANO_REQUIRE(n >= 0 && n <= 32767 && W > 0 && max_aw >= 0 && max_ah >= 0,
+                 "pano_multiband_blur_prepare: bad argument");
+    PANO_REQUIRE(!interior || tile_flags,
+                 "pano_multiband_blur_prepare: interior map without tile_flags");
+    if (n == 0 || max_aw == 0 || max_ah == 0 || !pano_blur_uses_mfma()) return PANO_OK;
+    return pano_prepare_blur_mfma(patches, n, max_aw, max_ah, W, interior, tile_flags,
+                                  (hipStream_t)stream);
+}
+
 // ---- cv2.pyrDown -----------------------------------------------------------
 // c*6 + (l1 + r1)*4 + l2 + r2 along rows, the same along columns, then /256.
 __global__ __launch_bounds__(256) void pyr_down_kernel(const float *__restrict__ src,

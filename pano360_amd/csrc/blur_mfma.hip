@@ -51,6 +51,9 @@ typedef GLOBAL_AS float *gf32;
 typedef const GLOBAL_AS int16_t *gci16;
 typedef const GLOBAL_AS float4u *gcf32x4;
 
+#ifndef MB_SCHED
+#define MB_SCHED 1
+#endif
 #define MB_XT 64                    // output columns per workgroup: two 32-column tiles
 #define MB_PITCH 200                // halfs per band row (64 + 2*64 + 8): 400 B, conflict-free b128
 #define MB_GROUP 4                  // levels per workgroup: one pair of waves each
@@ -157,7 +160,7 @@ __device__ __forceinline__ void mb_colpass(f32x16 (&acc)[2 * ((C + 1) / 2) + 1],
             acc[k] = __builtin_amdgcn_mfma_f32_32x32x16_f16(t_hi, m_hi[s], acc[k], 0, 0, 0);
             acc[k] = __builtin_amdgcn_mfma_f32_32x32x16_f16(t_lo, m_hi[s], acc[k], 0, 0, 0);
             acc[k] = __builtin_amdgcn_mfma_f32_32x32x16_f16(t_hi, m_lo[s], acc[k], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);           // keep the operand reads next to their use
+            if (MB_SCHED) __builtin_amdgcn_sched_barrier(0);
         }
     }
 }
@@ -380,7 +383,7 @@ __device__ __forceinline__ void mb_body(const pano_patch &p, const int ch, const
                     const half8 a_lo = *(const half8 *)(brow + 16 * s);
                     mid = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo, b_hi, mid, 0, 0, 0);
                 }
-                if (s & 1) __builtin_amdgcn_sched_barrier(0);
+                if (MB_SCHED && (s & 1)) __builtin_amdgcn_sched_barrier(0);
             }
             int u = t % NB;
             if (u < 0) u += NB;
@@ -670,6 +673,51 @@ __global__ __launch_bounds__(256) void mb_sort_kernel(const int2 *__restrict__ i
 // Host side: called by pano_multiband_blur (blur.hip).  taps / ntaps: the caller's
 // padded tables (include/pano360.h); `extra[k]` zeros precede level k's first tap
 // after the PANO_TAP_LEAD ones.
+// The work list of a table of records: tile flags (with an interior map), items, sort.
+// Depends on the records' geometry and the interior map only, not on the warped planes, so
+// the caller may queue it on another stream while the warp runs (pano_multiband_blur_prepare).
+static int2 *g_item_buf = nullptr;             // [2][g_item_cap]: unsorted, sorted (grow-only)
+static int *g_item_counter = nullptr;
+static int g_item_cap = 0;
+static const pano_patch *g_prepared_table = nullptr;   // whose list `sorted` currently holds
+static int g_prepared_n = 0;
+
+int pano_prepare_blur_mfma(const pano_patch *table, int n, int max_aw, int max_ah, int W,
+                           const uint8_t *interior, uint8_t *tile_flags, hipStream_t stream) {
+    const int ntx_max = (max_aw + 62) / 32, nty_max = (max_ah + 62) / 32;
+    PANO_REQUIRE(nty_max <= MB_NEED_MAX, "pano_multiband_blur: %d rows of tiles exceed %d", nty_max,
+                 MB_NEED_MAX);
+    const uint8_t *flags = nullptr;
+    if (interior) {
+        dim3 grid(ceil_div(ntx_max, 32), ceil_div(nty_max, 8), n);
+        PANO_TIMED(PK_TILE_FLAGS, stream,
+                   hipLaunchKernelGGL(tile_flags32_kernel, grid, dim3(256), 0, stream, table,
+                                      interior, ceil_div(W, 8), tile_flags));
+        PANO_LAUNCH_CHECK("tile_flags32_kernel");
+        flags = tile_flags;
+    }
+    // at most ceil(ntx / 2) pairs per record
+    const int cap = n * ceil_div(ntx_max, 2);
+    if (cap > g_item_cap) {
+        if (g_item_buf) PANO_HIP(hipFree(g_item_buf));
+        g_item_cap = cap * 2;
+        PANO_HIP(hipMalloc((void **)&g_item_buf, (size_t)g_item_cap * 2 * sizeof(int2)));
+    }
+    if (!g_item_counter) {
+        PANO_HIP(hipMalloc((void **)&g_item_counter, sizeof(int)));
+        PANO_HIP(hipMemsetAsync(g_item_counter, 0, sizeof(int), stream));
+    }
+    hipLaunchKernelGGL(mb_items_kernel, dim3(n), dim3(64), 0, stream, table, flags, g_item_buf,
+                       g_item_counter, cap);
+    PANO_LAUNCH_CHECK("mb_items_kernel");
+    hipLaunchKernelGGL(mb_sort_kernel, dim3(1), dim3(256), 0, stream, g_item_buf, g_item_counter,
+                       cap, g_item_buf + g_item_cap);
+    PANO_LAUNCH_CHECK("mb_sort_kernel");
+    g_prepared_table = table;
+    g_prepared_n = n;
+    return PANO_OK;
+}
+
 int pano_launch_blur_mfma(const pano_patch *table, int n, int max_aw, int max_ah,
                           const int16_t *owner, int W, const float *taps, const int *ntaps,
                           int n_blur, const uint8_t *interior, uint8_t *tile_flags,
@@ -684,39 +732,16 @@ int pano_launch_blur_mfma(const pano_patch *table, int n, int max_aw, int max_ah
         L.ntaps[k] = ntaps[k];
         off += (size_t)ntaps[k] + PANO_TAP_PAD;
     }
-    const int ntx_max = (max_aw + 62) / 32, nty_max = (max_ah + 62) / 32;
-    PANO_REQUIRE(nty_max <= MB_NEED_MAX, "pano_multiband_blur: %d rows of tiles exceed %d", nty_max,
-                 MB_NEED_MAX);
-    const uint8_t *flags = nullptr;
-    if (interior) {
-        dim3 grid(ceil_div(ntx_max, 32), ceil_div(nty_max, 8), n);
-        PANO_TIMED(PK_TILE_FLAGS, stream,
-                   hipLaunchKernelGGL(tile_flags32_kernel, grid, dim3(256), 0, stream, table,
-                                      interior, ceil_div(W, 8), tile_flags));
-        PANO_LAUNCH_CHECK("tile_flags32_kernel");
-        flags = tile_flags;
-    }
-    // work list: at most ceil(ntx / 2) pairs per record (grow-only device buffers, kept)
+    const int ntx_max = (max_aw + 62) / 32;
+    // the work list: prepared by the caller for this table, or made here
+    if (g_prepared_table != table || g_prepared_n != n)
+        if (int rc = pano_prepare_blur_mfma(table, n, max_aw, max_ah, W, interior, tile_flags,
+                                            stream))
+            return rc;
+    g_prepared_table = nullptr;
+    const uint8_t *flags = interior ? tile_flags : nullptr;
     const int cap = n * ceil_div(ntx_max, 2);
-    static int2 *item_buf = nullptr;           // [2][item_cap]: unsorted, sorted
-    static int *item_counter = nullptr;
-    static int item_cap = 0;
-    if (cap > item_cap) {
-        if (item_buf) PANO_HIP(hipFree(item_buf));
-        item_cap = cap * 2;
-        PANO_HIP(hipMalloc((void **)&item_buf, (size_t)item_cap * 2 * sizeof(int2)));
-    }
-    if (!item_counter) {
-        PANO_HIP(hipMalloc((void **)&item_counter, sizeof(int)));
-        PANO_HIP(hipMemsetAsync(item_counter, 0, sizeof(int), stream));
-    }
-    int2 *sorted = item_buf + item_cap;
-    hipLaunchKernelGGL(mb_items_kernel, dim3(n), dim3(64), 0, stream, table, flags, item_buf,
-                       item_counter, cap);
-    PANO_LAUNCH_CHECK("mb_items_kernel");
-    hipLaunchKernelGGL(mb_sort_kernel, dim3(1), dim3(256), 0, stream, item_buf, item_counter, cap,
-                       sorted);
-    PANO_LAUNCH_CHECK("mb_sort_kernel");
+    const int2 *sorted = g_item_buf + g_item_cap;
     static int dbg = -1;                  // PANO_MFMA_DBG: switch parts off (timing experiments)
     if (dbg < 0) dbg = getenv("PANO_MFMA_DBG") ? atoi(getenv("PANO_MFMA_DBG")) : 0;
     // Toeplitz tables of this tap set: one small device buffer per distinct (table pointer,

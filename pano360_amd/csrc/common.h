@@ -81,6 +81,8 @@ int pano_launch_blur_mfma(const pano_patch *table, int n, int max_aw, int max_ah
                           const int16_t *owner, int W, const float *taps, const int *ntaps,
                           int n_blur, const uint8_t *interior, uint8_t *tile_flags,
                           hipStream_t stream);
+int pano_prepare_blur_mfma(const pano_patch *table, int n, int max_aw, int max_ah, int W,
+                           const uint8_t *interior, uint8_t *tile_flags, hipStream_t stream);
 bool pano_blur_uses_mfma();
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 

@@ -747,8 +747,29 @@ class Engine:
         done.record(self.side)
         return mosaic, fl, done
 
+    def prepare_blur_async(self, table, W, interior):
+        """Tile flags and the sorted work list of the blur (they depend on the records and
+        the interior map, not on the warped planes) on the side stream, beside the warp.
+        Returns (tile flags, event) for ``blur_and_compose(prepared=...)``."""
+        torch = _torch()
+        flags = (torch.empty(max(table.n_tiles, 1), dtype=torch.uint8, device=self.device)
+                 if interior is not None else None)
+        uploaded = torch.cuda.Event()
+        uploaded.record(torch.cuda.current_stream(self.device))      # the record table
+        self.side.wait_event(uploaded)
+        for t in (flags, interior, table.dev):
+            if t is not None:
+                t.record_stream(self.side)
+        _lib.check(self.lib.pano_multiband_blur_prepare(
+            table.ptr, table.n, table.max_aw, table.max_ah, W, _ptr(interior), _ptr(flags),
+            C.c_void_p(self.side.cuda_stream)), "pano_multiband_blur_prepare")
+        listed = torch.cuda.Event()
+        listed.record(self.side)
+        return flags, listed
+
     def blur_and_compose(self, table, owner, valid, shape, n_levels, want_float=False,
-                         strip=None, interior=None, cams=None, plan=None, luts=None, out=None):
+                         strip=None, interior=None, cams=None, plan=None, luts=None, out=None,
+                         prepared=None):
         """All Gaussian levels of all patches (n_levels launches), then the gather
         over the mosaic columns ``strip`` (default: all of them).  With an
         ``interior`` map, blur tiles and gathers are skipped where the result is
@@ -758,8 +779,12 @@ class Engine:
         c0, c1 = strip if strip is not None else (0, W)
         taps, ntaps, n_blur, _ = self.blur_tables(n_levels)
         if n_blur:
-            flags = (torch.empty(max(table.n_tiles, 1), dtype=torch.uint8, device=self.device)
-                     if interior is not None else None)
+            if prepared is not None:        # tile flags and work list queued on the side stream
+                flags, listed = prepared
+                torch.cuda.current_stream(self.device).wait_event(listed)
+            else:
+                flags = (torch.empty(max(table.n_tiles, 1), dtype=torch.uint8,
+                                     device=self.device) if interior is not None else None)
             _lib.check(self.lib.pano_multiband_blur(
                 table.ptr, table.n, table.max_aw, table.max_vh, table.max_ah, _ptr(owner), W,
                 _ptr(taps), ntaps, n_blur, _ptr(interior), _ptr(flags), self.stream()),
@@ -968,13 +993,15 @@ class Engine:
         entries = (index, rects, area, window)
         patches = FusedPatches(entries, self.device, n_blur)
         table = patches.table
+        prepared = (self.prepare_blur_async(table, plan.shape[1], interior)
+                    if n_blur and self.overlap_interior else None)
         _lib.check(self.lib.pano_warp_windows(
             _ptr(cams), table.ptr, table.n, table.max_vw, table.max_vh, _ptr(plan.dev[0]),
             _ptr(plan.dev[1]), _ptr(plan.dev[2]), *self._lut_args(luts), self.stream()),
             "pano_warp_windows")
         mosaic, fl = self.blur_and_compose(table, owner, valid, plan.shape, n_levels,
                                            want_float, (c0, c1), interior, cams, plan, luts,
-                                           out=early)
+                                           out=early, prepared=prepared)
         return mosaic, fl, valid, patches
 
     def blend_fused(self, frames, plan, linear, frame_ids=None, strip=None, luts=None):
