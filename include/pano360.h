@@ -77,6 +77,16 @@ typedef struct pano_patch {
                                   ceil(aw/64) per row)                        */
 } pano_patch;
 
+/* What pano_layout_windows reports besides the records. */
+typedef struct pano_layout {
+    int64_t planes_floats;     /* arena sizes the records' pointers will index     */
+    int64_t blurred_floats;
+    int64_t scratch_floats;
+    int32_t n_records, n_tiles;
+    int32_t max_vw, max_vh, max_aw, max_ah;
+    int32_t missing;           /* records of cameras flagged absent in `have`      */
+} pano_layout;
+
 /* One registered frame (reference: bundle_adj.Image, bundle_adj.py:18-33,
  * plus the patch rectangle stitch() derives for it). */
 typedef struct pano_camera {
@@ -251,6 +261,23 @@ int pano_multiband_blur(const pano_patch *patches, int n, int max_aw,
 int pano_interior_map(const int16_t *owner, int H, int W, int xs0, int xs1,
                       int radius, int16_t *block_owner, uint8_t *interior,
                       void *stream);
+
+/* Host side of the fused path: the record table from the owned regions
+ * (no reference counterpart; the arithmetic of "Windows" above).  regions: host copy
+ * of pano_owned_regions' output, [n][5 + 2 max_spans]; rects: host int32 [n][4] =
+ * patch rectangles (y0, y1, x0, x1) in mosaic coordinates; have (optional): [n], 0 =
+ * that camera's frame is not resident; radius = the largest Gaussian radius;
+ * [xs0, xs1) = the mosaic columns to produce.  Writes one record per (camera, owned
+ * column span) that reaches the strip, in camera order, with rectangles A and V,
+ * pitches, tile offsets, and - until pano_layout_place - arena OFFSETS in the pointer
+ * fields.  pano_layout_place turns them into addresses inside the three arenas
+ * (blurred aligned up to 128 bytes; blurred / scratch may be NULL when unused). */
+int pano_layout_windows(const int32_t *regions, int n, int max_spans,
+                        const int32_t *rects, const uint8_t *have, int radius,
+                        int xs0, int xs1, int n_blur, pano_patch *records, int cap,
+                        pano_layout *out);
+int pano_layout_place(pano_patch *records, int n_records, void *planes, void *blurred,
+                      void *scratch);
 
 /* Band-pass build + collapse                     stitcher.py:210-241
  * Gathers, per mosaic pixel and in patch order, layer_k / wsum_k of every

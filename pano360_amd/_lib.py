@@ -35,6 +35,14 @@ class Patch(C.Structure):
                 ("index", C.c_int32), ("tiles_off", C.c_int32)]
 
 
+class Layout(C.Structure):
+    """``pano_layout`` of include/pano360.h."""
+    _fields_ = [("planes_floats", C.c_int64), ("blurred_floats", C.c_int64),
+                ("scratch_floats", C.c_int64), ("n_records", C.c_int32), ("n_tiles", C.c_int32),
+                ("max_vw", C.c_int32), ("max_vh", C.c_int32), ("max_aw", C.c_int32),
+                ("max_ah", C.c_int32), ("missing", C.c_int32)]
+
+
 class Pair(C.Structure):
     """``pano_pair`` of include/pano360.h (80 bytes)."""
     _fields_ = [("minv", C.c_double * 9), ("i", C.c_int32), ("j", C.c_int32)]
@@ -74,6 +82,8 @@ _SIGNATURES = {
     "pano_multiband_blur": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _vp,
                                  C.POINTER(C.c_int), _i, _vp, _vp, _vp]),
     "pano_multiband_blur_prepare": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "pano_layout_windows": (_i, [_vp, _i, _i, _vp, _vp, _i, _i, _i, _i, _vp, _i, _vp]),
+    "pano_layout_place": (_i, [_vp, _i, _vp, _vp, _vp]),
     "pano_interior_map": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "pano_multiband_compose": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp,
                                     _vp, _vp, _i, _vp, _vp, _i, _vp]),

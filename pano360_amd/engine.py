@@ -441,6 +441,16 @@ class DevicePatch:
 class PatchTable:
     """Device array of ``pano_patch`` records + the extents that size the grids."""
 
+    @classmethod
+    def from_layout(cls, records, lay, device):
+        """Records laid out by ``pano_layout_windows`` (tile offsets and extents known)."""
+        self = cls.__new__(cls)
+        self.host, self.n, self.n_tiles = records, len(records), int(lay.n_tiles)
+        self.dev = _to_device(records, device)
+        self.max_vw, self.max_vh, self.max_aw, self.max_ah = (int(lay.max_vw), int(lay.max_vh),
+                                                              int(lay.max_aw), int(lay.max_ah))
+        return self
+
     def __init__(self, records, device):
         self.host = np.array(records, dtype=PATCH_DTYPE).reshape(-1)
         self.n = len(self.host)
@@ -497,6 +507,49 @@ class FusedPatches:
                                                   device=device)
         return have
 
+    @classmethod
+    def from_regions(cls, raw, max_spans, rects, have, radius, strip, n_blur, device):
+        """The record table straight from the region search's output: one native call
+        lays out rectangles, pitches, arena offsets and tile offsets
+        (``pano_layout_windows``); the arenas are (re)used as in ``__init__``.
+        ``have``: uint8 [n], 0 = that camera's frame is not resident."""
+        lib = _lib.lib()
+        n = len(rects)
+        rec = np.zeros(n * max_spans, dtype=PATCH_DTYPE)
+        lay = _lib.Layout()
+        raw = np.ascontiguousarray(raw, np.int32)
+        rects = np.ascontiguousarray(rects, np.int32)
+        have = np.ascontiguousarray(have, np.uint8)
+        _lib.check(lib.pano_layout_windows(
+            raw.ctypes.data, n, max_spans, rects.ctypes.data, have.ctypes.data, radius,
+            strip[0], strip[1], n_blur, rec.ctypes.data, len(rec), C.byref(lay)),
+            "pano_layout_windows")
+        rec = rec[:lay.n_records]
+        if lay.missing:
+            missing = sorted({int(i) for i in rec["index"] if not have[int(i)]})
+            raise _lib.PanoError(f"frames {missing} are needed for columns [{strip[0]}, "
+                                 f"{strip[1]}) but are not resident on this device")
+        self = cls.__new__(cls)
+        self.planes = cls._arena(device, "planes", int(lay.planes_floats))
+        self.blurred = cls._arena(device, "blurred", int(lay.blurred_floats))
+        self.scratch = cls._arena(device, "scratch", int(lay.scratch_floats))
+        _lib.check(lib.pano_layout_place(rec.ctypes.data, len(rec), self.planes.data_ptr(),
+                                         self.blurred.data_ptr(), self.scratch.data_ptr()),
+                   "pano_layout_place")
+        self._area = self._window = None
+        self.table = PatchTable.from_layout(rec, lay, device)
+        return self
+
+    def _rectangles(self):
+        if self._area is None:
+            h = self.table.host
+            i64 = lambda k: h[k].astype(np.int64)   # noqa: E731
+            self._area = np.stack([i64("ay0"), i64("ay0") + i64("ah"), i64("ax0"),
+                                   i64("ax0") + i64("aw")], axis=1)
+            self._window = np.stack([i64("vy0"), i64("vy0") + i64("vh"), i64("vx0"),
+                                     i64("vx0") + i64("vw")], axis=1)
+        return self._area, self._window
+
     def __init__(self, entries, device, n_blur):
         if isinstance(entries, tuple):                   # (index [k], rects [k][4], A [k][4], V [k][4])
             index, rects, area, window = (np.asarray(v, np.int64) for v in entries)
@@ -548,13 +601,13 @@ class FusedPatches:
     @property
     def info(self):
         return [WindowInfo(tuple(int(v) for v in a), tuple(int(v) for v in w))
-                for a, w in zip(self._area, self._window)]
+                for a, w in zip(*self._rectangles())]
 
     def __iter__(self):
         return iter(self.info)
 
     def __len__(self):
-        return len(self._area)
+        return self.table.n
 
     @property
     def warped_pixels(self):
@@ -930,7 +983,8 @@ class Engine:
             host = host_buf.numpy().copy()
             spans = [host[i, 5:5 + 2 * host[i, 4]].reshape(-1, 2) for i in range(n)]
             return host[:, :4], spans
-        wait.raw = lambda: (done.synchronize(), host_buf.numpy().copy())[1]
+        wait.raw = lambda: (done.synchronize(), host_buf.numpy())[1]     # valid until the next call
+        wait.max_spans = max_spans
         return wait
 
     def owned_regions(self, owner, n, strip=None, min_gap=0, max_spans=4):
@@ -977,21 +1031,12 @@ class Engine:
         early = (self.compose_interior_async(owner, plan.shape, (c0, c1), interior, cams, plan,
                                              luts, want_float)
                  if interior is not None and self.overlap_interior else None)
-        raw = regions.raw().astype(np.int64)             # [n][5 + 2 max_spans]
-        counts = raw[:, 4]
-        index = np.repeat(np.arange(plan.n), counts)
-        nth = np.arange(len(index)) - np.repeat(np.cumsum(counts) - counts, counts)
-        xa, xb = raw[index, 5 + 2 * nth], raw[index, 6 + 2 * nth]
-        rects = np.asarray(plan.rects, np.int64)[index]
-        keep, area, window = windows_for_many(
-            np.stack([raw[index, 0], raw[index, 1], xa, xb], axis=1), rects, radius, (c0, c1))
-        index, rects, area, window = index[keep], rects[keep], area[keep], window[keep]
-        missing = sorted({int(i) for i in index if int(i) not in have})
-        if missing:
-            raise _lib.PanoError(f"frames {missing} are needed for columns [{c0}, {c1}) "
-                                 "but are not resident on this device")
-        entries = (index, rects, area, window)
-        patches = FusedPatches(entries, self.device, n_blur)
+        # the host is on the critical path from here to the warp: one native call lays out
+        # the records (rectangles A and V, arena offsets, tile offsets)
+        resident = np.zeros(plan.n, np.uint8)
+        resident[[i for i in have if 0 <= i < plan.n]] = 1
+        patches = FusedPatches.from_regions(regions.raw(), regions.max_spans, plan.rects,
+                                            resident, radius, (c0, c1), n_blur, self.device)
         table = patches.table
         prepared = (self.prepare_blur_async(table, plan.shape[1], interior)
                     if n_blur and self.overlap_interior else None)

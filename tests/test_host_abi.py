@@ -248,3 +248,63 @@ def test_windows_for_many_equals_windows_for():
             assert bool(keep[i]) == (want is not None)
             if want is not None:
                 assert tuple(area[i]) == want[0] and tuple(window[i]) == want[1], (box, rect, radius)
+
+
+def test_native_window_layout_equals_windows_for():
+    """pano_layout_windows (the host's one call between the region search and the warp)
+    against the scalar windows_for, on random rectangles, boxes, spans and strips; arena
+    offsets must not overlap and tile offsets must follow the 32 x 32 anchored grid."""
+    import ctypes as C
+    from pano360_amd import _lib, engine
+    lib = _lib.lib()
+    rng = np.random.default_rng(11)
+    max_spans, radius, n_blur = 4, 43, 4
+    for trial in range(30):
+        n = int(rng.integers(1, 12))
+        rects = np.zeros((n, 4), np.int32)
+        raw = np.zeros((n, 5 + 2 * max_spans), np.int32)
+        for i in range(n):
+            y0, x0 = int(rng.integers(0, 50)), int(rng.integers(0, 3000))
+            h, w = int(rng.integers(1, 400)), int(rng.integers(1, 900))
+            rects[i] = (y0, y0 + h, x0, x0 + w)
+            if rng.random() < 0.2:
+                raw[i, :4] = (1, 0, 1, 0)                     # owns nothing
+                continue
+            ys = np.sort(rng.integers(y0, y0 + h, 2))
+            k = int(rng.integers(1, max_spans + 1))
+            xs = np.sort(rng.choice(np.arange(x0, x0 + w), size=min(2 * k, w), replace=False))
+            k = len(xs) // 2
+            raw[i, :5] = (ys[0], ys[1], xs[0], xs[2 * k - 1], k)
+            raw[i, 5:5 + 2 * k] = xs[:2 * k]
+        strip = (int(rng.integers(0, 1500)), int(rng.integers(1500, 4000))) if trial % 2 else (0, 10 ** 6)
+        have = np.ones(n, np.uint8)
+        rec = np.zeros(n * max_spans, dtype=engine.PATCH_DTYPE)
+        lay = _lib.Layout()
+        _lib.check(lib.pano_layout_windows(raw.ctypes.data, n, max_spans, rects.ctypes.data,
+                                           have.ctypes.data, radius, strip[0], strip[1], n_blur,
+                                           rec.ctypes.data, len(rec), C.byref(lay)), "layout")
+        want = []
+        for i in range(n):
+            for s in range(int(raw[i, 4])):
+                box = (raw[i, 0], raw[i, 1], raw[i, 5 + 2 * s], raw[i, 6 + 2 * s])
+                got = engine.windows_for(box, tuple(int(v) for v in rects[i]), radius, strip)
+                if got is not None:
+                    want.append((i,) + got)
+        assert lay.n_records == len(want)
+        tiles = planes = blurred = 0
+        for r, (i, a, v) in zip(rec[:lay.n_records], want):
+            assert r["index"] == i
+            assert (r["ay0"], r["ay0"] + r["ah"], r["ax0"], r["ax0"] + r["aw"]) == a
+            assert (r["vy0"], r["vy0"] + r["vh"], r["vx0"], r["vx0"] + r["vw"]) == v
+            assert r["vpitch"] == (r["vw"] + 3) & ~3 and r["apitch"] == (r["aw"] + 31) & ~31
+            assert r["tiles_off"] == tiles and r["planes"] == planes
+            assert r["blurred"] == blurred + (r["ax0"] & 31)
+            tiles += ((((a[3] - 1) >> 5) - (a[2] >> 5) + 1) * (((a[1] - 1) >> 5) - (a[0] >> 5) + 1))
+            planes += 3 * int(r["vh"]) * int(r["vpitch"])
+            blurred += n_blur * 4 * int(r["ah"]) * int(r["apitch"]) + 32
+        assert (lay.n_tiles, lay.planes_floats, lay.blurred_floats) == (tiles, planes, blurred + 32)
+        have[:] = 0
+        _lib.check(lib.pano_layout_windows(raw.ctypes.data, n, max_spans, rects.ctypes.data,
+                                           have.ctypes.data, radius, strip[0], strip[1], n_blur,
+                                           rec.ctypes.data, len(rec), C.byref(lay)), "layout")
+        assert lay.missing == lay.n_records
