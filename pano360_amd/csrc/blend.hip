@@ -379,27 +379,53 @@ __global__ __launch_bounds__(256) void blend_cameras_kernel(
 // The same pass marks, per patch, the columns in which it owns anything
 // (marks[o][x] = 1 at the top pixel of every vertical run - idempotent plain
 // stores); owned_spans_kernel turns the marks into column spans.
-__global__ __launch_bounds__(256) void owned_boxes_kernel(const int16_t *__restrict__ owner,
-                                                          int H, int W, int xs0, int xs1,
-                                                          int32_t *__restrict__ boxes, int stride,
-                                                          uint8_t *__restrict__ marks) {
-    const int x = xs0 + blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
-    if (x >= xs1 || y >= H) return;
-    const int16_t *row = owner + (size_t)y * W;
-    const int o = row[x];
+typedef short own8 __attribute__((ext_vector_type(8), aligned(2)));     // 8 owners, any address
+
+__device__ __forceinline__ void owned_box_pixel(int o, int x, int y, bool up, bool down, bool left,
+                                                bool right, int W, int32_t *__restrict__ boxes,
+                                                int stride, uint8_t *__restrict__ marks) {
     if (o < 0) return;
-    const bool up = y == 0 || row[x - W] != o;
     if (up && marks) marks[(size_t)o * W + x] = 1;
-    const bool left = x == xs0 || row[x - 1] != o;      // the strip's edge counts as foreign
-    const bool right = x == xs1 - 1 || row[x + 1] != o;
     if (!left && !right) return;
-    const bool down = y == H - 1 || row[x + W] != o;
     if (left && up) {
         atomicMin(&boxes[(size_t)stride * o + 0], y);
         atomicMin(&boxes[(size_t)stride * o + 2], x);
     }
     if (left && down) atomicMax(&boxes[(size_t)stride * o + 1], y);
     if (right && up) atomicMax(&boxes[(size_t)stride * o + 3], x);
+}
+
+// Eight pixels of a row per thread: the row and its two neighbours as 16-byte loads (one
+// thread per pixel made five 2-byte loads each and was bound by their number).
+__global__ __launch_bounds__(256) void owned_boxes_kernel(const int16_t *__restrict__ owner,
+                                                          int H, int W, int xs0, int xs1,
+                                                          int32_t *__restrict__ boxes, int stride,
+                                                          uint8_t *__restrict__ marks) {
+    const int x8 = xs0 + (blockIdx.x * 64 + threadIdx.x) * 8, y = blockIdx.y * 4 + threadIdx.y;
+    if (x8 >= xs1 || y >= H) return;
+    const int16_t *row = owner + (size_t)y * W;
+    const bool top = y == 0, bottom = y == H - 1;
+    if (x8 + 8 <= xs1) {
+        const own8 cur = *(const own8 *)(row + x8);
+        const own8 upv = top ? cur : *(const own8 *)(row - W + x8);
+        const own8 dnv = bottom ? cur : *(const own8 *)(row + W + x8);
+        const int before = x8 == xs0 ? -32768 : row[x8 - 1];       // the strip's edge is foreign
+        const int after = x8 + 8 == xs1 ? -32768 : row[x8 + 8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int o = cur[j];
+            const int l = j == 0 ? before : cur[j - 1], r = j == 7 ? after : cur[j + 1];
+            owned_box_pixel(o, x8 + j, y, top || upv[j] != o, bottom || dnv[j] != o, l != o, r != o,
+                            W, boxes, stride, marks);
+        }
+        return;
+    }
+    for (int x = x8; x < xs1; ++x) {                                // ragged end of the strip
+        const int o = row[x];
+        owned_box_pixel(o, x, y, top || row[x - W] != o, bottom || row[x + W] != o,
+                        x == xs0 || row[x - 1] != o, x == xs1 - 1 || row[x + 1] != o, W, boxes,
+                        stride, marks);
+    }
 }
 
 // uint8(255 * v) with C truncation; v is in [0, 1] up to rounding.
@@ -749,6 +775,10 @@ __global__ __launch_bounds__(64) void owned_spans_kernel(const uint8_t *__restri
     const uint8_t *row = marks + (size_t)blockIdx.x * W;
     int32_t *out = regions + (size_t)blockIdx.x * stride + 5;
     int cnt = 0, last = 0;
+    // marks exist only between the box's first and last column (owned_boxes_kernel ran before)
+    const int32_t *box = regions + (size_t)blockIdx.x * stride;
+    xs0 = max(xs0, box[2]);
+    xs1 = min(xs1, box[3] + 1);
     // four 64-column groups per trip: their loads are issued together, the run extraction
     // (a serial chain through cnt / last) then works on the four ballots in order
     for (int base0 = xs0; base0 < xs1; base0 += 256) {
@@ -810,7 +840,7 @@ extern "C" int pano_owned_regions(const int16_t *owner, int H, int W, int xs0, i
                        stride);
     PANO_LAUNCH_CHECK("init_regions_kernel");
     if (xs0 == xs1) return PANO_OK;
-    dim3 block(64, 4), grid(ceil_div(xs1 - xs0, 64), ceil_div(H, 4));
+    dim3 block(64, 4), grid(ceil_div(xs1 - xs0, 512), ceil_div(H, 4));
     // the box fields are the first four ints of each record: stride-aware view
     PANO_TIMED(PK_OWNED_BOXES, s,
                hipLaunchKernelGGL(owned_boxes_kernel, grid, block, 0, s, owner, H, W, xs0, xs1,
