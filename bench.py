@@ -71,7 +71,7 @@ def kernel_times(lib):
     return out
 
 
-def pmc_traffic(name):
+def pmc_traffic(name, workload=None):
     """HBM bytes per launch of kernel `name` from the committed PMC summary of this
     same command (profiles/<round>/pmc_traffic.json, written from tools/pmc.sh
     output: FETCH_SIZE x 2 + WRITE_SIZE, KiB -> bytes, per MI355X_MICROARCH.md)."""
@@ -79,12 +79,14 @@ def pmc_traffic(name):
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "pmc_traffic.json")))[::-1]:
         with open(path) as fid:
             table = json.load(fid)
+        if workload is not None and table.get("workload") != workload:
+            continue                       # counters of another workload say nothing here
         if name in table.get("bytes_per_launch", {}):
             return table["bytes_per_launch"][name], os.path.relpath(path, ROOT)
     return None, None
 
 
-def roofline_for(times, plan, patches, n_levels, steps, px_active):
+def roofline_for(times, plan, patches, n_levels, steps, px_active, workload=None):
     """Roofline entry of the kernel with the largest share of the timed region.
     Algorithmic work per launch counts the pixels that launch really produced
     (windows V / rectangles A of the patches, only the column tiles that were
@@ -106,7 +108,7 @@ def roofline_for(times, plan, patches, n_levels, steps, px_active):
         px = px_rows if name == "blur_rows_kernel" else px_cols
         flop = steps * sum(2.0 * t * 4 * px for t in taps)
         achieved = flop / launches / avg_s / 1e12
-        traffic, source = pmc_traffic(name)
+        traffic, source = pmc_traffic(name, workload)
         return dict(kernel=name, bound="mfma", achieved=achieved, peak=F32_PEAK_TFLOPS,
                     unit="TFLOP/s", frac=achieved / F32_PEAK_TFLOPS, traffic=traffic,
                     traffic_source=source,
@@ -127,7 +129,7 @@ def roofline_for(times, plan, patches, n_levels, steps, px_active):
         "blur_mfma_kernel": 14.0 * px_warp + 16.0 * (n_levels - 1) * px_cols,
     }.get(name, 0.0)
     achieved = per_step * steps / launches / avg_s / 1e9
-    traffic, source = pmc_traffic(name)
+    traffic, source = pmc_traffic(name, workload)
     out = dict(kernel=name, bound="hbm", achieved=achieved, peak=HBM_PEAK_GBPS,
                unit="GB/s", frac=achieved / HBM_PEAK_GBPS, traffic=traffic,
                traffic_source=source, avg_launch_ms=avg_s * 1e3, launches=launches)
@@ -305,7 +307,7 @@ def main():
             },
             "kernel_ms_per_step": {k: v[0] / args.steps for k, v in sorted(times.items())},
             "roofline": roofline_for(times, plan, patches, n_levels, args.steps,
-                                     eng.active_tile_pixels()),
+                                     eng.active_tile_pixels(), args.workload),
             "active_megapixels": {
                 "warped": sum((p.window[1] - p.window[0]) * (p.window[3] - p.window[2])
                               for p in patches) / 1e6,

@@ -22,5 +22,5 @@ run fetch FETCH_SIZE
 run write WRITE_SIZE
 run grbm GRBM_GUI_ACTIVE
 cd "$HERE"
-python3 tools/pmc_summary.py "$OUT" | tee "$OUT/summary.txt"
+python3 tools/pmc_summary.py "$OUT" "$WL" | tee "$OUT/summary.txt"
 find "$OUT" -name "*.csv" -size +8M -delete

@@ -12,7 +12,7 @@ import re
 import sys
 
 
-def main(root):
+def main(root, workload="cfg3"):
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
     for path in glob.glob(os.path.join(root, "*", "**", "*counter_collection.csv"), recursive=True):
         with open(path) as fid:
@@ -32,10 +32,11 @@ def main(root):
         if f and w:
             traffic[name] = (2.0 * sum(f) / len(f) + sum(w) / len(w)) * 1024.0
     with open(os.path.join(root, "pmc_traffic.json"), "w") as fid:
-        json.dump({"command": "bench.py (see tools/pmc.sh)", "unit": "bytes per launch",
+        json.dump({"command": "bench.py (see tools/pmc.sh)", "workload": workload,
+                   "unit": "bytes per launch",
                    "formula": "(2 x FETCH_SIZE + WRITE_SIZE) x 1024",
                    "bytes_per_launch": traffic}, fid, indent=1)
 
 
 if __name__ == "__main__":
-    main(sys.argv[1])
+    main(*sys.argv[1:3])
