@@ -67,6 +67,21 @@ typedef const GLOBAL_AS float4u *gcf32x4;
 #define MB_NEED_LEN (MB_NEED_MAX + 2 * MB_NEED_PAD)
 #define MB_WLEN (PANO_MAX_TAPS + 3)
 
+#ifdef MB_STAMP
+// phase timers (timing experiments only): [wave 0 | wave 4][phase] summed cycles, and counts
+__device__ unsigned long long g_mb_stamps[2][12];
+#define STAMP(k)                                                                         \
+    do {                                                                                 \
+        if (stamped) {                                                                   \
+            const unsigned long long now_ = __builtin_readcyclecounter();               \
+            if (lane == 0) atomicAdd(&g_mb_stamps[wv >> 2][k], now_ - tlast);            \
+            tlast = __builtin_readcyclecounter();                                        \
+        }                                                                                \
+    } while (0)
+#else
+#define STAMP(k) do { } while (0)
+#endif
+
 struct MbLevels {
     const float *w[PANO_MAX_LEVELS];    // first tap of each level
     int ntaps[PANO_MAX_LEVELS];
@@ -167,34 +182,51 @@ __device__ __forceinline__ void mb_colpass(f32x16 (&acc)[2 * ((C + 1) / 2) + 1],
 
 // After step t, output tile t - DMAX has all its contributions: store it, clear the
 // accumulator for the tile that takes its place.
+// Stores go through a buffer descriptor of the (level, channel) plane: the address of a lane
+// is one 32-bit byte offset (a 64-bit address per lane and dword made the stores the longest
+// phase of a step: the 8 waves of a workgroup push 128 of them through the CU's one path to
+// the address unit); the row of each register goes into the instruction's scalar offset.
 template <int C>
 __device__ __forceinline__ void mb_store(f32x16 (&acc)[2 * ((C + 1) / 2) + 1],
                                          const bool wanted, const int t, const int lane,
-                                         const pano_patch &p, const gf32 dst, const int px0,
-                                         const int u) {
+                                         const pano_patch &p, const __amdgpu_buffer_rsrc_t plane,
+                                         const int px0, const int u) {
     constexpr int DMAX = (C + 1) / 2, NB = 2 * DMAX + 1;
     const int slot = __builtin_amdgcn_readfirstlane((u + DMAX + 1) % NB);
     const int n = lane & 31, h = lane >> 5;
     const int o = t - DMAX, ax = px0 + n - p.ax0;
-    const bool inside = 32 * o >= p.ay0 && 32 * o + 32 <= p.ay0 + p.ah && px0 >= p.ax0 &&
-                        px0 + 32 <= p.ax0 + p.aw;             // wave-uniform
+    const int rowstep = p.apitch * 4;                               // bytes, uniform
 #pragma unroll
     for (int k = 0; k < NB; ++k) {
         if (k != slot) continue;                                    // wave-uniform
         if (wanted) {
-            const int ay0 = 32 * o + 4 * h - p.ay0;                 // row of register 0
-            const unsigned base = (unsigned)(ay0 * p.apitch + ax);  // uniform dst + 32-bit offset
+            // byte offset of register 0's pixel in a VGPR, the row of register q in the scalar
+            // offset: no per-store address arithmetic on the vector side
+            const int row0 = 32 * o + 4 * h - p.ay0;
+            const unsigned base = (unsigned)(row0 * p.apitch + ax) * 4u;
+            const bool inside = 32 * o >= p.ay0 && 32 * o + 32 <= p.ay0 + p.ah && px0 >= p.ax0 &&
+                                px0 + 32 <= p.ax0 + p.aw;           // wave-uniform
             if (inside) {                                // the whole tile lies in A: no masks
+                // Scaled in place, then sixteen stores that share one offset register and write
+                // no vector register between them: a store holds its operand registers until
+                // the address unit has read them, and a register rewritten for the next store
+                // (one value / one address at a time) makes every store wait out that hand-over.
+#pragma unroll
+                for (int q = 0; q < 16; ++q) acc[k][q] = acc[k][q] * MB_OUT_SCALE;
 #pragma unroll
                 for (int q = 0; q < 16; ++q)
-                    dst[base + (unsigned)(((q & 3) + 8 * (q >> 2)) * p.apitch)] =
-                        acc[k][q] * MB_OUT_SCALE;
-            } else {
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[k][q]), plane, base,
+                                                          ((q & 3) + 8 * (q >> 2)) * rowstep, 0);
+            } else if ((unsigned)ax < (unsigned)p.aw) {
 #pragma unroll
                 for (int q = 0; q < 16; ++q) {
                     const int dy = (q & 3) + 8 * (q >> 2);
-                    if ((unsigned)(ay0 + dy) < (unsigned)p.ah && (unsigned)ax < (unsigned)p.aw)
-                        dst[base + (unsigned)(dy * p.apitch)] = acc[k][q] * MB_OUT_SCALE;
+                    // the whole offset in the VGPR here: the range check looks at it alone,
+                    // and above A it is negative before the row is added
+                    if ((unsigned)(row0 + dy) < (unsigned)p.ah)
+                        __builtin_amdgcn_raw_buffer_store_b32(
+                            __float_as_uint(acc[k][q] * MB_OUT_SCALE), plane,
+                            base + (unsigned)(dy * rowstep), 0, 0);
                     __builtin_amdgcn_sched_barrier(0);   // one address / value pair live at a time
                 }
             }
@@ -240,7 +272,10 @@ __device__ __forceinline__ void mb_body(const pano_patch &p, const int ch, const
         for (int q = 0; q < 16; ++q) acc[i][q] = 0.0f;
 
     const gcf32 src = alpha ? nullptr : (gcf32)(p.planes + (size_t)ch * p.vh * p.vpitch);
-    const gf32 dst = (gf32)(p.blurred + (size_t)(level * 4 + ch) * p.ah * p.apitch);
+    // this wave's output plane as a buffer: base and size are wave-uniform
+    const __amdgpu_buffer_rsrc_t dst = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)(p.blurred + (size_t)(level * 4 + ch) * p.ah * p.apitch), 0, p.ah * p.apitch * 4,
+        0x00020000);
     const gci16 owner = (gci16)owner_;
     // need flags of this wave's tile column; a wave without a level wants nothing
     const uint16_t *info_w = sh.info + (live ? tile * MB_NEED_LEN : 0) + MB_NEED_PAD - g.O0;
@@ -354,18 +389,28 @@ __device__ __forceinline__ void mb_body(const pano_patch &p, const int ch, const
     if (t <= sh.t_hi) fetch(std::integral_constant<int, 0>{}, t);
     if (t1 <= sh.t_hi) fetch(std::integral_constant<int, 1>{}, t1);
     unsigned inf = t <= sh.t_hi ? info_at(t) : 0u;       // flags of band t
+#ifdef MB_STAMP
+    const bool stamped = (wv & 3) == 0 && ch == 0 && (blockIdx.x >> 2) % 7 == 3;
+    unsigned long long tlast = __builtin_readcyclecounter();
+#endif
     auto step = [&](auto slot_c) {
+        STAMP(0);                                        // loop skeleton since the last stamp
         const unsigned inf1 = t1 <= sh.t_hi ? info_at(t1) : 0u;    // one flag word per step
         lds_barrier();                                   // everybody finished reading the band
+        STAMP(1);
         if (!(sh.dbg & 4)) commit(slot_c);
+        STAMP(2);
         lds_barrier();
+        STAMP(3);
 #ifndef MB_NO_STORE
         if (live && !(sh.dbg & 1)) flush();
 #endif
+        STAMP(4);
         const int t2 = (inf1 >> 9) & 1u ? t1 + 1 : next_wanted(t1);
 #ifndef MB_NO_FETCH
         if (t2 <= sh.t_hi && !(sh.dbg & 2)) fetch(slot_c, t2);
 #endif
+        STAMP(5);
         if (t >= my_lo && t <= my_hi && (inf & (DMAX == 1 ? 0x0eu : 0x1fu)) && !(sh.dbg & 8)) {
             f32x16 mid;
 #pragma unroll
@@ -385,10 +430,15 @@ __device__ __forceinline__ void mb_body(const pano_patch &p, const int ch, const
                 }
                 if (MB_SCHED && (s & 1)) __builtin_amdgcn_sched_barrier(0);
             }
+            STAMP(6);                                    // row pass
             int u = t % NB;
             if (u < 0) u += NB;
             mb_colpass<C>(acc, mid, s_ty, inf, lane, u, r);
+            STAMP(7);                                    // column pass
         }
+#ifdef MB_STAMP
+        if (stamped && lane == 0) atomicAdd(&g_mb_stamps[wv >> 2][11], 1ull);
+#endif
         // bands up to the next wanted one only complete tiles
         const int upto = t1 < my_hi + 1 ? t1 : my_hi + 1;
         if (upto > done_end) done_end = upto;
@@ -673,6 +723,17 @@ __global__ __launch_bounds__(256) void mb_sort_kernel(const int2 *__restrict__ i
 // Host side: called by pano_multiband_blur (blur.hip).  taps / ntaps: the caller's
 // padded tables (include/pano360.h); `extra[k]` zeros precede level k's first tap
 // after the PANO_TAP_LEAD ones.
+#ifdef MB_STAMP
+extern "C" int pano_debug_stamps(unsigned long long *out, int reset) {
+    if (out) PANO_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_mb_stamps), sizeof(unsigned long long) * 24));
+    if (reset) {
+        unsigned long long zero[24] = {};
+        PANO_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_mb_stamps), zero, sizeof(zero)));
+    }
+    return PANO_OK;
+}
+#endif
+
 // The work list of a table of records: tile flags (with an interior map), items, sort.
 // Depends on the records' geometry and the interior map only, not on the warped planes, so
 // the caller may queue it on another stream while the warp runs (pano_multiband_blur_prepare).
