@@ -40,6 +40,8 @@
 #include "common.h"
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef short shortx4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef short short8 __attribute__((ext_vector_type(8)));
 typedef float float4u __attribute__((ext_vector_type(4), aligned(4)));   // dword-aligned 16-B load
@@ -263,7 +265,7 @@ __device__ __forceinline__ void mb_body(const pano_patch &p, const int ch, const
     const MbGeom g = mb_geom(p);
     const int X0 = g.gx0 + 32 * tx0;                    // first output column of the workgroup
     const int px0 = X0 + 32 * tile;                     // ... of this wave
-    const int BW = MB_XT + 32 * sh.CM, GPR = BW >> 3, NGRP = 32 * GPR;
+    const int BW = MB_XT + 32 * sh.CM;
 
     f32x16 acc[NB];
 #pragma unroll
@@ -271,7 +273,6 @@ __device__ __forceinline__ void mb_body(const pano_patch &p, const int ch, const
 #pragma unroll
         for (int q = 0; q < 16; ++q) acc[i][q] = 0.0f;
 
-    const gcf32 src = alpha ? nullptr : (gcf32)(p.planes + (size_t)ch * p.vh * p.vpitch);
     // this wave's output plane as a buffer: base and size are wave-uniform
     const __amdgpu_buffer_rsrc_t dst = __builtin_amdgcn_make_buffer_rsrc(
         (void *)(p.blurred + (size_t)(level * 4 + ch) * p.ah * p.apitch), 0, p.ah * p.apitch * 4,
@@ -285,82 +286,103 @@ __device__ __forceinline__ void mb_body(const pano_patch &p, const int ch, const
     };
     const int my_lo = g.O0 - DMAX, my_hi = g.O1 + DMAX;             // bands this wave can use
 
-    // Band t (rows 32 t .. 32 t + 31) into registers, 8 consecutive columns per group; two
-    // bands in flight.  Every load is unconditional (clamped address, value selected
-    // afterwards): a load under a divergent branch is waited for on the spot.
-    // The registers keep what the loads return, untouched, plus a validity mask: anything
-    // computed from a loaded value here would be a wait right behind the load.
-    float pf[2][2][8];
-    unsigned pm[2][2];                                   // bit j: element j is a real sample
-    const bool vec_ok = p.vw >= 8;                       // uniform
+    // Band t (rows 32 t .. 32 t + 31) into registers, four consecutive columns (one 16-byte
+    // load) per chunk, chunks dealt out row-major so that a wave's load covers whole rows; two
+    // bands in flight.  Colour planes are read through a buffer descriptor: the address is one
+    // 32-bit offset, and a chunk that does not exist (row beyond V, column beyond the window)
+    // gets an out-of-range offset, for which the hardware returns zeros - exactly the value
+    // such samples must have (only zero taps reach them), so there are no masks and no selects.
+    // Every load is unconditional: a load under a divergent branch is waited for on the spot,
+    // and nothing is computed from a loaded value before the commit.
+    constexpr unsigned OOB = 0x80000000u;                // beyond any plane (planes < 2 GiB)
+    const int CPR = BW >> 2, NCH = 32 * CPR;             // chunks per band row / per band
+    float pf[2][3][4];
+    unsigned pm[2][3];                                   // alpha only: bit j = a real sample
+    // what does not change from band to band: a chunk's row, its place in the row and its
+    // four columns of V (first column, validity bits, contiguous or not)
+    int g_rr[3];
+    unsigned g_ci[3];                                    // c0 | bits << 16 | contig << 20 | c4 << 24
+#pragma unroll
+    for (int it = 0; it < 3; ++it) {
+        const int grp = tid + MB_THREADS * it;
+        const int rr = grp / CPR, c4 = grp - rr * CPR;
+        const shortx4 cm = *(const shortx4 *)(sh.col + (grp < NCH ? 4 * c4 : 0));
+        unsigned bits = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bits |= (cm[j] >= 0 ? 1u : 0u) << j;
+        const bool contig = cm[0] >= 0 && cm[3] - cm[0] == 3;
+        g_rr[it] = grp < NCH ? rr : -1;
+        g_ci[it] = (unsigned)(unsigned short)cm[0] | bits << 16 | (contig ? 1u << 20 : 0u) |
+                   (unsigned)c4 << 24;
+    }
+    const __amdgpu_buffer_rsrc_t srcb = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)(alpha ? p.planes : p.planes + (size_t)ch * p.vh * p.vpitch), 0,
+        p.vh * p.vpitch * 4, 0x00020000);
     auto fetch = [&](auto slot_c, const int t) {
         constexpr int S = decltype(slot_c)::value;
 #pragma unroll
-        for (int it = 0; it < 2; ++it) {
-            const int grp = tid + MB_THREADS * it;
-            const int rr = grp / GPR, bc0 = (grp - rr * GPR) * 8;
-            const int ry = reflect_101(32 * t + rr, p.h);
+        for (int it = 0; it < 3; ++it) {
+            const int rr = g_rr[it];
+            const unsigned ci = g_ci[it];
+            const int ry = reflect_101(32 * t + (rr < 0 ? 0 : rr), p.h);
             const int vr = ry - p.vy0;
-            const bool row_ok = grp < NGRP && (unsigned)vr < (unsigned)p.vh;
-            const short8 cm = *(const short8 *)(sh.col + (grp < NGRP ? bc0 : 0));
-            unsigned each = 0;                           // per-element validity
-#pragma unroll
-            for (int j = 0; j < 8; ++j) each |= (row_ok && cm[j] >= 0 ? 1u : 0u) << j;
-            // uniform base + 32-bit per-lane offset: one address register per load
-            if (src) {
-                const unsigned rowoff = (unsigned)(row_ok ? vr : 0) * (unsigned)p.vpitch;
-                const bool contig = cm[0] >= 0 && cm[7] - cm[0] == 7;
-                if (vec_ok) {
-                    const unsigned o = rowoff + (unsigned)(contig ? cm[0] : 0);
-                    const float4u lo4 = *(gcf32x4)(src + o);
-                    const float4u hi4 = *(gcf32x4)(src + o + 4);
+            const bool row_ok = rr >= 0 && (unsigned)vr < (unsigned)p.vh;
+            const bool contig = (ci >> 20) & 1u;
+            const unsigned bits = (ci >> 16) & 15u;
+            if (!alpha) {
+                const unsigned rowoff = (unsigned)vr * (unsigned)p.vpitch;
+                const unsigned voff = row_ok && contig ? (rowoff + (ci & 0xffffu)) * 4u : OOB;
+                const uint4 v = __builtin_bit_cast(
+                    uint4, __builtin_amdgcn_raw_buffer_load_b128(srcb, voff, 0, 0));
+                pf[S][it][0] = __uint_as_float(v.x);
+                pf[S][it][1] = __uint_as_float(v.y);
+                pf[S][it][2] = __uint_as_float(v.z);
+                pf[S][it][3] = __uint_as_float(v.w);
+                const bool ragged = row_ok && bits != 0 && !contig;
+                if (__any(ragged)) {                     // a patch / window edge inside the chunk: rare
+                    const shortx4 cm = *(const shortx4 *)(sh.col + 4 * (ci >> 24));
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        pf[S][it][j] = lo4[j];
-                        pf[S][it][4 + j] = hi4[j];
-                    }
-                }
-                pm[S][it] = row_ok && contig && vec_ok ? 0xffu : 0u;
-                const bool ragged = each != 0 && !(contig && vec_ok);
-                if (__any(ragged)) {                     // a patch / window edge inside the group: rare
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const float e = src[rowoff + (unsigned)(cm[j] >= 0 ? cm[j] : 0)];
+                        const unsigned o = ragged && cm[j] >= 0 ? (rowoff + (unsigned)cm[j]) * 4u : OOB;
+                        const float e = __uint_as_float(
+                            __builtin_amdgcn_raw_buffer_load_b32(srcb, o, 0, 0));
                         if (ragged) pf[S][it][j] = e;
                     }
-                    if (ragged) pm[S][it] = each;
                 }
             } else {
+                const shortx4 cm = *(const shortx4 *)(sh.col + 4 * (ci >> 24));
                 const unsigned rowoff = (unsigned)(p.y0 + (row_ok ? ry : 0)) * (unsigned)W +
                                         (unsigned)(p.x0 + p.vx0);
 #pragma unroll
-                for (int j = 0; j < 8; ++j)
+                for (int j = 0; j < 4; ++j)
                     pf[S][it][j] = __int_as_float(
                         (int)owner[rowoff + (unsigned)(cm[j] >= 0 ? cm[j] : 0)]);
-                pm[S][it] = each;
+                pm[S][it] = row_ok ? bits : 0u;
             }
         }
     };
     auto commit = [&](auto slot_c) {                     // registers -> hi / lo float16 in LDS
         constexpr int S = decltype(slot_c)::value;
 #pragma unroll
-        for (int it = 0; it < 2; ++it) {
-            const int grp = tid + MB_THREADS * it;
-            if (grp >= NGRP) break;
-            const int rr = grp / GPR, bc0 = (grp - rr * GPR) * 8;
-            half8 hi, lo;
+        for (int it = 0; it < 3; ++it) {
+            const int rr = g_rr[it];
+            if (rr < 0) continue;
+            half4 hi, lo;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
+            for (int j = 0; j < 4; ++j) {
                 float v = pf[S][it][j];
-                if (alpha) v = __float_as_int(v) == p.index ? 1.0f : 0.0f;   // stitcher.py:208
-                v = (pm[S][it] >> j) & 1u ? v : 0.0f;    // beyond V: only zero taps reach it
+                if (alpha) {                             // stitcher.py:208; beyond V: zero
+                    v = __float_as_int(v) == p.index ? 1.0f : 0.0f;
+                    v = (pm[S][it] >> j) & 1u ? v : 0.0f;
+                }
                 _Float16 a, b;
                 split16(v * MB_IN_SCALE, a, b);
                 hi[j] = a;
                 lo[j] = b;
             }
-            *(half8 *)(sh.hi + rr * MB_PITCH + bc0) = hi;
-            *(half8 *)(sh.lo + rr * MB_PITCH + bc0) = lo;
+            const int at = rr * MB_PITCH + 4 * (int)(g_ci[it] >> 24);
+            *(half4 *)(sh.hi + at) = hi;
+            *(half4 *)(sh.lo + at) = lo;
         }
     };
     auto next_wanted = [&](int t) {                      // first band after t that any wave wants
