@@ -738,6 +738,55 @@ def test_full_size_properties_1080p(eng):
     assert torch.equal(lin, lin_staged)
 
 
+def test_full_size_properties_32x4k(eng):
+    """BASELINE config 3 at full size (32 x 4K, native resolution: the bench workload),
+    through properties that need no oracle: the eight column strips of a multi-GPU run
+    compose the single-GPU mosaic bit for bit; the two-stream schedule (interior pixels
+    and the blur's work list on the side stream) equals the single-stream one bit for
+    bit; the interior shortcut moves no pixel by more than one level; a constant scene
+    comes back constant."""
+    import torch
+    from pano360_amd import dist as pdist
+    from pano360_amd import engine, synth
+    cfg = synth.CONFIGS["cfg3"]
+    n, w, h = cfg["n"], cfg["width"], cfg["height"]
+    rots, intrs = synth.make_cameras(n, w, h, sweep_deg=cfg["sweep_deg"])
+    rng = np.random.default_rng(3)
+    tile = rng.integers(0, 256, (240, 256, 3), dtype=np.uint8)
+    imgs = [np.roll(np.tile(tile, (h // 240, w // 256, 1)), 17 * i, axis=1) for i in range(n)]
+    shapes = [(h, w)] * n
+    frames = eng.upload_frames(imgs)
+    plan = engine.Plan(shapes, rots, intrs, True, 10 ** 9)
+    assert plan.shape == (2474, 13760)
+    whole, fl, valid, _ = eng.stitch(frames, plan, "multiband", 5, want_float=True)
+    # one stream
+    eng.overlap_interior = False
+    try:
+        serial, _, _, _ = eng.stitch(frames, engine.Plan(shapes, rots, intrs, True, 10 ** 9),
+                                     "multiband", 5)
+    finally:
+        eng.overlap_interior = True
+    assert torch.equal(whole, serial)
+    # column strips of 8 ranks, run one after the other on this GPU
+    strips, bounds = pdist.emulate_on_one_device(eng, imgs, rots, intrs, 5, 8)
+    assert bounds[-1] == plan.shape[1] and torch.equal(strips, whole)
+    # the interior shortcut against the full blend
+    full, fl_full, _, _ = eng.stitch(frames, engine.Plan(shapes, rots, intrs, True, 10 ** 9),
+                                     "multiband", 5, want_float=True, shortcut=False)
+    assert (whole.int() - full.int()).abs().max().item() <= 1
+    assert (fl - fl_full).abs().max().item() <= 1e-6
+    del strips, full, fl_full, serial
+    # a constant scene telescopes back to the constant
+    const = eng.upload_frames([np.full((h, w, 3), (200, 90, 30), np.uint8)] * 2)
+    flat, fl2, valid2, _ = eng.stitch(
+        [const[i % 2] for i in range(n)], engine.Plan(shapes, rots, intrs, True, 10 ** 9),
+        "multiband", 5, want_float=True)
+    want = torch.tensor([200, 90, 30], device=eng.device, dtype=torch.float32) / 255
+    v = valid2.bool()
+    assert (fl2[v] - want).abs().max().item() <= 2e-6 and (flat[~v] == 0).all()
+    assert torch.equal(valid2, valid)
+
+
 # ------------------------------------------------------------------ laplacian / ingest
 @pytest.mark.parametrize("case", ["a", "b", "c"])
 def test_laplacian_blending_matches_reference_golden(eng, case):
