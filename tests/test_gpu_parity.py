@@ -385,6 +385,43 @@ def test_fused_windows_on_a_wide_sweep(eng, oracle):
     assert np.abs(m1.cpu().numpy().astype(int) - ref_u8.astype(int)).max() <= 1
 
 
+@pytest.mark.parametrize("case", ["single", "disjoint", "tiny", "tall"])
+def test_degenerate_scenes_against_oracle(eng, oracle, case):
+    """Edge cases of the fused path against the oracle: one frame alone; two frames that do
+    not overlap (a hole in the coverage); frames smaller than the blur radius (the window
+    reflects more than once); a portrait frame.  Valid mask bit-exact, float mosaic within
+    1e-4, uint8 within one level, for the multiband, linear and paste blenders."""
+    from pano360_amd import engine, synth
+    if case == "single":
+        imgs, rots, intrs = synth.make_scene(1, 200, 120, sweep_deg=0.0, seed=1, kind="B")
+    elif case == "disjoint":
+        imgs, rots, intrs = synth.make_scene(2, 160, 100, step_deg=75.0, seed=2, kind="B")
+    elif case == "tiny":
+        imgs, rots, intrs = synth.make_scene(3, 24, 14, sweep_deg=50.0, jitter=0.01, seed=3,
+                                             kind="A")
+    else:
+        imgs, rots, intrs = synth.make_scene(4, 90, 260, sweep_deg=40.0, jitter=0.01, seed=4,
+                                             kind="B")
+    shapes = [im.shape[:2] for im in imgs]
+    frames = eng.upload_frames(imgs)
+    for blend in ("multiband", "linear", "none"):
+        plan = engine.Plan(shapes, rots, intrs, blend == "multiband", 10 ** 9)
+        mosaic, fl, valid, _ = eng.stitch(frames, plan, blend, 5, want_float=blend == "multiband")
+        ref = oracle.stitch(imgs, rots, intrs, blend, 5, max_resolution=10 ** 9,
+                            return_float=blend == "multiband")
+        ref_u8, ref_f = ref if blend == "multiband" else (ref, None)
+        got = mosaic.cpu().numpy()
+        assert got.shape == ref_u8.shape, (case, blend)
+        assert np.abs(got.astype(int) - ref_u8.astype(int)).max() <= (1 if blend == "multiband" else 0)
+        if blend == "multiband":
+            assert rel_l2(fl.cpu().numpy(), ref_f) <= REL_TOL, (case, blend)
+            _, ref_patches, _ = oracle.warp_all(imgs, rots, intrs, True, max_resolution=10 ** 9)
+            assert np.array_equal(valid.cpu().numpy().astype(bool),
+                                  oracle.valid(ref_patches, plan.shape)), case
+    if case == "disjoint":
+        assert not valid.cpu().numpy().all()             # there is a hole between the frames
+
+
 @pytest.mark.parametrize("kind", ["A", "B"])
 def test_interior_shortcut(eng, oracle, kind):
     """Default fused path: farther than the largest Gaussian radius from any seam
