@@ -167,11 +167,15 @@ int pano_warp_spherical(const uint8_t *frame, int sh, int sw,
  * cams[i].frame is warped into patches[i].planes ([3][vh][vpitch]).  Alpha and
  * mask are not produced: the fused path gets them from
  * pano_ownership_cameras.  cams, patches: dev arrays of n records;
- * max_vw / max_vh: the largest window among them (sizes the grid). */
+ * max_vw / max_vh: the largest window among them (sizes the grid).
+ * need (optional): the per-tile flags pano_blur_tiles writes (one byte per 32 x 32
+ * tile of every record, at patches[i].tiles_off); 64 x 4 pixel blocks none of whose
+ * tiles is needed are left unwritten - nothing reads them. */
 int pano_warp_windows(const pano_camera *cams, const pano_patch *patches, int n,
                       int max_vw, int max_vh, const double *sin_t,
                       const double *cos_t, const double *tan_p,
-                      const float *lut, int lut_stride, void *stream);
+                      const float *lut, int lut_stride, const uint8_t *need,
+                      void *stream);
 
 /* Ownership + validity from warped patches   stitcher.py:196-204, 266-271
  * owner = first-index argmax of the patches' alpha plane (planes[3]), -1 where
@@ -237,8 +241,16 @@ int pano_owned_regions(const int16_t *owner, int H, int W, int xs0, int xs1,
  * the matrix-core kernel).  It may be queued on another stream while the warp fills the
  * planes; the caller orders it before the pano_multiband_blur call on the same table
  * (same patches pointer and n) with an event.  Without it pano_multiband_blur does
- * the same work itself. */
+ * the same work itself.
+ * pano_blur_tiles (optional, tile grid 32 only, before the two above, same stream order):
+ * writes tile_flags from the interior map and warp_need = the tiles of window V whose
+ * pixels the blur (its band fetches reach 16 ceil(radius / 16) columns and two tile rows
+ * past an active tile) or the collapse will read, for pano_warp_windows; the following
+ * prepare / blur call on the same table does not recompute the flags. */
 int pano_blur_tile_grid(void);
+int pano_blur_tiles(const pano_patch *patches, int n, int max_aw, int max_ah, int W,
+                    int radius, const uint8_t *interior, uint8_t *tile_flags,
+                    uint8_t *warp_need, void *stream);
 int pano_multiband_blur_prepare(const pano_patch *patches, int n, int max_aw, int max_ah,
                                 int W, const uint8_t *interior, uint8_t *tile_flags,
                                 void *stream);

@@ -75,7 +75,8 @@ _SIGNATURES = {
     "pano_add_weights": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "pano_warp_spherical": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                  _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
-    "pano_warp_windows": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp]),
+    "pano_warp_windows": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
+    "pano_blur_tiles": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "pano_ownership": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp]),
     "pano_ownership_cameras": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "pano_owned_regions": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),

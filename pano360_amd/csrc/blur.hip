@@ -443,6 +443,18 @@ extern "C" int pano_multiband_blur(const pano_patch *patches, int n, int max_aw,
                        n_blur, interior, tile_flags, (hipStream_t)stream, "pano_multiband_blur");
 }
 
+extern "C" int pano_blur_tiles(const pano_patch *patches, int n, int max_aw, int max_ah, int W,
+                               int radius, const uint8_t *interior, uint8_t *tile_flags,
+                               uint8_t *warp_need, void *stream) {
+    PANO_REQUIRE(patches && interior && tile_flags, "pano_blur_tiles: null pointer");
+    PANO_REQUIRE(n >= 0 && n <= 32767 && W > 0 && max_aw >= 0 && max_ah >= 0 && radius >= 0,
+                 "pano_blur_tiles: bad argument");
+    PANO_REQUIRE(pano_blur_uses_mfma(), "pano_blur_tiles: needs the 32 x 32 tile grid");
+    if (n == 0 || max_aw == 0 || max_ah == 0) return PANO_OK;
+    return pano_tiles_blur_mfma(patches, n, max_aw, max_ah, W, radius, interior, tile_flags,
+                                warp_need, (hipStream_t)stream);
+}
+
 extern "C" int pano_multiband_blur_prepare(const pano_patch *patches, int n, int max_aw,
                                            int max_ah, int W, const uint8_t *interior,
                                            uint8_t *tile_flags, void *stream) {

@@ -651,6 +651,27 @@ __global__ __launch_bounds__(256) void tile_flags32_kernel(const pano_patch *__r
     flags[p.tiles_off + ty * g.ntx + tx] = active ? 1 : 0;
 }
 
+// Which tiles' pixels of the warped planes anything will read: the blur fetches, for a pair
+// of tile columns opened at an active column, the band columns [32 c - 16 CM, 32 c + 64 + 16 CM)
+// of every band within DMAX tiles of a wanted tile, and the collapse reads the non-interior
+// pixels (inside active tiles).  need = the active flags dilated by hx tile columns and vy
+// tile rows (a superset); the warp skips the rest of window V (about half of it on cfg3).
+__global__ __launch_bounds__(256) void warp_need_kernel(const pano_patch *__restrict__ table,
+                                                        const uint8_t *__restrict__ flags, int hx,
+                                                        int vy, uint8_t *__restrict__ need) {
+    const pano_patch p = table[blockIdx.z];
+    if (p.aw <= 0 || p.ah <= 0) return;
+    const MbGeom g = mb_geom(p);
+    const int nty = g.O1 - g.O0 + 1;
+    const int tx = blockIdx.x * 32 + (threadIdx.x & 31), ty = blockIdx.y * 8 + (threadIdx.x >> 5);
+    if (tx >= g.ntx || ty >= nty) return;
+    bool any = false;
+    for (int y = max(ty - vy, 0); y <= min(ty + vy, nty - 1) && !any; ++y)
+        for (int x = max(tx - hx, 0); x <= min(tx + hx, g.ntx - 1) && !any; ++x)
+            any = flags[p.tiles_off + y * g.ntx + x] != 0;
+    need[p.tiles_off + ty * g.ntx + tx] = any ? 1 : 0;
+}
+
 // The work list.  An item = (record, pair of adjacent tile columns); every item becomes one
 // workgroup per channel and level group.  A seam's active tiles span a few tile columns that
 // start at any parity and drift with the row, so (a) pairs open at every active column not
@@ -764,6 +785,39 @@ static int *g_item_counter = nullptr;
 static int g_item_cap = 0;
 static const pano_patch *g_prepared_table = nullptr;   // whose list `sorted` currently holds
 static int g_prepared_n = 0;
+static const pano_patch *g_flags_table = nullptr;      // whose tile flags pano_tiles_blur_mfma made
+static int g_flags_n = 0;
+
+static int launch_tile_flags(const pano_patch *table, int n, int ntx_max, int nty_max, int W,
+                             const uint8_t *interior, uint8_t *tile_flags, hipStream_t stream) {
+    dim3 grid(ceil_div(ntx_max, 32), ceil_div(nty_max, 8), n);
+    PANO_TIMED(PK_TILE_FLAGS, stream,
+               hipLaunchKernelGGL(tile_flags32_kernel, grid, dim3(256), 0, stream, table, interior,
+                                  ceil_div(W, 8), tile_flags));
+    PANO_LAUNCH_CHECK("tile_flags32_kernel");
+    return PANO_OK;
+}
+
+// Tile flags and, from them, the tiles of V the warp has to fill; the following
+// pano_prepare_blur_mfma / pano_launch_blur_mfma on the same table reuse the flags.
+int pano_tiles_blur_mfma(const pano_patch *table, int n, int max_aw, int max_ah, int W, int radius,
+                         const uint8_t *interior, uint8_t *tile_flags, uint8_t *warp_need,
+                         hipStream_t stream) {
+    const int ntx_max = (max_aw + 62) / 32, nty_max = (max_ah + 62) / 32;
+    if (int rc = launch_tile_flags(table, n, ntx_max, nty_max, W, interior, tile_flags, stream))
+        return rc;
+    g_flags_table = table;
+    g_flags_n = n;
+    if (warp_need) {
+        const int cm = (radius + 15) / 16 < 1 ? 1 : (radius + 15) / 16;
+        const int hx = (16 * cm + 31) / 32 + 1, vy = (cm + 1) / 2;
+        dim3 grid(ceil_div(ntx_max, 32), ceil_div(nty_max, 8), n);
+        hipLaunchKernelGGL(warp_need_kernel, grid, dim3(256), 0, stream, table, tile_flags, hx, vy,
+                           warp_need);
+        PANO_LAUNCH_CHECK("warp_need_kernel");
+    }
+    return PANO_OK;
+}
 
 int pano_prepare_blur_mfma(const pano_patch *table, int n, int max_aw, int max_ah, int W,
                            const uint8_t *interior, uint8_t *tile_flags, hipStream_t stream) {
@@ -772,11 +826,11 @@ int pano_prepare_blur_mfma(const pano_patch *table, int n, int max_aw, int max_a
                  MB_NEED_MAX);
     const uint8_t *flags = nullptr;
     if (interior) {
-        dim3 grid(ceil_div(ntx_max, 32), ceil_div(nty_max, 8), n);
-        PANO_TIMED(PK_TILE_FLAGS, stream,
-                   hipLaunchKernelGGL(tile_flags32_kernel, grid, dim3(256), 0, stream, table,
-                                      interior, ceil_div(W, 8), tile_flags));
-        PANO_LAUNCH_CHECK("tile_flags32_kernel");
+        if (g_flags_table != table || g_flags_n != n)
+            if (int rc = launch_tile_flags(table, n, ntx_max, nty_max, W, interior, tile_flags,
+                                           stream))
+                return rc;
+        g_flags_table = nullptr;
         flags = tile_flags;
     }
     // at most ceil(ntx / 2) pairs per record

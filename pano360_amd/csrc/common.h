@@ -83,6 +83,9 @@ int pano_launch_blur_mfma(const pano_patch *table, int n, int max_aw, int max_ah
                           hipStream_t stream);
 int pano_prepare_blur_mfma(const pano_patch *table, int n, int max_aw, int max_ah, int W,
                            const uint8_t *interior, uint8_t *tile_flags, hipStream_t stream);
+int pano_tiles_blur_mfma(const pano_patch *table, int n, int max_aw, int max_ah, int W, int radius,
+                         const uint8_t *interior, uint8_t *tile_flags, uint8_t *warp_need,
+                         hipStream_t stream);
 bool pano_blur_uses_mfma();
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 

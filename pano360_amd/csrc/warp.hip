@@ -66,10 +66,26 @@ __global__ __launch_bounds__(256) void warp_spherical_kernel(
 __global__ __launch_bounds__(256) void warp_windows_kernel(
     const pano_camera *__restrict__ cams, const pano_patch *__restrict__ patches,
     const double *__restrict__ sin_t, const double *__restrict__ cos_t,
-    const double *__restrict__ tan_p, const float *__restrict__ lut, int lut_stride) {
+    const double *__restrict__ tan_p, const float *__restrict__ lut, int lut_stride,
+    const uint8_t *__restrict__ need) {
     __shared__ float s_lut[256];
     const pano_patch p = patches[blockIdx.z];
     if ((int)blockIdx.x * 64 >= p.vw || (int)blockIdx.y * 4 >= p.vh) return;   // uniform
+    if (need) {
+        // the 32 x 32 tiles (grid of rectangle A, clamped) under this block's four rows and
+        // 64 columns: nothing will read the block if none of them is needed
+        const int ntx = ((p.ax0 + p.aw - 1) >> 5) - (p.ax0 >> 5) + 1;
+        const int nty = ((p.ay0 + p.ah - 1) >> 5) - (p.ay0 >> 5) + 1;
+        const int px0 = p.vx0 + (int)blockIdx.x * 64, py0 = p.vy0 + (int)blockIdx.y * 4;
+        const int ty0 = min(max((py0 >> 5) - (p.ay0 >> 5), 0), nty - 1);
+        const int ty1 = min(max(((py0 + 3) >> 5) - (p.ay0 >> 5), 0), nty - 1);
+        const int tx0 = min(max((px0 >> 5) - (p.ax0 >> 5), 0), ntx - 1);
+        const int tx1 = min(max(((px0 + 63) >> 5) - (p.ax0 >> 5), 0), ntx - 1);
+        bool any = false;
+        for (int ty = ty0; ty <= ty1; ++ty)
+            for (int tx = tx0; tx <= tx1; ++tx) any |= need[p.tiles_off + ty * ntx + tx] != 0;
+        if (!any) return;                                                       // uniform
+    }
     s_lut[threadIdx.y * 64 + threadIdx.x] =
         lut[(size_t)p.index * lut_stride + threadIdx.y * 64 + threadIdx.x];
     __syncthreads();
@@ -157,7 +173,8 @@ extern "C" int pano_warp_spherical(const uint8_t *frame, int sh, int sw,
 extern "C" int pano_warp_windows(const pano_camera *cams, const pano_patch *patches, int n,
                                  int max_vw, int max_vh, const double *sin_t,
                                  const double *cos_t, const double *tan_p,
-                                 const float *lut, int lut_stride, void *stream) {
+                                 const float *lut, int lut_stride, const uint8_t *need,
+                                 void *stream) {
     PANO_REQUIRE(cams && patches && sin_t && cos_t && tan_p && lut && lut_stride >= 0,
                  "pano_warp_windows: null pointer");
     PANO_REQUIRE(n >= 0 && n <= 65535 && max_vw >= 0 && max_vh >= 0,
@@ -166,7 +183,7 @@ extern "C" int pano_warp_windows(const pano_camera *cams, const pano_patch *patc
     dim3 block(64, 4), grid(ceil_div(max_vw, 64), ceil_div(max_vh, 4), n);
     PANO_TIMED(PK_WARP_WINDOWS, (hipStream_t)stream,
                hipLaunchKernelGGL(warp_windows_kernel, grid, block, 0, (hipStream_t)stream,
-                                  cams, patches, sin_t, cos_t, tan_p, lut, lut_stride));
+                                  cams, patches, sin_t, cos_t, tan_p, lut, lut_stride, need));
     PANO_LAUNCH_CHECK("warp_windows_kernel");
     return PANO_OK;
 }

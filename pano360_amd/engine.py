@@ -800,13 +800,13 @@ class Engine:
         done.record(self.side)
         return mosaic, fl, done
 
-    def prepare_blur_async(self, table, W, interior):
+    def prepare_blur_async(self, table, W, interior, flags=None):
         """Tile flags and the sorted work list of the blur (they depend on the records and
         the interior map, not on the warped planes) on the side stream, beside the warp.
         Returns (tile flags, event) for ``blur_and_compose(prepared=...)``."""
         torch = _torch()
-        flags = (torch.empty(max(table.n_tiles, 1), dtype=torch.uint8, device=self.device)
-                 if interior is not None else None)
+        if flags is None and interior is not None:
+            flags = torch.empty(max(table.n_tiles, 1), dtype=torch.uint8, device=self.device)
         uploaded = torch.cuda.Event()
         uploaded.record(torch.cuda.current_stream(self.device))      # the record table
         self.side.wait_event(uploaded)
@@ -834,7 +834,8 @@ class Engine:
         if n_blur:
             if prepared is not None:        # tile flags and work list queued on the side stream
                 flags, listed = prepared
-                torch.cuda.current_stream(self.device).wait_event(listed)
+                if listed is not None:
+                    torch.cuda.current_stream(self.device).wait_event(listed)
             else:
                 flags = (torch.empty(max(table.n_tiles, 1), dtype=torch.uint8,
                                      device=self.device) if interior is not None else None)
@@ -1038,12 +1039,29 @@ class Engine:
         patches = FusedPatches.from_regions(regions.raw(), regions.max_spans, plan.rects,
                                             resident, radius, (c0, c1), n_blur, self.device)
         table = patches.table
-        prepared = (self.prepare_blur_async(table, plan.shape[1], interior)
-                    if n_blur and self.overlap_interior else None)
+        # tile flags first (this stream): they tell the warp which blocks of the windows
+        # anything will read; the blur's work list then goes to the side stream
+        flags = need = None
+        # (worth it when the rectangles are wide against the blur's reach of ~3 tiles either
+        # side of a seam: 8 x 1080p -4 %; on 32 x 4K nearly every tile is within reach and the
+        # two small kernels in front of the warp cost more than they save)
+        wide = table.n and float(np.mean(table.host["aw"])) >= 768.0
+        choice = os.environ.get("PANO_WARP_NEED", "auto")
+        if (interior is not None and n_blur and self.lib.pano_blur_tile_grid() == 32
+                and (choice == "1" or (choice == "auto" and wide))):
+            torch = _torch()
+            flags = torch.empty(max(table.n_tiles, 1), dtype=torch.uint8, device=self.device)
+            need = torch.empty(max(table.n_tiles, 1), dtype=torch.uint8, device=self.device)
+            _lib.check(self.lib.pano_blur_tiles(
+                table.ptr, table.n, table.max_aw, table.max_ah, plan.shape[1], radius,
+                _ptr(interior), _ptr(flags), _ptr(need), self.stream()), "pano_blur_tiles")
+        prepared = (self.prepare_blur_async(table, plan.shape[1], interior, flags)
+                    if n_blur and self.overlap_interior else
+                    ((flags, None) if flags is not None else None))
         _lib.check(self.lib.pano_warp_windows(
             _ptr(cams), table.ptr, table.n, table.max_vw, table.max_vh, _ptr(plan.dev[0]),
-            _ptr(plan.dev[1]), _ptr(plan.dev[2]), *self._lut_args(luts), self.stream()),
-            "pano_warp_windows")
+            _ptr(plan.dev[1]), _ptr(plan.dev[2]), *self._lut_args(luts), _ptr(need),
+            self.stream()), "pano_warp_windows")
         mosaic, fl = self.blur_and_compose(table, owner, valid, plan.shape, n_levels,
                                            want_float, (c0, c1), interior, cams, plan, luts,
                                            out=early, prepared=prepared)

@@ -364,6 +364,31 @@ def test_fused_windows_equal_whole_patch_path(eng, name, levels):
     assert torch.equal(f1.view(torch.int32), f2.view(torch.int32))
 
 
+def test_warp_need_flags_change_nothing(eng, monkeypatch):
+    """The warp may skip the blocks of a window nobody reads (pano_blur_tiles' need flags):
+    with the flags forced on and off the mosaics are the same bit for bit, also after the
+    workspace was filled with other data."""
+    import torch
+    from pano360_amd import engine, synth
+    for seed, (w, h, sweep) in enumerate([(640, 360, 50.0), (960, 200, 30.0)]):
+        imgs, rots, intrs = synth.make_scene(4, w, h, sweep_deg=sweep, jitter=0.01, seed=50 + seed,
+                                             kind="A")
+        shapes = [im.shape[:2] for im in imgs]
+        frames = eng.upload_frames(imgs)
+        out = {}
+        for mode in ("1", "0", "1"):
+            monkeypatch.setenv("PANO_WARP_NEED", mode)
+            engine.FusedPatches._arenas.get((str(eng.device), "planes")).fill_(float("nan"))
+            m, f, _, _ = eng.stitch(frames, engine.Plan(shapes, rots, intrs, True, 10 ** 9),
+                                    "multiband", 5, want_float=True)
+            if mode in out:
+                assert torch.equal(out[mode][0], m)
+            out[mode] = (m, f)
+        assert torch.equal(out["0"][0], out["1"][0])
+        assert torch.equal(out["0"][1].view(torch.int32), out["1"][1].view(torch.int32))
+        assert not torch.isnan(out["1"][1]).any()
+
+
 def test_fused_windows_on_a_wide_sweep(eng, oracle):
     """Frames much wider than the blur radius, so the windows really cut work
     (and the 64-column / 128-row tile seams fall inside them)."""
