@@ -13,7 +13,7 @@ frames = [eng.upload_frames([synth.make_frame(i, cfg["width"], cfg["height"], "A
 lib = C.CDLL(os.path.join(os.path.dirname(engine.__file__), "libpano360_hip.so"))
 for it in range(3):
     plan = engine.Plan(shapes, rots, intrs, True, 10 ** 9)
-    eng.stitch(frames, plan, "multiband", 5)
+    eng.stitch(frames, plan, "multiband", int(os.environ.get("LEVELS", "5")))
     torch.cuda.synchronize()
     buf = (C.c_ulonglong * 24)()
     lib.pano_debug_stamps(buf, 1)
