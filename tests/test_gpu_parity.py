@@ -410,6 +410,22 @@ def test_fused_windows_on_a_wide_sweep(eng, oracle):
     assert np.abs(m1.cpu().numpy().astype(int) - ref_u8.astype(int)).max() <= 1
 
 
+@pytest.mark.parametrize("levels", [3, 7, 8])
+def test_level_counts_against_oracle(eng, oracle, levels):
+    """n_levels the goldens do not hold, 8 being the ABI's limit: two groups of levels per
+    workgroup and the widest Toeplitz tables (97- and 105-tap levels, C = 4)."""
+    from pano360_amd import engine, synth
+    imgs, rots, intrs = synth.make_scene(4, 400, 240, sweep_deg=60.0, jitter=0.01, seed=60 + levels,
+                                         kind="B")
+    plan = engine.Plan([im.shape[:2] for im in imgs], rots, intrs, True, 10 ** 9)
+    mosaic, fl, _, _ = eng.stitch(eng.upload_frames(imgs), plan, "multiband", levels,
+                                  want_float=True)
+    ref_u8, ref_f = oracle.stitch(imgs, rots, intrs, "multiband", levels, max_resolution=10 ** 9,
+                                  return_float=True)
+    assert rel_l2(fl.cpu().numpy(), ref_f) <= REL_TOL
+    assert np.abs(mosaic.cpu().numpy().astype(int) - ref_u8.astype(int)).max() <= 1
+
+
 @pytest.mark.parametrize("case", ["single", "disjoint", "tiny", "tall"])
 def test_degenerate_scenes_against_oracle(eng, oracle, case):
     """Edge cases of the fused path against the oracle: one frame alone; two frames that do
