@@ -182,6 +182,9 @@ extern "C" int pano_layout_windows(const int32_t *regions, int n, int max_spans,
                 ssz = (long)n_blur * 4 * r.vh * r.apitch;
                 ntile = (long)((r.aw + 63) / 64) * ((r.ah + 127) / 128);
             }
+            // the blur addresses a plane through a buffer descriptor with 32-bit byte offsets
+            PANO_REQUIRE((long)r.vh * r.vpitch * 4 < (1l << 31) && (long)r.ah * r.apitch * 4 < (1l << 31),
+                         "pano_layout_windows: a plane of record %d exceeds 2 GiB", k - 1);
             // arena offsets in floats, turned into addresses by pano_layout_place
             r.planes = (float *)(uintptr_t)planes;
             r.blurred = (float *)(uintptr_t)(blurred + lead);
