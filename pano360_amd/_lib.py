@@ -12,7 +12,8 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpano360_hip.so")
+# PANO_LIB: another build of the same library (A/B timing of kernel variants)
+LIB_PATH = os.environ.get("PANO_LIB") or os.path.join(_HERE, "libpano360_hip.so")
 
 MAX_TAPS = 129
 MAX_LEVELS = 8

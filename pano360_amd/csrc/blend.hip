@@ -177,7 +177,9 @@ __device__ __forceinline__ AlphaBound alpha_bound(const pano_camera *cam, const 
     return out;
 }
 
+#ifndef OWN_ROWS
 #define OWN_ROWS 16
+#endif
 
 __global__ __launch_bounds__(256) void ownership_cameras_kernel(
     const pano_camera *__restrict__ cams, int n, int H, int W, int xs0, int xs1,
