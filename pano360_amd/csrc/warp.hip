@@ -63,6 +63,13 @@ __global__ __launch_bounds__(256) void warp_spherical_kernel(
 }
 
 // Colour planes of window V of every patch in one launch (blockIdx.z = patch).
+// WARP_ROWS rows per thread (rows y and y + 4 of a 64 x 8 block): the kernel is bound by the
+// latency of its dependent loads (trig tables -> taps -> LUT), not by their number, and at
+// 22 registers the CU already holds all the waves it can; two independent pixels per thread
+// put twice as many loads in flight.  The two share their column's sin / cos.
+#ifndef WARP_ROWS
+#define WARP_ROWS 4
+#endif
 __global__ __launch_bounds__(256) void warp_windows_kernel(
     const pano_camera *__restrict__ cams, const pano_patch *__restrict__ patches,
     const double *__restrict__ sin_t, const double *__restrict__ cos_t,
@@ -70,15 +77,16 @@ __global__ __launch_bounds__(256) void warp_windows_kernel(
     const uint8_t *__restrict__ need) {
     __shared__ float s_lut[256];
     const pano_patch p = patches[blockIdx.z];
-    if ((int)blockIdx.x * 64 >= p.vw || (int)blockIdx.y * 4 >= p.vh) return;   // uniform
+    constexpr int BH = 4 * WARP_ROWS;
+    if ((int)blockIdx.x * 64 >= p.vw || (int)blockIdx.y * BH >= p.vh) return;   // uniform
     if (need) {
-        // the 32 x 32 tiles (grid of rectangle A, clamped) under this block's four rows and
-        // 64 columns: nothing will read the block if none of them is needed
+        // the 32 x 32 tiles (grid of rectangle A, clamped) under this block's rows and 64
+        // columns: nothing will read the block if none of them is needed
         const int ntx = ((p.ax0 + p.aw - 1) >> 5) - (p.ax0 >> 5) + 1;
         const int nty = ((p.ay0 + p.ah - 1) >> 5) - (p.ay0 >> 5) + 1;
-        const int px0 = p.vx0 + (int)blockIdx.x * 64, py0 = p.vy0 + (int)blockIdx.y * 4;
+        const int px0 = p.vx0 + (int)blockIdx.x * 64, py0 = p.vy0 + (int)blockIdx.y * BH;
         const int ty0 = min(max((py0 >> 5) - (p.ay0 >> 5), 0), nty - 1);
-        const int ty1 = min(max(((py0 + 3) >> 5) - (p.ay0 >> 5), 0), nty - 1);
+        const int ty1 = min(max(((py0 + BH - 1) >> 5) - (p.ay0 >> 5), 0), nty - 1);
         const int tx0 = min(max((px0 >> 5) - (p.ax0 >> 5), 0), ntx - 1);
         const int tx1 = min(max(((px0 + 63) >> 5) - (p.ax0 >> 5), 0), ntx - 1);
         bool any = false;
@@ -91,21 +99,37 @@ __global__ __launch_bounds__(256) void warp_windows_kernel(
     __syncthreads();
 
     const int x = blockIdx.x * 64 + threadIdx.x;
-    const int y = blockIdx.y * 4 + threadIdx.y;
-    if (x >= p.vw || y >= p.vh) return;
+    const int y0 = blockIdx.y * BH + threadIdx.y;
+    if (x >= p.vw || y0 >= p.vh) return;
     const pano_camera *cam = cams + p.index;
     const int sw = cam->sw, sh = cam->sh;
-    const int gx = p.x0 + p.vx0 + x, gy = p.y0 + p.vy0 + y;
-    float px, py;
-    map_pixel(cam->proj, sin_t[gx], cos_t[gx], tan_p[gy], sw, sh, px, py);
-    const Taps tp = make_taps(px, py, sw, sh);
-    const TapBytes tb = load_taps(cam->frame, sw, tp);
-    const size_t plane = (size_t)p.vh * p.vpitch;
-    const size_t o = (size_t)y * p.vpitch + x;
+    const int gx = p.x0 + p.vx0 + x;
+    const double s = sin_t[gx], c = cos_t[gx];
+    double t[WARP_ROWS];
 #pragma unroll
-    for (int k = 0; k < 3; ++k)
-        p.planes[k * plane + o] = lerp4(s_lut[tb.v[0][k]], s_lut[tb.v[1][k]], s_lut[tb.v[2][k]],
-                                        s_lut[tb.v[3][k]], tp);
+    for (int j = 0; j < WARP_ROWS; ++j)
+        t[j] = tan_p[p.y0 + p.vy0 + min(y0 + 4 * j, p.vh - 1)];
+    Taps tp[WARP_ROWS];
+    TapBytes tb[WARP_ROWS];
+#pragma unroll
+    for (int j = 0; j < WARP_ROWS; ++j) {
+        float px, py;
+        map_pixel(cam->proj, s, c, t[j], sw, sh, px, py);
+        tp[j] = make_taps(px, py, sw, sh);
+    }
+#pragma unroll
+    for (int j = 0; j < WARP_ROWS; ++j) tb[j] = load_taps(cam->frame, sw, tp[j]);
+    const size_t plane = (size_t)p.vh * p.vpitch;
+#pragma unroll
+    for (int j = 0; j < WARP_ROWS; ++j) {
+        const int y = y0 + 4 * j;
+        if (y >= p.vh) break;
+        const size_t o = (size_t)y * p.vpitch + x;
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+            p.planes[k * plane + o] = lerp4(s_lut[tb[j].v[0][k]], s_lut[tb[j].v[1][k]],
+                                            s_lut[tb[j].v[2][k]], s_lut[tb[j].v[3][k]], tp[j]);
+    }
 }
 
 __global__ __launch_bounds__(256) void add_weights_kernel(
@@ -180,7 +204,7 @@ extern "C" int pano_warp_windows(const pano_camera *cams, const pano_patch *patc
     PANO_REQUIRE(n >= 0 && n <= 65535 && max_vw >= 0 && max_vh >= 0,
                  "pano_warp_windows: bad argument");
     if (n == 0 || max_vw == 0 || max_vh == 0) return PANO_OK;
-    dim3 block(64, 4), grid(ceil_div(max_vw, 64), ceil_div(max_vh, 4), n);
+    dim3 block(64, 4), grid(ceil_div(max_vw, 64), ceil_div(max_vh, 4 * WARP_ROWS), n);
     PANO_TIMED(PK_WARP_WINDOWS, (hipStream_t)stream,
                hipLaunchKernelGGL(warp_windows_kernel, grid, block, 0, (hipStream_t)stream,
                                   cams, patches, sin_t, cos_t, tan_p, lut, lut_stride, need));

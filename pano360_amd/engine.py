@@ -635,7 +635,15 @@ class Engine:
         self._region_bufs = {}
         # second stream for the part of the collapse that needs no blurred planes
         self.side = torch.cuda.Stream(self.device)
-        self.overlap_interior = os.environ.get("PANO_SIDE_STREAM", "1") != "0"
+        # PANO_SIDE_STREAM: 0 = one stream (default); 1 = interior collapse and the blur's work
+        # list on the side stream; 2 = the work list only.  The side stream paid while the host
+        # kept the GPU waiting between the region search and the warp (2.76 -> 2.67 ms); with
+        # the native record layout there is no gap left to fill and one stream is as fast or
+        # faster (cfg3 medians of 5 x 20 stitches: 2.352 / 2.421 / 2.350 ms; cfg2 0.661 / 0.654 /
+        # 0.669), so it stays an option for hosts that are slower than this pool's.
+        mode = os.environ.get("PANO_SIDE_STREAM", "0")
+        self.overlap_interior = mode == "1"
+        self.overlap_prepare = mode in ("1", "2")
 
     # -- small cached tables ------------------------------------------------
     def stream(self):
@@ -1056,7 +1064,7 @@ class Engine:
                 table.ptr, table.n, table.max_aw, table.max_ah, plan.shape[1], radius,
                 _ptr(interior), _ptr(flags), _ptr(need), self.stream()), "pano_blur_tiles")
         prepared = (self.prepare_blur_async(table, plan.shape[1], interior, flags)
-                    if n_blur and self.overlap_interior else
+                    if n_blur and self.overlap_prepare else
                     ((flags, None) if flags is not None else None))
         _lib.check(self.lib.pano_warp_windows(
             _ptr(cams), table.ptr, table.n, table.max_vw, table.max_vh, _ptr(plan.dev[0]),

@@ -819,8 +819,8 @@ def test_full_size_properties_1080p(eng):
 def test_full_size_properties_32x4k(eng):
     """BASELINE config 3 at full size (32 x 4K, native resolution: the bench workload),
     through properties that need no oracle: the eight column strips of a multi-GPU run
-    compose the single-GPU mosaic bit for bit; the two-stream schedule (interior pixels
-    and the blur's work list on the side stream) equals the single-stream one bit for
+    compose the single-GPU mosaic bit for bit; the optional two-stream schedule (interior
+    pixels and the blur's work list on a side stream) equals the single-stream one bit for
     bit; the interior shortcut moves no pixel by more than one level; a constant scene
     comes back constant."""
     import torch
@@ -837,14 +837,14 @@ def test_full_size_properties_32x4k(eng):
     plan = engine.Plan(shapes, rots, intrs, True, 10 ** 9)
     assert plan.shape == (2474, 13760)
     whole, fl, valid, _ = eng.stitch(frames, plan, "multiband", 5, want_float=True)
-    # one stream
-    eng.overlap_interior = False
+    # two streams: interior collapse and the blur's work list on the side stream
+    eng.overlap_interior = eng.overlap_prepare = True
     try:
-        serial, _, _, _ = eng.stitch(frames, engine.Plan(shapes, rots, intrs, True, 10 ** 9),
-                                     "multiband", 5)
+        two, _, _, _ = eng.stitch(frames, engine.Plan(shapes, rots, intrs, True, 10 ** 9),
+                                  "multiband", 5)
     finally:
-        eng.overlap_interior = True
-    assert torch.equal(whole, serial)
+        eng.overlap_interior = eng.overlap_prepare = False
+    assert torch.equal(whole, two)
     # column strips of 8 ranks, run one after the other on this GPU
     strips, bounds = pdist.emulate_on_one_device(eng, imgs, rots, intrs, 5, 8)
     assert bounds[-1] == plan.shape[1] and torch.equal(strips, whole)
@@ -853,7 +853,7 @@ def test_full_size_properties_32x4k(eng):
                                      "multiband", 5, want_float=True, shortcut=False)
     assert (whole.int() - full.int()).abs().max().item() <= 1
     assert (fl - fl_full).abs().max().item() <= 1e-6
-    del strips, full, fl_full, serial
+    del strips, full, fl_full, two
     # a constant scene telescopes back to the constant
     const = eng.upload_frames([np.full((h, w, 3), (200, 90, 30), np.uint8)] * 2)
     flat, fl2, valid2, _ = eng.stitch(
