@@ -680,55 +680,71 @@ __global__ __launch_bounds__(256) void warp_need_kernel(const pano_patch *__rest
 // (in blockIdx order of a (pairs, records) grid the kernel ran at 60 % occupancy).
 //   item.x = record | first tile column << 16,  item.y = bands the workgroup will process
 #define MB_SORT_BINS 2048
-__global__ __launch_bounds__(64) void mb_items_kernel(const pano_patch *__restrict__ table,
-                                                      const uint8_t *__restrict__ flags,
-                                                      int2 *__restrict__ items,
-                                                      int *__restrict__ counter, int cap) {
+__global__ __launch_bounds__(256) void mb_items_kernel(const pano_patch *__restrict__ table,
+                                                       const uint8_t *__restrict__ flags,
+                                                       int2 *__restrict__ items,
+                                                       int *__restrict__ counter, int cap) {
     __shared__ int16_t s_start[1024];
+    __shared__ unsigned long long s_any[4];
+    __shared__ int s_base;
     const pano_patch p = table[blockIdx.x];
-    const int lane = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (p.aw <= 0 || p.ah <= 0) return;
     const MbGeom g = mb_geom(p);
     const int nty = g.O1 - g.O0 + 1;
+    const uint8_t *rec = flags ? flags + p.tiles_off : nullptr;
     int count = 0;
     bool covered = false;                                // column 0 of this chunk is in a pair
     for (int c0 = 0; c0 < g.ntx; c0 += 64) {
+        // which columns of the chunk hold an active tile: the four waves take the rows in turn
         const int tx = c0 + lane;
         bool any = false;
         if (tx < g.ntx) {
-            any = flags == nullptr;
-            for (int ty = 0; ty < nty && !any; ++ty)
-                any = flags[p.tiles_off + ty * g.ntx + tx] != 0;
+            any = rec == nullptr;
+            for (int ty = wave; ty < nty && !any; ty += 4) any = rec[ty * g.ntx + tx] != 0;
         }
-        unsigned long long m = __ballot(any);
+        const unsigned long long mine = __ballot(any);
+        __syncthreads();                                 // s_any of the previous chunk is read
+        if (lane == 0) s_any[wave] = mine;
+        __syncthreads();
+        unsigned long long m = s_any[0] | s_any[1] | s_any[2] | s_any[3];
         if (covered) m &= ~1ull;
         covered = false;
-        while (m) {                                      // uniform
+        while (m) {                                      // uniform across the block
             const int b = __ffsll((long long)m) - 1;
-            if (lane == 0 && count < 1024) s_start[count] = (int16_t)(c0 + b);
+            if (tid == 0 && count < 1024) s_start[count] = (int16_t)(c0 + b);
             ++count;
             m &= ~(3ull << b);
             covered = b == 63;
         }
     }
     count = count < 1024 ? count : 1024;                 // 65536 columns: beyond any mosaic
+    if (tid == 0) s_base = atomicAdd(counter, count);
     __syncthreads();
-    int base = 0;
-    if (lane == 0) base = atomicAdd(counter, count);
-    base = __shfl(base, 0, 64);
-    for (int k = lane; k < count; k += 64) {
+    const int base = s_base;
+    // One wave per pair: bands within two tiles of a wanted tile of the pair (what the kernel
+    // steps through).  Lane = band; its five rows' flags are independent loads.
+    for (int k = wave; k < count; k += 4) {
         const int tx0 = s_start[k];
-        // bands within two tiles of a wanted tile of the pair (what the kernel steps through)
-        int bands = 0, last = -1000;
-        for (int ty = 0; ty < nty; ++ty) {
-            bool want = flags == nullptr || flags[p.tiles_off + ty * g.ntx + tx0] != 0;
-            if (!want && tx0 + 1 < g.ntx) want = flags[p.tiles_off + ty * g.ntx + tx0 + 1] != 0;
-            if (!want) continue;
-            const int lo = ty - 2 > last + 1 ? ty - 2 : last + 1;
-            bands += ty + 2 - lo + 1;
-            last = ty + 2;
+        const bool two = tx0 + 1 < g.ntx;
+        int bands = 0;
+        for (int r0 = 0; r0 < nty; r0 += 64) {
+            const int ty = r0 + lane;
+            bool reach = false;
+            if (ty < nty) {
+                reach = rec == nullptr;
+                for (int d = -2; d <= 2 && rec; ++d) {
+                    const int y = ty + d;
+                    if (y < 0 || y >= nty) continue;
+                    reach |= rec[y * g.ntx + tx0] != 0;
+                    if (two) reach |= rec[y * g.ntx + tx0 + 1] != 0;
+                }
+            }
+            bands += __popcll(__ballot(reach));
         }
-        if (base + k < cap) items[base + k] = make_int2((int)blockIdx.x | (tx0 << 16), bands);
+        // the kernel also walks DMAX bands past either end of the strip
+        if (lane == 0 && base + k < cap)
+            items[base + k] = make_int2((int)blockIdx.x | (tx0 << 16), bands + 4);
     }
 }
 
@@ -844,7 +860,7 @@ int pano_prepare_blur_mfma(const pano_patch *table, int n, int max_aw, int max_a
         PANO_HIP(hipMalloc((void **)&g_item_counter, sizeof(int)));
         PANO_HIP(hipMemsetAsync(g_item_counter, 0, sizeof(int), stream));
     }
-    hipLaunchKernelGGL(mb_items_kernel, dim3(n), dim3(64), 0, stream, table, flags, g_item_buf,
+    hipLaunchKernelGGL(mb_items_kernel, dim3(n), dim3(256), 0, stream, table, flags, g_item_buf,
                        g_item_counter, cap);
     PANO_LAUNCH_CHECK("mb_items_kernel");
     hipLaunchKernelGGL(mb_sort_kernel, dim3(1), dim3(256), 0, stream, g_item_buf, g_item_counter,
