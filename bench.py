@@ -86,6 +86,19 @@ def pmc_traffic(name, workload=None):
     return None, None
 
 
+def measured_traffic(times, steps, workload):
+    """HBM bytes per step over all timed kernels, from the committed PMC summary of this
+    workload (per-launch bytes x launches per step); None when there is no summary."""
+    total, seen = 0.0, False
+    for name, (_, launches) in times.items():
+        per_launch, _ = pmc_traffic({"tile_flags_kernel": "tile_flags32_kernel"}.get(name, name),
+                                    workload)
+        if per_launch is not None:
+            total += per_launch * launches / steps
+            seen = True
+    return total if seen else None
+
+
 def roofline_for(times, plan, patches, n_levels, steps, px_active, workload=None):
     """Roofline entry of the kernel with the largest share of the timed region.
     Algorithmic work per launch counts the pixels that launch really produced
@@ -306,6 +319,13 @@ def main():
                 "mosaic_MPps": sets_per_step * M / (ms * 1e-3) / 1e6,
             },
             "kernel_ms_per_step": {k: v[0] / args.steps for k, v in sorted(times.items())},
+            "hbm_traffic": (lambda b: None if b is None else {
+                "GB_per_step_per_gpu": b / 1e9,
+                "GBps_per_gpu": b / (ms * 1e-3) / 1e9,
+                "frac_of_hbm_peak": b / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                "source": "profiles/*/pmc_traffic.json (FETCH_SIZE x 2 + WRITE_SIZE per launch) "
+                          "x launches per step, this rank's kernels"})(
+                measured_traffic(times, args.steps, args.workload)),
             "roofline": roofline_for(times, plan, patches, n_levels, args.steps,
                                      eng.active_tile_pixels(), args.workload),
             "active_megapixels": {
