@@ -761,13 +761,28 @@ __global__ __launch_bounds__(256) void mb_sort_kernel(const int2 *__restrict__ i
     for (int i = tid; i < n; i += 256)
         atomicAdd(&s_hist[MB_SORT_BINS - 1 - min(items[i].y, MB_SORT_BINS - 1)], 1);   // long first
     __syncthreads();
-    if (tid == 0) {
-        int run = 0;
-        for (int i = 0; i < MB_SORT_BINS; ++i) {
-            const int c = s_hist[i];
-            s_hist[i] = run;
-            run += c;
-        }
+    // exclusive prefix over the bins: eight bins per thread, then a scan of the 256 sums
+    __shared__ int s_part[256];
+    constexpr int PER = MB_SORT_BINS / 256;
+    int mine[PER], sum = 0;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        mine[j] = s_hist[tid * PER + j];
+        sum += mine[j];
+    }
+    s_part[tid] = sum;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {            // Hillis-Steele, inclusive
+        const int v = tid >= off ? s_part[tid - off] : 0;
+        __syncthreads();
+        s_part[tid] += v;
+        __syncthreads();
+    }
+    int run = s_part[tid] - sum;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        s_hist[tid * PER + j] = run;
+        run += mine[j];
     }
     __syncthreads();
     for (int i = tid; i < n; i += 256) {
