@@ -508,14 +508,15 @@ class FusedPatches:
         return have
 
     @classmethod
-    def from_regions(cls, raw, max_spans, rects, have, radius, strip, n_blur, device):
+    def from_regions(cls, raw, max_spans, rects, have, radius, strip, n_blur, device, rec=None):
         """The record table straight from the region search's output: one native call
         lays out rectangles, pitches, arena offsets and tile offsets
         (``pano_layout_windows``); the arenas are (re)used as in ``__init__``.
         ``have``: uint8 [n], 0 = that camera's frame is not resident."""
         lib = _lib.lib()
         n = len(rects)
-        rec = np.zeros(n * max_spans, dtype=PATCH_DTYPE)
+        if rec is None:
+            rec = np.zeros(n * max_spans, dtype=PATCH_DTYPE)
         lay = _lib.Layout()
         raw = np.ascontiguousarray(raw, np.int32)
         rects = np.ascontiguousarray(rects, np.int32)
@@ -1042,10 +1043,14 @@ class Engine:
                  if interior is not None and self.overlap_interior else None)
         # the host is on the critical path from here to the warp: one native call lays out
         # the records (rectangles A and V, arena offsets, tile offsets)
+        # (everything that does not need the regions is made ready before the wait)
         resident = np.zeros(plan.n, np.uint8)
         resident[[i for i in have if 0 <= i < plan.n]] = 1
-        patches = FusedPatches.from_regions(regions.raw(), regions.max_spans, plan.rects,
-                                            resident, radius, (c0, c1), n_blur, self.device)
+        rects32 = np.ascontiguousarray(plan.rects, np.int32)
+        records = np.zeros(plan.n * regions.max_spans, dtype=PATCH_DTYPE)
+        patches = FusedPatches.from_regions(regions.raw(), regions.max_spans, rects32,
+                                            resident, radius, (c0, c1), n_blur, self.device,
+                                            records)
         table = patches.table
         # tile flags first (this stream): they tell the warp which blocks of the windows
         # anything will read; the blur's work list then goes to the side stream
