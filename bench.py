@@ -60,17 +60,6 @@ def workload(name):
     return dict(synth.CONFIGS[name])
 
 
-def kernel_times(lib):
-    import ctypes as C
-    out = {}
-    for kid in range(lib.pano_kernel_count()):
-        ms, n = C.c_double(), C.c_int()
-        lib.pano_timing_read(kid, C.byref(ms), C.byref(n))
-        if n.value:
-            out[lib.pano_kernel_name(kid).decode()] = (ms.value, n.value)
-    return out
-
-
 def pmc_traffic(name, workload=None):
     """HBM bytes per launch of kernel `name` from the committed PMC summary of this
     same command (profiles/<round>/pmc_traffic.json, written from tools/pmc.sh
@@ -182,14 +171,14 @@ def timed_steps(eng, step, steps, warmup, fence):
     for _ in range(warmup):
         step()
     fence()
-    eng.lib.pano_timing_enable(1)
+    eng.timing(True)
     t0 = time.perf_counter()
     for _ in range(steps):
         result = step()
     fence()
     elapsed = time.perf_counter() - t0
-    times = kernel_times(eng.lib)
-    eng.lib.pano_timing_enable(0)
+    times = eng.kernel_times()
+    eng.timing(False)
     return elapsed, result, times
 
 

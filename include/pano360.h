@@ -9,14 +9,20 @@
  * (INTEGRATION.md shows the binding).
  *
  * Conventions
+ *   - every kernel-launching entry point takes a context (pano_ctx, below) first:
+ *     it names the device and the stream the work is enqueued on, carries the
+ *     option switches and owns everything the library remembers between calls
+ *     (work-list buffers of the blur, device copies and operand tables of the
+ *     tap sets it has seen, the timing registry).  There is no process-wide
+ *     state: two contexts - two streams, two devices, two host threads - do not
+ *     see each other.  A context is not thread-safe: one per host thread;
  *   - every pointer marked "dev" is a device (HBM) pointer owned by the
  *     caller; "host" pointers are ordinary host memory read before return;
- *   - `stream` is a hipStream_t passed as void* (NULL = default stream); all
- *     work is enqueued asynchronously on it, nothing synchronises;
+ *   - all work is enqueued asynchronously on the context's stream, nothing
+ *     synchronises;
  *   - return value: 0 on success, a negative PANO_E* code otherwise, with a
  *     thread-local message available from pano_last_error();
- *   - no exceptions cross the boundary; the only global state is the
- *     optional timing registry (pano_timing_*).
+ *   - no exceptions cross the boundary.
  *
  * Layouts
  *   frame      uint8  [H][W][3]      as cv2.imread hands it to the reference
@@ -130,22 +136,53 @@ int pano_device_count(void);
 /* Row pitch (in floats) used for every float plane of width w. */
 int pano_pitch(int w);
 
+/* The context (no reference counterpart: the reference is one Python process
+ * with OpenCV's global state).  pano_ctx_create binds a device and a stream
+ * (a hipStream_t passed as void*, NULL = the default stream); the caller keeps
+ * the stream alive for as long as the context uses it.  pano_ctx_set_stream
+ * re-targets later calls (work already queued stays where it is; state built
+ * on the old stream - tile flags, work lists, tap tables - is ordered by the
+ * caller with events, as for any two streams).  pano_ctx_destroy waits for the
+ * context's stream and frees what the context owns.
+ * Options (pano_ctx_set_option / pano_ctx_get_option):
+ *   PANO_OPT_BLUR_KERNEL  which kernels run the multiband Gaussian levels:
+ *                         PANO_BLUR_MFMA (default) = the fused matrix-core kernel
+ *                         (split float16 operands, float32 accumulate),
+ *                         PANO_BLUR_VALU = separate row / column passes in float32
+ *                         on the vector ALU (one FMA per tap)
+ *   PANO_OPT_OWN_PRUNE    1 (default) = pano_ownership_cameras skips cameras that
+ *                         rigorous bounds exclude; 0 = evaluate every camera
+ *   PANO_OPT_COLS_PIPE    vector-ALU column pass: 1 = software-pipelined trips
+ *                         (default 0, measured slower on config 3) */
+typedef struct pano_ctx pano_ctx;
+#define PANO_OPT_BLUR_KERNEL 0
+#define PANO_OPT_OWN_PRUNE 1
+#define PANO_OPT_COLS_PIPE 2
+#define PANO_OPT_COUNT 3
+#define PANO_BLUR_MFMA 0
+#define PANO_BLUR_VALU 1
+int pano_ctx_create(int device, void *stream, pano_ctx **out);
+int pano_ctx_destroy(pano_ctx *ctx);
+int pano_ctx_set_stream(pano_ctx *ctx, void *stream);
+int pano_ctx_set_option(pano_ctx *ctx, int option, int value);
+int pano_ctx_get_option(const pano_ctx *ctx, int option, int *value);
+
 /* Instrumentation for bench.py (no reference counterpart): when enabled every
- * kernel launch is bracketed by HIP events recorded on its own stream.
- * pano_timing_read waits for kernel class `kid`'s events and returns the
- * summed duration in ms and the number of launches since the last enable. */
-int pano_timing_enable(int on);
+ * kernel launch of this context is bracketed by HIP events recorded on its
+ * stream.  pano_timing_read waits for kernel class `kid`'s events and returns
+ * the summed duration in ms and the number of launches since the last enable. */
+int pano_timing_enable(pano_ctx *ctx, int on);
 int pano_kernel_count(void);
 const char *pano_kernel_name(int kid);
-int pano_timing_read(int kid, double *total_ms, int *launches);
+int pano_timing_read(pano_ctx *ctx, int kid, double *total_ms, int *launches);
 
 /* _add_weights                                        stitcher.py:251-263
  * frame uint8 [h][w][3] -> rgba float32 [h][w][4] interleaved (the array the
  * reference leaves in reg.img).  lut255: dev float[256] = float32(i)/255
  * (built on the host with NumPy); hat_x / hat_y: dev double[w] / [h]. */
-int pano_add_weights(const uint8_t *frame, int h, int w, const float *lut255,
-                     const double *hat_x, const double *hat_y, float *rgba,
-                     void *stream);
+int pano_add_weights(pano_ctx *ctx, const uint8_t *frame, int h, int w,
+                     const float *lut255, const double *hat_x, const double *hat_y,
+                     float *rgba);
 
 /* Inverse map + mask + bilinear REFLECT remap of one whole patch
  *                                       stitcher.py:300-317 (+ cv2.remap)
@@ -155,13 +192,11 @@ int pano_add_weights(const uint8_t *frame, int h, int w, const float *lut255,
  * (gx0, gy0) = patch origin in the mosaic, pw x ph = patch size.
  * Outputs: planes [4][ph][pitch] (alpha already multiplied by ~mask, :317),
  * mask [ph][pw]; map_x / map_y float [ph][pw] optional (NULL to skip). */
-int pano_warp_spherical(const uint8_t *frame, int sh, int sw,
-                        const double *proj, const double *sin_t,
-                        const double *cos_t, const double *tan_p,
-                        const float *lut255, const double *hat_x,
+int pano_warp_spherical(pano_ctx *ctx, const uint8_t *frame, int sh, int sw,
+                        const double *proj, const double *sin_t, const double *cos_t,
+                        const double *tan_p, const float *lut255, const double *hat_x,
                         const double *hat_y, int gx0, int gy0, int pw, int ph,
-                        float *planes, uint8_t *mask, float *map_x,
-                        float *map_y, void *stream);
+                        float *planes, uint8_t *mask, float *map_x, float *map_y);
 
 /* Same arithmetic, colour only, for window V of EVERY patch in one launch:
  * cams[i].frame is warped into patches[i].planes ([3][vh][vpitch]).  Alpha and
@@ -171,18 +206,17 @@ int pano_warp_spherical(const uint8_t *frame, int sh, int sw,
  * need (optional): the per-tile flags pano_blur_tiles writes (one byte per 32 x 32
  * tile of every record, at patches[i].tiles_off); 64 x 4 pixel blocks none of whose
  * tiles is needed are left unwritten - nothing reads them. */
-int pano_warp_windows(const pano_camera *cams, const pano_patch *patches, int n,
-                      int max_vw, int max_vh, const double *sin_t,
-                      const double *cos_t, const double *tan_p,
-                      const float *lut, int lut_stride, const uint8_t *need,
-                      void *stream);
+int pano_warp_windows(pano_ctx *ctx, const pano_camera *cams, const pano_patch *patches,
+                      int n, int max_vw, int max_vh, const double *sin_t,
+                      const double *cos_t, const double *tan_p, const float *lut,
+                      int lut_stride, const uint8_t *need);
 
 /* Ownership + validity from warped patches   stitcher.py:196-204, 266-271
  * owner = first-index argmax of the patches' alpha plane (planes[3]), -1 where
  * all are 0; valid = OR over patches of ~mask.  patches: dev array of n
  * pano_patch with 4 planes and a mask, V = whole patch. */
-int pano_ownership(const pano_patch *patches, int n, int H, int W,
-                   int16_t *owner, uint8_t *valid, void *stream);
+int pano_ownership(pano_ctx *ctx, const pano_patch *patches, int n, int H, int W,
+                   int16_t *owner, uint8_t *valid);
 
 /* The same two maps straight from the cameras (no pixel data is read): for
  * every mosaic pixel in columns [xs0, xs1) and every camera whose patch
@@ -190,12 +224,11 @@ int pano_ownership(const pano_patch *patches, int n, int H, int W,
  * re-evaluated exactly as pano_warp_spherical does - but only for the cameras
  * that can still win: per 64 x 16 tile, cameras whose alpha is bounded (interval
  * arithmetic on the ray, rigorous) below another camera's lower bound are
- * skipped, which changes neither map (PANO_OWN_PRUNE=0 disables it).
+ * skipped, which changes neither map (option PANO_OPT_OWN_PRUNE = 0 disables it).
  * cams: dev array. */
-int pano_ownership_cameras(const pano_camera *cams, int n, int H, int W,
-                           int xs0, int xs1, const double *sin_t,
-                           const double *cos_t, const double *tan_p,
-                           int16_t *owner, uint8_t *valid, void *stream);
+int pano_ownership_cameras(pano_ctx *ctx, const pano_camera *cams, int n, int H, int W,
+                           int xs0, int xs1, const double *sin_t, const double *cos_t,
+                           const double *tan_p, int16_t *owner, uint8_t *valid);
 
 /* Where each patch owns pixels inside the column strip [xs0, xs1), one record
  * of 5 + 2*max_spans int32 per patch:
@@ -205,9 +238,9 @@ int pano_ownership_cameras(const pano_camera *cams, int n, int H, int W,
  * the patch owns at least one pixel, runs closer than min_gap columns merged
  * (so that the spans' rectangles A stay disjoint), at most max_spans (later
  * runs are folded into the last span).  marks: dev uint8 [n][W] workspace. */
-int pano_owned_regions(const int16_t *owner, int H, int W, int xs0, int xs1,
+int pano_owned_regions(pano_ctx *ctx, const int16_t *owner, int H, int W, int xs0, int xs1,
                        int n, int min_gap, int max_spans, uint8_t *marks,
-                       int32_t *regions, void *stream);
+                       int32_t *regions);
 
 /* The n_levels-1 Gaussian blurs of every patch  stitcher.py:207-208, 218, 226
  * (cv2.GaussianBlur(warped, (0,0), 4*sqrt(2k+1)) with the alpha channel
@@ -217,23 +250,24 @@ int pano_owned_regions(const int16_t *owner, int H, int W, int xs0, int xs1,
  * all levels and one column pass per level through patches[i].scratch).
  * patches: dev array of n records with planes and blurred set (scratch only for
  * the vector-ALU kernels); max_aw / max_vh / max_ah: the largest extents.
- * taps: dev float, n_blur tables laid out back to back; table k has
+ * taps: HOST float, n_blur tables laid out back to back; table k has
  * ntaps[k] + PANO_TAP_PAD floats: PANO_TAP_LEAD + ((R - r_k) & 3) zeros, the
  * ntaps[k] taps, zeros, where r_k = ntaps[k] / 2 and R = max r_k (the extra
  * zeros keep the row pass's 16-byte LDS reads aligned for every level).
- * ntaps: host int[n_blur].  Writes patches[i].blurred.  The first call with a
- * given (taps pointer, apertures) builds that tap set's operand tables on the
- * device and keeps them (at most 8 distinct sets per process).
+ * ntaps: host int[n_blur].  Writes patches[i].blurred.  The context keeps a
+ * device copy (and the matrix-core operand tables) of every tap set it has
+ * seen, keyed on the apertures and the tap VALUES; the first call with a new
+ * set uploads it in stream order, later calls only hash ~400 floats.
  * interior (optional, with tile_flags): the map of pano_interior_map; tiles
  * that hold only interior pixels (and the intermediate rows only they would
  * read) are skipped.  tile_flags: dev uint8, one entry per tile of every record,
  * record i's entries starting at patches[i].tiles_off, written here.  The tile
- * grid is the library's choice, reported by pano_blur_tile_grid():
+ * grid follows the context's PANO_OPT_BLUR_KERNEL, reported by pano_blur_tile_grid():
  *   32: 32 x 32 tiles anchored at multiples of 32 in patch coordinates, i.e.
  *       ((ax0+aw-1)>>5) - (ax0>>5) + 1 per row, ((ay0+ah-1)>>5) - (ay0>>5) + 1
  *       rows (the matrix-core kernel, default);
  *    0: 64-column x 128-row tiles relative to A, ceil(aw/64) per row,
- *       ceil(ah/128) rows (the vector-ALU kernels, PANO_BLUR=valu).
+ *       ceil(ah/128) rows (the vector-ALU kernels, PANO_BLUR_VALU).
  * The matrix-core kernel computes in split float16 (hi + lo, three products)
  * with float32 accumulation and does not use patches[i].scratch.
  * pano_multiband_blur_prepare (optional): the part of the call that depends on the
@@ -247,18 +281,17 @@ int pano_owned_regions(const int16_t *owner, int H, int W, int xs0, int xs1,
  * pixels the blur (its band fetches reach 16 ceil(radius / 16) columns and two tile rows
  * past an active tile) or the collapse will read, for pano_warp_windows; the following
  * prepare / blur call on the same table does not recompute the flags. */
-int pano_blur_tile_grid(void);
-int pano_blur_tiles(const pano_patch *patches, int n, int max_aw, int max_ah, int W,
-                    int radius, const uint8_t *interior, uint8_t *tile_flags,
-                    uint8_t *warp_need, void *stream);
-int pano_multiband_blur_prepare(const pano_patch *patches, int n, int max_aw, int max_ah,
-                                int W, const uint8_t *interior, uint8_t *tile_flags,
-                                void *stream);
-int pano_multiband_blur(const pano_patch *patches, int n, int max_aw,
+int pano_blur_tile_grid(const pano_ctx *ctx);
+int pano_blur_tiles(pano_ctx *ctx, const pano_patch *patches, int n, int max_aw,
+                    int max_ah, int W, int radius, const uint8_t *interior,
+                    uint8_t *tile_flags, uint8_t *warp_need);
+int pano_multiband_blur_prepare(pano_ctx *ctx, const pano_patch *patches, int n,
+                                int max_aw, int max_ah, int W, const uint8_t *interior,
+                                uint8_t *tile_flags);
+int pano_multiband_blur(pano_ctx *ctx, const pano_patch *patches, int n, int max_aw,
                         int max_vh, int max_ah, const int16_t *owner, int W,
                         const float *taps, const int *ntaps, int n_blur,
-                        const uint8_t *interior, uint8_t *tile_flags,
-                        void *stream);
+                        const uint8_t *interior, uint8_t *tile_flags);
 
 /* Interior map (no reference counterpart: an exact-in-real-arithmetic property
  * of stitcher.py:210-241).  Where every pixel within `radius` (the largest
@@ -270,21 +303,21 @@ int pano_multiband_blur(const pano_patch *patches, int n, int max_aw,
  * (conservative: tested on whole blocks); block_owner: dev int16 workspace,
  * twice that shape ([2][ceil(H/8)][ceil(W/8)]).  Only columns [xs0, xs1) of
  * owner are read. */
-int pano_interior_map(const int16_t *owner, int H, int W, int xs0, int xs1,
-                      int radius, int16_t *block_owner, uint8_t *interior,
-                      void *stream);
+int pano_interior_map(pano_ctx *ctx, const int16_t *owner, int H, int W, int xs0, int xs1,
+                      int radius, int16_t *block_owner, uint8_t *interior);
 
 /* Host side of the fused path: the record table from the owned regions
  * (no reference counterpart; the arithmetic of "Windows" above).  regions: host copy
  * of pano_owned_regions' output, [n][5 + 2 max_spans]; rects: host int32 [n][4] =
  * patch rectangles (y0, y1, x0, x1) in mosaic coordinates; have (optional): [n], 0 =
  * that camera's frame is not resident; radius = the largest Gaussian radius;
- * [xs0, xs1) = the mosaic columns to produce.  Writes one record per (camera, owned
+ * [xs0, xs1) = the mosaic columns to produce; tile_grid = pano_blur_tile_grid() of the
+ * context that will run the blur (32 or 0).  Writes one record per (camera, owned
  * column span) that reaches the strip, in camera order, with rectangles A and V,
  * pitches, tile offsets, and - until pano_layout_place - arena OFFSETS in the pointer
  * fields.  pano_layout_place turns them into addresses inside the three arenas
  * (blurred aligned up to 128 bytes; blurred / scratch may be NULL when unused). */
-int pano_layout_windows(const int32_t *regions, int n, int max_spans,
+int pano_layout_windows(int tile_grid, const int32_t *regions, int n, int max_spans,
                         const int32_t *rects, const uint8_t *have, int radius,
                         int xs0, int xs1, int n_blur, pano_patch *records, int cap,
                         pano_layout *out);
@@ -306,14 +339,12 @@ int pano_layout_place(pano_patch *records, int n_records, void *planes, void *bl
  * on the owner map and the frames, not on the patches (patches / valid may be
  * NULL), so this part can be queued on another stream beside the warp and the
  * blur; 2 = the remaining pixels only. */
-int pano_multiband_compose(const pano_patch *patches, int n, int H, int W,
-                           int xs0, int xs1, int n_levels,
-                           const int16_t *owner, const uint8_t *valid,
-                           const uint8_t *interior, const pano_camera *cams,
-                           const double *sin_t, const double *cos_t,
-                           const double *tan_p, const float *lut,
-                           int lut_stride, uint8_t *mosaic, float *mosaic_f32,
-                           int part, void *stream);
+int pano_multiband_compose(pano_ctx *ctx, const pano_patch *patches, int n, int H, int W,
+                           int xs0, int xs1, int n_levels, const int16_t *owner,
+                           const uint8_t *valid, const uint8_t *interior,
+                           const pano_camera *cams, const double *sin_t,
+                           const double *cos_t, const double *tan_p, const float *lut,
+                           int lut_stride, uint8_t *mosaic, float *mosaic_f32, int part);
 
 /* linear_blend (linear != 0) or no_blend (linear == 0) of the mosaic columns
  * [xs0, xs1) straight from the frames         stitcher.py:160-183 + :300-317
@@ -321,11 +352,10 @@ int pano_multiband_compose(const pano_patch *patches, int n, int H, int W,
  * patch rectangles, stitcher.py:289-291) are mapped, sampled and combined in
  * index order.  cams: dev array with frame pointers set.  valid (optional,
  * dev uint8 [H][W]) receives _valid (stitcher.py:266-271) for the strip. */
-int pano_blend_cameras(const pano_camera *cams, int n, int H, int W, int xs0,
-                       int xs1, int linear, const double *sin_t,
-                       const double *cos_t, const double *tan_p,
-                       const float *lut, int lut_stride, uint8_t *mosaic,
-                       uint8_t *valid, void *stream);
+int pano_blend_cameras(pano_ctx *ctx, const pano_camera *cams, int n, int H, int W,
+                       int xs0, int xs1, int linear, const double *sin_t,
+                       const double *cos_t, const double *tan_p, const float *lut,
+                       int lut_stride, uint8_t *mosaic, uint8_t *valid);
 
 /* Overlap statistics of equalize_gains           stitcher.py:36-63
  * For each pair, every pixel (x, y) of frame i is looked up in frame j as
@@ -348,33 +378,34 @@ int pano_blend_cameras(const pano_camera *cams, int n, int H, int W, int xs0,
  * Sums are taken in double in a fixed order (the reference's np.mean sums in
  * float32 pairwise; the two agree to ~1e-7 relative). */
 int pano_overlap_blocks(int h, int w);
-int pano_overlap_stats(const pano_camera *cams, const pano_pair *pairs,
+int pano_overlap_stats(pano_ctx *ctx, const pano_camera *cams, const pano_pair *pairs,
                        int n_pairs, int h, int w, int bw0, const float *lut255,
-                       double *partials, double *stats, void *stream);
+                       double *partials, double *stats);
 
 /* linear_blend on warped patches                        stitcher.py:171-183 */
-int pano_linear_blend(const pano_patch *patches, int n, int H, int W,
-                      uint8_t *mosaic, void *stream);
+int pano_linear_blend(pano_ctx *ctx, const pano_patch *patches, int n, int H, int W,
+                      uint8_t *mosaic);
 
 /* no_blend                                              stitcher.py:160-168 */
-int pano_no_blend(const pano_patch *patches, int n, int H, int W,
-                  uint8_t *mosaic, void *stream);
+int pano_no_blend(pano_ctx *ctx, const pano_patch *patches, int n, int H, int W,
+                  uint8_t *mosaic);
 
 /* crop_mosaic rectangle                                 stitcher.py:340-369
  * valid: dev uint8 [H][W].  heights: dev int32 [H][W] workspace.
  * result: dev int64[6] = {found, y0, x0, h, w, area}. */
-int pano_crop_rect(const uint8_t *valid, int H, int W, int32_t *heights,
-                   int64_t *result, void *stream);
+int pano_crop_rect(pano_ctx *ctx, const uint8_t *valid, int H, int W, int32_t *heights,
+                   int64_t *result);
 
 /* Separable symmetric filter on one float plane, BORDER_REFLECT_101
  *                     cv2.GaussianBlur at features.py:24 / stitcher.py:226
- * taps: dev padded table (see pano_multiband_blur); tmp: dev [h][pitch]. */
-int pano_blur_plane(const float *src, float *dst, float *tmp, int h, int w,
-                    int pitch, const float *taps, int ntaps, void *stream);
+ * taps: HOST padded table of one aperture (layout and caching as for
+ * pano_multiband_blur); tmp: dev [h][pitch]. */
+int pano_blur_plane(pano_ctx *ctx, const float *src, float *dst, float *tmp, int h, int w,
+                    int pitch, const float *taps, int ntaps);
 
 /* cv2.pyrDown on one float plane                        features.py:155
  * src [h][w] (dense) -> dst [(h+1)/2][(w+1)/2] (dense). */
-int pano_pyr_down(const float *src, int h, int w, float *dst, void *stream);
+int pano_pyr_down(pano_ctx *ctx, const float *src, int h, int w, float *dst);
 
 /* Scale-space building blocks of the SIFT detector the reference obtains from
  * OpenCV (features.py:192-201); with pano_blur_plane they make the Gaussian and
@@ -384,11 +415,10 @@ int pano_pyr_down(const float *src, int h, int w, float *dst, void *stream);
  *   pano_resize_up2  resize(2w x 2h, INTER_LINEAR): float [h][w] -> [2h][2w]
  *   pano_decimate2   resize(w/2 x h/2, INTER_NEAREST): float [h][w] -> [h/2][w/2]
  *   pano_subtract    out = a - b over n floats (one DoG layer) */
-int pano_gray_u8(const uint8_t *bgr, int h, int w, float *out, void *stream);
-int pano_resize_up2(const float *src, int h, int w, float *dst, void *stream);
-int pano_decimate2(const float *src, int h, int w, float *dst, void *stream);
-int pano_subtract(const float *a, const float *b, size_t n, float *out,
-                  void *stream);
+int pano_gray_u8(pano_ctx *ctx, const uint8_t *bgr, int h, int w, float *out);
+int pano_resize_up2(pano_ctx *ctx, const float *src, int h, int w, float *dst);
+int pano_decimate2(pano_ctx *ctx, const float *src, int h, int w, float *dst);
+int pano_subtract(pano_ctx *ctx, const float *a, const float *b, size_t n, float *out);
 
 /* Decimated Laplacian-pyramid blending of two images     blend.py:105-140
  * (blend.laplacian_blending: cv2.pyrDown / cv2.pyrUp pyramids of two float32
@@ -401,17 +431,18 @@ int pano_subtract(const float *a, const float *b, size_t n, float *out,
  *                        `other` [oh][ow][c]: mode 0 = the up-sampled image,
  *                        1 = other - up (a Laplacian level), 2 = other + up (collapse)
  *   pano_u8_to_f32       img.astype("float32")                        blend.py:132-133
- *   pano_laplacian_mix   out = la*gm + lb*(1.0 - gm), float64           blend.py:136
+ *   pano_laplacian_mix   out = la*gm + lb*(1.0 - gm) in the mask's type   blend.py:136
+ *                        (float64 against the default / a float64 mask, float32 against a
+ *                        float32 mask, as NumPy promotes them)
  *   pano_clip_u8         np.clip(x, 0, 255).astype("uint8")             blend.py:140 */
-int pano_pyr_down_image(const void *src, int h, int w, int c, int is_f64, void *dst,
-                        void *stream);
-int pano_pyr_up_image(const void *src, int sh, int sw, int c, int is_f64,
-                      const void *other, int mode, void *dst, int oh, int ow,
-                      void *stream);
-int pano_u8_to_f32(const uint8_t *src, size_t n, float *dst, void *stream);
-int pano_laplacian_mix(const float *la, const float *lb, const double *gm, size_t n,
-                       double *out, void *stream);
-int pano_clip_u8(const double *src, size_t n, uint8_t *dst, void *stream);
+int pano_pyr_down_image(pano_ctx *ctx, const void *src, int h, int w, int c, int is_f64,
+                        void *dst);
+int pano_pyr_up_image(pano_ctx *ctx, const void *src, int sh, int sw, int c, int is_f64,
+                      const void *other, int mode, void *dst, int oh, int ow);
+int pano_u8_to_f32(pano_ctx *ctx, const uint8_t *src, size_t n, float *dst);
+int pano_laplacian_mix(pano_ctx *ctx, const float *la, const float *lb, const void *gm, size_t n,
+                       int is_f64, void *out);
+int pano_clip_u8(pano_ctx *ctx, const void *src, size_t n, int is_f64, uint8_t *dst);
 
 /* cv2.resize(im, None, fx=1/shrink, fy=1/shrink) on a uint8 image   stitcher.py:419-420
  * (INTER_LINEAR, OpenCV's 8-bit fixed-point path restated; parity unpinned).
@@ -419,8 +450,8 @@ int pano_clip_u8(const double *src, size_t n, uint8_t *dst, void *stream);
  * the first, of the second; 11-bit fixed point), built by the host exactly as the
  * oracle builds them.  Both NULL: the exact 2:1 reduction, which cv2.resize takes by
  * rounded 2 x 2 box means (sh == 2 oh, sw == 2 ow). */
-int pano_resize_u8(const uint8_t *src, int sh, int sw, int c, const int32_t *xtab,
-                   const int32_t *ytab, uint8_t *dst, int oh, int ow, void *stream);
+int pano_resize_u8(pano_ctx *ctx, const uint8_t *src, int sh, int sw, int c,
+                   const int32_t *xtab, const int32_t *ytab, uint8_t *dst, int oh, int ow);
 
 /* Keypoints and descriptors of SIFT_create().detectAndCompute  features.py:192-198
  * (the arithmetic lives in OpenCV's xfeatures2d/sift.cpp, restated with the
@@ -440,17 +471,15 @@ int pano_resize_u8(const uint8_t *src, int sh, int sw, int c, const int32_t *xta
  *                       0..255.  RootSIFT (features.py:198) is left to the caller.
  * List order is arbitrary (atomics); sort as KeyPointsFilter::removeDuplicatedSorted
  * does before describing. */
-int pano_sift_extrema(const float *dog, int rows, int cols, int octave,
-                      int n_layers, float contrast_thr, float edge_thr,
-                      float sigma, pano_sift_keypoint *cands, int *count,
-                      int max_cands, void *stream);
-int pano_sift_orient(const float *const *gauss, const int *dims, int n_layers,
-                     const pano_sift_keypoint *cands, const int *n_cands,
-                     int max_cands, pano_sift_keypoint *kpts, int *count,
-                     int max_kpts, void *stream);
-int pano_sift_describe(const float *const *gauss, const int *dims,
+int pano_sift_extrema(pano_ctx *ctx, const float *dog, int rows, int cols, int octave,
+                      int n_layers, float contrast_thr, float edge_thr, float sigma,
+                      pano_sift_keypoint *cands, int *count, int max_cands);
+int pano_sift_orient(pano_ctx *ctx, const float *const *gauss, const int *dims,
+                     int n_layers, const pano_sift_keypoint *cands, const int *n_cands,
+                     int max_cands, pano_sift_keypoint *kpts, int *count, int max_kpts);
+int pano_sift_describe(pano_ctx *ctx, const float *const *gauss, const int *dims,
                        int first_octave, const pano_sift_keypoint *kpts, int n,
-                       float *desc, void *stream);
+                       float *desc);
 
 #ifdef __cplusplus
 }

@@ -71,11 +71,19 @@ class Spy:
 
 
 def run_stitch(imgs, rots, intrs, blend, crop=False, n_levels=None,
-               max_resolution=None, equalize=False):
-    """Drive reference stitch(); returns (mosaic, spy, regions)."""
+               max_resolution=None, equalize=False, blur_spy=None):
+    """Drive reference stitch(); returns (mosaic, spy, regions).  ``blur_spy``: a list that
+    receives (input copy, sigma, output copy) of every cv2.GaussianBlur call the reference's
+    multiband_blend makes (stitcher.py:226)."""
     spy = Spy()
     saved = (ref_st.cv2.remap, ref_st.multiband_blend, ref_st.MAX_RESOLUTION,
              ref_st.multiband_blend.__defaults__, ref_st.find_gains)
+    real_blur = ref_st.cv2.GaussianBlur
+
+    def _spy_blur(src, ksize, sigma, *args, **kwargs):
+        res = real_blur(src, ksize, sigma, *args, **kwargs)
+        blur_spy.append((np.array(src, copy=True), float(sigma), np.array(res, copy=True)))
+        return res
     regions = regions_from(imgs, rots, intrs)
 
     def _spy_gains(overlaps, sizes, *args, **kwargs):
@@ -85,6 +93,8 @@ def run_stitch(imgs, rots, intrs, blend, crop=False, n_levels=None,
     try:
         ref_st.cv2.remap = spy.remap
         ref_st.find_gains = _spy_gains
+        if blur_spy is not None:
+            ref_st.cv2.GaussianBlur = _spy_blur
         if max_resolution is not None:
             ref_st.MAX_RESOLUTION = max_resolution
         if blend == "multiband":
@@ -101,6 +111,7 @@ def run_stitch(imgs, rots, intrs, blend, crop=False, n_levels=None,
                                equalize=equalize)
     finally:
         ref_st.cv2.remap = saved[0]
+        ref_st.cv2.GaussianBlur = real_blur
         ref_st.find_gains = saved[4]
         ref_st.multiband_blend = saved[1]
         ref_st.MAX_RESOLUTION = saved[2]
@@ -120,7 +131,7 @@ def crop_rect(valid):
 
 
 def scene_fixture(name, n, width, height, sweep_deg, jitter, seed, kind,
-                  levels=(5,), max_resolution=None, keep_warped=True):
+                  levels=(5,), max_resolution=None, keep_warped=True, blur_patch=None):
     imgs, rots, intrs = synth.make_scene(n, width, height, sweep_deg=sweep_deg,
                                          jitter=jitter, seed=seed, kind=kind)
     out = dict(imgs=np.stack(imgs), rots=rots, intrs=intrs,
@@ -128,10 +139,22 @@ def scene_fixture(name, n, width, height, sweep_deg, jitter, seed, kind,
                                        else max_resolution))
     # ---- multiband (padded patches) -------------------------------------
     for lv in levels:
+        blurs = [] if (blur_patch is not None and lv == levels[0]) else None
         mosaic, spy, regions = run_stitch(imgs, rots, intrs, "multiband",
                                           n_levels=lv,
-                                          max_resolution=max_resolution)
+                                          max_resolution=max_resolution, blur_spy=blurs)
         out[f"mb{lv}_mosaic"] = mosaic
+        if blurs is not None:
+            # the reference blurs patch after patch, level after level (stitcher.py:215-226):
+            # call k * n + blur_patch is level k of patch `blur_patch`; its input is the
+            # warped patch with the sharp ownership mask in the alpha channel (:207-208)
+            per_level = [blurs[k * n + blur_patch] for k in range(lv - 1)]
+            assert all(np.array_equal(b[0], per_level[0][0]) for b in per_level)
+            out["blur_patch"] = np.int64(blur_patch)
+            out["blur_in"] = per_level[0][0]
+            out["blur_sigma"] = np.array([b[1] for b in per_level])
+            for k, b in enumerate(per_level):
+                out[f"blur_out_{k}"] = b[2]
         if lv == levels[0]:
             out["mb_shape"] = np.array(spy.shape, np.int64)
             out["range_min"] = np.stack([r.range[0] for r in regions])
@@ -308,8 +331,29 @@ def pure_fixture():
     out["gf_img"] = img
     out["gf_s1"] = ref_ft.gaussian_filter(img)            # sigma 1 -> 5 taps
     out["gf_s2"] = ref_ft.gaussian_filter(img, 2.0)       # sigma 2 -> 11 taps
-    out["pyr_1"] = cv2_shim.pyrDown(img)
-    out["pyr_2"] = cv2_shim.pyrDown(out["pyr_1"])
+    # cv2.pyrDown as the reference calls it (features.py:155 sits inside the MSOP detector,
+    # which needs half of OpenCV; blend.py:117-122 is the same call on a float32 image):
+    # the reference's laplacian_blending runs on an image whose first channel is `img`,
+    # a spying pyrDown records what the reference's own _gassian_pyr got back
+    import blend as ref_blend
+    assert ref_blend.__file__.startswith(REF)
+    seen = []
+    real_down = ref_blend.cv2.pyrDown
+
+    def spy_down(src):
+        res = real_down(src)
+        seen.append((np.array(src, copy=True), np.array(res, copy=True)))
+        return res
+    rgb = np.stack([img, img[::-1], img[:, ::-1]], axis=-1)
+    ref_blend.cv2.pyrDown = spy_down
+    try:
+        ref_blend.laplacian_blending(rgb, rgb[::-1].copy(), n_levels=2)
+    finally:
+        ref_blend.cv2.pyrDown = real_down
+    assert np.array_equal(seen[0][0][..., 0], img) and seen[1][0] is not None
+    assert np.array_equal(seen[1][0], seen[0][1])          # level 2 was made from level 1
+    out["pyr_1"] = np.ascontiguousarray(seen[0][1][..., 0])
+    out["pyr_2"] = np.ascontiguousarray(seen[1][1][..., 0])
     path = os.path.join(OUT, "pure.npz")
     np.savez_compressed(path, **out)
     print(f"pure: {os.path.getsize(path) / 1e6:.2f} MB")
@@ -346,7 +390,7 @@ def main():
                                              **gains_fixture()),
         "scene_small_noise": lambda: scene_fixture(
             "scene_small_noise", n=4, width=96, height=64, sweep_deg=60.0,
-            jitter=0.01, seed=0, kind="A", levels=(5, 6)),
+            jitter=0.01, seed=0, kind="A", levels=(5, 6), blur_patch=1),
         "scene_small_smooth": lambda: scene_fixture(
             "scene_small_smooth", n=5, width=128, height=72, sweep_deg=100.0,
             jitter=0.01, seed=10, kind="B", levels=(5,)),

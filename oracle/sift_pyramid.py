@@ -69,13 +69,16 @@ def n_octaves(height, width):
     return int(np.rint(np.log(float(min(2 * height, 2 * width))) / np.log(2.0) - 2)) + 1
 
 
-def sift_pyramid(bgr, octaves=None, sigma=1.6, layers=3):
+def sift_pyramid(bgr, octaves=None, sigma=1.6, layers=3, blur=None):
+    """``blur(image, sigma)``: the GaussianBlur to use (default: the NumPy shim's; the C
+    oracle's, bit-identical and OpenMP-parallel, for 4K frames)."""
     h, w = bgr.shape[:2]
     if octaves is None:
         octaves = n_octaves(h, w)
     sig_diff = float(np.sqrt(max(np.float32(sigma) ** 2 - np.float32(0.5) ** 2 * 4,
                                  np.float32(0.01))))
-    blur = lambda im, s: cv2_shim.GaussianBlur(im, (0, 0), s, s)    # noqa: E731
+    if blur is None:
+        blur = lambda im, s: cv2_shim.GaussianBlur(im, (0, 0), s, s)    # noqa: E731
     base = blur(resize_up2(gray_u8(bgr)), sig_diff)
     sig = sigmas(sigma, layers)
     gauss, dog = [], []

@@ -19,6 +19,9 @@ MAX_TAPS = 129
 MAX_LEVELS = 8
 TAP_LEAD = 7
 TAP_PAD = 40
+# pano_ctx options (include/pano360.h)
+OPT_BLUR_KERNEL, OPT_OWN_PRUNE, OPT_COLS_PIPE = 0, 1, 2
+BLUR_MFMA, BLUR_VALU = 0, 1
 
 
 class PanoError(RuntimeError):
@@ -69,50 +72,55 @@ _SIGNATURES = {
     "pano_last_error": (C.c_char_p, []),
     "pano_device_count": (_i, []),
     "pano_pitch": (_i, [_i]),
-    "pano_timing_enable": (_i, [_i]),
+    "pano_ctx_create": (_i, [_i, _vp, C.POINTER(C.c_void_p)]),
+    "pano_ctx_destroy": (_i, [_vp]),
+    "pano_ctx_set_stream": (_i, [_vp, _vp]),
+    "pano_ctx_set_option": (_i, [_vp, _i, _i]),
+    "pano_ctx_get_option": (_i, [_vp, _i, C.POINTER(C.c_int)]),
+    "pano_timing_enable": (_i, [_vp, _i]),
     "pano_kernel_count": (_i, []),
     "pano_kernel_name": (C.c_char_p, [_i]),
-    "pano_timing_read": (_i, [_i, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
-    "pano_add_weights": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
-    "pano_warp_spherical": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
-                                 _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
-    "pano_warp_windows": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
-    "pano_blur_tiles": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
-    "pano_ownership": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp]),
-    "pano_ownership_cameras": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
-    "pano_owned_regions": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
-    "pano_multiband_blur": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _vp,
-                                 C.POINTER(C.c_int), _i, _vp, _vp, _vp]),
-    "pano_multiband_blur_prepare": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp]),
-    "pano_layout_windows": (_i, [_vp, _i, _i, _vp, _vp, _i, _i, _i, _i, _vp, _i, _vp]),
+    "pano_timing_read": (_i, [_vp, _i, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
+    "pano_add_weights": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp]),
+    "pano_warp_spherical": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i,
+                                 _i, _vp, _vp, _vp, _vp]),
+    "pano_warp_windows": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp]),
+    "pano_blur_tiles": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "pano_ownership": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
+    "pano_ownership_cameras": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "pano_owned_regions": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
+    "pano_multiband_blur": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _i, _vp, C.POINTER(C.c_int), _i,
+                                 _vp, _vp]),
+    "pano_multiband_blur_prepare": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "pano_layout_windows": (_i, [_i, _vp, _i, _i, _vp, _vp, _i, _i, _i, _i, _vp, _i, _vp]),
     "pano_layout_place": (_i, [_vp, _i, _vp, _vp, _vp]),
-    "pano_interior_map": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
-    "pano_multiband_compose": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp,
-                                    _vp, _vp, _i, _vp, _vp, _i, _vp]),
-    "pano_blend_cameras": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp,
+    "pano_interior_map": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    "pano_multiband_compose": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp,
+                                    _vp, _vp, _vp, _i, _vp, _vp, _i]),
+    "pano_blend_cameras": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp,
                                 _vp]),
-    "pano_blur_tile_grid": (_i, []),
+    "pano_blur_tile_grid": (_i, [_vp]),
     "pano_overlap_blocks": (_i, [_i, _i]),
-    "pano_overlap_stats": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
-    "pano_linear_blend": (_i, [_vp, _i, _i, _i, _vp, _vp]),
-    "pano_no_blend": (_i, [_vp, _i, _i, _i, _vp, _vp]),
-    "pano_crop_rect": (_i, [_vp, _i, _i, _vp, _vp, _vp]),
-    "pano_blur_plane": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _i, _vp]),
-    "pano_pyr_down": (_i, [_vp, _i, _i, _vp, _vp]),
-    "pano_gray_u8": (_i, [_vp, _i, _i, _vp, _vp]),
-    "pano_resize_up2": (_i, [_vp, _i, _i, _vp, _vp]),
-    "pano_decimate2": (_i, [_vp, _i, _i, _vp, _vp]),
-    "pano_subtract": (_i, [_vp, _vp, C.c_size_t, _vp, _vp]),
-    "pano_pyr_down_image": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
-    "pano_pyr_up_image": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _vp, _i, _i, _vp]),
-    "pano_u8_to_f32": (_i, [_vp, C.c_size_t, _vp, _vp]),
-    "pano_laplacian_mix": (_i, [_vp, _vp, _vp, C.c_size_t, _vp, _vp]),
-    "pano_clip_u8": (_i, [_vp, C.c_size_t, _vp, _vp]),
-    "pano_resize_u8": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _i, _i, _vp]),
-    "pano_sift_extrema": (_i, [_vp, _i, _i, _i, _i, C.c_float, C.c_float, C.c_float, _vp, _vp, _i,
-                               _vp]),
-    "pano_sift_orient": (_i, [_vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _vp]),
-    "pano_sift_describe": (_i, [_vp, _vp, _i, _vp, _i, _vp, _vp]),
+    "pano_overlap_stats": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "pano_linear_blend": (_i, [_vp, _vp, _i, _i, _i, _vp]),
+    "pano_no_blend": (_i, [_vp, _vp, _i, _i, _i, _vp]),
+    "pano_crop_rect": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
+    "pano_blur_plane": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _i]),
+    "pano_pyr_down": (_i, [_vp, _vp, _i, _i, _vp]),
+    "pano_gray_u8": (_i, [_vp, _vp, _i, _i, _vp]),
+    "pano_resize_up2": (_i, [_vp, _vp, _i, _i, _vp]),
+    "pano_decimate2": (_i, [_vp, _vp, _i, _i, _vp]),
+    "pano_subtract": (_i, [_vp, _vp, _vp, C.c_size_t, _vp]),
+    "pano_pyr_down_image": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    "pano_pyr_up_image": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _i, _vp, _i, _i]),
+    "pano_u8_to_f32": (_i, [_vp, _vp, C.c_size_t, _vp]),
+    "pano_laplacian_mix": (_i, [_vp, _vp, _vp, _vp, C.c_size_t, _i, _vp]),
+    "pano_clip_u8": (_i, [_vp, _vp, C.c_size_t, _i, _vp]),
+    "pano_resize_u8": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _i, _i]),
+    "pano_sift_extrema": (_i, [_vp, _vp, _i, _i, _i, _i, C.c_float, C.c_float, C.c_float, _vp,
+                               _vp, _i]),
+    "pano_sift_orient": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _i]),
+    "pano_sift_describe": (_i, [_vp, _vp, _vp, _i, _vp, _i, _vp]),
 }
 EXPORTS = tuple(_SIGNATURES)
 

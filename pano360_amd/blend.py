@@ -29,13 +29,15 @@ class _Pyr:
         import torch
         self.eng, self.lib, self.torch = eng, eng.lib, torch
 
+    def _wide(self, img):
+        return int(img.dtype == self.torch.float64)
+
     def down(self, img):
         h, w, c = img.shape
         out = self.torch.empty(((h + 1) // 2, (w + 1) // 2, c), dtype=img.dtype,
                                device=img.device)
-        _lib.check(self.lib.pano_pyr_down_image(_ptr(img), h, w, c,
-                                                int(img.dtype == self.torch.float64),
-                                                _ptr(out), self.eng.stream()),
+        _lib.check(self.lib.pano_pyr_down_image(self.eng.ctx(), _ptr(img), h, w, c,
+                                                self._wide(img), _ptr(out)),
                    "pano_pyr_down_image")
         return out
 
@@ -44,24 +46,26 @@ class _Pyr:
         sh, sw, c = img.shape
         oh, ow = like.shape[:2]
         out = self.torch.empty((oh, ow, c), dtype=img.dtype, device=img.device)
-        _lib.check(self.lib.pano_pyr_up_image(_ptr(img), sh, sw, c,
-                                              int(img.dtype == self.torch.float64), _ptr(like),
-                                              mode, _ptr(out), oh, ow, self.eng.stream()),
-                   "pano_pyr_up_image")
+        _lib.check(self.lib.pano_pyr_up_image(self.eng.ctx(), _ptr(img), sh, sw, c,
+                                              self._wide(img), _ptr(like), mode, _ptr(out), oh,
+                                              ow), "pano_pyr_up_image")
         return out
 
-    def gaussian(self, img, n_levels):             # blend.py:117-122
-        pyr = [img]
-        for _ in range(n_levels):
-            pyr.append(self.down(pyr[-1]))
-        return pyr
+    def reduce_chain(self, img, depth):
+        """[img, pyrDown(img), pyrDown^2(img), ...]: depth + 1 images (blend.py:117-122)."""
+        chain = [img]
+        while len(chain) <= depth:
+            chain.append(self.down(chain[-1]))
+        return chain
 
-    def laplacian(self, img, n_levels):            # blend.py:124-130
-        pyr = self.gaussian(img, n_levels)
-        lap = [pyr[-1]]
-        for idx in range(n_levels, 0, -1):
-            lap.append(self.up(pyr[idx], pyr[idx - 1], 1))
-        return lap
+    def detail_chain(self, img, depth):
+        """Coarsest image first, then each finer image minus the expanded coarser one
+        (blend.py:124-130)."""
+        chain = self.reduce_chain(img, depth)
+        levels = [chain[depth]]
+        for k in range(depth, 0, -1):
+            levels.append(self.up(chain[k], chain[k - 1], 1))
+        return levels
 
 
 def _as_f32(eng, img):
@@ -71,22 +75,30 @@ def _as_f32(eng, img):
     if img.dtype == np.uint8:
         dev = torch.from_numpy(img).to(eng.device)
         out = torch.empty(img.shape, dtype=torch.float32, device=eng.device)
-        _lib.check(eng.lib.pano_u8_to_f32(_ptr(dev), img.size, _ptr(out), eng.stream()),
+        _lib.check(eng.lib.pano_u8_to_f32(eng.ctx(), _ptr(dev), img.size, _ptr(out)),
                    "pano_u8_to_f32")
         return out
     return torch.from_numpy(img.astype(np.float32)).to(eng.device)
 
 
 def default_mask(shape):
-    """The sigmoid ramp of blend.py:107-111 (host: H x W x C float64 of closed form)."""
-    hh_, ww_, cc_ = shape
-    mask = np.linspace(1, -1, ww_).reshape((1, ww_, 1))
-    mask = 1.0 / (1 + np.exp(-100 * mask))
-    return np.tile(mask, (hh_, 1, cc_))
+    """The mask the reference builds when none is given (blend.py:107-111): a logistic
+    step across the width, 1 / (1 + exp(-100 u)) with u falling linearly from 1 at the left
+    edge to -1 at the right, the same on every row and channel; float64."""
+    rows, cols, chans = shape
+    ramp = np.linspace(1, -1, cols)
+    step = 1.0 / (1 + np.exp(-100 * ramp))
+    return np.broadcast_to(step[None, :, None], (rows, cols, chans)).copy()
 
 
 def laplacian_blending(img1, img2, mask=None, n_levels=6):
-    """Use a Laplacian pyramid on the images for blending (blend.py:105-140)."""
+    """Use a Laplacian pyramid on the images for blending (blend.py:105-140).
+
+    Same call and result type as the reference.  The mask keeps its float type the way
+    NumPy's promotion keeps it there: float64 (the default mask) makes the per-level mix
+    and the collapse float64, a float32 mask keeps them float32.  Limit: every pyramid
+    level must be at least 2 pixels wide and high (OpenCV's pyrUp of a 1-pixel row is not
+    restated here); integer masks are not supported."""
     import torch
     eng = _eng.engine()
     if img1.ndim != 3 or img1.shape != img2.shape or img1.shape[2] > 4:
@@ -101,23 +113,24 @@ def laplacian_blending(img1, img2, mask=None, n_levels=6):
     smallest = min(img1.shape[:2]) >> (n_levels - 1) if n_levels else 2
     if smallest < 2:
         raise ValueError(f"n_levels={n_levels} leaves a pyramid level narrower than 2 pixels")
+    wide = mask.dtype != np.float32                # float16 / float64 -> float64 like NumPy's mix
+    mdtype, tdtype = (np.float64, torch.float64) if wide else (np.float32, torch.float32)
     pyr = _Pyr(eng)
-    pyr1 = pyr.laplacian(_as_f32(eng, img1), n_levels)
-    pyr2 = pyr.laplacian(_as_f32(eng, img2), n_levels)
-    gmask = torch.from_numpy(np.ascontiguousarray(mask, dtype=np.float64)).to(eng.device)
-    pyrm = pyr.gaussian(gmask, n_levels)[::-1]
-    pyrs = []
-    for la, lb, gm in zip(pyr1, pyr2, pyrm):       # blend.py:136
-        out = torch.empty(la.shape, dtype=torch.float64, device=eng.device)
-        _lib.check(eng.lib.pano_laplacian_mix(_ptr(la), _ptr(lb), _ptr(gm), la.numel(),
-                                              _ptr(out), eng.stream()), "pano_laplacian_mix")
-        pyrs.append(out)
-    blended = pyrs[0]
-    for ls_ in pyrs[1:]:                           # blend.py:137-138
-        blended = pyr.up(blended, ls_, 2)
+    details1 = pyr.detail_chain(_as_f32(eng, img1), n_levels)
+    details2 = pyr.detail_chain(_as_f32(eng, img2), n_levels)
+    weights = pyr.reduce_chain(
+        torch.from_numpy(np.ascontiguousarray(mask, dtype=mdtype)).to(eng.device), n_levels)
+    blended = None
+    # coarsest level first; the weight pyramid is walked from its coarsest end (blend.py:134-138)
+    for first, second, weight in zip(details1, details2, reversed(weights)):
+        mixed = torch.empty(first.shape, dtype=tdtype, device=eng.device)
+        _lib.check(eng.lib.pano_laplacian_mix(eng.ctx(), _ptr(first), _ptr(second), _ptr(weight),
+                                              first.numel(), int(wide), _ptr(mixed)),
+                   "pano_laplacian_mix")
+        blended = mixed if blended is None else pyr.up(blended, mixed, 2)
     out = torch.empty(blended.shape, dtype=torch.uint8, device=eng.device)
-    _lib.check(eng.lib.pano_clip_u8(_ptr(blended), blended.numel(), _ptr(out), eng.stream()),
-               "pano_clip_u8")
+    _lib.check(eng.lib.pano_clip_u8(eng.ctx(), _ptr(blended), blended.numel(), int(wide),
+                                    _ptr(out)), "pano_clip_u8")
     return out.cpu().numpy()
 
 
@@ -152,10 +165,10 @@ def shrink_device(frame, shrink, eng=None):
     if abs(scale - 2.0) < np.finfo(float).eps and w % 2 == 0 and h % 2 == 0:
         xtab = ytab = None                         # exact 2:1: the area path
     else:
-        xtab = _eng._to_device(_resize_taps(ow, w, scale), frame.device)
-        ytab = _eng._to_device(_resize_taps(oh, h, scale), frame.device)
-    _lib.check(eng.lib.pano_resize_u8(_ptr(frame), h, w, c, _ptr(xtab), _ptr(ytab), _ptr(out),
-                                      oh, ow, eng.stream()), "pano_resize_u8")
+        xtab = eng.to_device(_resize_taps(ow, w, scale))
+        ytab = eng.to_device(_resize_taps(oh, h, scale))
+    _lib.check(eng.lib.pano_resize_u8(eng.ctx(), _ptr(frame), h, w, c, _ptr(xtab), _ptr(ytab),
+                                      _ptr(out), oh, ow), "pano_resize_u8")
     return out
 
 

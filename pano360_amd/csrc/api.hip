@@ -1,6 +1,7 @@
 // Library-level entry points: version, error string, device probe.
 #include <stdarg.h>
 #include <stdio.h>
+#include <string.h>
 
 #include <vector>
 
@@ -30,12 +31,151 @@ extern "C" int pano_device_count(void) {
 
 extern "C" int pano_pitch(int w) { return pano_pitch_of(w); }
 
+// ---- the context ---------------------------------------------------------------------
+extern "C" int pano_ctx_create(int device, void *stream, pano_ctx **out) {
+    PANO_REQUIRE(out, "pano_ctx_create: null output");
+    *out = nullptr;
+    PANO_REQUIRE(device >= 0 && device < pano_device_count(), "pano_ctx_create: no device %d",
+                 device);
+    PANO_HIP(hipSetDevice(device));
+    // kernels whose tiles need more than the default 64 KiB of LDS (per device, idempotent)
+    if (int rc = pano_blur_mfma_opt_in()) return rc;
+    if (int rc = pano_blur_valu_opt_in()) return rc;
+    pano_ctx *ctx = new pano_ctx();
+    ctx->device = device;
+    ctx->stream = (hipStream_t)stream;
+    ctx->opt[PANO_OPT_BLUR_KERNEL] = PANO_BLUR_MFMA;
+    ctx->opt[PANO_OPT_OWN_PRUNE] = 1;
+    ctx->opt[PANO_OPT_COLS_PIPE] = 0;
+    *out = ctx;
+    return PANO_OK;
+}
+
+int pano_ctx_enter(pano_ctx *ctx) {
+    PANO_HIP(hipSetDevice(ctx->device));
+    return PANO_OK;
+}
+
+static void timing_clear(pano_ctx *ctx) {
+    for (int k = 0; k < PK_COUNT; ++k) {
+        for (hipEvent_t e : ctx->t_begin[k]) (void)hipEventDestroy(e);
+        for (hipEvent_t e : ctx->t_end[k]) (void)hipEventDestroy(e);
+        ctx->t_begin[k].clear();
+        ctx->t_end[k].clear();
+    }
+}
+
+static void tap_set_free(PanoTapSet &ts) {
+    if (ts.taps) (void)hipFree(ts.taps);
+    if (ts.tables) (void)hipFree(ts.tables);
+    ts.taps = nullptr;
+    ts.tables = nullptr;
+}
+
+extern "C" int pano_ctx_destroy(pano_ctx *ctx) {
+    if (!ctx) return PANO_OK;
+    PANO_HIP(hipSetDevice(ctx->device));
+    // queued kernels may still read the context's tables; the stream may be gone already
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess) {
+        (void)hipGetLastError();
+        (void)hipDeviceSynchronize();
+    }
+    timing_clear(ctx);
+    for (PanoTapSet &ts : ctx->tap_sets) tap_set_free(ts);
+    if (ctx->item_buf) (void)hipFree(ctx->item_buf);
+    if (ctx->item_counter) (void)hipFree(ctx->item_counter);
+    delete ctx;
+    return PANO_OK;
+}
+
+extern "C" int pano_ctx_set_stream(pano_ctx *ctx, void *stream) {
+    PANO_REQUIRE(ctx, "pano_ctx_set_stream: null context");
+    ctx->stream = (hipStream_t)stream;
+    return PANO_OK;
+}
+
+extern "C" int pano_ctx_set_option(pano_ctx *ctx, int option, int value) {
+    PANO_REQUIRE(ctx, "pano_ctx_set_option: null context");
+    PANO_REQUIRE(option >= 0 && option < PANO_OPT_COUNT, "pano_ctx_set_option: option %d", option);
+    if (option == PANO_OPT_BLUR_KERNEL)
+        PANO_REQUIRE(value == PANO_BLUR_MFMA || value == PANO_BLUR_VALU,
+                     "pano_ctx_set_option: blur kernel %d", value);
+    else
+        PANO_REQUIRE(value == 0 || value == 1, "pano_ctx_set_option: option %d takes 0 or 1", option);
+    ctx->opt[option] = value;
+    // tile flags / work lists made for the other tile grid are void
+    ctx->prepared_table = ctx->flags_table = nullptr;
+    return PANO_OK;
+}
+
+extern "C" int pano_ctx_get_option(const pano_ctx *ctx, int option, int *value) {
+    PANO_REQUIRE(ctx && value, "pano_ctx_get_option: null pointer");
+    PANO_REQUIRE(option >= 0 && option < PANO_OPT_COUNT, "pano_ctx_get_option: option %d", option);
+    *value = ctx->opt[option];
+    return PANO_OK;
+}
+
+// Tap sets are keyed on their values: a caller may rebuild its host tables, or free and
+// reuse their memory, at will.  FNV-1a over the apertures and the float bits.
+static uint64_t tap_hash(const float *taps, const int *ntaps, int n, size_t floats) {
+    uint64_t h = 1469598103934665603ull;
+    auto eat = [&](const void *p, size_t bytes) {
+        const unsigned char *b = (const unsigned char *)p;
+        for (size_t i = 0; i < bytes; ++i) h = (h ^ b[i]) * 1099511628211ull;
+    };
+    eat(&n, sizeof(n));
+    eat(ntaps, n * sizeof(int));
+    eat(taps, floats * sizeof(float));
+    return h;
+}
+
+#define PANO_TAP_SETS_MAX 64
+int pano_ctx_tap_set(pano_ctx *ctx, const float *taps, const int *ntaps, int n, size_t table_bytes,
+                     PanoTapSet **out, bool *fresh) {
+    size_t floats = 0;
+    for (int k = 0; k < n; ++k) floats += (size_t)ntaps[k] + PANO_TAP_PAD;
+    const uint64_t key = tap_hash(taps, ntaps, n, floats);
+    *fresh = false;
+    for (PanoTapSet &ts : ctx->tap_sets)
+        if (ts.key == key && ts.n == n && !memcmp(ts.ntaps, ntaps, n * sizeof(int))) {
+            ts.used = ++ctx->tick;
+            if (table_bytes && !ts.tables) {
+                PANO_HIP(hipMalloc((void **)&ts.tables, table_bytes));
+                *fresh = true;
+            }
+            *out = &ts;
+            return PANO_OK;
+        }
+    if (ctx->tap_sets.size() >= PANO_TAP_SETS_MAX) {        // drop the least recently used one
+        size_t old = 0;
+        for (size_t i = 1; i < ctx->tap_sets.size(); ++i)
+            if (ctx->tap_sets[i].used < ctx->tap_sets[old].used) old = i;
+        PANO_HIP(hipStreamSynchronize(ctx->stream));        // kernels may still read its tables
+        tap_set_free(ctx->tap_sets[old]);
+        ctx->tap_sets.erase(ctx->tap_sets.begin() + old);
+    }
+    PanoTapSet ts = {};
+    ts.key = key;
+    ts.n = n;
+    memcpy(ts.ntaps, ntaps, n * sizeof(int));
+    PANO_HIP(hipMalloc((void **)&ts.taps, floats * sizeof(float)));
+    // pageable source: the runtime stages it before returning, the caller's table is free again
+    PANO_HIP(hipMemcpyAsync(ts.taps, taps, floats * sizeof(float), hipMemcpyHostToDevice,
+                            ctx->stream));
+    if (table_bytes) {
+        PANO_HIP(hipMalloc((void **)&ts.tables, table_bytes));
+        *fresh = true;
+    }
+    ts.used = ++ctx->tick;
+    ctx->tap_sets.push_back(ts);
+    *out = &ctx->tap_sets.back();
+    return PANO_OK;
+}
+
 // ---- per-kernel timing -------------------------------------------------------
 // bench.py measures the dominant kernel's launch durations live with HIP events
 // recorded on the stream the kernel is launched on.  Instrumentation only: off
-// unless pano_timing_enable(1) was called; single-threaded use.
-bool g_pano_timing_on = false;
-static std::vector<hipEvent_t> g_begin[PK_COUNT], g_end[PK_COUNT];
+// unless pano_timing_enable(ctx, 1) was called.
 static const char *const g_kernel_names[PK_COUNT] = {
     "add_weights_kernel", "warp_spherical_kernel", "ownership_kernel", "blur_rows_kernel",
     "blur_cols_kernel",   "multiband_compose_kernel", "linear_blend_kernel",
@@ -46,25 +186,17 @@ static const char *const g_kernel_names[PK_COUNT] = {
     "blur_mfma_kernel", "sift_extrema_kernel", "sift_orient_kernel", "sift_describe_kernel",
     "compose_interior_kernel"};
 
-void pano_timing_edge(int kid, hipStream_t stream, bool begin) {
+void pano_timing_edge(pano_ctx *ctx, int kid, hipStream_t stream, bool begin) {
     hipEvent_t ev;
     if (hipEventCreate(&ev) != hipSuccess) return;
     (void)hipEventRecord(ev, stream);
-    (begin ? g_begin : g_end)[kid].push_back(ev);
+    (begin ? ctx->t_begin : ctx->t_end)[kid].push_back(ev);
 }
 
-static void timing_clear() {
-    for (int k = 0; k < PK_COUNT; ++k) {
-        for (hipEvent_t e : g_begin[k]) (void)hipEventDestroy(e);
-        for (hipEvent_t e : g_end[k]) (void)hipEventDestroy(e);
-        g_begin[k].clear();
-        g_end[k].clear();
-    }
-}
-
-extern "C" int pano_timing_enable(int on) {
-    timing_clear();
-    g_pano_timing_on = on != 0;
+extern "C" int pano_timing_enable(pano_ctx *ctx, int on) {
+    PANO_REQUIRE(ctx, "pano_timing_enable: null context");
+    timing_clear(ctx);
+    ctx->timing_on = on != 0;
     return PANO_OK;
 }
 
@@ -74,14 +206,16 @@ extern "C" const char *pano_kernel_name(int kid) {
     return kid >= 0 && kid < PK_COUNT ? g_kernel_names[kid] : "";
 }
 
-extern "C" int pano_timing_read(int kid, double *total_ms, int *launches) {
-    PANO_REQUIRE(kid >= 0 && kid < PK_COUNT && total_ms && launches, "pano_timing_read: bad argument");
+extern "C" int pano_timing_read(pano_ctx *ctx, int kid, double *total_ms, int *launches) {
+    PANO_REQUIRE(ctx && kid >= 0 && kid < PK_COUNT && total_ms && launches,
+                 "pano_timing_read: bad argument");
     double sum = 0.0;
-    const size_t n = g_end[kid].size() < g_begin[kid].size() ? g_end[kid].size() : g_begin[kid].size();
+    const size_t nb = ctx->t_begin[kid].size(), ne = ctx->t_end[kid].size();
+    const size_t n = ne < nb ? ne : nb;
     for (size_t i = 0; i < n; ++i) {
-        PANO_HIP(hipEventSynchronize(g_end[kid][i]));
+        PANO_HIP(hipEventSynchronize(ctx->t_end[kid][i]));
         float ms = 0.f;
-        PANO_HIP(hipEventElapsedTime(&ms, g_begin[kid][i], g_end[kid][i]));
+        PANO_HIP(hipEventElapsedTime(&ms, ctx->t_begin[kid][i], ctx->t_end[kid][i]));
         sum += ms;
     }
     *total_ms = sum;
@@ -119,14 +253,15 @@ static void reflect_closed(long lo, long hi, long n, long &a, long &b) {
     b = b < n ? b : n;
 }
 
-extern "C" int pano_layout_windows(const int32_t *regions, int n, int max_spans,
+extern "C" int pano_layout_windows(int tile_grid, const int32_t *regions, int n, int max_spans,
                                    const int32_t *rects, const uint8_t *have, int radius,
                                    int xs0, int xs1, int n_blur, pano_patch *records, int cap,
                                    pano_layout *out) {
     PANO_REQUIRE(regions && rects && records && out, "pano_layout_windows: null pointer");
+    PANO_REQUIRE(tile_grid == 0 || tile_grid == 32, "pano_layout_windows: tile grid %d", tile_grid);
     PANO_REQUIRE(n >= 0 && max_spans >= 1 && radius >= 0 && n_blur >= 0 && cap >= 0,
                  "pano_layout_windows: bad argument");
-    const bool grid32 = pano_blur_tile_grid() == 32;
+    const bool grid32 = tile_grid == 32;
     const int stride = 5 + 2 * max_spans;
     pano_layout lay = {};
     lay.missing = 0;

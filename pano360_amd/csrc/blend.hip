@@ -706,8 +706,9 @@ static int check_table(const void *table, int n, int H, int W, const char *who) 
 #define MOSAIC_GRID dim3 block(64, 4), grid(ceil_div(W, 64), ceil_div(H, 4))
 
 // The stage-level kernels index whole-patch planes: V must be the patch.
-extern "C" int pano_ownership(const pano_patch *patches, int n, int H, int W,
-                              int16_t *owner, uint8_t *valid, void *stream) {
+extern "C" int pano_ownership(pano_ctx *ctx, const pano_patch *patches, int n, int H, int W,
+                              int16_t *owner, uint8_t *valid) {
+    PANO_ENTER(ctx, "pano_ownership");
     if (int rc = check_table(patches, n, H, W, "pano_ownership")) return rc;
     PANO_REQUIRE(owner && valid, "pano_ownership: null output");
     MOSAIC_GRID;
@@ -718,18 +719,17 @@ extern "C" int pano_ownership(const pano_patch *patches, int n, int H, int W,
     return PANO_OK;
 }
 
-extern "C" int pano_ownership_cameras(const pano_camera *cams, int n, int H, int W,
-                                      int xs0, int xs1, const double *sin_t,
-                                      const double *cos_t, const double *tan_p,
-                                      int16_t *owner, uint8_t *valid, void *stream) {
+extern "C" int pano_ownership_cameras(pano_ctx *ctx, const pano_camera *cams, int n, int H, int W,
+                                      int xs0, int xs1, const double *sin_t, const double *cos_t,
+                                      const double *tan_p, int16_t *owner, uint8_t *valid) {
+    PANO_ENTER(ctx, "pano_ownership_cameras");
     if (int rc = check_table(cams, n, H, W, "pano_ownership_cameras")) return rc;
     PANO_REQUIRE(sin_t && cos_t && tan_p && owner && valid, "pano_ownership_cameras: null pointer");
     PANO_REQUIRE(xs0 >= 0 && xs1 <= W && xs0 <= xs1, "pano_ownership_cameras: bad strip [%d, %d)", xs0, xs1);
     if (xs0 == xs1) return PANO_OK;
-    // PANO_OWN_PRUNE=0 evaluates every listed camera at every pixel (A/B and the
-    // exactness tests compare the two)
-    const char *env = getenv("PANO_OWN_PRUNE");
-    const int prune = !(env && env[0] == '0');
+    // option PANO_OPT_OWN_PRUNE = 0 evaluates every listed camera at every pixel (A/B and
+    // the exactness tests compare the two)
+    const int prune = ctx->opt[PANO_OPT_OWN_PRUNE] != 0;
     dim3 block(64, 4), grid(ceil_div(xs1 - xs0, 64), ceil_div(H, OWN_ROWS));
     PANO_TIMED(PK_OWNERSHIP_CAMS, (hipStream_t)stream,
                hipLaunchKernelGGL(ownership_cameras_kernel, grid, block, 0,
@@ -739,11 +739,11 @@ extern "C" int pano_ownership_cameras(const pano_camera *cams, int n, int H, int
     return PANO_OK;
 }
 
-extern "C" int pano_blend_cameras(const pano_camera *cams, int n, int H, int W, int xs0,
-                                  int xs1, int linear, const double *sin_t,
-                                  const double *cos_t, const double *tan_p,
-                                  const float *lut, int lut_stride, uint8_t *mosaic,
-                                  uint8_t *valid, void *stream) {
+extern "C" int pano_blend_cameras(pano_ctx *ctx, const pano_camera *cams, int n, int H, int W,
+                                  int xs0, int xs1, int linear, const double *sin_t,
+                                  const double *cos_t, const double *tan_p, const float *lut,
+                                  int lut_stride, uint8_t *mosaic, uint8_t *valid) {
+    PANO_ENTER(ctx, "pano_blend_cameras");
     if (int rc = check_table(cams, n, H, W, "pano_blend_cameras")) return rc;
     PANO_REQUIRE(sin_t && cos_t && tan_p && lut && mosaic, "pano_blend_cameras: null pointer");
     PANO_REQUIRE(lut_stride == 0 || lut_stride == 256,
@@ -827,9 +827,10 @@ __global__ void init_regions_kernel(int32_t *regions, int n, int stride) {
     r[4] = 0;
 }
 
-extern "C" int pano_owned_regions(const int16_t *owner, int H, int W, int xs0, int xs1, int n,
-                                  int min_gap, int max_spans, uint8_t *marks,
-                                  int32_t *regions, void *stream) {
+extern "C" int pano_owned_regions(pano_ctx *ctx, const int16_t *owner, int H, int W, int xs0,
+                                  int xs1, int n, int min_gap, int max_spans, uint8_t *marks,
+                                  int32_t *regions) {
+    PANO_ENTER(ctx, "pano_owned_regions");
     PANO_REQUIRE(owner && marks && regions, "pano_owned_regions: null pointer");
     PANO_REQUIRE(H > 0 && W > 0 && n >= 0 && n <= 32767 && max_spans >= 1 && min_gap >= 0,
                  "pano_owned_regions: bad argument");
@@ -855,9 +856,9 @@ extern "C" int pano_owned_regions(const int16_t *owner, int H, int W, int xs0, i
     return PANO_OK;
 }
 
-extern "C" int pano_interior_map(const int16_t *owner, int H, int W, int xs0, int xs1,
-                                 int radius, int16_t *block_owner, uint8_t *interior,
-                                 void *stream) {
+extern "C" int pano_interior_map(pano_ctx *ctx, const int16_t *owner, int H, int W, int xs0,
+                                 int xs1, int radius, int16_t *block_owner, uint8_t *interior) {
+    PANO_ENTER(ctx, "pano_interior_map");
     PANO_REQUIRE(owner && block_owner && interior, "pano_interior_map: null pointer");
     PANO_REQUIRE(H > 0 && W > 0 && radius >= 0, "pano_interior_map: bad argument");
     PANO_REQUIRE(xs0 >= 0 && xs1 <= W && xs0 <= xs1, "pano_interior_map: bad strip [%d, %d)", xs0, xs1);
@@ -876,14 +877,14 @@ extern "C" int pano_interior_map(const int16_t *owner, int H, int W, int xs0, in
     return PANO_OK;
 }
 
-extern "C" int pano_multiband_compose(const pano_patch *patches, int n, int H, int W,
-                                      int xs0, int xs1, int n_levels,
-                                      const int16_t *owner, const uint8_t *valid,
-                                      const uint8_t *interior, const pano_camera *cams,
-                                      const double *sin_t, const double *cos_t,
-                                      const double *tan_p, const float *lut,
+extern "C" int pano_multiband_compose(pano_ctx *ctx, const pano_patch *patches, int n, int H,
+                                      int W, int xs0, int xs1, int n_levels, const int16_t *owner,
+                                      const uint8_t *valid, const uint8_t *interior,
+                                      const pano_camera *cams, const double *sin_t,
+                                      const double *cos_t, const double *tan_p, const float *lut,
                                       int lut_stride, uint8_t *mosaic, float *mosaic_f32,
-                                      int part, void *stream) {
+                                      int part) {
+    PANO_ENTER(ctx, "pano_multiband_compose");
     PANO_REQUIRE(part >= 0 && part <= 2, "pano_multiband_compose: part %d outside 0..2", part);
     PANO_REQUIRE(part == 0 || interior, "pano_multiband_compose: parts need the interior map");
     if (part != 1)
@@ -937,8 +938,9 @@ extern "C" int pano_multiband_compose(const pano_patch *patches, int n, int H, i
     return PANO_OK;
 }
 
-extern "C" int pano_linear_blend(const pano_patch *patches, int n, int H, int W,
-                                 uint8_t *mosaic, void *stream) {
+extern "C" int pano_linear_blend(pano_ctx *ctx, const pano_patch *patches, int n, int H, int W,
+                                 uint8_t *mosaic) {
+    PANO_ENTER(ctx, "pano_linear_blend");
     if (int rc = check_table(patches, n, H, W, "pano_linear_blend")) return rc;
     PANO_REQUIRE(mosaic, "pano_linear_blend: null output");
     MOSAIC_GRID;
@@ -949,8 +951,9 @@ extern "C" int pano_linear_blend(const pano_patch *patches, int n, int H, int W,
     return PANO_OK;
 }
 
-extern "C" int pano_no_blend(const pano_patch *patches, int n, int H, int W,
-                             uint8_t *mosaic, void *stream) {
+extern "C" int pano_no_blend(pano_ctx *ctx, const pano_patch *patches, int n, int H, int W,
+                             uint8_t *mosaic) {
+    PANO_ENTER(ctx, "pano_no_blend");
     if (int rc = check_table(patches, n, H, W, "pano_no_blend")) return rc;
     PANO_REQUIRE(mosaic, "pano_no_blend: null output");
     MOSAIC_GRID;

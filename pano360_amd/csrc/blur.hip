@@ -329,28 +329,18 @@ static int make_levels(const float *taps, const int *ntaps, int n_blur, Levels *
     return PANO_OK;
 }
 
-static int launch_blur(const pano_patch *table, const pano_patch &single, int n, int nch,
-                       int alpha_ch, int max_aw, int max_vh, int max_ah,
-                       const int16_t *owner, int W, const float *taps, const int *ntaps,
-                       int n_blur, const uint8_t *interior, uint8_t *tile_flags,
-                       hipStream_t stream, const char *who) {
+static int launch_blur(pano_ctx *ctx, const pano_patch *table, const pano_patch &single, int n,
+                       int nch, int alpha_ch, int max_aw, int max_vh, int max_ah,
+                       const int16_t *owner, int W, const float *host_taps, const int *ntaps,
+                       int n_blur, const uint8_t *interior, uint8_t *tile_flags, const char *who) {
+    const hipStream_t stream = ctx->stream;
+    PanoTapSet *set = nullptr;
+    bool fresh = false;
+    if (int rc = pano_ctx_tap_set(ctx, host_taps, ntaps, n_blur, 0, &set, &fresh)) return rc;
     Levels L = {};
     const float *col_wz[PANO_MAX_LEVELS];
-    if (int rc = make_levels(taps, ntaps, n_blur, &L, col_wz, who)) return rc;
-    static bool lds_opt_in = false;   // column tiles above 64 KiB need the opt-in
-    if (!lds_opt_in) {
-        const void *fns[] = {(const void *)blur_cols_kernel<true, true>,
-                             (const void *)blur_cols_kernel<true, false>,
-                             (const void *)blur_cols_kernel<false, true>,
-                             (const void *)blur_cols_kernel<false, false>};
-        for (const void *fn : fns)
-            PANO_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                         160 * 1024));
-        lds_opt_in = true;
-    }
-    // A/B switch for tools/ab_bench.py; the default is the measured-faster form
-    const char *env = getenv("PANO_COLS_PIPE");
-    const bool pipe = env ? env[0] != '0' : false;   // measured: 1.78 vs 1.92 ms (cfg3)
+    if (int rc = make_levels(set->taps, ntaps, n_blur, &L, col_wz, who)) return rc;
+    const bool pipe = ctx->opt[PANO_OPT_COLS_PIPE] != 0;   // measured: 1.78 vs 1.92 ms (cfg3)
     const uint8_t *flags = nullptr;
     if (interior && table) {
         dim3 grid(ceil_div(max_aw, COL_TW), ceil_div(max_ah, COL_TH), n);
@@ -391,12 +381,24 @@ static int launch_blur(const pano_patch *table, const pano_patch &single, int n,
     return PANO_OK;
 }
 
-extern "C" int pano_blur_plane(const float *src, float *dst, float *tmp, int h,
-                               int w, int pitch, const float *taps, int ntaps,
-                               void *stream) {
+// column tiles above 64 KiB need the opt-in (once per device; pano_ctx_create)
+int pano_blur_valu_opt_in(void) {
+    const void *fns[] = {(const void *)blur_cols_kernel<true, true>,
+                         (const void *)blur_cols_kernel<true, false>,
+                         (const void *)blur_cols_kernel<false, true>,
+                         (const void *)blur_cols_kernel<false, false>};
+    for (const void *fn : fns)
+        PANO_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    return PANO_OK;
+}
+
+extern "C" int pano_blur_plane(pano_ctx *ctx, const float *src, float *dst, float *tmp, int h,
+                               int w, int pitch, const float *taps, int ntaps) {
+    PANO_ENTER(ctx, "pano_blur_plane");
     PANO_REQUIRE(src && dst && tmp && taps, "pano_blur_plane: null pointer");
     PANO_REQUIRE(h > 0 && w > 0 && pitch >= w && (pitch & 3) == 0,
                  "pano_blur_plane: bad shape %dx%d pitch %d", h, w, pitch);
+    if (int rc = check_taps(ntaps, "pano_blur_plane")) return rc;
     pano_patch p = {};
     p.planes = const_cast<float *>(src);
     p.scratch = tmp;
@@ -404,68 +406,62 @@ extern "C" int pano_blur_plane(const float *src, float *dst, float *tmp, int h,
     p.h = p.vh = p.ah = h;
     p.w = p.vw = p.aw = w;
     p.vpitch = p.apitch = pitch;
-    return launch_blur(nullptr, p, 1, 1, -1, w, h, h, nullptr, 0, taps, &ntaps, 1, nullptr,
-                       nullptr, (hipStream_t)stream, "pano_blur_plane");
+    return launch_blur(ctx, nullptr, p, 1, 1, -1, w, h, h, nullptr, 0, taps, &ntaps, 1, nullptr,
+                       nullptr, "pano_blur_plane");
 }
 
-// PANO_BLUR=valu selects the vector-ALU kernels above for the multiband levels (A/B
-// comparison); the default is the matrix-core kernel of blur_mfma.hip (cfg3: 1.6 ms
-// against 2.4 ms for row + column passes).
-bool pano_blur_uses_mfma() {
-    static int mode = -1;
-    if (mode < 0) {
-        const char *env = getenv("PANO_BLUR");
-        mode = !(env && env[0] == 'v');
-    }
-    return mode == 1;
+// The context's PANO_OPT_BLUR_KERNEL selects the vector-ALU kernels above or the
+// matrix-core kernel of blur_mfma.hip (default; cfg3: 0.95 ms against 2.4 ms for the row +
+// column passes) for the multiband levels; single planes always take the kernels above.
+extern "C" int pano_blur_tile_grid(const pano_ctx *ctx) {
+    return ctx && !pano_blur_uses_mfma(ctx) ? 0 : 32;
 }
 
-extern "C" int pano_blur_tile_grid(void) { return pano_blur_uses_mfma() ? 32 : 0; }
-
-extern "C" int pano_multiband_blur(const pano_patch *patches, int n, int max_aw,
+extern "C" int pano_multiband_blur(pano_ctx *ctx, const pano_patch *patches, int n, int max_aw,
                                    int max_vh, int max_ah, const int16_t *owner, int W,
                                    const float *taps, const int *ntaps, int n_blur,
-                                   const uint8_t *interior, uint8_t *tile_flags,
-                                   void *stream) {
+                                   const uint8_t *interior, uint8_t *tile_flags) {
+    PANO_ENTER(ctx, "pano_multiband_blur");
     PANO_REQUIRE(patches && owner && taps && ntaps, "pano_multiband_blur: null pointer");
     PANO_REQUIRE(n >= 0 && n <= 32767 && W > 0, "pano_multiband_blur: bad argument");
     PANO_REQUIRE(max_aw >= 0 && max_vh >= 0 && max_ah >= 0, "pano_multiband_blur: bad extents");
     PANO_REQUIRE(!interior || tile_flags, "pano_multiband_blur: interior map without tile_flags");
     if (n == 0 || n_blur == 0 || max_aw == 0 || max_vh == 0 || max_ah == 0) return PANO_OK;
+    PANO_REQUIRE(n_blur >= 1 && n_blur < PANO_MAX_LEVELS, "pano_multiband_blur: %d blur levels", n_blur);
     for (int k = 0; k < n_blur; ++k)
         if (int rc = check_taps(ntaps[k], "pano_multiband_blur")) return rc;
-    PANO_REQUIRE(n_blur < PANO_MAX_LEVELS, "pano_multiband_blur: %d blur levels", n_blur);
-    if (pano_blur_uses_mfma())
-        return pano_launch_blur_mfma(patches, n, max_aw, max_ah, owner, W, taps, ntaps, n_blur,
-                                     interior, tile_flags, (hipStream_t)stream);
+    if (pano_blur_uses_mfma(ctx))
+        return pano_launch_blur_mfma(ctx, patches, n, max_aw, max_ah, owner, W, taps, ntaps, n_blur,
+                                     interior, tile_flags);
     pano_patch none = {};
-    return launch_blur(patches, none, n, 4, 3, max_aw, max_vh, max_ah, owner, W, taps, ntaps,
-                       n_blur, interior, tile_flags, (hipStream_t)stream, "pano_multiband_blur");
+    return launch_blur(ctx, patches, none, n, 4, 3, max_aw, max_vh, max_ah, owner, W, taps, ntaps,
+                       n_blur, interior, tile_flags, "pano_multiband_blur");
 }
 
-extern "C" int pano_blur_tiles(const pano_patch *patches, int n, int max_aw, int max_ah, int W,
-                               int radius, const uint8_t *interior, uint8_t *tile_flags,
-                               uint8_t *warp_need, void *stream) {
+extern "C" int pano_blur_tiles(pano_ctx *ctx, const pano_patch *patches, int n, int max_aw,
+                               int max_ah, int W, int radius, const uint8_t *interior,
+                               uint8_t *tile_flags, uint8_t *warp_need) {
+    PANO_ENTER(ctx, "pano_blur_tiles");
     PANO_REQUIRE(patches && interior && tile_flags, "pano_blur_tiles: null pointer");
     PANO_REQUIRE(n >= 0 && n <= 32767 && W > 0 && max_aw >= 0 && max_ah >= 0 && radius >= 0,
                  "pano_blur_tiles: bad argument");
-    PANO_REQUIRE(pano_blur_uses_mfma(), "pano_blur_tiles: needs the 32 x 32 tile grid");
+    PANO_REQUIRE(pano_blur_uses_mfma(ctx), "pano_blur_tiles: needs the 32 x 32 tile grid");
     if (n == 0 || max_aw == 0 || max_ah == 0) return PANO_OK;
-    return pano_tiles_blur_mfma(patches, n, max_aw, max_ah, W, radius, interior, tile_flags,
-                                warp_need, (hipStream_t)stream);
+    return pano_tiles_blur_mfma(ctx, patches, n, max_aw, max_ah, W, radius, interior, tile_flags,
+                                warp_need);
 }
 
-extern "C" int pano_multiband_blur_prepare(const pano_patch *patches, int n, int max_aw,
-                                           int max_ah, int W, const uint8_t *interior,
-                                           uint8_t *tile_flags, void *stream) {
+extern "C" int pano_multiband_blur_prepare(pano_ctx *ctx, const pano_patch *patches, int n,
+                                           int max_aw, int max_ah, int W,
+                                           const uint8_t *interior, uint8_t *tile_flags) {
+    PANO_ENTER(ctx, "pano_multiband_blur_prepare");
     PANO_REQUIRE(patches, "pano_multiband_blur_prepare: null pointer");
     PANO_REQUIRE(n >= 0 && n <= 32767 && W > 0 && max_aw >= 0 && max_ah >= 0,
                  "pano_multiband_blur_prepare: bad argument");
     PANO_REQUIRE(!interior || tile_flags,
                  "pano_multiband_blur_prepare: interior map without tile_flags");
-    if (n == 0 || max_aw == 0 || max_ah == 0 || !pano_blur_uses_mfma()) return PANO_OK;
-    return pano_prepare_blur_mfma(patches, n, max_aw, max_ah, W, interior, tile_flags,
-                                  (hipStream_t)stream);
+    if (n == 0 || max_aw == 0 || max_ah == 0 || !pano_blur_uses_mfma(ctx)) return PANO_OK;
+    return pano_prepare_blur_mfma(ctx, patches, n, max_aw, max_ah, W, interior, tile_flags);
 }
 
 // ---- cv2.pyrDown -----------------------------------------------------------
@@ -492,7 +488,8 @@ __global__ __launch_bounds__(256) void pyr_down_kernel(const float *__restrict__
         (rowv[2] * 6.0f + (rowv[1] + rowv[3]) * 4.0f + rowv[0] + rowv[4]) * (1.0f / 256.0f);
 }
 
-extern "C" int pano_pyr_down(const float *src, int h, int w, float *dst, void *stream) {
+extern "C" int pano_pyr_down(pano_ctx *ctx, const float *src, int h, int w, float *dst) {
+    PANO_ENTER(ctx, "pano_pyr_down");
     PANO_REQUIRE(src && dst, "pano_pyr_down: null pointer");
     PANO_REQUIRE(h > 0 && w > 0, "pano_pyr_down: bad shape %dx%d", h, w);
     const int oh = (h + 1) / 2, ow = (w + 1) / 2;

@@ -249,7 +249,6 @@ struct MbShared {
     short *col;                     // band column -> column of V, or -1
     int CM;                         // largest C of the group: the band reaches 16 CM columns out
     int t_lo, t_hi;                 // bands any wave may want
-    int dbg;
 };
 
 template <int C>
@@ -420,20 +419,16 @@ __device__ __forceinline__ void mb_body(const pano_patch &p, const int ch, const
         const unsigned inf1 = t1 <= sh.t_hi ? info_at(t1) : 0u;    // one flag word per step
         lds_barrier();                                   // everybody finished reading the band
         STAMP(1);
-        if (!(sh.dbg & 4)) commit(slot_c);
+        commit(slot_c);
         STAMP(2);
         lds_barrier();
         STAMP(3);
-#ifndef MB_NO_STORE
-        if (live && !(sh.dbg & 1)) flush();
-#endif
+        if (live) flush();
         STAMP(4);
         const int t2 = (inf1 >> 9) & 1u ? t1 + 1 : next_wanted(t1);
-#ifndef MB_NO_FETCH
-        if (t2 <= sh.t_hi && !(sh.dbg & 2)) fetch(slot_c, t2);
-#endif
+        if (t2 <= sh.t_hi) fetch(slot_c, t2);
         STAMP(5);
-        if (t >= my_lo && t <= my_hi && (inf & (DMAX == 1 ? 0x0eu : 0x1fu)) && !(sh.dbg & 8)) {
+        if (t >= my_lo && t <= my_hi && (inf & (DMAX == 1 ? 0x0eu : 0x1fu))) {
             f32x16 mid;
 #pragma unroll
             for (int q = 0; q < 16; ++q) mid[q] = 0.0f;
@@ -475,7 +470,7 @@ __device__ __forceinline__ void mb_body(const pano_patch &p, const int ch, const
     }
     if (live) {
         if (my_hi + 1 > done_end) done_end = my_hi + 1;
-        if (!(sh.dbg & 1)) flush();
+        flush();
     }
 }
 
@@ -523,7 +518,7 @@ __global__ __launch_bounds__(128) void mb_tables_kernel(MbLevels L, unsigned cha
 __global__ __launch_bounds__(MB_THREADS, 1) void blur_mfma_kernel(
     const pano_patch *__restrict__ table, MbLevels L, const unsigned char *__restrict__ tables,
     const int16_t *__restrict__ owner, int W, const uint8_t *__restrict__ flags,
-    const int2 *__restrict__ items, int dbg) {
+    const int2 *__restrict__ items) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
     // x = (work item * level groups + level group) * 4 + channel; the items - (record, first
@@ -567,7 +562,6 @@ __global__ __launch_bounds__(MB_THREADS, 1) void blur_mfma_kernel(
         }
         off += mb_table_bytes(L.ntaps[l0 + lk]);
     }
-    sh.dbg = dbg;
     const int dmaxm = (sh.CM + 1) / 2;
     sh.t_lo = g.O0 - dmaxm;
     sh.t_hi = g.O1 + dmaxm;
@@ -811,16 +805,10 @@ extern "C" int pano_debug_stamps(unsigned long long *out, int reset) {
 // The work list of a table of records: tile flags (with an interior map), items, sort.
 // Depends on the records' geometry and the interior map only, not on the warped planes, so
 // the caller may queue it on another stream while the warp runs (pano_multiband_blur_prepare).
-static int2 *g_item_buf = nullptr;             // [2][g_item_cap]: unsorted, sorted (grow-only)
-static int *g_item_counter = nullptr;
-static int g_item_cap = 0;
-static const pano_patch *g_prepared_table = nullptr;   // whose list `sorted` currently holds
-static int g_prepared_n = 0;
-static const pano_patch *g_flags_table = nullptr;      // whose tile flags pano_tiles_blur_mfma made
-static int g_flags_n = 0;
-
-static int launch_tile_flags(const pano_patch *table, int n, int ntx_max, int nty_max, int W,
-                             const uint8_t *interior, uint8_t *tile_flags, hipStream_t stream) {
+// The buffers and the note of whose list / flags they hold belong to the context.
+static int launch_tile_flags(pano_ctx *ctx, const pano_patch *table, int n, int ntx_max,
+                             int nty_max, int W, const uint8_t *interior, uint8_t *tile_flags) {
+    const hipStream_t stream = ctx->stream;
     dim3 grid(ceil_div(ntx_max, 32), ceil_div(nty_max, 8), n);
     PANO_TIMED(PK_TILE_FLAGS, stream,
                hipLaunchKernelGGL(tile_flags32_kernel, grid, dim3(256), 0, stream, table, interior,
@@ -831,14 +819,15 @@ static int launch_tile_flags(const pano_patch *table, int n, int ntx_max, int nt
 
 // Tile flags and, from them, the tiles of V the warp has to fill; the following
 // pano_prepare_blur_mfma / pano_launch_blur_mfma on the same table reuse the flags.
-int pano_tiles_blur_mfma(const pano_patch *table, int n, int max_aw, int max_ah, int W, int radius,
-                         const uint8_t *interior, uint8_t *tile_flags, uint8_t *warp_need,
-                         hipStream_t stream) {
+int pano_tiles_blur_mfma(pano_ctx *ctx, const pano_patch *table, int n, int max_aw, int max_ah,
+                         int W, int radius, const uint8_t *interior, uint8_t *tile_flags,
+                         uint8_t *warp_need) {
+    const hipStream_t stream = ctx->stream;
     const int ntx_max = (max_aw + 62) / 32, nty_max = (max_ah + 62) / 32;
-    if (int rc = launch_tile_flags(table, n, ntx_max, nty_max, W, interior, tile_flags, stream))
+    if (int rc = launch_tile_flags(ctx, table, n, ntx_max, nty_max, W, interior, tile_flags))
         return rc;
-    g_flags_table = table;
-    g_flags_n = n;
+    ctx->flags_table = table;
+    ctx->flags_n = n;
     if (warp_need) {
         const int cm = (radius + 15) / 16 < 1 ? 1 : (radius + 15) / 16;
         const int hx = (16 * cm + 31) / 32 + 1, vy = (cm + 1) / 2;
@@ -850,94 +839,91 @@ int pano_tiles_blur_mfma(const pano_patch *table, int n, int max_aw, int max_ah,
     return PANO_OK;
 }
 
-int pano_prepare_blur_mfma(const pano_patch *table, int n, int max_aw, int max_ah, int W,
-                           const uint8_t *interior, uint8_t *tile_flags, hipStream_t stream) {
+int pano_prepare_blur_mfma(pano_ctx *ctx, const pano_patch *table, int n, int max_aw, int max_ah,
+                           int W, const uint8_t *interior, uint8_t *tile_flags) {
+    const hipStream_t stream = ctx->stream;
     const int ntx_max = (max_aw + 62) / 32, nty_max = (max_ah + 62) / 32;
     PANO_REQUIRE(nty_max <= MB_NEED_MAX, "pano_multiband_blur: %d rows of tiles exceed %d", nty_max,
                  MB_NEED_MAX);
     const uint8_t *flags = nullptr;
     if (interior) {
-        if (g_flags_table != table || g_flags_n != n)
-            if (int rc = launch_tile_flags(table, n, ntx_max, nty_max, W, interior, tile_flags,
-                                           stream))
+        if (ctx->flags_table != table || ctx->flags_n != n)
+            if (int rc = launch_tile_flags(ctx, table, n, ntx_max, nty_max, W, interior, tile_flags))
                 return rc;
-        g_flags_table = nullptr;
+        ctx->flags_table = nullptr;
         flags = tile_flags;
     }
     // at most ceil(ntx / 2) pairs per record
     const int cap = n * ceil_div(ntx_max, 2);
-    if (cap > g_item_cap) {
-        if (g_item_buf) PANO_HIP(hipFree(g_item_buf));
-        g_item_cap = cap * 2;
-        PANO_HIP(hipMalloc((void **)&g_item_buf, (size_t)g_item_cap * 2 * sizeof(int2)));
+    if (cap > ctx->item_cap) {
+        if (ctx->item_buf) {
+            PANO_HIP(hipStreamSynchronize(stream));          // a queued blur may still read it
+            PANO_HIP(hipFree(ctx->item_buf));
+            ctx->item_buf = nullptr;
+        }
+        ctx->item_cap = cap * 2;
+        PANO_HIP(hipMalloc((void **)&ctx->item_buf, (size_t)ctx->item_cap * 2 * sizeof(int2)));
     }
-    if (!g_item_counter) {
-        PANO_HIP(hipMalloc((void **)&g_item_counter, sizeof(int)));
-        PANO_HIP(hipMemsetAsync(g_item_counter, 0, sizeof(int), stream));
+    if (!ctx->item_counter) {
+        PANO_HIP(hipMalloc((void **)&ctx->item_counter, sizeof(int)));
+        PANO_HIP(hipMemsetAsync(ctx->item_counter, 0, sizeof(int), stream));
     }
-    hipLaunchKernelGGL(mb_items_kernel, dim3(n), dim3(256), 0, stream, table, flags, g_item_buf,
-                       g_item_counter, cap);
+    hipLaunchKernelGGL(mb_items_kernel, dim3(n), dim3(256), 0, stream, table, flags, ctx->item_buf,
+                       ctx->item_counter, cap);
     PANO_LAUNCH_CHECK("mb_items_kernel");
-    hipLaunchKernelGGL(mb_sort_kernel, dim3(1), dim3(256), 0, stream, g_item_buf, g_item_counter,
-                       cap, g_item_buf + g_item_cap);
+    hipLaunchKernelGGL(mb_sort_kernel, dim3(1), dim3(256), 0, stream, ctx->item_buf,
+                       ctx->item_counter, cap, ctx->item_buf + ctx->item_cap);
     PANO_LAUNCH_CHECK("mb_sort_kernel");
-    g_prepared_table = table;
-    g_prepared_n = n;
+    ctx->prepared_table = table;
+    ctx->prepared_n = n;
     return PANO_OK;
 }
 
-int pano_launch_blur_mfma(const pano_patch *table, int n, int max_aw, int max_ah,
-                          const int16_t *owner, int W, const float *taps, const int *ntaps,
-                          int n_blur, const uint8_t *interior, uint8_t *tile_flags,
-                          hipStream_t stream) {
+// 116 KiB of Toeplitz tables per workgroup (once per device; pano_ctx_create)
+int pano_blur_mfma_opt_in(void) {
+    PANO_HIP(hipFuncSetAttribute((const void *)blur_mfma_kernel,
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    return PANO_OK;
+}
+
+int pano_launch_blur_mfma(pano_ctx *ctx, const pano_patch *table, int n, int max_aw, int max_ah,
+                          const int16_t *owner, int W, const float *host_taps, const int *ntaps,
+                          int n_blur, const uint8_t *interior, uint8_t *tile_flags) {
+    const hipStream_t stream = ctx->stream;
     MbLevels L = {};
     L.n = n_blur;
-    int rmax = 0;
-    for (int k = 0; k < n_blur; ++k) rmax = ntaps[k] / 2 > rmax ? ntaps[k] / 2 : rmax;
-    size_t off = 0;
+    int rmax = 0, total = 0;
     for (int k = 0; k < n_blur; ++k) {
-        L.w[k] = taps + off + PANO_TAP_LEAD + ((rmax - ntaps[k] / 2) & 3);
-        L.ntaps[k] = ntaps[k];
-        off += (size_t)ntaps[k] + PANO_TAP_PAD;
-    }
-    const int ntx_max = (max_aw + 62) / 32;
-    // the work list: prepared by the caller for this table, or made here
-    if (g_prepared_table != table || g_prepared_n != n)
-        if (int rc = pano_prepare_blur_mfma(table, n, max_aw, max_ah, W, interior, tile_flags,
-                                            stream))
-            return rc;
-    g_prepared_table = nullptr;
-    const uint8_t *flags = interior ? tile_flags : nullptr;
-    const int cap = n * ceil_div(ntx_max, 2);
-    const int2 *sorted = g_item_buf + g_item_cap;
-    static int dbg = -1;                  // PANO_MFMA_DBG: switch parts off (timing experiments)
-    if (dbg < 0) dbg = getenv("PANO_MFMA_DBG") ? atoi(getenv("PANO_MFMA_DBG")) : 0;
-    // Toeplitz tables of this tap set: one small device buffer per distinct (table pointer,
-    // apertures), built on first use in stream order and kept
-    struct TableSet { const float *taps; int n; int ntaps[PANO_MAX_LEVELS]; unsigned char *dev; };
-    static TableSet sets[8];
-    static int n_sets = 0;
-    int total = 0;
-    for (int k = 0; k < n_blur; ++k) {
+        rmax = ntaps[k] / 2 > rmax ? ntaps[k] / 2 : rmax;
         L.tab_off[k] = total;
         total += mb_table_bytes(ntaps[k]);
     }
-    unsigned char *tables = nullptr;
-    for (int i = 0; i < n_sets && !tables; ++i)
-        if (sets[i].taps == taps && sets[i].n == n_blur &&
-            !memcmp(sets[i].ntaps, ntaps, n_blur * sizeof(int)))
-            tables = sets[i].dev;
-    if (!tables) {
-        PANO_REQUIRE(n_sets < 8, "pano_multiband_blur: more than 8 distinct tap tables in one process");
-        PANO_HIP(hipMalloc((void **)&tables, total));
-        TableSet &ts = sets[n_sets++];
-        ts.taps = taps;
-        ts.n = n_blur;
-        memcpy(ts.ntaps, ntaps, n_blur * sizeof(int));
-        ts.dev = tables;
+    // device copy of the taps and the Toeplitz operand tables of this tap set: kept by the
+    // context, keyed on the tap values, built on first use in stream order
+    PanoTapSet *set = nullptr;
+    bool fresh = false;
+    if (int rc = pano_ctx_tap_set(ctx, host_taps, ntaps, n_blur, (size_t)total, &set, &fresh))
+        return rc;
+    size_t off = 0;
+    for (int k = 0; k < n_blur; ++k) {
+        L.w[k] = set->taps + off + PANO_TAP_LEAD + ((rmax - ntaps[k] / 2) & 3);
+        L.ntaps[k] = ntaps[k];
+        off += (size_t)ntaps[k] + PANO_TAP_PAD;
+    }
+    unsigned char *tables = set->tables;
+    if (fresh) {
         hipLaunchKernelGGL(mb_tables_kernel, dim3(n_blur), dim3(128), 0, stream, L, tables);
         PANO_LAUNCH_CHECK("mb_tables_kernel");
     }
+    const int ntx_max = (max_aw + 62) / 32;
+    // the work list: prepared by the caller for this table, or made here
+    if (ctx->prepared_table != table || ctx->prepared_n != n)
+        if (int rc = pano_prepare_blur_mfma(ctx, table, n, max_aw, max_ah, W, interior, tile_flags))
+            return rc;
+    ctx->prepared_table = nullptr;
+    const uint8_t *flags = interior ? tile_flags : nullptr;
+    const int cap = n * ceil_div(ntx_max, 2);
+    const int2 *sorted = ctx->item_buf + ctx->item_cap;
     // dynamic LDS: the largest level group's tables
     const int ngroups = ceil_div(n_blur, MB_GROUP);
     int lds = 0;
@@ -948,18 +934,12 @@ int pano_launch_blur_mfma(const pano_patch *table, int n, int max_aw, int max_ah
         lds = bytes > lds ? bytes : lds;
     }
     PANO_REQUIRE(lds <= 160 * 1024, "pano_multiband_blur: %d bytes of LDS tables", lds);
-    static bool lds_opt_in = false;
-    if (!lds_opt_in) {
-        PANO_HIP(hipFuncSetAttribute((const void *)blur_mfma_kernel,
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        lds_opt_in = true;
-    }
     PANO_REQUIRE((long long)cap * 4 * ngroups < (1ll << 31), "pano_multiband_blur: %d work items",
                  cap);
     dim3 grid((unsigned)cap * 4 * ngroups, 1, 1);
     PANO_TIMED(PK_BLUR_MFMA, stream,
                hipLaunchKernelGGL(blur_mfma_kernel, grid, dim3(MB_THREADS), lds, stream, table, L,
-                                  tables, owner, W, flags, sorted, dbg));
+                                  tables, owner, W, flags, sorted));
     PANO_LAUNCH_CHECK("blur_mfma_kernel");
     return PANO_OK;
 }

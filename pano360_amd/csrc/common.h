@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <vector>
+
 #include "../../include/pano360.h"
 
 // ---- error plumbing --------------------------------------------------------
@@ -63,30 +65,74 @@ enum PanoKernelId {
     PK_COMPOSE_INTERIOR,
     PK_COUNT
 };
-extern bool g_pano_timing_on;
-void pano_timing_edge(int kid, hipStream_t stream, bool begin);
+// ---- the context (include/pano360.h: pano_ctx) ------------------------------------
+// Everything the library remembers between calls lives here: device and stream, the
+// option switches, the timing registry, the blur's work-list buffers and the operand
+// tables of the tap sets it has seen.  One context per host thread; nothing is shared
+// between contexts.
+struct PanoTapSet {                 // one set of Gaussian apertures (pano_multiband_blur)
+    uint64_t key;                   // hash of the apertures and the tap values
+    int n, ntaps[PANO_MAX_LEVELS];
+    float *taps;                    // dev: the caller's padded tables, back to back
+    unsigned char *tables;          // dev: matrix-core operand tables (built on first use)
+    uint64_t used;                  // last use (eviction order)
+};
+
+struct pano_ctx {
+    int device;
+    hipStream_t stream;
+    int opt[PANO_OPT_COUNT];
+    bool timing_on;
+    std::vector<hipEvent_t> t_begin[PK_COUNT], t_end[PK_COUNT];
+    // matrix-core blur: work list (unsorted, sorted), its counter, and whose list / tile
+    // flags the buffers currently hold
+    int2 *item_buf;
+    int *item_counter;
+    int item_cap;
+    const pano_patch *prepared_table, *flags_table;
+    int prepared_n, flags_n;
+    std::vector<PanoTapSet> tap_sets;
+    uint64_t tick;
+};
+
+int pano_ctx_enter(pano_ctx *ctx);
+// Device copy of a host tap table set (and, with `tables`, its matrix-core operand tables'
+// buffer, `table_bytes` long, `*fresh` = it was just allocated and must be filled).
+int pano_ctx_tap_set(pano_ctx *ctx, const float *taps, const int *ntaps, int n, size_t table_bytes,
+                     PanoTapSet **out, bool *fresh);
+
+#define PANO_ENTER(ctx, who)                                       \
+    PANO_REQUIRE((ctx) != nullptr, "%s: null context", who);       \
+    if (int rc_ = pano_ctx_enter(ctx)) return rc_;                 \
+    void *const stream = (void *)(ctx)->stream;                    \
+    (void)stream
+
+void pano_timing_edge(pano_ctx *ctx, int kid, hipStream_t stream, bool begin);
 
 // Launch `...` on `stream`; when timing is enabled bracket it with events.
-#define PANO_TIMED(kid, stream, ...)                                 \
-    do {                                                             \
-        if (g_pano_timing_on) pano_timing_edge(kid, stream, true);   \
-        __VA_ARGS__;                                                 \
-        if (g_pano_timing_on) pano_timing_edge(kid, stream, false);  \
+#define PANO_TIMED(kid, stream, ...)                                        \
+    do {                                                                    \
+        if (ctx->timing_on) pano_timing_edge(ctx, kid, stream, true);       \
+        __VA_ARGS__;                                                        \
+        if (ctx->timing_on) pano_timing_edge(ctx, kid, stream, false);      \
     } while (0)
 
 static inline int pano_pitch_of(int w) { return (w + 3) & ~3; }
 
 // blur_mfma.hip: all multiband levels of all records on the matrix cores
-int pano_launch_blur_mfma(const pano_patch *table, int n, int max_aw, int max_ah,
+int pano_launch_blur_mfma(pano_ctx *ctx, const pano_patch *table, int n, int max_aw, int max_ah,
                           const int16_t *owner, int W, const float *taps, const int *ntaps,
-                          int n_blur, const uint8_t *interior, uint8_t *tile_flags,
-                          hipStream_t stream);
-int pano_prepare_blur_mfma(const pano_patch *table, int n, int max_aw, int max_ah, int W,
-                           const uint8_t *interior, uint8_t *tile_flags, hipStream_t stream);
-int pano_tiles_blur_mfma(const pano_patch *table, int n, int max_aw, int max_ah, int W, int radius,
-                         const uint8_t *interior, uint8_t *tile_flags, uint8_t *warp_need,
-                         hipStream_t stream);
-bool pano_blur_uses_mfma();
+                          int n_blur, const uint8_t *interior, uint8_t *tile_flags);
+int pano_prepare_blur_mfma(pano_ctx *ctx, const pano_patch *table, int n, int max_aw, int max_ah,
+                           int W, const uint8_t *interior, uint8_t *tile_flags);
+int pano_tiles_blur_mfma(pano_ctx *ctx, const pano_patch *table, int n, int max_aw, int max_ah,
+                         int W, int radius, const uint8_t *interior, uint8_t *tile_flags,
+                         uint8_t *warp_need);
+int pano_blur_mfma_opt_in(void);
+int pano_blur_valu_opt_in(void);
+static inline bool pano_blur_uses_mfma(const pano_ctx *ctx) {
+    return ctx->opt[PANO_OPT_BLUR_KERNEL] == PANO_BLUR_MFMA;
+}
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
 // ---- device helpers --------------------------------------------------------

@@ -156,9 +156,10 @@ extern "C" int pano_overlap_blocks(int h, int w) {
     return h > 0 && w > 0 ? ceil_div(w, OV_TW) * ceil_div(h, OV_TH) : 0;
 }
 
-extern "C" int pano_overlap_stats(const pano_camera *cams, const pano_pair *pairs, int n_pairs,
-                                  int h, int w, int bw0, const float *lut255, double *partials,
-                                  double *stats, void *stream) {
+extern "C" int pano_overlap_stats(pano_ctx *ctx, const pano_camera *cams, const pano_pair *pairs,
+                                  int n_pairs, int h, int w, int bw0, const float *lut255,
+                                  double *partials, double *stats) {
+    PANO_ENTER(ctx, "pano_overlap_stats");
     PANO_REQUIRE(cams && pairs && lut255 && partials && stats, "pano_overlap_stats: null pointer");
     PANO_REQUIRE(n_pairs >= 0 && h > 1 && w > 1 && bw0 > 0 && h < 32768 && w < 32768,
                  "pano_overlap_stats: bad sizes (%d pairs, %d x %d, block width %d)", n_pairs, h,

@@ -93,27 +93,30 @@ __global__ __launch_bounds__(256) void lap_from_u8_kernel(const uint8_t *__restr
     if (i < n) dst[i] = (float)src[i];                              // .astype("float32")
 }
 
-// la * gm + lb * (1.0 - gm): float32 operands promoted to float64, one rounding per
-// operation (blend.py:136)
+// la * gm + lb * (1.0 - gm) (blend.py:136), one rounding per operation, in the mask's
+// type: NumPy promotes the float32 Laplacian levels to float64 against a float64 mask (the
+// default sigmoid), and keeps everything float32 against a float32 mask.
+template <typename T>
 __global__ __launch_bounds__(256) void lap_mix_kernel(const float *__restrict__ la,
                                                       const float *__restrict__ lb,
-                                                      const double *__restrict__ gm, size_t n,
-                                                      double *__restrict__ out) {
+                                                      const T *__restrict__ gm, size_t n,
+                                                      T *__restrict__ out) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    const double g = gm[i];
-    const double a = (double)la[i] * g;
-    const double b = (double)lb[i] * (1.0 - g);
+    const T g = gm[i];
+    const T a = (T)la[i] * g;
+    const T b = (T)lb[i] * ((T)1.0 - g);
     out[i] = a + b;
 }
 
 // np.clip(blended, 0, 255).astype("uint8") (blend.py:140)
-__global__ __launch_bounds__(256) void lap_finish_kernel(const double *__restrict__ src, size_t n,
+template <typename T>
+__global__ __launch_bounds__(256) void lap_finish_kernel(const T *__restrict__ src, size_t n,
                                                          uint8_t *__restrict__ dst) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    double v = src[i];
-    v = v < 0.0 ? 0.0 : (v > 255.0 ? 255.0 : v);
+    T v = src[i];
+    v = v < (T)0 ? (T)0 : (v > (T)255 ? (T)255 : v);
     dst[i] = (uint8_t)(int)v;
 }
 
@@ -178,17 +181,18 @@ static int pyr_up_any(const T *src, int sh, int sw, int c, const T *other, int m
     return PANO_OK;
 }
 
-extern "C" int pano_pyr_down_image(const void *src, int h, int w, int c, int is_f64, void *dst,
-                                   void *stream) {
+extern "C" int pano_pyr_down_image(pano_ctx *ctx, const void *src, int h, int w, int c, int is_f64,
+                                   void *dst) {
+    PANO_ENTER(ctx, "pano_pyr_down_image");
     PANO_REQUIRE(src && dst && h > 0 && w > 0 && c >= 1 && c <= 4,
                  "pano_pyr_down_image: bad argument");
     return is_f64 ? pyr_down_any((const double *)src, h, w, c, (double *)dst, (hipStream_t)stream)
                   : pyr_down_any((const float *)src, h, w, c, (float *)dst, (hipStream_t)stream);
 }
 
-extern "C" int pano_pyr_up_image(const void *src, int sh, int sw, int c, int is_f64,
-                                 const void *other, int mode, void *dst, int oh, int ow,
-                                 void *stream) {
+extern "C" int pano_pyr_up_image(pano_ctx *ctx, const void *src, int sh, int sw, int c, int is_f64,
+                                 const void *other, int mode, void *dst, int oh, int ow) {
+    PANO_ENTER(ctx, "pano_pyr_up_image");
     PANO_REQUIRE(src && dst && c >= 1 && c <= 4, "pano_pyr_up_image: bad argument");
     PANO_REQUIRE(sh >= 2 && sw >= 2, "pano_pyr_up_image: source %dx%d is narrower than 2", sh, sw);
     PANO_REQUIRE(oh > 0 && ow > 0 && oh <= 2 * sh && ow <= 2 * sw,
@@ -201,7 +205,8 @@ extern "C" int pano_pyr_up_image(const void *src, int sh, int sw, int c, int is_
                                (float *)dst, oh, ow, (hipStream_t)stream);
 }
 
-extern "C" int pano_u8_to_f32(const uint8_t *src, size_t n, float *dst, void *stream) {
+extern "C" int pano_u8_to_f32(pano_ctx *ctx, const uint8_t *src, size_t n, float *dst) {
+    PANO_ENTER(ctx, "pano_u8_to_f32");
     PANO_REQUIRE(src && dst, "pano_u8_to_f32: null pointer");
     if (n == 0) return PANO_OK;
     hipLaunchKernelGGL(lap_from_u8_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
@@ -210,27 +215,41 @@ extern "C" int pano_u8_to_f32(const uint8_t *src, size_t n, float *dst, void *st
     return PANO_OK;
 }
 
-extern "C" int pano_laplacian_mix(const float *la, const float *lb, const double *gm, size_t n,
-                                  double *out, void *stream) {
+extern "C" int pano_laplacian_mix(pano_ctx *ctx, const float *la, const float *lb, const void *gm,
+                                  size_t n, int is_f64, void *out) {
+    PANO_ENTER(ctx, "pano_laplacian_mix");
     PANO_REQUIRE(la && lb && gm && out, "pano_laplacian_mix: null pointer");
     if (n == 0) return PANO_OK;
-    hipLaunchKernelGGL(lap_mix_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
-                       (hipStream_t)stream, la, lb, gm, n, out);
+    const dim3 grid((unsigned)((n + 255) / 256)), block(256);
+    if (is_f64)
+        hipLaunchKernelGGL(lap_mix_kernel<double>, grid, block, 0, (hipStream_t)stream, la, lb,
+                           (const double *)gm, n, (double *)out);
+    else
+        hipLaunchKernelGGL(lap_mix_kernel<float>, grid, block, 0, (hipStream_t)stream, la, lb,
+                           (const float *)gm, n, (float *)out);
     PANO_LAUNCH_CHECK("lap_mix_kernel");
     return PANO_OK;
 }
 
-extern "C" int pano_clip_u8(const double *src, size_t n, uint8_t *dst, void *stream) {
+extern "C" int pano_clip_u8(pano_ctx *ctx, const void *src, size_t n, int is_f64, uint8_t *dst) {
+    PANO_ENTER(ctx, "pano_clip_u8");
     PANO_REQUIRE(src && dst, "pano_clip_u8: null pointer");
     if (n == 0) return PANO_OK;
-    hipLaunchKernelGGL(lap_finish_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
-                       (hipStream_t)stream, src, n, dst);
+    const dim3 grid((unsigned)((n + 255) / 256)), block(256);
+    if (is_f64)
+        hipLaunchKernelGGL(lap_finish_kernel<double>, grid, block, 0, (hipStream_t)stream,
+                           (const double *)src, n, dst);
+    else
+        hipLaunchKernelGGL(lap_finish_kernel<float>, grid, block, 0, (hipStream_t)stream,
+                           (const float *)src, n, dst);
     PANO_LAUNCH_CHECK("lap_finish_kernel");
     return PANO_OK;
 }
 
-extern "C" int pano_resize_u8(const uint8_t *src, int sh, int sw, int c, const int32_t *xtab,
-                              const int32_t *ytab, uint8_t *dst, int oh, int ow, void *stream) {
+extern "C" int pano_resize_u8(pano_ctx *ctx, const uint8_t *src, int sh, int sw, int c,
+                              const int32_t *xtab, const int32_t *ytab, uint8_t *dst, int oh,
+                              int ow) {
+    PANO_ENTER(ctx, "pano_resize_u8");
     PANO_REQUIRE(src && dst && sh > 0 && sw > 0 && oh > 0 && ow > 0 && c >= 1 && c <= 4,
                  "pano_resize_u8: bad argument");
     PANO_REQUIRE((xtab == nullptr) == (ytab == nullptr),

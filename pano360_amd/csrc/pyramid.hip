@@ -81,7 +81,8 @@ __global__ __launch_bounds__(256) void subtract_kernel(const float *__restrict__
     if (i < n) out[i] = a[i] - b[i];
 }
 
-extern "C" int pano_gray_u8(const uint8_t *bgr, int h, int w, float *out, void *stream) {
+extern "C" int pano_gray_u8(pano_ctx *ctx, const uint8_t *bgr, int h, int w, float *out) {
+    PANO_ENTER(ctx, "pano_gray_u8");
     PANO_REQUIRE(bgr && out && h > 0 && w > 0, "pano_gray_u8: bad argument");
     const size_t n = (size_t)h * w;
     hipLaunchKernelGGL(gray_u8_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
@@ -90,7 +91,8 @@ extern "C" int pano_gray_u8(const uint8_t *bgr, int h, int w, float *out, void *
     return PANO_OK;
 }
 
-extern "C" int pano_resize_up2(const float *src, int h, int w, float *dst, void *stream) {
+extern "C" int pano_resize_up2(pano_ctx *ctx, const float *src, int h, int w, float *dst) {
+    PANO_ENTER(ctx, "pano_resize_up2");
     PANO_REQUIRE(src && dst && h > 0 && w > 0, "pano_resize_up2: bad argument");
     dim3 block(64, 4), grid(ceil_div(2 * w, 64), ceil_div(2 * h, 4));
     hipLaunchKernelGGL(resize_up2_kernel, grid, block, 0, (hipStream_t)stream, src, h, w, dst);
@@ -98,7 +100,8 @@ extern "C" int pano_resize_up2(const float *src, int h, int w, float *dst, void 
     return PANO_OK;
 }
 
-extern "C" int pano_decimate2(const float *src, int h, int w, float *dst, void *stream) {
+extern "C" int pano_decimate2(pano_ctx *ctx, const float *src, int h, int w, float *dst) {
+    PANO_ENTER(ctx, "pano_decimate2");
     PANO_REQUIRE(src && dst && h > 1 && w > 1, "pano_decimate2: bad argument");
     dim3 block(64, 4), grid(ceil_div(w / 2, 64), ceil_div(h / 2, 4));
     hipLaunchKernelGGL(decimate2_kernel, grid, block, 0, (hipStream_t)stream, src, h, w, dst);
@@ -106,8 +109,8 @@ extern "C" int pano_decimate2(const float *src, int h, int w, float *dst, void *
     return PANO_OK;
 }
 
-extern "C" int pano_subtract(const float *a, const float *b, size_t n, float *out,
-                             void *stream) {
+extern "C" int pano_subtract(pano_ctx *ctx, const float *a, const float *b, size_t n, float *out) {
+    PANO_ENTER(ctx, "pano_subtract");
     PANO_REQUIRE(a && b && out, "pano_subtract: null pointer");
     if (n == 0) return PANO_OK;
     hipLaunchKernelGGL(subtract_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,

@@ -351,10 +351,10 @@ __global__ __launch_bounds__(64) void sift_describe_kernel(
     }
 }
 
-extern "C" int pano_sift_extrema(const float *dog, int rows, int cols, int octave, int n_layers,
-                                 float contrast_thr, float edge_thr, float sigma,
-                                 pano_sift_keypoint *cands, int *count, int max_cands,
-                                 void *stream) {
+extern "C" int pano_sift_extrema(pano_ctx *ctx, const float *dog, int rows, int cols, int octave,
+                                 int n_layers, float contrast_thr, float edge_thr, float sigma,
+                                 pano_sift_keypoint *cands, int *count, int max_cands) {
+    PANO_ENTER(ctx, "pano_sift_extrema");
     PANO_REQUIRE(dog && cands && count, "pano_sift_extrema: null pointer");
     PANO_REQUIRE(rows > 0 && cols > 0 && n_layers >= 1 && octave >= 0 && octave < 32 && max_cands > 0,
                  "pano_sift_extrema: bad argument");
@@ -370,9 +370,11 @@ extern "C" int pano_sift_extrema(const float *dog, int rows, int cols, int octav
     return PANO_OK;
 }
 
-extern "C" int pano_sift_orient(const float *const *gauss, const int *dims, int n_layers,
-                                const pano_sift_keypoint *cands, const int *n_cands, int max_cands,
-                                pano_sift_keypoint *kpts, int *count, int max_kpts, void *stream) {
+extern "C" int pano_sift_orient(pano_ctx *ctx, const float *const *gauss, const int *dims,
+                                int n_layers, const pano_sift_keypoint *cands, const int *n_cands,
+                                int max_cands, pano_sift_keypoint *kpts, int *count,
+                                int max_kpts) {
+    PANO_ENTER(ctx, "pano_sift_orient");
     PANO_REQUIRE(gauss && dims && cands && n_cands && kpts && count, "pano_sift_orient: null pointer");
     PANO_REQUIRE(max_cands > 0 && max_kpts > 0 && n_layers >= 1, "pano_sift_orient: bad argument");
     const int blocks = max_cands < 16384 ? max_cands : 16384;
@@ -384,8 +386,10 @@ extern "C" int pano_sift_orient(const float *const *gauss, const int *dims, int 
     return PANO_OK;
 }
 
-extern "C" int pano_sift_describe(const float *const *gauss, const int *dims, int first_octave,
-                                  const pano_sift_keypoint *kpts, int n, float *desc, void *stream) {
+extern "C" int pano_sift_describe(pano_ctx *ctx, const float *const *gauss, const int *dims,
+                                  int first_octave, const pano_sift_keypoint *kpts, int n,
+                                  float *desc) {
+    PANO_ENTER(ctx, "pano_sift_describe");
     PANO_REQUIRE(gauss && dims && (n == 0 || (kpts && desc)), "pano_sift_describe: null pointer");
     PANO_REQUIRE(n >= 0, "pano_sift_describe: bad count");
     if (n == 0) return PANO_OK;

@@ -148,9 +148,10 @@ __global__ __launch_bounds__(256) void add_weights_kernel(
     rgba[(size_t)y * w + x] = v;
 }
 
-extern "C" int pano_add_weights(const uint8_t *frame, int h, int w,
-                                const float *lut255, const double *hat_x,
-                                const double *hat_y, float *rgba, void *stream) {
+extern "C" int pano_add_weights(pano_ctx *ctx, const uint8_t *frame, int h, int w,
+                                const float *lut255, const double *hat_x, const double *hat_y,
+                                float *rgba) {
+    PANO_ENTER(ctx, "pano_add_weights");
     PANO_REQUIRE(frame && lut255 && hat_x && hat_y && rgba, "pano_add_weights: null pointer");
     PANO_REQUIRE(h > 0 && w > 0, "pano_add_weights: bad shape %dx%d", h, w);
     dim3 block(64, 4), grid(ceil_div(w, 64), ceil_div(h, 4));
@@ -169,13 +170,12 @@ static int check_frame(const char *who, int sh, int sw, int pw, int ph, int gx0,
     return PANO_OK;
 }
 
-extern "C" int pano_warp_spherical(const uint8_t *frame, int sh, int sw,
-                                   const double *proj, const double *sin_t,
-                                   const double *cos_t, const double *tan_p,
-                                   const float *lut255, const double *hat_x,
-                                   const double *hat_y, int gx0, int gy0,
-                                   int pw, int ph, float *planes, uint8_t *mask,
-                                   float *map_x, float *map_y, void *stream) {
+extern "C" int pano_warp_spherical(pano_ctx *ctx, const uint8_t *frame, int sh, int sw,
+                                   const double *proj, const double *sin_t, const double *cos_t,
+                                   const double *tan_p, const float *lut255, const double *hat_x,
+                                   const double *hat_y, int gx0, int gy0, int pw, int ph,
+                                   float *planes, uint8_t *mask, float *map_x, float *map_y) {
+    PANO_ENTER(ctx, "pano_warp_spherical");
     PANO_REQUIRE(frame && proj && sin_t && cos_t && tan_p && lut255 && hat_x &&
                      hat_y && planes && mask,
                  "pano_warp_spherical: null pointer");
@@ -194,11 +194,11 @@ extern "C" int pano_warp_spherical(const uint8_t *frame, int sh, int sw,
     return PANO_OK;
 }
 
-extern "C" int pano_warp_windows(const pano_camera *cams, const pano_patch *patches, int n,
-                                 int max_vw, int max_vh, const double *sin_t,
-                                 const double *cos_t, const double *tan_p,
-                                 const float *lut, int lut_stride, const uint8_t *need,
-                                 void *stream) {
+extern "C" int pano_warp_windows(pano_ctx *ctx, const pano_camera *cams, const pano_patch *patches,
+                                 int n, int max_vw, int max_vh, const double *sin_t,
+                                 const double *cos_t, const double *tan_p, const float *lut,
+                                 int lut_stride, const uint8_t *need) {
+    PANO_ENTER(ctx, "pano_warp_windows");
     PANO_REQUIRE(cams && patches && sin_t && cos_t && tan_p && lut && lut_stride >= 0,
                  "pano_warp_windows: null pointer");
     PANO_REQUIRE(n >= 0 && n <= 65535 && max_vw >= 0 && max_vh >= 0,

@@ -9,7 +9,6 @@ resolution), :283-302 (mosaic shape, patch rectangles, angle grids), :218
 (level sigmas); OpenCV's getGaussianKernel for the taps (host, 33..97 floats).
 """
 import ctypes as C
-import os
 
 import numpy as np
 
@@ -325,17 +324,6 @@ class _PinnedRing:
         return dev
 
 
-_rings = {}
-
-
-def _to_device(array, device):
-    """Bytes of a NumPy array as a uint8 device tensor (asynchronous copy)."""
-    torch = _torch()
-    key = str(torch.device(device))
-    if key not in _rings:
-        _rings[key] = _PinnedRing(device)
-    return _rings[key].upload(array)
-
 
 def reflect_closed(lo, hi, n):
     """Smallest [a, b) inside [0, n) that holds reflect_101(p, n) for every p in
@@ -442,20 +430,20 @@ class PatchTable:
     """Device array of ``pano_patch`` records + the extents that size the grids."""
 
     @classmethod
-    def from_layout(cls, records, lay, device):
+    def from_layout(cls, records, lay, eng):
         """Records laid out by ``pano_layout_windows`` (tile offsets and extents known)."""
         self = cls.__new__(cls)
         self.host, self.n, self.n_tiles = records, len(records), int(lay.n_tiles)
-        self.dev = _to_device(records, device)
+        self.dev = eng.to_device(records)
         self.max_vw, self.max_vh, self.max_aw, self.max_ah = (int(lay.max_vw), int(lay.max_vh),
                                                               int(lay.max_aw), int(lay.max_ah))
         return self
 
-    def __init__(self, records, device):
+    def __init__(self, records, eng):
         self.host = np.array(records, dtype=PATCH_DTYPE).reshape(-1)
         self.n = len(self.host)
         aw, ah = self.host["aw"].astype(np.int64), self.host["ah"].astype(np.int64)
-        if _lib.lib().pano_blur_tile_grid() == 32:
+        if eng.tile_grid == 32:
             # 32 x 32 tiles anchored at multiples of 32 in patch coordinates
             ax0, ay0 = self.host["ax0"].astype(np.int64), self.host["ay0"].astype(np.int64)
             tiles = (((ax0 + aw - 1) >> 5) - (ax0 >> 5) + 1) * (((ay0 + ah - 1) >> 5) - (ay0 >> 5) + 1)
@@ -464,7 +452,7 @@ class PatchTable:
             tiles = ((aw + 63) // 64) * ((ah + 127) // 128)          # 64 x 128 column tiles
         self.host["tiles_off"] = np.concatenate([[0], np.cumsum(tiles)[:-1]]) if self.n else 0
         self.n_tiles = int(tiles.sum())
-        self.dev = _to_device(self.host, device)
+        self.dev = eng.to_device(self.host)
         mx = lambda k: int(self.host[k].max()) if self.n else 0   # noqa: E731
         self.max_vw, self.max_vh, self.max_aw, self.max_ah = (mx("vw"), mx("vh"), mx("aw"),
                                                               mx("ah"))
@@ -474,9 +462,9 @@ class PatchTable:
         return _ptr(self.dev)
 
 
-def patch_table(patches, device):
+def patch_table(patches, eng):
     """``pano_patch`` table of stage-level patches."""
-    return PatchTable([p.record(i) for i, p in enumerate(patches)], device)
+    return PatchTable([p.record(i) for i, p in enumerate(patches)], eng)
 
 
 class WindowInfo:
@@ -492,23 +480,8 @@ class FusedPatches:
     them.  ``entries`` = [(camera index, patch rect, ``windows_for`` output)], one
     per owned column span, in camera order."""
 
-    _arenas = {}       # (device, name) -> float32 tensor kept across stitches
-
     @classmethod
-    def _arena(cls, device, name, floats):
-        """Workspace reused from stitch to stitch (grown by 12 % when too small): a
-        fresh multi-gigabyte allocation costs 70-90 ms, more than ten stitches."""
-        torch = _torch()
-        key = (str(device), name)
-        have = cls._arenas.get(key)
-        if have is None or have.numel() < floats:
-            cls._arenas[key] = None                     # let the old block go first
-            have = cls._arenas[key] = torch.empty(int(floats * 1.125) + 4, dtype=torch.float32,
-                                                  device=device)
-        return have
-
-    @classmethod
-    def from_regions(cls, raw, max_spans, rects, have, radius, strip, n_blur, device, rec=None):
+    def from_regions(cls, raw, max_spans, rects, have, radius, strip, n_blur, eng, rec=None):
         """The record table straight from the region search's output: one native call
         lays out rectangles, pitches, arena offsets and tile offsets
         (``pano_layout_windows``); the arenas are (re)used as in ``__init__``.
@@ -522,7 +495,8 @@ class FusedPatches:
         rects = np.ascontiguousarray(rects, np.int32)
         have = np.ascontiguousarray(have, np.uint8)
         _lib.check(lib.pano_layout_windows(
-            raw.ctypes.data, n, max_spans, rects.ctypes.data, have.ctypes.data, radius,
+            eng.tile_grid, raw.ctypes.data, n, max_spans, rects.ctypes.data, have.ctypes.data,
+            radius,
             strip[0], strip[1], n_blur, rec.ctypes.data, len(rec), C.byref(lay)),
             "pano_layout_windows")
         rec = rec[:lay.n_records]
@@ -531,14 +505,14 @@ class FusedPatches:
             raise _lib.PanoError(f"frames {missing} are needed for columns [{strip[0]}, "
                                  f"{strip[1]}) but are not resident on this device")
         self = cls.__new__(cls)
-        self.planes = cls._arena(device, "planes", int(lay.planes_floats))
-        self.blurred = cls._arena(device, "blurred", int(lay.blurred_floats))
-        self.scratch = cls._arena(device, "scratch", int(lay.scratch_floats))
+        self.planes = eng.arena("planes", int(lay.planes_floats))
+        self.blurred = eng.arena("blurred", int(lay.blurred_floats))
+        self.scratch = eng.arena("scratch", int(lay.scratch_floats))
         _lib.check(lib.pano_layout_place(rec.ctypes.data, len(rec), self.planes.data_ptr(),
                                          self.blurred.data_ptr(), self.scratch.data_ptr()),
                    "pano_layout_place")
         self._area = self._window = None
-        self.table = PatchTable.from_layout(rec, lay, device)
+        self.table = PatchTable.from_layout(rec, lay, eng)
         return self
 
     def _rectangles(self):
@@ -551,7 +525,7 @@ class FusedPatches:
                                      i64("vx0") + i64("vw")], axis=1)
         return self._area, self._window
 
-    def __init__(self, entries, device, n_blur):
+    def __init__(self, entries, eng, n_blur):
         if isinstance(entries, tuple):                   # (index [k], rects [k][4], A [k][4], V [k][4])
             index, rects, area, window = (np.asarray(v, np.int64) for v in entries)
         else:
@@ -573,7 +547,7 @@ class FusedPatches:
         vh, ah = rec["vh"].astype(np.int64), rec["ah"].astype(np.int64)
         planes_sz = 3 * vh * rec["vpitch"]
         lead = np.zeros(n, np.int64)
-        if _lib.lib().pano_blur_tile_grid() == 32:
+        if eng.tile_grid == 32:
             # the matrix-core blur writes 32-column tile rows anchored at multiples of 32 in
             # patch coordinates: 128-byte rows, and the anchor column on a 128-byte boundary,
             # make each such row one cache line instead of two; no row-pass scratch
@@ -585,9 +559,9 @@ class FusedPatches:
             rec["apitch"] = (rec["aw"] + 3) & ~3
             blurred_sz = n_blur * 4 * ah * rec["apitch"]
             scratch_sz = n_blur * 4 * vh * rec["apitch"]
-        self.planes = self._arena(device, "planes", int(planes_sz.sum()))
-        self.blurred = self._arena(device, "blurred", int(blurred_sz.sum()) + 32)
-        self.scratch = self._arena(device, "scratch", int(scratch_sz.sum()))
+        self.planes = eng.arena("planes", int(planes_sz.sum()))
+        self.blurred = eng.arena("blurred", int(blurred_sz.sum()) + 32)
+        self.scratch = eng.arena("scratch", int(scratch_sz.sum()))
         for key, sizes, arena in (("planes", planes_sz, self.planes),
                                   ("blurred", blurred_sz, self.blurred),
                                   ("scratch", scratch_sz, self.scratch)):
@@ -597,7 +571,7 @@ class FusedPatches:
                 base += -base % 128                         # arenas come 512-byte aligned anyway
                 offs = offs + lead
             rec[key] = base + 4 * offs
-        self.table = PatchTable(rec, device)
+        self.table = PatchTable(rec, eng)
 
     @property
     def info(self):
@@ -620,36 +594,112 @@ class FusedPatches:
 
 
 class Engine:
-    """Sequences the HIP stages for one device.  One instance per process/GPU."""
+    """Sequences the HIP stages for one device and one stream: owns a ``pano_ctx``
+    (include/pano360.h), the workspaces kept from stitch to stitch and the pinned upload
+    ring.  Nothing is shared between engines, so several may run side by side (one per
+    host thread, each under its own ``torch.cuda.stream``).
 
-    def __init__(self, device=None):
+    ``blur``: which kernels run the multiband Gaussian levels - "mfma" (default, the fused
+    matrix-core kernel) or "valu" (separate float32 row / column passes on the vector ALU).
+    ``side_stream``: 0 = one stream (default); 1 = interior collapse and the blur's work
+    list on a second stream; 2 = the work list only.  The second stream paid while the host
+    kept the GPU waiting between the region search and the warp (2.76 -> 2.67 ms); with the
+    native record layout there is no gap left to fill and one stream is as fast or faster
+    (cfg3 medians of 5 x 20 stitches: 2.352 / 2.421 / 2.350 ms; cfg2 0.661 / 0.654 /
+    0.669), so it stays an option for hosts slower than this pool's."""
+
+    def __init__(self, device=None, blur="mfma", side_stream=0, own_prune=True):
         torch = _torch()
         self.lib = _lib.lib()
         if not torch.cuda.is_available() or self.lib.pano_device_count() < 1:
             raise _lib.PanoError("no MI355X visible: the HIP path has no CPU fallback")
         self.device = torch.device(device if device is not None
                                    else f"cuda:{torch.cuda.current_device()}")
+        index = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        self.device = torch.device("cuda", index)
+        handle = C.c_void_p()
+        self._ctx_stream = torch.cuda.current_stream(self.device).cuda_stream
+        _lib.check(self.lib.pano_ctx_create(index, C.c_void_p(self._ctx_stream), C.byref(handle)),
+                   "pano_ctx_create")
+        self._ctx = handle
+        if blur not in ("mfma", "valu"):
+            raise ValueError(f"blur kernel {blur!r}: 'mfma' or 'valu'")
+        self.set_option(_lib.OPT_BLUR_KERNEL, _lib.BLUR_VALU if blur == "valu" else _lib.BLUR_MFMA)
+        self.set_option(_lib.OPT_OWN_PRUNE, 1 if own_prune else 0)
+        self.tile_grid = int(self.lib.pano_blur_tile_grid(self._ctx))
         lut = np.arange(256, dtype=np.float32) / np.float32(255)   # stitcher.py:259
         self.lut255 = torch.from_numpy(lut).to(self.device)
         self._hats = {}
         self._taps = {}
         self._region_bufs = {}
+        self._arenas = {}           # name -> float32 tensor kept across stitches
+        self._ring = None
         # second stream for the part of the collapse that needs no blurred planes
         self.side = torch.cuda.Stream(self.device)
-        # PANO_SIDE_STREAM: 0 = one stream (default); 1 = interior collapse and the blur's work
-        # list on the side stream; 2 = the work list only.  The side stream paid while the host
-        # kept the GPU waiting between the region search and the warp (2.76 -> 2.67 ms); with
-        # the native record layout there is no gap left to fill and one stream is as fast or
-        # faster (cfg3 medians of 5 x 20 stitches: 2.352 / 2.421 / 2.350 ms; cfg2 0.661 / 0.654 /
-        # 0.669), so it stays an option for hosts that are slower than this pool's.
-        mode = os.environ.get("PANO_SIDE_STREAM", "0")
-        self.overlap_interior = mode == "1"
-        self.overlap_prepare = mode in ("1", "2")
+        self.overlap_interior = side_stream == 1
+        self.overlap_prepare = side_stream in (1, 2)
+        self.warp_need = "auto"     # "auto" | True | False: see multiband_fused
+
+    def __del__(self):
+        ctx, self._ctx = getattr(self, "_ctx", None), None
+        if ctx is not None and ctx.value:
+            try:
+                self.lib.pano_ctx_destroy(ctx)
+            except Exception:       # noqa: BLE001 - interpreter shutdown
+                pass
+
+    # -- the context ----------------------------------------------------------
+    def ctx(self, stream=None):
+        """The context handle, targeted at ``stream`` (default: torch's current stream of
+        this device - what ``with torch.cuda.stream(s):`` selects in this thread)."""
+        torch = _torch()
+        raw = (stream if stream is not None else torch.cuda.current_stream(self.device)).cuda_stream
+        if raw != self._ctx_stream:
+            _lib.check(self.lib.pano_ctx_set_stream(self._ctx, C.c_void_p(raw)),
+                       "pano_ctx_set_stream")
+            self._ctx_stream = raw
+        return self._ctx
+
+    def set_option(self, option, value):
+        _lib.check(self.lib.pano_ctx_set_option(self._ctx, option, int(value)),
+                   "pano_ctx_set_option")
+        if option == _lib.OPT_BLUR_KERNEL:
+            self.tile_grid = int(self.lib.pano_blur_tile_grid(self._ctx))
+
+    def timing(self, on):
+        _lib.check(self.lib.pano_timing_enable(self._ctx, 1 if on else 0), "pano_timing_enable")
+
+    def kernel_times(self):
+        """{kernel name: (summed ms, launches)} since ``timing(True)``; waits for the events."""
+        out = {}
+        for kid in range(self.lib.pano_kernel_count()):
+            ms, n = C.c_double(), C.c_int()
+            _lib.check(self.lib.pano_timing_read(self._ctx, kid, C.byref(ms), C.byref(n)),
+                       "pano_timing_read")
+            if n.value:
+                out[self.lib.pano_kernel_name(kid).decode()] = (ms.value, n.value)
+        return out
+
+    # -- workspaces -----------------------------------------------------------
+    def arena(self, name, floats):
+        """Workspace reused from stitch to stitch (grown by 12 % when too small): a
+        fresh multi-gigabyte allocation costs 70-90 ms, more than ten stitches."""
+        torch = _torch()
+        have = self._arenas.get(name)
+        if have is None or have.numel() < floats:
+            self._arenas[name] = None                       # let the old block go first
+            have = self._arenas[name] = torch.empty(int(floats * 1.125) + 4,
+                                                    dtype=torch.float32, device=self.device)
+        return have
+
+    def to_device(self, array):
+        """Bytes of a NumPy array as a uint8 device tensor (asynchronous copy out of this
+        engine's pinned ring)."""
+        if self._ring is None:
+            self._ring = _PinnedRing(self.device)
+        return self._ring.upload(array)
 
     # -- small cached tables ------------------------------------------------
-    def stream(self):
-        return C.c_void_p(_torch().cuda.current_stream(self.device).cuda_stream)
-
     def hat_tables(self, shape):
         torch = _torch()
         if shape not in self._hats:
@@ -659,16 +709,16 @@ class Engine:
         return self._hats[shape]
 
     def blur_tables(self, n_levels):
-        """(taps on device, ntaps C array, n_blur, largest radius) of the
-        n_levels-1 blurs; tables back to back, padded as include/pano360.h says."""
-        torch = _torch()
+        """(host taps, ntaps C array, n_blur, largest radius) of the n_levels-1 blurs;
+        tables back to back, padded as include/pano360.h says.  The context keeps the
+        device copies, keyed on the values."""
         if n_levels not in self._taps:
             sig = level_sigmas(n_levels)
             sizes = [gaussian_ksize(s) for s in sig]
             rmax = max([k // 2 for k in sizes], default=0)
             flat = np.concatenate([padded_taps(gaussian_taps(k, s), (rmax - k // 2) & 3)
                                    for k, s in zip(sizes, sig)]) if sig else np.zeros(1, np.float32)
-            self._taps[n_levels] = (torch.from_numpy(flat).to(self.device),
+            self._taps[n_levels] = (np.ascontiguousarray(flat, np.float32),
                                     (C.c_int * max(len(sizes), 1))(*sizes), len(sizes), rmax)
         return self._taps[n_levels]
 
@@ -682,8 +732,8 @@ class Engine:
         buffer (three pageable copies cost 1.5 ms of host time per stitch)."""
         torch = _torch()
         nx, ny = len(plan.sin_t), len(plan.tan_p)
-        dev = _to_device(np.concatenate([plan.sin_t, plan.cos_t, plan.tan_p]),
-                         self.device).view(torch.float64)
+        dev = self.to_device(np.concatenate([plan.sin_t, plan.cos_t, plan.tan_p])).view(
+            torch.float64)
         plan.dev = (dev[:nx], dev[nx:2 * nx], dev[2 * nx:2 * nx + ny])
         return plan
 
@@ -696,8 +746,8 @@ class Engine:
         hx, hy = self.hat_tables((h, w))
         out = torch.empty((h, w, 4), dtype=torch.float32, device=self.device)
         lut = self.lut255 if lut is None else lut
-        _lib.check(self.lib.pano_add_weights(_ptr(frame), h, w, _ptr(lut), _ptr(hx),
-                                             _ptr(hy), _ptr(out), self.stream()),
+        _lib.check(self.lib.pano_add_weights(self.ctx(), _ptr(frame), h, w, _ptr(lut), _ptr(hx),
+                                             _ptr(hy), _ptr(out)),
                    "pano_add_weights")
         return out
 
@@ -713,10 +763,10 @@ class Engine:
             my = torch.empty_like(mx)
         proj = plan.projs[index]
         _lib.check(self.lib.pano_warp_spherical(
-            _ptr(frame), sh, sw, proj.ctypes.data_as(C.c_void_p), _ptr(plan.dev[0]),
+            self.ctx(), _ptr(frame), sh, sw, proj.ctypes.data_as(C.c_void_p), _ptr(plan.dev[0]),
             _ptr(plan.dev[1]), _ptr(plan.dev[2]), _ptr(lut), _ptr(hx), _ptr(hy),
             x0, y0, patch.w, patch.h, _ptr(patch.planes), _ptr(patch.mask), _ptr(mx),
-            _ptr(my), self.stream()), "pano_warp_spherical")
+            _ptr(my)), "pano_warp_spherical")
         return mx, my
 
     def warp_all(self, frames, plan, n_blur=0, want_maps=False, luts=None):
@@ -733,15 +783,15 @@ class Engine:
         H, W = shape
         owner = torch.empty((H, W), dtype=torch.int16, device=self.device)
         valid = torch.empty((H, W), dtype=torch.uint8, device=self.device)
-        _lib.check(self.lib.pano_ownership(table.ptr, table.n, H, W, _ptr(owner), _ptr(valid),
-                                           self.stream()), "pano_ownership")
+        _lib.check(self.lib.pano_ownership(self.ctx(), table.ptr, table.n, H, W, _ptr(owner),
+                                           _ptr(valid)), "pano_ownership")
         return owner, valid
 
     def multiband(self, patches, shape, n_levels, want_float=False, table=None):
         """Stage-level multiband: ownership from the alpha planes -> blurs ->
         collapse.  Returns (mosaic u8, float mosaic or None, owner, valid)."""
         if table is None:
-            table = patch_table(patches, self.device)
+            table = patch_table(patches, self)
         owner, valid = self.ownership(table, shape)
         mosaic, fl = self.blur_and_compose(table, owner, valid, shape, n_levels, want_float)
         return mosaic, fl, owner, valid
@@ -755,9 +805,8 @@ class Engine:
         shape8 = ((H + 7) // 8, (W + 7) // 8)
         bown = torch.empty((2,) + shape8, dtype=torch.int16, device=self.device)
         interior = torch.empty(shape8, dtype=torch.uint8, device=self.device)
-        _lib.check(self.lib.pano_interior_map(_ptr(owner), H, W, c0, c1, radius, _ptr(bown),
-                                              _ptr(interior), self.stream()),
-                   "pano_interior_map")
+        _lib.check(self.lib.pano_interior_map(self.ctx(), _ptr(owner), H, W, c0, c1, radius,
+                                              _ptr(bown), _ptr(interior)), "pano_interior_map")
         return interior
 
     def active_tile_pixels(self):
@@ -770,7 +819,7 @@ class Engine:
         if flags is None:
             return int((host["ah"].astype(np.int64) * host["aw"]).sum())
         on = flags.cpu().numpy()
-        if self.lib.pano_blur_tile_grid() == 32:
+        if self.tile_grid == 32:
             return int(on[:table.n_tiles].astype(np.int64).sum()) * 1024      # upper bound: whole tiles
         total = 0
         for rec in host:
@@ -801,9 +850,10 @@ class Engine:
             if t is not None:
                 t.record_stream(self.side)
         _lib.check(self.lib.pano_multiband_compose(
-            None, 0, H, W, strip[0], strip[1], 1, _ptr(owner), None, _ptr(interior), _ptr(cams),
+            self.ctx(self.side), None, 0, H, W, strip[0], strip[1], 1, _ptr(owner), None,
+            _ptr(interior), _ptr(cams),
             _ptr(plan.dev[0]), _ptr(plan.dev[1]), _ptr(plan.dev[2]), *self._lut_args(luts),
-            _ptr(mosaic), _ptr(fl), 1, C.c_void_p(self.side.cuda_stream)),
+            _ptr(mosaic), _ptr(fl), 1),
             "pano_multiband_compose")
         done = torch.cuda.Event()
         done.record(self.side)
@@ -823,8 +873,8 @@ class Engine:
             if t is not None:
                 t.record_stream(self.side)
         _lib.check(self.lib.pano_multiband_blur_prepare(
-            table.ptr, table.n, table.max_aw, table.max_ah, W, _ptr(interior), _ptr(flags),
-            C.c_void_p(self.side.cuda_stream)), "pano_multiband_blur_prepare")
+            self.ctx(self.side), table.ptr, table.n, table.max_aw, table.max_ah, W, _ptr(interior),
+            _ptr(flags)), "pano_multiband_blur_prepare")
         listed = torch.cuda.Event()
         listed.record(self.side)
         return flags, listed
@@ -849,8 +899,8 @@ class Engine:
                 flags = (torch.empty(max(table.n_tiles, 1), dtype=torch.uint8,
                                      device=self.device) if interior is not None else None)
             _lib.check(self.lib.pano_multiband_blur(
-                table.ptr, table.n, table.max_aw, table.max_vh, table.max_ah, _ptr(owner), W,
-                _ptr(taps), ntaps, n_blur, _ptr(interior), _ptr(flags), self.stream()),
+                self.ctx(), table.ptr, table.n, table.max_aw, table.max_vh, table.max_ah,
+                _ptr(owner), W, taps.ctypes.data, ntaps, n_blur, _ptr(interior), _ptr(flags)),
                 "pano_multiband_blur")
             self.last_tiles = (table, flags)        # for active_tile_pixels (reporting)
         if out is None:
@@ -863,10 +913,10 @@ class Engine:
             part = 2
         tabs = plan.dev if interior is not None else (None, None, None)
         _lib.check(self.lib.pano_multiband_compose(
-            table.ptr, table.n, H, W, c0, c1, n_levels, _ptr(owner), _ptr(valid),
+            self.ctx(), table.ptr, table.n, H, W, c0, c1, n_levels, _ptr(owner), _ptr(valid),
             _ptr(interior), _ptr(cams) if interior is not None else None, _ptr(tabs[0]),
             _ptr(tabs[1]), _ptr(tabs[2]), *self._lut_args(luts), _ptr(mosaic), _ptr(fl),
-            part, self.stream()), "pano_multiband_compose")
+            part), "pano_multiband_compose")
         if out is not None:
             torch.cuda.current_stream(self.device).wait_event(done)
         return mosaic, fl
@@ -875,10 +925,10 @@ class Engine:
         torch = _torch()
         H, W = shape
         if table is None:
-            table = patch_table(patches, self.device)
+            table = patch_table(patches, self)
         mosaic = torch.empty((H, W, 3), dtype=torch.uint8, device=self.device)
         fn = self.lib.pano_linear_blend if linear else self.lib.pano_no_blend
-        _lib.check(fn(table.ptr, table.n, H, W, _ptr(mosaic), self.stream()),
+        _lib.check(fn(self.ctx(), table.ptr, table.n, H, W, _ptr(mosaic)),
                    "pano_linear_blend" if linear else "pano_no_blend")
         return mosaic
 
@@ -910,7 +960,7 @@ class Engine:
             for k, frame in enumerate(frames):
                 rec[k] = (np.zeros(9), frame.data_ptr(), hx.data_ptr(), hy.data_ptr(), h, w,
                           0, 0, 0, 0)
-            cams = _to_device(rec, self.device)
+            cams = self.to_device(rec)
             nblk = int(self.lib.pano_overlap_blocks(h, w))
             bw0 = min(1024 // min(16, h), w)
             step = max(1, chunk_bytes // (nblk * 24))
@@ -921,8 +971,9 @@ class Engine:
                 part = pairs[a:a + step]
                 dev_pairs = torch.from_numpy(part.view(np.uint8).reshape(-1)).to(self.device)
                 _lib.check(self.lib.pano_overlap_stats(
-                    _ptr(cams), _ptr(dev_pairs), len(part), h, w, bw0, _ptr(self.lut255),
-                    _ptr(partials), _ptr(stats[a:]), self.stream()), "pano_overlap_stats")
+                    self.ctx(), _ptr(cams), _ptr(dev_pairs), len(part), h, w, bw0,
+                    _ptr(self.lut255),
+                    _ptr(partials), _ptr(stats[a:])), "pano_overlap_stats")
             host = stats.cpu().numpy()
             for (_, i, j), (count, sum_i, sum_j) in zip(pairs, host):
                 sizes[i, j] = sizes[j, i] = count                       # stitcher.py:59
@@ -945,7 +996,7 @@ class Engine:
             frame = frames.get(i) if frames else None
             rec[i] = (plan.projs[i].ravel(), frame.data_ptr() if frame is not None else 0,
                       hx.data_ptr(), hy.data_ptr(), sh, sw, y0, x0, y1 - y0, x1 - x0)
-        return _to_device(rec, self.device)
+        return self.to_device(rec)
 
     def ownership_cameras(self, plan, strip=None, out=None, cams=None):
         """owner / valid of the mosaic (or of the column strip [xs0, xs1)) from the
@@ -961,8 +1012,8 @@ class Engine:
         if cams is None:
             cams = self.camera_table(plan)
         _lib.check(self.lib.pano_ownership_cameras(
-            _ptr(cams), plan.n, H, W, xs0, xs1, _ptr(plan.dev[0]), _ptr(plan.dev[1]),
-            _ptr(plan.dev[2]), _ptr(owner), _ptr(valid), self.stream()),
+            self.ctx(), _ptr(cams), plan.n, H, W, xs0, xs1, _ptr(plan.dev[0]), _ptr(plan.dev[1]),
+            _ptr(plan.dev[2]), _ptr(owner), _ptr(valid)),
             "pano_ownership_cameras")
         return owner, valid
 
@@ -976,8 +1027,9 @@ class Engine:
         c0, c1 = strip if strip is not None else (0, W)
         marks = torch.empty((n, W), dtype=torch.uint8, device=self.device)
         regions = torch.empty((n, 5 + 2 * max_spans), dtype=torch.int32, device=self.device)
-        _lib.check(self.lib.pano_owned_regions(_ptr(owner), H, W, c0, c1, n, min_gap, max_spans,
-                                               _ptr(marks), _ptr(regions), self.stream()),
+        _lib.check(self.lib.pano_owned_regions(
+            self.ctx(), _ptr(owner), H, W, c0, c1, n, min_gap, max_spans,
+                                               _ptr(marks), _ptr(regions)),
                    "pano_owned_regions")
         key = (n, max_spans)
         host_buf = self._region_bufs.get(key)
@@ -1049,8 +1101,7 @@ class Engine:
         rects32 = np.ascontiguousarray(plan.rects, np.int32)
         records = np.zeros(plan.n * regions.max_spans, dtype=PATCH_DTYPE)
         patches = FusedPatches.from_regions(regions.raw(), regions.max_spans, rects32,
-                                            resident, radius, (c0, c1), n_blur, self.device,
-                                            records)
+                                            resident, radius, (c0, c1), n_blur, self, records)
         table = patches.table
         # tile flags first (this stream): they tell the warp which blocks of the windows
         # anything will read; the blur's work list then goes to the side stream
@@ -1059,22 +1110,22 @@ class Engine:
         # side of a seam: 8 x 1080p -4 %; on 32 x 4K nearly every tile is within reach and the
         # two small kernels in front of the warp cost more than they save)
         wide = table.n and float(np.mean(table.host["aw"])) >= 768.0
-        choice = os.environ.get("PANO_WARP_NEED", "auto")
-        if (interior is not None and n_blur and self.lib.pano_blur_tile_grid() == 32
-                and (choice == "1" or (choice == "auto" and wide))):
+        choice = self.warp_need
+        if (interior is not None and n_blur and self.tile_grid == 32
+                and (choice is True or (choice == "auto" and wide))):
             torch = _torch()
             flags = torch.empty(max(table.n_tiles, 1), dtype=torch.uint8, device=self.device)
             need = torch.empty(max(table.n_tiles, 1), dtype=torch.uint8, device=self.device)
             _lib.check(self.lib.pano_blur_tiles(
-                table.ptr, table.n, table.max_aw, table.max_ah, plan.shape[1], radius,
-                _ptr(interior), _ptr(flags), _ptr(need), self.stream()), "pano_blur_tiles")
+                self.ctx(), table.ptr, table.n, table.max_aw, table.max_ah, plan.shape[1], radius,
+                _ptr(interior), _ptr(flags), _ptr(need)), "pano_blur_tiles")
         prepared = (self.prepare_blur_async(table, plan.shape[1], interior, flags)
                     if n_blur and self.overlap_prepare else
                     ((flags, None) if flags is not None else None))
         _lib.check(self.lib.pano_warp_windows(
-            _ptr(cams), table.ptr, table.n, table.max_vw, table.max_vh, _ptr(plan.dev[0]),
-            _ptr(plan.dev[1]), _ptr(plan.dev[2]), *self._lut_args(luts), _ptr(need),
-            self.stream()), "pano_warp_windows")
+            self.ctx(), _ptr(cams), table.ptr, table.n, table.max_vw, table.max_vh,
+            _ptr(plan.dev[0]),
+            _ptr(plan.dev[1]), _ptr(plan.dev[2]), *self._lut_args(luts), _ptr(need)), "pano_warp_windows")
         mosaic, fl = self.blur_and_compose(table, owner, valid, plan.shape, n_levels,
                                            want_float, (c0, c1), interior, cams, plan, luts,
                                            out=early, prepared=prepared)
@@ -1097,9 +1148,9 @@ class Engine:
         mosaic = torch.empty((H, W, 3), dtype=torch.uint8, device=self.device)
         valid = torch.empty((H, W), dtype=torch.uint8, device=self.device)
         _lib.check(self.lib.pano_blend_cameras(
-            _ptr(cams), plan.n, H, W, c0, c1, 1 if linear else 0, _ptr(plan.dev[0]),
+            self.ctx(), _ptr(cams), plan.n, H, W, c0, c1, 1 if linear else 0, _ptr(plan.dev[0]),
             _ptr(plan.dev[1]), _ptr(plan.dev[2]), *self._lut_args(luts), _ptr(mosaic),
-            _ptr(valid), self.stream()), "pano_blend_cameras")
+            _ptr(valid)), "pano_blend_cameras")
         return mosaic, valid
 
     # -- crop and filters -------------------------------------------------------------
@@ -1109,20 +1160,19 @@ class Engine:
         H, W = valid.shape
         heights = torch.empty((H, W), dtype=torch.int32, device=self.device)
         result = torch.zeros(6, dtype=torch.int64, device=self.device)
-        _lib.check(self.lib.pano_crop_rect(_ptr(valid), H, W, _ptr(heights), _ptr(result),
-                                           self.stream()), "pano_crop_rect")
+        _lib.check(self.lib.pano_crop_rect(
+            self.ctx(), _ptr(valid), H, W, _ptr(heights), _ptr(result)), "pano_crop_rect")
         res = result.cpu().numpy()
         if not res[0]:
             return None
         return tuple(int(v) for v in res[1:5])
 
     def plane_taps(self, ksize, sigma):
-        """Padded tap table of one Gaussian on the device, cached per (ksize, sigma)."""
-        torch = _torch()
+        """Padded host tap table of one Gaussian, cached per (ksize, sigma); the context
+        keeps the device copy."""
         key = ("plane", int(ksize), float(sigma))
         if key not in self._taps:
-            self._taps[key] = torch.from_numpy(padded_taps(gaussian_taps(ksize, sigma))).to(
-                self.device)
+            self._taps[key] = np.ascontiguousarray(padded_taps(gaussian_taps(ksize, sigma)))
         return self._taps[key]
 
     def blur_plane(self, plane, ksize, sigma, out=None):
@@ -1138,9 +1188,9 @@ class Engine:
             src[:, :w] = plane
         dst = out if out is not None and pitch == w else torch.empty_like(src)
         tmp = torch.empty_like(src)
-        _lib.check(self.lib.pano_blur_plane(_ptr(src), _ptr(dst), _ptr(tmp), h, w, pitch,
-                                            _ptr(self.plane_taps(ksize, sigma)), ksize,
-                                            self.stream()), "pano_blur_plane")
+        _lib.check(self.lib.pano_blur_plane(
+            self.ctx(), _ptr(src), _ptr(dst), _ptr(tmp), h, w, pitch,
+            self.plane_taps(ksize, sigma).ctypes.data, ksize), "pano_blur_plane")
         return dst[:, :w]
 
     def pyr_down(self, plane):
@@ -1149,7 +1199,7 @@ class Engine:
         h, w = plane.shape
         out = torch.empty(((h + 1) // 2, (w + 1) // 2), dtype=torch.float32,
                           device=self.device)
-        _lib.check(self.lib.pano_pyr_down(_ptr(plane), h, w, _ptr(out), self.stream()),
+        _lib.check(self.lib.pano_pyr_down(self.ctx(), _ptr(plane), h, w, _ptr(out)),
                    "pano_pyr_down")
         return out
 
@@ -1169,7 +1219,7 @@ class Engine:
             return mosaic, None, valid, []
         n_blur = n_levels - 1 if blend == "multiband" else 0
         patches, _ = self.warp_all(frames, plan, n_blur, luts=luts)
-        table = patch_table(patches, self.device)
+        table = patch_table(patches, self)
         if blend == "multiband":
             mosaic, fl, _, valid = self.multiband(patches, plan.shape, n_levels, want_float,
                                                   table)

@@ -97,28 +97,28 @@ class _Dev:
     def gray(self, frame):
         h, w = frame.shape[:2]
         out = self._new(h, w)
-        _lib.check(self.lib.pano_gray_u8(_eng._ptr(frame), h, w, _eng._ptr(out),
-                                         self.eng.stream()), "pano_gray_u8")
+        _lib.check(self.lib.pano_gray_u8(self.eng.ctx(), _eng._ptr(frame), h, w, _eng._ptr(out)),
+                   "pano_gray_u8")
         return out
 
     def up2(self, plane):
         h, w = plane.shape
         out = self._new(2 * h, 2 * w)
-        _lib.check(self.lib.pano_resize_up2(_eng._ptr(plane), h, w, _eng._ptr(out),
-                                            self.eng.stream()), "pano_resize_up2")
+        _lib.check(self.lib.pano_resize_up2(self.eng.ctx(), _eng._ptr(plane), h, w,
+                                            _eng._ptr(out)), "pano_resize_up2")
         return out
 
     def half(self, plane):
         h, w = plane.shape
         out = self._new(h // 2, w // 2)
-        _lib.check(self.lib.pano_decimate2(_eng._ptr(plane), h, w, _eng._ptr(out),
-                                           self.eng.stream()), "pano_decimate2")
+        _lib.check(self.lib.pano_decimate2(self.eng.ctx(), _eng._ptr(plane), h, w,
+                                           _eng._ptr(out)), "pano_decimate2")
         return out
 
     def sub(self, a, b):
         out = self._new(*a.shape)
-        _lib.check(self.lib.pano_subtract(_eng._ptr(a), _eng._ptr(b), C.c_size_t(a.numel()),
-                                          _eng._ptr(out), self.eng.stream()), "pano_subtract")
+        _lib.check(self.lib.pano_subtract(self.eng.ctx(), _eng._ptr(a), _eng._ptr(b),
+                                          C.c_size_t(a.numel()), _eng._ptr(out)), "pano_subtract")
         return out
 
     def blur(self, plane, sigma):
@@ -164,8 +164,8 @@ def sift_pyramid_device(frame, n_octaves=None, sigma=SIFT_SIGMA, layers=SIFT_LAY
             blur_into(stack[i], stack[i - 1], sig[i])
         diff = torch.empty((layers + 2, oh, ow), dtype=torch.float32, device=eng.device)
         for i in range(layers + 2):
-            _lib.check(eng.lib.pano_subtract(_eng._ptr(stack[i + 1]), _eng._ptr(stack[i]),
-                                             C.c_size_t(oh * ow), _eng._ptr(diff[i]), eng.stream()),
+            _lib.check(eng.lib.pano_subtract(eng.ctx(), _eng._ptr(stack[i + 1]), _eng._ptr(stack[i]),
+                                             C.c_size_t(oh * ow), _eng._ptr(diff[i])),
                        "pano_subtract")
         gauss.append(stack)
         dog.append(diff)
@@ -225,13 +225,13 @@ def sift_detect_device(frame, max_keypoints=1 << 18, pyramid=None):
     counts = torch.zeros(2, dtype=torch.int32, device=dev)
     for o, diff in enumerate(dog):
         _, oh, ow = diff.shape
-        _lib.check(lib.pano_sift_extrema(_eng._ptr(diff), oh, ow, o, SIFT_LAYERS, SIFT_CONTRAST,
-                                         SIFT_EDGE, SIFT_SIGMA, _eng._ptr(cands),
-                                         _eng._ptr(counts[0:]), max_keypoints, eng.stream()),
+        _lib.check(lib.pano_sift_extrema(eng.ctx(), _eng._ptr(diff), oh, ow, o, SIFT_LAYERS,
+                                         SIFT_CONTRAST, SIFT_EDGE, SIFT_SIGMA, _eng._ptr(cands),
+                                         _eng._ptr(counts[0:]), max_keypoints),
                    "pano_sift_extrema")
-    _lib.check(lib.pano_sift_orient(_eng._ptr(gptr), _eng._ptr(dims), SIFT_LAYERS, _eng._ptr(cands),
-                                    _eng._ptr(counts[0:]), max_keypoints, _eng._ptr(kpts),
-                                    _eng._ptr(counts[1:]), max_keypoints, eng.stream()),
+    _lib.check(lib.pano_sift_orient(eng.ctx(), _eng._ptr(gptr), _eng._ptr(dims), SIFT_LAYERS,
+                                    _eng._ptr(cands), _eng._ptr(counts[0:]), max_keypoints,
+                                    _eng._ptr(kpts), _eng._ptr(counts[1:]), max_keypoints),
                "pano_sift_orient")
     n_cand, n_kp = (int(v) for v in counts.cpu().numpy())
     if max(n_cand, n_kp) > max_keypoints:
@@ -245,9 +245,9 @@ def sift_detect_device(frame, max_keypoints=1 << 18, pyramid=None):
     desc = torch.empty((len(host), 128), dtype=torch.float32, device=dev)
     if len(host):
         dkp = torch.from_numpy(host.view(np.uint8).reshape(-1)).to(dev)
-        _lib.check(lib.pano_sift_describe(_eng._ptr(gptr), _eng._ptr(dims), SIFT_FIRST_OCTAVE,
-                                          _eng._ptr(dkp), len(host), _eng._ptr(desc), eng.stream()),
-                   "pano_sift_describe")
+        _lib.check(lib.pano_sift_describe(eng.ctx(), _eng._ptr(gptr), _eng._ptr(dims),
+                                          SIFT_FIRST_OCTAVE, _eng._ptr(dkp), len(host),
+                                          _eng._ptr(desc)), "pano_sift_describe")
     return host, desc
 
 

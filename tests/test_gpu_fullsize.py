@@ -1,0 +1,284 @@
+"""GPU: parity of the default kernels at plane level and at BASELINE sizes.
+
+* the matrix-core blur (``pano_multiband_blur``) compared PLANE BY PLANE with the
+  oracle's ``cv2.GaussianBlur`` (stitcher.py:218, 226), not only through the
+  collapsed mosaic; stated bound 1e-6 absolute on [0, 1] data (split-float16
+  operands, float32 accumulate), the measured maximum is printed;
+* BASELINE config 2 (8 x 1080p) at full size against the oracle: valid mask and
+  crop rectangle bit-exact, uint8 mosaic <= 1 LSB, float mosaic <= 1e-4 rel-L2;
+* the crop on the real config-3 valid mask and on a config-5-width mask
+  (>= 46 079 columns) against the oracle, bit-exact; the config-3 valid mask
+  itself against the oracle's inverse maps;
+* config 4: the Gaussian / DoG scale space of one 3840 x 2160 frame against the
+  oracle (all 11 octaves, 7680 x 4320 base).
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+REL_TOL = 1e-4
+PLANE_TOL = 1e-6        # blurred planes, absolute, data in [0, 1]
+
+
+def rel_l2(a, b):
+    return float(np.linalg.norm(a.astype(np.float64) - b) / np.linalg.norm(b))
+
+
+def _sharp_rgba(ref_patches, own):
+    """The blur input of stitcher.py:207-208: alpha replaced by owner == index."""
+    out = []
+    for idx, (warped, _, ir) in enumerate(ref_patches):
+        rgba = warped.copy()
+        rgba[..., 3] = (own[ir] == idx).astype(np.float32)
+        out.append(rgba)
+    return out
+
+
+@pytest.mark.parametrize("blur", ["mfma", "valu"])
+@pytest.mark.parametrize("kind,levels,size", [("A", 5, (400, 240)), ("B", 5, (330, 200)),
+                                              ("A", 8, (300, 170)), ("B", 8, (400, 240))])
+def test_multiband_blur_planes_match_oracle(oracle, blur, kind, levels, size):
+    """Whole-patch records through ``pano_multiband_blur``: every level's four
+    blurred planes (R, G, B and the sharp alpha) against ``oracle.gaussian_blur``.
+    L = 5: 33 / 57 / 73 / 87 taps (K-steps C = 1, 2, 3, 3); L = 8 adds 97 / 105 / 115
+    taps (C = 4); patch sizes are not multiples of 32, so every tile column and row
+    ends in a ragged tile.  Noise ("A") is the stress input, "B" the smooth one."""
+    from pano360_amd import engine, synth
+    eng = engine.Engine(blur=blur)
+    w, h = size
+    imgs, rots, intrs = synth.make_scene(4, w, h, sweep_deg=60.0, jitter=0.01, seed=90 + levels,
+                                         kind=kind)
+    shapes = [im.shape[:2] for im in imgs]
+    plan = eng.upload_plan(engine.Plan(shapes, rots, intrs, True, 10 ** 9))
+    n_blur = levels - 1
+    patches, _ = eng.warp_all(eng.upload_frames(imgs), plan, n_blur)
+    table = engine.patch_table(patches, eng)
+    owner, valid = eng.ownership(table, plan.shape)
+    eng.blur_and_compose(table, owner, valid, plan.shape, levels)
+    _, ref_patches, _ = oracle.warp_all(imgs, rots, intrs, True, 10 ** 9)
+    own = oracle.ownership(ref_patches, plan.shape)
+    assert np.array_equal(owner.cpu().numpy().astype(np.int32), own)
+    sig = engine.level_sigmas(levels)
+    worst = 0.0
+    for dp, rgba in zip(patches, _sharp_rgba(ref_patches, own)):
+        got = dp.blurred[:, :, :, :dp.w].cpu().numpy()              # [level][channel][h][w]
+        assert np.isfinite(got).all()
+        for k, s in enumerate(sig):
+            want = oracle.gaussian_blur(rgba, engine.gaussian_ksize(s), s)
+            err = np.abs(got[k].transpose(1, 2, 0) - want).max()
+            worst = max(worst, float(err))
+            assert err <= PLANE_TOL, (blur, kind, levels, k, err)
+    print(f"blurred planes ({blur}, {kind}, L={levels}): max abs error {worst:.3e}")
+
+
+@pytest.mark.parametrize("blur", ["mfma", "valu"])
+def test_multiband_blur_planes_match_reference_golden(blur):
+    """The same comparison against planes recorded while the REFERENCE ran (a spying
+    cv2.GaussianBlur inside its multiband_blend, tests/golden/scene_small_noise.npz): all
+    four levels of one patch of the small noise scene."""
+    from conftest import load_golden, scene_inputs
+    from pano360_amd import engine
+    g = load_golden("scene_small_noise")
+    imgs, rots, intrs, mr = scene_inputs(g)
+    eng = engine.Engine(blur=blur)
+    plan = eng.upload_plan(engine.Plan([im.shape[:2] for im in imgs], rots, intrs, True, mr))
+    patches, _ = eng.warp_all(eng.upload_frames(imgs), plan, 4)
+    table = engine.patch_table(patches, eng)
+    owner, valid = eng.ownership(table, plan.shape)
+    eng.blur_and_compose(table, owner, valid, plan.shape, 5)
+    dp = patches[int(g["blur_patch"])]
+    got = dp.blurred[:, :, :, :dp.w].cpu().numpy()
+    for k in range(4):
+        err = np.abs(got[k].transpose(1, 2, 0) - g[f"blur_out_{k}"]).max()
+        assert err <= PLANE_TOL, (blur, k, err)
+
+
+@pytest.mark.parametrize("blur", ["mfma", "valu"])
+def test_windowed_blur_planes_match_oracle(oracle, blur):
+    """The fused path's records (windows V, rectangles A cut out of the patches, tiles
+    anchored at multiples of 32 in patch coordinates): the blurred copies over A equal the
+    oracle's blur of the WHOLE patch cut to A, every level and channel."""
+    from pano360_amd import engine, synth
+    eng = engine.Engine(blur=blur)
+    imgs, rots, intrs = synth.make_scene(6, 640, 360, sweep_deg=50.0, jitter=0.01, seed=31,
+                                         kind="A")
+    shapes = [im.shape[:2] for im in imgs]
+    plan = engine.Plan(shapes, rots, intrs, True, 10 ** 9)
+    _, _, _, fused = eng.stitch(eng.upload_frames(imgs), plan, "multiband", 5, shortcut=False)
+    import torch
+    torch.cuda.synchronize()
+    _, ref_patches, _ = oracle.warp_all(imgs, rots, intrs, True, 10 ** 9)
+    own = oracle.ownership(ref_patches, plan.shape)
+    rgbas = _sharp_rgba(ref_patches, own)
+    sig = engine.level_sigmas(5)
+    want = {}
+    arena, base = fused.blurred, fused.blurred.data_ptr()
+    worst, seen = 0.0, 0
+    for rec in fused.table.host:
+        idx, ah, aw, ap = int(rec["index"]), int(rec["ah"]), int(rec["aw"]), int(rec["apitch"])
+        ay0, ax0 = int(rec["ay0"]), int(rec["ax0"])
+        off = (int(rec["blurred"]) - base) // 4
+        got = arena[off:off + 4 * 4 * ah * ap].view(4, 4, ah, ap)[:, :, :, :aw].cpu().numpy()
+        if idx not in want:
+            want[idx] = [oracle.gaussian_blur(rgbas[idx], engine.gaussian_ksize(s), s)
+                         for s in sig]
+        for k in range(4):
+            ref = want[idx][k][ay0:ay0 + ah, ax0:ax0 + aw]
+            err = np.abs(got[k].transpose(1, 2, 0) - ref).max()
+            worst = max(worst, float(err))
+            assert err <= PLANE_TOL, (blur, idx, k, err)
+        seen += 1
+    assert seen >= len(imgs)
+    assert (int(fused.table.host["aw"].max()) < max(r[3] - r[2] for r in plan.rects))
+    print(f"windowed blurred planes ({blur}): max abs error {worst:.3e} over {seen} records")
+
+
+def test_cfg2_full_size_against_oracle(eng, oracle):
+    """BASELINE config 2 as the bench runs it (8 x 1920x1080, 140 degree sweep, native
+    resolution, L = 5; smooth pixel set B for the relative-error criterion): valid mask
+    and crop rectangle bit-exact, uint8 mosaic within one level, float mosaic within
+    1e-4 relative L2 of ``oracle.stitch``."""
+    from pano360_amd import engine, synth
+    cfg = synth.CONFIGS["cfg2"]
+    imgs, rots, intrs = synth.make_scene(cfg["n"], cfg["width"], cfg["height"],
+                                         sweep_deg=cfg["sweep_deg"], seed=0, kind="B")
+    shapes = [im.shape[:2] for im in imgs]
+    plan = engine.Plan(shapes, rots, intrs, True, 10 ** 9)
+    assert plan.shape == (1237, 6400)
+    mosaic, fl, valid, _ = eng.stitch(eng.upload_frames(imgs), plan, "multiband", 5,
+                                      want_float=True)
+    oplan, ref_patches, _ = oracle.warp_all(imgs, rots, intrs, True, 10 ** 9)
+    assert oplan.shape == plan.shape and oplan.rects == plan.rects
+    ref_valid = oracle.valid(ref_patches, plan.shape)
+    got_valid = valid.cpu().numpy().astype(bool)
+    assert np.array_equal(got_valid, ref_valid)
+    assert eng.crop_rect(valid) == oracle.crop_rect(ref_valid)
+    ref_u8, ref_f = oracle.multiband_blend(ref_patches, plan.shape, 5, return_float=True)
+    got = mosaic.cpu().numpy()
+    lsb = np.abs(got.astype(int) - ref_u8.astype(int))
+    rel = rel_l2(fl.cpu().numpy(), ref_f)
+    print(f"cfg2 full size: rel-L2 {rel:.2e}, {int((lsb > 0).sum())} of {lsb.size} uint8 values "
+          f"differ by one level")
+    assert lsb.max() <= 1 and rel <= REL_TOL
+    # the paste and linear blenders on the unpadded plan: exact
+    for blend in ("none", "linear"):
+        plan_l = engine.Plan(shapes, rots, intrs, False, 10 ** 9)
+        got_l, _, _, _ = eng.stitch(eng.upload_frames(imgs), plan_l, blend)
+        assert np.array_equal(got_l.cpu().numpy(),
+                              oracle.stitch(imgs, rots, intrs, blend, max_resolution=10 ** 9))
+
+
+def test_cfg3_valid_and_crop_against_oracle(eng, oracle):
+    """BASELINE config 3 (32 x 4K): the valid mask of the fused path against the OR of
+    the oracle's inverse-map masks (stitcher.py:266-271, 305 MP of float64 maps on the
+    host cores), and the crop rectangle of that mask (2474 x 13760) bit-exact."""
+    from pano360_amd import engine, synth
+    cfg = synth.CONFIGS["cfg3"]
+    n, w, h = cfg["n"], cfg["width"], cfg["height"]
+    rots, intrs = synth.make_cameras(n, w, h, sweep_deg=cfg["sweep_deg"])
+    shapes = [(h, w)] * n
+    plan = eng.upload_plan(engine.Plan(shapes, rots, intrs, True, 10 ** 9))
+    owner, valid = eng.ownership_cameras(plan)
+    oplan = oracle.Plan(shapes, rots, intrs, True, 10 ** 9)
+    assert oplan.shape == plan.shape == (2474, 13760) and oplan.rects == plan.rects
+    ref_valid = np.zeros(plan.shape, bool)
+    for proj, rect in zip(oplan.projs, oplan.rects):
+        _, _, mask = oracle.inverse_map(proj, oplan, rect, (h, w))
+        ref_valid[rect[0]:rect[1], rect[2]:rect[3]] |= ~mask
+    got = valid.cpu().numpy().astype(bool)
+    assert np.array_equal(got, ref_valid)
+    assert eng.crop_rect(valid) == oracle.crop_rect(ref_valid)
+    # with the frames: the stitch reports the same mask
+    frames = eng.upload_frames([synth.make_frame(0, w, h, "A")] * 2)
+    _, _, valid2, _ = eng.stitch([frames[i % 2] for i in range(n)],
+                                 engine.Plan(shapes, rots, intrs, True, 10 ** 9), "multiband", 5)
+    assert np.array_equal(valid2.cpu().numpy().astype(bool), ref_valid)
+
+
+@pytest.mark.parametrize("shape", [(4948, 46079), (150, 65535), (3000, 46080)])
+def test_crop_at_cfg5_width(eng, oracle, shape):
+    """crop_mosaic's rectangle on masks as wide as config 5's mosaic (46 079 columns; the
+    kernel's limit is 65 535): a covered band with wavy upper and lower borders, sparse
+    holes and an invalid column run, bit-exact against the oracle."""
+    import torch
+    H, W = shape
+    rng = np.random.default_rng(H + W)
+    x = np.arange(W)
+    top = (0.08 * H * (1 + np.sin(x / 911.0))).astype(np.int64)
+    bot = H - (0.06 * H * (1 + np.cos(x / 1501.0))).astype(np.int64)
+    rows = np.arange(H)[:, None]
+    mask = (rows >= top[None, :]) & (rows < bot[None, :])
+    holes = rng.integers(0, H * W, size=max(H * W // 2_000_000, 3))
+    mask.reshape(-1)[holes] = False
+    mask[:, W // 3:W // 3 + 7] = False
+    dev = torch.from_numpy(mask.view(np.uint8)).to(eng.device)
+    assert eng.crop_rect(dev) == oracle.crop_rect(mask)
+
+
+def test_cfg4_scale_space_of_a_4k_frame(eng, oracle):
+    """BASELINE config 4 at full size, one frame: Gaussian and DoG pyramid of a
+    3840 x 2160 frame (first octave -1: a 7680 x 4320 base, 11 octaves) against the
+    oracle (oracle/sift_pyramid.py with the C oracle's GaussianBlur, which equals the
+    NumPy shim bit for bit).  Values are on the 0..255 scale; one FMA per tap against
+    multiply + add: <= 2e-4 on the Gaussian layers, <= 4e-4 on the DoG layers."""
+    import sift_pyramid as ref
+    from pano360_amd import features, synth
+    img = synth.make_frame(11, 3840, 2160, "B")
+    gauss, dog = features.sift_pyramid_device(eng.upload_frames([img])[0])
+    want_g, want_d = ref.sift_pyramid(
+        img, blur=lambda im, s: oracle.gaussian_blur(im, oracle.gaussian_ksize(s), s))
+    assert len(gauss) == len(want_g) == ref.n_octaves(2160, 3840) == 11
+    worst_g = worst_d = 0.0
+    for o in range(len(want_g)):
+        got_g, got_d = gauss[o].cpu().numpy(), dog[o].cpu().numpy()
+        assert got_g.shape == (6,) + want_g[o][0].shape and got_d.shape[0] == 5
+        for layer in range(6):
+            worst_g = max(worst_g, float(np.abs(got_g[layer] - want_g[o][layer]).max()))
+        for layer in range(5):
+            worst_d = max(worst_d, float(np.abs(got_d[layer] - want_d[o][layer]).max()))
+    print(f"cfg4 4K scale space: max abs error gauss {worst_g:.2e}, dog {worst_d:.2e}")
+    assert worst_g <= 2e-4 and worst_d <= 4e-4
+
+
+def test_two_contexts_on_two_streams_concurrently(eng):
+    """A context owns everything the library remembers (work lists, tile flags, tap
+    tables, timing): two engines - two ``pano_ctx`` - driven from two host threads on two
+    streams of one device at the same time each reproduce the single-stream mosaic bit for
+    bit, strip by strip (the column-strip decomposition of the multi-GPU path, 2 and 3
+    ranks emulated in turn by either thread)."""
+    import threading
+
+    import torch
+    from pano360_amd import dist as pdist
+    from pano360_amd import engine, synth
+    imgs, rots, intrs = synth.make_scene(10, 480, 270, sweep_deg=120.0, jitter=0.01, seed=41,
+                                         kind="A")
+    shapes = [im.shape[:2] for im in imgs]
+    plan = engine.Plan(shapes, rots, intrs, True, 10 ** 9)
+    whole, _, _, _ = eng.stitch(eng.upload_frames(imgs), plan, "multiband", 5)
+    torch.cuda.synchronize()
+    results, errors = {}, []
+
+    def worker(tag, world, blur):
+        try:
+            stream = torch.cuda.Stream(eng.device)
+            with torch.cuda.stream(stream):
+                mine = engine.Engine(eng.device, blur=blur)
+                for _ in range(4):
+                    strips, _ = pdist.emulate_on_one_device(mine, imgs, rots, intrs, 5, world)
+                stream.synchronize()
+            results[tag] = strips
+        except Exception as err:      # noqa: BLE001 - reported below, in the main thread
+            errors.append((tag, repr(err)))
+
+    threads = [threading.Thread(target=worker, args=args)
+               for args in (("a", 2, "mfma"), ("b", 3, "mfma"), ("c", 2, "valu"))]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors
+    assert torch.equal(results["a"], whole) and torch.equal(results["b"], whole)
+    # the vector-ALU blur rounds differently: within one level of the matrix-core mosaic
+    assert (results["c"].int() - whole.int()).abs().max().item() <= 1

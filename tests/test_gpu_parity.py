@@ -241,7 +241,7 @@ def test_ownership_bit_exact(eng, oracle):
     imgs, rots, intrs, mr = scene_inputs(g)
     plan = eng.upload_plan(engine.Plan([im.shape[:2] for im in imgs], rots, intrs, True, mr))
     patches, _ = eng.warp_all(eng.upload_frames(imgs), plan)
-    owner, valid = eng.ownership(engine.patch_table(patches, eng.device), plan.shape)
+    owner, valid = eng.ownership(engine.patch_table(patches, eng), plan.shape)
     _, ref_patches, _ = oracle.warp_all(imgs, rots, intrs, True, mr)
     assert np.array_equal(owner.cpu().numpy().astype(np.int32),
                           oracle.ownership(ref_patches, plan.shape))
@@ -258,7 +258,7 @@ def test_ownership_from_cameras_equals_ownership_from_planes(eng, name):
     imgs, rots, intrs, mr = scene_inputs(g)
     plan = eng.upload_plan(engine.Plan([im.shape[:2] for im in imgs], rots, intrs, True, mr))
     patches, _ = eng.warp_all(eng.upload_frames(imgs), plan)
-    owner_b, valid_b = eng.ownership(engine.patch_table(patches, eng.device), plan.shape)
+    owner_b, valid_b = eng.ownership(engine.patch_table(patches, eng), plan.shape)
     owner_a, valid_a = eng.ownership_cameras(plan)
     assert torch.equal(owner_a, owner_b) and torch.equal(valid_a, valid_b)
     assert np.array_equal(valid_a.cpu().numpy().astype(bool), g["mb_valid"])
@@ -279,7 +279,7 @@ def test_ownership_from_cameras_equals_ownership_from_planes(eng, name):
 
 
 @pytest.mark.parametrize("seed", range(6))
-def test_ownership_bounds_against_exhaustive_evaluation(eng, seed, monkeypatch):
+def test_ownership_bounds_against_exhaustive_evaluation(eng, seed):
     """The interval bounds that prune cameras per 64 x 16 tile never change the
     owner / valid maps: random rotations (roll and pitch included), mixed focal
     lengths, native and capped resolutions, a camera looking away."""
@@ -296,10 +296,13 @@ def test_ownership_bounds_against_exhaustive_evaluation(eng, seed, monkeypatch):
                       for _ in range(n)]).astype(np.float64)
     cap = (10 ** 9, 700, 180)[seed % 3]
     plan = eng.upload_plan(engine.Plan([(h, w)] * n, rots, intrs, seed % 2 == 0, cap))
-    monkeypatch.setenv("PANO_OWN_PRUNE", "0")
-    owner_all, valid_all = eng.ownership_cameras(plan)
-    torch.cuda.synchronize()
-    monkeypatch.setenv("PANO_OWN_PRUNE", "1")
+    from pano360_amd import _lib
+    eng.set_option(_lib.OPT_OWN_PRUNE, 0)                 # every camera at every pixel
+    try:
+        owner_all, valid_all = eng.ownership_cameras(plan)
+        torch.cuda.synchronize()
+    finally:
+        eng.set_option(_lib.OPT_OWN_PRUNE, 1)
     owner, valid = eng.ownership_cameras(plan)
     assert torch.equal(owner, owner_all) and torch.equal(valid, valid_all)
     assert (owner_all >= 0).any() and (owner_all < 0).any()
@@ -333,7 +336,7 @@ def test_ownership_pruning_is_exact(eng, case):
     imgs = [synth.make_frame(i, w, h, "A") for i in range(n)]
     plan = eng.upload_plan(engine.Plan([(h, w)] * n, rots, intrs, True, 10 ** 9))
     patches, _ = eng.warp_all(eng.upload_frames(imgs), plan)
-    owner_b, valid_b = eng.ownership(engine.patch_table(patches, eng.device), plan.shape)
+    owner_b, valid_b = eng.ownership(engine.patch_table(patches, eng), plan.shape)
     owner_a, valid_a = eng.ownership_cameras(plan)
     assert torch.equal(owner_a, owner_b) and torch.equal(valid_a, valid_b)
     if case == "identical":
@@ -364,7 +367,7 @@ def test_fused_windows_equal_whole_patch_path(eng, name, levels):
     assert torch.equal(f1.view(torch.int32), f2.view(torch.int32))
 
 
-def test_warp_need_flags_change_nothing(eng, monkeypatch):
+def test_warp_need_flags_change_nothing(eng):
     """The warp may skip the blocks of a window nobody reads (pano_blur_tiles' need flags):
     with the flags forced on and off the mosaics are the same bit for bit, also after the
     workspace was filled with other data."""
@@ -376,17 +379,20 @@ def test_warp_need_flags_change_nothing(eng, monkeypatch):
         shapes = [im.shape[:2] for im in imgs]
         frames = eng.upload_frames(imgs)
         out = {}
-        for mode in ("1", "0", "1"):
-            monkeypatch.setenv("PANO_WARP_NEED", mode)
-            engine.FusedPatches._arenas.get((str(eng.device), "planes")).fill_(float("nan"))
-            m, f, _, _ = eng.stitch(frames, engine.Plan(shapes, rots, intrs, True, 10 ** 9),
-                                    "multiband", 5, want_float=True)
-            if mode in out:
-                assert torch.equal(out[mode][0], m)
-            out[mode] = (m, f)
-        assert torch.equal(out["0"][0], out["1"][0])
-        assert torch.equal(out["0"][1].view(torch.int32), out["1"][1].view(torch.int32))
-        assert not torch.isnan(out["1"][1]).any()
+        try:
+            for mode in (True, False, True):
+                eng.warp_need = mode
+                eng.arena("planes", 1).fill_(float("nan"))
+                m, f, _, _ = eng.stitch(frames, engine.Plan(shapes, rots, intrs, True, 10 ** 9),
+                                        "multiband", 5, want_float=True)
+                if mode in out:
+                    assert torch.equal(out[mode][0], m)
+                out[mode] = (m, f)
+        finally:
+            eng.warp_need = "auto"
+        assert torch.equal(out[False][0], out[True][0])
+        assert torch.equal(out[False][1].view(torch.int32), out[True][1].view(torch.int32))
+        assert not torch.isnan(out[True][1]).any()
 
 
 def test_fused_windows_on_a_wide_sweep(eng, oracle):
@@ -808,7 +814,7 @@ def test_full_size_properties_1080p(eng):
                                          10 ** 9))
     non, _, valid_f, _ = eng.stitch(frames, plan_l, "none")
     non_staged, _, _, patches = eng.stitch(frames, plan_l, "none", fused=False)
-    _, valid_l = eng.ownership(engine.patch_table(patches, eng.device), plan_l.shape)
+    _, valid_l = eng.ownership(engine.patch_table(patches, eng), plan_l.shape)
     assert torch.equal(non, non_staged) and torch.equal(valid_f, valid_l)
     assert torch.equal(non.any(-1), valid_l.bool())
     lin, _, _, _ = eng.stitch(frames, plan_l, "linear")

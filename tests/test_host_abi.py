@@ -280,7 +280,7 @@ def test_native_window_layout_equals_windows_for():
         have = np.ones(n, np.uint8)
         rec = np.zeros(n * max_spans, dtype=engine.PATCH_DTYPE)
         lay = _lib.Layout()
-        _lib.check(lib.pano_layout_windows(raw.ctypes.data, n, max_spans, rects.ctypes.data,
+        _lib.check(lib.pano_layout_windows(32, raw.ctypes.data, n, max_spans, rects.ctypes.data,
                                            have.ctypes.data, radius, strip[0], strip[1], n_blur,
                                            rec.ctypes.data, len(rec), C.byref(lay)), "layout")
         want = []
@@ -304,7 +304,7 @@ def test_native_window_layout_equals_windows_for():
             blurred += n_blur * 4 * int(r["ah"]) * int(r["apitch"]) + 32
         assert (lay.n_tiles, lay.planes_floats, lay.blurred_floats) == (tiles, planes, blurred + 32)
         have[:] = 0
-        _lib.check(lib.pano_layout_windows(raw.ctypes.data, n, max_spans, rects.ctypes.data,
+        _lib.check(lib.pano_layout_windows(32, raw.ctypes.data, n, max_spans, rects.ctypes.data,
                                            have.ctypes.data, radius, strip[0], strip[1], n_blur,
                                            rec.ctypes.data, len(rec), C.byref(lay)), "layout")
         assert lay.missing == lay.n_records

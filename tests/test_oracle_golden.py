@@ -275,3 +275,22 @@ def test_resize_u8_oracle_properties():
     flat = np.full((30, 50, 3), 201, np.uint8)
     for shrink in (2, 3, 4, 2.5):
         assert np.all(cv.resize(flat, None, fx=1 / shrink, fy=1 / shrink) == 201)
+
+
+def test_multiband_blur_levels_golden(oracle):
+    """What the reference's multiband_blend hands to cv2.GaussianBlur and gets back
+    (stitcher.py:207-208, 218, 226; recorded by a spy while the reference ran): the input is
+    the warped patch with the sharp ownership mask as alpha, the sigmas are 4 sqrt(2k + 1),
+    and the oracle's blur reproduces every level bit for bit."""
+    g = load_golden("scene_small_noise")
+    imgs, rots, intrs, mr = scene_inputs(g)
+    idx = int(g["blur_patch"])
+    _, patches, _ = oracle.warp_all(imgs, rots, intrs, True, mr)
+    own = oracle.ownership(patches, tuple(int(v) for v in g["mb_shape"]))
+    rgba = patches[idx][0].copy()
+    rgba[..., 3] = own[patches[idx][2]] == idx
+    assert np.array_equal(bits(rgba), bits(g["blur_in"]))
+    assert np.array_equal(g["blur_sigma"], [np.sqrt(2 * k + 1.0) * 4 for k in range(4)])
+    for k, sigma in enumerate(g["blur_sigma"]):
+        got = oracle.gaussian_blur(g["blur_in"], oracle.gaussian_ksize(sigma), sigma)
+        assert np.array_equal(bits(got), bits(g[f"blur_out_{k}"])), k
