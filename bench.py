@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Headline benchmark: blended megapixels/s of warp + multiband blend.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--workload cfg3|cfg2|cfg5|cfg4]
 
 One "step" = one full stitch of the workload: uint8 frames + cameras resident
 in HBM -> uint8 mosaic in HBM (the boundary of the reference's own timer,
@@ -11,12 +11,20 @@ reference algorithm warps and blends ("P") / step time.
 
 Workload (BASELINE.json): the metric is quoted on N x 4K frames, so the default
 is config 3 - 32 synthetic 3840x2160 frames, 5 deg yaw steps, hfov 60 deg,
-native resolution, 5 levels.  With N GPUs a step stitches N such image sets,
-one per GPU (independent panoramas: weak scaling, no data-path collective);
-the same launch then also times ONE image set split into column strips over
-the N GPUs (strong scaling, strips gathered over RCCL) and reports it under
-"strips".  ``--mode strips`` makes that the headline instead; ``--workload
-cfg2`` runs the 8 x 1080p configuration.
+native resolution, 5 levels.
+
+N > 1 (one process per GPU, launched by torch.distributed.run): ONE panorama
+per step, its mosaic split into N column strips, one per GPU; every rank
+stitches its strip with the single-GPU kernels and the finished uint8 strips are
+composed on rank 0 over RCCL (default: point-to-point gather of the packed
+strips; ``--exchange reduce``: one sum-reduce of zero-padded full-width mosaics),
+the exchange of stitch k overlapping the kernels of stitch k + 1.  Strong
+scaling: total work is fixed as N grows.  The same launch then also times the
+other exchange and N independent image sets (replicas, no collective) and
+reports them as secondary fields.
+
+``--workload cfg4``: the Gaussian / DoG scale space (features.py:192-201) of 4K
+frames, one frame per step, with its own metric (input megapixels/s).
 
 Prints ONE JSON line on rank 0.
 """
@@ -24,9 +32,8 @@ import argparse
 import json
 import os
 import sys
+import threading
 import time
-
-import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -41,15 +48,20 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="cfg3", choices=["cfg2", "cfg3", "cfg5", "tiny"])
+    ap.add_argument("--workload", default="cfg3",
+                    choices=["cfg2", "cfg3", "cfg5", "cfg4", "tiny"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--mode", default="sets", choices=["sets", "strips"],
-                    help="N > 1: 'sets' = one independent image set per GPU and step "
-                         "(default, weak scaling); 'strips' = one image set, its mosaic "
-                         "split into column strips (strong scaling)")
-    ap.add_argument("--no-strips", action="store_true",
-                    help="N > 1, mode sets: skip the secondary column-strip measurement")
-    ap.add_argument("--strips-timeout", type=float, default=120.0)
+    ap.add_argument("--mode", default="strips", choices=["strips", "sets"],
+                    help="N > 1: 'strips' = one image set per step, its mosaic split into "
+                         "column strips (default, strong scaling); 'sets' = one independent "
+                         "image set per GPU and step (replicas, weak scaling)")
+    ap.add_argument("--exchange", default="gather", choices=["gather", "reduce"],
+                    help="N > 1, strips: how the strips are composed on rank 0")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="N > 1: skip the secondary measurements (other exchange, replicas)")
+    ap.add_argument("--secondary-timeout", type=float, default=180.0)
+    ap.add_argument("--detect", action="store_true",
+                    help="cfg4: time detectAndCompute (keypoints + descriptors) too")
     return ap.parse_args()
 
 
@@ -62,10 +74,10 @@ def workload(name):
 
 def pmc_traffic(name, workload=None):
     """HBM bytes per launch of kernel `name` from the committed PMC summary of this
-    same command (profiles/<round>/pmc_traffic.json, written from tools/pmc.sh
+    same command (profiles/<round>/pmc_traffic*.json, written from tools/pmc.sh
     output: FETCH_SIZE x 2 + WRITE_SIZE, KiB -> bytes, per MI355X_MICROARCH.md)."""
     import glob
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "pmc_traffic.json")))[::-1]:
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "pmc_traffic*.json")))[::-1]:
         with open(path) as fid:
             table = json.load(fid)
         if workload is not None and table.get("workload") != workload:
@@ -88,38 +100,18 @@ def measured_traffic(times, steps, workload):
     return total if seen else None
 
 
-def roofline_for(times, plan, patches, n_levels, steps, px_active, workload=None):
-    """Roofline entry of the kernel with the largest share of the timed region.
-    Algorithmic work per launch counts the pixels that launch really produced
-    (windows V / rectangles A of the patches, only the column tiles that were
-    not skipped as interior - DESIGN.md §Kernels), not the reference's
-    whole-patch count P."""
-    from pano360_amd import engine
-    name = max(times, key=lambda k: times[k][0])
-    total_ms, launches = times[name]
-    avg_s = total_ms / launches * 1e-3
+def algorithmic_bytes(plan, patches, n_levels, px_active):
+    """Algorithmic HBM bytes per step of each big kernel: every logical
+    array the kernel consumes or produces counted once, on the pixels this run really
+    processed (windows V / rectangles A / active tiles), not on the reference's P."""
     M = plan.shape[0] * plan.shape[1]
     win = [((p.window[1] - p.window[0]), (p.window[3] - p.window[2]),
             (p.area[1] - p.area[0]), (p.area[3] - p.area[2])) for p in patches]
-    px_rows = sum(vh * aw for vh, vw, ah, aw in win)      # row pass: rows of V x cols of A
-    px_cols = px_active or sum(ah * aw for vh, vw, ah, aw in win)   # column pass / gather
-    px_warp = sum(vh * vw for vh, vw, ah, aw in win)      # warp: V
-    taps = [engine.gaussian_ksize(s) for s in engine.level_sigmas(n_levels)]
-    if name in ("blur_rows_kernel", "blur_cols_kernel"):
-        # one launch = one level of one patch, 4 channels: taps FMAs per output
-        px = px_rows if name == "blur_rows_kernel" else px_cols
-        flop = steps * sum(2.0 * t * 4 * px for t in taps)
-        achieved = flop / launches / avg_s / 1e12
-        traffic, source = pmc_traffic(name, workload)
-        return dict(kernel=name, bound="mfma", achieved=achieved, peak=F32_PEAK_TFLOPS,
-                    unit="TFLOP/s", frac=achieved / F32_PEAK_TFLOPS, traffic=traffic,
-                    traffic_source=source,
-                    note="f32 FMA on the vector ALU; gfx950 f32 MFMA peak equals the "
-                         "f32 vector peak (157.3 TFLOP/s), no MFMA is issued",
-                    avg_launch_ms=avg_s * 1e3, launches=launches)
-    per_step = {
+    px_cols = px_active or sum(ah * aw for vh, vw, ah, aw in win)   # blurred / gathered pixels
+    px_warp = sum(vh * vw for vh, vw, ah, aw in win)                # warped pixels (V)
+    return {
         # 3 float planes written + the frame bytes under the window (about 1:1 scale)
-        "warp_spherical_kernel": 12.0 * px_warp + 3.0 * px_warp,
+        "warp_windows_kernel": 12.0 * px_warp + 3.0 * px_warp,
         # no pixel data read: owner (2 B) + valid (1 B) written per mosaic pixel
         "ownership_cameras_kernel": 3.0 * M,
         "owned_boxes_kernel": 2.0 * M,
@@ -129,17 +121,40 @@ def roofline_for(times, plan, patches, n_levels, steps, px_active, workload=None
         # and owner map (2 B) read over V, L-1 blurred RGBA copies written over the active
         # tiles; the intermediate image never reaches memory
         "blur_mfma_kernel": 14.0 * px_warp + 16.0 * (n_levels - 1) * px_cols,
-    }.get(name, 0.0)
-    achieved = per_step * steps / launches / avg_s / 1e9
+    }, dict(px_warp=px_warp, px_cols=px_cols,
+            px_rows=sum(vh * aw for vh, vw, ah, aw in win))
+
+
+def roofline_for(times, plan, patches, n_levels, steps, px_active, workload=None):
+    """Roofline entry of the kernel with the largest share of the timed region, plus the
+    time-weighted fraction over the three kernels that move the pixels (warp, blur,
+    collapse)."""
+    from pano360_amd import engine
+    per_step, px = algorithmic_bytes(plan, patches, n_levels, px_active)
+    name = max(times, key=lambda k: times[k][0])
+    total_ms, launches = times[name]
+    avg_s = total_ms / launches * 1e-3
+    taps = [engine.gaussian_ksize(s) for s in engine.level_sigmas(n_levels)]
+    achieved = per_step.get(name, 0.0) * steps / launches / avg_s / 1e9
     traffic, source = pmc_traffic(name, workload)
     out = dict(kernel=name, bound="hbm", achieved=achieved, peak=HBM_PEAK_GBPS,
                unit="GB/s", frac=achieved / HBM_PEAK_GBPS, traffic=traffic,
                traffic_source=source, avg_launch_ms=avg_s * 1e3, launches=launches)
     if name == "blur_mfma_kernel":
-        flop = steps * sum(2.0 * t * 4 * (px_rows + px_cols) for t in taps)
+        flop = steps * sum(2.0 * t * 4 * (px["px_rows"] + px["px_cols"]) for t in taps)
         out["note"] = ("split-float16 Toeplitz products on the matrix cores (3 MFMAs per "
                        "float32-accurate product); %.1f TFLOP/s of useful float32-equivalent "
                        "FMA work" % (flop / launches / avg_s / 1e12))
+    big = [k for k in ("warp_windows_kernel", "blur_mfma_kernel", "multiband_compose_kernel")
+           if k in times]
+    if big:
+        bytes_sum = sum(per_step[k] for k in big) * steps
+        secs = sum(times[k][0] for k in big) * 1e-3
+        out["weighted"] = dict(
+            kernels=big, achieved=bytes_sum / secs / 1e9,
+            frac=bytes_sum / secs / 1e9 / HBM_PEAK_GBPS, ms_per_step=secs / steps * 1e3,
+            GB_per_step=bytes_sum / steps / 1e9,
+            note="algorithmic bytes of the three pixel-moving kernels / their summed time")
     return out
 
 
@@ -165,21 +180,151 @@ def cpu_baseline(cfg):
                        f"oracle/pano_oracle.c (gcc -O2 -fopenmp), {os.cpu_count()} host CPUs")
 
 
-def timed_steps(eng, step, steps, warmup, fence):
+def timed_steps(eng, step, steps, warmup, fence, finish=None):
     """W untimed steps, then exactly K steps between two fences.  Returns
-    (seconds on this rank, last step's result, per-kernel HIP-event times)."""
+    (seconds on this rank, last step's result, per-kernel HIP-event times).  ``finish``
+    completes what the steps left in flight (the exchange of the last stitch) inside the
+    timed region."""
     for _ in range(warmup):
         step()
+    if finish:
+        finish()
     fence()
     eng.timing(True)
     t0 = time.perf_counter()
     for _ in range(steps):
         result = step()
+    if finish:
+        finish()
     fence()
     elapsed = time.perf_counter() - t0
     times = eng.kernel_times()
     eng.timing(False)
     return elapsed, result, times
+
+
+class Watchdog:
+    """The secondary measurements run a second round of collectives; if they stall, the
+    headline line (already complete) is printed with the failure noted and the process
+    exits NON-zero - a hang is a failure, whatever was measured before it."""
+
+    def __init__(self, seconds, rank, line):
+        self.rank, self.line, self.lock = rank, line, threading.Lock()
+        self.done = False
+        self.timer = threading.Timer(seconds, self.fire)
+        self.timer.daemon = True
+        self.seconds = seconds
+
+    def start(self):
+        self.timer.start()
+
+    def fire(self):
+        with self.lock:
+            if self.done:
+                return
+            self.done = True
+            if self.rank == 0:
+                self.line["secondary_error"] = f"no result within {self.seconds} s"
+                print(json.dumps(self.line), flush=True)
+        os._exit(3)
+
+    def cancel(self):
+        """True when the caller may still print (the timer had not fired)."""
+        self.timer.cancel()
+        with self.lock:
+            if self.done:
+                return False
+            self.done = True
+            return True
+
+
+def run_cfg4(args, eng, rank, world):
+    """Config 4: Gaussian / DoG scale space of 3840 x 2160 frames, one frame per step."""
+    import torch
+    from pano360_amd import features, synth
+    w, h = 3840, 2160
+    pool = [eng.upload_frames([synth.make_frame(1000 * rank + i, w, h, "B")])[0] for i in range(4)]
+    state = dict(i=0)
+
+    def step():
+        frame = pool[state["i"] % len(pool)]
+        state["i"] += 1
+        pyr = features.sift_pyramid_device(frame, eng=eng)
+        if args.detect:
+            kps, _ = features.sift_detect_device(frame, pyramid=pyr, eng=eng)
+            return pyr, len(kps)
+        return pyr, None
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(2):
+        step()
+    fence()
+    elapsed, (pyr, n_kp), times = timed_steps(eng, step, args.steps, args.warmup, fence)
+    return elapsed, pyr, n_kp, times, (w, h)
+
+
+def cfg4_line(args, world, elapsed, pyr, n_kp, times, size):
+    w, h = size
+    ms = elapsed / args.steps * 1e3
+    gauss, dog = pyr
+    g_px = sum(int(g.shape[0]) * int(g.shape[1]) * int(g.shape[2]) for g in gauss)
+    d_px = sum(int(d.shape[0]) * int(d.shape[1]) * int(d.shape[2]) for d in dog)
+    base_px = int(gauss[0].shape[1]) * int(gauss[0].shape[2])
+    # SURVEY §8d: per input pixel 1 (grey read) + 32 (2x base written + read) + (4 * 4/3) *
+    # (6 * 4 written + 5 * 4 read + 5 * 4 DoG written) = ~375 B; here counted on the real
+    # plane sizes of this frame: every Gaussian layer written once and read once, every DoG
+    # layer written once, the frame read once, the base written and read
+    algo = 3.0 * w * h + 8.0 * base_px + 8.0 * g_px + 4.0 * d_px
+    out = {
+        "metric": "input megapixels/sec (Gaussian + DoG scale space, 4K frames)",
+        "value": world * w * h / (ms * 1e-3) / 1e6, "unit": "MP/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": f"cfg4: Gaussian / DoG pyramid of {w}x{h} frames (SIFT front end, "
+                               f"first octave -1: {gauss[0].shape[2]}x{gauss[0].shape[1]} base, "
+                               f"{len(gauss)} octaves, 6 + 5 layers each), one frame per step "
+                               f"and GPU" + (", + keypoints and descriptors" if args.detect else ""),
+                   "frames_per_step": world, "gauss_megapixels": g_px / 1e6,
+                   "dog_megapixels": d_px / 1e6,
+                   "parallelism": "independent frames, one per GPU (replicas only)"},
+        "kernel_ms_per_step": {k: v[0] / args.steps for k, v in sorted(times.items())},
+    }
+    if n_kp is not None:
+        out["config"]["keypoints_per_frame"] = n_kp
+    name = max(times, key=lambda k: times[k][0]) if times else None
+    out["roofline"] = dict(kernel=name or "scale space (all launches)", bound="hbm",
+                           achieved=algo / (ms * 1e-3) / 1e9, peak=HBM_PEAK_GBPS, unit="GB/s",
+                           frac=algo / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, traffic=None,
+                           note="whole scale space of a frame: %.0f algorithmic bytes per input "
+                                "pixel (SURVEY §8d: ~375) / step time" % (algo / (w * h)))
+    if name is not None:
+        t_ms, launches = times[name]
+        out["roofline"]["avg_launch_ms"] = t_ms / launches
+        out["roofline"]["launches"] = launches
+    return out
+
+
+def cpu_baseline_cfg4():
+    """The NumPy/C oracle's scale space of one 4K frame on this host."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import pano_oracle as po
+    import sift_pyramid as ref
+    from pano360_amd import synth
+    img = synth.make_frame(1, 3840, 2160, "B")
+    t0 = time.time()
+    ref.sift_pyramid(img, blur=lambda im, s: po.gaussian_blur(im, po.gaussian_ksize(s), s))
+    dt = time.time() - t0
+    return dict(value=3840 * 2160 / dt / 1e6, unit="MP/s", cores=po.max_threads(), kind="port",
+                sample=f"one 3840x2160 frame, 11 octaves, in {dt:.1f} s; oracle = "
+                       f"oracle/sift_pyramid.py (NumPy) with the C oracle's OpenMP GaussianBlur, "
+                       f"{os.cpu_count()} host CPUs")
 
 
 def main():
@@ -206,6 +351,22 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
         else:
             dist.init_process_group(backend)
+        assert dist.get_world_size() == world == args.gpus, (dist.get_world_size(), world)
+
+    eng = engine.Engine(f"cuda:{local}")
+    reduce_device = eng.device if backend == "nccl" else "cpu"
+
+    if args.workload == "cfg4":
+        elapsed, pyr, n_kp, times, size = run_cfg4(args, eng, rank, world)
+        elapsed = pdist.max_over_ranks(elapsed, reduce_device)
+        if rank == 0:
+            out = cfg4_line(args, world, elapsed, pyr, n_kp, times, size)
+            if not args.no_cpu_baseline and world == 1:
+                out["cpu_baseline"] = cpu_baseline_cfg4()
+            print(json.dumps(out), flush=True)
+        if dist is not None:
+            dist.destroy_process_group()
+        return
 
     cfg = workload(args.workload)
     n_levels = cfg["n_levels"]
@@ -213,8 +374,6 @@ def main():
                                      sweep_deg=cfg.get("sweep_deg"),
                                      step_deg=cfg.get("step_deg"))
     shapes = [(cfg["height"], cfg["width"])] * cfg["n"]
-    eng = engine.Engine(f"cuda:{local}")
-    reduce_device = eng.device if backend == "nccl" else "cpu"
 
     def upload(set_id, which):      # one frame at a time: 120 x 8K is 12 GB
         return [eng.upload_frames([synth.make_frame(set_id * cfg["n"] + i, cfg["width"],
@@ -226,18 +385,23 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    strips = args.mode == "strips" and world > 1
-    if strips:
-        # ONE panorama (image set 0) split into column strips, one per rank; the
-        # finished strips are gathered on rank 0 (strong scaling)
-        runner = pdist.ShardedStitcher(eng, shapes, rots, intrs, n_levels, rank, world)
+    def run_strips(exchange):
+        """ONE panorama (image set 0) split into column strips, one per rank; the finished
+        strips are composed on rank 0 (strong scaling)."""
+        runner = pdist.ShardedStitcher(eng, shapes, rots, intrs, n_levels, rank, world,
+                                       exchange=exchange, depth=2)
         frames = upload(0, runner.my_frames)
+        for _ in range(3):        # setup: first-touch allocations of the workspaces
+            runner.step(frames)
+        runner.finish()
+        fence()
+        elapsed, (plan, _, patches), times = timed_steps(
+            eng, lambda: runner.step(frames), args.steps, args.warmup, fence, runner.finish)
+        return pdist.max_over_ranks(elapsed, reduce_device), plan, patches, times, runner
 
-        def step():
-            return runner.step(frames)
-    else:
-        # one image set per rank and step (rank r holds set r): the sets of a step
-        # are independent panoramas, nothing crosses a GPU (weak scaling)
+    def run_sets():
+        """One image set per rank and step (rank r holds set r): independent panoramas,
+        nothing crosses a GPU (replicas; the N = 1 path)."""
         my_set = pdist.assign_sets(world, rank, world)[0]
         frames = upload(my_set, range(cfg["n"]))
 
@@ -247,42 +411,55 @@ def main():
             # keep only the window geometry: holding the arenas across steps would make
             # the allocator carve out fresh gigabytes every step
             return plan, mosaic, list(patches)
+        for _ in range(3):
+            step()
+        fence()
+        elapsed, (plan, _, patches), times = timed_steps(eng, step, args.steps, args.warmup,
+                                                         fence)
+        return pdist.max_over_ranks(elapsed, reduce_device), plan, patches, times
 
-    for _ in range(3):            # setup: first-touch allocations of the workspaces
-        step()
-    fence()
     # Python's cyclic collector walks every live object (all of torch and numpy) when its
     # oldest generation comes due - 37 ms, ten stitches, in the middle of a timed step.
     # Everything alive after setup is long-lived: park it where the collector does not look.
     import gc
     gc.collect()
     gc.freeze()
-    elapsed, (plan, mosaic, patches), times = timed_steps(eng, step, args.steps, args.warmup,
-                                                          fence)
-    elapsed = pdist.max_over_ranks(elapsed, reduce_device)
-    sets_per_step = 1 if strips else world
+
+    strips = args.mode == "strips" and world > 1
+    runner = None
+    if strips:
+        elapsed, plan, patches, times, runner = run_strips(args.exchange)
+    else:
+        elapsed, plan, patches, times = run_sets()
+    sets_per_step = 1 if strips or world == 1 else world
 
     out = None
     if rank == 0:
         ms = elapsed / args.steps * 1e3
         P, M = plan.patch_pixels, plan.shape[0] * plan.shape[1]
         S = cfg["n"] * cfg["width"] * cfg["height"]
-        algo_bytes = sets_per_step * (3.0 * S + (33 + 64 * n_levels) * P
-                                      + (16 * n_levels + 3) * M)
+        ref_bytes = sets_per_step * (3.0 * S + (33 + 64 * n_levels) * P
+                                     + (16 * n_levels + 3) * M)
         if strips:
-            how = (f"one image set per step, its mosaic split into {world} column strips "
-                   f"(one per GPU), finished uint8 strips gathered on rank 0 over RCCL")
+            how = (f"one image set per step, its mosaic split into {world} column strips (one "
+                   f"per GPU, frames resident where needed), finished uint8 strips composed on "
+                   f"rank 0 over RCCL by {args.exchange}, overlapped with the next stitch")
         elif world > 1:
-            how = (f"{world} independent image sets per step, one per GPU, no data-path "
-                   f"collective (the column-strip split of ONE mosaic is timed under 'strips')")
+            how = (f"{world} independent image sets per step, one per GPU (replicas), no "
+                   f"data-path collective")
         else:
             how = "one image set per step on one GPU"
+        warped = sum((p.window[1] - p.window[0]) * (p.window[3] - p.window[2]) for p in patches)
+        blurred = sum((p.area[1] - p.area[0]) * (p.area[3] - p.area[2]) for p in patches)
         out = {
             "metric": "blended megapixels/sec (multiband)",
             "value": sets_per_step * P / (ms * 1e-3) / 1e6,
             "unit": "MP/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "n_gpus": world, "world_size": dist.get_world_size() if dist is not None else 1,
+            "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms,
+            # one stitch = one image set; with replicas a step holds several
+            "ms_per_stitch": ms / sets_per_step,
             "higher_is_better": True,
             "scaling": "strong" if strips else "weak",
             "vs_baseline": None,
@@ -299,72 +476,75 @@ def main():
                 "mosaic_megapixels": M / 1e6,
                 "parallelism": how,
             },
-            "pipeline": {
-                "algorithmic_GB_per_step": algo_bytes / 1e9,
-                "algorithmic_GBps": algo_bytes / (ms * 1e-3) / 1e9,
-                "frac_of_hbm_peak_all_gpus": algo_bytes / (ms * 1e-3) / 1e9
-                                             / (HBM_PEAK_GBPS * world),
-                "input_MPps": sets_per_step * S / (ms * 1e-3) / 1e6,
+            # `value` counts the reference's patch pixels P (every stage of the reference is
+            # linear in P); what the kernels of THIS rank really touch is far less - windows
+            # near owned pixels only, interior pixels straight from the frames:
+            "processed": {
+                "warped_megapixels_rank0": warped / 1e6,
+                "blurred_megapixels_rank0": blurred / 1e6,
+                "warped_MPps_rank0": warped / (ms * 1e-3) / 1e6,
                 "mosaic_MPps": sets_per_step * M / (ms * 1e-3) / 1e6,
+                "input_MPps": sets_per_step * S / (ms * 1e-3) / 1e6,
+            },
+            "reference_formula": {
+                "note": "SURVEY §8d bytes of the reference's whole-patch algorithm (3S + "
+                        "(33 + 64 L) P + (16 L + 3) M) over the step time: a ratio to the HBM "
+                        "peak above 1 says how much of that traffic the windows and the interior "
+                        "shortcut remove, not a bandwidth",
+                "GB_per_step": ref_bytes / 1e9,
+                "ratio_to_hbm_peak_all_gpus": ref_bytes / (ms * 1e-3) / 1e9
+                                              / (HBM_PEAK_GBPS * world),
             },
             "kernel_ms_per_step": {k: v[0] / args.steps for k, v in sorted(times.items())},
             "hbm_traffic": (lambda b: None if b is None else {
                 "GB_per_step_per_gpu": b / 1e9,
                 "GBps_per_gpu": b / (ms * 1e-3) / 1e9,
                 "frac_of_hbm_peak": b / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-                "source": "profiles/*/pmc_traffic.json (FETCH_SIZE x 2 + WRITE_SIZE per launch) "
+                "source": "profiles/*/pmc_traffic*.json (FETCH_SIZE x 2 + WRITE_SIZE per launch) "
                           "x launches per step, this rank's kernels"})(
-                measured_traffic(times, args.steps, args.workload)),
+                measured_traffic(times, args.steps, args.workload) if world == 1 else None),
             "roofline": roofline_for(times, plan, patches, n_levels, args.steps,
                                      eng.active_tile_pixels(), args.workload),
-            "active_megapixels": {
-                "warped": sum((p.window[1] - p.window[0]) * (p.window[3] - p.window[2])
-                              for p in patches) / 1e6,
-                "blurred": sum((p.area[1] - p.area[0]) * (p.area[3] - p.area[2])
-                               for p in patches) / 1e6},
         }
+        if world > 1:
+            out["scaling_note"] = "unmeasured on multi-GPU hardware by the builder (1-GPU boxes)"
+        if strips:
+            out["frames_on_rank0"] = len(runner.my_frames)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(cfg)
 
-    if world > 1 and not strips and not args.no_strips:
-        # Secondary measurement, same launch: ONE panorama over all GPUs (latency mode).
-        # It is the only part of this program with a data exchange, so a watchdog makes
-        # sure the headline line above is printed whatever happens here.
-        import threading
-
-        def give_up():
-            if rank == 0:
-                out["strips"] = {"error": f"no result within {args.strips_timeout} s"}
-                print(json.dumps(out), flush=True)
-            os._exit(0)
-
-        dog = threading.Timer(args.strips_timeout, give_up)
-        dog.daemon = True
+    if world > 1 and not args.no_secondary and args.workload != "cfg5":
+        # Secondary measurements, same launch: the other exchange, and replicas.
+        dog = Watchdog(args.secondary_timeout, rank, out)
         dog.start()
+        extra = {}
         try:
-            runner = pdist.ShardedStitcher(eng, shapes, rots, intrs, n_levels, rank, world)
-            sframes = upload(0, runner.my_frames)
-            for _ in range(3):
-                runner.step(sframes)
-            fence()
-            s_elapsed, (splan, _, _), s_times = timed_steps(
-                eng, lambda: runner.step(sframes), args.steps, args.warmup, fence)
-            s_elapsed = pdist.max_over_ranks(s_elapsed, reduce_device)
-            if rank == 0:
-                s_ms = s_elapsed / args.steps * 1e3
-                out["strips"] = {
-                    "what": f"one {cfg['n']}-frame image set per step, mosaic split into "
-                            f"{world} column strips, uint8 strips gathered on rank 0 "
-                            f"({backend}); strong scaling",
-                    "ms_per_step": s_ms,
-                    "value": splan.patch_pixels / (s_ms * 1e-3) / 1e6, "unit": "MP/s",
-                    "frames_on_rank0": len(runner.my_frames),
-                    "kernel_ms_per_step_rank0": {k: v[0] / args.steps
-                                                 for k, v in sorted(s_times.items())}}
-        except Exception as err:       # noqa: BLE001 - reported, the headline stands
-            if rank == 0:
-                out["strips"] = {"error": repr(err)[:300]}
-        dog.cancel()
+            if strips:
+                other = "reduce" if args.exchange == "gather" else "gather"
+                runner = None
+                e2, p2, _, _, _ = run_strips(other)
+                extra[f"strips_{other}"] = {"ms_per_step": e2 / args.steps * 1e3,
+                                            "value": p2.patch_pixels / e2 * args.steps / 1e6}
+                e3, p3, _, _ = run_sets()
+                extra["replicas"] = {
+                    "what": f"{world} independent image sets per step, one per GPU, no collective",
+                    "ms_per_step": e3 / args.steps * 1e3,
+                    "value": world * p3.patch_pixels / e3 * args.steps / 1e6, "unit": "MP/s"}
+            else:
+                e2, p2, _, _, _ = run_strips(args.exchange)
+                extra[f"strips_{args.exchange}"] = {
+                    "ms_per_step": e2 / args.steps * 1e3,
+                    "value": p2.patch_pixels / e2 * args.steps / 1e6}
+        except Exception as err:       # noqa: BLE001 - reported; the peers may be stuck in a
+            extra["error"] = repr(err)[:300]        # collective this rank left: end the job
+            if dog.cancel() and rank == 0:
+                out["secondary"] = extra
+                print(json.dumps(out), flush=True)
+            os._exit(4)
+        if not dog.cancel():
+            return
+        if rank == 0:
+            out["secondary"] = extra
 
     if rank == 0:
         print(json.dumps(out), flush=True)

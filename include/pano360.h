@@ -416,6 +416,13 @@ int pano_pyr_down(pano_ctx *ctx, const float *src, int h, int w, float *dst);
  *   pano_decimate2   resize(w/2 x h/2, INTER_NEAREST): float [h][w] -> [h/2][w/2]
  *   pano_subtract    out = a - b over n floats (one DoG layer) */
 int pano_gray_u8(pano_ctx *ctx, const uint8_t *bgr, int h, int w, float *out);
+/* One step of buildGaussianPyramid + buildDoGPyramid, fused (csrc/scalespace.hip):
+ *   dst = GaussianBlur(src, taps) (REFLECT_101; both passes in one launch, the row-pass
+ *   image stays in LDS), dog (optional) = dst - src.
+ * src, dst, dog: dev float [h][w] dense, distinct; taps: HOST float[ntaps] (the bare kernel
+ * of cv::getGaussianKernel, no padding), ntaps odd and <= 33 (sigma <= 4). */
+int pano_scale_step(pano_ctx *ctx, const float *src, int h, int w, const float *taps, int ntaps,
+                    float *dst, float *dog);
 int pano_resize_up2(pano_ctx *ctx, const float *src, int h, int w, float *dst);
 int pano_decimate2(pano_ctx *ctx, const float *src, int h, int w, float *dst);
 int pano_subtract(pano_ctx *ctx, const float *a, const float *b, size_t n, float *out);

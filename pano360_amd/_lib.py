@@ -108,6 +108,7 @@ _SIGNATURES = {
     "pano_blur_plane": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _i]),
     "pano_pyr_down": (_i, [_vp, _vp, _i, _i, _vp]),
     "pano_gray_u8": (_i, [_vp, _vp, _i, _i, _vp]),
+    "pano_scale_step": (_i, [_vp, _vp, _i, _i, _vp, _i, _vp, _vp]),
     "pano_resize_up2": (_i, [_vp, _vp, _i, _i, _vp]),
     "pano_decimate2": (_i, [_vp, _vp, _i, _i, _vp]),
     "pano_subtract": (_i, [_vp, _vp, _vp, C.c_size_t, _vp]),

@@ -63,6 +63,8 @@ enum PanoKernelId {
     PK_SIFT_ORIENT,
     PK_SIFT_DESCRIBE,
     PK_COMPOSE_INTERIOR,
+    PK_SCALE_STEP,
+    PK_KNN2,
     PK_COUNT
 };
 // ---- the context (include/pano360.h: pano_ctx) ------------------------------------

@@ -1,0 +1,150 @@
+// One Gaussian step of a SIFT octave, fused: both passes of the separable blur in one
+// launch (the row-pass image lives in LDS only) and the difference-of-Gaussian layer
+// emitted from the same tile.
+//
+// Reference: features.py:192-201 hands the whole scale space to OpenCV
+// (cv2.xfeatures2d.SIFT_create().detectAndCompute); what is restated is OpenCV's
+// buildGaussianPyramid / buildDoGPyramid: layer i = GaussianBlur(layer i-1, sigma_i)
+// (REFLECT_101, aperture cvRound(8 sigma + 1) | 1), DoG i-1 = layer i - layer i-1.
+// PARITY UNPINNED (OpenCV is not in the reference repo; oracle/sift_pyramid.py).
+//
+// Why one kernel: the step is pure streaming - 2 x (11..27) FMAs per pixel against 12
+// algorithmic bytes (read the previous layer, write the new one and the DoG).  As a row
+// launch + a column launch through a scratch plane + a subtract launch it moved 28 bytes
+// per pixel; fused it moves 12 + the halo re-reads (L2 hits).
+//
+// Tile: 64 x 32 outputs per 256-thread workgroup.  The (32 + 2r) x (64 + 2r) input tile
+// (r <= 16) is staged in LDS with REFLECT_101 applied on the way in, the row pass writes
+// (32 + 2r) x 64 sums back to LDS, the column pass reads them.  Register blocking: a
+// thread makes 4 adjacent row-pass outputs from one sliding window (r/2 + 1 LDS reads per
+// output instead of 2r + 1) and 8 stacked column-pass outputs of one column.  Sums run in
+// ascending tap order, one FMA per tap, like pano_blur_plane (csrc/blur.hip).
+#include "common.h"
+
+#define SS_TW 64
+#define SS_TH 32
+#define SS_RMAX 16
+#define SS_IN_W 128                            // >= 64 + 2 r + 7; a multiple of 64 floats keeps the
+                                               // row pass's 16-byte reads conflict-free
+#define SS_IN_H (SS_TH + 2 * SS_RMAX)          // 64
+#define SS_MID_PITCH (SS_TW + 1)               // column reads of 64 lanes: conflict-free
+#define SS_NTAP 36                             // 2 r + 1 rounded up to the row pass's trip of 4
+
+struct SsTaps {
+    float w[SS_NTAP];                          // zero beyond n
+    int n;
+};
+
+// dog (optional) = out - in at the same pixel
+__global__ __launch_bounds__(256) void scale_step_kernel(const float *__restrict__ in, int h, int w,
+                                                         SsTaps taps, float *__restrict__ out,
+                                                         float *__restrict__ dog) {
+    __shared__ __attribute__((aligned(16))) float s_in[SS_IN_H * SS_IN_W];
+    __shared__ float s_mid[SS_IN_H * SS_MID_PITCH];
+    const int tid = threadIdx.x;
+    const int r = taps.n >> 1;
+    const int x0 = blockIdx.x * SS_TW, y0 = blockIdx.y * SS_TH;
+    const int iw = SS_TW + 2 * r, ih = SS_TH + 2 * r;
+
+    // stage the input tile; rows / columns beyond the image arrive reflected.  The row pass
+    // reads whole 16-byte groups: columns up to the next multiple of 4 past the halo (+ 4) are
+    // zero-filled, so that the zero taps there multiply finite numbers
+    const int iwp = ((iw + 3) & ~3) + 4;
+    for (int i = tid; i < ih * iwp; i += 256) {
+        const int ty = i / iwp, tx = i - ty * iwp;
+        float v = 0.f;
+        if (tx < iw) {
+            const int sy = reflect_101(y0 - r + ty, h), sx = reflect_101(x0 - r + tx, w);
+            v = in[(size_t)sy * w + sx];
+        }
+        s_in[ty * SS_IN_W + tx] = v;
+    }
+    __syncthreads();
+
+    // row pass: ih rows x 64 outputs; a thread makes 4 adjacent outputs, four taps per trip
+    // from one aligned 16-byte LDS read (window = the previous read + this one)
+    const int trips = (taps.n + 3) >> 2;
+    for (int i = tid; i < ih * (SS_TW / 4); i += 256) {
+        const int ty = i >> 4, q = (i & 15) * 4;
+        const float4 *row = (const float4 *)(s_in + ty * SS_IN_W + q);
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        float4 lo = row[0];
+        for (int k = 0; k < trips; ++k) {
+            const float4 hi = row[k + 1];
+            const float w0 = taps.w[4 * k], w1 = taps.w[4 * k + 1], w2 = taps.w[4 * k + 2],
+                        w3 = taps.w[4 * k + 3];
+            // output j meets tap 4 k + t at window entry j + t
+            a0 = __builtin_fmaf(w0, lo.x, a0);
+            a1 = __builtin_fmaf(w0, lo.y, a1);
+            a2 = __builtin_fmaf(w0, lo.z, a2);
+            a3 = __builtin_fmaf(w0, lo.w, a3);
+            a0 = __builtin_fmaf(w1, lo.y, a0);
+            a1 = __builtin_fmaf(w1, lo.z, a1);
+            a2 = __builtin_fmaf(w1, lo.w, a2);
+            a3 = __builtin_fmaf(w1, hi.x, a3);
+            a0 = __builtin_fmaf(w2, lo.z, a0);
+            a1 = __builtin_fmaf(w2, lo.w, a1);
+            a2 = __builtin_fmaf(w2, hi.x, a2);
+            a3 = __builtin_fmaf(w2, hi.y, a3);
+            a0 = __builtin_fmaf(w3, lo.w, a0);
+            a1 = __builtin_fmaf(w3, hi.x, a1);
+            a2 = __builtin_fmaf(w3, hi.y, a2);
+            a3 = __builtin_fmaf(w3, hi.z, a3);
+            lo = hi;
+        }
+        float *m = s_mid + ty * SS_MID_PITCH + q;
+        m[0] = a0;
+        m[1] = a1;
+        m[2] = a2;
+        m[3] = a3;
+    }
+    __syncthreads();
+
+    // column pass: 64 columns x 32 rows, 8 stacked outputs per thread
+    const int cx = tid & 63, cy = (tid >> 6) * 8;
+    float acc[8];
+#pragma unroll
+    for (int o = 0; o < 8; ++o) acc[o] = 0.f;
+    const float *col = s_mid + cy * SS_MID_PITCH + cx;
+    float win[8];
+#pragma unroll
+    for (int o = 0; o < 7; ++o) win[o] = col[o * SS_MID_PITCH];
+    for (int k = 0; k < taps.n; ++k) {
+        win[7] = col[(k + 7) * SS_MID_PITCH];
+        const float wk = taps.w[k];
+#pragma unroll
+        for (int o = 0; o < 8; ++o) acc[o] = __builtin_fmaf(wk, win[o], acc[o]);
+#pragma unroll
+        for (int o = 0; o < 7; ++o) win[o] = win[o + 1];
+    }
+    const int x = x0 + cx;
+    if (x < w) {
+#pragma unroll
+        for (int o = 0; o < 8; ++o) {
+            const int y = y0 + cy + o;
+            if (y >= h) break;
+            const size_t at = (size_t)y * w + x;
+            out[at] = acc[o];
+            if (dog) dog[at] = acc[o] - s_in[(cy + o + r) * SS_IN_W + cx + r];
+        }
+    }
+}
+
+extern "C" int pano_scale_step(pano_ctx *ctx, const float *src, int h, int w, const float *taps,
+                               int ntaps, float *dst, float *dog) {
+    PANO_ENTER(ctx, "pano_scale_step");
+    PANO_REQUIRE(src && dst && taps, "pano_scale_step: null pointer");
+    PANO_REQUIRE(h > 0 && w > 0, "pano_scale_step: bad shape %dx%d", h, w);
+    PANO_REQUIRE(ntaps >= 1 && (ntaps & 1) && ntaps <= 2 * SS_RMAX + 1 && ntaps <= SS_NTAP,
+                 "pano_scale_step: aperture %d must be odd and at most %d", ntaps, 2 * SS_RMAX + 1);
+    PANO_REQUIRE(src != dst && src != dog, "pano_scale_step: in place is not supported");
+    SsTaps t = {};
+    t.n = ntaps;
+    for (int k = 0; k < ntaps; ++k) t.w[k] = taps[k];
+    dim3 grid(ceil_div(w, SS_TW), ceil_div(h, SS_TH));
+    PANO_TIMED(PK_SCALE_STEP, (hipStream_t)stream,
+               hipLaunchKernelGGL(scale_step_kernel, grid, dim3(256), 0, (hipStream_t)stream, src, h,
+                                  w, t, dst, dog));
+    PANO_LAUNCH_CHECK("scale_step_kernel");
+    return PANO_OK;
+}

@@ -1,29 +1,29 @@
 """Multi-GPU stitching: one process per GPU.
 
-Two ways to use N GPUs, both driven by ``bench.py --gpus N``:
+The reference is single-process; this is new design.  What shards is the
+*mosaic*, by columns (``ShardedStitcher``): rank r produces columns [c_r, c_{r+1}) of the
+final mosaic from the frames whose patches reach that strip, using exactly the single-GPU
+kernels restricted to the strip (``Engine.multiband_fused``, ``strip=``).  Ownership is
+evaluated on the strip grown by the blur radius and the patches' rectangles are cut to the
+strip, so no partial sums ever cross a GPU and each strip equals the same columns of the
+single-GPU mosaic bit for bit.  Frames are resident where they are needed: rank r holds the
+contiguous run of frames whose patch rectangles come within two blur radii of its strip.
 
-* **image sets** (throughput; ``assign_sets``): a stitching service sees a stream of
-  independent image sets (one panorama per time step of a camera rig).  Sets are
-  dealt out round-robin, every rank stitches its own sets with the single-GPU path
-  and nothing crosses a GPU - the path partitions by object, so there is no
-  data-path collective (weak scaling: per-GPU work is fixed as N grows).
-* **column strips** (latency of ONE panorama; ``ShardedStitcher``): the mosaic is
-  split into column strips, described below.
+The one exchange is the composition of the finished uint8 strips on rank 0
+(``StripExchange``), in either of two forms:
 
-The reference is single-process; this is new design.  What
-shards: the *mosaic*, by columns.  Rank r produces columns [c_r, c_{r+1}) of
-the final mosaic from the frames whose patches reach that strip, using exactly
-the single-GPU kernels restricted to the strip (``Engine.multiband_fused``,
-``strip=``): ownership is evaluated on the strip grown by the blur radius, the
-patches' rectangles are cut to the strip, so no partial sums ever cross a GPU
-and each strip equals the same columns of the single-GPU mosaic bit for bit.
-The only exchange is the composition of the finished uint8 strips, a gather
-onto rank 0 (RCCL point-to-point sends over xGMI, all seven links into rank 0
-busy at once - not a ring, which would be bound by one link).
+* ``"gather"`` (default): every rank sends its packed strip - 1/N of the mosaic - to rank 0
+  (RCCL point-to-point, all xGMI links into rank 0 busy at once);
+* ``"reduce"``: every rank writes its strip into a zero-initialised full-width mosaic and one
+  RCCL ``reduce(sum)`` onto rank 0 composites them - the supports are disjoint, so the sum
+  IS the composition, byte for byte.  It moves N times the bytes of the gather (every rank
+  contributes a whole mosaic), which a ring over point-to-point xGMI links pays in full.
 
-Frames are resident where they are needed: rank r holds the contiguous run of
-frames whose patch rectangles come within two blur radii of its strip, so
-neighbouring ranks both hold the few frames that straddle their boundary.
+Either way the exchange of stitch k is asynchronous (RCCL's own stream) and overlaps the
+kernels of stitch k + 1; buffers are allocated once and cycled.
+
+``assign_sets`` deals independent image sets out to the ranks (replicas of the single-GPU
+path, no collective): the secondary throughput figure of ``bench.py``.
 """
 
 from . import engine as _eng
@@ -58,48 +58,147 @@ def frames_for_strip(rects, strip, margin):
     return [i for i, (_, _, x0, x1) in enumerate(rects) if x0 < hi and x1 > lo]
 
 
-def pack_strip(mosaic, strip, width):
-    """Columns ``strip`` of an [H][W][3] mosaic as a dense [H][width][3] tensor
-    (zero padded on the right), the unit of the gather."""
-    import torch
-    c0, c1 = strip
-    out = torch.zeros((mosaic.shape[0], width, 3), dtype=mosaic.dtype, device=mosaic.device)
-    out[:, :c1 - c0] = mosaic[:, c0:c1]
-    return out
+class StripExchange:
+    """Composes the ranks' finished strips into the mosaic on rank 0, one stitch behind the
+    kernels: ``target()`` hands out the full-size [H][W][3] uint8 buffer the collapse writes
+    its strip into, ``submit()`` starts the (asynchronous) exchange of that buffer and
+    returns at once, ``collect()`` returns the oldest finished mosaic (rank 0; ``None``
+    elsewhere) - ``depth`` sets of buffers are cycled, so up to ``depth - 1`` exchanges are
+    in flight behind the stitch being computed.  ``world == 1`` needs no process group."""
 
+    MODES = ("gather", "reduce")
 
-def gather_strips(packed, bounds, rank, world, group=None):
-    """Compose the mosaic on rank 0 from every rank's packed strip.  Returns the
-    [H][W][3] mosaic on rank 0, None elsewhere.  world == 1 needs no process
-    group."""
-    import torch
-    width = bounds[-1]
-    if world == 1:
-        return packed[:, :width].contiguous()
-    import torch.distributed as dist
-    device = packed.device
-    if dist.get_backend(group) == "gloo":      # CPU rendezvous (tests, 1-GPU dry runs)
-        packed = packed.cpu()
-    parts = [torch.empty_like(packed) for _ in range(world)] if rank == 0 else None
-    dist.gather(packed, parts, dst=0, group=group)
-    if rank != 0:
-        return None
-    mosaic = torch.empty((packed.shape[0], width, 3), dtype=packed.dtype, device=device)
-    for r in range(world):
-        c0, c1 = bounds[r], bounds[r + 1]
-        mosaic[:, c0:c1] = parts[r][:, :c1 - c0]
-    return mosaic
+    def __init__(self, shape, bounds, rank, world, device, mode="gather", group=None, depth=2):
+        import torch
+        if mode not in self.MODES:
+            raise ValueError(f"exchange {mode!r}: one of {self.MODES}")
+        self.H, self.W = shape
+        self.bounds, self.rank, self.world, self.group = list(bounds), rank, world, group
+        self.strip = (self.bounds[rank], self.bounds[rank + 1])
+        self.mode, self.depth, self.device = mode, max(int(depth), 1), device
+        self.host_staged = False
+        if world > 1:
+            import torch.distributed as dist
+            if dist.get_world_size(group) != world:
+                raise ValueError(f"process group has {dist.get_world_size(group)} ranks, "
+                                 f"the strips were cut for {world}")
+            # gloo moves host memory only (CPU tests, 1-GPU dry runs): stage through the host
+            self.host_staged = (dist.get_backend(group) == "gloo"
+                                and torch.device(device).type != "cpu")
+        widths = [b - a for a, b in zip(self.bounds[:-1], self.bounds[1:])]
+        self.pack_w = max(widths)
+        self.even = len(set(widths)) == 1
+        u8 = dict(dtype=torch.uint8, device=device)
+        # the collapse writes only its strip's columns: everything else stays zero for good
+        # (reduce: rank 0's copy receives the sum in place and is wiped again in collect)
+        self.full = [torch.zeros((self.H, self.W, 3), **u8)
+                     for _ in range(self.depth if mode == "reduce" or world == 1 else 1)]
+        if mode == "gather" and world > 1:
+            self.packed = [torch.zeros((self.H, self.pack_w, 3), **u8) for _ in range(self.depth)]
+            self.parts = ([torch.empty((world, self.H, self.pack_w, 3), **u8)
+                           for _ in range(self.depth)] if rank == 0 else None)
+            self.mosaic = ([torch.empty((self.H, self.W, 3), **u8) for _ in range(self.depth)]
+                           if rank == 0 else None)
+        self.slot = 0
+        self.inflight = []              # [(slot, work or None)], oldest first
+
+    def target(self):
+        """The buffer the next stitch's collapse writes its strip into."""
+        if len(self.inflight) >= self.depth:
+            raise RuntimeError("collect() the finished mosaic before starting another stitch")
+        return self.full[self.slot % len(self.full)]
+
+    def submit(self):
+        """Start the exchange of the buffer ``target()`` handed out."""
+        import torch
+        slot = self.slot
+        self.slot = (self.slot + 1) % self.depth
+        work = None
+        if self.world > 1:
+            import torch.distributed as dist
+            if self.mode == "reduce":
+                buf = self.full[slot]
+                if self.host_staged:
+                    host = buf.cpu()
+                    dist.reduce(host, dst=0, op=dist.ReduceOp.SUM, group=self.group)
+                    if self.rank == 0:
+                        buf.copy_(host)
+                else:
+                    work = dist.reduce(buf, dst=0, op=dist.ReduceOp.SUM, group=self.group,
+                                       async_op=True)
+            else:
+                c0, c1 = self.strip
+                packed = self.packed[slot]
+                packed[:, :c1 - c0].copy_(self.full[0][:, c0:c1])
+                parts = self.parts[slot] if self.rank == 0 else None
+                if self.host_staged:
+                    hp = packed.cpu()
+                    hparts = ([torch.empty_like(hp) for _ in range(self.world)]
+                              if self.rank == 0 else None)
+                    dist.gather(hp, hparts, dst=0, group=self.group)
+                    if self.rank == 0:
+                        parts.copy_(torch.stack(hparts))
+                else:
+                    work = dist.gather(packed, list(parts.unbind(0)) if self.rank == 0 else None,
+                                       dst=0, group=self.group, async_op=True)
+        self.inflight.append((slot, work))
+
+    def collect(self):
+        """The oldest stitch's mosaic, [H][W][3] uint8 on rank 0 (valid until its buffers
+        come round again, ``depth`` stitches later), ``None`` on the other ranks."""
+        slot, work = self.inflight.pop(0)
+        if work is not None:
+            work.wait()                  # orders the current stream behind the collective
+        if self.rank != 0:
+            return None
+        if self.world == 1:
+            return self.full[slot]
+        if self.mode == "reduce":
+            done = self.full[slot]
+            if self.depth == 1:
+                return done.clone()
+            return done
+        parts, mosaic = self.parts[slot], self.mosaic[slot]
+        if self.even:
+            mosaic.view(self.H, self.world, self.pack_w, 3).copy_(parts.permute(1, 0, 2, 3))
+        else:
+            for r in range(self.world):
+                c0, c1 = self.bounds[r], self.bounds[r + 1]
+                mosaic[:, c0:c1].copy_(parts[r, :, :c1 - c0])
+        return mosaic
+
+    def recycle(self):
+        """reduce mode: on rank 0 the sum landed in this rank's strip buffer, and a backend may
+        use the other ranks' buffers as workspace (gloo does): wipe the columns outside the
+        strip before the buffer takes the next one (a memset, ~20 us for 100 MB)."""
+        if self.mode != "reduce" or self.world == 1:
+            return
+        c0, c1 = self.strip
+        buf = self.full[self.slot % len(self.full)]
+        if c0 > 0:
+            buf[:, :c0].zero_()
+        if c1 < self.W:
+            buf[:, c1:].zero_()
+
+    def drain(self):
+        """Finish every exchange in flight; returns the last mosaic (rank 0) or None."""
+        last = None
+        while self.inflight:
+            last = self.collect()
+        return last
 
 
 class ShardedStitcher:
-    """Strong-scaling driver used by ``bench.py --gpus N`` and the tests.
+    """One panorama over ``world`` GPUs (strong scaling); used by ``bench.py --gpus N`` and
+    the tests.
 
-    ``my_frames``: the camera indices whose frames must be uploaded on this
-    rank before ``step`` is called (fixed by the cameras, decided here once).
-    """
+    ``my_frames``: the camera indices whose frames must be uploaded on this rank before
+    ``step`` is called (fixed by the cameras, decided here once).  ``step`` runs this rank's
+    strip of one stitch and starts its exchange; the composed mosaic of the PREVIOUS step
+    comes back from the same call (rank 0), the last one from ``finish()``."""
 
     def __init__(self, eng, shapes, rots, intrs, n_levels, rank, world, max_resolution=10 ** 9,
-                 group=None):
+                 group=None, exchange="gather", depth=2):
         self.eng, self.rank, self.world, self.group = eng, rank, world, group
         self.shapes, self.rots, self.intrs = shapes, rots, intrs
         self.n_levels, self.max_resolution = n_levels, max_resolution
@@ -108,31 +207,42 @@ class ShardedStitcher:
                      default=0)
         self.bounds = strip_bounds(plan.shape[1], world)
         self.strip = (self.bounds[rank], self.bounds[rank + 1])
-        self.pack_width = max(b - a for a, b in zip(self.bounds[:-1], self.bounds[1:]))
         # windows reach one radius past the strip for A's owners and one more for V
         self.my_frames = frames_for_strip(plan.rects, self.strip, 2 * radius)
+        # exchange=None: geometry only (emulation of the ranks on one device)
+        self.exchange = (StripExchange(plan.shape, self.bounds, rank, world, eng.device,
+                                       exchange, group, depth) if exchange else None)
 
     def step(self, frames):
-        """frames[j] = device tensor of camera my_frames[j].  Returns
-        (plan, mosaic on rank 0 / None elsewhere, this rank's patches)."""
+        """frames[j] = device tensor of camera my_frames[j].  Returns (plan, the previous
+        step's mosaic on rank 0 / None, this rank's patches)."""
+        ex = self.exchange
         plan = _eng.Plan(self.shapes, self.rots, self.intrs, True, self.max_resolution)
         self.eng.upload_plan(plan)
-        mosaic, _, _, patches = self.eng.multiband_fused(
-            frames, plan, self.n_levels, frame_ids=self.my_frames, strip=self.strip)
-        packed = pack_strip(mosaic, self.strip, self.pack_width)
-        full = gather_strips(packed, self.bounds, self.rank, self.world, self.group)
-        return plan, full, list(patches)          # window geometry only, not the arenas
+        ex.recycle()
+        _, _, _, patches = self.eng.multiband_fused(
+            frames, plan, self.n_levels, frame_ids=self.my_frames, strip=self.strip,
+            mosaic_out=ex.target())
+        ex.submit()
+        # the exchange just started runs behind the next stitch's kernels; what is handed
+        # back is the stitch before it (depth 1: this one, synchronously)
+        previous = ex.collect() if len(ex.inflight) > ex.depth - 1 else None
+        return plan, previous, list(patches)          # window geometry only, not the arenas
+
+    def finish(self):
+        """Completes the exchanges in flight; the last stitch's mosaic on rank 0."""
+        return self.exchange.drain()
 
 
 def emulate_on_one_device(eng, imgs, rots, intrs, n_levels, world, max_resolution=10 ** 9):
-    """Run every rank's ``step`` one after the other on a single GPU and compose
+    """Run every rank's strip one after the other on a single GPU and compose
     the strips locally - the test double of an N-GPU run."""
     import torch
     shapes = [im.shape[:2] for im in imgs]
     strips, bounds = [], None
     for rank in range(world):
-        st = ShardedStitcher(eng, shapes, rots, intrs, n_levels, rank, world, max_resolution)
-        st.world = 1                       # no process group: keep the packed strip
+        st = ShardedStitcher(eng, shapes, rots, intrs, n_levels, rank, world, max_resolution,
+                             exchange=None)
         frames = eng.upload_frames([imgs[i] for i in st.my_frames])
         plan = _eng.Plan(shapes, rots, intrs, True, max_resolution)
         eng.upload_plan(plan)

@@ -833,14 +833,15 @@ class Engine:
         return total
 
     def compose_interior_async(self, owner, shape, strip, interior, cams, plan, luts,
-                               want_float=False):
+                               want_float=False, mosaic_out=None):
         """Part 1 of the collapse - the interior pixels, which need the owner map and
         the frames only - queued on the side stream behind everything queued so far.
         Returns (mosaic, float mosaic, event) for ``blur_and_compose(out=...)``."""
         torch = _torch()
         H, W = shape
         main = torch.cuda.current_stream(self.device)
-        mosaic = torch.empty((H, W, 3), dtype=torch.uint8, device=self.device)
+        mosaic = (mosaic_out if mosaic_out is not None else
+                  torch.empty((H, W, 3), dtype=torch.uint8, device=self.device))
         fl = (torch.empty((H, W, 3), dtype=torch.float32, device=self.device)
               if want_float else None)
         ready = torch.cuda.Event()
@@ -881,7 +882,7 @@ class Engine:
 
     def blur_and_compose(self, table, owner, valid, shape, n_levels, want_float=False,
                          strip=None, interior=None, cams=None, plan=None, luts=None, out=None,
-                         prepared=None):
+                         prepared=None, mosaic_out=None):
         """All Gaussian levels of all patches (n_levels launches), then the gather
         over the mosaic columns ``strip`` (default: all of them).  With an
         ``interior`` map, blur tiles and gathers are skipped where the result is
@@ -904,7 +905,8 @@ class Engine:
                 "pano_multiband_blur")
             self.last_tiles = (table, flags)        # for active_tile_pixels (reporting)
         if out is None:
-            mosaic = torch.empty((H, W, 3), dtype=torch.uint8, device=self.device)
+            mosaic = (mosaic_out if mosaic_out is not None else
+                      torch.empty((H, W, 3), dtype=torch.uint8, device=self.device))
             fl = (torch.empty((H, W, 3), dtype=torch.float32, device=self.device)
                   if want_float else None)
             part = 0
@@ -1056,7 +1058,7 @@ class Engine:
         return self.owned_regions(owner, n, strip)[0]
 
     def multiband_fused(self, frames, plan, n_levels, want_float=False, frame_ids=None,
-                        strip=None, shortcut=True, luts=None):
+                        strip=None, shortcut=True, luts=None, mosaic_out=None):
         """The headline path, for the mosaic columns ``strip`` = (c0, c1) (default:
         the whole mosaic).  ``frames[j]`` is the frame of camera ``frame_ids[j]``
         (default: all cameras in order); every camera whose patch reaches within
@@ -1067,7 +1069,8 @@ class Engine:
         in there), each patch's rectangle A is cut to the strip and its window V
         grows from that.  Strips therefore shard a stitch over GPUs with no
         exchange inside the blend, and the union of the strips' columns is the
-        single-GPU mosaic bit for bit."""
+        single-GPU mosaic bit for bit.  ``mosaic_out``: a uint8 [H][W][3] buffer to
+        write the strip's columns into instead of a fresh one (other columns untouched)."""
         H, W = plan.shape
         c0, c1 = strip if strip is not None else (0, W)
         taps, ntaps, n_blur, radius = self.blur_tables(n_levels)
@@ -1091,7 +1094,7 @@ class Engine:
         # out the windows, and run beside the warp.  (Queued behind the warp instead they
         # share the CUs with the blur and slow it by as much as they take: measured.)
         early = (self.compose_interior_async(owner, plan.shape, (c0, c1), interior, cams, plan,
-                                             luts, want_float)
+                                             luts, want_float, mosaic_out)
                  if interior is not None and self.overlap_interior else None)
         # the host is on the critical path from here to the warp: one native call lays out
         # the records (rectangles A and V, arena offsets, tile offsets)
@@ -1128,7 +1131,7 @@ class Engine:
             _ptr(plan.dev[1]), _ptr(plan.dev[2]), *self._lut_args(luts), _ptr(need)), "pano_warp_windows")
         mosaic, fl = self.blur_and_compose(table, owner, valid, plan.shape, n_levels,
                                            want_float, (c0, c1), interior, cams, plan, luts,
-                                           out=early, prepared=prepared)
+                                           out=early, prepared=prepared, mosaic_out=mosaic_out)
         return mosaic, fl, valid, patches
 
     def blend_fused(self, frames, plan, linear, frame_ids=None, strip=None, luts=None):

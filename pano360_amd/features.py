@@ -8,7 +8,7 @@
   ``cv2.xfeatures2d.SIFT_create().detectAndCompute``.
 
 All filters run in ``libpano360_hip.so`` (``pano_blur_plane``, ``pano_pyr_down``,
-``pano_gray_u8``, ``pano_resize_up2``, ``pano_decimate2``, ``pano_subtract``).
+``pano_gray_u8``, ``pano_resize_up2``, ``pano_decimate2``, ``pano_scale_step``).
 The SIFT arithmetic is inside OpenCV, not in the reference repo: its published
 algorithm (SIFT defaults: sigma 1.6, 3 layers per octave, first octave -1) is
 restated, parity unpinned.
@@ -125,12 +125,25 @@ class _Dev:
         return self.eng.blur_plane(plane, _eng.gaussian_ksize(sigma), sigma).contiguous()
 
 
-def sift_pyramid_device(frame, n_octaves=None, sigma=SIFT_SIGMA, layers=SIFT_LAYERS):
+_STEP_TAPS = {}
+
+
+def _step_taps(sigma):
+    """cv::getGaussianKernel(cvRound(8 sigma + 1) | 1, sigma) as a host float32 array."""
+    key = float(sigma)
+    if key not in _STEP_TAPS:
+        _STEP_TAPS[key] = np.ascontiguousarray(_eng.gaussian_taps(_eng.gaussian_ksize(key), key))
+    return _STEP_TAPS[key]
+
+
+def sift_pyramid_device(frame, n_octaves=None, sigma=SIFT_SIGMA, layers=SIFT_LAYERS, eng=None):
     """Gaussian and DoG pyramids of a uint8 BGR frame already on the device.
     Returns (gauss, dog): lists over octaves of contiguous stacks
-    [layers+3][h][w] / [layers+2][h][w] (index them like lists of planes)."""
+    [layers+3][h][w] / [layers+2][h][w] (index them like lists of planes).
+    One launch per layer: ``pano_scale_step`` blurs layer i-1 into layer i (both passes, the
+    row-pass image staying in LDS) and writes the DoG layer i-1 from the same tile."""
     import torch
-    eng = _eng.engine()
+    eng = eng or _eng.engine()
     dev = _Dev(eng)
     h, w = frame.shape[:2]
     if n_octaves is None:
@@ -141,10 +154,12 @@ def sift_pyramid_device(frame, n_octaves=None, sigma=SIFT_SIGMA, layers=SIFT_LAY
     sig = sift_sigmas(sigma, layers)
     gauss, dog = [], []
 
-    def blur_into(dst, src, s):
-        res = eng.blur_plane(src, _eng.gaussian_ksize(s), s, out=dst)
-        if res.data_ptr() != dst.data_ptr():
-            dst.copy_(res)
+    def step(src, s, dst, diff):
+        taps = _step_taps(s)
+        hh, ww = src.shape
+        _lib.check(eng.lib.pano_scale_step(eng.ctx(), _eng._ptr(src), hh, ww, taps.ctypes.data,
+                                           len(taps), _eng._ptr(dst), _eng._ptr(diff)),
+                   "pano_scale_step")
 
     for o in range(n_octaves):
         if o == 0:
@@ -156,17 +171,13 @@ def sift_pyramid_device(frame, n_octaves=None, sigma=SIFT_SIGMA, layers=SIFT_LAY
             first = dev.half(prev)
         oh, ow = first.shape
         stack = torch.empty((layers + 3, oh, ow), dtype=torch.float32, device=eng.device)
+        diff = torch.empty((layers + 2, oh, ow), dtype=torch.float32, device=eng.device)
         if o == 0:
-            blur_into(stack[0], first, sig_diff)
+            step(first, sig_diff, stack[0], None)
         else:
             stack[0].copy_(first)
         for i in range(1, layers + 3):
-            blur_into(stack[i], stack[i - 1], sig[i])
-        diff = torch.empty((layers + 2, oh, ow), dtype=torch.float32, device=eng.device)
-        for i in range(layers + 2):
-            _lib.check(eng.lib.pano_subtract(eng.ctx(), _eng._ptr(stack[i + 1]), _eng._ptr(stack[i]),
-                                             C.c_size_t(oh * ow), _eng._ptr(diff[i])),
-                       "pano_subtract")
+            step(stack[i - 1], sig[i], stack[i], diff[i - 1])
         gauss.append(stack)
         dog.append(diff)
     return gauss, dog
@@ -209,14 +220,14 @@ def sift_sort_unique(kps):
     return kps
 
 
-def sift_detect_device(frame, max_keypoints=1 << 18, pyramid=None):
+def sift_detect_device(frame, max_keypoints=1 << 18, pyramid=None, eng=None):
     """detectAndCompute on a uint8 BGR frame on the device.  Returns (keypoints as a
     KP_DTYPE array in OpenCV's order, descriptors float32 [K][128] with values 0..255).
     ``pyramid`` = (gauss, dog) device stacks replaces the scale space of ``frame``."""
     import torch
-    eng = _eng.engine()
+    eng = eng or _eng.engine()
     lib = eng.lib
-    gauss, dog = pyramid if pyramid is not None else sift_pyramid_device(frame)
+    gauss, dog = pyramid if pyramid is not None else sift_pyramid_device(frame, eng=eng)
     dev = eng.device
     dims = torch.tensor([v for g in gauss for v in g.shape[1:]], dtype=torch.int32, device=dev)
     gptr = torch.tensor([g.data_ptr() for g in gauss], dtype=torch.int64, device=dev)

@@ -1,7 +1,9 @@
-"""CPU, world_size 2 over gloo: the only exchange of the multi-GPU path (strip
-gather onto rank 0) and the host-side sharding logic.  The kernels themselves
-need a GPU; their strip-restricted form is checked against the whole-mosaic run
-in tests/test_gpu_parity.py::test_column_strips_compose_the_single_gpu_mosaic."""
+"""CPU, world_size 2 and 3 over gloo: the only exchange of the multi-GPU path (the
+composition of the ranks' strips on rank 0: point-to-point gather, or sum-reduce of
+zero-padded mosaics; pipelined one stitch deep) driven through the same ShardedStitcher
+steps bench.py --gpus N runs, and the host-side sharding logic.  The kernels themselves
+need a GPU; their strip-restricted form is checked against the whole-mosaic run in
+tests/test_gpu_parity.py::test_column_strips_compose_the_single_gpu_mosaic."""
 import os
 import socket
 
@@ -21,24 +23,66 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, H, W, result):
+class _HostEngine:
+    """Stands in for the HIP engine on a GPU-less host: "stitches" strip [c0, c1) of step k
+    by writing the known mosaic of step k into those columns of the target buffer and
+    nothing else - what Engine.multiband_fused(strip=, mosaic_out=) does with kernels."""
+    device = "cpu"
+
+    def __init__(self, shape):
+        self.shape, self.k = shape, 0
+
+    def truth(self, k):
+        H, W = self.shape
+        base = torch.arange(H * W * 3, dtype=torch.int64).reshape(H, W, 3)
+        return (base * 7 + 13 * k).remainder(251).to(torch.uint8)
+
+    def upload_plan(self, plan):
+        return plan
+
+    def multiband_fused(self, frames, plan, n_levels, frame_ids=None, strip=None,
+                        mosaic_out=None, **_):
+        assert tuple(mosaic_out.shape[:2]) == self.shape == tuple(plan.shape)
+        c0, c1 = strip
+        mosaic_out[:, c0:c1] = self.truth(self.k)[:, c0:c1]
+        self.k += 1
+        return mosaic_out, None, None, []
+
+
+def _scene():
+    rots, intrs = synth.make_cameras(5, 160, 90, sweep_deg=80.0)
+    return [(90, 160)] * 5, rots, intrs
+
+
+def _worker(rank, world, port, mode, depth, result):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        bounds = pdist.strip_bounds(W, world)
-        truth = torch.arange(H * W * 3, dtype=torch.int64).reshape(H, W, 3).remainder(251)
-        truth = truth.to(torch.uint8)
-        # this rank only "computed" its own columns; everything else is junk
-        mine = torch.full((H, W, 3), 200 + rank, dtype=torch.uint8)
-        c0, c1 = bounds[rank], bounds[rank + 1]
-        mine[:, c0:c1] = truth[:, c0:c1]
-        width = max(b - a for a, b in zip(bounds[:-1], bounds[1:]))
-        packed = pdist.pack_strip(mine, (c0, c1), width)
-        full = pdist.gather_strips(packed, bounds, rank, world)
+        shapes, rots, intrs = _scene()
+        shape = engine.Plan(shapes, rots, intrs, True, 10 ** 9).shape
+        eng = _HostEngine(shape)
+        # the bench's strips step: ShardedStitcher over the process group, K steps, finish
+        st = pdist.ShardedStitcher(eng, shapes, rots, intrs, 5, rank, world, exchange=mode,
+                                   depth=depth)
+        assert st.exchange.world == dist.get_world_size() == world
+        got = []
+        for _ in range(5):
+            _, previous, _ = st.step(frames=None)
+            if previous is not None:
+                got.append(previous.clone())
+        last = st.finish()
+        if last is not None:
+            got.append(last.clone())
         if rank == 0:
-            result.put(bool(torch.equal(full, truth)))
+            ok = len(got) == 5 and all(torch.equal(m, eng.truth(k)) for k, m in enumerate(got))
+            result.put(bool(ok))
         else:
-            assert full is None
+            assert not got
+        # a process group of another size is refused
+        if world > 1:
+            with pytest.raises(ValueError):
+                pdist.StripExchange(shape, pdist.strip_bounds(shape[1], world + 1), 0, world + 1,
+                                    "cpu", mode)
         # max-over-ranks timing reduction used by bench.py
         assert pdist.max_over_ranks(float(rank + 1)) == world
         # image sets of a stream, dealt out over the ranks: each set exactly once
@@ -50,12 +94,28 @@ def _worker(rank, world, port, H, W, result):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("W", [64, 37])
-def test_strip_gather_world_2(W):
+@pytest.mark.parametrize("mode,depth,world", [("gather", 2, 2), ("reduce", 2, 2), ("gather", 1, 2),
+                                              ("reduce", 1, 3), ("gather", 2, 3)])
+def test_sharded_steps_over_gloo(mode, depth, world):
+    """The strips step of bench.py --gpus N at world 2 and 3 (mosaic widths that do and do
+    not divide evenly), both exchanges - point-to-point gather of packed strips, sum-reduce
+    of zero-padded full-width mosaics - synchronous and pipelined one stitch deep: rank 0
+    composes exactly the known mosaic of every step, in order."""
     ctx = mp.get_context("spawn")
     result = ctx.SimpleQueue()
-    mp.spawn(_worker, args=(2, _free_port(), 9, W, result), nprocs=2, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), mode, depth, result), nprocs=world, join=True)
     assert result.get() is True
+
+
+def test_exchange_world_1_needs_no_process_group():
+    shapes, rots, intrs = _scene()
+    shape = engine.Plan(shapes, rots, intrs, True, 10 ** 9).shape
+    for mode in pdist.StripExchange.MODES:
+        eng = _HostEngine(shape)
+        st = pdist.ShardedStitcher(eng, shapes, rots, intrs, 5, 0, 1, exchange=mode, depth=2)
+        assert st.step(None)[1] is None
+        assert torch.equal(st.step(None)[1], eng.truth(0))
+        assert torch.equal(st.finish(), eng.truth(1))
 
 
 def test_strip_bounds_cover_the_mosaic():

@@ -560,8 +560,8 @@ def test_column_strips_compose_the_single_gpu_mosaic(eng, world):
     assert torch.equal(strips, whole)
     # the ranks did not all need all frames
     shapes = [im.shape[:2] for im in imgs]
-    held = [len(pdist.ShardedStitcher(eng, shapes, rots, intrs, 5, r, world).my_frames)
-            for r in range(world)]
+    held = [len(pdist.ShardedStitcher(eng, shapes, rots, intrs, 5, r, world,
+                                      exchange=None).my_frames) for r in range(world)]
     assert min(held) < len(imgs)
 
 
@@ -571,11 +571,17 @@ def test_sharded_stitcher_world_1_equals_stitch(eng):
     from pano360_amd import engine, synth
     imgs, rots, intrs = synth.make_scene(5, 320, 180, sweep_deg=70.0, seed=43, kind="B")
     shapes = [im.shape[:2] for im in imgs]
-    st = pdist.ShardedStitcher(eng, shapes, rots, intrs, 5, 0, 1)
+    st = pdist.ShardedStitcher(eng, shapes, rots, intrs, 5, 0, 1, depth=1)
     assert st.my_frames == list(range(5))
     plan, mosaic, _ = st.step(eng.upload_frames(imgs))
     whole, _, _, _ = eng.stitch(eng.upload_frames(imgs), plan, "multiband", 5)
     assert torch.equal(mosaic, whole)
+    # pipelined (depth 2): a step hands back the stitch before it, finish() the last one
+    st2 = pdist.ShardedStitcher(eng, shapes, rots, intrs, 5, 0, 1, depth=2, exchange="reduce")
+    frames = eng.upload_frames(imgs)
+    assert st2.step(frames)[1] is None
+    assert torch.equal(st2.step(frames)[1], whole)
+    assert torch.equal(st2.finish(), whole)
     with pytest.raises(Exception):       # a needed frame that is not resident
         eng.multiband_fused(eng.upload_frames(imgs[:2]), eng.upload_plan(plan), 5,
                             frame_ids=[0, 1])

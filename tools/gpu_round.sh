@@ -4,30 +4,37 @@
 #   tools/gpu_round.sh <tag> [quick]
 set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
-OUT=gpurun_out/${1:-r01}
+OUT=gpurun_out/${1:-r02}
 MODE=${2:-full}
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 { rocm-smi --showproductname 2>&1 | head -12; nproc; } > "$OUT/info.log"
 echo "== pytest -m gpu"
-timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -30 | tee "$OUT/pytest_gpu.log"
+timeout -k 10 1500 python -m pytest tests -m gpu -x -q -s > "$OUT/pytest_gpu.log" 2>&1; tail -5 "$OUT/pytest_gpu.log"
 echo "== smoke"
-timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3 | tee "$OUT/smoke.log"
-echo "== bench cfg2"
-timeout 600 python bench.py --workload cfg2 --steps 10 --warmup 3 --no-cpu-baseline 2>&1 | tail -1 | tee "$OUT/bench_cfg2.json"
-echo "== bench cfg3"
-if [ "$MODE" = quick ]; then
-  timeout 900 python bench.py --steps 10 --warmup 3 --no-cpu-baseline 2>&1 | tail -1 | tee "$OUT/bench_cfg3.json"
-else
-  timeout 900 python bench.py --steps 10 --warmup 3 2>&1 | tail -1 | tee "$OUT/bench_cfg3.json"
+timeout -k 10 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3 | tee "$OUT/smoke.log"
+for wl in cfg2 cfg3 cfg4; do
+  echo "== bench $wl"
+  extra="--no-cpu-baseline"; [ "$MODE" = full ] && extra=""
+  timeout -k 10 900 python bench.py --workload $wl --steps 20 --warmup 3 $extra 2> "$OUT/bench_$wl.err" | tail -1 > "$OUT/bench_$wl.json"
+  python - "$OUT/bench_$wl.json" <<'P'
+import json, sys
+d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+print("ms/step %.3f value %.0f %s" % (d["ms_per_step"], d["value"], d["unit"]), "roofline", d["roofline"]["kernel"], "%.3f" % d["roofline"]["frac"],
+      {k: round(v, 3) for k, v in d["kernel_ms_per_step"].items() if v > 0.01})
+P
+done
+if [ "$MODE" = full ]; then
+  echo "== bench cfg5 (one GPU)"
+  timeout -k 10 900 python bench.py --workload cfg5 --steps 5 --warmup 2 --no-cpu-baseline 2> "$OUT/bench_cfg5.err" | tail -1 > "$OUT/bench_cfg5.json"; cut -c1-400 "$OUT/bench_cfg5.json"
   echo "== 2-rank dry run on one GPU (gloo rendezvous, shared device)"
-  PANO_DIST_BACKEND=gloo timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 \
-      --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 2 --steps 3 --warmup 1 2>&1 | tail -2 | tee "$OUT/bench_cfg3_2rank_dryrun.json"
+  PANO_DIST_BACKEND=gloo timeout -k 10 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 \
+      --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 2 --steps 3 --warmup 1 2> "$OUT/bench_2rank.err" | tail -1 > "$OUT/bench_cfg3_2rank_dryrun.json"; cut -c1-600 "$OUT/bench_cfg3_2rank_dryrun.json"
+  echo "== rocprof"
+  HERE=$PWD
+  cd /tmp
+  timeout -k 10 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$HERE/$OUT/prof_cfg3" -- python3 "$HERE/bench.py" --steps 5 --warmup 2 --no-cpu-baseline > "$HERE/$OUT/rocprof.log" 2>&1
+  cd "$HERE"
+  f=$(find "$OUT/prof_cfg3" -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cut -c1-160 "$f"
+  find "$OUT/prof_cfg3" -name "*kernel_trace.csv" -size +20M -delete
 fi
-echo "== rocprof"
-HERE=$PWD
-cd /tmp
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$HERE/$OUT/prof_cfg3" -- python3 "$HERE/bench.py" --steps 5 --warmup 2 --no-cpu-baseline > "$HERE/$OUT/rocprof.log" 2>&1
-cd "$HERE"
-f=$(find "$OUT/prof_cfg3" -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cat "$f" | cut -c1-160
-find "$OUT/prof_cfg3" -name "*kernel_trace.csv" -size +20M -delete
