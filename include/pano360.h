@@ -423,6 +423,18 @@ int pano_gray_u8(pano_ctx *ctx, const uint8_t *bgr, int h, int w, float *out);
  * of cv::getGaussianKernel, no padding), ntaps odd and <= 33 (sigma <= 4). */
 int pano_scale_step(pano_ctx *ctx, const float *src, int h, int w, const float *taps, int ntaps,
                     float *dst, float *dog);
+/* The whole scale space of one frame in ONE call (createInitialImage + buildGaussianPyramid
+ * + buildDoGPyramid): grey -> 2x bilinear -> blur to sigma, then per octave n_layers + 2
+ * pano_scale_step launches and the nearest-neighbour halving of layer n_layers into the
+ * next octave.  frame: dev uint8 [h][w][3]; octave o is rows_o x cols_o with rows_0 = 2h,
+ * cols_0 = 2w, halved (floor) from octave to octave, all >= 1; gauss / dog: HOST arrays of
+ * n_octaves dev pointers, gauss[o] = float [n_layers+3][rows_o][cols_o], dog[o] likewise
+ * with n_layers+2; taps: HOST float, n_layers + 3 bare kernels back to back (kernel 0: the
+ * base blur, kernel i: the step into layer i), ntaps: HOST their apertures;
+ * work: dev float [5 h w] scratch (grey image, doubled base). */
+int pano_scale_space(pano_ctx *ctx, const uint8_t *frame, int h, int w, int n_octaves,
+                     int n_layers, const float *taps, const int *ntaps, float *const *gauss,
+                     float *const *dog, float *work);
 int pano_resize_up2(pano_ctx *ctx, const float *src, int h, int w, float *dst);
 int pano_decimate2(pano_ctx *ctx, const float *src, int h, int w, float *dst);
 int pano_subtract(pano_ctx *ctx, const float *a, const float *b, size_t n, float *out);
@@ -487,6 +499,22 @@ int pano_sift_orient(pano_ctx *ctx, const float *const *gauss, const int *dims,
 int pano_sift_describe(pano_ctx *ctx, const float *const *gauss, const int *dims,
                        int first_octave, const pano_sift_keypoint *kpts, int n,
                        float *desc);
+
+/* The two nearest rows of `train` for every row of `query` (Euclidean), the search behind
+ * flann_matching                                                  features.py:222-232
+ * (cv2.FlannBasedMatcher().knnMatch(des1, des2, k=2): FLANN's randomised kd-trees give an
+ * approximate answer; this search is exhaustive and its answer exact).  The cross terms of
+ * |q - t|^2 run on the matrix cores in split float16 and only rank the candidates; the
+ * three best per query are re-evaluated in float32 (sum of squared differences) and a bound
+ * on the ranking error proves that no other row can be among the best two - a query whose
+ * proof fails is rescanned exactly (counted in *rescans, optional dev int).
+ * query: dev float [nq][d], train: dev float [nt][d], nt >= 2, d <= 128; scale: a power of
+ * two with max |value| * scale <= 2048 (keeps the float16 halves normal); work: dev scratch
+ * of pano_knn2_work_bytes(nq, nt, d) bytes.  idx: dev int32 [nq][2], dist: dev float [nq][2],
+ * nearest first (equal distances: lower index first). */
+size_t pano_knn2_work_bytes(int nq, int nt, int d);
+int pano_knn2(pano_ctx *ctx, const float *query, int nq, const float *train, int nt, int d,
+              float scale, void *work, int32_t *idx, float *dist, int *rescans);
 
 #ifdef __cplusplus
 }

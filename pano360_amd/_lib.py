@@ -109,6 +109,7 @@ _SIGNATURES = {
     "pano_pyr_down": (_i, [_vp, _vp, _i, _i, _vp]),
     "pano_gray_u8": (_i, [_vp, _vp, _i, _i, _vp]),
     "pano_scale_step": (_i, [_vp, _vp, _i, _i, _vp, _i, _vp, _vp]),
+    "pano_scale_space": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "pano_resize_up2": (_i, [_vp, _vp, _i, _i, _vp]),
     "pano_decimate2": (_i, [_vp, _vp, _i, _i, _vp]),
     "pano_subtract": (_i, [_vp, _vp, _vp, C.c_size_t, _vp]),
@@ -122,6 +123,8 @@ _SIGNATURES = {
                                _vp, _i]),
     "pano_sift_orient": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _i]),
     "pano_sift_describe": (_i, [_vp, _vp, _vp, _i, _vp, _i, _vp]),
+    "pano_knn2_work_bytes": (C.c_size_t, [_i, _i, _i]),
+    "pano_knn2": (_i, [_vp, _vp, _i, _vp, _i, _i, C.c_float, _vp, _vp, _vp, _vp]),
 }
 EXPORTS = tuple(_SIGNATURES)
 

@@ -1,0 +1,332 @@
+// Exhaustive two-nearest-neighbour search between two descriptor sets, the arithmetic
+// behind `flann_matching` (features.py:222-232: FLANN's kd-trees asked for k = 2, then
+// Lowe's ratio test).  An exact search replaces FLANN's approximate one.
+//
+// This is the one dense contraction of the whole path - |q - t|^2 = |q|^2 + |t|^2 - 2 q.t
+// with the cross terms a [queries x train] matrix product - so it runs on the matrix cores:
+// v_mfma_f32_32x32x16_f16 with every operand split into float16 hi + lo (hi.hi + hi.lo +
+// lo.hi, float32 accumulate: ~2^-21 relative, i.e. float32-GEMM accuracy).  The product
+// only RANKS the candidates: the three best per query are then re-evaluated exactly in
+// float32 (sum of squared differences in a fixed order), and a bound on the product's error
+// proves per query that no other row can beat the second of them; a query for which the
+// proof fails (near ties) is rescanned exactly.  So the answer is the exact one.
+//
+// Layout: both sets are packed once into MFMA fragment order (tile of 32 rows, k-step of 16
+// features, hi / lo, lane: 8 halves) so that every operand read is one aligned 16-byte
+// access.  A wave keeps 32 queries' fragments in registers (the B operand: the result tile
+// then has the query on the lane and 16 train rows in the lane's registers, so the running
+// top-3 is private to a lane) and streams the train tiles through LDS, shared by the 4 waves
+// of the workgroup and double-buffered.
+#include "common.h"
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define KNN_MAX_KS 8                  // k-steps of 16 features: d <= 128
+#define KNN_EPS 1.0e-4f               // error bound of a ranked value, relative to |q|^2 + max |t|^2
+
+__device__ __forceinline__ void knn_split(float v, _Float16 &hi, _Float16 &lo) {
+    hi = (_Float16)v;
+    lo = (_Float16)(v - (float)hi);
+}
+
+// rows [n][d] float -> fragments [tile][k-step][hi, lo][lane] half8 (values scaled), zero
+// beyond n / d.  One thread per (tile, k-step, lane).
+__global__ __launch_bounds__(256) void knn_pack_kernel(const float *__restrict__ src, int n, int d,
+                                                       int ks, float scale,
+                                                       half8 *__restrict__ packed) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const int lane = (int)(i & 63);
+    const size_t ts = i >> 6;
+    const int s = (int)(ts % ks);
+    const size_t tile = ts / ks;
+    const size_t row = tile * 32 + (lane & 31);
+    if (tile * 32 >= (size_t)((n + 31) & ~31)) return;
+    half8 hi, lo;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int k = 16 * s + 8 * (lane >> 5) + j;
+        const float v = row < (size_t)n && k < d ? src[row * d + k] * scale : 0.0f;
+        _Float16 a, b;
+        knn_split(v, a, b);
+        hi[j] = a;
+        lo[j] = b;
+    }
+    packed[((tile * ks + s) * 2) * 64 + lane] = hi;
+    packed[((tile * ks + s) * 2 + 1) * 64 + lane] = lo;
+}
+
+// |row * scale|^2 in float32, one wave per row; rows beyond n get +inf (never chosen);
+// the largest norm goes to *maxnorm (float bits, non-negative: integer max).
+__global__ __launch_bounds__(256) void knn_norm_kernel(const float *__restrict__ src, int n,
+                                                       int n_pad, int d, float scale,
+                                                       float *__restrict__ norms,
+                                                       unsigned *__restrict__ maxnorm) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= n_pad) return;
+    float acc = 0.0f;
+    if (row < n)
+        for (int k = lane; k < d; k += 64) {
+            const float v = src[(size_t)row * d + k] * scale;
+            acc = __builtin_fmaf(v, v, acc);
+        }
+#pragma unroll
+    for (int off = 32; off; off >>= 1) acc += __shfl_xor(acc, off);
+    if (lane == 0) {
+        norms[row] = row < n ? acc : __builtin_inff();
+        if (row < n && maxnorm) atomicMax(maxnorm, __float_as_uint(acc));
+    }
+}
+
+struct KnnTop3 {
+    float v0, v1, v2;
+    int i0, i1, i2;
+};
+
+__device__ __forceinline__ void knn_insert(KnnTop3 &t, float v, int j) {
+    if (v < t.v2 || (v == t.v2 && j < t.i2)) {
+        if (v < t.v1 || (v == t.v1 && j < t.i1)) {
+            t.v2 = t.v1;
+            t.i2 = t.i1;
+            if (v < t.v0 || (v == t.v0 && j < t.i0)) {
+                t.v1 = t.v0;
+                t.i1 = t.i0;
+                t.v0 = v;
+                t.i0 = j;
+            } else {
+                t.v1 = v;
+                t.i1 = j;
+            }
+        } else {
+            t.v2 = v;
+            t.i2 = j;
+        }
+    }
+}
+
+// cand_idx [nq][3], cand_val [nq][3] (scaled |t|^2 - 2 q.t, ascending)
+template <int KS>
+__global__ __launch_bounds__(256) void knn2_kernel(const half8 *__restrict__ pq,
+                                                   const half8 *__restrict__ pt,
+                                                   const float *__restrict__ norm_t, int nq, int nt,
+                                                   int32_t *__restrict__ cand_idx,
+                                                   float *__restrict__ cand_val) {
+    __shared__ __attribute__((aligned(16))) half8 s_tile[2][KS * 2 * 64];
+    __shared__ __attribute__((aligned(16))) float s_norm[2][32];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int n = lane & 31, h = lane >> 5;
+    const int tq = blockIdx.x * 4 + wv;                       // this wave's query tile
+    const int ntq = (nq + 31) >> 5, ntt = (nt + 31) >> 5;
+    const bool live = tq < ntq;
+    half8 bq[KS][2];
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+#pragma unroll
+        for (int part = 0; part < 2; ++part)
+            bq[s][part] = pq[(((size_t)(live ? tq : 0) * KS + s) * 2 + part) * 64 + lane];
+    KnnTop3 top = {__builtin_inff(), __builtin_inff(), __builtin_inff(), 0x7fffffff, 0x7fffffff,
+                   0x7fffffff};
+    constexpr int CHUNKS = KS * 2 * 64 / 256;                 // 16-byte pieces per thread and tile
+    half8 next[CHUNKS];
+    float next_norm = 0.0f;
+    auto fetch = [&](int tt) {                                // global -> registers
+        const half8 *src = pt + (size_t)tt * KS * 2 * 64;
+#pragma unroll
+        for (int c = 0; c < CHUNKS; ++c) next[c] = src[tid + 256 * c];
+        if (tid < 32) next_norm = norm_t[tt * 32 + tid];
+    };
+    auto commit = [&](int buf) {                              // registers -> LDS
+#pragma unroll
+        for (int c = 0; c < CHUNKS; ++c) s_tile[buf][tid + 256 * c] = next[c];
+        if (tid < 32) s_norm[buf][tid] = next_norm;
+    };
+    fetch(0);
+    commit(0);
+    __syncthreads();
+    for (int tt = 0; tt < ntt; ++tt) {
+        const int buf = tt & 1;
+        if (tt + 1 < ntt) fetch(tt + 1);                      // in flight while this tile multiplies
+        f32x16 acc;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[q] = 0.0f;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const half8 a_hi = s_tile[buf][(s * 2) * 64 + lane];
+            const half8 a_lo = s_tile[buf][(s * 2 + 1) * 64 + lane];
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, bq[s][0], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, bq[s][1], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo, bq[s][0], acc, 0, 0, 0);
+        }
+        // register q of lane (n, h) = query n against train row (q & 3) + 8 (q >> 2) + 4 h
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 nr = *(const float4 *)(&s_norm[buf][8 * g + 4 * h]);
+            const float nv[4] = {nr.x, nr.y, nr.z, nr.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float v = __builtin_fmaf(-2.0f, acc[4 * g + e], nv[e]);    // +inf beyond nt
+                if (__any(v < top.v2)) knn_insert(top, v, tt * 32 + 8 * g + 4 * h + e);
+            }
+        }
+        if (tt + 1 < ntt) commit(buf ^ 1);                    // nobody reads that buffer now
+        __syncthreads();
+    }
+    // the two halves of a wave hold different train rows for the same query: merge
+    KnnTop3 other;
+    other.v0 = __shfl_xor(top.v0, 32);
+    other.v1 = __shfl_xor(top.v1, 32);
+    other.v2 = __shfl_xor(top.v2, 32);
+    other.i0 = __shfl_xor(top.i0, 32);
+    other.i1 = __shfl_xor(top.i1, 32);
+    other.i2 = __shfl_xor(top.i2, 32);
+    knn_insert(top, other.v0, other.i0);
+    knn_insert(top, other.v1, other.i1);
+    knn_insert(top, other.v2, other.i2);
+    const int q = tq * 32 + n;
+    if (live && h == 0 && q < nq) {
+        cand_idx[3 * q] = top.i0;
+        cand_idx[3 * q + 1] = top.i1;
+        cand_idx[3 * q + 2] = top.i2;
+        cand_val[3 * q] = top.v0;
+        cand_val[3 * q + 1] = top.v1;
+        cand_val[3 * q + 2] = top.v2;
+    }
+}
+
+// sum_k (q_k - t_k)^2 in float32, features dealt out over the lanes, a fixed reduction tree
+__device__ __forceinline__ float knn_exact(const float *__restrict__ q, const float *__restrict__ t,
+                                           int d, int lane) {
+    float acc = 0.0f;
+    for (int k = lane; k < d; k += 64) {
+        const float df = q[k] - t[k];
+        acc = __builtin_fmaf(df, df, acc);
+    }
+#pragma unroll
+    for (int off = 32; off; off >>= 1) acc += __shfl_xor(acc, off);
+    return acc;
+}
+
+// One wave per query: exact distances of its three candidates, the proof that nothing else
+// can be among the best two (or an exact rescan), the two nearest in order.
+__global__ __launch_bounds__(256) void knn2_refine_kernel(
+    const float *__restrict__ query, const float *__restrict__ train, int nq, int nt, int d,
+    float scale, const float *__restrict__ norm_q, const unsigned *__restrict__ maxnorm,
+    const int32_t *__restrict__ cand_idx, const float *__restrict__ cand_val,
+    int32_t *__restrict__ idx, float *__restrict__ dist, int *__restrict__ rescans) {
+    const int qi = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (qi >= nq) return;
+    const float *q = query + (size_t)qi * d;
+    float best = __builtin_inff(), second = __builtin_inff();
+    int bi = 0x7fffffff, si = 0x7fffffff;
+    auto take = [&](float v, int j) {
+        if (v < best || (v == best && j < bi)) {
+            second = best;
+            si = bi;
+            best = v;
+            bi = j;
+        } else if (v < second || (v == second && j < si)) {
+            second = v;
+            si = j;
+        }
+    };
+    for (int c = 0; c < 3; ++c) {
+        const int j = cand_idx[3 * qi + c];
+        if (j < nt) take(knn_exact(q, train + (size_t)j * d, d, lane), j);
+    }
+    // every row outside the list ranked at or above the third listed value, and a ranked value
+    // is within eps of the true one: its squared distance is at least this
+    const float s2 = scale * scale;
+    const float eps = KNN_EPS * (norm_q[qi] + __uint_as_float(*maxnorm));
+    const float floor_d2 = (cand_val[3 * qi + 2] + norm_q[qi] - eps) / s2;
+    if (nt > 3 && !(second <= floor_d2)) {                     // not proven: exact rescan
+        best = second = __builtin_inff();
+        bi = si = 0x7fffffff;
+        for (int j = 0; j < nt; ++j) take(knn_exact(q, train + (size_t)j * d, d, lane), j);
+        if (lane == 0 && rescans) atomicAdd(rescans, 1);
+    }
+    if (lane == 0) {
+        idx[2 * qi] = bi;
+        idx[2 * qi + 1] = si;
+        dist[2 * qi] = sqrtf(best);
+        dist[2 * qi + 1] = sqrtf(second);
+    }
+}
+
+static size_t knn_align(size_t v) { return (v + 255) & ~(size_t)255; }
+
+struct KnnWork {
+    size_t pq, pt, nq, ntn, cidx, cval, scal, total;
+};
+
+static KnnWork knn_layout(int nq, int nt, int d) {
+    const int ks = d <= 64 ? 4 : 8;
+    const size_t tq = (size_t)((nq + 31) / 32), tt = (size_t)((nt + 31) / 32);
+    KnnWork w;
+    size_t off = 0;
+    w.pq = off;
+    off += knn_align(tq * ks * 2 * 64 * sizeof(half8));
+    w.pt = off;
+    off += knn_align(tt * ks * 2 * 64 * sizeof(half8));
+    w.nq = off;
+    off += knn_align(tq * 32 * sizeof(float));
+    w.ntn = off;
+    off += knn_align(tt * 32 * sizeof(float));
+    w.cidx = off;
+    off += knn_align((size_t)nq * 3 * sizeof(int32_t));
+    w.cval = off;
+    off += knn_align((size_t)nq * 3 * sizeof(float));
+    w.scal = off;
+    off += 256;
+    w.total = off;
+    return w;
+}
+
+extern "C" size_t pano_knn2_work_bytes(int nq, int nt, int d) {
+    if (nq < 0 || nt < 0 || d < 1) return 0;
+    return knn_layout(nq, nt, d).total;
+}
+
+extern "C" int pano_knn2(pano_ctx *ctx, const float *query, int nq, const float *train, int nt, int d,
+                         float scale, void *work, int32_t *idx, float *dist, int *rescans) {
+    PANO_ENTER(ctx, "pano_knn2");
+    PANO_REQUIRE(query && train && work && idx && dist, "pano_knn2: null pointer");
+    PANO_REQUIRE(nq >= 0 && nt >= 2, "pano_knn2: %d queries against %d rows (at least 2)", nq, nt);
+    PANO_REQUIRE(d >= 1 && d <= 16 * KNN_MAX_KS, "pano_knn2: %d features (at most %d)", d,
+                 16 * KNN_MAX_KS);
+    PANO_REQUIRE(scale > 0.0f, "pano_knn2: scale %g", (double)scale);
+    if (nq == 0) return PANO_OK;
+    const hipStream_t s = (hipStream_t)stream;
+    const KnnWork w = knn_layout(nq, nt, d);
+    const int ks = d <= 64 ? 4 : 8;
+    unsigned char *base = (unsigned char *)work;
+    half8 *pq = (half8 *)(base + w.pq), *pt = (half8 *)(base + w.pt);
+    float *norm_q = (float *)(base + w.nq), *norm_t = (float *)(base + w.ntn);
+    int32_t *cidx = (int32_t *)(base + w.cidx);
+    float *cval = (float *)(base + w.cval);
+    unsigned *maxnorm = (unsigned *)(base + w.scal);
+    const int tq = (nq + 31) / 32, tt = (nt + 31) / 32;
+    PANO_HIP(hipMemsetAsync(maxnorm, 0, 256, s));
+    if (rescans) PANO_HIP(hipMemsetAsync(rescans, 0, sizeof(int), s));
+    hipLaunchKernelGGL(knn_pack_kernel, dim3((unsigned)(((size_t)tq * ks * 64 + 255) / 256)), dim3(256),
+                       0, s, query, nq, d, ks, scale, pq);
+    hipLaunchKernelGGL(knn_pack_kernel, dim3((unsigned)(((size_t)tt * ks * 64 + 255) / 256)), dim3(256),
+                       0, s, train, nt, d, ks, scale, pt);
+    hipLaunchKernelGGL(knn_norm_kernel, dim3(ceil_div(tq * 32, 4)), dim3(256), 0, s, query, nq,
+                       tq * 32, d, scale, norm_q, (unsigned *)nullptr);
+    hipLaunchKernelGGL(knn_norm_kernel, dim3(ceil_div(tt * 32, 4)), dim3(256), 0, s, train, nt,
+                       tt * 32, d, scale, norm_t, maxnorm);
+    PANO_LAUNCH_CHECK("knn_pack_kernel");
+    if (ks == 4)
+        PANO_TIMED(PK_KNN2, s,
+                   hipLaunchKernelGGL(knn2_kernel<4>, dim3(ceil_div(tq, 4)), dim3(256), 0, s, pq, pt,
+                                      norm_t, nq, nt, cidx, cval));
+    else
+        PANO_TIMED(PK_KNN2, s,
+                   hipLaunchKernelGGL(knn2_kernel<8>, dim3(ceil_div(tq, 4)), dim3(256), 0, s, pq, pt,
+                                      norm_t, nq, nt, cidx, cval));
+    PANO_LAUNCH_CHECK("knn2_kernel");
+    hipLaunchKernelGGL(knn2_refine_kernel, dim3(ceil_div(nq, 4)), dim3(256), 0, s, query, train, nq, nt,
+                       d, scale, norm_q, maxnorm, cidx, cval, idx, dist, rescans);
+    PANO_LAUNCH_CHECK("knn2_refine_kernel");
+    return PANO_OK;
+}

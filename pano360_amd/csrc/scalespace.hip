@@ -35,42 +35,50 @@ struct SsTaps {
     int n;
 };
 
-// dog (optional) = out - in at the same pixel
+// dog (optional) = out - in at the same pixel.  NT = the aperture (compile-time for the
+// five steps of an octave and the base blur, so that every loop unrolls, the taps sit in
+// scalar registers and the LDS reads of a pass are all in flight before its first FMA);
+// NT = 0: any odd aperture up to 33, looped.
+template <int NT>
 __global__ __launch_bounds__(256) void scale_step_kernel(const float *__restrict__ in, int h, int w,
                                                          SsTaps taps, float *__restrict__ out,
                                                          float *__restrict__ dog) {
     __shared__ __attribute__((aligned(16))) float s_in[SS_IN_H * SS_IN_W];
     __shared__ float s_mid[SS_IN_H * SS_MID_PITCH];
     const int tid = threadIdx.x;
-    const int r = taps.n >> 1;
+    const int nt = NT ? NT : taps.n;
+    const int r = nt >> 1;
     const int x0 = blockIdx.x * SS_TW, y0 = blockIdx.y * SS_TH;
     const int iw = SS_TW + 2 * r, ih = SS_TH + 2 * r;
 
-    // stage the input tile; rows / columns beyond the image arrive reflected.  The row pass
-    // reads whole 16-byte groups: columns up to the next multiple of 4 past the halo (+ 4) are
-    // zero-filled, so that the zero taps there multiply finite numbers
+    // stage the input tile; rows / columns beyond the image arrive reflected.  A wave takes
+    // every fourth row (the reflected source row is wave-uniform), a lane the same two columns
+    // in every row (reflected once).  The row pass reads whole 16-byte groups: columns up to
+    // the next multiple of 4 past the halo (+ 4) are zero-filled, so that the zero taps there
+    // multiply finite numbers
     const int iwp = ((iw + 3) & ~3) + 4;
-    for (int i = tid; i < ih * iwp; i += 256) {
-        const int ty = i / iwp, tx = i - ty * iwp;
-        float v = 0.f;
-        if (tx < iw) {
-            const int sy = reflect_101(y0 - r + ty, h), sx = reflect_101(x0 - r + tx, w);
-            v = in[(size_t)sy * w + sx];
-        }
-        s_in[ty * SS_IN_W + tx] = v;
+    const int lane = tid & 63, wv = tid >> 6;
+    const int ca = lane, cb = lane + 64;
+    const int sxa = reflect_101(x0 - r + ca, w), sxb = reflect_101(x0 - r + (cb < iw ? cb : 0), w);
+    for (int ty = wv; ty < ih; ty += 4) {
+        const int sy = __builtin_amdgcn_readfirstlane(reflect_101(y0 - r + ty, h));
+        const float *src = in + (size_t)sy * w;
+        const float va = src[sxa];
+        const float vb = cb < iw ? src[sxb] : 0.f;
+        s_in[ty * SS_IN_W + ca] = va;
+        if (cb < iwp) s_in[ty * SS_IN_W + cb] = vb;
     }
     __syncthreads();
 
     // row pass: ih rows x 64 outputs; a thread makes 4 adjacent outputs, four taps per trip
     // from one aligned 16-byte LDS read (window = the previous read + this one)
-    const int trips = (taps.n + 3) >> 2;
+    constexpr int TRIPS = NT ? (NT + 3) / 4 : 0;
+    const int trips = NT ? TRIPS : (nt + 3) >> 2;
     for (int i = tid; i < ih * (SS_TW / 4); i += 256) {
         const int ty = i >> 4, q = (i & 15) * 4;
         const float4 *row = (const float4 *)(s_in + ty * SS_IN_W + q);
         float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-        float4 lo = row[0];
-        for (int k = 0; k < trips; ++k) {
-            const float4 hi = row[k + 1];
+        auto trip = [&](const float4 lo, const float4 hi, const int k) {
             const float w0 = taps.w[4 * k], w1 = taps.w[4 * k + 1], w2 = taps.w[4 * k + 2],
                         w3 = taps.w[4 * k + 3];
             // output j meets tap 4 k + t at window entry j + t
@@ -90,7 +98,20 @@ __global__ __launch_bounds__(256) void scale_step_kernel(const float *__restrict
             a1 = __builtin_fmaf(w3, hi.x, a1);
             a2 = __builtin_fmaf(w3, hi.y, a2);
             a3 = __builtin_fmaf(w3, hi.z, a3);
-            lo = hi;
+        };
+        if (NT) {
+            float4 win[TRIPS + 1];
+#pragma unroll
+            for (int k = 0; k <= TRIPS; ++k) win[k] = row[k];
+#pragma unroll
+            for (int k = 0; k < TRIPS; ++k) trip(win[k], win[k + 1], k);
+        } else {
+            float4 lo = row[0];
+            for (int k = 0; k < trips; ++k) {
+                const float4 hi = row[k + 1];
+                trip(lo, hi, k);
+                lo = hi;
+            }
         }
         float *m = s_mid + ty * SS_MID_PITCH + q;
         m[0] = a0;
@@ -106,16 +127,28 @@ __global__ __launch_bounds__(256) void scale_step_kernel(const float *__restrict
 #pragma unroll
     for (int o = 0; o < 8; ++o) acc[o] = 0.f;
     const float *col = s_mid + cy * SS_MID_PITCH + cx;
-    float win[8];
+    if (NT) {
+        float v[NT + 7];
 #pragma unroll
-    for (int o = 0; o < 7; ++o) win[o] = col[o * SS_MID_PITCH];
-    for (int k = 0; k < taps.n; ++k) {
-        win[7] = col[(k + 7) * SS_MID_PITCH];
-        const float wk = taps.w[k];
+        for (int k = 0; k < NT + 7; ++k) v[k] = col[k * SS_MID_PITCH];
 #pragma unroll
-        for (int o = 0; o < 8; ++o) acc[o] = __builtin_fmaf(wk, win[o], acc[o]);
+        for (int k = 0; k < NT; ++k) {
+            const float wk = taps.w[k];
 #pragma unroll
-        for (int o = 0; o < 7; ++o) win[o] = win[o + 1];
+            for (int o = 0; o < 8; ++o) acc[o] = __builtin_fmaf(wk, v[k + o], acc[o]);
+        }
+    } else {
+        float win[8];
+#pragma unroll
+        for (int o = 0; o < 7; ++o) win[o] = col[o * SS_MID_PITCH];
+        for (int k = 0; k < nt; ++k) {
+            win[7] = col[(k + 7) * SS_MID_PITCH];
+            const float wk = taps.w[k];
+#pragma unroll
+            for (int o = 0; o < 8; ++o) acc[o] = __builtin_fmaf(wk, win[o], acc[o]);
+#pragma unroll
+            for (int o = 0; o < 7; ++o) win[o] = win[o + 1];
+        }
     }
     const int x = x0 + cx;
     if (x < w) {
@@ -142,9 +175,68 @@ extern "C" int pano_scale_step(pano_ctx *ctx, const float *src, int h, int w, co
     t.n = ntaps;
     for (int k = 0; k < ntaps; ++k) t.w[k] = taps[k];
     dim3 grid(ceil_div(w, SS_TW), ceil_div(h, SS_TH));
-    PANO_TIMED(PK_SCALE_STEP, (hipStream_t)stream,
-               hipLaunchKernelGGL(scale_step_kernel, grid, dim3(256), 0, (hipStream_t)stream, src, h,
-                                  w, t, dst, dog));
+#define SS_LAUNCH(N)                                                                          \
+    PANO_TIMED(PK_SCALE_STEP, (hipStream_t)stream,                                            \
+               hipLaunchKernelGGL(scale_step_kernel<N>, grid, dim3(256), 0, (hipStream_t)stream, \
+                                  src, h, w, t, dst, dog))
+    switch (ntaps) {              // the apertures of SIFT's sigma 1.6, 3 layers per octave
+        case 11: SS_LAUNCH(11); break;
+        case 13: SS_LAUNCH(13); break;
+        case 17: SS_LAUNCH(17); break;
+        case 21: SS_LAUNCH(21); break;
+        case 27: SS_LAUNCH(27); break;
+        default: SS_LAUNCH(0); break;
+    }
+#undef SS_LAUNCH
     PANO_LAUNCH_CHECK("scale_step_kernel");
+    return PANO_OK;
+}
+
+static int scale_step_launch(pano_ctx *ctx, const float *src, int h, int w, const float *taps,
+                             int ntaps, float *dst, float *dog) {
+    return pano_scale_step(ctx, src, h, w, taps, ntaps, dst, dog);
+}
+
+// The whole scale space of one frame in one call: a frame is ~60 launches, and a Python /
+// ctypes round trip per launch (10-20 us) would cost more than the kernels of the small
+// octaves.
+extern "C" int pano_scale_space(pano_ctx *ctx, const uint8_t *frame, int h, int w, int n_octaves,
+                                int n_layers, const float *taps, const int *ntaps,
+                                float *const *gauss, float *const *dog, float *work) {
+    PANO_ENTER(ctx, "pano_scale_space");
+    PANO_REQUIRE(frame && taps && ntaps && gauss && dog && work, "pano_scale_space: null pointer");
+    PANO_REQUIRE(h > 0 && w > 0 && n_octaves >= 1 && n_layers >= 1 && n_layers <= 8,
+                 "pano_scale_space: bad argument");
+    const float *kern[16];
+    size_t off = 0;
+    for (int i = 0; i < n_layers + 3; ++i) {
+        kern[i] = taps + off;
+        off += (size_t)ntaps[i];
+    }
+    float *grey = work, *base = work + (size_t)h * w;
+    if (int rc = pano_gray_u8(ctx, frame, h, w, grey)) return rc;
+    if (int rc = pano_resize_up2(ctx, grey, h, w, base)) return rc;
+    int rows = 2 * h, cols = 2 * w;
+    for (int o = 0; o < n_octaves; ++o) {
+        PANO_REQUIRE(rows >= 1 && cols >= 1 && gauss[o] && dog[o],
+                     "pano_scale_space: octave %d is empty", o);
+        const size_t plane = (size_t)rows * cols;
+        if (o == 0) {
+            if (int rc = scale_step_launch(ctx, base, rows, cols, kern[0], ntaps[0], gauss[0], nullptr))
+                return rc;
+        }
+        for (int i = 1; i < n_layers + 3; ++i)
+            if (int rc = scale_step_launch(ctx, gauss[o] + (i - 1) * plane, rows, cols, kern[i],
+                                           ntaps[i], gauss[o] + i * plane, dog[o] + (i - 1) * plane))
+                return rc;
+        if (o + 1 < n_octaves) {
+            PANO_REQUIRE(rows >= 2 && cols >= 2, "pano_scale_space: octave %d cannot be halved", o);
+            if (int rc = pano_decimate2(ctx, gauss[o] + (size_t)n_layers * plane, rows, cols,
+                                        gauss[o + 1]))
+                return rc;
+            rows /= 2;
+            cols /= 2;
+        }
+    }
     return PANO_OK;
 }

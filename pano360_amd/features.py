@@ -16,9 +16,10 @@ restated, parity unpinned.
   descriptors (``pano_sift_extrema`` / ``_orient`` / ``_describe``) and the RootSIFT
   normalisation.
 * ``flann_matching(des1, des2)``        - features.py:222-232: the 2-nearest-neighbour
-  search and Lowe's 0.7 ratio test, exhaustive on the GPU (a library GEMM for the
-  cross terms + top-2) where the reference asks FLANN's randomised kd-trees for an
-  approximate answer; homography estimation (RANSAC) stays outside.
+  search and Lowe's 0.7 ratio test, exhaustive and exact on the GPU (``pano_knn2``:
+  matrix-core cross terms rank the candidates, the winners are re-evaluated in float32)
+  where the reference asks FLANN's randomised kd-trees for an approximate answer;
+  homography estimation (RANSAC) stays outside.
 """
 import ctypes as C
 
@@ -140,46 +141,35 @@ def sift_pyramid_device(frame, n_octaves=None, sigma=SIFT_SIGMA, layers=SIFT_LAY
     """Gaussian and DoG pyramids of a uint8 BGR frame already on the device.
     Returns (gauss, dog): lists over octaves of contiguous stacks
     [layers+3][h][w] / [layers+2][h][w] (index them like lists of planes).
-    One launch per layer: ``pano_scale_step`` blurs layer i-1 into layer i (both passes, the
-    row-pass image staying in LDS) and writes the DoG layer i-1 from the same tile."""
+    One native call (``pano_scale_space``) queues every launch of the frame; one launch per
+    layer (``scale_step_kernel``) blurs layer i-1 into layer i - both passes, the row-pass
+    image staying in LDS - and writes the DoG layer i-1 from the same tile."""
     import torch
     eng = eng or _eng.engine()
-    dev = _Dev(eng)
-    h, w = frame.shape[:2]
+    h, w = (int(v) for v in frame.shape[:2])
     if n_octaves is None:
         n_octaves = sift_octaves(h, w)
     # createInitialImage: grey -> float -> 2x bilinear -> blur to sigma
     sig_diff = float(np.sqrt(max(np.float32(sigma) ** 2 - np.float32(SIFT_INIT_SIGMA) ** 2 * 4,
                                  np.float32(0.01))))
-    sig = sift_sigmas(sigma, layers)
-    gauss, dog = [], []
-
-    def step(src, s, dst, diff):
-        taps = _step_taps(s)
-        hh, ww = src.shape
-        _lib.check(eng.lib.pano_scale_step(eng.ctx(), _eng._ptr(src), hh, ww, taps.ctypes.data,
-                                           len(taps), _eng._ptr(dst), _eng._ptr(diff)),
-                   "pano_scale_step")
-
+    kernels = [_step_taps(s) for s in [sig_diff] + sift_sigmas(sigma, layers)[1:]]
+    dims, rows, cols = [], 2 * h, 2 * w
     for o in range(n_octaves):
-        if o == 0:
-            first = dev.up2(dev.gray(frame))
-        else:
-            prev = gauss[-1][layers]
-            if min(prev.shape) < 2:
-                break
-            first = dev.half(prev)
-        oh, ow = first.shape
-        stack = torch.empty((layers + 3, oh, ow), dtype=torch.float32, device=eng.device)
-        diff = torch.empty((layers + 2, oh, ow), dtype=torch.float32, device=eng.device)
-        if o == 0:
-            step(first, sig_diff, stack[0], None)
-        else:
-            stack[0].copy_(first)
-        for i in range(1, layers + 3):
-            step(stack[i - 1], sig[i], stack[i], diff[i - 1])
-        gauss.append(stack)
-        dog.append(diff)
+        dims.append((rows, cols))
+        if min(rows, cols) < 2:             # buildGaussianPyramid would halve it to nothing
+            break
+        rows, cols = rows // 2, cols // 2
+    f32 = dict(dtype=torch.float32, device=eng.device)
+    gauss = [torch.empty((layers + 3, r, c), **f32) for r, c in dims]
+    dog = [torch.empty((layers + 2, r, c), **f32) for r, c in dims]
+    work = torch.empty(5 * h * w, **f32)
+    taps = np.ascontiguousarray(np.concatenate(kernels), np.float32)
+    ntaps = (C.c_int * len(kernels))(*[len(k) for k in kernels])
+    gptr = (C.c_void_p * len(dims))(*[g.data_ptr() for g in gauss])
+    dptr = (C.c_void_p * len(dims))(*[d.data_ptr() for d in dog])
+    _lib.check(eng.lib.pano_scale_space(eng.ctx(), _eng._ptr(frame), h, w, len(dims), layers,
+                                        taps.ctypes.data, ntaps, gptr, dptr, _eng._ptr(work)),
+               "pano_scale_space")
     return gauss, dog
 
 
@@ -296,25 +286,31 @@ class DMatch:
         self.queryIdx, self.trainIdx, self.distance = int(query), int(train), float(distance)
 
 
-def knn2_device(des1, des2, chunk=8192):
+def knn2_device(des1, des2, eng=None, want_rescans=False):
     """Two nearest rows of ``des2`` (Euclidean) for every row of ``des1``; both device
-    float32 [K][D].  Returns (indices int64 [K1][2], distances float32 [K1][2]).
-    |a - b|^2 = |a|^2 + |b|^2 - 2 a.b with the cross terms from one hipBLASLt GEMM per
-    chunk of queries; the two winners' distances are then recomputed directly, so the
-    ratio test does not see the cancellation error of that expansion."""
+    float32 [K][D], D <= 128.  Returns (indices int64 [K1][2], distances float32 [K1][2]),
+    nearest first.  ``pano_knn2``: the cross terms of |a - b|^2 on the matrix cores (split
+    float16) rank the rows, the three best per query are re-evaluated exactly in float32 and
+    an error bound proves the rest cannot beat them (else that query is rescanned exactly)."""
     import torch
-    n2 = (des2 * des2).sum(dim=1)
-    idx_out, dist_out = [], []
-    for a in range(0, des1.shape[0], chunk):
-        q = des1[a:a + chunk]
-        d2 = (q * q).sum(dim=1, keepdim=True) + n2[None, :] - 2.0 * (q @ des2.T)
-        _, idx = torch.topk(d2, k=2, dim=1, largest=False)
-        near = des2[idx]                                          # [k][2][D]
-        dist = torch.sqrt(((near - q[:, None, :]) ** 2).sum(dim=2))
-        order = torch.argsort(dist, dim=1, stable=True)
-        idx_out.append(torch.gather(idx, 1, order))
-        dist_out.append(torch.gather(dist, 1, order))
-    return torch.cat(idx_out), torch.cat(dist_out)
+    eng = eng or _eng.engine()
+    nq, d = (int(v) for v in des1.shape)
+    nt = int(des2.shape[0])
+    des1, des2 = des1.contiguous(), des2.contiguous()
+    # a power of two that brings the largest magnitude to ~1024: float16 halves stay normal
+    peak = float(torch.maximum(des1.abs().amax(), des2.abs().amax()).item()) if nq else 1.0
+    scale = float(2.0 ** np.floor(np.log2(1024.0 / peak))) if peak > 0 else 1.0
+    work = torch.empty(int(eng.lib.pano_knn2_work_bytes(nq, nt, d)), dtype=torch.uint8,
+                       device=eng.device)
+    idx = torch.empty((nq, 2), dtype=torch.int32, device=eng.device)
+    dist = torch.empty((nq, 2), dtype=torch.float32, device=eng.device)
+    rescans = torch.zeros(1, dtype=torch.int32, device=eng.device)
+    _lib.check(eng.lib.pano_knn2(eng.ctx(), _eng._ptr(des1), nq, _eng._ptr(des2), nt, d,
+                                 C.c_float(scale), _eng._ptr(work), _eng._ptr(idx),
+                                 _eng._ptr(dist), _eng._ptr(rescans)), "pano_knn2")
+    if want_rescans:
+        return idx.long(), dist, int(rescans.item())
+    return idx.long(), dist
 
 
 def flann_matching(des1, des2, ratio=0.7):

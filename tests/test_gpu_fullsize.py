@@ -282,3 +282,44 @@ def test_two_contexts_on_two_streams_concurrently(eng):
     assert torch.equal(results["a"], whole) and torch.equal(results["b"], whole)
     # the vector-ALU blur rounds differently: within one level of the matrix-core mosaic
     assert (results["c"].int() - whole.int()).abs().max().item() <= 1
+
+
+@pytest.mark.parametrize("case", ["random", "unit", "d64", "ties", "tiny"])
+def test_knn2_kernel_is_exact(eng, case):
+    """``pano_knn2`` (the search behind flann_matching, features.py:222-232) against a
+    float64 brute force: the same two nearest rows for every query, distances to float32
+    rounding.  Cases: random 128-d rows, unit-norm RootSIFT-like rows with planted near
+    duplicates, 64-d rows (four k-steps), duplicated train rows (exact ties: the proof of the
+    ranking fails and those queries are rescanned), and two / three train rows."""
+    import torch
+    from pano360_amd import features
+    rng = np.random.default_rng({"random": 1, "unit": 2, "d64": 3, "ties": 4, "tiny": 5}[case])
+    d = 64 if case == "d64" else 128
+    nq, nt = (700, 1333) if case != "tiny" else (45, 3)
+    a = rng.random((nq, d)).astype(np.float32)
+    b = rng.random((nt, d)).astype(np.float32)
+    if case == "unit":
+        a, b = np.sqrt(a / a.sum(1, keepdims=True)), np.sqrt(b / b.sum(1, keepdims=True))
+        b[:300] = a[rng.permutation(nq)[:300]] + 1e-3 * rng.random((300, d)).astype(np.float32)
+    if case == "ties":
+        b[500:700] = b[100:300]                          # every row of 100..299 exists twice
+        a[:200] = b[100:300] + 1e-4 * rng.random((200, d)).astype(np.float32)
+    for rows in ((a, b), (a, b[:2])) if case == "tiny" else ((a, b),):
+        q, t = rows
+        idx, dist, rescans = features.knn2_device(torch.from_numpy(q).to(eng.device),
+                                                  torch.from_numpy(t).to(eng.device), eng=eng,
+                                                  want_rescans=True)
+        idx, dist = idx.cpu().numpy(), dist.cpu().numpy()
+        ref = np.sqrt(((q[:, None, :].astype(np.float64) - t[None, :, :]) ** 2).sum(-1))
+        order = np.argsort(ref, axis=1, kind="stable")[:, :2]
+        want = np.take_along_axis(ref, order, axis=1)
+        got = np.take_along_axis(ref, idx, axis=1)          # float64 distance of the rows found
+        # the rows found are the nearest two (equal distances may swap labels)
+        np.testing.assert_allclose(got, want, rtol=0, atol=1e-6)
+        np.testing.assert_allclose(dist, want, rtol=2e-6, atol=1e-6)
+        if case != "ties":
+            assert np.array_equal(idx, order)
+        else:
+            assert rescans > 0                               # the duplicated rows defeated the proof
+            assert (idx[:, 0] != idx[:, 1]).all()
+    print(f"knn2 {case}: {rescans} of {nq} queries rescanned")
