@@ -61,6 +61,9 @@ extern "C" {
 #define PANO_MAX_LEVELS 8      /* n_levels of multiband_blend              */
 #define PANO_TAP_LEAD 7        /* zero taps in front of a padded tap table */
 #define PANO_TAP_PAD 40        /* padded table length = ntaps + this       */
+#ifndef PANO_INTERIOR_BLOCK
+#define PANO_INTERIOR_BLOCK 4  /* side of the blocks of pano_interior_map  */
+#endif
 
 /* One warped patch as the blenders see it (reference: the tuples appended at
  * stitcher.py:318-319).  All pointers dev. */
@@ -135,6 +138,8 @@ const char *pano_last_error(void);
 int pano_device_count(void);
 /* Row pitch (in floats) used for every float plane of width w. */
 int pano_pitch(int w);
+/* PANO_INTERIOR_BLOCK as this build of the library was compiled with it. */
+int pano_interior_block(void);
 
 /* The context (no reference counterpart: the reference is one Python process
  * with OpenCV's global state).  pano_ctx_create binds a device and a stream
@@ -299,10 +304,9 @@ int pano_multiband_blur(pano_ctx *ctx, const pano_patch *patches, int n, int max
  * all of that patch's blurred alphas equal the full tap sum, every other
  * patch's are exact zeros, and the multiband mosaic at p is the patch's warped
  * colour (to float32 rounding, <= 6e-8 absolute).  interior: dev uint8
- * [ceil(H/8)][ceil(W/8)], 1 = every pixel of the 8 x 8 block is such a pixel
- * (conservative: tested on whole blocks); block_owner: dev int16 workspace,
- * twice that shape ([2][ceil(H/8)][ceil(W/8)]).  Only columns [xs0, xs1) of
- * owner are read. */
+ * [ceil(H/B)][ceil(W/B)], B = PANO_INTERIOR_BLOCK, 1 = every pixel of the B x B
+ * block is such a pixel (conservative: tested on whole blocks); block_owner: dev
+ * int16 workspace, twice that shape.  Only columns [xs0, xs1) of owner are read. */
 int pano_interior_map(pano_ctx *ctx, const int16_t *owner, int H, int W, int xs0, int xs1,
                       int radius, int16_t *block_owner, uint8_t *interior);
 
@@ -505,7 +509,7 @@ int pano_sift_describe(pano_ctx *ctx, const float *const *gauss, const int *dims
  * (cv2.FlannBasedMatcher().knnMatch(des1, des2, k=2): FLANN's randomised kd-trees give an
  * approximate answer; this search is exhaustive and its answer exact).  The cross terms of
  * |q - t|^2 run on the matrix cores in split float16 and only rank the candidates; the
- * three best per query are re-evaluated in float32 (sum of squared differences) and a bound
+ * four best per query are re-evaluated in float32 (sum of squared differences) and a bound
  * on the ranking error proves that no other row can be among the best two - a query whose
  * proof fails is rescanned exactly (counted in *rescans, optional dev int).
  * query: dev float [nq][d], train: dev float [nt][d], nt >= 2, d <= 128; scale: a power of

@@ -72,6 +72,7 @@ _SIGNATURES = {
     "pano_last_error": (C.c_char_p, []),
     "pano_device_count": (_i, []),
     "pano_pitch": (_i, [_i]),
+    "pano_interior_block": (_i, []),
     "pano_ctx_create": (_i, [_i, _vp, C.POINTER(C.c_void_p)]),
     "pano_ctx_destroy": (_i, [_vp]),
     "pano_ctx_set_stream": (_i, [_vp, _vp]),

@@ -31,6 +31,8 @@ extern "C" int pano_device_count(void) {
 
 extern "C" int pano_pitch(int w) { return pano_pitch_of(w); }
 
+extern "C" int pano_interior_block(void) { return PANO_INTERIOR_BLOCK; }
+
 // ---- the context ---------------------------------------------------------------------
 extern "C" int pano_ctx_create(int device, void *stream, pano_ctx **out) {
     PANO_REQUIRE(out, "pano_ctx_create: null output");

@@ -443,7 +443,7 @@ __device__ __forceinline__ uint8_t quant255(float v) { return (uint8_t)(int)(255
 // R of a seam or of the border of the covered area.  The test runs on 8 x 8
 // blocks (conservative): a block is interior when all blocks within
 // ceil((R + 7) / 8) of it are uniformly owned by the same patch.
-#define IB 8
+#define IB PANO_INTERIOR_BLOCK
 
 __global__ __launch_bounds__(256) void block_owner_kernel(const int16_t *__restrict__ owner,
                                                           int H, int W, int xs0, int xs1,
@@ -455,14 +455,17 @@ __global__ __launch_bounds__(256) void block_owner_kernel(const int16_t *__restr
     int o = -2;                                  // -2: mixed, or not inside the strip
     if (x0 >= xs0 && (x0 + IB < W ? x0 + IB : W) <= xs1) {
         o = owner[(size_t)y0 * W + x0];
-        const bool whole = x0 + IB <= W && (W & 1) == 0;      // rows 4-byte aligned, 8 in range
+        const bool whole = x0 + IB <= W && (W & 1) == 0;      // rows 4-byte aligned, IB in range
         for (int dy = 0; dy < IB && o != -2; ++dy) {
             const int y = y0 + dy;
             if (y >= H) break;
-            if (whole) {                         // one row of the block = four 32-bit words
+            if (whole) {                         // one row of the block = IB / 2 32-bit words
                 const uint32_t *q = (const uint32_t *)(owner + (size_t)y * W + x0);
                 const uint32_t both = ((uint32_t)(uint16_t)o << 16) | (uint16_t)o;
-                if ((q[0] ^ both) | (q[1] ^ both) | (q[2] ^ both) | (q[3] ^ both)) o = -2;
+                uint32_t diff = 0;
+#pragma unroll
+                for (int k = 0; k < IB / 2; ++k) diff |= q[k] ^ both;
+                if (diff) o = -2;
             } else {
                 for (int dx = 0; dx < IB; ++dx) {
                     const int x = x0 + dx;

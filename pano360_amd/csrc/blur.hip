@@ -287,7 +287,8 @@ __global__ __launch_bounds__(64) void tile_flags_kernel(const pano_patch *__rest
     const int ax1 = p.x0 + p.ax0 + p.aw, ay1 = p.y0 + p.ay0 + p.ah;
     gx1 = gx1 < ax1 ? gx1 : ax1;
     gy1 = gy1 < ay1 ? gy1 : ay1;
-    const int bx0 = gx0 >> 3, bx1 = (gx1 - 1) >> 3, by0 = gy0 >> 3, by1 = (gy1 - 1) >> 3;
+    const int bx0 = gx0 / PANO_INTERIOR_BLOCK, bx1 = (gx1 - 1) / PANO_INTERIOR_BLOCK;
+    const int by0 = gy0 / PANO_INTERIOR_BLOCK, by1 = (gy1 - 1) / PANO_INTERIOR_BLOCK;
     const int nbx = bx1 - bx0 + 1, total = nbx * (by1 - by0 + 1);
     bool active = false;
     for (int i = threadIdx.x; i < total; i += 64)
@@ -346,7 +347,7 @@ static int launch_blur(pano_ctx *ctx, const pano_patch *table, const pano_patch 
         dim3 grid(ceil_div(max_aw, COL_TW), ceil_div(max_ah, COL_TH), n);
         PANO_TIMED(PK_TILE_FLAGS, stream,
                    hipLaunchKernelGGL(tile_flags_kernel, grid, dim3(64), 0, stream, table, interior,
-                                      ceil_div(W, 8), tile_flags));
+                                      ceil_div(W, PANO_INTERIOR_BLOCK), tile_flags));
         PANO_LAUNCH_CHECK("tile_flags_kernel");
         flags = tile_flags;
     }

@@ -622,7 +622,7 @@ __global__ __launch_bounds__(MB_THREADS, 1) void blur_mfma_kernel(
     }
 }
 
-// One thread per 32 x 32 tile of every record: active = some 8 x 8 block under the
+// One thread per 32 x 32 tile of every record: active = some interior-map block under the
 // tile (cut to A) is not interior.
 __global__ __launch_bounds__(256) void tile_flags32_kernel(const pano_patch *__restrict__ table,
                                                            const uint8_t *__restrict__ interior,
@@ -637,8 +637,8 @@ __global__ __launch_bounds__(256) void tile_flags32_kernel(const pano_patch *__r
     y0 = max(y0, p.ay0);
     x1 = min(x1, p.ax0 + p.aw);
     y1 = min(y1, p.ay0 + p.ah);
-    const int bx0 = (p.x0 + x0) >> 3, bx1 = (p.x0 + x1 - 1) >> 3;
-    const int by0 = (p.y0 + y0) >> 3, by1 = (p.y0 + y1 - 1) >> 3;
+    const int bx0 = (p.x0 + x0) / PANO_INTERIOR_BLOCK, bx1 = (p.x0 + x1 - 1) / PANO_INTERIOR_BLOCK;
+    const int by0 = (p.y0 + y0) / PANO_INTERIOR_BLOCK, by1 = (p.y0 + y1 - 1) / PANO_INTERIOR_BLOCK;
     bool active = false;
     for (int by = by0; by <= by1; ++by)
         for (int bx = bx0; bx <= bx1; ++bx) active |= interior[(size_t)by * W8 + bx] == 0;
@@ -812,7 +812,7 @@ static int launch_tile_flags(pano_ctx *ctx, const pano_patch *table, int n, int 
     dim3 grid(ceil_div(ntx_max, 32), ceil_div(nty_max, 8), n);
     PANO_TIMED(PK_TILE_FLAGS, stream,
                hipLaunchKernelGGL(tile_flags32_kernel, grid, dim3(256), 0, stream, table, interior,
-                                  ceil_div(W, 8), tile_flags));
+                                  ceil_div(W, PANO_INTERIOR_BLOCK), tile_flags));
     PANO_LAUNCH_CHECK("tile_flags32_kernel");
     return PANO_OK;
 }

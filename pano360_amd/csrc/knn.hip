@@ -6,7 +6,7 @@
 // with the cross terms a [queries x train] matrix product - so it runs on the matrix cores:
 // v_mfma_f32_32x32x16_f16 with every operand split into float16 hi + lo (hi.hi + hi.lo +
 // lo.hi, float32 accumulate: ~2^-21 relative, i.e. float32-GEMM accuracy).  The product
-// only RANKS the candidates: the three best per query are then re-evaluated exactly in
+// only RANKS the candidates: the four best per query are then re-evaluated exactly in
 // float32 (sum of squared differences in a fixed order), and a bound on the product's error
 // proves per query that no other row can beat the second of them; a query for which the
 // proof fails (near ties) is rescanned exactly.  So the answer is the exact one.
@@ -15,7 +15,7 @@
 // features, hi / lo, lane: 8 halves) so that every operand read is one aligned 16-byte
 // access.  A wave keeps 32 queries' fragments in registers (the B operand: the result tile
 // then has the query on the lane and 16 train rows in the lane's registers, so the running
-// top-3 is private to a lane) and streams the train tiles through LDS, shared by the 4 waves
+// candidate list is private to a lane) and streams the train tiles through LDS, shared by the 4 waves
 // of the workgroup and double-buffered.
 #include "common.h"
 
@@ -23,7 +23,12 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define KNN_MAX_KS 8                  // k-steps of 16 features: d <= 128
-#define KNN_EPS 1.0e-4f               // error bound of a ranked value, relative to |q|^2 + max |t|^2
+// error bound of a ranked value, relative to |q|^2 + max |t|^2: 384 float32 accumulations
+// (<= 384 * 2^-24 of sum |q_i t_i| <= half of |q|^2 + |t|^2), twice for the factor -2, plus
+// the split's 3 * 2^-22 and the norms' own rounding: 2.6e-5; taken as 4e-5
+#define KNN_EPS 4.0e-5f
+#define KNN_KEEP 4                    // candidates kept per query: the proof compares the exact
+                                      // second with the ranked value of the last one kept
 
 __device__ __forceinline__ void knn_split(float v, _Float16 &hi, _Float16 &lo) {
     hi = (_Float16)v;
@@ -78,33 +83,27 @@ __global__ __launch_bounds__(256) void knn_norm_kernel(const float *__restrict__
     }
 }
 
-struct KnnTop3 {
-    float v0, v1, v2;
-    int i0, i1, i2;
+struct KnnTop {
+    float v[KNN_KEEP];                // ascending
+    int i[KNN_KEEP];
 };
 
-__device__ __forceinline__ void knn_insert(KnnTop3 &t, float v, int j) {
-    if (v < t.v2 || (v == t.v2 && j < t.i2)) {
-        if (v < t.v1 || (v == t.v1 && j < t.i1)) {
-            t.v2 = t.v1;
-            t.i2 = t.i1;
-            if (v < t.v0 || (v == t.v0 && j < t.i0)) {
-                t.v1 = t.v0;
-                t.i1 = t.i0;
-                t.v0 = v;
-                t.i0 = j;
-            } else {
-                t.v1 = v;
-                t.i1 = j;
-            }
-        } else {
-            t.v2 = v;
-            t.i2 = j;
-        }
+__device__ __forceinline__ bool knn_before(float v, int j, float w, int k) {
+    return v < w || (v == w && j < k);
+}
+
+__device__ __forceinline__ void knn_insert(KnnTop &t, float v, int j) {
+    if (!knn_before(v, j, t.v[KNN_KEEP - 1], t.i[KNN_KEEP - 1])) return;
+#pragma unroll
+    for (int s = KNN_KEEP - 1; s >= 0; --s) {
+        const bool up = s > 0 && knn_before(v, j, t.v[s - 1], t.i[s - 1]);
+        t.v[s] = up ? t.v[s - 1] : v;
+        t.i[s] = up ? t.i[s - 1] : j;
+        if (!up) break;
     }
 }
 
-// cand_idx [nq][3], cand_val [nq][3] (scaled |t|^2 - 2 q.t, ascending)
+// cand_idx [nq][KNN_KEEP], cand_val [nq][KNN_KEEP] (scaled |t|^2 - 2 q.t, ascending)
 template <int KS>
 __global__ __launch_bounds__(256) void knn2_kernel(const half8 *__restrict__ pq,
                                                    const half8 *__restrict__ pt,
@@ -124,8 +123,12 @@ __global__ __launch_bounds__(256) void knn2_kernel(const half8 *__restrict__ pq,
 #pragma unroll
         for (int part = 0; part < 2; ++part)
             bq[s][part] = pq[(((size_t)(live ? tq : 0) * KS + s) * 2 + part) * 64 + lane];
-    KnnTop3 top = {__builtin_inff(), __builtin_inff(), __builtin_inff(), 0x7fffffff, 0x7fffffff,
-                   0x7fffffff};
+    KnnTop top;
+#pragma unroll
+    for (int s = 0; s < KNN_KEEP; ++s) {
+        top.v[s] = __builtin_inff();
+        top.i[s] = 0x7fffffff;
+    }
     constexpr int CHUNKS = KS * 2 * 64 / 256;                 // 16-byte pieces per thread and tile
     half8 next[CHUNKS];
     float next_norm = 0.0f;
@@ -165,31 +168,28 @@ __global__ __launch_bounds__(256) void knn2_kernel(const half8 *__restrict__ pq,
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const float v = __builtin_fmaf(-2.0f, acc[4 * g + e], nv[e]);    // +inf beyond nt
-                if (__any(v < top.v2)) knn_insert(top, v, tt * 32 + 8 * g + 4 * h + e);
+                if (__any(v < top.v[KNN_KEEP - 1])) knn_insert(top, v, tt * 32 + 8 * g + 4 * h + e);
             }
         }
         if (tt + 1 < ntt) commit(buf ^ 1);                    // nobody reads that buffer now
         __syncthreads();
     }
     // the two halves of a wave hold different train rows for the same query: merge
-    KnnTop3 other;
-    other.v0 = __shfl_xor(top.v0, 32);
-    other.v1 = __shfl_xor(top.v1, 32);
-    other.v2 = __shfl_xor(top.v2, 32);
-    other.i0 = __shfl_xor(top.i0, 32);
-    other.i1 = __shfl_xor(top.i1, 32);
-    other.i2 = __shfl_xor(top.i2, 32);
-    knn_insert(top, other.v0, other.i0);
-    knn_insert(top, other.v1, other.i1);
-    knn_insert(top, other.v2, other.i2);
+    KnnTop other;
+#pragma unroll
+    for (int s = 0; s < KNN_KEEP; ++s) {
+        other.v[s] = __shfl_xor(top.v[s], 32);
+        other.i[s] = __shfl_xor(top.i[s], 32);
+    }
+#pragma unroll
+    for (int s = 0; s < KNN_KEEP; ++s) knn_insert(top, other.v[s], other.i[s]);
     const int q = tq * 32 + n;
     if (live && h == 0 && q < nq) {
-        cand_idx[3 * q] = top.i0;
-        cand_idx[3 * q + 1] = top.i1;
-        cand_idx[3 * q + 2] = top.i2;
-        cand_val[3 * q] = top.v0;
-        cand_val[3 * q + 1] = top.v1;
-        cand_val[3 * q + 2] = top.v2;
+#pragma unroll
+        for (int s = 0; s < KNN_KEEP; ++s) {
+            cand_idx[KNN_KEEP * q + s] = top.i[s];
+            cand_val[KNN_KEEP * q + s] = top.v[s];
+        }
     }
 }
 
@@ -229,16 +229,16 @@ __global__ __launch_bounds__(256) void knn2_refine_kernel(
             si = j;
         }
     };
-    for (int c = 0; c < 3; ++c) {
-        const int j = cand_idx[3 * qi + c];
+    for (int c = 0; c < KNN_KEEP; ++c) {
+        const int j = cand_idx[KNN_KEEP * qi + c];
         if (j < nt) take(knn_exact(q, train + (size_t)j * d, d, lane), j);
     }
-    // every row outside the list ranked at or above the third listed value, and a ranked value
+    // every row outside the list ranked at or above the last listed value, and a ranked value
     // is within eps of the true one: its squared distance is at least this
     const float s2 = scale * scale;
     const float eps = KNN_EPS * (norm_q[qi] + __uint_as_float(*maxnorm));
-    const float floor_d2 = (cand_val[3 * qi + 2] + norm_q[qi] - eps) / s2;
-    if (nt > 3 && !(second <= floor_d2)) {                     // not proven: exact rescan
+    const float floor_d2 = (cand_val[KNN_KEEP * qi + KNN_KEEP - 1] + norm_q[qi] - eps) / s2;
+    if (nt > KNN_KEEP && !(second <= floor_d2)) {                     // not proven: exact rescan
         best = second = __builtin_inff();
         bi = si = 0x7fffffff;
         for (int j = 0; j < nt; ++j) take(knn_exact(q, train + (size_t)j * d, d, lane), j);
@@ -272,9 +272,9 @@ static KnnWork knn_layout(int nq, int nt, int d) {
     w.ntn = off;
     off += knn_align(tt * 32 * sizeof(float));
     w.cidx = off;
-    off += knn_align((size_t)nq * 3 * sizeof(int32_t));
+    off += knn_align((size_t)nq * KNN_KEEP * sizeof(int32_t));
     w.cval = off;
-    off += knn_align((size_t)nq * 3 * sizeof(float));
+    off += knn_align((size_t)nq * KNN_KEEP * sizeof(float));
     w.scal = off;
     off += 256;
     w.total = off;

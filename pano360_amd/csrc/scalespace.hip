@@ -60,13 +60,25 @@ __global__ __launch_bounds__(256) void scale_step_kernel(const float *__restrict
     const int lane = tid & 63, wv = tid >> 6;
     const int ca = lane, cb = lane + 64;
     const int sxa = reflect_101(x0 - r + ca, w), sxb = reflect_101(x0 - r + (cb < iw ? cb : 0), w);
-    for (int ty = wv; ty < ih; ty += 4) {
-        const int sy = __builtin_amdgcn_readfirstlane(reflect_101(y0 - r + ty, h));
+    // all of a wave's loads are issued before the first LDS store: a load waited for on the
+    // spot, sixteen times over, is sixteen memory latencies per tile
+    constexpr int ROWS = (SS_IN_H + 3) / 4;                   // rows per wave, at most
+    float va[ROWS], vb[ROWS];
+#pragma unroll
+    for (int i = 0; i < ROWS; ++i) {
+        const int ty = wv + 4 * i;
+        const int sy = __builtin_amdgcn_readfirstlane(reflect_101(y0 - r + (ty < ih ? ty : 0), h));
         const float *src = in + (size_t)sy * w;
-        const float va = src[sxa];
-        const float vb = cb < iw ? src[sxb] : 0.f;
-        s_in[ty * SS_IN_W + ca] = va;
-        if (cb < iwp) s_in[ty * SS_IN_W + cb] = vb;
+        va[i] = src[sxa];
+        vb[i] = src[sxb];
+    }
+#pragma unroll
+    for (int i = 0; i < ROWS; ++i) {
+        const int ty = wv + 4 * i;
+        if (ty < ih) {
+            s_in[ty * SS_IN_W + ca] = va[i];
+            if (cb < iwp) s_in[ty * SS_IN_W + cb] = cb < iw ? vb[i] : 0.f;
+        }
     }
     __syncthreads();
 

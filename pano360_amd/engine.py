@@ -627,6 +627,7 @@ class Engine:
         self.set_option(_lib.OPT_BLUR_KERNEL, _lib.BLUR_VALU if blur == "valu" else _lib.BLUR_MFMA)
         self.set_option(_lib.OPT_OWN_PRUNE, 1 if own_prune else 0)
         self.tile_grid = int(self.lib.pano_blur_tile_grid(self._ctx))
+        self.interior_block = int(self.lib.pano_interior_block())
         lut = np.arange(256, dtype=np.float32) / np.float32(255)   # stitcher.py:259
         self.lut255 = torch.from_numpy(lut).to(self.device)
         self._hats = {}
@@ -797,12 +798,14 @@ class Engine:
         return mosaic, fl, owner, valid
 
     def interior_map(self, owner, radius, strip=None):
-        """uint8 [ceil(H/8)][ceil(W/8)]: 8 x 8 blocks whose pixels all have a single
-        owner within ``radius`` - there the multiband mosaic is the owner's colour."""
+        """uint8 [ceil(H/B)][ceil(W/B)], B = the library's interior block: B x B blocks whose
+        pixels all have a single owner within ``radius`` - there the multiband mosaic is the
+        owner's colour."""
         torch = _torch()
         H, W = owner.shape
         c0, c1 = strip if strip is not None else (0, W)
-        shape8 = ((H + 7) // 8, (W + 7) // 8)
+        ib = self.interior_block
+        shape8 = ((H + ib - 1) // ib, (W + ib - 1) // ib)
         bown = torch.empty((2,) + shape8, dtype=torch.int16, device=self.device)
         interior = torch.empty(shape8, dtype=torch.uint8, device=self.device)
         _lib.check(self.lib.pano_interior_map(self.ctx(), _ptr(owner), H, W, c0, c1, radius,
@@ -1077,7 +1080,9 @@ class Engine:
         # the owner map is needed one radius past the strip for the windows, and as
         # far as the 8 x 8-block interior test looks, so that every strip classifies
         # its pixels exactly as the whole mosaic would
-        margin = max(radius, 8 * ((radius + 14) // 8) + 7) if shortcut and n_blur else radius
+        ib = self.interior_block
+        margin = (max(radius, ib * ((radius + 2 * ib - 2) // ib) + ib - 1) if shortcut and n_blur
+                  else radius)
         ext = (max(c0 - margin, 0), min(c1 + margin, W))
         ids = list(range(plan.n)) if frame_ids is None else list(frame_ids)
         have = dict(zip(ids, frames))

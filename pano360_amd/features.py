@@ -290,7 +290,7 @@ def knn2_device(des1, des2, eng=None, want_rescans=False):
     """Two nearest rows of ``des2`` (Euclidean) for every row of ``des1``; both device
     float32 [K][D], D <= 128.  Returns (indices int64 [K1][2], distances float32 [K1][2]),
     nearest first.  ``pano_knn2``: the cross terms of |a - b|^2 on the matrix cores (split
-    float16) rank the rows, the three best per query are re-evaluated exactly in float32 and
+    float16) rank the rows, the four best per query are re-evaluated exactly in float32 and
     an error bound proves the rest cannot beat them (else that query is rescanned exactly)."""
     import torch
     eng = eng or _eng.engine()

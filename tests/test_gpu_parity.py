@@ -492,7 +492,8 @@ def test_interior_shortcut(eng, oracle, kind):
     interior = eng.interior_map(owner, 43).bool()
     frac = interior.float().mean().item()
     assert 0.2 < frac < 0.8                         # both branches are exercised
-    big = interior.repeat_interleave(8, 0).repeat_interleave(8, 1)[:plan.shape[0], :plan.shape[1]]
+    ib = eng.interior_block
+    big = interior.repeat_interleave(ib, 0).repeat_interleave(ib, 1)[:plan.shape[0], :plan.shape[1]]
     assert torch.equal(m1[~big], m2[~big])          # untouched outside the interior
     # the interior test is conservative: every pixel of an interior block has one
     # owner over the whole (2R+1)^2 window

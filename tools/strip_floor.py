@@ -1,0 +1,58 @@
+#!/usr/bin/env python3
+"""What one rank of an N-GPU strips run costs per stitch when only its strip's kernels run:
+rank r of world N emulated on this one GPU (no exchange).  The time that does not shrink with
+N - the plan, the launches, the one synchronisation - is the floor of strong scaling.
+    python tools/strip_floor.py [cfg3] [world ...]"""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+from pano360_amd import dist as pdist  # noqa: E402
+from pano360_amd import engine, synth  # noqa: E402
+
+name = sys.argv[1] if len(sys.argv) > 1 else "cfg3"
+worlds = [int(v) for v in sys.argv[2:]] or [1, 2, 4, 8]
+cfg = dict(synth.CONFIGS[name])
+rots, intrs = synth.make_cameras(cfg["n"], cfg["width"], cfg["height"],
+                                 sweep_deg=cfg.get("sweep_deg"), step_deg=cfg.get("step_deg"))
+shapes = [(cfg["height"], cfg["width"])] * cfg["n"]
+eng = engine.Engine()
+pool = {}
+for world in worlds:
+    worst = (0.0, None)
+    for rank in sorted({0, world // 2, world - 1}):
+        st = pdist.ShardedStitcher(eng, shapes, rots, intrs, cfg["n_levels"], rank, world,
+                                   exchange=None)
+        for i in st.my_frames:
+            if i not in pool:
+                pool[i] = eng.upload_frames([synth.make_frame(i, cfg["width"], cfg["height"], "A")])[0]
+        frames = [pool[i] for i in st.my_frames]
+        out = torch.zeros(engine.Plan(shapes, rots, intrs, True, 10 ** 9).shape + (3,),
+                          dtype=torch.uint8, device=eng.device)
+
+        def step():
+            plan = engine.Plan(shapes, rots, intrs, True, 10 ** 9)
+            eng.upload_plan(plan)
+            eng.multiband_fused(frames, plan, cfg["n_levels"], frame_ids=st.my_frames,
+                                strip=st.strip, mosaic_out=out)
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize()
+        eng.timing(True)
+        t0 = time.perf_counter()
+        for _ in range(20):
+            step()
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / 20 * 1e3
+        kern = sum(v[0] for v in eng.kernel_times().values()) / 20
+        eng.timing(False)
+        if ms > worst[0]:
+            worst = (ms, rank, kern, len(frames))
+    print(f"world {world}: slowest of ranks sampled = rank {worst[1]}: {worst[0]:.3f} ms per stitch "
+          f"(timed kernels {worst[2]:.3f} ms, {worst[3]} frames resident)")
+t0 = time.perf_counter()
+for _ in range(50):
+    engine.Plan(shapes, rots, intrs, True, 10 ** 9)
+print("Plan alone: %.3f ms" % ((time.perf_counter() - t0) / 50 * 1e3))
