@@ -27,7 +27,7 @@
 #define SS_IN_W 128                            // >= 64 + 2 r + 7; a multiple of 64 floats keeps the
                                                // row pass's 16-byte reads conflict-free
 #define SS_IN_H (SS_TH + 2 * SS_RMAX)          // 64
-#define SS_MID_PITCH (SS_TW + 1)               // column reads of 64 lanes: conflict-free
+#define SS_MID_PITCH (SS_TW + 4)               // 16-byte rows; the column pass reads float4
 #define SS_NTAP 36                             // 2 r + 1 rounded up to the row pass's trip of 4
 
 struct SsTaps {
@@ -44,7 +44,7 @@ __global__ __launch_bounds__(256) void scale_step_kernel(const float *__restrict
                                                          SsTaps taps, float *__restrict__ out,
                                                          float *__restrict__ dog) {
     __shared__ __attribute__((aligned(16))) float s_in[SS_IN_H * SS_IN_W];
-    __shared__ float s_mid[SS_IN_H * SS_MID_PITCH];
+    __shared__ __attribute__((aligned(16))) float s_mid[SS_IN_H * SS_MID_PITCH];
     const int tid = threadIdx.x;
     const int nt = NT ? NT : taps.n;
     const int r = nt >> 1;
@@ -62,22 +62,60 @@ __global__ __launch_bounds__(256) void scale_step_kernel(const float *__restrict
     const int sxa = reflect_101(x0 - r + ca, w), sxb = reflect_101(x0 - r + (cb < iw ? cb : 0), w);
     // all of a wave's loads are issued before the first LDS store: a load waited for on the
     // spot, sixteen times over, is sixteen memory latencies per tile
-    constexpr int ROWS = (SS_IN_H + 3) / 4;                   // rows per wave, at most
-    float va[ROWS], vb[ROWS];
+    const int gx = x0 - r;                                    // image column of tile column 0
+    constexpr int CPR = (SS_TW + (NT ? NT : 1) - 1 + 3 + 3) / 4;   // 16-byte chunks per tile row
+    const bool inner = NT && gx >= 0 && gx + 4 * CPR <= w && y0 - r >= 0 &&
+                       y0 + SS_TH + r <= h && (w & 3) == 0;    // uniform: no reflection, 16-B rows
+    if (inner) {
+        // 16-byte loads aligned in the image: chunk c of a row covers image columns
+        // ga + 4 c .. + 3 with ga = gx rounded down to a multiple of 4
+        const int ga = gx & ~3, shift = gx - ga;
+        constexpr int TOT = (SS_TH + NT - 1) * CPR;
+        constexpr int PER = (TOT + 255) / 256;
+        float4 v[PER];
 #pragma unroll
-    for (int i = 0; i < ROWS; ++i) {
-        const int ty = wv + 4 * i;
-        const int sy = __builtin_amdgcn_readfirstlane(reflect_101(y0 - r + (ty < ih ? ty : 0), h));
-        const float *src = in + (size_t)sy * w;
-        va[i] = src[sxa];
-        vb[i] = src[sxb];
-    }
+        for (int i = 0; i < PER; ++i) {
+            const int c = tid + 256 * i;
+            const int ty = c / CPR, cc = c - ty * CPR;
+            v[i] = c < TOT ? *(const float4 *)(in + (size_t)(y0 - r + ty) * w + ga + 4 * cc)
+                           : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
 #pragma unroll
-    for (int i = 0; i < ROWS; ++i) {
-        const int ty = wv + 4 * i;
-        if (ty < ih) {
-            s_in[ty * SS_IN_W + ca] = va[i];
-            if (cb < iwp) s_in[ty * SS_IN_W + cb] = cb < iw ? vb[i] : 0.f;
+        for (int i = 0; i < PER; ++i) {
+            const int c = tid + 256 * i;
+            if (c < TOT) {
+                const int ty = c / CPR, cc = c - ty * CPR;
+                float *d = s_in + ty * SS_IN_W + 4 * cc - shift;       // tile column of v[i].x
+                const int tc = 4 * cc - shift;
+                if (tc >= 0) d[0] = v[i].x;
+                if (tc + 1 >= 0) d[1] = v[i].y;
+                if (tc + 2 >= 0) d[2] = v[i].z;
+                d[3] = v[i].w;
+            }
+        }
+        // the zero columns past the halo (the chunks above end at or past column iw - 1)
+        for (int i = tid; i < ih * 8; i += 256) {
+            const int ty = i >> 3, tx = CPR * 4 - 3 + (i & 7);
+            if (tx >= iw && tx < iwp) s_in[ty * SS_IN_W + tx] = 0.f;
+        }
+    } else {
+        constexpr int ROWS = (SS_IN_H + 3) / 4;               // rows per wave, at most
+        float va[ROWS], vb[ROWS];
+#pragma unroll
+        for (int i = 0; i < ROWS; ++i) {
+            const int ty = wv + 4 * i;
+            const int sy = __builtin_amdgcn_readfirstlane(reflect_101(y0 - r + (ty < ih ? ty : 0), h));
+            const float *src = in + (size_t)sy * w;
+            va[i] = src[sxa];
+            vb[i] = src[sxb];
+        }
+#pragma unroll
+        for (int i = 0; i < ROWS; ++i) {
+            const int ty = wv + 4 * i;
+            if (ty < ih) {
+                s_in[ty * SS_IN_W + ca] = va[i];
+                if (cb < iwp) s_in[ty * SS_IN_W + cb] = cb < iw ? vb[i] : 0.f;
+            }
         }
     }
     __syncthreads();
@@ -133,44 +171,55 @@ __global__ __launch_bounds__(256) void scale_step_kernel(const float *__restrict
     }
     __syncthreads();
 
-    // column pass: 64 columns x 32 rows, 8 stacked outputs per thread
-    const int cx = tid & 63, cy = (tid >> 6) * 8;
-    float acc[8];
-#pragma unroll
-    for (int o = 0; o < 8; ++o) acc[o] = 0.f;
-    const float *col = s_mid + cy * SS_MID_PITCH + cx;
+    // column pass: 64 columns x 32 rows; a thread makes 4 adjacent columns x 2 stacked rows
+    // from 16-byte LDS reads (the FMAs pair up into v_pk_fma_f32) and stores 16 bytes per row
+    const int cq = (tid & 15) * 4, cy = (tid >> 4) * 2;
+    float4 acc0 = make_float4(0.f, 0.f, 0.f, 0.f), acc1 = acc0;
+    const float *col = s_mid + cy * SS_MID_PITCH + cq;
+    auto fma4 = [](float wk, const float4 v, float4 &a) {
+        a.x = __builtin_fmaf(wk, v.x, a.x);
+        a.y = __builtin_fmaf(wk, v.y, a.y);
+        a.z = __builtin_fmaf(wk, v.z, a.z);
+        a.w = __builtin_fmaf(wk, v.w, a.w);
+    };
     if (NT) {
-        float v[NT + 7];
+        float4 v[NT + 1];
 #pragma unroll
-        for (int k = 0; k < NT + 7; ++k) v[k] = col[k * SS_MID_PITCH];
+        for (int k = 0; k < NT + 1; ++k) v[k] = *(const float4 *)(col + k * SS_MID_PITCH);
 #pragma unroll
         for (int k = 0; k < NT; ++k) {
-            const float wk = taps.w[k];
-#pragma unroll
-            for (int o = 0; o < 8; ++o) acc[o] = __builtin_fmaf(wk, v[k + o], acc[o]);
+            fma4(taps.w[k], v[k], acc0);
+            fma4(taps.w[k], v[k + 1], acc1);
         }
     } else {
-        float win[8];
-#pragma unroll
-        for (int o = 0; o < 7; ++o) win[o] = col[o * SS_MID_PITCH];
+        float4 lo = *(const float4 *)col;
         for (int k = 0; k < nt; ++k) {
-            win[7] = col[(k + 7) * SS_MID_PITCH];
-            const float wk = taps.w[k];
-#pragma unroll
-            for (int o = 0; o < 8; ++o) acc[o] = __builtin_fmaf(wk, win[o], acc[o]);
-#pragma unroll
-            for (int o = 0; o < 7; ++o) win[o] = win[o + 1];
+            const float4 hi = *(const float4 *)(col + (k + 1) * SS_MID_PITCH);
+            fma4(taps.w[k], lo, acc0);
+            fma4(taps.w[k], hi, acc1);
+            lo = hi;
         }
     }
-    const int x = x0 + cx;
-    if (x < w) {
+    const int x = x0 + cq;
+    const float4 res[2] = {acc0, acc1};
 #pragma unroll
-        for (int o = 0; o < 8; ++o) {
-            const int y = y0 + cy + o;
-            if (y >= h) break;
-            const size_t at = (size_t)y * w + x;
-            out[at] = acc[o];
-            if (dog) dog[at] = acc[o] - s_in[(cy + o + r) * SS_IN_W + cx + r];
+    for (int o = 0; o < 2; ++o) {
+        const int y = y0 + cy + o;
+        if (y >= h || x >= w) break;
+        const size_t at = (size_t)y * w + x;
+        const float *c = s_in + (cy + o + r) * SS_IN_W + cq + r;          // the input's centre
+        const float4 d = make_float4(res[o].x - c[0], res[o].y - c[1], res[o].z - c[2],
+                                     res[o].w - c[3]);
+        if (x + 4 <= w && (w & 3) == 0) {
+            *(float4 *)(out + at) = res[o];
+            if (dog) *(float4 *)(dog + at) = d;
+        } else {
+            const float rv[4] = {res[o].x, res[o].y, res[o].z, res[o].w};
+            const float dv[4] = {d.x, d.y, d.z, d.w};
+            for (int j = 0; j < 4 && x + j < w; ++j) {
+                out[at + j] = rv[j];
+                if (dog) dog[at + j] = dv[j];
+            }
         }
     }
 }

@@ -916,6 +916,22 @@ def test_laplacian_pyramid_levels_bit_exact(eng):
                           lo.laplacian_blending(img1, img2))
 
 
+def test_laplacian_blending_keeps_a_float32_mask_float32(eng):
+    """NumPy keeps the per-level mix and the collapse in float32 when the mask is float32
+    (blend.py:134-140: float32 * float32, 1.0 - float32): bit-exact against the oracle, and
+    different from what the same mask gives as float64."""
+    import laplacian_oracle as lo
+    from pano360_amd import blend, synth
+    img1, img2 = synth.make_frame(7, 203, 130, "B"), synth.make_frame(8, 203, 130, "A")
+    yy, xx = np.mgrid[0:130, 0:203]
+    mask64 = (0.5 + 0.5 * np.sin(xx / 17.0) * np.cos(yy / 11.0))[..., None]
+    mask32 = mask64.astype(np.float32)
+    got32 = blend.laplacian_blending(img1, img2, mask32, 5)
+    assert np.array_equal(got32, lo.laplacian_blending(img1, img2, mask32, 5))
+    got64 = blend.laplacian_blending(img1, img2, mask32.astype(np.float64), 5)
+    assert np.array_equal(got64, lo.laplacian_blending(img1, img2, mask32.astype(np.float64), 5))
+
+
 def test_laplacian_blending_argument_errors(eng):
     from pano360_amd import blend
     img = np.zeros((8, 8, 3), np.uint8)

@@ -308,3 +308,30 @@ def test_native_window_layout_equals_windows_for():
                                            have.ctypes.data, radius, strip[0], strip[1], n_blur,
                                            rec.ctypes.data, len(rec), C.byref(lay)), "layout")
         assert lay.missing == lay.n_records
+
+
+def test_top_level_stitcher_is_the_module_itself():
+    """``import stitcher`` must hand out the module whose globals ``stitch`` reads at call
+    time: setting ``stitcher.MAX_RESOLUTION`` as a reference caller does (stitcher.py:17,
+    153-155) changes the resolution the very next call computes."""
+    import bundle_adj
+    import stitcher
+    import pano360_amd.stitcher as impl
+    from pano360_amd import synth
+    assert stitcher is impl
+    rots, intrs = synth.make_cameras(5, 240, 136, sweep_deg=90.0)
+    regions = [bundle_adj.Image(np.zeros((136, 240, 3), np.uint8), r, k) for r, k in zip(rots, intrs)]
+    for reg in regions:
+        reg.range = stitcher._proj_img_range_border(reg.img.shape[:2], reg.hom())
+    saved = stitcher.MAX_RESOLUTION
+    try:
+        sizes = {}
+        for cap in (1400, 300, 10 ** 9):
+            stitcher.MAX_RESOLUTION = cap
+            res, (lo, hi) = stitcher.estimate_resolution(regions)
+            sizes[cap] = np.round((hi - lo) / res).astype(int)
+    finally:
+        stitcher.MAX_RESOLUTION = saved
+    # native size 600 x 156: the default cap of 1400 does not bind, a cap of 300 does
+    assert list(sizes[10 ** 9]) == list(sizes[1400]) == [600, 156]
+    assert list(sizes[300]) == [300, 78]

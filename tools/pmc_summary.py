@@ -12,13 +12,17 @@ import re
 import sys
 
 
-def main(root, workload="cfg3"):
+def main(root, workload="cfg3", by_grid=""):
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
     for path in glob.glob(os.path.join(root, "*", "**", "*counter_collection.csv"), recursive=True):
         with open(path) as fid:
             for row in csv.DictReader(fid):
                 name = row["Kernel_Name"].split("(")[0].replace("void ", "")
                 name = re.sub(r"<.*", "", name)[:40]
+                if by_grid:                      # kernels launched at many sizes: one line per size
+                    tmpl = re.search(r"<([^>]*)>", row["Kernel_Name"])
+                    name += f"<{tmpl.group(1)}>" if tmpl else ""
+                    name += f" grid {row.get('Grid_Size', '?')}"
                 acc[name][row["Counter_Name"]].append(float(row["Counter_Value"]))
     counters = sorted({c for k in acc.values() for c in k})
     traffic = {}
@@ -39,4 +43,4 @@ def main(root, workload="cfg3"):
 
 
 if __name__ == "__main__":
-    main(*sys.argv[1:3])
+    main(*sys.argv[1:4])
