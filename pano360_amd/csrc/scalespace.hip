@@ -14,64 +14,62 @@
 // per pixel; fused it moves 12 + the halo re-reads (L2 hits).
 //
 // Tile: 64 x 32 outputs per 256-thread workgroup.  The (32 + 2r) x (64 + 2r) input tile
-// (r <= 16) is staged in LDS with REFLECT_101 applied on the way in, the row pass writes
-// (32 + 2r) x 64 sums back to LDS, the column pass reads them.  Register blocking: a
-// thread makes 4 adjacent row-pass outputs from one sliding window (r/2 + 1 LDS reads per
-// output instead of 2r + 1) and 8 stacked column-pass outputs of one column.  Sums run in
-// ascending tap order, one FMA per tap, like pano_blur_plane (csrc/blur.hip).
+// (r <= 16) is staged in LDS (16-byte loads and stores away from the borders, REFLECT_101
+// applied on the way in at the borders), the row pass writes (32 + 2r) x 64 sums back to
+// LDS, the column pass reads them.  Register blocking: a thread makes 4 adjacent row-pass
+// outputs from one sliding window of 16-byte reads and 4 columns x 2 rows of column-pass
+// outputs; every LDS access is 16 bytes wide and laid out conflict-free (the first version
+// spent 60 % of its LDS cycles in bank conflicts).  Sums run in ascending tap order, one
+// FMA per tap, like pano_blur_plane (csrc/blur.hip).
 #include "common.h"
 
 #define SS_TW 64
 #define SS_TH 32
 #define SS_RMAX 16
-#define SS_IN_W 128                            // >= 64 + 2 r + 7; a multiple of 64 floats keeps the
-                                               // row pass's 16-byte reads conflict-free
-#define SS_IN_H (SS_TH + 2 * SS_RMAX)          // 64
-#define SS_MID_PITCH (SS_TW + 4)               // 16-byte rows; the column pass reads float4
-#define SS_NTAP 36                             // 2 r + 1 rounded up to the row pass's trip of 4
+#define SS_IN_W 128                 // floats per tile row in LDS: a multiple of 64 keeps the row
+                                    // pass's 16-byte reads of four rows at once conflict-free
+#define SS_MID_W 96                 // row-pass image: two rows apart = 0 mod 64 banks, so the
+                                    // column pass's 16-byte reads of two row pairs do not collide
+#define SS_NTAP 40                  // 3 leading zeros + 33 taps, rounded up to the trip of 4
 
 struct SsTaps {
-    float w[SS_NTAP];                          // zero beyond n
-    int n;
+    float w[SS_NTAP];               // `lead` zeros, the n taps, zeros
+    int n, lead;
 };
 
-// dog (optional) = out - in at the same pixel.  NT = the aperture (compile-time for the
-// five steps of an octave and the base blur, so that every loop unrolls, the taps sit in
-// scalar registers and the LDS reads of a pass are all in flight before its first FMA);
-// NT = 0: any odd aperture up to 33, looped.
+// LDS column L of the tile is image column ga + L with ga = x0 - r - lead a multiple of 4
+// (lead = (-r) & 3): 16-byte groups of the image land on 16-byte groups of the tile, and the
+// row pass takes the `lead` extra columns in front of its window with zero taps.
+//
+// dog (optional) = out - in at the same pixel.  NT = the aperture (compile-time for the five
+// steps of an octave and the base blur: every loop unrolls, the taps sit in scalar registers,
+// the LDS reads of a pass are all in flight before its first FMA, and the LDS arrays are cut
+// to the rows that aperture needs); NT = 0: any odd aperture up to 33, looped.
 template <int NT>
 __global__ __launch_bounds__(256) void scale_step_kernel(const float *__restrict__ in, int h, int w,
                                                          SsTaps taps, float *__restrict__ out,
                                                          float *__restrict__ dog) {
-    __shared__ __attribute__((aligned(16))) float s_in[SS_IN_H * SS_IN_W];
-    __shared__ __attribute__((aligned(16))) float s_mid[SS_IN_H * SS_MID_PITCH];
+    constexpr int IH = NT ? SS_TH + NT - 1 : SS_TH + 2 * SS_RMAX;
+    __shared__ __attribute__((aligned(16))) float s_in[IH * SS_IN_W];
+    __shared__ __attribute__((aligned(16))) float s_mid[IH * SS_MID_W];
     const int tid = threadIdx.x;
     const int nt = NT ? NT : taps.n;
     const int r = nt >> 1;
+    const int lead = NT ? ((4 - (r & 3)) & 3) : taps.lead;
     const int x0 = blockIdx.x * SS_TW, y0 = blockIdx.y * SS_TH;
-    const int iw = SS_TW + 2 * r, ih = SS_TH + 2 * r;
+    const int ih = SS_TH + 2 * r;
+    const int ga = x0 - r - lead;                             // image column of LDS column 0
+    const int trips = (nt + lead + 3) >> 2;                   // row pass: 4 taps per trip
+    const int cols = SS_TW + 4 * trips + 4;                   // LDS columns the row pass reads
+    constexpr int CPR = NT ? (SS_TW + 4 * ((NT + ((4 - ((NT >> 1) & 3)) & 3) + 3) / 4) + 4 + 3) / 4 : 1;
 
-    // stage the input tile; rows / columns beyond the image arrive reflected.  A wave takes
-    // every fourth row (the reflected source row is wave-uniform), a lane the same two columns
-    // in every row (reflected once).  The row pass reads whole 16-byte groups: columns up to
-    // the next multiple of 4 past the halo (+ 4) are zero-filled, so that the zero taps there
-    // multiply finite numbers
-    const int iwp = ((iw + 3) & ~3) + 4;
-    const int lane = tid & 63, wv = tid >> 6;
-    const int ca = lane, cb = lane + 64;
-    const int sxa = reflect_101(x0 - r + ca, w), sxb = reflect_101(x0 - r + (cb < iw ? cb : 0), w);
-    // all of a wave's loads are issued before the first LDS store: a load waited for on the
-    // spot, sixteen times over, is sixteen memory latencies per tile
-    const int gx = x0 - r;                                    // image column of tile column 0
-    constexpr int CPR = (SS_TW + (NT ? NT : 1) - 1 + 3 + 3) / 4;   // 16-byte chunks per tile row
-    const bool inner = NT && gx >= 0 && gx + 4 * CPR <= w && y0 - r >= 0 &&
-                       y0 + SS_TH + r <= h && (w & 3) == 0;    // uniform: no reflection, 16-B rows
+    // ---- stage the input tile -----------------------------------------------------------
+    const bool inner = NT && ga >= 0 && ga + 4 * CPR <= w && y0 - r >= 0 && y0 + SS_TH + r <= h &&
+                       (w & 3) == 0;                          // uniform: no reflection, 16-B rows
     if (inner) {
-        // 16-byte loads aligned in the image: chunk c of a row covers image columns
-        // ga + 4 c .. + 3 with ga = gx rounded down to a multiple of 4
-        const int ga = gx & ~3, shift = gx - ga;
-        constexpr int TOT = (SS_TH + NT - 1) * CPR;
-        constexpr int PER = (TOT + 255) / 256;
+        // all loads are issued before the first LDS store: a load waited for on the spot is a
+        // memory latency per row
+        constexpr int TOT = IH * CPR, PER = (TOT + 255) / 256;
         float4 v[PER];
 #pragma unroll
         for (int i = 0; i < PER; ++i) {
@@ -85,97 +83,111 @@ __global__ __launch_bounds__(256) void scale_step_kernel(const float *__restrict
             const int c = tid + 256 * i;
             if (c < TOT) {
                 const int ty = c / CPR, cc = c - ty * CPR;
-                float *d = s_in + ty * SS_IN_W + 4 * cc - shift;       // tile column of v[i].x
-                const int tc = 4 * cc - shift;
-                if (tc >= 0) d[0] = v[i].x;
-                if (tc + 1 >= 0) d[1] = v[i].y;
-                if (tc + 2 >= 0) d[2] = v[i].z;
-                d[3] = v[i].w;
+                *(float4 *)(s_in + ty * SS_IN_W + 4 * cc) = v[i];
             }
         }
-        // the zero columns past the halo (the chunks above end at or past column iw - 1)
-        for (int i = tid; i < ih * 8; i += 256) {
-            const int ty = i >> 3, tx = CPR * 4 - 3 + (i & 7);
-            if (tx >= iw && tx < iwp) s_in[ty * SS_IN_W + tx] = 0.f;
-        }
     } else {
-        constexpr int ROWS = (SS_IN_H + 3) / 4;               // rows per wave, at most
+        // borders (and the looped form): rows / columns beyond the image arrive reflected
+        // (REFLECT_101), the leading columns and those past the halo as zeros
+        const int lane = tid & 63, wv = tid >> 6;
+        int sx[2];
+        bool real[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int L = lane + 64 * j, tc = L - lead;       // tile column
+            real[j] = tc >= 0 && tc < SS_TW + 2 * r;
+            sx[j] = reflect_101(x0 - r + (real[j] ? tc : 0), w);
+        }
+        constexpr int ROWS = (IH + 3) / 4;                    // rows per wave, at most
         float va[ROWS], vb[ROWS];
 #pragma unroll
         for (int i = 0; i < ROWS; ++i) {
             const int ty = wv + 4 * i;
             const int sy = __builtin_amdgcn_readfirstlane(reflect_101(y0 - r + (ty < ih ? ty : 0), h));
             const float *src = in + (size_t)sy * w;
-            va[i] = src[sxa];
-            vb[i] = src[sxb];
+            va[i] = src[sx[0]];
+            vb[i] = src[sx[1]];
         }
 #pragma unroll
         for (int i = 0; i < ROWS; ++i) {
             const int ty = wv + 4 * i;
             if (ty < ih) {
-                s_in[ty * SS_IN_W + ca] = va[i];
-                if (cb < iwp) s_in[ty * SS_IN_W + cb] = cb < iw ? vb[i] : 0.f;
+                s_in[ty * SS_IN_W + lane] = real[0] ? va[i] : 0.f;
+                if (lane + 64 < cols) s_in[ty * SS_IN_W + lane + 64] = real[1] ? vb[i] : 0.f;
             }
         }
     }
     __syncthreads();
 
-    // row pass: ih rows x 64 outputs; a thread makes 4 adjacent outputs, four taps per trip
+    // ---- row pass: ih rows x 64 outputs; a thread makes 4 adjacent outputs, four taps per trip
     // from one aligned 16-byte LDS read (window = the previous read + this one)
-    constexpr int TRIPS = NT ? (NT + 3) / 4 : 0;
-    const int trips = NT ? TRIPS : (nt + 3) >> 2;
-    for (int i = tid; i < ih * (SS_TW / 4); i += 256) {
-        const int ty = i >> 4, q = (i & 15) * 4;
-        const float4 *row = (const float4 *)(s_in + ty * SS_IN_W + q);
-        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-        auto trip = [&](const float4 lo, const float4 hi, const int k) {
-            const float w0 = taps.w[4 * k], w1 = taps.w[4 * k + 1], w2 = taps.w[4 * k + 2],
-                        w3 = taps.w[4 * k + 3];
-            // output j meets tap 4 k + t at window entry j + t
-            a0 = __builtin_fmaf(w0, lo.x, a0);
-            a1 = __builtin_fmaf(w0, lo.y, a1);
-            a2 = __builtin_fmaf(w0, lo.z, a2);
-            a3 = __builtin_fmaf(w0, lo.w, a3);
-            a0 = __builtin_fmaf(w1, lo.y, a0);
-            a1 = __builtin_fmaf(w1, lo.z, a1);
-            a2 = __builtin_fmaf(w1, lo.w, a2);
-            a3 = __builtin_fmaf(w1, hi.x, a3);
-            a0 = __builtin_fmaf(w2, lo.z, a0);
-            a1 = __builtin_fmaf(w2, lo.w, a1);
-            a2 = __builtin_fmaf(w2, hi.x, a2);
-            a3 = __builtin_fmaf(w2, hi.y, a3);
-            a0 = __builtin_fmaf(w3, lo.w, a0);
-            a1 = __builtin_fmaf(w3, hi.x, a1);
-            a2 = __builtin_fmaf(w3, hi.y, a2);
-            a3 = __builtin_fmaf(w3, hi.z, a3);
-        };
-        if (NT) {
-            float4 win[TRIPS + 1];
+    constexpr int TRIPS = NT ? (NT + ((4 - ((NT >> 1) & 3)) & 3) + 3) / 4 : 0;
+    if (NT) {
+        // 8 adjacent outputs per thread: TRIPS + 2 reads of 16 bytes feed 8 x 4 TRIPS FMAs
+        for (int i = tid; i < ih * (SS_TW / 8); i += 256) {
+            const int ty = i >> 3, q = (i & 7) * 8;
+            const float4 *row = (const float4 *)(s_in + ty * SS_IN_W + q);
+            float4 win[TRIPS + 2];
 #pragma unroll
-            for (int k = 0; k <= TRIPS; ++k) win[k] = row[k];
+            for (int k = 0; k < TRIPS + 2; ++k) win[k] = row[k];
+            float a[8];
 #pragma unroll
-            for (int k = 0; k < TRIPS; ++k) trip(win[k], win[k + 1], k);
-        } else {
+            for (int j = 0; j < 8; ++j) a[j] = 0.f;
+#pragma unroll
+            for (int k = 0; k < TRIPS; ++k) {
+                const float e[12] = {win[k].x,     win[k].y,     win[k].z,     win[k].w,
+                                     win[k + 1].x, win[k + 1].y, win[k + 1].z, win[k + 1].w,
+                                     win[k + 2].x, win[k + 2].y, win[k + 2].z, win[k + 2].w};
+#pragma unroll
+                for (int tt = 0; tt < 4; ++tt) {
+                    const float wt = taps.w[4 * k + tt];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) a[j] = __builtin_fmaf(wt, e[j + tt], a[j]);
+                }
+            }
+            float4 *m = (float4 *)(s_mid + ty * SS_MID_W + q);
+            m[0] = make_float4(a[0], a[1], a[2], a[3]);
+            m[1] = make_float4(a[4], a[5], a[6], a[7]);
+        }
+    } else {
+        for (int i = tid; i < ih * (SS_TW / 4); i += 256) {
+            const int ty = i >> 4, q = (i & 15) * 4;
+            const float4 *row = (const float4 *)(s_in + ty * SS_IN_W + q);
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
             float4 lo = row[0];
             for (int k = 0; k < trips; ++k) {
                 const float4 hi = row[k + 1];
-                trip(lo, hi, k);
+                const float w0 = taps.w[4 * k], w1 = taps.w[4 * k + 1], w2 = taps.w[4 * k + 2],
+                            w3 = taps.w[4 * k + 3];
+                // output j meets tap 4 k + t at window entry j + t
+                a0 = __builtin_fmaf(w0, lo.x, a0);
+                a1 = __builtin_fmaf(w0, lo.y, a1);
+                a2 = __builtin_fmaf(w0, lo.z, a2);
+                a3 = __builtin_fmaf(w0, lo.w, a3);
+                a0 = __builtin_fmaf(w1, lo.y, a0);
+                a1 = __builtin_fmaf(w1, lo.z, a1);
+                a2 = __builtin_fmaf(w1, lo.w, a2);
+                a3 = __builtin_fmaf(w1, hi.x, a3);
+                a0 = __builtin_fmaf(w2, lo.z, a0);
+                a1 = __builtin_fmaf(w2, lo.w, a1);
+                a2 = __builtin_fmaf(w2, hi.x, a2);
+                a3 = __builtin_fmaf(w2, hi.y, a3);
+                a0 = __builtin_fmaf(w3, lo.w, a0);
+                a1 = __builtin_fmaf(w3, hi.x, a1);
+                a2 = __builtin_fmaf(w3, hi.y, a2);
+                a3 = __builtin_fmaf(w3, hi.z, a3);
                 lo = hi;
             }
+            *(float4 *)(s_mid + ty * SS_MID_W + q) = make_float4(a0, a1, a2, a3);
         }
-        float *m = s_mid + ty * SS_MID_PITCH + q;
-        m[0] = a0;
-        m[1] = a1;
-        m[2] = a2;
-        m[3] = a3;
     }
     __syncthreads();
 
-    // column pass: 64 columns x 32 rows; a thread makes 4 adjacent columns x 2 stacked rows
-    // from 16-byte LDS reads (the FMAs pair up into v_pk_fma_f32) and stores 16 bytes per row
+    // ---- column pass: 64 columns x 32 rows; a thread makes 4 adjacent columns x 2 stacked rows
+    // from 16-byte LDS reads and stores 16 bytes per row
     const int cq = (tid & 15) * 4, cy = (tid >> 4) * 2;
     float4 acc0 = make_float4(0.f, 0.f, 0.f, 0.f), acc1 = acc0;
-    const float *col = s_mid + cy * SS_MID_PITCH + cq;
+    const float *col = s_mid + cy * SS_MID_W + cq;
     auto fma4 = [](float wk, const float4 v, float4 &a) {
         a.x = __builtin_fmaf(wk, v.x, a.x);
         a.y = __builtin_fmaf(wk, v.y, a.y);
@@ -185,18 +197,18 @@ __global__ __launch_bounds__(256) void scale_step_kernel(const float *__restrict
     if (NT) {
         float4 v[NT + 1];
 #pragma unroll
-        for (int k = 0; k < NT + 1; ++k) v[k] = *(const float4 *)(col + k * SS_MID_PITCH);
+        for (int k = 0; k < NT + 1; ++k) v[k] = *(const float4 *)(col + k * SS_MID_W);
 #pragma unroll
         for (int k = 0; k < NT; ++k) {
-            fma4(taps.w[k], v[k], acc0);
-            fma4(taps.w[k], v[k + 1], acc1);
+            fma4(taps.w[lead + k], v[k], acc0);
+            fma4(taps.w[lead + k], v[k + 1], acc1);
         }
     } else {
         float4 lo = *(const float4 *)col;
         for (int k = 0; k < nt; ++k) {
-            const float4 hi = *(const float4 *)(col + (k + 1) * SS_MID_PITCH);
-            fma4(taps.w[k], lo, acc0);
-            fma4(taps.w[k], hi, acc1);
+            const float4 hi = *(const float4 *)(col + (k + 1) * SS_MID_W);
+            fma4(taps.w[lead + k], lo, acc0);
+            fma4(taps.w[lead + k], hi, acc1);
             lo = hi;
         }
     }
@@ -207,9 +219,10 @@ __global__ __launch_bounds__(256) void scale_step_kernel(const float *__restrict
         const int y = y0 + cy + o;
         if (y >= h || x >= w) break;
         const size_t at = (size_t)y * w + x;
-        const float *c = s_in + (cy + o + r) * SS_IN_W + cq + r;          // the input's centre
-        const float4 d = make_float4(res[o].x - c[0], res[o].y - c[1], res[o].z - c[2],
-                                     res[o].w - c[3]);
+        // the input's centre: r + lead is a multiple of 4, one aligned 16-byte read
+        const float4 c = *(const float4 *)(s_in + (cy + o + r) * SS_IN_W + cq + r + lead);
+        const float4 d = make_float4(res[o].x - c.x, res[o].y - c.y, res[o].z - c.z,
+                                     res[o].w - c.w);
         if (x + 4 <= w && (w & 3) == 0) {
             *(float4 *)(out + at) = res[o];
             if (dog) *(float4 *)(dog + at) = d;
@@ -229,12 +242,13 @@ extern "C" int pano_scale_step(pano_ctx *ctx, const float *src, int h, int w, co
     PANO_ENTER(ctx, "pano_scale_step");
     PANO_REQUIRE(src && dst && taps, "pano_scale_step: null pointer");
     PANO_REQUIRE(h > 0 && w > 0, "pano_scale_step: bad shape %dx%d", h, w);
-    PANO_REQUIRE(ntaps >= 1 && (ntaps & 1) && ntaps <= 2 * SS_RMAX + 1 && ntaps <= SS_NTAP,
+    PANO_REQUIRE(ntaps >= 1 && (ntaps & 1) && ntaps <= 2 * SS_RMAX + 1,
                  "pano_scale_step: aperture %d must be odd and at most %d", ntaps, 2 * SS_RMAX + 1);
     PANO_REQUIRE(src != dst && src != dog, "pano_scale_step: in place is not supported");
     SsTaps t = {};
     t.n = ntaps;
-    for (int k = 0; k < ntaps; ++k) t.w[k] = taps[k];
+    t.lead = (4 - ((ntaps >> 1) & 3)) & 3;
+    for (int k = 0; k < ntaps; ++k) t.w[t.lead + k] = taps[k];
     dim3 grid(ceil_div(w, SS_TW), ceil_div(h, SS_TH));
 #define SS_LAUNCH(N)                                                                          \
     PANO_TIMED(PK_SCALE_STEP, (hipStream_t)stream,                                            \
