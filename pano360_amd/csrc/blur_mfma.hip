@@ -57,15 +57,25 @@ typedef const GLOBAL_AS float4u *gcf32x4;
 #define MB_SCHED 1
 #endif
 #define MB_XT 64                    // output columns per workgroup: two 32-column tiles
-#define MB_PITCH 200                // halfs per band row (64 + 2*64 + 8): 400 B, conflict-free b128
-#define MB_GROUP 4                  // levels per workgroup: one pair of waves each
-#define MB_THREADS (128 * MB_GROUP)
+// halfs per band row: 64 + 2 * 48 + 8.  336 B = 84 dwords, and 84 = 4 * 21 with 21 odd: the 16
+// lanes of a ds_read_b128 group (one band row each) start on 16 different multiples of 4
+// banks - conflict-free (as 400 B = 4 * 25 dwords was)
+#define MB_PITCH 168
+#define MB_PITCH4 200               // groups with a level of more than 97 taps (4 K-steps either side)
+// levels per workgroup, one pair of waves (two tile columns) each.  2: four waves, and with the
+// tables cut to their non-zero blocks two workgroups fit a CU's LDS - they run out of step, one
+// storing and fetching while the other multiplies; 4: eight waves in lockstep, one workgroup per CU
+// (template parameter GROUP of the kernel: 2 whenever no level needs more than 3 K-steps either
+// side - every level count of the reference's defaults - else 4)
+#define MB_THREADS_OF(G) (128 * (G))
+// band chunks (4 columns) per thread: the widest band of the form is 64 + 32 CM columns
+#define MB_ITS_OF(G) ((32 * ((MB_XT + 32 * ((G) == 2 ? 3 : 4)) / 4) + 128 * (G) - 1) / (128 * (G)))
 #define MB_IN_SCALE 2048.0f         // inputs in [0, 1] -> hi/lo normal in f16
 #define MB_TAP_SCALE 256.0f         // taps <= 0.1
 #define MB_MID_SCALE (1.0f / 256.0f)            // Mid back to input scale before its split
 #define MB_OUT_SCALE (1.0f / (2048.0f * 256.0f))
 #define MB_NEED_PAD 8               // slack entries either side of a strip's need flags
-#define MB_NEED_MAX 1024            // 32-row tiles of the tallest patch (rows < 32768)
+#define MB_NEED_MAX 256             // 32-row tiles of the tallest patch (rows <= 8192)
 #define MB_NEED_LEN (MB_NEED_MAX + 2 * MB_NEED_PAD)
 #define MB_WLEN (PANO_MAX_TAPS + 3)
 
@@ -84,10 +94,11 @@ __device__ unsigned long long g_mb_stamps[2][12];
 #define STAMP(k) do { } while (0)
 #endif
 
-struct MbLevels {
+struct MbLevels {                       // entries in WORK order: a group = GROUP consecutive entries
     const float *w[PANO_MAX_LEVELS];    // first tap of each level
     int ntaps[PANO_MAX_LEVELS];
     int tab_off[PANO_MAX_LEVELS];       // byte offset of each level's Toeplitz tables
+    int out[PANO_MAX_LEVELS];           // the level's index in the blurred planes (stitcher.py:218's lvl)
     int n;
 };
 
@@ -99,15 +110,25 @@ __host__ __device__ static inline int mb_c_of(int ntaps) {       // K-steps eith
 // pairs q and q + 2 do: heavy levels (large radius) sit next to light ones
 __host__ __device__ static inline int mb_level_of_pair(int nl, int q) {
     const int order[4][4] = {{0, -1, -1, -1}, {1, 0, -1, -1}, {2, 1, 0, -1}, {3, 2, 0, 1}};
-    return order[nl - 1][q];
+    return q < 4 ? order[nl - 1][q] : -1;
+}
+// Column-pass Toeplitz blocks (d, s), d = -DMAX .. DMAX, s = 0, 1, hold tap[32 d + k - m + r] for
+// k in [16 s, 16 s + 16), m in [0, 32): block (-DMAX, 0) / (DMAX, 1) is all zeros when it lies
+// beyond the radius, and is then neither stored nor read (z0 / z1)
+__host__ __device__ static inline bool mb_block_zero(int d, int s, int r) {
+    return 32 * d + 16 * s - 31 > r || 32 * d + 16 * s + 15 < -r;
 }
 // dynamic LDS: band (hi, lo), need flags of the two tile columns, any flags, column map,
 // then each pair's two Toeplitz tables
-#define MB_FIXED_BYTES (2 * 32 * MB_PITCH * 2 + 2 * MB_NEED_LEN + MB_NEED_LEN + 4 * MB_NEED_LEN + \
-                        (MB_PITCH + 8) * 2)
+__host__ __device__ static inline int mb_pitch_of(int cm) { return cm > 3 ? MB_PITCH4 : MB_PITCH; }
+__host__ __device__ static inline int mb_fixed_bytes(int cm) {
+    return 2 * 32 * mb_pitch_of(cm) * 2 + 2 * MB_NEED_LEN + MB_NEED_LEN + 4 * MB_NEED_LEN +
+           (MB_PITCH4 + 8) * 2;
+}
 __host__ __device__ static inline int mb_table_bytes(int ntaps) {
-    const int c = mb_c_of(ntaps), ks = 2 + 2 * c, nb = 2 * ((c + 1) / 2) + 1;
-    return ks * 2 * 1024 + nb * 4 * 1024;
+    const int c = mb_c_of(ntaps), ks = 2 + 2 * c, dmax = (c + 1) / 2, nb = 2 * dmax + 1, r = ntaps >> 1;
+    const int blocks = 2 * nb - (mb_block_zero(-dmax, 0, r) ? 1 : 0) - (mb_block_zero(dmax, 1, r) ? 1 : 0);
+    return ks * 2 * 1024 + blocks * 2 * 1024;
 }
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for every
@@ -161,17 +182,16 @@ __device__ __forceinline__ void mb_colpass(f32x16 (&acc)[2 * ((C + 1) / 2) + 1],
             m_hi[s][j] = a;
             m_lo[s][j] = b;
         }
+    const int z0 = mb_block_zero(-DMAX, 0, r) ? 1 : 0;              // first block not stored
 #pragma unroll
     for (int k = 0; k < NB; ++k) {
         int d = u - k;
         d = d > DMAX ? d - NB : (d < -DMAX ? d + NB : d);
         if (!((inf >> (d + 2)) & 1u)) continue;                     // tile t - d, wave-uniform
-        const half8 *ty = s_ty + (d + DMAX) * 4 * 64 + lane;        // [d][s][hi, lo][lane]
+        const half8 *ty = s_ty + ((d + DMAX) * 2 - z0) * 2 * 64 + lane;   // [block][hi, lo][lane]
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-            // Toeplitz block (d, s) holds tap[32 d + k - m + r], k in [16 s, 16 s + 16),
-            // m in [0, 32): all zeros when the whole block lies beyond the radius
-            if (32 * d + 16 * s - 31 > r || 32 * d + 16 * s + 15 < -r) continue;   // uniform
+            if (mb_block_zero(d, s, r)) continue;                   // uniform; such a block is not stored
             const half8 t_hi = ty[(s * 2) * 64];
             const half8 t_lo = ty[(s * 2 + 1) * 64];
             acc[k] = __builtin_amdgcn_mfma_f32_32x32x16_f16(t_hi, m_hi[s], acc[k], 0, 0, 0);
@@ -240,7 +260,7 @@ __device__ __forceinline__ void mb_store(f32x16 (&acc)[2 * ((C + 1) / 2) + 1],
 
 // What every wave of the workgroup shares.
 struct MbShared {
-    _Float16 *hi, *lo;              // band, [32][MB_PITCH]
+    _Float16 *hi, *lo;              // band, [32][P]
     uint8_t *need;                  // [2][MB_NEED_LEN]: output tile o of tile column 0 / 1 is wanted
     uint8_t *any;                   // [MB_NEED_LEN]: band t is wanted by some wave
     // [2][MB_NEED_LEN], one word per band t and tile column: bit d + 2 = tile t - d is wanted
@@ -248,11 +268,12 @@ struct MbShared {
     uint16_t *info;
     short *col;                     // band column -> column of V, or -1
     int CM;                         // largest C of the group: the band reaches 16 CM columns out
+    int P;                          // halfs per band row (mb_pitch_of(CM))
     int t_lo, t_hi;                 // bands any wave may want
 };
 
-template <int C>
-__device__ __forceinline__ void mb_body(const pano_patch &p, const int ch, const int level,
+template <int C, int GROUP>
+__device__ __forceinline__ void mb_body(const pano_patch &p, const int ch, const int out_level,
                                         const bool live, const half8 *s_tx,
                                         const half8 *s_ty, const MbShared &sh,
                                         const int16_t *__restrict__ owner_, const int W,
@@ -274,7 +295,7 @@ __device__ __forceinline__ void mb_body(const pano_patch &p, const int ch, const
 
     // this wave's output plane as a buffer: base and size are wave-uniform
     const __amdgpu_buffer_rsrc_t dst = __builtin_amdgcn_make_buffer_rsrc(
-        (void *)(p.blurred + (size_t)(level * 4 + ch) * p.ah * p.apitch), 0, p.ah * p.apitch * 4,
+        (void *)(p.blurred + (size_t)(out_level * 4 + ch) * p.ah * p.apitch), 0, p.ah * p.apitch * 4,
         0x00020000);
     const gci16 owner = (gci16)owner_;
     // need flags of this wave's tile column; a wave without a level wants nothing
@@ -295,15 +316,16 @@ __device__ __forceinline__ void mb_body(const pano_patch &p, const int ch, const
     // and nothing is computed from a loaded value before the commit.
     constexpr unsigned OOB = 0x80000000u;                // beyond any plane (planes < 2 GiB)
     const int CPR = BW >> 2, NCH = 32 * CPR;             // chunks per band row / per band
-    float pf[2][3][4];
-    unsigned pm[2][3];                                   // alpha only: bit j = a real sample
+    constexpr int ITS = MB_ITS_OF(GROUP), THREADS = MB_THREADS_OF(GROUP);
+    float pf[2][ITS][4];
+    unsigned pm[2][ITS];                                   // alpha only: bit j = a real sample
     // what does not change from band to band: a chunk's row, its place in the row and its
     // four columns of V (first column, validity bits, contiguous or not)
-    int g_rr[3];
-    unsigned g_ci[3];                                    // c0 | bits << 16 | contig << 20 | c4 << 24
+    int g_rr[ITS];
+    unsigned g_ci[ITS];                                    // c0 | bits << 16 | contig << 20 | c4 << 24
 #pragma unroll
-    for (int it = 0; it < 3; ++it) {
-        const int grp = tid + MB_THREADS * it;
+    for (int it = 0; it < ITS; ++it) {
+        const int grp = tid + THREADS * it;
         const int rr = grp / CPR, c4 = grp - rr * CPR;
         const shortx4 cm = *(const shortx4 *)(sh.col + (grp < NCH ? 4 * c4 : 0));
         unsigned bits = 0;
@@ -320,7 +342,7 @@ __device__ __forceinline__ void mb_body(const pano_patch &p, const int ch, const
     auto fetch = [&](auto slot_c, const int t) {
         constexpr int S = decltype(slot_c)::value;
 #pragma unroll
-        for (int it = 0; it < 3; ++it) {
+        for (int it = 0; it < ITS; ++it) {
             const int rr = g_rr[it];
             const unsigned ci = g_ci[it];
             const int ry = reflect_101(32 * t + (rr < 0 ? 0 : rr), p.h);
@@ -363,7 +385,7 @@ __device__ __forceinline__ void mb_body(const pano_patch &p, const int ch, const
     auto commit = [&](auto slot_c) {                     // registers -> hi / lo float16 in LDS
         constexpr int S = decltype(slot_c)::value;
 #pragma unroll
-        for (int it = 0; it < 3; ++it) {
+        for (int it = 0; it < ITS; ++it) {
             const int rr = g_rr[it];
             if (rr < 0) continue;
             half4 hi, lo;
@@ -379,7 +401,7 @@ __device__ __forceinline__ void mb_body(const pano_patch &p, const int ch, const
                 hi[j] = a;
                 lo[j] = b;
             }
-            const int at = rr * MB_PITCH + 4 * (int)(g_ci[it] >> 24);
+            const int at = rr * sh.P + 4 * (int)(g_ci[it] >> 24);
             *(half4 *)(sh.hi + at) = hi;
             *(half4 *)(sh.lo + at) = lo;
         }
@@ -432,7 +454,7 @@ __device__ __forceinline__ void mb_body(const pano_patch &p, const int ch, const
             f32x16 mid;
 #pragma unroll
             for (int q = 0; q < 16; ++q) mid[q] = 0.0f;
-            const int o = n * MB_PITCH + 16 * (sh.CM - C) + 32 * tile + 8 * h;
+            const int o = n * sh.P + 16 * (sh.CM - C) + 32 * tile + 8 * h;
             const _Float16 *arow = sh.hi + o, *brow = sh.lo + o;
 #pragma unroll
             for (int s = 0; s < KS; ++s) {
@@ -499,9 +521,12 @@ __global__ __launch_bounds__(128) void mb_tables_kernel(MbLevels L, unsigned cha
         tx[(s * 2) * 64 + l] = hi;
         tx[(s * 2 + 1) * 64 + l] = lo;
     }
+    const int z0 = mb_block_zero(-DMAX, 0, r) ? 1 : 0;
     for (int idx = threadIdx.x; idx < NB * 2 * 64; idx += 128) {
-        const int ds = idx >> 6, l = idx & 63, mm = l & 31, hh = l >> 5;
-        const int di = ds >> 1, s = ds & 1;
+        const int full = idx >> 6, l = idx & 63, mm = l & 31, hh = l >> 5;
+        const int di = full >> 1, s = full & 1;
+        if (mb_block_zero(di - DMAX, s, r)) continue;               // not stored
+        const int ds = full - z0;
         half8 hi, lo;
         for (int j = 0; j < 8; ++j) {
             const int kk = 16 * s + 8 * (j >> 2) + 4 * hh + (j & 3);
@@ -515,7 +540,8 @@ __global__ __launch_bounds__(128) void mb_tables_kernel(MbLevels L, unsigned cha
     }
 }
 
-__global__ __launch_bounds__(MB_THREADS, 1) void blur_mfma_kernel(
+template <int GROUP>
+__global__ __launch_bounds__(MB_THREADS_OF(GROUP), 4 / GROUP) void blur_mfma_kernel(
     const pano_patch *__restrict__ table, MbLevels L, const unsigned char *__restrict__ tables,
     const int16_t *__restrict__ owner, int W, const uint8_t *__restrict__ flags,
     const int2 *__restrict__ items) {
@@ -524,7 +550,7 @@ __global__ __launch_bounds__(MB_THREADS, 1) void blur_mfma_kernel(
     // x = (work item * level groups + level group) * 4 + channel; the items - (record, first
     // tile column of a pair) - are sorted by decreasing length (mb_sort_kernel), so the
     // hardware's in-order dispatch starts the long strips first
-    const int ngroups = (L.n + MB_GROUP - 1) / MB_GROUP;
+    const int ngroups = (L.n + GROUP - 1) / GROUP;
     const int ch = blockIdx.x & 3, rest = blockIdx.x >> 2;
     const int slot = rest / ngroups, grp = rest - slot * ngroups;
     const int2 item = items[slot];
@@ -532,24 +558,18 @@ __global__ __launch_bounds__(MB_THREADS, 1) void blur_mfma_kernel(
     const int pid = item.x & 0xffff, tx0 = item.x >> 16;
     const pano_patch p = table[pid];
     const MbGeom g = mb_geom(p);
-    const int l0 = MB_GROUP * grp, nl = L.n - l0 < MB_GROUP ? L.n - l0 : MB_GROUP;
+    const int l0 = GROUP * grp, nl = L.n - l0 < GROUP ? L.n - l0 : GROUP;
     const int q = __builtin_amdgcn_readfirstlane(wv >> 1);
     const int lv = mb_level_of_pair(nl, q);
     const bool live = lv >= 0;
     const int level = l0 + (live ? lv : 0);
     const int ntaps = L.ntaps[level], c = mb_c_of(ntaps);
 
+    // the group's levels: its reach CM (largest C), and where each pair's tables start
     MbShared sh;
-    sh.hi = (_Float16 *)smem;
-    sh.lo = sh.hi + 32 * MB_PITCH;
-    sh.need = (uint8_t *)(sh.lo + 32 * MB_PITCH);
-    sh.any = sh.need + 2 * MB_NEED_LEN;
-    sh.info = (uint16_t *)(sh.any + MB_NEED_LEN);
-    sh.col = (short *)(sh.info + 2 * MB_NEED_LEN);
-    int off = MB_FIXED_BYTES, my_tx = 0, my_ty = 0;
     sh.CM = 1;
-    int dmax_of[MB_GROUP];
-    for (int k = 0; k < MB_GROUP; ++k) {
+    int dmax_of[GROUP], rel = 0, my_tx = 0, my_ty = 0;
+    for (int k = 0; k < GROUP; ++k) {
         const int lk = mb_level_of_pair(nl, k);
         dmax_of[k] = -1;
         if (lk < 0) continue;
@@ -557,11 +577,20 @@ __global__ __launch_bounds__(MB_THREADS, 1) void blur_mfma_kernel(
         sh.CM = ck > sh.CM ? ck : sh.CM;
         dmax_of[k] = (ck + 1) / 2;
         if (k == q) {
-            my_tx = off;
-            my_ty = off + (2 + 2 * ck) * 2 * 1024;
+            my_tx = rel;
+            my_ty = rel + (2 + 2 * ck) * 2 * 1024;
         }
-        off += mb_table_bytes(L.ntaps[l0 + lk]);
+        rel += mb_table_bytes(L.ntaps[l0 + lk]);
     }
+    sh.P = mb_pitch_of(sh.CM);
+    sh.hi = (_Float16 *)smem;
+    sh.lo = sh.hi + 32 * sh.P;
+    sh.need = (uint8_t *)(sh.lo + 32 * sh.P);
+    sh.any = sh.need + 2 * MB_NEED_LEN;
+    sh.info = (uint16_t *)(sh.any + MB_NEED_LEN);
+    sh.col = (short *)(sh.info + 2 * MB_NEED_LEN);
+    my_tx += mb_fixed_bytes(sh.CM);
+    my_ty += mb_fixed_bytes(sh.CM);
     const int dmaxm = (sh.CM + 1) / 2;
     sh.t_lo = g.O0 - dmaxm;
     sh.t_hi = g.O1 + dmaxm;
@@ -574,7 +603,7 @@ __global__ __launch_bounds__(MB_THREADS, 1) void blur_mfma_kernel(
         for (int i = tid & 127; i < n16; i += 128) to[i] = from[i];
     }
     const int X0 = g.gx0 + 32 * tx0, BW = MB_XT + 32 * sh.CM;
-    for (int bc = tid; bc < MB_PITCH + 8; bc += MB_THREADS) {
+    for (int bc = tid; bc < MB_PITCH4 + 8; bc += MB_THREADS_OF(GROUP)) {
         const int vc = reflect_101(X0 - 16 * sh.CM + bc, p.w) - p.vx0;
         sh.col[bc] = bc < BW && (unsigned)vc < (unsigned)p.vw ? (short)vc : (short)-1;
     }
@@ -590,16 +619,16 @@ __global__ __launch_bounds__(MB_THREADS, 1) void blur_mfma_kernel(
     }
     __syncthreads();
     // any[i]: band t_lo + i is within reach (its own DMAX) of a wanted tile of some pair
-    for (int i = tid; i <= sh.t_hi - sh.t_lo; i += MB_THREADS) {
+    for (int i = tid; i <= sh.t_hi - sh.t_lo; i += MB_THREADS_OF(GROUP)) {
         const int o = sh.t_lo + i - g.O0 + MB_NEED_PAD;         // index of tile t into need[]
         bool v = false;
-        for (int k = 0; k < MB_GROUP; ++k)
+        for (int k = 0; k < GROUP; ++k)
             for (int d = -dmax_of[k]; d <= dmax_of[k]; ++d)
                 v |= (sh.need[o - d] | sh.need[MB_NEED_LEN + o - d]) != 0;
         sh.any[i] = v ? 1 : 0;
     }
     __syncthreads();
-    for (int i = tid; i < 2 * (sh.t_hi - sh.t_lo + 1); i += MB_THREADS) {
+    for (int i = tid; i < 2 * (sh.t_hi - sh.t_lo + 1); i += MB_THREADS_OF(GROUP)) {
         const int col = i & 1, k = i >> 1, t = sh.t_lo + k;
         const int o = t - g.O0 + MB_NEED_PAD;                   // index of tile t into need[]
         unsigned v = 0;
@@ -610,15 +639,12 @@ __global__ __launch_bounds__(MB_THREADS, 1) void blur_mfma_kernel(
     }
     __syncthreads();
     const half8 *s_tx = (const half8 *)(smem + my_tx), *s_ty = (const half8 *)(smem + my_ty);
-#ifdef MB_ONLY
-    mb_body<MB_ONLY>(p, ch, level, live, s_tx, s_ty, sh, owner, W, ntaps >> 1, tx0);
-    return;
-#endif
+    const int out_level = L.out[level];
     switch (c) {                                         // wave-uniform
-        case 1: mb_body<1>(p, ch, level, live, s_tx, s_ty, sh, owner, W, ntaps >> 1, tx0); break;
-        case 2: mb_body<2>(p, ch, level, live, s_tx, s_ty, sh, owner, W, ntaps >> 1, tx0); break;
-        case 3: mb_body<3>(p, ch, level, live, s_tx, s_ty, sh, owner, W, ntaps >> 1, tx0); break;
-        default: mb_body<4>(p, ch, level, live, s_tx, s_ty, sh, owner, W, ntaps >> 1, tx0); break;
+        case 1: mb_body<1, GROUP>(p, ch, out_level, live, s_tx, s_ty, sh, owner, W, ntaps >> 1, tx0); break;
+        case 2: mb_body<2, GROUP>(p, ch, out_level, live, s_tx, s_ty, sh, owner, W, ntaps >> 1, tx0); break;
+        case 3: mb_body<3, GROUP>(p, ch, out_level, live, s_tx, s_ty, sh, owner, W, ntaps >> 1, tx0); break;
+        default: mb_body<4, GROUP>(p, ch, out_level, live, s_tx, s_ty, sh, owner, W, ntaps >> 1, tx0); break;
     }
 }
 
@@ -881,7 +907,9 @@ int pano_prepare_blur_mfma(pano_ctx *ctx, const pano_patch *table, int n, int ma
 
 // 116 KiB of Toeplitz tables per workgroup (once per device; pano_ctx_create)
 int pano_blur_mfma_opt_in(void) {
-    PANO_HIP(hipFuncSetAttribute((const void *)blur_mfma_kernel,
+    PANO_HIP(hipFuncSetAttribute((const void *)blur_mfma_kernel<2>,
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    PANO_HIP(hipFuncSetAttribute((const void *)blur_mfma_kernel<4>,
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     return PANO_OK;
 }
@@ -890,13 +918,42 @@ int pano_launch_blur_mfma(pano_ctx *ctx, const pano_patch *table, int n, int max
                           const int16_t *owner, int W, const float *host_taps, const int *ntaps,
                           int n_blur, const uint8_t *interior, uint8_t *tile_flags) {
     const hipStream_t stream = ctx->stream;
+    // Levels per workgroup.  Four (eight waves in lockstep, one workgroup per CU) shares one
+    // staged band between four levels; two (four waves, two workgroups per CU running out of
+    // step) stages every band twice as often.  Measured (profiles/r02/notes.md): four levels -
+    // the reference's default - 0.87 ms as one group of four against 1.00 ms as two groups of
+    // two (config 3); five levels 10.9 ms as 4 + 1 against 9.5 ms as 2 + 2 + 1 (config 5).  So:
+    // two per workgroup when the count leaves a group of four mostly idle, and only while every
+    // level fits 3 K-steps either side (the narrow band pitch; apertures up to 97 taps).
+    int group = (n_blur <= 2 || n_blur == 5 || n_blur == 6) ? 2 : 4;
+    for (int k = 0; k < n_blur; ++k)
+        if (mb_c_of(ntaps[k]) > 3) group = 4;
+    // Work order of the levels: a workgroup takes `group` consecutive entries.  With two per
+    // workgroup the heaviest level goes with the lightest, the second heaviest with the second
+    // lightest, ...: the groups' tables then have about the same size, and two workgroups fit
+    // the LDS of a CU.  (Apertures grow with the level: stitcher.py:218.)
+    int ord[PANO_MAX_LEVELS];
+    if (group == 2) {
+        int by_size[PANO_MAX_LEVELS];
+        for (int k = 0; k < n_blur; ++k) by_size[k] = k;
+        for (int a = 1; a < n_blur; ++a)                      // insertion sort, largest aperture first
+            for (int b = a; b > 0 && ntaps[by_size[b]] > ntaps[by_size[b - 1]]; --b) {
+                const int tmp = by_size[b];
+                by_size[b] = by_size[b - 1];
+                by_size[b - 1] = tmp;
+            }
+        for (int i = 0, lo = 0, hi = n_blur - 1; i < n_blur; ++i)
+            ord[i] = (i & 1) ? by_size[hi--] : by_size[lo++];
+    } else {
+        for (int k = 0; k < n_blur; ++k) ord[k] = k;
+    }
     MbLevels L = {};
     L.n = n_blur;
     int rmax = 0, total = 0;
-    for (int k = 0; k < n_blur; ++k) {
-        rmax = ntaps[k] / 2 > rmax ? ntaps[k] / 2 : rmax;
-        L.tab_off[k] = total;
-        total += mb_table_bytes(ntaps[k]);
+    for (int k = 0; k < n_blur; ++k) rmax = ntaps[k] / 2 > rmax ? ntaps[k] / 2 : rmax;
+    for (int i = 0; i < n_blur; ++i) {
+        L.tab_off[i] = total;
+        total += mb_table_bytes(ntaps[ord[i]]);
     }
     // device copy of the taps and the Toeplitz operand tables of this tap set: kept by the
     // context, keyed on the tap values, built on first use in stream order
@@ -904,11 +961,15 @@ int pano_launch_blur_mfma(pano_ctx *ctx, const pano_patch *table, int n, int max
     bool fresh = false;
     if (int rc = pano_ctx_tap_set(ctx, host_taps, ntaps, n_blur, (size_t)total, &set, &fresh))
         return rc;
-    size_t off = 0;
+    size_t first[PANO_MAX_LEVELS], off = 0;
     for (int k = 0; k < n_blur; ++k) {
-        L.w[k] = set->taps + off + PANO_TAP_LEAD + ((rmax - ntaps[k] / 2) & 3);
-        L.ntaps[k] = ntaps[k];
+        first[k] = off + PANO_TAP_LEAD + ((rmax - ntaps[k] / 2) & 3);
         off += (size_t)ntaps[k] + PANO_TAP_PAD;
+    }
+    for (int i = 0; i < n_blur; ++i) {
+        L.w[i] = set->taps + first[ord[i]];
+        L.ntaps[i] = ntaps[ord[i]];
+        L.out[i] = ord[i];
     }
     unsigned char *tables = set->tables;
     if (fresh) {
@@ -924,22 +985,30 @@ int pano_launch_blur_mfma(pano_ctx *ctx, const pano_patch *table, int n, int max
     const uint8_t *flags = interior ? tile_flags : nullptr;
     const int cap = n * ceil_div(ntx_max, 2);
     const int2 *sorted = ctx->item_buf + ctx->item_cap;
-    // dynamic LDS: the largest level group's tables
-    const int ngroups = ceil_div(n_blur, MB_GROUP);
+    // dynamic LDS: the largest level group's band, flags and tables
+    const int ngroups = ceil_div(n_blur, group);
     int lds = 0;
     for (int gidx = 0; gidx < ngroups; ++gidx) {
-        int bytes = MB_FIXED_BYTES;
-        for (int k = MB_GROUP * gidx; k < n_blur && k < MB_GROUP * (gidx + 1); ++k)
-            bytes += mb_table_bytes(ntaps[k]);
+        int bytes = 0, cm = 1;
+        for (int i = group * gidx; i < n_blur && i < group * (gidx + 1); ++i) {
+            bytes += mb_table_bytes(L.ntaps[i]);
+            cm = mb_c_of(L.ntaps[i]) > cm ? mb_c_of(L.ntaps[i]) : cm;
+        }
+        bytes += mb_fixed_bytes(cm);
         lds = bytes > lds ? bytes : lds;
     }
     PANO_REQUIRE(lds <= 160 * 1024, "pano_multiband_blur: %d bytes of LDS tables", lds);
     PANO_REQUIRE((long long)cap * 4 * ngroups < (1ll << 31), "pano_multiband_blur: %d work items",
                  cap);
     dim3 grid((unsigned)cap * 4 * ngroups, 1, 1);
-    PANO_TIMED(PK_BLUR_MFMA, stream,
-               hipLaunchKernelGGL(blur_mfma_kernel, grid, dim3(MB_THREADS), lds, stream, table, L,
-                                  tables, owner, W, flags, sorted));
+    if (group == 2)
+        PANO_TIMED(PK_BLUR_MFMA, stream,
+                   hipLaunchKernelGGL(blur_mfma_kernel<2>, grid, dim3(MB_THREADS_OF(2)), lds, stream,
+                                      table, L, tables, owner, W, flags, sorted));
+    else
+        PANO_TIMED(PK_BLUR_MFMA, stream,
+                   hipLaunchKernelGGL(blur_mfma_kernel<4>, grid, dim3(MB_THREADS_OF(4)), lds, stream,
+                                      table, L, tables, owner, W, flags, sorted));
     PANO_LAUNCH_CHECK("blur_mfma_kernel");
     return PANO_OK;
 }
