@@ -239,17 +239,17 @@ __device__ __forceinline__ void mb_store(f32x16 (&acc)[2 * ((C + 1) / 2) + 1],
                 for (int q = 0; q < 16; ++q)
                     __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[k][q]), plane, base,
                                                           ((q & 3) + 8 * (q >> 2)) * rowstep, 0);
-            } else if ((unsigned)ax < (unsigned)p.aw) {
+            } else {
+                // a tile on the edge of A: the same sixteen stores, a pixel outside A gets an
+                // offset beyond the plane and the hardware drops it (no branches, no masks)
+                const bool col_in = (unsigned)ax < (unsigned)p.aw;
 #pragma unroll
                 for (int q = 0; q < 16; ++q) {
                     const int dy = (q & 3) + 8 * (q >> 2);
-                    // the whole offset in the VGPR here: the range check looks at it alone,
-                    // and above A it is negative before the row is added
-                    if ((unsigned)(row0 + dy) < (unsigned)p.ah)
-                        __builtin_amdgcn_raw_buffer_store_b32(
-                            __float_as_uint(acc[k][q] * MB_OUT_SCALE), plane,
-                            base + (unsigned)(dy * rowstep), 0, 0);
-                    __builtin_amdgcn_sched_barrier(0);   // one address / value pair live at a time
+                    const bool in = col_in && (unsigned)(row0 + dy) < (unsigned)p.ah;
+                    __builtin_amdgcn_raw_buffer_store_b32(
+                        __float_as_uint(acc[k][q] * MB_OUT_SCALE), plane,
+                        in ? base + (unsigned)(dy * rowstep) : 0x80000000u, 0, 0);
                 }
             }
         }

@@ -10,7 +10,7 @@ rots, intrs = synth.make_cameras(cfg["n"], cfg["width"], cfg["height"], sweep_de
 shapes = [(cfg["height"], cfg["width"])] * cfg["n"]
 eng = engine.Engine("cuda:0")
 frames = [eng.upload_frames([synth.make_frame(i, cfg["width"], cfg["height"], "A")])[0] for i in range(cfg["n"])]
-lib = C.CDLL(os.path.join(os.path.dirname(engine.__file__), "libpano360_hip.so"))
+lib = eng.lib
 for it in range(3):
     plan = engine.Plan(shapes, rots, intrs, True, 10 ** 9)
     eng.stitch(frames, plan, "multiband", int(os.environ.get("LEVELS", "5")))
