@@ -429,6 +429,11 @@ __device__ __forceinline__ void mb_body(const pano_patch &p, const int ch, const
     // the sequence of wanted bands t, t1, t2, ...: band t is committed from slot S while t1
     // is in flight in the other slot and t2 is fetched into S
     int t = next_wanted(sh.t_lo - 1), t1 = next_wanted(t);
+    // Nothing before the first wanted band has touched an accumulator: the flush starts there.
+    // (Starting at my_lo, the first flush - one step AFTER the first band - would clear the slots
+    // of the never-computed tiles above, and slot (t - 1 - DMAX) mod NB is also tile t + DMAX's,
+    // which band t has just given its first, outermost contribution.)
+    if (t > done_t) done_t = done_end = t < my_hi + 1 ? t : my_hi + 1;
     if (t <= sh.t_hi) fetch(std::integral_constant<int, 0>{}, t);
     if (t1 <= sh.t_hi) fetch(std::integral_constant<int, 1>{}, t1);
     unsigned inf = t <= sh.t_hi ? info_at(t) : 0u;       // flags of band t
@@ -558,6 +563,10 @@ __global__ __launch_bounds__(MB_THREADS_OF(GROUP), 4 / GROUP) void blur_mfma_ker
     const int pid = item.x & 0xffff, tx0 = item.x >> 16;
     const pano_patch p = table[pid];
     const MbGeom g = mb_geom(p);
+    // a vertical segment of the item (mb_sort_kernel): tile rows [o_begin, o_end) of the record
+    const int n_seg = item.y >> 16, seg = (item.y >> 12) & 15, nty_all = g.O1 - g.O0 + 1;
+    const int o_begin = n_seg > 1 ? nty_all * seg / n_seg : 0;
+    const int o_end = n_seg > 1 ? nty_all * (seg + 1) / n_seg : nty_all;
     const int l0 = GROUP * grp, nl = L.n - l0 < GROUP ? L.n - l0 : GROUP;
     const int q = __builtin_amdgcn_readfirstlane(wv >> 1);
     const int lv = mb_level_of_pair(nl, q);
@@ -612,7 +621,7 @@ __global__ __launch_bounds__(MB_THREADS_OF(GROUP), 4 / GROUP) void blur_mfma_ker
         const int txg = ((X0 - g.gx0) >> 5) + wv;
         for (int i = lane; i < nty + 2 * MB_NEED_PAD; i += 64) {
             const int o = i - MB_NEED_PAD;
-            bool v = txg < g.ntx && o >= 0 && o < nty;
+            bool v = txg < g.ntx && o >= o_begin && o < o_end;
             if (v && flags) v = flags[p.tiles_off + o * g.ntx + txg] != 0;
             sh.need[wv * MB_NEED_LEN + i] = v ? 1 : 0;
         }
@@ -770,16 +779,35 @@ __global__ __launch_bounds__(256) void mb_items_kernel(const pano_patch *__restr
 
 // Counting sort of the items by decreasing length (one workgroup); slots past the last item
 // get record -1.  Resets the counter for the next launch.
+// Few items - one GPU's column strip of a panorama, a small scene - leave most CUs idle while
+// every workgroup marches its whole column: each item is then cut into S vertical segments
+// (S chosen so that about `target_wgs` workgroups exist, at most 8; the sorted list has
+// `scap` >= cap + target_wgs / wgs_per_item slots, which n * S never exceeds).  A segment's
+// entry is (item.x, length | segment << 12 | S << 16); the kernel keeps the need flags of
+// its rows only and pays DMAX bands of lead-in.
+#define MB_SEG_MAX 8
+#define MB_SEG_TARGET (3 * 256)          // three workgroups per CU
+#define MB_SEG_SLOTS (MB_SEG_TARGET / 4) // four workgroups (channels) per item at least
 __global__ __launch_bounds__(256) void mb_sort_kernel(const int2 *__restrict__ items,
-                                                      int *__restrict__ counter, int cap,
+                                                      int *__restrict__ counter, int cap, int scap,
+                                                      int wgs_per_item, int target_wgs,
                                                       int2 *__restrict__ sorted) {
     __shared__ int s_hist[MB_SORT_BINS];
     const int tid = threadIdx.x;
     const int n = min(*counter, cap);
+    int S = n > 0 ? (target_wgs + n * wgs_per_item - 1) / (n * wgs_per_item) : 1;
+    S = max(1, min(min(S, MB_SEG_MAX), n > 0 ? scap / n : 1));
+    const int total = n * S;
+    auto entry = [&](const int i) {
+        const int2 it = items[i / S];
+        const int seg = i - (i / S) * S;
+        const int len = S == 1 ? it.y : (it.y + S - 1) / S + 4;
+        return make_int2(it.x, min(len, MB_SORT_BINS - 1) | seg << 12 | (S == 1 ? 0 : S) << 16);
+    };
     for (int i = tid; i < MB_SORT_BINS; i += 256) s_hist[i] = 0;
     __syncthreads();
-    for (int i = tid; i < n; i += 256)
-        atomicAdd(&s_hist[MB_SORT_BINS - 1 - min(items[i].y, MB_SORT_BINS - 1)], 1);   // long first
+    for (int i = tid; i < total; i += 256)
+        atomicAdd(&s_hist[MB_SORT_BINS - 1 - (entry(i).y & 0xfff)], 1);                 // long first
     __syncthreads();
     // exclusive prefix over the bins: eight bins per thread, then a scan of the 256 sums
     __shared__ int s_part[256];
@@ -805,11 +833,11 @@ __global__ __launch_bounds__(256) void mb_sort_kernel(const int2 *__restrict__ i
         run += mine[j];
     }
     __syncthreads();
-    for (int i = tid; i < n; i += 256) {
-        const int2 it = items[i];
-        sorted[atomicAdd(&s_hist[MB_SORT_BINS - 1 - min(it.y, MB_SORT_BINS - 1)], 1)] = it;
+    for (int i = tid; i < total; i += 256) {
+        const int2 e = entry(i);
+        sorted[atomicAdd(&s_hist[MB_SORT_BINS - 1 - (e.y & 0xfff)], 1)] = e;
     }
-    for (int i = n + tid; i < cap; i += 256) sorted[i] = make_int2(-1, 0);
+    for (int i = total + tid; i < scap; i += 256) sorted[i] = make_int2(-1, 0);
     __syncthreads();
     if (tid == 0) *counter = 0;
 }
@@ -888,7 +916,8 @@ int pano_prepare_blur_mfma(pano_ctx *ctx, const pano_patch *table, int n, int ma
             ctx->item_buf = nullptr;
         }
         ctx->item_cap = cap * 2;
-        PANO_HIP(hipMalloc((void **)&ctx->item_buf, (size_t)ctx->item_cap * 2 * sizeof(int2)));
+        PANO_HIP(hipMalloc((void **)&ctx->item_buf,
+                           ((size_t)ctx->item_cap * 2 + MB_SEG_SLOTS) * sizeof(int2)));
     }
     if (!ctx->item_counter) {
         PANO_HIP(hipMalloc((void **)&ctx->item_counter, sizeof(int)));
@@ -897,8 +926,11 @@ int pano_prepare_blur_mfma(pano_ctx *ctx, const pano_patch *table, int n, int ma
     hipLaunchKernelGGL(mb_items_kernel, dim3(n), dim3(256), 0, stream, table, flags, ctx->item_buf,
                        ctx->item_counter, cap);
     PANO_LAUNCH_CHECK("mb_items_kernel");
+    // 4 channels (x level groups) workgroups per item
     hipLaunchKernelGGL(mb_sort_kernel, dim3(1), dim3(256), 0, stream, ctx->item_buf,
-                       ctx->item_counter, cap, ctx->item_buf + ctx->item_cap);
+                       ctx->item_counter, cap, cap + MB_SEG_SLOTS, 4,
+                       ctx->opt[PANO_OPT_BLUR_SEGMENTS] ? MB_SEG_TARGET : 0,
+                       ctx->item_buf + ctx->item_cap);
     PANO_LAUNCH_CHECK("mb_sort_kernel");
     ctx->prepared_table = table;
     ctx->prepared_n = n;
@@ -983,7 +1015,7 @@ int pano_launch_blur_mfma(pano_ctx *ctx, const pano_patch *table, int n, int max
             return rc;
     ctx->prepared_table = nullptr;
     const uint8_t *flags = interior ? tile_flags : nullptr;
-    const int cap = n * ceil_div(ntx_max, 2);
+    const int cap = n * ceil_div(ntx_max, 2) + MB_SEG_SLOTS;      // slots of the sorted list
     const int2 *sorted = ctx->item_buf + ctx->item_cap;
     // dynamic LDS: the largest level group's band, flags and tables
     const int ngroups = ceil_div(n_blur, group);

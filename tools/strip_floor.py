@@ -46,12 +46,13 @@ for world in worlds:
             step()
         torch.cuda.synchronize()
         ms = (time.perf_counter() - t0) / 20 * 1e3
-        kern = sum(v[0] for v in eng.kernel_times().values()) / 20
+        times = eng.kernel_times()
+        kern = sum(v[0] for v in times.values()) / 20
         eng.timing(False)
         if ms > worst[0]:
-            worst = (ms, rank, kern, len(frames))
+            worst = (ms, rank, kern, len(frames), {k: round(v[0] / 20, 3) for k, v in times.items()})
     print(f"world {world}: slowest of ranks sampled = rank {worst[1]}: {worst[0]:.3f} ms per stitch "
-          f"(timed kernels {worst[2]:.3f} ms, {worst[3]} frames resident)")
+          f"(timed kernels {worst[2]:.3f} ms, {worst[3]} frames resident) {worst[4]}")
 t0 = time.perf_counter()
 for _ in range(50):
     engine.Plan(shapes, rots, intrs, True, 10 ** 9)
