@@ -780,23 +780,59 @@ __global__ __launch_bounds__(256) void mb_items_kernel(const pano_patch *__restr
 // Counting sort of the items by decreasing length (one workgroup); slots past the last item
 // get record -1.  Resets the counter for the next launch.
 // Few items - one GPU's column strip of a panorama, a small scene - leave most CUs idle while
-// every workgroup marches its whole column: each item is then cut into S vertical segments
-// (S chosen so that about `target_wgs` workgroups exist, at most 8; the sorted list has
-// `scap` >= cap + target_wgs / wgs_per_item slots, which n * S never exceeds).  A segment's
-// entry is (item.x, length | segment << 12 | S << 16); the kernel keeps the need flags of
-// its rows only and pays DMAX bands of lead-in.
+// every workgroup marches its whole column: each item is then cut into S vertical segments.
+// S minimises a two-term model of the launch, in bands: the longest workgroup,
+// ceil(Lmax / S) + lead, against the work per workgroup slot, (sum of lengths + n S lead)
+// wgs_per_item / slots, where `lead` = the 2 DMAX bands a segment steps through outside its
+// rows plus the copy of the operand tables into LDS (MB_SEG_LEAD bands in all, an estimate).
+// S > 1 only when the model gains 15 %; at most MB_SEG_MAX; the sorted list has
+// `scap` >= cap + MB_SEG_SLOTS slots, which n S never exceeds.  A segment's entry is
+// (item.x, length | segment << 12 | S << 16); the kernel keeps the need flags of its rows only.
 #define MB_SEG_MAX 8
-#define MB_SEG_TARGET (3 * 256)          // three workgroups per CU
-#define MB_SEG_SLOTS (MB_SEG_TARGET / 4) // four workgroups (channels) per item at least
+#define MB_SEG_LEAD 8
+#define MB_SEG_SLOTS 192
 __global__ __launch_bounds__(256) void mb_sort_kernel(const int2 *__restrict__ items,
                                                       int *__restrict__ counter, int cap, int scap,
-                                                      int wgs_per_item, int target_wgs,
+                                                      int wgs_per_item, int slots,
                                                       int2 *__restrict__ sorted) {
     __shared__ int s_hist[MB_SORT_BINS];
+    __shared__ int s_lmax, s_lsum;
     const int tid = threadIdx.x;
     const int n = min(*counter, cap);
-    int S = n > 0 ? (target_wgs + n * wgs_per_item - 1) / (n * wgs_per_item) : 1;
-    S = max(1, min(min(S, MB_SEG_MAX), n > 0 ? scap / n : 1));
+    int S = 1;
+    if (slots > 0 && n > 0) {                                    // uniform
+        if (tid == 0) s_lmax = s_lsum = 0;
+        __syncthreads();
+        int lmax = 0, lsum = 0;
+        for (int i = tid; i < n; i += 256) {
+            const int len = items[i].y;
+            lmax = max(lmax, len);
+            lsum += len;
+        }
+        atomicMax(&s_lmax, lmax);
+        atomicAdd(&s_lsum, lsum);
+        __syncthreads();
+        const int Lmax = s_lmax, Lsum = s_lsum;
+        auto model = [&](const int s) {
+            const int longest = (Lmax + s - 1) / s + MB_SEG_LEAD;
+            const int share = (int)(((long long)Lsum + (long long)n * s * MB_SEG_LEAD) *
+                                    wgs_per_item / slots);
+            return max(longest, share);
+        };
+        const int base = model(1);
+        int best = base;
+        for (int s = 2; s <= MB_SEG_MAX && n * s <= scap && n * s <= n + MB_SEG_SLOTS; ++s) {
+            const int m = model(s);
+            if (m < best && m * 100 <= base * 85) {
+                best = m;
+                S = s;
+            }
+        }
+#ifdef MB_SEG_DEBUG
+        if (tid == 0) printf("mb_sort: n %d Lmax %d Lsum %d model(1) %d -> S %d model %d\n", n, Lmax, Lsum, base, S, best);
+#endif
+        __syncthreads();
+    }
     const int total = n * S;
     auto entry = [&](const int i) {
         const int2 it = items[i / S];
@@ -929,7 +965,7 @@ int pano_prepare_blur_mfma(pano_ctx *ctx, const pano_patch *table, int n, int ma
     // 4 channels (x level groups) workgroups per item
     hipLaunchKernelGGL(mb_sort_kernel, dim3(1), dim3(256), 0, stream, ctx->item_buf,
                        ctx->item_counter, cap, cap + MB_SEG_SLOTS, 4,
-                       ctx->opt[PANO_OPT_BLUR_SEGMENTS] ? MB_SEG_TARGET : 0,
+                       ctx->opt[PANO_OPT_BLUR_SEGMENTS] ? 256 : 0,
                        ctx->item_buf + ctx->item_cap);
     PANO_LAUNCH_CHECK("mb_sort_kernel");
     ctx->prepared_table = table;
