@@ -50,4 +50,4 @@ for _ in range(50):
     step()
 prof.disable()
 torch.cuda.synchronize()
-pstats.Stats(prof).sort_stats("cumulative").print_stats(45)
+pstats.Stats(prof).sort_stats("tottime").print_stats(40)
