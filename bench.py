@@ -204,12 +204,13 @@ def timed_steps(eng, step, steps, warmup, fence, finish=None):
 
 
 class Watchdog:
-    """The secondary measurements run a second round of collectives; if they stall, the
-    headline line (already complete) is printed with the failure noted and the process
-    exits NON-zero - a hang is a failure, whatever was measured before it."""
+    """Everything with a data exchange runs under this timer; if it stalls, rank 0 prints the
+    line it holds - the replicas' figure while the strips headline is being measured, the
+    strips line afterwards - with the failure noted under `key`, and the process exits
+    NON-zero: a hang is a failure, whatever was measured before it."""
 
-    def __init__(self, seconds, rank, line):
-        self.rank, self.line, self.lock = rank, line, threading.Lock()
+    def __init__(self, seconds, rank, line, key="secondary_error"):
+        self.rank, self.line, self.key, self.lock = rank, line, key, threading.Lock()
         self.done = False
         self.timer = threading.Timer(seconds, self.fire)
         self.timer.daemon = True
@@ -218,13 +219,17 @@ class Watchdog:
     def start(self):
         self.timer.start()
 
+    def retarget(self, line, key):
+        with self.lock:
+            self.line, self.key = line, key
+
     def fire(self):
         with self.lock:
             if self.done:
                 return
             self.done = True
-            if self.rank == 0:
-                self.line["secondary_error"] = f"no result within {self.seconds} s"
+            if self.rank == 0 and self.line is not None:
+                self.line[self.key] = f"no result within {self.seconds} s"
                 print(json.dumps(self.line), flush=True)
         os._exit(3)
 
@@ -426,15 +431,10 @@ def main():
     gc.freeze()
 
     strips = args.mode == "strips" and world > 1
-    runner = None
-    if strips:
-        elapsed, plan, patches, times, runner = run_strips(args.exchange)
-    else:
-        elapsed, plan, patches, times = run_sets()
-    sets_per_step = 1 if strips or world == 1 else world
 
-    out = None
-    if rank == 0:
+    def build_line(strips, elapsed, plan, patches, times, frames_rank0=None):
+        """The JSON line of a measurement (rank 0 only)."""
+        sets_per_step = 1 if strips or world == 1 else world
         ms = elapsed / args.steps * 1e3
         P, M = plan.patch_pixels, plan.shape[0] * plan.shape[1]
         S = cfg["n"] * cfg["width"] * cfg["height"]
@@ -508,44 +508,86 @@ def main():
         }
         if world > 1:
             out["scaling_note"] = "unmeasured on multi-GPU hardware by the builder (1-GPU boxes)"
-        if strips:
-            out["frames_on_rank0"] = len(runner.my_frames)
-        if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(cfg)
+        if frames_rank0 is not None:
+            out["frames_on_rank0"] = frames_rank0
+        return out
 
-    if world > 1 and not args.no_secondary and args.workload != "cfg5":
-        # Secondary measurements, same launch: the other exchange, and replicas.
-        dog = Watchdog(args.secondary_timeout, rank, out)
-        dog.start()
-        extra = {}
-        try:
-            if strips:
-                other = "reduce" if args.exchange == "gather" else "gather"
-                runner = None
-                e2, p2, _, _, _ = run_strips(other)
-                extra[f"strips_{other}"] = {"ms_per_step": e2 / args.steps * 1e3,
-                                            "value": p2.patch_pixels / e2 * args.steps / 1e6}
-                e3, p3, _, _ = run_sets()
-                extra["replicas"] = {
-                    "what": f"{world} independent image sets per step, one per GPU, no collective",
-                    "ms_per_step": e3 / args.steps * 1e3,
-                    "value": world * p3.patch_pixels / e3 * args.steps / 1e6, "unit": "MP/s"}
-            else:
+    if not strips:
+        elapsed, plan, patches, times = run_sets()
+        out = build_line(False, elapsed, plan, patches, times) if rank == 0 else None
+        if rank == 0 and not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(cfg)
+        if world > 1 and not args.no_secondary and args.workload != "cfg5":
+            dog = Watchdog(args.secondary_timeout, rank, out)
+            dog.start()
+            extra = {}
+            try:
                 e2, p2, _, _, _ = run_strips(args.exchange)
                 extra[f"strips_{args.exchange}"] = {
                     "ms_per_step": e2 / args.steps * 1e3,
                     "value": p2.patch_pixels / e2 * args.steps / 1e6}
-        except Exception as err:       # noqa: BLE001 - reported; the peers may be stuck in a
-            extra["error"] = repr(err)[:300]        # collective this rank left: end the job
-            if dog.cancel() and rank == 0:
+            except Exception as err:   # noqa: BLE001 - reported; the peers may be stuck in a
+                extra["error"] = repr(err)[:300]    # collective this rank left: end the job
+                if dog.cancel() and rank == 0:
+                    out["secondary"] = extra
+                    print(json.dumps(out), flush=True)
+                os._exit(4)
+            if not dog.cancel():
+                return
+            if rank == 0:
                 out["secondary"] = extra
+        if rank == 0:
+            print(json.dumps(out), flush=True)
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
+    # ---- N > 1, one panorama over all GPUs -----------------------------------------------------
+    # The strips' exchange is the one part of this repo that a 1-GPU box cannot rehearse on
+    # RCCL.  So the replicas (no data-path collective) are measured FIRST, and everything with
+    # an exchange runs under a watchdog: should it hang or fail, rank 0 still prints a valid
+    # line - the replicas' figure, marked as the fallback it is - and the job ends non-zero.
+    fallback = None
+    if not args.no_secondary and args.workload != "cfg5":
+        e3, p3, pa3, t3 = run_sets()
+        if rank == 0:
+            fallback = build_line(False, e3, p3, pa3, t3)
+            fallback["fallback"] = ("the strips run (one panorama over all GPUs, the intended "
+                                    "headline) did not finish; this line is the replicas' figure")
+    dog = Watchdog(args.secondary_timeout, rank, fallback, key="strips_error")
+    dog.start()
+    try:
+        elapsed, plan, patches, times, runner = run_strips(args.exchange)
+    except Exception as err:           # noqa: BLE001 - see above
+        if dog.cancel() and rank == 0 and fallback is not None:
+            fallback["strips_error"] = repr(err)[:300]
+            print(json.dumps(fallback), flush=True)
+        os._exit(4)
+    out = None
+    if rank == 0:
+        out = build_line(True, elapsed, plan, patches, times, len(runner.my_frames))
+        if fallback is not None:
+            out["secondary"] = {"replicas": {
+                "what": f"{world} independent image sets per step, one per GPU, no collective",
+                "ms_per_step": fallback["ms_per_step"], "value": fallback["value"],
+                "unit": "MP/s"}}
+    dog.retarget(out, "secondary_error")    # from here on a timeout still prints the strips line
+    if not args.no_secondary and args.workload != "cfg5":
+        other = "reduce" if args.exchange == "gather" else "gather"
+        runner = None
+        try:
+            e2, p2, _, _, _ = run_strips(other)
+            if rank == 0:
+                out["secondary"][f"strips_{other}"] = {
+                    "ms_per_step": e2 / args.steps * 1e3,
+                    "value": p2.patch_pixels / e2 * args.steps / 1e6}
+        except Exception as err:       # noqa: BLE001
+            if dog.cancel() and rank == 0:
+                out["secondary"]["error"] = repr(err)[:300]
                 print(json.dumps(out), flush=True)
             os._exit(4)
-        if not dog.cancel():
-            return
-        if rank == 0:
-            out["secondary"] = extra
-
+    if not dog.cancel():
+        return
     if rank == 0:
         print(json.dumps(out), flush=True)
     if dist is not None:
