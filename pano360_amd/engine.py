@@ -617,6 +617,7 @@ class Engine:
                                    else f"cuda:{torch.cuda.current_device()}")
         index = self.device.index if self.device.index is not None else torch.cuda.current_device()
         self.device = torch.device("cuda", index)
+        self._device_index = index
         handle = C.c_void_p()
         self._ctx_stream = torch.cuda.current_stream(self.device).cuda_stream
         _lib.check(self.lib.pano_ctx_create(index, C.c_void_p(self._ctx_stream), C.byref(handle)),
@@ -640,6 +641,7 @@ class Engine:
         self.overlap_interior = side_stream == 1
         self.overlap_prepare = side_stream in (1, 2)
         self.warp_need = "auto"     # "auto" | True | False: see multiband_fused
+        self._cam_template = None
 
     def __del__(self):
         ctx, self._ctx = getattr(self, "_ctx", None), None
@@ -653,8 +655,8 @@ class Engine:
     def ctx(self, stream=None):
         """The context handle, targeted at ``stream`` (default: torch's current stream of
         this device - what ``with torch.cuda.stream(s):`` selects in this thread)."""
-        torch = _torch()
-        raw = (stream if stream is not None else torch.cuda.current_stream(self.device)).cuda_stream
+        raw = (stream.cuda_stream if stream is not None
+               else _torch()._C._cuda_getCurrentRawStream(self._device_index))
         if raw != self._ctx_stream:
             _lib.check(self.lib.pano_ctx_set_stream(self._ctx, C.c_void_p(raw)),
                        "pano_ctx_set_stream")
@@ -993,14 +995,24 @@ class Engine:
     def camera_table(self, plan, frames=None):
         """Device array of ``pano_camera``; ``frames`` maps camera index -> frame
         tensor (cameras without a frame get a NULL pointer)."""
-        rec = np.zeros(plan.n, dtype=CAMERA_DTYPE)
-        for i in range(plan.n):
-            sh, sw = plan.shapes[i]
-            hx, hy = self.hat_tables((sh, sw))
-            y0, y1, x0, x1 = plan.rects[i]
-            frame = frames.get(i) if frames else None
-            rec[i] = (plan.projs[i].ravel(), frame.data_ptr() if frame is not None else 0,
-                      hx.data_ptr(), hy.data_ptr(), sh, sw, y0, x0, y1 - y0, x1 - x0)
+        # what depends on the frames and their sizes only (pointers, hat tables) is kept from
+        # stitch to stitch; the projections and rectangles are filled column-wise
+        key = (tuple(plan.shapes),
+               tuple(sorted((i, f.data_ptr()) for i, f in frames.items())) if frames else ())
+        if self._cam_template is None or self._cam_template[0] != key:
+            rec = np.zeros(plan.n, dtype=CAMERA_DTYPE)
+            for i in range(plan.n):
+                sh, sw = plan.shapes[i]
+                hx, hy = self.hat_tables((sh, sw))
+                frame = frames.get(i) if frames else None
+                rec[i] = (np.zeros(9), frame.data_ptr() if frame is not None else 0,
+                          hx.data_ptr(), hy.data_ptr(), sh, sw, 0, 0, 0, 0)
+            self._cam_template = (key, rec)
+        rec = self._cam_template[1].copy()
+        rec["proj"] = np.asarray(plan.projs, np.float64).reshape(plan.n, 9)
+        rects = np.asarray(plan.rects, np.int32)
+        rec["y0"], rec["x0"] = rects[:, 0], rects[:, 2]
+        rec["h"], rec["w"] = rects[:, 1] - rects[:, 0], rects[:, 3] - rects[:, 2]
         return self.to_device(rec)
 
     def ownership_cameras(self, plan, strip=None, out=None, cams=None):
