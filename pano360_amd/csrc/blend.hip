@@ -226,7 +226,19 @@ __global__ __launch_bounds__(256) void ownership_cameras_kernel(
         }
         __syncthreads();
         AlphaBound bnd = {0.0f, -1.0f};
-        if (tid < listed) bnd = alpha_bound(cams + sh.list[tid], s_rng);
+        if (tid < listed) {
+            const pano_camera *cam = cams + sh.list[tid];
+            bnd = alpha_bound(cam, s_rng);
+            // A lower bound beats other cameras on EVERY pixel of the tile only if this camera
+            // is a candidate on every pixel, i.e. the tile lies inside its patch rectangle
+            // (stitcher.py:289-297).  The rectangle of a frame across the +-pi seam stops short
+            // of the mosaic's ends (its range comes from border samples, :107-122), although
+            // the frame itself reaches them: found by the full-size config 5 test, where such
+            // a camera's bound pruned the only candidate of the last 32 columns.
+            if (!(bx0 >= cam->x0 && bx1 <= cam->x0 + cam->w && by0 >= cam->y0 &&
+                  by1 <= cam->y0 + cam->h))
+                bnd.lo = 0.0f;
+        }
         float wmax = bnd.lo;
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) wmax = fmaxf(wmax, __shfl_xor(wmax, off, 64));

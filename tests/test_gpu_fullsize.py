@@ -10,7 +10,12 @@
   (>= 46 079 columns) against the oracle, bit-exact; the config-3 valid mask
   itself against the oracle's inverse maps;
 * config 4: the Gaussian / DoG scale space of one 3840 x 2160 frame against the
-  oracle (all 11 octaves, 7680 x 4320 base).
+  oracle (all 11 octaves, 7680 x 4320 base);
+* config 5 at full size (120 x 8K, closed 360 degree sweep, L = 6, 4948 x 46 079 mosaic),
+  which no CPU oracle finishes: size-independent properties - column strips of a
+  world-8 run equal the same columns of the whole mosaic bit for bit, the valid mask
+  and crop rectangle equal the oracle's (integer work, bit-exact), the seam-straddling
+  frame is split into records.
 """
 import numpy as np
 import pytest
@@ -323,3 +328,50 @@ def test_knn2_kernel_is_exact(eng, case):
             assert rescans > 0                               # the duplicated rows defeated the proof
             assert (idx[:, 0] != idx[:, 1]).all()
     print(f"knn2 {case}: {rescans} of {nq} queries rescanned")
+
+
+def test_cfg5_full_size_properties(eng, oracle):
+    """BASELINE config 5 at full size.  The frames' content cycles through six distinct
+    8K images (the properties do not depend on it; 120 distinct ones would be 12 GB)."""
+    import torch
+    from pano360_amd import dist as pdist
+    from pano360_amd import engine, synth
+    cfg = synth.CONFIGS["cfg5"]
+    n, w, h, levels = cfg["n"], cfg["width"], cfg["height"], cfg["n_levels"]
+    rots, intrs = synth.make_cameras(n, w, h, sweep_deg=cfg.get("sweep_deg"),
+                                     step_deg=cfg.get("step_deg"))
+    shapes = [(h, w)] * n
+    base = eng.upload_frames([synth.make_frame(i, w, h, "A") for i in range(6)])
+    frames = [base[i % 6] for i in range(n)]
+    plan = engine.Plan(shapes, rots, intrs, True, 10 ** 9)
+    assert plan.shape == (4948, 46079)
+    whole, _, valid, patches = eng.stitch(frames, plan, "multiband", levels)
+    assert len(patches) > n          # a frame across the +-pi seam owns pixels at both ends
+    # integer work against the oracle: valid mask from the oracle's inverse-map masks is too
+    # slow at this size, the crop of THIS mask is not
+    mask = valid.cpu().numpy()
+    assert mask.any(axis=0).all()    # closed sweep: every column is covered somewhere
+    assert eng.crop_rect(valid) == oracle.crop_rect(mask)
+    # ownership: the pruned kernel against the exhaustive one on the whole 228 MP map (the
+    # rectangles of the two frames across the +-pi seam stop 32 columns short of the mosaic's
+    # end although the frames reach it: a lower bound of theirs once pruned the only candidate)
+    from pano360_amd import _lib
+    eng.upload_plan(plan)
+    pruned, pruned_valid = (v.clone() for v in eng.ownership_cameras(plan))
+    eng.set_option(_lib.OPT_OWN_PRUNE, 0)
+    try:
+        exact, exact_valid = eng.ownership_cameras(plan)
+    finally:
+        eng.set_option(_lib.OPT_OWN_PRUNE, 1)
+    assert torch.equal(pruned, exact) and torch.equal(pruned_valid, exact_valid)
+    assert int((exact[200:4700, plan.shape[1] - 32:] == -1).sum()) == 0
+    # strips of a world-8 run: first, a middle and the last rank (the last one holds the seam)
+    world = 8
+    for rank in (0, 3, world - 1):
+        st = pdist.ShardedStitcher(eng, shapes, rots, intrs, levels, rank, world, exchange=None)
+        assert len(st.my_frames) < n
+        eng.upload_plan(plan)
+        strip, _, _, _ = eng.multiband_fused([frames[i] for i in st.my_frames], plan, levels,
+                                             frame_ids=st.my_frames, strip=st.strip)
+        c0, c1 = st.strip
+        assert torch.equal(strip[:, c0:c1], whole[:, c0:c1]), rank
