@@ -494,3 +494,30 @@ def test_full_size_multiband_windows_against_oracle(eng, oracle, name):
     print(f"{name} full size, multiband windows: {total} values compared, at most "
           f"{100 * worst:.3f} % of a window differ by one level")
     assert worst < 0.02
+
+
+@pytest.mark.parametrize("world", [8, 5])
+def test_cfg3_full_size_strips_equal_whole(eng, world):
+    """BASELINE config 3 at full size cut into column strips (the N-GPU bench path, every
+    rank emulated on this GPU): each strip equals the same columns of the whole mosaic bit
+    for bit.  At world 8 a strip has 27-39 blur items, which the sort kernel cuts into 3-5
+    vertical segments each - the whole mosaic runs unsegmented."""
+    import torch
+    from pano360_amd import dist as pdist
+    from pano360_amd import engine, synth
+    cfg = synth.CONFIGS["cfg3"]
+    n, w, h, levels = cfg["n"], cfg["width"], cfg["height"], cfg["n_levels"]
+    rots, intrs = synth.make_cameras(n, w, h, sweep_deg=cfg.get("sweep_deg"),
+                                     step_deg=cfg.get("step_deg"))
+    shapes = [(h, w)] * n
+    base = eng.upload_frames([synth.make_frame(i, w, h, "A") for i in range(4)])
+    frames = [base[i % 4] for i in range(n)]
+    plan = engine.Plan(shapes, rots, intrs, True, 10 ** 9)
+    whole, _, _, _ = eng.stitch(frames, plan, "multiband", levels)
+    for rank in range(world):
+        st = pdist.ShardedStitcher(eng, shapes, rots, intrs, levels, rank, world, exchange=None)
+        eng.upload_plan(plan)
+        strip, _, _, _ = eng.multiband_fused([frames[i] for i in st.my_frames], plan, levels,
+                                             frame_ids=st.my_frames, strip=st.strip)
+        c0, c1 = st.strip
+        assert torch.equal(strip[:, c0:c1], whole[:, c0:c1]), (world, rank)
