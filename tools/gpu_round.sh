@@ -37,4 +37,11 @@ if [ "$MODE" = full ]; then
   cd "$HERE"
   f=$(find "$OUT/prof_cfg3" -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cut -c1-160 "$f"
   find "$OUT/prof_cfg3" -name "*kernel_trace.csv" -size +20M -delete
+  for wl in cfg4 cfg5; do
+    cd /tmp
+    timeout -k 10 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$HERE/$OUT/prof_$wl" -- python3 "$HERE/bench.py" --workload $wl --steps 3 --warmup 1 --no-cpu-baseline > "$HERE/$OUT/rocprof_$wl.log" 2>&1
+    cd "$HERE"
+    f=$(find "$OUT/prof_$wl" -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -4 "$f" | cut -c1-160
+    find "$OUT/prof_$wl" -name "*kernel_trace.csv" -delete
+  done
 fi
