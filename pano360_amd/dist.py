@@ -209,6 +209,9 @@ class ShardedStitcher:
         self.strip = (self.bounds[rank], self.bounds[rank + 1])
         # windows reach one radius past the strip for A's owners and one more for V
         self.my_frames = frames_for_strip(plan.rects, self.strip, 2 * radius)
+        # mosaic columns whose sin / cos this rank's kernels read: the strip, the reach of the
+        # interior test around it (ownership) and one radius more (windows V), generously
+        self.table_cols = (self.strip[0] - 4 * radius - 64, self.strip[1] + 4 * radius + 64)
         # exchange=None: geometry only (emulation of the ranks on one device)
         self.exchange = (StripExchange(plan.shape, self.bounds, rank, world, eng.device,
                                        exchange, group, depth) if exchange else None)
@@ -217,7 +220,8 @@ class ShardedStitcher:
         """frames[j] = device tensor of camera my_frames[j].  Returns (plan, the previous
         step's mosaic on rank 0 / None, this rank's patches)."""
         ex = self.exchange
-        plan = _eng.Plan(self.shapes, self.rots, self.intrs, True, self.max_resolution)
+        plan = _eng.Plan(self.shapes, self.rots, self.intrs, True, self.max_resolution,
+                         table_cols=self.table_cols)
         self.eng.upload_plan(plan)
         ex.recycle()
         _, _, _, patches = self.eng.multiband_fused(
@@ -244,7 +248,7 @@ def emulate_on_one_device(eng, imgs, rots, intrs, n_levels, world, max_resolutio
         st = ShardedStitcher(eng, shapes, rots, intrs, n_levels, rank, world, max_resolution,
                              exchange=None)
         frames = eng.upload_frames([imgs[i] for i in st.my_frames])
-        plan = _eng.Plan(shapes, rots, intrs, True, max_resolution)
+        plan = _eng.Plan(shapes, rots, intrs, True, max_resolution, table_cols=st.table_cols)
         eng.upload_plan(plan)
         mosaic, _, _, _ = eng.multiband_fused(frames, plan, n_levels, frame_ids=st.my_frames,
                                               strip=st.strip)

@@ -167,7 +167,10 @@ class Plan:
     """Host-side geometry of one stitch: everything stitcher.py:276-302
     derives before a pixel is touched."""
 
-    def __init__(self, shapes, rots, intrs, padded, max_resolution):
+    def __init__(self, shapes, rots, intrs, padded, max_resolution, table_cols=None):
+        """``table_cols`` = (a, b): the sin / cos tables are evaluated for mosaic columns [a, b) only
+        (one GPU's strip and its halo; the rest is NaN and must not be read) - at eight ranks
+        the two full tables are a fifth of a stitch's host time."""
         self.shapes = [tuple(int(v) for v in s) for s in shapes]
         self.n = len(self.shapes)
         # one LAPACK call per matrix either way: the stacked inverse has the same bits as
@@ -198,7 +201,17 @@ class Plan:
         rows = max(self.shape[0], max(r[1] for r in self.rects))
         theta = np.arange(cols, dtype=np.int64) * self.resolution[0] + self.low[0]
         phi = np.arange(rows, dtype=np.int64) * self.resolution[1] + self.low[1]
-        self.sin_t, self.cos_t, self.tan_p = np.sin(theta), np.cos(theta), np.tan(phi)
+        if table_cols is None:
+            self.sin_t, self.cos_t = np.sin(theta), np.cos(theta)
+        else:
+            a, b = max(int(table_cols[0]), 0), min(int(table_cols[1]), len(theta))
+            self.sin_t = np.full(len(theta), np.nan)
+            self.cos_t = np.full(len(theta), np.nan)
+            # the same NumPy loops on a slice: element for element the full tables' values
+            # (tests/test_host_abi.py checks that on this host)
+            self.sin_t[a:b] = np.sin(theta[a:b])
+            self.cos_t[a:b] = np.cos(theta[a:b])
+        self.tan_p = np.tan(phi)
 
     @property
     def patch_pixels(self):

@@ -370,8 +370,10 @@ def test_cfg5_full_size_properties(eng, oracle):
     for rank in (0, 3, world - 1):
         st = pdist.ShardedStitcher(eng, shapes, rots, intrs, levels, rank, world, exchange=None)
         assert len(st.my_frames) < n
-        eng.upload_plan(plan)
-        strip, _, _, _ = eng.multiband_fused([frames[i] for i in st.my_frames], plan, levels,
+        # the rank's own plan: sin / cos tables on its columns only, NaN elsewhere
+        mine = eng.upload_plan(engine.Plan(shapes, rots, intrs, True, 10 ** 9,
+                                           table_cols=st.table_cols))
+        strip, _, _, _ = eng.multiband_fused([frames[i] for i in st.my_frames], mine, levels,
                                              frame_ids=st.my_frames, strip=st.strip)
         c0, c1 = st.strip
         assert torch.equal(strip[:, c0:c1], whole[:, c0:c1]), rank
@@ -516,8 +518,9 @@ def test_cfg3_full_size_strips_equal_whole(eng, world):
     whole, _, _, _ = eng.stitch(frames, plan, "multiband", levels)
     for rank in range(world):
         st = pdist.ShardedStitcher(eng, shapes, rots, intrs, levels, rank, world, exchange=None)
-        eng.upload_plan(plan)
-        strip, _, _, _ = eng.multiband_fused([frames[i] for i in st.my_frames], plan, levels,
+        mine = eng.upload_plan(engine.Plan(shapes, rots, intrs, True, 10 ** 9,
+                                           table_cols=st.table_cols))
+        strip, _, _, _ = eng.multiband_fused([frames[i] for i in st.my_frames], mine, levels,
                                              frame_ids=st.my_frames, strip=st.strip)
         c0, c1 = st.strip
         assert torch.equal(strip[:, c0:c1], whole[:, c0:c1]), (world, rank)

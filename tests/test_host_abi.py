@@ -335,3 +335,23 @@ def test_top_level_stitcher_is_the_module_itself():
     # native size 600 x 156: the default cap of 1400 does not bind, a cap of 300 does
     assert list(sizes[10 ** 9]) == list(sizes[1400]) == [600, 156]
     assert list(sizes[300]) == [300, 78]
+
+
+def test_plan_tables_on_a_column_range_equal_the_full_tables():
+    """Plan(table_cols=...) (one GPU's strip): the sin / cos entries it evaluates are the full
+    tables' values bit for bit - NumPy's loops do not depend on where a slice starts - and
+    everything else is NaN; ranges, rectangles and tan are untouched."""
+    from pano360_amd import engine, synth
+    imgs_shape = (270, 480)
+    rots, intrs = synth.make_cameras(12, 480, 270, sweep_deg=150.0)
+    shapes = [imgs_shape] * 12
+    full = engine.Plan(shapes, rots, intrs, True, 10 ** 9)
+    W = full.shape[1]
+    for a, b in [(0, W), (1, 7), (3, W - 5), (W // 3 + 1, W // 2), (-50, 40), (W - 33, W + 100)]:
+        part = engine.Plan(shapes, rots, intrs, True, 10 ** 9, table_cols=(a, b))
+        lo, hi = max(a, 0), min(b, len(full.sin_t))
+        assert np.array_equal(part.sin_t[lo:hi], full.sin_t[lo:hi])
+        assert np.array_equal(part.cos_t[lo:hi], full.cos_t[lo:hi])
+        assert np.isnan(part.sin_t[:lo]).all() and np.isnan(part.cos_t[hi:]).all()
+        assert np.array_equal(part.tan_p, full.tan_p)
+        assert part.rects == full.rects and part.shape == full.shape

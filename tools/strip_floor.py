@@ -33,7 +33,7 @@ for world in worlds:
                           dtype=torch.uint8, device=eng.device)
 
         def step():
-            plan = engine.Plan(shapes, rots, intrs, True, 10 ** 9)
+            plan = engine.Plan(shapes, rots, intrs, True, 10 ** 9, table_cols=st.table_cols)
             eng.upload_plan(plan)
             eng.multiband_fused(frames, plan, cfg["n_levels"], frame_ids=st.my_frames,
                                 strip=st.strip, mosaic_out=out)
