@@ -86,13 +86,25 @@ def ranges_from_border(shapes, homs):
     """range_from_border for many frames at once: the 3x3 products stay one BLAS
     call per frame (same numbers as the reference's), the arctangents and the
     min / max run over all frames together."""
-    pts = np.stack([h.dot(border_ring(s)) for s, h in zip(shapes, homs)])      # [n][3][400]
+    low, high = range_arrays_from_border(shapes, homs)
+    return [(low[i], high[i]) for i in range(len(shapes))]
+
+
+def range_arrays_from_border(shapes, homs):
+    """The same as two arrays [n][2] = (theta, phi) minima / maxima.  Frames of one size (the
+    usual case) take one stacked matmul: bit for bit the per-frame ``hom.dot(ring)`` of the
+    reference on every platform tried (tests/test_host_abi.py compares them), at a tenth of
+    the call overhead."""
+    if len(set(shapes)) == 1:
+        pts = np.matmul(np.asarray(homs, np.float64), border_ring(shapes[0]))  # [n][3][400]
+    else:
+        pts = np.stack([h.dot(border_ring(s)) for s, h in zip(shapes, homs)])
     x, y, z = pts[:, 0], pts[:, 1], pts[:, 2]
     theta = np.arctan2(x, z)
     phi = np.arctan2(y, np.sqrt(x ** 2 + z ** 2))
     low = np.stack([theta.min(axis=1), phi.min(axis=1)], axis=1)
     high = np.stack([theta.max(axis=1), phi.max(axis=1)], axis=1)
-    return [(low[i], high[i]) for i in range(len(shapes))]
+    return low, high
 
 
 def range_from_border(shape, hom):
@@ -121,7 +133,7 @@ def range_from_corners(shape, hom):
 def resolution_for(ranges, mid_shape, mid_hom, max_resolution):
     """rad/px of the central frame, capped so the long mosaic side is at most
     ``max_resolution`` pixels (reference stitcher.py:142-157)."""
-    lows, highs = zip(*ranges)
+    lows, highs = ranges if isinstance(ranges, tuple) else zip(*ranges)   # two [n][2] arrays, or pairs
     low, high = np.min(lows, axis=0), np.max(highs, axis=0)
     c_low, c_high = range_from_corners(mid_shape, mid_hom)
     res = (c_high - c_low) / np.array(mid_shape[::-1])
@@ -179,15 +191,14 @@ class Plan:
         self.homs = [np.asarray(r).T.dot(ki) for r, ki in zip(rots, kinv)]
         self.projs = [np.ascontiguousarray(np.asarray(k).dot(r), np.float64)
                       for r, k in zip(rots, intrs)]
-        self.ranges = ranges_from_border(self.shapes, self.homs)
+        lows, highs = range_arrays_from_border(self.shapes, self.homs)
+        self.ranges = [(lows[i], highs[i]) for i in range(self.n)]
         mid = self.n // 2
         self.resolution, (self.low, self.high) = resolution_for(
-            self.ranges, self.shapes[mid], self.homs[mid], max_resolution)
+            (lows, highs), self.shapes[mid], self.homs[mid], max_resolution)
         target = (self.high - self.low) / self.resolution
         self.shape = tuple(int(v) for v in np.round(target))[::-1]      # (H, W)
         limit = target.astype(np.int32)
-        lows = np.stack([r[0] for r in self.ranges])
-        highs = np.stack([r[1] for r in self.ranges])
         first = np.round((lows - self.low) / self.resolution).astype(np.int32)    # [n][x, y]
         last = np.round((highs - self.low) / self.resolution).astype(np.int32)
         if padded:

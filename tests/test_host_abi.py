@@ -355,3 +355,24 @@ def test_plan_tables_on_a_column_range_equal_the_full_tables():
         assert np.isnan(part.sin_t[:lo]).all() and np.isnan(part.cos_t[hi:]).all()
         assert np.array_equal(part.tan_p, full.tan_p)
         assert part.rects == full.rects and part.shape == full.shape
+
+
+def test_stacked_border_product_equals_the_per_frame_dot():
+    """``range_arrays_from_border`` multiplies all frames' homographies with the border ring in
+    one ``np.matmul``; the reference calls ``hom.dot(ring)`` per frame (stitcher.py:119).  Same
+    bits - checked here so that a platform whose BLAS disagrees fails loudly."""
+    from pano360_amd import engine, synth
+    for name in ("cfg2", "cfg3", "cfg5"):
+        cfg = synth.CONFIGS[name]
+        rots, intrs = synth.make_cameras(cfg["n"], cfg["width"], cfg["height"],
+                                         sweep_deg=cfg.get("sweep_deg"),
+                                         step_deg=cfg.get("step_deg"))
+        shapes = [(cfg["height"], cfg["width"])] * cfg["n"]
+        homs = [np.asarray(r).T.dot(np.linalg.inv(k)) for r, k in zip(rots, intrs)]
+        ring = engine.border_ring(shapes[0])
+        assert np.array_equal(np.matmul(np.asarray(homs), ring),
+                              np.stack([h.dot(ring) for h in homs])), name
+        low, high = engine.range_arrays_from_border(shapes, homs)
+        for i, hom in enumerate(homs[:5]):
+            lo, hi = engine.range_from_border(shapes[i], hom)
+            assert np.array_equal(lo, low[i]) and np.array_equal(hi, high[i])
