@@ -157,17 +157,14 @@ int pano_interior_block(void);
  *                         on the vector ALU (one FMA per tap)
  *   PANO_OPT_OWN_PRUNE    1 (default) = pano_ownership_cameras skips cameras that
  *                         rigorous bounds exclude; 0 = evaluate every camera
- *   PANO_OPT_COLS_PIPE    vector-ALU column pass: 1 = software-pipelined trips
- *                         (default 0, measured slower on config 3)
  *   PANO_OPT_BLUR_SEGMENTS  matrix-core blur: 1 (default) = when a launch has too few column
  *                         strips to fill the CUs (one GPU's share of a panorama, small
  *                         scenes) each strip is cut into vertical segments; 0 = never */
 typedef struct pano_ctx pano_ctx;
 #define PANO_OPT_BLUR_KERNEL 0
 #define PANO_OPT_OWN_PRUNE 1
-#define PANO_OPT_COLS_PIPE 2
-#define PANO_OPT_BLUR_SEGMENTS 3
-#define PANO_OPT_COUNT 4
+#define PANO_OPT_BLUR_SEGMENTS 2
+#define PANO_OPT_COUNT 3
 #define PANO_BLUR_MFMA 0
 #define PANO_BLUR_VALU 1
 int pano_ctx_create(int device, void *stream, pano_ctx **out);

@@ -48,7 +48,6 @@ extern "C" int pano_ctx_create(int device, void *stream, pano_ctx **out) {
     ctx->stream = (hipStream_t)stream;
     ctx->opt[PANO_OPT_BLUR_KERNEL] = PANO_BLUR_MFMA;
     ctx->opt[PANO_OPT_OWN_PRUNE] = 1;
-    ctx->opt[PANO_OPT_COLS_PIPE] = 0;
     ctx->opt[PANO_OPT_BLUR_SEGMENTS] = 1;
     *out = ctx;
     return PANO_OK;

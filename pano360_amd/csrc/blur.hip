@@ -195,9 +195,7 @@ __device__ __forceinline__ void col_trip_fma(const ColTrip &t, float4 (&acc)[8])
     }
 }
 
-// PIPE: issue trip t+1's LDS reads and scalar tap loads before trip t's 256
-// FMAs, so the wait in front of a trip's arithmetic finds its operands landed.
-template <bool TABLE, bool PIPE>
+template <bool TABLE>
 __global__ __launch_bounds__(256) void blur_cols_kernel(
     const pano_patch *__restrict__ table, pano_patch single, int nch, int level,
     const float *wz_global, int ntaps, const uint8_t *__restrict__ flags) {
@@ -244,25 +242,11 @@ __global__ __launch_bounds__(256) void blur_cols_kernel(
     const float *base = s_col + (8 * ty) * COL_TW + 4 * tx;
     // 8 input rows per trip: 15 consecutive taps serve all 8 x 8 (row, output)
     // pairs; a trip is 8 LDS reads + 15 scalar loads feeding 256 FMAs.
-    if (PIPE) {
-        ColTrip a, b;
-        col_trip_load(a, base, wz, 0);
-        for (int q = 0;;) {
-            if (q + 8 < steps) col_trip_load(b, base, wz, q + 8);
-            col_trip_fma(a, acc);
-            q += 8;
-            if (q >= steps) break;
-            if (q + 8 < steps) col_trip_load(a, base, wz, q + 8);
-            col_trip_fma(b, acc);
-            q += 8;
-            if (q >= steps) break;
-        }
-    } else {
-        for (int q = 0; q < steps; q += 8) {
-            ColTrip a;
-            col_trip_load(a, base, wz, q);
-            col_trip_fma(a, acc);
-        }
+    // (issuing trip t + 1's reads before trip t's FMAs was measured slower: 1.92 against 1.78 ms)
+    for (int q = 0; q < steps; q += 8) {
+        ColTrip a;
+        col_trip_load(a, base, wz, q);
+        col_trip_fma(a, acc);
     }
     if (x < p.apitch) {
 #pragma unroll
@@ -341,7 +325,6 @@ static int launch_blur(pano_ctx *ctx, const pano_patch *table, const pano_patch 
     Levels L = {};
     const float *col_wz[PANO_MAX_LEVELS];
     if (int rc = make_levels(set->taps, ntaps, n_blur, &L, col_wz, who)) return rc;
-    const bool pipe = ctx->opt[PANO_OPT_COLS_PIPE] != 0;   // measured: 1.78 vs 1.92 ms (cfg3)
     const uint8_t *flags = nullptr;
     if (interior && table) {
         dim3 grid(ceil_div(max_aw, COL_TW), ceil_div(max_ah, COL_TH), n);
@@ -367,15 +350,11 @@ static int launch_blur(pano_ctx *ctx, const pano_patch *table, const pano_patch 
         const int rows = (8 * 15 + COL_STEPS(ntaps[k]) + 15) & ~15;   // staged 16 at a time
         const size_t lds = (size_t)rows * COL_TW * sizeof(float);
         dim3 block(16, 16), grid(ceil_div(max_aw, COL_TW), ceil_div(max_ah, COL_TH), n * nch);
-#define LAUNCH_COLS(T, P)                                                              \
+#define LAUNCH_COLS(T)                                                                 \
     PANO_TIMED(PK_BLUR_COLS, stream,                                                   \
-               hipLaunchKernelGGL((blur_cols_kernel<T, P>), grid, block, lds, stream,  \
-                                  table, single, nch, k, col_wz[k], ntaps[k], flags))
-        if (table) {
-            if (pipe) LAUNCH_COLS(true, true); else LAUNCH_COLS(true, false);
-        } else {
-            if (pipe) LAUNCH_COLS(false, true); else LAUNCH_COLS(false, false);
-        }
+               hipLaunchKernelGGL(blur_cols_kernel<T>, grid, block, lds, stream, table, \
+                                  single, nch, k, col_wz[k], ntaps[k], flags))
+        if (table) LAUNCH_COLS(true); else LAUNCH_COLS(false);
 #undef LAUNCH_COLS
         PANO_LAUNCH_CHECK("blur_cols_kernel");
     }
@@ -384,10 +363,8 @@ static int launch_blur(pano_ctx *ctx, const pano_patch *table, const pano_patch 
 
 // column tiles above 64 KiB need the opt-in (once per device; pano_ctx_create)
 int pano_blur_valu_opt_in(void) {
-    const void *fns[] = {(const void *)blur_cols_kernel<true, true>,
-                         (const void *)blur_cols_kernel<true, false>,
-                         (const void *)blur_cols_kernel<false, true>,
-                         (const void *)blur_cols_kernel<false, false>};
+    const void *fns[] = {(const void *)blur_cols_kernel<true>,
+                         (const void *)blur_cols_kernel<false>};
     for (const void *fn : fns)
         PANO_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     return PANO_OK;

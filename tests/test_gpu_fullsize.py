@@ -524,3 +524,12 @@ def test_cfg3_full_size_strips_equal_whole(eng, world):
                                              frame_ids=st.my_frames, strip=st.strip)
         c0, c1 = st.strip
         assert torch.equal(strip[:, c0:c1], whole[:, c0:c1]), (world, rank)
+        if world == 8 and rank in (0, 4):        # the option: segments off, same bits
+            from pano360_amd import _lib
+            eng.set_option(_lib.OPT_BLUR_SEGMENTS, 0)
+            try:
+                plain, _, _, _ = eng.multiband_fused([frames[i] for i in st.my_frames], mine,
+                                                     levels, frame_ids=st.my_frames, strip=st.strip)
+            finally:
+                eng.set_option(_lib.OPT_BLUR_SEGMENTS, 1)
+            assert torch.equal(plain[:, c0:c1], whole[:, c0:c1]), (world, rank)
