@@ -106,6 +106,37 @@ def test_stage_api_blenders(eng, oracle):
     assert np.array_equal(stitcher.multiband_blend(_bl_patches(g), shape, 1), want1)
 
 
+
+def test_stitch_exact_mode(eng):
+    """``stitcher.EXACT`` (env PANO_EXACT=1): the drop-in ``stitch`` takes the full band sum on
+    every pixel and the float32 vector-ALU blur.  Same bound against the reference's mosaic
+    (one level; a handful of values sit on an integer boundary either way), and the same
+    result as the engine asked for those two things directly."""
+    import bundle_adj
+    from pano360_amd import engine, stitcher
+    g = load_golden("scene_small_noise")
+    imgs, rots, intrs, mr = scene_inputs(g)
+    saved = stitcher.MAX_RESOLUTION, stitcher.EXACT
+    stitcher.MAX_RESOLUTION = mr
+    try:
+        def run():
+            regs = [bundle_adj.Image(im.copy(), r.copy(), k.copy())
+                    for im, r, k in zip(imgs, rots, intrs)]
+            return stitcher.stitch(regs, stitcher.multiband_blend)
+        stitcher.EXACT = False
+        fast = run()
+        stitcher.EXACT = True
+        exact = run()
+    finally:
+        stitcher.MAX_RESOLUTION, stitcher.EXACT = saved
+    ref = g["mb5_mosaic"].astype(int)
+    assert np.abs(exact.astype(int) - ref).max() <= 1 and np.abs(fast.astype(int) - ref).max() <= 1
+    valu = engine.Engine(blur="valu")
+    plan = engine.Plan([im.shape[:2] for im in imgs], rots, intrs, True, mr)
+    direct = valu.stitch(valu.upload_frames(imgs), plan, "multiband", 5, shortcut=False)[0]
+    assert np.array_equal(exact, direct.cpu().numpy())
+
+
 @pytest.mark.parametrize("name", SCENES)
 def test_stitch_entry_point_against_reference_mosaics(eng, name):
     """stitch(regions, blender, crop) exactly as a reference caller writes it."""
