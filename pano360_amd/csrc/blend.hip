@@ -452,9 +452,9 @@ __device__ __forceinline__ uint8_t quant255(float v) { return (uint8_t)(int)(255
 // are exact zeros, and  sum_k (band_k * s_k) / s_k  telescopes to the warped
 // colour itself (|difference| <= 6e-8 measured against the oracle).  Such
 // "interior" pixels need no blur at all; multiband blending only happens within
-// R of a seam or of the border of the covered area.  The test runs on 8 x 8
-// blocks (conservative): a block is interior when all blocks within
-// ceil((R + 7) / 8) of it are uniformly owned by the same patch.
+// R of a seam or of the border of the covered area.  The test runs on IB x IB
+// blocks (IB = PANO_INTERIOR_BLOCK = 4; conservative): a block is interior when all blocks
+// within ceil((R + IB - 1) / IB) of it are uniformly owned by the same patch.
 #define IB PANO_INTERIOR_BLOCK
 
 __global__ __launch_bounds__(256) void block_owner_kernel(const int16_t *__restrict__ owner,

@@ -257,7 +257,7 @@ __global__ __launch_bounds__(256) void blur_cols_kernel(
     }
 }
 
-// One wave per column tile of every record: active = some 8 x 8 block under the
+// One wave per column tile of every record: active = some interior-map block under the
 // tile is not interior.
 __global__ __launch_bounds__(64) void tile_flags_kernel(const pano_patch *__restrict__ table,
                                                         const uint8_t *__restrict__ interior,

@@ -1114,7 +1114,7 @@ class Engine:
         c0, c1 = strip if strip is not None else (0, W)
         taps, ntaps, n_blur, radius = self.blur_tables(n_levels)
         # the owner map is needed one radius past the strip for the windows, and as
-        # far as the 8 x 8-block interior test looks, so that every strip classifies
+        # far as the block-wise interior test looks, so that every strip classifies
         # its pixels exactly as the whole mosaic would
         ib = self.interior_block
         margin = (max(radius, ib * ((radius + 2 * ib - 2) // ib) + ib - 1) if shortcut and n_blur
