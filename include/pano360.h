@@ -493,8 +493,14 @@ int pano_resize_u8(pano_ctx *ctx, const uint8_t *src, int sh, int sw, int c,
  *                       returns them (full-resolution coordinates, octave field
  *                       shifted by first_octave): desc dev float [n][128], values
  *                       0..255.  RootSIFT (features.py:198) is left to the caller.
- * List order is arbitrary (atomics); sort as KeyPointsFilter::removeDuplicatedSorted
- * does before describing. */
+ * List order is arbitrary (atomics); pano_sift_sort_unique puts it into OpenCV's:
+ *   pano_sift_sort_unique  KeyPointsFilter::removeDuplicatedSorted + the first-octave
+ *                       adjustment of detectAndCompute: the n keypoints of pano_sift_orient
+ *                       sorted by x, y, size (descending), angle, response (descending),
+ *                       octave (descending), the first of every (x, y, size, angle) group
+ *                       kept, positions and sizes scaled by 2^first_octave and the octave
+ *                       byte shifted by first_octave -> out (dev, room for n), *n_out (dev).
+ *                       work: dev scratch of pano_sift_sort_work_bytes(n) bytes. */
 int pano_sift_extrema(pano_ctx *ctx, const float *dog, int rows, int cols, int octave,
                       int n_layers, float contrast_thr, float edge_thr, float sigma,
                       pano_sift_keypoint *cands, int *count, int max_cands);
@@ -504,6 +510,9 @@ int pano_sift_orient(pano_ctx *ctx, const float *const *gauss, const int *dims,
 int pano_sift_describe(pano_ctx *ctx, const float *const *gauss, const int *dims,
                        int first_octave, const pano_sift_keypoint *kpts, int n,
                        float *desc);
+size_t pano_sift_sort_work_bytes(int n);
+int pano_sift_sort_unique(pano_ctx *ctx, const pano_sift_keypoint *kpts, int n, int first_octave,
+                          void *work, pano_sift_keypoint *out, int *n_out);
 
 /* The two nearest rows of `train` for every row of `query` (Euclidean), the search behind
  * flann_matching                                                  features.py:222-232
