@@ -2,7 +2,7 @@
 // detectAndCompute, on the device.
 //
 // Reference: features.py:192-201 gets keypoints from OpenCV already in this order; what is
-// restated is OpenCV's (PARITY UNPINNED, oracle/sift_oracle.py): sort by x, y, size
+// restated is OpenCV's (PARITY UNPINNED: OpenCV is not in the reference repo): sort by x, y, size
 // (descending), angle, response (descending), octave (descending); of keypoints that share
 // x, y, size and angle keep the first; then, for firstOctave = -1, halve positions and sizes
 // and shift the octave byte.
