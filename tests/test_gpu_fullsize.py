@@ -533,3 +533,43 @@ def test_cfg3_full_size_strips_equal_whole(eng, world):
             finally:
                 eng.set_option(_lib.OPT_BLUR_SEGMENTS, 1)
             assert torch.equal(plain[:, c0:c1], whole[:, c0:c1]), (world, rank)
+
+
+@pytest.mark.parametrize("n", [0, 1, 2, 1000, 70001])
+def test_sift_sort_unique_on_device_equals_the_host_lexsort(eng, n):
+    """``pano_sift_sort_unique`` against ``features.sift_sort_unique`` (np.lexsort + duplicate
+    removal, KeyPointsFilter::removeDuplicatedSorted) followed by the first-octave adjustment:
+    random keypoints with many ties in every key, exact duplicates, -0.0 and negative values."""
+    import ctypes as C
+    import torch
+    from pano360_amd import _lib, features
+    from pano360_amd.engine import _ptr
+    rng = np.random.default_rng(n)
+    kp = np.zeros(n, features.KP_DTYPE)
+    if n:
+        kp["x"] = rng.integers(0, 40, n).astype(np.float32) * 0.5 - 3.0
+        kp["y"] = rng.integers(0, 30, n).astype(np.float32) * 0.25
+        kp["size"] = rng.choice(np.float32([1.5, 2.0, 3.25, 7.0]), n)
+        kp["angle"] = rng.choice(np.float32([0.0, -0.0, 10.5, 359.9, 180.0]), n)
+        kp["response"] = rng.choice(np.float32([0.01, 0.02, 0.5]), n)
+        kp["octave"] = rng.choice(np.int32([0, 1, 255, (2 << 8) | 3, (1 << 16) | (1 << 8) | 2]), n)
+        kp["r"], kp["c"] = rng.integers(0, 99, n), rng.integers(0, 99, n)
+    want = features.sift_sort_unique(kp.copy())
+    want["octave"] = (want["octave"] & ~255) | ((want["octave"] + features.SIFT_FIRST_OCTAVE) & 255)
+    for key in ("x", "y", "size"):
+        want[key] = want[key] * np.float32(0.5)
+    dev = torch.from_numpy(kp.view(np.uint8).reshape(-1).copy()).to(eng.device)
+    out = torch.empty(max(n, 1) * 32, dtype=torch.uint8, device=eng.device)
+    work = torch.empty(int(eng.lib.pano_sift_sort_work_bytes(n)), dtype=torch.uint8,
+                       device=eng.device)
+    count = torch.full((1,), -1, dtype=torch.int32, device=eng.device)
+    _lib.check(eng.lib.pano_sift_sort_unique(eng.ctx(), _ptr(dev), n, features.SIFT_FIRST_OCTAVE,
+                                             _ptr(work), _ptr(out), _ptr(count)),
+               "pano_sift_sort_unique")
+    m = int(count.item())
+    assert m == len(want)
+    got = out[:m * 32].cpu().numpy().view(features.KP_DTYPE)
+    # ties in every sort key and in (x, y, size, angle) leave r / c of a kept keypoint to the
+    # stable order of equal records; all six sort keys must agree exactly
+    for key in ("x", "y", "size", "angle", "response", "octave"):
+        assert np.array_equal(got[key], want[key]), key
