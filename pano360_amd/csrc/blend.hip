@@ -604,24 +604,33 @@ __global__ __launch_bounds__(256) void multiband_compose_kernel(
         // interior pixel: the mosaic is the owner's warped colour, clipped, quantised
         if (ia.part == 2) return;                // compose_interior_kernel wrote it
         const int own = owner[(size_t)y * W + x];
-        const pano_camera *cam = ia.cams + own;
-        const float *__restrict__ gl = ia.lut + (size_t)own * 256;
-        const int sw = cam->sw, sh = cam->sh;
-        float fx, fy;
-        map_pixel(cam->proj, ia.sin_t[x], ia.cos_t[x], ia.tan_p[y], sw, sh, fx, fy);
-        const Taps tp = make_taps(fx, fy, sw, sh);
-        const TapBytes tb = load_taps(cam->frame, sw, tp);
-        const size_t g = ((size_t)y * W + x) * 3;
+        auto shade = [&](const pano_camera *cam, const float *__restrict__ gl) {
+            const int sw = cam->sw, sh = cam->sh;
+            float fx, fy;
+            map_pixel(cam->proj, ia.sin_t[x], ia.cos_t[x], ia.tan_p[y], sw, sh, fx, fy);
+            const Taps tp = make_taps(fx, fy, sw, sh);
+            const TapBytes tb = load_taps(cam->frame, sw, tp);
+            const size_t g = ((size_t)y * W + x) * 3;
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            float v = PERCAM ? lerp4(gl[tb.v[0][c]], gl[tb.v[1][c]], gl[tb.v[2][c]],
-                                     gl[tb.v[3][c]], tp)
-                             : lerp4(s_lut[tb.v[0][c]], s_lut[tb.v[1][c]], s_lut[tb.v[2][c]],
-                                     s_lut[tb.v[3][c]], tp);
-            v = v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v);
-            if (mosaic_f32) mosaic_f32[g + c] = v;
-            mosaic[g + c] = (uint8_t)(int)(255.0f * v);
-        }
+            for (int c = 0; c < 3; ++c) {
+                float v = PERCAM ? lerp4(gl[tb.v[0][c]], gl[tb.v[1][c]], gl[tb.v[2][c]],
+                                         gl[tb.v[3][c]], tp)
+                                 : lerp4(s_lut[tb.v[0][c]], s_lut[tb.v[1][c]], s_lut[tb.v[2][c]],
+                                         s_lut[tb.v[3][c]], tp);
+                v = v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v);
+                if (mosaic_f32) mosaic_f32[g + c] = v;
+                mosaic[g + c] = (uint8_t)(int)(255.0f * v);
+            }
+        };
+        // The interior pixels of a wave nearly always have one owner (a pixel is interior
+        // when everything within the blur radius of it has): then the camera record is read
+        // through a wave-uniform address - scalar loads of its 9 doubles instead of 64 lanes
+        // fetching the same 120 bytes each.
+        const int own_u = __builtin_amdgcn_readfirstlane(own);
+        if (__ballot(own != own_u) == 0)
+            shade(ia.cams + own_u, ia.lut + (size_t)own_u * 256);
+        else
+            shade(ia.cams + own, ia.lut + (size_t)own * 256);
         return;
     }
     float layer[L][3], wsum[L];
