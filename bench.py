@@ -190,24 +190,33 @@ def cpu_baseline(cfg):
                        f"oracle/pano_oracle.c (gcc -O2 -fopenmp), {os.cpu_count()} host CPUs")
 
 
+INSTRUMENTED = {}      # seconds of the instrumented pass of the last timed_steps call
+
+
 def timed_steps(eng, step, steps, warmup, fence, finish=None):
-    """W untimed steps, then exactly K steps between two fences.  Returns
-    (seconds on this rank, last step's result, per-kernel HIP-event times).  ``finish``
-    completes what the steps left in flight (the exchange of the last stitch) inside the
-    timed region."""
+    """W untimed steps, then exactly K steps between two fences: the headline time, with no
+    instrumentation inside.  Then the same K steps once more with HIP events around every
+    launch (`pano_timing_enable`): the per-kernel times of the roofline.  (The events cost
+    2 % of a config-3 stitch, 7 % of config 2 and 29 % of config 4's seventy launches per
+    frame - too much to charge the headline with.)  Returns (headline seconds on this rank,
+    last step's result, per-kernel times); ``finish`` completes what the steps left in
+    flight (the exchange of the last stitch) inside each timed region."""
+    def region(events):
+        fence()
+        eng.timing(events)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            result = step()
+        if finish:
+            finish()
+        fence()
+        return time.perf_counter() - t0, result
     for _ in range(warmup):
         step()
     if finish:
         finish()
-    fence()
-    eng.timing(True)
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        result = step()
-    if finish:
-        finish()
-    fence()
-    elapsed = time.perf_counter() - t0
+    elapsed, result = region(False)
+    INSTRUMENTED["seconds"], result = region(True)
     times = eng.kernel_times()
     eng.timing(False)
     return elapsed, result, times
@@ -310,6 +319,10 @@ def cfg4_line(args, world, elapsed, pyr, n_kp, times, size):
                    "dog_megapixels": d_px / 1e6,
                    "parallelism": "independent frames, one per GPU (replicas only)"},
         "kernel_ms_per_step": {k: v[0] / args.steps for k, v in sorted(times.items())},
+        "instrumented_ms_per_step": INSTRUMENTED.get("seconds", 0.0) / args.steps * 1e3,
+        "instrumentation": "ms_per_step / value: K steps with no instrumentation inside; "
+                           "kernel_ms_per_step and roofline: the same K steps once more with HIP "
+                           "events around every launch (instrumented_ms_per_step), rank 0",
     }
     if n_kp is not None:
         out["config"]["keypoints_per_frame"] = n_kp
@@ -506,6 +519,10 @@ def main():
                                               / (HBM_PEAK_GBPS * world),
             },
             "kernel_ms_per_step": {k: v[0] / args.steps for k, v in sorted(times.items())},
+            "instrumented_ms_per_step": INSTRUMENTED.get("seconds", 0.0) / args.steps * 1e3,
+            "instrumentation": "ms_per_step / value: K steps with no instrumentation inside; "
+                               "kernel_ms_per_step and roofline: the same K steps once more with HIP "
+                               "events around every launch (instrumented_ms_per_step), rank 0",
             "hbm_traffic": (lambda b: None if b is None else {
                 "GB_per_step_per_gpu": b / 1e9,
                 "GBps_per_gpu": b / (ms * 1e-3) / 1e9,
