@@ -461,18 +461,31 @@ __device__ __forceinline__ void mb_body(const pano_patch &p, const int ch, const
             for (int q = 0; q < 16; ++q) mid[q] = 0.0f;
             const int o = n * sh.P + 16 * (sh.CM - C) + 32 * tile + 8 * h;
             const _Float16 *arow = sh.hi + o, *brow = sh.lo + o;
+            // The operands of k-step s + 1 are read from LDS before the products of k-step s
+            // are issued: with the reads right in front of each product (what the compiler
+            // emits for the plain loop) every product waited out an LDS latency.
+            half8 a_hi[2], a_lo[2], b_hi[2], b_lo[2];
+            auto operands = [&](const int s, const int buf) {
+                a_hi[buf] = *(const half8 *)(arow + 16 * s);
+                b_hi[buf] = s_tx[(s * 2) * 64 + lane];
+                b_lo[buf] = s_tx[(s * 2 + 1) * 64 + lane];
+                if (!alpha) a_lo[buf] = *(const half8 *)(brow + 16 * s);
+            };
+            operands(0, 0);
 #pragma unroll
             for (int s = 0; s < KS; ++s) {
-                const half8 a_hi = *(const half8 *)(arow + 16 * s);
-                const half8 b_hi = s_tx[(s * 2) * 64 + lane];
-                const half8 b_lo = s_tx[(s * 2 + 1) * 64 + lane];
-                mid = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, b_hi, mid, 0, 0, 0);
-                mid = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, b_lo, mid, 0, 0, 0);
-                if (!alpha) {                            // the sharp mask is exact in float16
-                    const half8 a_lo = *(const half8 *)(brow + 16 * s);
-                    mid = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo, b_hi, mid, 0, 0, 0);
-                }
-                if (MB_SCHED && (s & 1)) __builtin_amdgcn_sched_barrier(0);
+                const int cur = s & 1;
+                if (s + 1 < KS) operands(s + 1, cur ^ 1);
+                mid = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi[cur], b_hi[cur], mid, 0, 0, 0);
+                mid = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi[cur], b_lo[cur], mid, 0, 0, 0);
+                if (!alpha)                              // the sharp mask is exact in float16
+                    mid = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo[cur], b_hi[cur], mid, 0, 0, 0);
+#if MB_SCHED
+                // next k-step's reads (DS read, mask 0x100) first, then this one's products
+                // (MFMA, mask 0x008)
+                __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+#endif
             }
             STAMP(6);                                    // row pass
             int u = t % NB;
