@@ -289,18 +289,20 @@ def test_two_contexts_on_two_streams_concurrently(eng):
     assert (results["c"].int() - whole.int()).abs().max().item() <= 1
 
 
-@pytest.mark.parametrize("case", ["random", "unit", "d64", "ties", "tiny"])
+@pytest.mark.parametrize("case", ["random", "unit", "d64", "d100", "one", "ties", "tiny"])
 def test_knn2_kernel_is_exact(eng, case):
     """``pano_knn2`` (the search behind flann_matching, features.py:222-232) against a
     float64 brute force: the same two nearest rows for every query, distances to float32
     rounding.  Cases: random 128-d rows, unit-norm RootSIFT-like rows with planted near
-    duplicates, 64-d rows (four k-steps), duplicated train rows (exact ties: the proof of the
+    duplicates, 64-d rows (four k-steps), 100-d and 5-d rows (a ragged last k-step), one query against 70 000 rows,
+    duplicated train rows (exact ties: the proof of the
     ranking fails and those queries are rescanned), and two / three train rows."""
     import torch
     from pano360_amd import features
-    rng = np.random.default_rng({"random": 1, "unit": 2, "d64": 3, "ties": 4, "tiny": 5}[case])
-    d = 64 if case == "d64" else 128
-    nq, nt = (700, 1333) if case != "tiny" else (45, 3)
+    rng = np.random.default_rng({"random": 1, "unit": 2, "d64": 3, "ties": 4, "tiny": 5, "d100": 6,
+                                 "one": 7}[case])
+    d = {"d64": 64, "d100": 100, "one": 5}.get(case, 128)      # 100, 5: not a multiple of a k-step
+    nq, nt = {"tiny": (45, 3), "one": (1, 70000)}.get(case, (700, 1333))
     a = rng.random((nq, d)).astype(np.float32)
     b = rng.random((nt, d)).astype(np.float32)
     if case == "unit":
