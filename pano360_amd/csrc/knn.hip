@@ -212,7 +212,8 @@ __global__ __launch_bounds__(256) void knn2_refine_kernel(
     const float *__restrict__ query, const float *__restrict__ train, int nq, int nt, int d,
     float scale, const float *__restrict__ norm_q, const unsigned *__restrict__ maxnorm,
     const int32_t *__restrict__ cand_idx, const float *__restrict__ cand_val,
-    int32_t *__restrict__ idx, float *__restrict__ dist, int *__restrict__ rescans) {
+    int32_t *__restrict__ idx, float *__restrict__ dist, int *__restrict__ n_rescan,
+    int32_t *__restrict__ rescan_list, unsigned long long *__restrict__ rescan_keys) {
     const int qi = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (qi >= nq) return;
     const float *q = query + (size_t)qi * d;
@@ -238,11 +239,16 @@ __global__ __launch_bounds__(256) void knn2_refine_kernel(
     const float s2 = scale * scale;
     const float eps = KNN_EPS * (norm_q[qi] + __uint_as_float(*maxnorm));
     const float floor_d2 = (cand_val[KNN_KEEP * qi + KNN_KEEP - 1] + norm_q[qi] - eps) / s2;
-    if (nt > KNN_KEEP && !(second <= floor_d2)) {                     // not proven: exact rescan
-        best = second = __builtin_inff();
-        bi = si = 0x7fffffff;
-        for (int j = 0; j < nt; ++j) take(knn_exact(q, train + (size_t)j * d, d, lane), j);
-        if (lane == 0 && rescans) atomicAdd(rescans, 1);
+    if (nt > KNN_KEEP && !(second <= floor_d2)) {
+        // not proven: the query goes on the list of exact rescans (knn2_rescan_kernel: one wave
+        // scanning all rows of `train` alone took 90 ms for 100 000 rows and set the duration of
+        // the whole search)
+        if (lane == 0) {
+            const int slot = atomicAdd(n_rescan, 1);
+            rescan_list[slot] = qi;
+            rescan_keys[2 * slot] = rescan_keys[2 * slot + 1] = ~0ull;
+        }
+        return;
     }
     if (lane == 0) {
         idx[2 * qi] = bi;
@@ -252,10 +258,63 @@ __global__ __launch_bounds__(256) void knn2_refine_kernel(
     }
 }
 
+// Exact rescans, all of them at once: block (x, y) scans rows x, x + gridDim.x, ... x 4 waves
+// of `train` for the listed queries y, y + gridDim.y, ...; a wave keeps its two best as keys
+// (distance bits << 32 | row: float order = integer order for non-negative floats, equal
+// distances: lower row first) and merges them into the query's pair with two atomic minima -
+// the smaller of (new, old first) stays first, the larger is offered to the second place, so
+// every value but the final minimum is offered to the second place exactly once.
+#define KNN_RESCAN_X 256
+__global__ __launch_bounds__(256) void knn2_rescan_kernel(
+    const float *__restrict__ query, const float *__restrict__ train, int nt, int d,
+    const int *__restrict__ n_rescan, const int32_t *__restrict__ rescan_list,
+    unsigned long long *__restrict__ rescan_keys) {
+    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int count = *n_rescan;
+    for (int r = blockIdx.y; r < count; r += gridDim.y) {
+        const float *q = query + (size_t)rescan_list[r] * d;
+        unsigned long long b1 = ~0ull, b2 = ~0ull;
+        for (int j = wave; j < nt; j += 4 * KNN_RESCAN_X) {
+            const float v = knn_exact(q, train + (size_t)j * d, d, lane);
+            const unsigned long long key = (unsigned long long)__float_as_uint(v) << 32 | (unsigned)j;
+            if (key < b1) {
+                b2 = b1;
+                b1 = key;
+            } else if (key < b2) {
+                b2 = key;
+            }
+        }
+        if (lane == 0) {
+            unsigned long long *g = rescan_keys + 2 * r;
+            for (const unsigned long long key : {b1, b2}) {
+                if (key == ~0ull) continue;
+                const unsigned long long prev = atomicMin(&g[0], key);
+                atomicMin(&g[1], prev > key ? prev : key);
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void knn2_finish_kernel(
+    const int *__restrict__ n_rescan, const int32_t *__restrict__ rescan_list,
+    const unsigned long long *__restrict__ rescan_keys, int32_t *__restrict__ idx,
+    float *__restrict__ dist) {
+    const int count = *n_rescan;
+    for (int r = blockIdx.x * 256 + threadIdx.x; r < count; r += gridDim.x * 256) {
+        const int qi = rescan_list[r];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const unsigned long long key = rescan_keys[2 * r + k];
+            idx[2 * qi + k] = (int32_t)(unsigned)key;
+            dist[2 * qi + k] = sqrtf(__uint_as_float((unsigned)(key >> 32)));
+        }
+    }
+}
+
 static size_t knn_align(size_t v) { return (v + 255) & ~(size_t)255; }
 
 struct KnnWork {
-    size_t pq, pt, nq, ntn, cidx, cval, scal, total;
+    size_t pq, pt, nq, ntn, cidx, cval, scal, rlist, rkeys, total;
 };
 
 static KnnWork knn_layout(int nq, int nt, int d) {
@@ -277,6 +336,10 @@ static KnnWork knn_layout(int nq, int nt, int d) {
     off += knn_align((size_t)nq * KNN_KEEP * sizeof(float));
     w.scal = off;
     off += 256;
+    w.rlist = off;
+    off += knn_align((size_t)nq * sizeof(int32_t));
+    w.rkeys = off;
+    off += knn_align((size_t)nq * 2 * sizeof(unsigned long long));
     w.total = off;
     return w;
 }
@@ -304,9 +367,11 @@ extern "C" int pano_knn2(pano_ctx *ctx, const float *query, int nq, const float 
     int32_t *cidx = (int32_t *)(base + w.cidx);
     float *cval = (float *)(base + w.cval);
     unsigned *maxnorm = (unsigned *)(base + w.scal);
+    int *n_rescan = (int *)(base + w.scal) + 1;          // both inside the 256 zeroed bytes
+    int32_t *rlist = (int32_t *)(base + w.rlist);
+    unsigned long long *rkeys = (unsigned long long *)(base + w.rkeys);
     const int tq = (nq + 31) / 32, tt = (nt + 31) / 32;
     PANO_HIP(hipMemsetAsync(maxnorm, 0, 256, s));
-    if (rescans) PANO_HIP(hipMemsetAsync(rescans, 0, sizeof(int), s));
     hipLaunchKernelGGL(knn_pack_kernel, dim3((unsigned)(((size_t)tq * ks * 64 + 255) / 256)), dim3(256),
                        0, s, query, nq, d, ks, scale, pq);
     hipLaunchKernelGGL(knn_pack_kernel, dim3((unsigned)(((size_t)tt * ks * 64 + 255) / 256)), dim3(256),
@@ -326,7 +391,16 @@ extern "C" int pano_knn2(pano_ctx *ctx, const float *query, int nq, const float 
                                       norm_t, nq, nt, cidx, cval));
     PANO_LAUNCH_CHECK("knn2_kernel");
     hipLaunchKernelGGL(knn2_refine_kernel, dim3(ceil_div(nq, 4)), dim3(256), 0, s, query, train, nq, nt,
-                       d, scale, norm_q, maxnorm, cidx, cval, idx, dist, rescans);
+                       d, scale, norm_q, maxnorm, cidx, cval, idx, dist, n_rescan, rlist, rkeys);
     PANO_LAUNCH_CHECK("knn2_refine_kernel");
+    // the unproven queries (their number is on the device: the grid walks the list)
+    hipLaunchKernelGGL(knn2_rescan_kernel, dim3(KNN_RESCAN_X, nq < 64 ? nq : 64), dim3(256), 0, s,
+                       query, train, nt, d, n_rescan, rlist, rkeys);
+    PANO_LAUNCH_CHECK("knn2_rescan_kernel");
+    hipLaunchKernelGGL(knn2_finish_kernel, dim3(ceil_div(nq < 65536 ? nq : 65536, 256)), dim3(256),
+                       0, s, n_rescan, rlist, rkeys, idx, dist);
+    PANO_LAUNCH_CHECK("knn2_finish_kernel");
+    if (rescans)
+        PANO_HIP(hipMemcpyAsync(rescans, n_rescan, sizeof(int), hipMemcpyDeviceToDevice, s));
     return PANO_OK;
 }
