@@ -31,16 +31,25 @@ __global__ __launch_bounds__(256) void crop_heights_kernel(
 #define CROP_CHUNK 64
 #define CROP_MAX_CHUNKS 1024       // mosaic width up to 65536
 
-// nearest index left of j with height < h, or -1
+// nearest index left of j with height < h, or -1.  cmin: minima of 64-column chunks, smin:
+// minima of 64-chunk super-chunks (a row of equal heights - the bottom rows of a closed sweep's
+// mask - made the walk over chunk minima 720 steps long per column)
 __device__ __forceinline__ int smaller_left(const int32_t *row, const int32_t *cmin,
-                                            int j, int h) {
+                                            const int32_t *smin, int j, int h) {
     int idx = j - 1;
     const int cstart = (j / CROP_CHUNK) * CROP_CHUNK;
     while (idx >= cstart && row[idx] >= h) --idx;
     if (idx >= cstart) return idx;
     int c = j / CROP_CHUNK - 1;
-    while (c >= 0 && cmin[c] >= h) --c;
-    if (c < 0) return -1;
+    const int sstart = (c >= 0 ? c / CROP_CHUNK : 0) * CROP_CHUNK;    // first chunk of c's super-chunk
+    while (c >= sstart && cmin[c] >= h) --c;
+    if (c < sstart) {                                       // nothing in this super-chunk
+        int s = sstart / CROP_CHUNK - 1;
+        while (s >= 0 && smin[s] >= h) --s;
+        if (s < 0) return -1;
+        c = s * CROP_CHUNK + CROP_CHUNK - 1;
+        while (cmin[c] >= h) --c;                           // this super-chunk holds a smaller one
+    }
     idx = c * CROP_CHUNK + CROP_CHUNK - 1;
     while (row[idx] >= h) --idx;      // this chunk holds a smaller height
     return idx;
@@ -48,15 +57,26 @@ __device__ __forceinline__ int smaller_left(const int32_t *row, const int32_t *c
 
 // nearest index right of j with height < h, or W
 __device__ __forceinline__ int smaller_right(const int32_t *row, const int32_t *cmin,
-                                             int j, int h, int W, int nchunks) {
+                                             const int32_t *smin, int j, int h, int W, int nchunks) {
     int idx = j + 1;
     int cend = (j / CROP_CHUNK + 1) * CROP_CHUNK;
     if (cend > W) cend = W;
     while (idx < cend && row[idx] >= h) ++idx;
     if (idx < cend) return idx;
     int c = j / CROP_CHUNK + 1;
-    while (c < nchunks && cmin[c] >= h) ++c;
-    if (c >= nchunks) return W;
+    int send = (j / CROP_CHUNK / CROP_CHUNK + 1) * CROP_CHUNK;       // one past the super-chunk's chunks
+    if (send > nchunks) send = nchunks;
+    if (c > send) send = c;
+    while (c < send && cmin[c] >= h) ++c;
+    if (c >= send) {
+        if (send >= nchunks) return W;
+        int s = send / CROP_CHUNK;
+        const int nsuper = (nchunks + CROP_CHUNK - 1) / CROP_CHUNK;
+        while (s < nsuper && smin[s] >= h) ++s;
+        if (s >= nsuper) return W;
+        c = s * CROP_CHUNK;
+        while (cmin[c] >= h) ++c;
+    }
     idx = c * CROP_CHUNK;
     while (row[idx] >= h) ++idx;
     return idx;
@@ -66,8 +86,17 @@ __global__ __launch_bounds__(256) void crop_rows_kernel(
     const int32_t *__restrict__ heights, int H, int W,
     unsigned long long *__restrict__ best) {
     __shared__ int32_t s_cmin[CROP_MAX_CHUNKS];
+    __shared__ int32_t s_smin[CROP_MAX_CHUNKS / CROP_CHUNK];
     __shared__ unsigned long long s_red[4];
-    const int i = blockIdx.x;
+    // Bottom rows first: they hold the tallest columns and settle the best area early; a
+    // candidate of height h is at most h W large, so everything that cannot reach the best
+    // area found so far is skipped - whole rows (h <= i + 1) at the top of the mosaic.  Only
+    // strictly smaller bounds are skipped: an equal area earlier in scan order must still win.
+    // (Every (row, column) evaluated: 79 ms for the 4948 x 46 079 mask of config 5.)
+    const int i = H - 1 - (int)blockIdx.x;
+    unsigned long long floor_area = __hip_atomic_load(best, __ATOMIC_RELAXED,
+                                                      __HIP_MEMORY_SCOPE_AGENT) >> 32;
+    if ((unsigned long long)(i + 1) * (unsigned)W < floor_area) return;
     const int32_t *row = heights + (size_t)i * W;
     const int nchunks = (W + CROP_CHUNK - 1) / CROP_CHUNK;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -81,17 +110,32 @@ __global__ __launch_bounds__(256) void crop_rows_kernel(
         if (lane == 0) s_cmin[c] = v;
     }
     __syncthreads();
+    for (int s = wave; s * CROP_CHUNK < nchunks; s += 4) {
+        const int c = s * CROP_CHUNK + lane;
+        int v = c < nchunks ? s_cmin[c] : 0x7fffffff;
+        for (int off = 32; off > 0; off >>= 1) {
+            int o = __shfl_xor(v, off);
+            v = o < v ? o : v;
+        }
+        if (lane == 0) s_smin[s] = v;
+    }
+    __syncthreads();
 
     unsigned long long key = 0;
     for (int j = threadIdx.x; j < W; j += 256) {
         const int h = row[j];
-        if (h == 0) continue;
-        const int l = smaller_left(row, s_cmin, j, h) + 1;
-        const int r = j == 0 ? 0 : smaller_right(row, s_cmin, j, h, W, nchunks) - 1;
+        // the bound rises while other rows finish: re-read it (an L2 hit) before every search
+        floor_area = __hip_atomic_load(best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 32;
+        if (h == 0 || (unsigned long long)h * (unsigned)W < floor_area) continue;
+        const int l = smaller_left(row, s_cmin, s_smin, j, h) + 1;
+        const int r = j == 0 ? 0 : smaller_right(row, s_cmin, s_smin, j, h, W, nchunks) - 1;
         const unsigned long long area = (unsigned long long)(r - l + 1) * (unsigned)h;
         const unsigned long long pos = (unsigned long long)i * W + j;
         const unsigned long long k = (area << 32) | (0xffffffffull - pos);
-        key = k > key ? k : key;
+        if (k > key) {
+            key = k;
+            if (area > floor_area) atomicMax(best, k);    // published at once: it prunes the others
+        }
     }
     for (int off = 32; off > 0; off >>= 1) {
         unsigned long long o = __shfl_xor(key, off);
