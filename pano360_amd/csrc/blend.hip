@@ -328,9 +328,55 @@ __global__ __launch_bounds__(256) void blend_cameras_kernel(
     __shared__ float s_lut[256];
     if (!PERCAM) s_lut[threadIdx.y * 64 + threadIdx.x] = lut[threadIdx.y * 64 + threadIdx.x];
     const int bx0 = xs0 + blockIdx.x * 64, by0 = blockIdx.y * 4;
-    const int listed = build_camera_list(sh, cams, n, bx0, min(bx0 + 64, xs1), by0,
-                                         min(by0 + 4, H));     // has the barriers s_lut needs
-    const int ncand = listed < 0 ? n : listed;
+    const int bx1 = min(bx0 + 64, xs1), by1 = min(by0 + 4, H);
+    const int listed = build_camera_list(sh, cams, n, bx0, bx1, by0, by1);   // has the barriers s_lut needs
+    int ncand = listed < 0 ? n : listed;
+    const int *list = sh.list;
+    // Cameras masked on the whole block (the interval bound of alpha_bound: behind the camera
+    // or outside the frame everywhere) contribute nothing to either blend and leave the list.
+    // On a closed sweep every pixel lies in the full-width rectangles of the ~20 frames across
+    // the +-pi seam (stitcher.py:107-122 has no wrap handling), nearly all of them masked there:
+    // 228 MP x 40 inverse maps made config 5's linear blend slower than its multiband blend.
+    __shared__ double s_rng[6];
+    __shared__ int s_keep[OWN_LIST];
+    __shared__ int s_kept[4];
+    if (listed > 16) {           // (a dozen cameras, config 3: the bounds cost more than they save)
+        const int lane = threadIdx.x, wave = threadIdx.y;
+        if (wave == 0) {
+            const int xc = min(bx0 + lane, bx1 - 1);
+            double lo_s = sin_t[xc], hi_s = lo_s, lo_c = cos_t[xc], hi_c = lo_c;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                lo_s = fmin(lo_s, __shfl_xor(lo_s, off, 64));
+                hi_s = fmax(hi_s, __shfl_xor(hi_s, off, 64));
+                lo_c = fmin(lo_c, __shfl_xor(lo_c, off, 64));
+                hi_c = fmax(hi_c, __shfl_xor(hi_c, off, 64));
+            }
+            if (lane == 0) {
+                s_rng[0] = lo_s; s_rng[1] = hi_s; s_rng[4] = lo_c; s_rng[5] = hi_c;
+            }
+        } else if (wave == 1 && lane == 0) {
+            double lo_t = tan_p[by0], hi_t = lo_t;
+            for (int yy = by0 + 1; yy < by1; ++yy) {
+                lo_t = fmin(lo_t, tan_p[yy]);
+                hi_t = fmax(hi_t, tan_p[yy]);
+            }
+            s_rng[2] = lo_t; s_rng[3] = hi_t;
+        }
+        __syncthreads();
+        const int tid = wave * 64 + lane;
+        const bool keep = tid < listed && alpha_bound(cams + sh.list[tid], s_rng).hi >= 0.0f;
+        const unsigned long long bal = __ballot(keep);
+        if (lane == 0) s_kept[wave] = __popcll(bal);
+        __syncthreads();
+        int off = 0;
+        for (int w = 0; w < wave; ++w) off += s_kept[w];
+        off += __popcll(bal & ((1ull << lane) - 1ull));
+        if (keep) s_keep[off] = sh.list[tid];                 // index order preserved
+        ncand = s_kept[0] + s_kept[1] + s_kept[2] + s_kept[3];
+        list = s_keep;
+        __syncthreads();
+    }
 
     const int x = bx0 + threadIdx.x, y = by0 + threadIdx.y;
     if (x >= xs1 || y >= H) return;
@@ -338,8 +384,11 @@ __global__ __launch_bounds__(256) void blend_cameras_kernel(
     float acc[3] = {0.0f, 0.0f, 0.0f}, wsum = 0.0f;
     uint8_t last[3] = {0, 0, 0};
     bool any = false;
-    for (int k = 0; k < ncand; ++k) {
-        const int i = listed < 0 ? k : __builtin_amdgcn_readfirstlane(sh.list[k]);
+    // no_blend keeps the LAST unmasked camera (stitcher.py:164-166): walked from the end, the
+    // first unmasked one is the answer
+    for (int kk = 0; kk < ncand; ++kk) {
+        const int k = LINEAR ? kk : ncand - 1 - kk;
+        const int i = listed < 0 ? k : __builtin_amdgcn_readfirstlane(list[k]);
         const pano_camera *cam = cams + i;
         const int px = x - cam->x0, py = y - cam->y0;
         if ((unsigned)px >= (unsigned)cam->w || (unsigned)py >= (unsigned)cam->h) continue;
@@ -365,6 +414,7 @@ __global__ __launch_bounds__(256) void blend_cameras_kernel(
         } else {
 #pragma unroll
             for (int ch = 0; ch < 3; ++ch) last[ch] = (uint8_t)(int)(255.0f * rgb[ch]);   // :166
+            break;
         }
     }
     const size_t g = ((size_t)y * W + x) * 3;
