@@ -10,8 +10,6 @@ The class is importable as ``bundle_adj.Image`` through the top-level
 ``bundle_adj.py`` re-export, so ``ba_<name>.pkl`` caches written by the
 reference CLI (stitcher.py:430-439) unpickle into it unchanged.
 """
-from dataclasses import dataclass, field
-
 import numpy as np
 
 
@@ -19,20 +17,52 @@ def _zero_range():
     return (np.zeros(2), np.zeros(2))
 
 
-@dataclass
+class Deferred:
+    """A pixel array that exists on the device and is copied to the host when first read
+    (``stitch`` leaves the float32 RGBA image of ``_add_weights`` in ``reg.img``,
+    stitcher.py:277-278: 133 MB per 4K frame that most callers never look at)."""
+
+    def __init__(self, make):
+        self.make = make
+
+
 class Image:
     """One registered frame: pixels, rotation R, calibration K, angular range.
 
-    ``img``   uint8 [H, W, 3] on entry to ``stitch`` (channel order opaque).
+    ``img``   uint8 [H, W, 3] on entry to ``stitch`` (channel order opaque); float32 RGBA
+              afterwards, as in the reference - fetched from the device on first access.
     ``rot``   float64 3x3 world->camera rotation.
     ``intr``  float64 3x3 ``[[f,0,cx],[0,f,cy],[0,0,1]]``.
     ``range`` (min, max) spherical angles, filled in by ``stitch``.
     """
 
-    img: np.ndarray
-    rot: np.ndarray
-    intr: np.ndarray
-    range: tuple = field(default_factory=_zero_range)
+    def __init__(self, img, rot, intr, range=None):        # noqa: A002 - the reference's name
+        self.img = img
+        self.rot = rot
+        self.intr = intr
+        self.range = _zero_range() if range is None else range
+
+    @property
+    def img(self):
+        if isinstance(self._img, Deferred):
+            self._img = self._img.make()
+        return self._img
+
+    @img.setter
+    def img(self, value):
+        self._img = value
+
+    # the reference's class pickles its plain attributes: keep that layout in both directions
+    def __getstate__(self):
+        return {"img": self.img, "rot": self.rot, "intr": self.intr, "range": self.range}
+
+    def __setstate__(self, state):
+        for key, value in state.items():
+            setattr(self, key, value)
+
+    def __repr__(self):
+        return (f"Image(img={type(self._img).__name__}, rot={self.rot!r}, intr={self.intr!r}, "
+                f"range={self.range!r})")
 
     def hom(self):
         """Pixel -> ray: ``R^T K^-1`` (reference bundle_adj.py:27-29)."""

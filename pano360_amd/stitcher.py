@@ -22,6 +22,7 @@ import time
 
 import numpy as np
 
+from . import bundle_adj as _ba
 from . import engine as _eng
 from .engine import CylProj, SphProj  # noqa: F401  (re-exported API)
 
@@ -234,7 +235,11 @@ def stitch(regions, blender=no_blend, equalize=False, crop=False):
                                   [r.intr for r in regions])[3]
     for i, (reg, rng, frame) in enumerate(zip(regions, plan.ranges, frames)):
         reg.range = rng
-        reg.img = eng.add_weights(frame, None if luts is None else luts[i]).cpu().numpy()
+        # stitcher.py:277-278 leaves _add_weights' float32 RGBA image in reg.img; our record
+        # type fetches it from the device when it is first read (32 x 133 MB for config 3)
+        rgba = (lambda f=frame, l=None if luts is None else luts[i]:
+                eng.add_weights(f, l).cpu().numpy())
+        reg.img = _ba.Deferred(rgba) if isinstance(reg, _ba.Image) else rgba()
     eng.upload_plan(plan)
 
     kind = _FUSED.get(blender)

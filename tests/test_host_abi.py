@@ -131,6 +131,20 @@ def test_pickled_cameras_use_the_reference_module_path():
     assert b"bundle_adj" in blob and b"pano360_amd" not in blob.split(b"bundle_adj")[0]
     back = pickle.loads(blob)[0]
     assert isinstance(back, top.Image) and np.array_equal(back.intr, cam.intr)
+    # the pickled state is the reference class's plain attribute dictionary (bundle_adj.py:18-25):
+    # a cache written here loads into the reference's Image and the other way round
+    assert cam.__getstate__().keys() == {"img", "rot", "intr", "range"}
+    plain = top.Image.__new__(top.Image)
+    plain.__setstate__({"img": cam.img, "rot": cam.rot, "intr": cam.intr, "range": cam.range})
+    assert np.array_equal(plain.img, cam.img) and np.array_equal(plain.hom(), cam.hom())
+    # pixels left on the device by stitch() arrive when first read, and pickle as arrays
+    from pano360_amd.bundle_adj import Deferred
+    calls = []
+    lazy = top.Image(Deferred(lambda: calls.append(1) or np.ones((2, 2, 4), np.float32)),
+                     np.eye(3), top.intrinsics(10.0))
+    assert not calls
+    assert lazy.img.shape == (2, 2, 4) and lazy.img is lazy.img and calls == [1]
+    assert np.array_equal(pickle.loads(pickle.dumps(lazy)).img, np.ones((2, 2, 4), np.float32))
 
 
 def test_product_fails_loudly_without_gpu():
