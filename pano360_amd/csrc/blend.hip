@@ -638,6 +638,7 @@ __global__ __launch_bounds__(256) void compose_interior_kernel(
     }
 }
 
+#define COMPOSE_MASKS 4            // 256 records through the wave-wide test, more: plain scan
 template <int L, bool PERCAM>
 __global__ __launch_bounds__(256) void multiband_compose_kernel(
     const pano_patch *__restrict__ patches, int n, int H, int W, int xs0, int xs1,
@@ -649,8 +650,30 @@ __global__ __launch_bounds__(256) void multiband_compose_kernel(
         __syncthreads();
     }
     const int x = xs0 + blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
-    if (x >= xs1 || y >= H) return;
-    if (ia.interior && ia.interior[(size_t)(y / IB) * ia.W8 + x / IB]) {
+    const bool inside = x < xs1 && y < H;
+    const bool is_interior = inside && ia.interior && ia.interior[(size_t)(y / IB) * ia.W8 + x / IB];
+    // A wave with a seam pixel first finds, with all its lanes (lane l tests record l), the
+    // records whose rectangle A meets its 64 pixels of row y: the seam pixels then walk the two
+    // or three set bits instead of testing all n records one scalar load at a time.  No
+    // barriers, no LDS (a per-block list built with barriers was slower than the plain scan).
+    unsigned long long cand[COMPOSE_MASKS] = {};
+    const bool masked = n <= 64 * COMPOSE_MASKS && __ballot(inside && !is_interior) != 0;
+    if (masked) {
+        const int wx0 = xs0 + blockIdx.x * 64, wx1 = min(wx0 + 64, xs1);
+#pragma unroll
+        for (int m = 0; m < COMPOSE_MASKS; ++m) {
+            const int i = 64 * m + (int)threadIdx.x;
+            bool hit = false;
+            if (i < n) {
+                const pano_patch *q = patches + i;
+                const int ax = q->x0 + q->ax0, ay = q->y0 + q->ay0;
+                hit = ax < wx1 && ax + q->aw > wx0 && ay <= y && y < ay + q->ah;
+            }
+            cand[m] = __ballot(hit);
+        }
+    }
+    if (!inside) return;
+    if (is_interior) {
         // interior pixel: the mosaic is the owner's warped colour, clipped, quantised
         if (ia.part == 2) return;                // compose_interior_kernel wrote it
         const int own = owner[(size_t)y * W + x];
@@ -687,7 +710,18 @@ __global__ __launch_bounds__(256) void multiband_compose_kernel(
 #pragma unroll
     for (int k = 0; k < L; ++k) layer[k][0] = layer[k][1] = layer[k][2] = wsum[k] = 0.0f;
 
-    for (int i = 0; i < n; ++i) {
+    // records in index order (the reference's summation order): the set bits, or all of them
+    int m = 0;
+    unsigned long long bits = masked ? cand[0] : 0ull;
+    for (int i = 0;; ++i) {
+        if (masked) {
+            while (bits == 0ull && ++m < COMPOSE_MASKS) bits = cand[m];
+            if (bits == 0ull) break;
+            i = 64 * m + __ffsll((long long)bits) - 1;
+            bits &= bits - 1ull;
+        } else if (i >= n) {
+            break;
+        }
         const pano_patch p = patches[i];
         // outside A every weight of this patch is an exact 0 (header, "Windows")
         const int ax = x - p.x0 - p.ax0, ay = y - p.y0 - p.ay0;
