@@ -1004,20 +1004,18 @@ int pano_blur_mfma_opt_in(void) {
     return PANO_OK;
 }
 
-int pano_launch_blur_mfma(pano_ctx *ctx, const pano_patch *table, int n, int max_aw, int max_ah,
-                          const int16_t *owner, int W, const float *host_taps, const int *ntaps,
-                          int n_blur, const uint8_t *interior, uint8_t *tile_flags) {
+// One launch for the levels [lev0, lev0 + cnt) of the caller's tap tables, `group` of them per
+// workgroup.  rmax_all: the largest radius of ALL the caller's levels (it fixes the zeros in
+// front of each padded table, include/pano360.h).
+static int launch_levels(pano_ctx *ctx, const pano_patch *table, int n, int max_aw,
+                         const int16_t *owner, int W, const float *host_taps_all,
+                         const int *ntaps_all, int lev0, int cnt, int rmax_all, int group,
+                         const uint8_t *flags) {
     const hipStream_t stream = ctx->stream;
-    // Levels per workgroup.  Four (eight waves in lockstep, one workgroup per CU) shares one
-    // staged band between four levels; two (four waves, two workgroups per CU running out of
-    // step) stages every band twice as often.  Measured (profiles/r02/notes.md): four levels -
-    // the reference's default - 0.87 ms as one group of four against 1.00 ms as two groups of
-    // two (config 3); five levels 10.9 ms as 4 + 1 against 9.5 ms as 2 + 2 + 1 (config 5).  So:
-    // two per workgroup when the count leaves a group of four mostly idle, and only while every
-    // level fits 3 K-steps either side (the narrow band pitch; apertures up to 97 taps).
-    int group = (n_blur <= 2 || n_blur == 5 || n_blur == 6) ? 2 : 4;
-    for (int k = 0; k < n_blur; ++k)
-        if (mb_c_of(ntaps[k]) > 3) group = 4;
+    const int *ntaps = ntaps_all + lev0;
+    size_t skip = 0;
+    for (int k = 0; k < lev0; ++k) skip += (size_t)ntaps_all[k] + PANO_TAP_PAD;
+    const float *host_taps = host_taps_all + skip;
     // Work order of the levels: a workgroup takes `group` consecutive entries.  With two per
     // workgroup the heaviest level goes with the lightest, the second heaviest with the second
     // lightest, ...: the groups' tables then have about the same size, and two workgroups fit
@@ -1025,23 +1023,22 @@ int pano_launch_blur_mfma(pano_ctx *ctx, const pano_patch *table, int n, int max
     int ord[PANO_MAX_LEVELS];
     if (group == 2) {
         int by_size[PANO_MAX_LEVELS];
-        for (int k = 0; k < n_blur; ++k) by_size[k] = k;
-        for (int a = 1; a < n_blur; ++a)                      // insertion sort, largest aperture first
+        for (int k = 0; k < cnt; ++k) by_size[k] = k;
+        for (int a = 1; a < cnt; ++a)                         // insertion sort, largest aperture first
             for (int b = a; b > 0 && ntaps[by_size[b]] > ntaps[by_size[b - 1]]; --b) {
                 const int tmp = by_size[b];
                 by_size[b] = by_size[b - 1];
                 by_size[b - 1] = tmp;
             }
-        for (int i = 0, lo = 0, hi = n_blur - 1; i < n_blur; ++i)
+        for (int i = 0, lo = 0, hi = cnt - 1; i < cnt; ++i)
             ord[i] = (i & 1) ? by_size[hi--] : by_size[lo++];
     } else {
-        for (int k = 0; k < n_blur; ++k) ord[k] = k;
+        for (int k = 0; k < cnt; ++k) ord[k] = k;
     }
     MbLevels L = {};
-    L.n = n_blur;
-    int rmax = 0, total = 0;
-    for (int k = 0; k < n_blur; ++k) rmax = ntaps[k] / 2 > rmax ? ntaps[k] / 2 : rmax;
-    for (int i = 0; i < n_blur; ++i) {
+    L.n = cnt;
+    int total = 0;
+    for (int i = 0; i < cnt; ++i) {
         L.tab_off[i] = total;
         total += mb_table_bytes(ntaps[ord[i]]);
     }
@@ -1049,38 +1046,32 @@ int pano_launch_blur_mfma(pano_ctx *ctx, const pano_patch *table, int n, int max
     // context, keyed on the tap values, built on first use in stream order
     PanoTapSet *set = nullptr;
     bool fresh = false;
-    if (int rc = pano_ctx_tap_set(ctx, host_taps, ntaps, n_blur, (size_t)total, &set, &fresh))
+    if (int rc = pano_ctx_tap_set(ctx, host_taps, ntaps, cnt, (size_t)total, &set, &fresh))
         return rc;
     size_t first[PANO_MAX_LEVELS], off = 0;
-    for (int k = 0; k < n_blur; ++k) {
-        first[k] = off + PANO_TAP_LEAD + ((rmax - ntaps[k] / 2) & 3);
+    for (int k = 0; k < cnt; ++k) {
+        first[k] = off + PANO_TAP_LEAD + ((rmax_all - ntaps[k] / 2) & 3);
         off += (size_t)ntaps[k] + PANO_TAP_PAD;
     }
-    for (int i = 0; i < n_blur; ++i) {
+    for (int i = 0; i < cnt; ++i) {
         L.w[i] = set->taps + first[ord[i]];
         L.ntaps[i] = ntaps[ord[i]];
-        L.out[i] = ord[i];
+        L.out[i] = lev0 + ord[i];
     }
     unsigned char *tables = set->tables;
     if (fresh) {
-        hipLaunchKernelGGL(mb_tables_kernel, dim3(n_blur), dim3(128), 0, stream, L, tables);
+        hipLaunchKernelGGL(mb_tables_kernel, dim3(cnt), dim3(128), 0, stream, L, tables);
         PANO_LAUNCH_CHECK("mb_tables_kernel");
     }
     const int ntx_max = (max_aw + 62) / 32;
-    // the work list: prepared by the caller for this table, or made here
-    if (ctx->prepared_table != table || ctx->prepared_n != n)
-        if (int rc = pano_prepare_blur_mfma(ctx, table, n, max_aw, max_ah, W, interior, tile_flags))
-            return rc;
-    ctx->prepared_table = nullptr;
-    const uint8_t *flags = interior ? tile_flags : nullptr;
     const int cap = mb_sorted_slots(n * ceil_div(ntx_max, 2));    // slots of the sorted list
     const int2 *sorted = ctx->item_buf + ctx->item_cap;
     // dynamic LDS: the largest level group's band, flags and tables
-    const int ngroups = ceil_div(n_blur, group);
+    const int ngroups = ceil_div(cnt, group);
     int lds = 0;
     for (int gidx = 0; gidx < ngroups; ++gidx) {
         int bytes = 0, cm = 1;
-        for (int i = group * gidx; i < n_blur && i < group * (gidx + 1); ++i) {
+        for (int i = group * gidx; i < cnt && i < group * (gidx + 1); ++i) {
             bytes += mb_table_bytes(L.ntaps[i]);
             cm = mb_c_of(L.ntaps[i]) > cm ? mb_c_of(L.ntaps[i]) : cm;
         }
@@ -1101,4 +1092,44 @@ int pano_launch_blur_mfma(pano_ctx *ctx, const pano_patch *table, int n, int max
                                       table, L, tables, owner, W, flags, sorted));
     PANO_LAUNCH_CHECK("blur_mfma_kernel");
     return PANO_OK;
+}
+
+int pano_launch_blur_mfma(pano_ctx *ctx, const pano_patch *table, int n, int max_aw, int max_ah,
+                          const int16_t *owner, int W, const float *host_taps, const int *ntaps,
+                          int n_blur, const uint8_t *interior, uint8_t *tile_flags) {
+    // Levels per workgroup.  Four (eight waves in lockstep, one workgroup per CU) shares one
+    // staged band between four levels; two (four waves, two workgroups per CU running out of
+    // step) stages every band twice as often.  Measured (profiles/r02/notes.md): four levels -
+    // the reference's default - 0.87 ms as one group of four against 1.00 ms as two groups of
+    // two (config 3); five levels in ONE launch 10.9 ms as 4 + 1 (the lone level's workgroup
+    // reserves the LDS of four) against 9.4 ms as 2 + 2 + 1 (config 5).  Two per workgroup only
+    // while every level fits 3 K-steps either side (the narrow band pitch; apertures up to 97).
+    bool narrow = true;
+    int rmax = 0;
+    for (int k = 0; k < n_blur; ++k) {
+        if (mb_c_of(ntaps[k]) > 3) narrow = false;
+        rmax = ntaps[k] / 2 > rmax ? ntaps[k] / 2 : rmax;
+    }
+    // the work list: prepared by the caller for this table, or made here
+    if (ctx->prepared_table != table || ctx->prepared_n != n)
+        if (int rc = pano_prepare_blur_mfma(ctx, table, n, max_aw, max_ah, W, interior, tile_flags))
+            return rc;
+    ctx->prepared_table = nullptr;
+    const uint8_t *flags = interior ? tile_flags : nullptr;
+#ifndef MB_SPLIT_LAUNCH
+#define MB_SPLIT_LAUNCH 1
+#endif
+    if (MB_SPLIT_LAUNCH && narrow && (n_blur == 5 || n_blur == 6)) {
+        // four levels as one group of four, the rest in a launch of their own (small workgroups,
+        // several per CU): the band is staged twice per item instead of three times.  Config 5
+        // (five levels): 8.9-9.05 ms against 9.2 ms as 2 + 2 + 1 in one launch.
+        if (int rc = launch_levels(ctx, table, n, max_aw, owner, W, host_taps, ntaps, 0, 4, rmax, 4,
+                                   flags))
+            return rc;
+        return launch_levels(ctx, table, n, max_aw, owner, W, host_taps, ntaps, 4, n_blur - 4, rmax, 2,
+                             flags);
+    }
+    const int group = narrow && (n_blur <= 2 || n_blur == 5 || n_blur == 6) ? 2 : 4;
+    return launch_levels(ctx, table, n, max_aw, owner, W, host_taps, ntaps, 0, n_blur, rmax, group,
+                         flags);
 }
