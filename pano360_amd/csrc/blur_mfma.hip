@@ -846,9 +846,6 @@ __global__ __launch_bounds__(256) void mb_sort_kernel(const int2 *__restrict__ i
                 S = s;
             }
         }
-#ifdef MB_SEG_DEBUG
-        if (tid == 0) printf("mb_sort: n %d Lmax %d Lsum %d model(1) %d -> S %d model %d\n", n, Lmax, Lsum, base, S, best);
-#endif
         __syncthreads();
     }
     const int total = n * S;
