@@ -567,14 +567,18 @@ __global__ __launch_bounds__(256) void interior_tile_kernel(const int16_t *__res
         s_own[i] = (y >= 0 && y < H8 && x >= 0 && x < W8) ? bown[(size_t)y * W8 + x] : (int16_t)-3;
     }
     __syncthreads();
+    // (no early exit: a loop that stops at the first mismatch is a chain of dependent LDS reads,
+    // one latency each; unconditional reads are independent and stream)
     for (int i = tid; i < IT_H * tw; i += 256) {
         const int ry = i / tw, tx = i - ry * tw;
-        int o = s_own[(ry + reach) * tw + tx];
-        for (int d = 0; d <= 2 * reach && o >= 0; ++d) {
+        const int o = s_own[(ry + reach) * tw + tx];
+        bool same = true;
+#pragma unroll 8
+        for (int d = 0; d <= 2 * reach; ++d) {
             const int v = s_own[(ry + d) * tw + tx];
-            if (v != o && v != -3) o = -2;
+            same &= (v == o) | (v == -3);
         }
-        s_col[i] = (int16_t)o;                          // -3 stays -3
+        s_col[i] = (int16_t)(o >= 0 && !same ? -2 : o);  // -3 stays -3
     }
     __syncthreads();
     for (int i = tid; i < IT_H * IT_W; i += 256) {
@@ -584,7 +588,8 @@ __global__ __launch_bounds__(256) void interior_tile_kernel(const int16_t *__res
         const int16_t *row = s_col + ry * tw + rx;       // row[d] = column x - reach + d
         const int o = row[reach];
         bool in = o >= 0;
-        for (int d = 0; d <= 2 * reach && in; ++d) in = row[d] == o || row[d] == -3;
+#pragma unroll 8
+        for (int d = 0; d <= 2 * reach; ++d) in &= (row[d] == o) | (row[d] == -3);
         interior[(size_t)y * W8 + x] = in ? 1 : 0;
     }
 }
