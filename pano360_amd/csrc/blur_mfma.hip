@@ -748,7 +748,10 @@ __global__ __launch_bounds__(256) void mb_items_kernel(const pano_patch *__restr
         bool any = false;
         if (tx < g.ntx) {
             any = rec == nullptr;
-            for (int ty = wave; ty < nty && !any; ty += 4) any = rec[ty * g.ntx + tx] != 0;
+            // (no early exit: stopping at the first hit makes the loads a dependent chain)
+            if (rec)
+#pragma unroll 4
+                for (int ty = wave; ty < nty; ty += 4) any |= rec[ty * g.ntx + tx] != 0;
         }
         const unsigned long long mine = __ballot(any);
         __syncthreads();                                 // s_any of the previous chunk is read
