@@ -986,3 +986,20 @@ def test_shrink_matches_resize_oracle(eng, shrink):
         got = blend.shrink_images([img], shrink)[0].cpu().numpy()
         assert np.array_equal(got, lo.shrink(img, shrink)), (h, w, shrink)
     assert blend.shrink_images([img], 1)[0].shape == img.shape
+
+
+@pytest.mark.parametrize("mode", [1, 2])
+def test_side_stream_modes_give_the_same_mosaic(eng, mode):
+    """``Engine(side_stream=...)``: 2 = the blur's tile flags and work list are made on a second
+    stream beside the warp, 1 = also the interior pixels of the collapse.  Same mosaic bit for
+    bit as on one stream, stitch after stitch (the streams are ordered by events only)."""
+    import torch
+    from pano360_amd import engine, synth
+    imgs, rots, intrs = synth.make_scene(10, 640, 360, sweep_deg=120.0, jitter=0.01, seed=77, kind="A")
+    shapes = [im.shape[:2] for im in imgs]
+    frames = eng.upload_frames(imgs)
+    want = eng.stitch(frames, engine.Plan(shapes, rots, intrs, True, 10 ** 9), "multiband", 5)[0]
+    other = engine.Engine(side_stream=mode)
+    for _ in range(12):
+        got = other.stitch(frames, engine.Plan(shapes, rots, intrs, True, 10 ** 9), "multiband", 5)[0]
+        assert torch.equal(got, want)
