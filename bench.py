@@ -275,8 +275,12 @@ def run_cfg4(args, eng, rank, world):
         state["i"] += 1
         pyr = features.sift_pyramid_device(frame, eng=eng)
         if args.detect:
-            kps, _ = features.sift_detect_device(frame, pyramid=pyr, eng=eng)
-            return pyr, len(kps)
+            # queued without waiting; the previous frame's keypoints are fetched meanwhile
+            job, state["job"] = state.get("job"), features.sift_detect_async(frame, pyramid=pyr,
+                                                                           eng=eng)
+            if job is not None:
+                state["n_kp"] = len(job.result()[0])
+            return pyr, state.get("n_kp")
         return pyr, None
 
     def fence():

@@ -500,7 +500,10 @@ int pano_resize_u8(pano_ctx *ctx, const uint8_t *src, int sh, int sw, int c,
  *                       octave (descending), the first of every (x, y, size, angle) group
  *                       kept, positions and sizes scaled by 2^first_octave and the octave
  *                       byte shifted by first_octave -> out (dev, room for n), *n_out (dev).
- *                       work: dev scratch of pano_sift_sort_work_bytes(n) bytes. */
+ *                       work: dev scratch of pano_sift_sort_work_bytes(n) bytes.
+ * n_dev (optional, pano_sift_sort_unique and pano_sift_describe): a device int holding the
+ * real count, at most n - the host then passes the capacity as n and never waits for the
+ * counters pano_sift_orient / pano_sift_sort_unique leave on the device. */
 int pano_sift_extrema(pano_ctx *ctx, const float *dog, int rows, int cols, int octave,
                       int n_layers, float contrast_thr, float edge_thr, float sigma,
                       pano_sift_keypoint *cands, int *count, int max_cands);
@@ -509,10 +512,10 @@ int pano_sift_orient(pano_ctx *ctx, const float *const *gauss, const int *dims,
                      int max_cands, pano_sift_keypoint *kpts, int *count, int max_kpts);
 int pano_sift_describe(pano_ctx *ctx, const float *const *gauss, const int *dims,
                        int first_octave, const pano_sift_keypoint *kpts, int n,
-                       float *desc);
+                       const int *n_dev, float *desc);
 size_t pano_sift_sort_work_bytes(int n);
-int pano_sift_sort_unique(pano_ctx *ctx, const pano_sift_keypoint *kpts, int n, int first_octave,
-                          void *work, pano_sift_keypoint *out, int *n_out);
+int pano_sift_sort_unique(pano_ctx *ctx, const pano_sift_keypoint *kpts, int n, const int *n_dev,
+                          int first_octave, void *work, pano_sift_keypoint *out, int *n_out);
 
 /* The two nearest rows of `train` for every row of `query` (Euclidean), the search behind
  * flann_matching                                                  features.py:222-232

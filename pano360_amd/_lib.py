@@ -123,9 +123,9 @@ _SIGNATURES = {
     "pano_sift_extrema": (_i, [_vp, _vp, _i, _i, _i, _i, C.c_float, C.c_float, C.c_float, _vp,
                                _vp, _i]),
     "pano_sift_orient": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _i]),
-    "pano_sift_describe": (_i, [_vp, _vp, _vp, _i, _vp, _i, _vp]),
+    "pano_sift_describe": (_i, [_vp, _vp, _vp, _i, _vp, _i, _vp, _vp]),
     "pano_sift_sort_work_bytes": (C.c_size_t, [_i]),
-    "pano_sift_sort_unique": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp]),
+    "pano_sift_sort_unique": (_i, [_vp, _vp, _i, _vp, _i, _vp, _vp, _vp]),
     "pano_knn2_work_bytes": (C.c_size_t, [_i, _i, _i]),
     "pano_knn2": (_i, [_vp, _vp, _i, _vp, _i, _i, C.c_float, _vp, _vp, _vp, _vp]),
 }

@@ -263,7 +263,8 @@ __global__ __launch_bounds__(64) void sift_orient_kernel(
 // first octave -1) and the adjusted packed octave, as SIFT::detectAndCompute returns them.
 __global__ __launch_bounds__(64) void sift_describe_kernel(
     const float *const *__restrict__ gauss, const int *__restrict__ dims, int first_octave,
-    const pano_sift_keypoint *__restrict__ kpts, int n, float *__restrict__ desc) {
+    const pano_sift_keypoint *__restrict__ kpts, int n_cap, const int *__restrict__ n_dev,
+    float *__restrict__ desc) {
     constexpr int d = SIFT_D, nb = SIFT_N, HL = (d + 2) * (d + 2) * (nb + 2);
     // The votes are summed in 64-bit fixed point (2^-24 units) with integer LDS atomics.  LDS
     // FLOAT atomics run far below the integer rate on gfx950: with ds_add_f32 the eight votes
@@ -273,6 +274,7 @@ __global__ __launch_bounds__(64) void sift_describe_kernel(
     // order of the additions; a vote is rounded to 6e-8, far below the final 8-bit rounding.
     __shared__ unsigned long long hist[HL];              // two's complement sums
     const int lane = threadIdx.x;
+    const int n = n_dev ? min(*n_dev, n_cap) : n_cap;   // the count may still be on the device
     for (int idx = blockIdx.x; idx < n; idx += gridDim.x) {
         const pano_sift_keypoint k = kpts[idx];
         int octave = k.octave & 255;
@@ -412,7 +414,7 @@ extern "C" int pano_sift_orient(pano_ctx *ctx, const float *const *gauss, const 
 
 extern "C" int pano_sift_describe(pano_ctx *ctx, const float *const *gauss, const int *dims,
                                   int first_octave, const pano_sift_keypoint *kpts, int n,
-                                  float *desc) {
+                                  const int *n_dev, float *desc) {
     PANO_ENTER(ctx, "pano_sift_describe");
     PANO_REQUIRE(gauss && dims && (n == 0 || (kpts && desc)), "pano_sift_describe: null pointer");
     PANO_REQUIRE(n >= 0, "pano_sift_describe: bad count");
@@ -420,7 +422,7 @@ extern "C" int pano_sift_describe(pano_ctx *ctx, const float *const *gauss, cons
     const int blocks = n < 65535 ? n : 65535;
     PANO_TIMED(PK_SIFT_DESCRIBE, (hipStream_t)stream,
                hipLaunchKernelGGL(sift_describe_kernel, dim3(blocks), dim3(64), 0,
-                                  (hipStream_t)stream, gauss, dims, first_octave, kpts, n, desc));
+                                  (hipStream_t)stream, gauss, dims, first_octave, kpts, n, n_dev, desc));
     PANO_LAUNCH_CHECK("sift_describe_kernel");
     return PANO_OK;
 }

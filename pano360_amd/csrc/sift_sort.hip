@@ -29,10 +29,18 @@ __device__ __forceinline__ uint32_t ordered(float v) {
 // desc, y, x
 __global__ __launch_bounds__(256) void sift_keys_kernel(const pano_sift_keypoint *__restrict__ kp,
                                                         const uint32_t *__restrict__ idx, int n,
-                                                        int which, uint32_t *__restrict__ keys) {
+                                                        const int *__restrict__ n_dev, int which,
+                                                        uint32_t *__restrict__ keys) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    const pano_sift_keypoint k = kp[idx ? idx[i] : (uint32_t)i];
+    // slots past the device-side count hold nothing: the largest key in every pass keeps them
+    // at the end (the passes are stable)
+    const uint32_t src = idx ? idx[i] : (uint32_t)i;
+    if (n_dev && (int)src >= min(*n_dev, n)) {
+        keys[i] = 0xffffffffu;
+        return;
+    }
+    const pano_sift_keypoint k = kp[src];
     uint32_t key;
     switch (which) {
         case 0: key = ~((uint32_t)k.octave ^ 0x80000000u); break;      // signed, descending
@@ -53,9 +61,14 @@ __global__ __launch_bounds__(256) void sift_iota_kernel(uint32_t *__restrict__ i
 // 1 = the first of its (x, y, size, angle) group in sorted order
 __global__ __launch_bounds__(256) void sift_flags_kernel(const pano_sift_keypoint *__restrict__ kp,
                                                          const uint32_t *__restrict__ idx, int n,
+                                                         const int *__restrict__ n_dev,
                                                          int *__restrict__ flags) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
+    if (n_dev && i >= min(*n_dev, n)) {                 // sorted to the end: not a keypoint
+        flags[i] = 0;
+        return;
+    }
     int keep = 1;
     if (i > 0) {
         const pano_sift_keypoint a = kp[idx[i - 1]], b = kp[idx[i]];
@@ -71,7 +84,7 @@ __global__ __launch_bounds__(256) void sift_compact_kernel(
     float scale, pano_sift_keypoint *__restrict__ out, int *__restrict__ n_out) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    if (i == n - 1) *n_out = pos[i] + flags[i];
+    if (i == n - 1) *n_out = pos[i] + flags[i];         // flags past the count are 0
     if (!flags[i]) return;
     pano_sift_keypoint k = kp[idx[i]];
     k.octave = (k.octave & ~255) | ((k.octave + first_octave) & 255);
@@ -109,8 +122,8 @@ SortLayout sort_layout(int n) {
 extern "C" size_t pano_sift_sort_work_bytes(int n) { return sort_layout(n > 0 ? n : 1).total; }
 
 extern "C" int pano_sift_sort_unique(pano_ctx *ctx, const pano_sift_keypoint *kpts, int n,
-                                     int first_octave, void *work, pano_sift_keypoint *out,
-                                     int *n_out) {
+                                     const int *n_dev, int first_octave, void *work,
+                                     pano_sift_keypoint *out, int *n_out) {
     PANO_ENTER(ctx, "pano_sift_sort_unique");
     PANO_REQUIRE(n >= 0 && n_out, "pano_sift_sort_unique: bad argument");
     hipStream_t s = (hipStream_t)stream;
@@ -130,7 +143,7 @@ extern "C" int pano_sift_sort_unique(pano_ctx *ctx, const pano_sift_keypoint *kp
     hipLaunchKernelGGL(sift_iota_kernel, grid, block, 0, s, idx_a, n);
     PANO_LAUNCH_CHECK("sift_iota_kernel");
     for (int which = 0; which < 6; ++which) {
-        hipLaunchKernelGGL(sift_keys_kernel, grid, block, 0, s, kpts, idx_a, n, which, keys_a);
+        hipLaunchKernelGGL(sift_keys_kernel, grid, block, 0, s, kpts, idx_a, n, n_dev, which, keys_a);
         PANO_LAUNCH_CHECK("sift_keys_kernel");
         size_t temp = L.temp_bytes;
         PANO_HIP(hipcub::DeviceRadixSort::SortPairs(base, temp, keys_a, keys_b, idx_a, idx_b, n, 0,
@@ -139,7 +152,7 @@ extern "C" int pano_sift_sort_unique(pano_ctx *ctx, const pano_sift_keypoint *kp
         idx_a = idx_b;
         idx_b = t;
     }
-    hipLaunchKernelGGL(sift_flags_kernel, grid, block, 0, s, kpts, idx_a, n, flags);
+    hipLaunchKernelGGL(sift_flags_kernel, grid, block, 0, s, kpts, idx_a, n, n_dev, flags);
     PANO_LAUNCH_CHECK("sift_flags_kernel");
     size_t temp = L.temp_bytes;
     PANO_HIP(hipcub::DeviceScan::ExclusiveSum(base, temp, flags, pos, n, s));

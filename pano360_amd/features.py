@@ -210,20 +210,69 @@ def sift_sort_unique(kps):
     return kps
 
 
-def sift_detect_device(frame, max_keypoints=1 << 18, pyramid=None, eng=None):
-    """detectAndCompute on a uint8 BGR frame on the device.  Returns (keypoints as a
-    KP_DTYPE array in OpenCV's order, descriptors float32 [K][128] with values 0..255).
-    ``pyramid`` = (gauss, dog) device stacks replaces the scale space of ``frame``."""
+class SiftDetection:
+    """A ``detectAndCompute`` queued on the device: nothing has been waited for yet.
+    ``result()`` waits, checks the counters and returns (keypoints as a KP_DTYPE array in
+    OpenCV's order, descriptors float32 [K][128] on the device, values 0..255)."""
+
+    _copy_streams = {}
+
+    def __init__(self, counts, kpts, desc, max_keypoints, keep):
+        import torch
+        self.counts, self.kpts, self.desc, self.max_keypoints = counts, kpts, desc, max_keypoints
+        self.keep = keep                    # buffers the queued kernels still read
+        self._out = None
+        # the counters travel to pinned memory behind this frame's kernels; `done` marks that
+        # point, so result() waits for THIS frame only, not for whatever was queued after it
+        self.host_counts = torch.empty(3, dtype=torch.int32).pin_memory()
+        self.host_counts.copy_(counts, non_blocking=True)
+        self.done = torch.cuda.Event()
+        self.done.record(torch.cuda.current_stream(counts.device))
+
+    def result(self):
+        import torch
+        if self._out is None:
+            self.done.synchronize()
+            n_cand, n_kp, n_out = (int(v) for v in self.host_counts.numpy())
+            if max(n_cand, n_kp) > self.max_keypoints:
+                raise _lib.PanoError(f"sift: {max(n_cand, n_kp)} keypoints exceed max_keypoints")
+            # the keypoints on a stream of their own: a copy on the compute stream would queue
+            # behind the next frame's kernels
+            dev = self.kpts.device
+            if dev not in self._copy_streams:
+                self._copy_streams[dev] = (torch.cuda.Stream(dev),
+                                           torch.empty(self.max_keypoints * 32,
+                                                       dtype=torch.uint8).pin_memory())
+            side, pinned = self._copy_streams[dev]
+            if pinned.numel() < n_out * 32:
+                pinned = torch.empty(n_out * 32, dtype=torch.uint8).pin_memory()
+                self._copy_streams[dev] = (side, pinned)
+            with torch.cuda.stream(side):       # pinned: a DMA, no staging kernel on the GPU
+                pinned[:n_out * 32].copy_(self.kpts[:n_out * 32], non_blocking=True)
+            side.synchronize()
+            self._out = (pinned[:n_out * 32].numpy().view(KP_DTYPE).copy(), self.desc[:n_out])
+            self.keep = None
+        return self._out
+
+
+def sift_detect_async(frame, max_keypoints=1 << 18, pyramid=None, eng=None):
+    """detectAndCompute of a uint8 BGR frame on the device, queued without a single wait: the
+    candidate and keypoint counts stay on the device (``n_dev`` of ``pano_sift_sort_unique`` /
+    ``pano_sift_describe``), so consecutive frames follow each other on the GPU.  (With a wait
+    for every counter a 4K frame took 12.4 ms for 7.1 ms of kernels.)  ``pyramid`` =
+    (gauss, dog) device stacks replaces the scale space of ``frame``."""
     import torch
     eng = eng or _eng.engine()
     lib = eng.lib
     gauss, dog = pyramid if pyramid is not None else sift_pyramid_device(frame, eng=eng)
     dev = eng.device
-    dims = torch.tensor([v for g in gauss for v in g.shape[1:]], dtype=torch.int32, device=dev)
-    gptr = torch.tensor([g.data_ptr() for g in gauss], dtype=torch.int64, device=dev)
+    dims_host = np.array([v for g in gauss for v in g.shape[1:]], np.int32)
+    gptr_host = np.array([g.data_ptr() for g in gauss], np.int64)
+    dims = eng.to_device(dims_host).view(torch.int32)
+    gptr = eng.to_device(gptr_host).view(torch.int64)
     cands = torch.empty(max_keypoints * 32, dtype=torch.uint8, device=dev)
     kpts = torch.empty(max_keypoints * 32, dtype=torch.uint8, device=dev)
-    counts = torch.zeros(2, dtype=torch.int32, device=dev)
+    counts = torch.zeros(3, dtype=torch.int32, device=dev)    # candidates, keypoints, kept
     for o, diff in enumerate(dog):
         _, oh, ow = diff.shape
         _lib.check(lib.pano_sift_extrema(eng.ctx(), _eng._ptr(diff), oh, ow, o, SIFT_LAYERS,
@@ -234,24 +283,26 @@ def sift_detect_device(frame, max_keypoints=1 << 18, pyramid=None, eng=None):
                                     _eng._ptr(cands), _eng._ptr(counts[0:]), max_keypoints,
                                     _eng._ptr(kpts), _eng._ptr(counts[1:]), max_keypoints),
                "pano_sift_orient")
-    n_cand, n_kp = (int(v) for v in counts.cpu().numpy())
-    if max(n_cand, n_kp) > max_keypoints:
-        raise _lib.PanoError(f"sift: {max(n_cand, n_kp)} keypoints exceed max_keypoints")
     # OpenCV's order and duplicate removal, and the first-octave adjustment (positions and
     # sizes halved, octave byte shifted: sift.cpp, detectAndCompute), on the device: the
-    # six-key lexsort took 54 of a 4K frame's 69 ms on the host
-    work = torch.empty(int(lib.pano_sift_sort_work_bytes(n_kp)), dtype=torch.uint8, device=dev)
-    _lib.check(lib.pano_sift_sort_unique(eng.ctx(), _eng._ptr(kpts), n_kp, SIFT_FIRST_OCTAVE,
-                                         _eng._ptr(work), _eng._ptr(cands), _eng._ptr(counts[0:])),
+    # six-key lexsort took 54 of a 4K frame's 69 ms on the host.  The capacity is sorted; the
+    # slots past the device-side count sort to the end.
+    work = torch.empty(int(lib.pano_sift_sort_work_bytes(max_keypoints)), dtype=torch.uint8,
+                       device=dev)
+    _lib.check(lib.pano_sift_sort_unique(eng.ctx(), _eng._ptr(kpts), max_keypoints,
+                                         _eng._ptr(counts[1:]), SIFT_FIRST_OCTAVE, _eng._ptr(work),
+                                         _eng._ptr(cands), _eng._ptr(counts[2:])),
                "pano_sift_sort_unique")                      # cands: free again, reused as output
-    n_out = int(counts[0].item())
-    desc = torch.empty((n_out, 128), dtype=torch.float32, device=dev)
-    if n_out:
-        _lib.check(lib.pano_sift_describe(eng.ctx(), _eng._ptr(gptr), _eng._ptr(dims),
-                                          SIFT_FIRST_OCTAVE, _eng._ptr(cands), n_out,
-                                          _eng._ptr(desc)), "pano_sift_describe")
-    host = cands[:n_out * 32].cpu().numpy().view(KP_DTYPE).copy()
-    return host, desc
+    desc = torch.empty((max_keypoints, 128), dtype=torch.float32, device=dev)
+    _lib.check(lib.pano_sift_describe(eng.ctx(), _eng._ptr(gptr), _eng._ptr(dims),
+                                      SIFT_FIRST_OCTAVE, _eng._ptr(cands), max_keypoints,
+                                      _eng._ptr(counts[2:]), _eng._ptr(desc)), "pano_sift_describe")
+    return SiftDetection(counts, cands, desc, max_keypoints, (gauss, dog, dims, gptr, kpts, work))
+
+
+def sift_detect_device(frame, max_keypoints=1 << 18, pyramid=None, eng=None):
+    """``sift_detect_async(...).result()``."""
+    return sift_detect_async(frame, max_keypoints, pyramid, eng).result()
 
 
 def sift_detector():

@@ -565,9 +565,9 @@ def test_sift_sort_unique_on_device_equals_the_host_lexsort(eng, n):
     work = torch.empty(int(eng.lib.pano_sift_sort_work_bytes(n)), dtype=torch.uint8,
                        device=eng.device)
     count = torch.full((1,), -1, dtype=torch.int32, device=eng.device)
-    _lib.check(eng.lib.pano_sift_sort_unique(eng.ctx(), _ptr(dev), n, features.SIFT_FIRST_OCTAVE,
-                                             _ptr(work), _ptr(out), _ptr(count)),
-               "pano_sift_sort_unique")
+    _lib.check(eng.lib.pano_sift_sort_unique(eng.ctx(), _ptr(dev), n, None,
+                                             features.SIFT_FIRST_OCTAVE, _ptr(work), _ptr(out),
+                                             _ptr(count)), "pano_sift_sort_unique")
     m = int(count.item())
     assert m == len(want)
     got = out[:m * 32].cpu().numpy().view(features.KP_DTYPE)
@@ -575,3 +575,15 @@ def test_sift_sort_unique_on_device_equals_the_host_lexsort(eng, n):
     # stable order of equal records; all six sort keys must agree exactly
     for key in ("x", "y", "size", "angle", "response", "octave"):
         assert np.array_equal(got[key], want[key]), key
+    if n > 2:
+        # the count on the device, the capacity on the host: the first 2 n / 3 records only
+        part = 2 * n // 3
+        n_dev = torch.tensor([part], dtype=torch.int32, device=eng.device)
+        _lib.check(eng.lib.pano_sift_sort_unique(eng.ctx(), _ptr(dev), n, _ptr(n_dev),
+                                                 features.SIFT_FIRST_OCTAVE, _ptr(work), _ptr(out),
+                                                 _ptr(count)), "pano_sift_sort_unique")
+        sub = features.sift_sort_unique(kp[:part].copy())
+        assert int(count.item()) == len(sub)
+        got_sub = out[:len(sub) * 32].cpu().numpy().view(features.KP_DTYPE)
+        assert np.array_equal(got_sub["angle"], sub["angle"])
+        assert np.array_equal(got_sub["y"], sub["y"] * np.float32(0.5))
