@@ -1032,3 +1032,47 @@ def test_three_hundred_cameras(eng, oracle, step_deg):
         got = eng.stitch(frames, plan_l, kind)[0]
         assert np.array_equal(got.cpu().numpy(),
                               oracle.stitch(imgs, rots, intrs, kind, max_resolution=10 ** 9)), kind
+
+
+def _edge_scene(case):
+    from pano360_amd import synth
+    if case in ("one camera", "two cameras"):
+        imgs, rots, intrs = synth.make_scene(3, 160, 90, sweep_deg=40.0, seed=1, kind="B")
+        k = 1 if case == "one camera" else 2
+        return imgs[:k], rots[:k], intrs[:k], 5, 10 ** 9
+    if case == "gaps between the frames":
+        return synth.make_scene(3, 120, 80, sweep_deg=170.0, seed=2, kind="B") + (5, 10 ** 9)
+    if case == "frames of 16 x 12":
+        return synth.make_scene(4, 16, 12, sweep_deg=30.0, seed=3, kind="A") + (2, 10 ** 9)
+    imgs, rots, intrs = synth.make_scene(4, 200, 120, sweep_deg=60.0, seed=4, kind="B")
+    if case == "mixed frame sizes":
+        imgs = [imgs[0], imgs[1][:100, :150].copy(), imgs[2], imgs[3][:90, :180].copy()]
+        return imgs, rots, intrs, 5, 10 ** 9
+    if case == "mosaic capped at 37 pixels":
+        return imgs, rots, intrs, 2, 37
+    assert case == "strong roll and pitch"
+    return synth.make_scene(5, 200, 120, sweep_deg=60.0, jitter=0.08, seed=5, kind="B") + (5, 10 ** 9)
+
+
+@pytest.mark.parametrize("case", ["one camera", "two cameras", "gaps between the frames",
+                                  "frames of 16 x 12", "mixed frame sizes",
+                                  "mosaic capped at 37 pixels", "strong roll and pitch"])
+def test_edge_case_scenes(eng, oracle, case):
+    """Degenerate and awkward inputs through the fused paths against the oracle: multiband within
+    one level, linear / none / valid / crop rectangle bit-exact."""
+    from pano360_amd import engine
+    imgs, rots, intrs, levels, mr = _edge_scene(case)
+    shapes = [im.shape[:2] for im in imgs]
+    frames = eng.upload_frames(imgs)
+    plan = engine.Plan(shapes, rots, intrs, True, mr)
+    mosaic, _, valid, _ = eng.stitch(frames, plan, "multiband", levels)
+    ref = oracle.stitch(imgs, rots, intrs, "multiband", levels, max_resolution=mr)
+    assert np.abs(mosaic.cpu().numpy().astype(int) - ref.astype(int)).max() <= 1
+    _, ref_patches, _ = oracle.warp_all(imgs, rots, intrs, True, mr)
+    ref_valid = oracle.valid(ref_patches, plan.shape)
+    assert np.array_equal(valid.cpu().numpy().astype(bool), ref_valid)
+    assert eng.crop_rect(valid) == oracle.crop_rect(ref_valid)
+    plan_l = engine.Plan(shapes, rots, intrs, False, mr)
+    for kind in ("linear", "none"):
+        got = eng.stitch(frames, plan_l, kind)[0].cpu().numpy()
+        assert np.array_equal(got, oracle.stitch(imgs, rots, intrs, kind, max_resolution=mr)), kind
