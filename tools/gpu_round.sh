@@ -25,6 +25,8 @@ print("ms/step %.3f value %.0f %s" % (d["ms_per_step"], d["value"], d["unit"]), 
 P
 done
 if [ "$MODE" = full ]; then
+  echo "== bench cfg4 with keypoints and descriptors"
+  timeout -k 10 900 python bench.py --workload cfg4 --detect --steps 8 --warmup 2 --no-cpu-baseline 2> "$OUT/bench_cfg4_detect.err" | tail -1 > "$OUT/bench_cfg4_detect.json"; cut -c1-200 "$OUT/bench_cfg4_detect.json"
   echo "== bench cfg5 (one GPU)"
   timeout -k 10 900 python bench.py --workload cfg5 --steps 5 --warmup 2 --no-cpu-baseline 2> "$OUT/bench_cfg5.err" | tail -1 > "$OUT/bench_cfg5.json"; cut -c1-400 "$OUT/bench_cfg5.json"
   echo "== 2-rank dry run on one GPU (gloo rendezvous, shared device)"
