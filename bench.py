@@ -58,7 +58,9 @@ def parse():
     ap.add_argument("--exchange", default="gather", choices=["gather", "reduce"],
                     help="N > 1, strips: how the strips are composed on rank 0")
     ap.add_argument("--no-secondary", action="store_true",
-                    help="N > 1: skip the secondary measurements (other exchange, replicas)")
+                    help="skip the secondary measurements (N = 1, default workload: the other "
+                         "BASELINE configs and the float32 vector-ALU blur; N > 1: the other "
+                         "exchange, replicas)")
     ap.add_argument("--secondary-timeout", type=float, default=180.0)
     ap.add_argument("--detect", action="store_true",
                     help="cfg4: time detectAndCompute (keypoints + descriptors) too")
@@ -262,8 +264,11 @@ class Watchdog:
             return True
 
 
-def run_cfg4(args, eng, rank, world):
+def run_cfg4(args, eng, rank, world, steps=None, warmup=None, detect=None):
     """Config 4: Gaussian / DoG scale space of 3840 x 2160 frames, one frame per step."""
+    steps = args.steps if steps is None else steps
+    warmup = args.warmup if warmup is None else warmup
+    detect = args.detect if detect is None else detect
     import torch
     from pano360_amd import features, synth
     w, h = 3840, 2160
@@ -274,7 +279,7 @@ def run_cfg4(args, eng, rank, world):
         frame = pool[state["i"] % len(pool)]
         state["i"] += 1
         pyr = features.sift_pyramid_device(frame, eng=eng)
-        if args.detect:
+        if detect:
             # queued without waiting; the previous frame's keypoints are fetched meanwhile
             job, state["job"] = state.get("job"), features.sift_detect_async(frame, pyramid=pyr,
                                                                            eng=eng)
@@ -293,8 +298,18 @@ def run_cfg4(args, eng, rank, world):
     for _ in range(2):
         step()
     fence()
-    elapsed, (pyr, n_kp), times = timed_steps(eng, step, args.steps, args.warmup, fence)
+    elapsed, (pyr, n_kp), times = timed_steps(eng, step, steps, warmup, fence)
+    job = state.get("job")
+    if job is not None:                      # the last frame's keypoints are still in flight
+        state["n_kp"] = n_kp = len(job.result()[0])
     return elapsed, pyr, n_kp, times, (w, h)
+
+
+class _Steps:
+    """steps / warmup / detect of a secondary measurement, shaped like the parsed arguments."""
+
+    def __init__(self, steps, warmup, detect=False):
+        self.steps, self.warmup, self.detect = steps, warmup, detect
 
 
 def cfg4_line(args, world, elapsed, pyr, n_kp, times, size):
@@ -357,6 +372,95 @@ def cpu_baseline_cfg4():
                 sample=f"one 3840x2160 frame, 11 octaves, in {dt:.1f} s; oracle = "
                        f"oracle/sift_pyramid.py (NumPy) with the C oracle's OpenMP GaussianBlur, "
                        f"{os.cpu_count()} host CPUs")
+
+
+def secondary_single_gpu(eng, fence):
+    """What the default line carries besides the config-3 headline (one GPU): every other
+    BASELINE config with a GPU path, measured in this same process right after the headline -
+    config 2 (8 x 1080p), config 4 (scale space of a 4K frame, then with keypoints and
+    descriptors), config 5 (120 x 8K, L = 6, on ONE GPU; six distinct 8K frames cycled through
+    the 120 cameras so that synthesis stays short) - and config 3 once more through the float32
+    vector-ALU blur (`Engine(blur="valu")`: one FMA per tap, no float16 anywhere), the strict
+    reading of `dtype: "f32"`.  Each entry: ms_per_step, its metric, per-kernel ms, roofline."""
+    import torch
+    from pano360_amd import engine, synth
+    out = {}
+
+    def stitches(name, steps, warmup, distinct=None, use=None):
+        use = use or eng
+        cfg = workload(name)
+        rots, intrs = synth.make_cameras(cfg["n"], cfg["width"], cfg["height"],
+                                         sweep_deg=cfg.get("sweep_deg"),
+                                         step_deg=cfg.get("step_deg"))
+        shapes = [(cfg["height"], cfg["width"])] * cfg["n"]
+        k = distinct or cfg["n"]
+        pool = [use.upload_frames([synth.make_frame(i, cfg["width"], cfg["height"], "A")])[0]
+                for i in range(k)]
+        frames = [pool[i % k] for i in range(cfg["n"])]
+
+        def step():
+            plan = engine.Plan(shapes, rots, intrs, True, NATIVE)
+            mosaic, _, _, patches = use.stitch(frames, plan, "multiband", cfg["n_levels"])
+            return plan, mosaic, list(patches)
+        for _ in range(3):
+            step()
+        fence()
+        elapsed, (plan, _, patches), times = timed_steps(use, step, steps, warmup, fence)
+        ms = elapsed / steps * 1e3
+        P = plan.patch_pixels
+        entry = {
+            "workload": f"{name}: {cfg['n']} synthetic {cfg['width']}x{cfg['height']} frames, "
+                        f"multiband L={cfg['n_levels']}, native resolution, one GPU"
+                        + (f" ({k} distinct frames cycled through the cameras)" if distinct else ""),
+            "metric": "blended megapixels/sec (multiband)", "value": P / (ms * 1e-3) / 1e6,
+            "unit": "MP/s", "ms_per_step": ms, "steps": steps, "warmup": warmup,
+            "mosaic": list(plan.shape), "patch_megapixels": P / 1e6,
+            "warped_megapixels": sum((p.window[1] - p.window[0]) * (p.window[3] - p.window[2])
+                                     for p in patches) / 1e6,
+            "kernel_ms_per_step": {k_: v[0] / steps for k_, v in sorted(times.items())},
+            "instrumented_ms_per_step": INSTRUMENTED.get("seconds", 0.0) / steps * 1e3,
+            "roofline": roofline_for(times, plan, patches, cfg["n_levels"], steps,
+                                     use.active_tile_pixels(), name),
+        }
+        del pool, frames
+        use._arenas.clear()
+        torch.cuda.empty_cache()
+        return entry
+
+    def guarded(key, fn):
+        try:
+            out[key] = fn()
+        except Exception as err:       # noqa: BLE001 - a secondary must not cost the headline
+            out[key] = {"error": repr(err)[:300]}
+            torch.cuda.synchronize()
+
+    guarded("cfg2", lambda: stitches("cfg2", 20, 3))
+
+    def cfg4(detect):
+        steps = 8 if detect else 12
+        elapsed, pyr, n_kp, times, size = run_cfg4(None, eng, 0, 1, steps, 2, detect)
+        line = cfg4_line(_Steps(steps, 2, detect), 1, elapsed, pyr, n_kp, times, size)
+        keep = ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "kernel_ms_per_step",
+                "instrumented_ms_per_step", "roofline", "sift")
+        entry = {k_: line[k_] for k_ in keep if k_ in line}
+        entry["workload"] = line["config"]["workload"]
+        if n_kp is not None:
+            entry["keypoints_per_frame"] = n_kp
+        return entry
+    guarded("cfg4", lambda: cfg4(False))
+    guarded("cfg4_detect", lambda: cfg4(True))
+    torch.cuda.empty_cache()
+
+    def valu():
+        strict = engine.Engine(eng.device, blur="valu")
+        entry = stitches("cfg3", 10, 2, use=strict)
+        entry["what"] = ("config 3 with every Gaussian level on the float32 vector ALU "
+                         "(blur_rows_kernel + blur_cols_kernel: float32 taps, float32 products, "
+                         "one FMA per tap) instead of the split-float16 matrix-core kernel")
+        return entry
+    guarded("blur_valu_f32", valu)
+    guarded("cfg5", lambda: stitches("cfg5", 5, 2, distinct=6))
+    return out
 
 
 def main():
@@ -548,6 +652,8 @@ def main():
         out = build_line(False, elapsed, plan, patches, times) if rank == 0 else None
         if rank == 0 and not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(cfg)
+        if world == 1 and not args.no_secondary and args.workload == "cfg3":
+            out["secondary"] = secondary_single_gpu(eng, fence)
         if world > 1 and not args.no_secondary and args.workload != "cfg5":
             dog = Watchdog(args.secondary_timeout, rank, out)
             dog.start()

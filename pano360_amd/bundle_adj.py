@@ -10,6 +10,8 @@ The class is importable as ``bundle_adj.Image`` through the top-level
 ``bundle_adj.py`` re-export, so ``ba_<name>.pkl`` caches written by the
 reference CLI (stitcher.py:430-439) unpickle into it unchanged.
 """
+from dataclasses import dataclass, field
+
 import numpy as np
 
 
@@ -26,31 +28,27 @@ class Deferred:
         self.make = make
 
 
+@dataclass(repr=False)
 class Image:
-    """One registered frame: pixels, rotation R, calibration K, angular range.
+    """One registered frame: pixels, rotation R, calibration K, angular range - a dataclass
+    with the reference's four fields (``dataclasses.fields`` / ``asdict`` / ``replace`` and the
+    keyword constructor work as they do on the reference's class).
 
     ``img``   uint8 [H, W, 3] on entry to ``stitch`` (channel order opaque); float32 RGBA
-              afterwards, as in the reference - fetched from the device on first access.
+              afterwards, as in the reference.  ``stitch`` stores a ``Deferred`` there: the
+              RGBA image is made on the device and downloaded when ``img`` is first READ.
+              Until then the record keeps the device frame, the colour table and the engine
+              alive; reading it (or assigning to it) releases them.  The read runs
+              ``_add_weights`` on the engine's current stream at that moment.
     ``rot``   float64 3x3 world->camera rotation.
     ``intr``  float64 3x3 ``[[f,0,cx],[0,f,cy],[0,0,1]]``.
     ``range`` (min, max) spherical angles, filled in by ``stitch``.
     """
 
-    def __init__(self, img, rot, intr, range=None):        # noqa: A002 - the reference's name
-        self.img = img
-        self.rot = rot
-        self.intr = intr
-        self.range = _zero_range() if range is None else range
-
-    @property
-    def img(self):
-        if isinstance(self._img, Deferred):
-            self._img = self._img.make()
-        return self._img
-
-    @img.setter
-    def img(self, value):
-        self._img = value
+    img: np.ndarray
+    rot: np.ndarray
+    intr: np.ndarray
+    range: tuple = field(default_factory=_zero_range)        # noqa: A003 - the reference's name
 
     # the reference's class pickles its plain attributes: keep that layout in both directions
     def __getstate__(self):
@@ -61,8 +59,8 @@ class Image:
             setattr(self, key, value)
 
     def __repr__(self):
-        return (f"Image(img={type(self._img).__name__}, rot={self.rot!r}, intr={self.intr!r}, "
-                f"range={self.range!r})")
+        return (f"Image(img={type(self.__dict__.get('_img')).__name__}, rot={self.rot!r}, "
+                f"intr={self.intr!r}, range={self.range!r})")
 
     def hom(self):
         """Pixel -> ray: ``R^T K^-1`` (reference bundle_adj.py:27-29)."""
@@ -72,6 +70,21 @@ class Image:
         """Ray -> pixel: ``K R`` (reference bundle_adj.py:31-33)."""
         return self.intr.dot(self.rot)
 
+
+def _img_get(self):
+    value = self.__dict__.get("_img")
+    if isinstance(value, Deferred):
+        value = self.__dict__["_img"] = value.make()
+    return value
+
+
+def _img_set(self, value):
+    self.__dict__["_img"] = value
+
+
+# the field `img` is served by a property (attached after @dataclass has read the annotations):
+# the generated __init__ / __eq__ / replace go through it like any other attribute access
+Image.img = property(_img_get, _img_set)
 
 # pickles name the class by module path: keep the reference's, so camera caches
 # move between the reference CLI and this build in both directions

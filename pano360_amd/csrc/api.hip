@@ -1,6 +1,7 @@
 // Library-level entry points: version, error string, device probe.
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <vector>
@@ -70,8 +71,12 @@ static void timing_clear(pano_ctx *ctx) {
 static void tap_set_free(PanoTapSet &ts) {
     if (ts.taps) (void)hipFree(ts.taps);
     if (ts.tables) (void)hipFree(ts.tables);
+    if (ts.ready) (void)hipEventDestroy(ts.ready);
+    free(ts.host);
     ts.taps = nullptr;
     ts.tables = nullptr;
+    ts.ready = nullptr;
+    ts.host = nullptr;
 }
 
 extern "C" int pano_ctx_destroy(pano_ctx *ctx) {
@@ -139,8 +144,12 @@ int pano_ctx_tap_set(pano_ctx *ctx, const float *taps, const int *ntaps, int n, 
     const uint64_t key = tap_hash(taps, ntaps, n, floats);
     *fresh = false;
     for (PanoTapSet &ts : ctx->tap_sets)
-        if (ts.key == key && ts.n == n && !memcmp(ts.ntaps, ntaps, n * sizeof(int))) {
+        if (ts.key == key && ts.n == n && !memcmp(ts.ntaps, ntaps, n * sizeof(int)) &&
+            ts.floats == floats && !memcmp(ts.host, taps, floats * sizeof(float))) {
             ts.used = ++ctx->tick;
+            // the upload (and the table build) were queued on the stream the context targeted
+            // then: a use from another stream is ordered behind them
+            if (ctx->stream != ts.built_on) PANO_HIP(hipStreamWaitEvent(ctx->stream, ts.ready, 0));
             if (table_bytes && !ts.tables) {
                 PANO_HIP(hipMalloc((void **)&ts.tables, table_bytes));
                 *fresh = true;
@@ -152,7 +161,8 @@ int pano_ctx_tap_set(pano_ctx *ctx, const float *taps, const int *ntaps, int n, 
         size_t old = 0;
         for (size_t i = 1; i < ctx->tap_sets.size(); ++i)
             if (ctx->tap_sets[i].used < ctx->tap_sets[old].used) old = i;
-        PANO_HIP(hipStreamSynchronize(ctx->stream));        // kernels may still read its tables
+        // kernels on ANY stream this context has targeted may still read its tables
+        PANO_HIP(hipDeviceSynchronize());
         tap_set_free(ctx->tap_sets[old]);
         ctx->tap_sets.erase(ctx->tap_sets.begin() + old);
     }
@@ -160,10 +170,17 @@ int pano_ctx_tap_set(pano_ctx *ctx, const float *taps, const int *ntaps, int n, 
     ts.key = key;
     ts.n = n;
     memcpy(ts.ntaps, ntaps, n * sizeof(int));
+    ts.floats = floats;
+    ts.host = (float *)malloc(floats * sizeof(float));
+    PANO_REQUIRE(ts.host, "pano_ctx_tap_set: out of host memory");
+    memcpy(ts.host, taps, floats * sizeof(float));
     PANO_HIP(hipMalloc((void **)&ts.taps, floats * sizeof(float)));
     // pageable source: the runtime stages it before returning, the caller's table is free again
     PANO_HIP(hipMemcpyAsync(ts.taps, taps, floats * sizeof(float), hipMemcpyHostToDevice,
                             ctx->stream));
+    PANO_HIP(hipEventCreateWithFlags(&ts.ready, hipEventDisableTiming));
+    PANO_HIP(hipEventRecord(ts.ready, ctx->stream));
+    ts.built_on = ctx->stream;
     if (table_bytes) {
         PANO_HIP(hipMalloc((void **)&ts.tables, table_bytes));
         *fresh = true;
@@ -171,6 +188,14 @@ int pano_ctx_tap_set(pano_ctx *ctx, const float *taps, const int *ntaps, int n, 
     ts.used = ++ctx->tick;
     ctx->tap_sets.push_back(ts);
     *out = &ctx->tap_sets.back();
+    return PANO_OK;
+}
+
+int pano_ctx_tap_set_built(pano_ctx *ctx, PanoTapSet *set) {
+    // the fill was queued on ctx->stream behind a wait for the previous `ready` (if that was
+    // another stream's), so the new record covers the upload too
+    PANO_HIP(hipEventRecord(set->ready, ctx->stream));
+    set->built_on = ctx->stream;
     return PANO_OK;
 }
 

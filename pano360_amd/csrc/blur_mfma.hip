@@ -1062,6 +1062,7 @@ static int launch_levels(pano_ctx *ctx, const pano_patch *table, int n, int max_
     if (fresh) {
         hipLaunchKernelGGL(mb_tables_kernel, dim3(cnt), dim3(128), 0, stream, L, tables);
         PANO_LAUNCH_CHECK("mb_tables_kernel");
+        if (int rc = pano_ctx_tap_set_built(ctx, set)) return rc;
     }
     const int ntx_max = (max_aw + 62) / 32;
     const int cap = mb_sorted_slots(n * ceil_div(ntx_max, 2));    // slots of the sorted list

@@ -78,6 +78,10 @@ struct PanoTapSet {                 // one set of Gaussian apertures (pano_multi
     float *taps;                    // dev: the caller's padded tables, back to back
     unsigned char *tables;          // dev: matrix-core operand tables (built on first use)
     uint64_t used;                  // last use (eviction order)
+    float *host;                    // the values themselves: a hash hit is confirmed by comparing them
+    size_t floats;
+    hipEvent_t ready;               // recorded behind the upload and the table build
+    hipStream_t built_on;           // the stream those were queued on
 };
 
 struct pano_ctx {
@@ -102,6 +106,9 @@ int pano_ctx_enter(pano_ctx *ctx);
 // buffer, `table_bytes` long, `*fresh` = it was just allocated and must be filled).
 int pano_ctx_tap_set(pano_ctx *ctx, const float *taps, const int *ntaps, int n, size_t table_bytes,
                      PanoTapSet **out, bool *fresh);
+// After the caller has queued the fill of a `fresh` table buffer on ctx->stream: uses from other
+// streams wait for it.
+int pano_ctx_tap_set_built(pano_ctx *ctx, PanoTapSet *set);
 
 #define PANO_ENTER(ctx, who)                                       \
     PANO_REQUIRE((ctx) != nullptr, "%s: null context", who);       \

@@ -122,9 +122,15 @@ __global__ __launch_bounds__(256) void crop_rows_kernel(
     // (the bottom ~160 of config 3's 2474) and one workgroup per row left most CUs idle
     const int i = H - 1 - (int)blockIdx.y;
     const int j_begin = (int)blockIdx.x * CROP_SEG, j_end = min(j_begin + CROP_SEG, W);
-    unsigned long long floor_area = __hip_atomic_load(best, __ATOMIC_RELAXED,
-                                                      __HIP_MEMORY_SCOPE_AGENT) >> 32;
-    if ((unsigned long long)(i + 1) * (unsigned)W < floor_area) return;
+    // The bound rises while other rows finish, so two waves of this block could read different
+    // values: ONE thread reads it, and the whole block leaves or stays on that value (a wave
+    // that left on its own would skip the barriers below and its share of the chunk minima).
+    __shared__ unsigned long long s_floor;
+    if (threadIdx.x == 0)
+        s_floor = __hip_atomic_load(best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 32;
+    __syncthreads();
+    unsigned long long floor_area = s_floor;
+    if ((unsigned long long)(i + 1) * (unsigned)W < floor_area) return;       // block-uniform
     const int32_t *row = heights + (size_t)i * W;
     const int nchunks = (W + CROP_CHUNK - 1) / CROP_CHUNK;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;

@@ -99,6 +99,11 @@ class StripExchange:
                            for _ in range(self.depth)] if rank == 0 else None)
             self.mosaic = ([torch.empty((self.H, self.W, 3), **u8) for _ in range(self.depth)]
                            if rank == 0 else None)
+        if mode == "reduce" and world > 1:
+            # rank 0 hands the sum out as a copy in a ring of its own, as the gather does: the
+            # buffer that received it is wiped by recycle() at the very next step
+            self.mosaic = ([torch.empty((self.H, self.W, 3), **u8) for _ in range(self.depth)]
+                           if rank == 0 else None)
         self.slot = 0
         self.inflight = []              # [(slot, work or None)], oldest first
 
@@ -154,10 +159,8 @@ class StripExchange:
         if self.world == 1:
             return self.full[slot]
         if self.mode == "reduce":
-            done = self.full[slot]
-            if self.depth == 1:
-                return done.clone()
-            return done
+            self.mosaic[slot].copy_(self.full[slot])
+            return self.mosaic[slot]
         parts, mosaic = self.parts[slot], self.mosaic[slot]
         if self.even:
             mosaic.view(self.H, self.world, self.pack_w, 3).copy_(parts.permute(1, 0, 2, 3))
@@ -220,6 +223,9 @@ class ShardedStitcher:
         """frames[j] = device tensor of camera my_frames[j].  Returns (plan, the previous
         step's mosaic on rank 0 / None, this rank's patches)."""
         ex = self.exchange
+        if ex is None:
+            raise RuntimeError("ShardedStitcher(exchange=None) holds the strip geometry only "
+                               "(emulate_on_one_device); step() needs an exchange mode")
         plan = _eng.Plan(self.shapes, self.rots, self.intrs, True, self.max_resolution,
                          table_cols=self.table_cols)
         self.eng.upload_plan(plan)

@@ -750,8 +750,10 @@ class Engine:
         return self._taps[n_levels]
 
     def upload_frames(self, imgs):
+        """uint8 host images -> device tensors; images already on the device pass through."""
         torch = _torch()
-        return [torch.from_numpy(np.ascontiguousarray(im, np.uint8)).to(self.device)
+        return [im.to(self.device) if isinstance(im, torch.Tensor) else
+                torch.from_numpy(np.ascontiguousarray(im, np.uint8)).to(self.device)
                 for im in imgs]
 
     def upload_plan(self, plan):
@@ -839,27 +841,15 @@ class Engine:
         return interior
 
     def active_tile_pixels(self):
-        """Pixels of the 64 x 128 column tiles the last blur really computed (all of
-        every rectangle A when no interior map was in use).  Synchronises."""
+        """Pixels of the 32 x 32 tiles the last blur really computed - whole tiles, an upper
+        bound - or all of every rectangle A when no tile flags were in use.  Synchronises."""
         table, flags = getattr(self, "last_tiles", (None, None))
         if table is None:
             return 0
-        host = table.host
         if flags is None:
+            host = table.host
             return int((host["ah"].astype(np.int64) * host["aw"]).sum())
-        on = flags.cpu().numpy()
-        if self.tile_grid == 32:
-            return int(on[:table.n_tiles].astype(np.int64).sum()) * 1024      # upper bound: whole tiles
-        total = 0
-        for rec in host:
-            ntx, nty = (int(rec["aw"]) + 63) // 64, (int(rec["ah"]) + 127) // 128
-            if ntx * nty == 0:
-                continue
-            grid = on[int(rec["tiles_off"]):int(rec["tiles_off"]) + ntx * nty].reshape(nty, ntx)
-            wx = np.minimum(64, int(rec["aw"]) - 64 * np.arange(ntx))
-            wy = np.minimum(128, int(rec["ah"]) - 128 * np.arange(nty))
-            total += int((grid.astype(np.int64) * wy[:, None] * wx[None, :]).sum())
-        return total
+        return int(flags[:table.n_tiles].to(_torch().int64).sum().item()) * 1024
 
     def compose_interior_async(self, owner, shape, strip, interior, cams, plan, luts,
                                want_float=False, mosaic_out=None):

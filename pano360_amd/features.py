@@ -210,24 +210,65 @@ def sift_sort_unique(kps):
     return kps
 
 
+class _SiftHost:
+    """Per-engine host side of the detector: the copy stream, the pinned staging buffer of
+    the keypoints and a ring of pinned counter slots.  Engines (one per host thread) share
+    nothing; a lock orders the detections of one engine that finish from several threads."""
+
+    SLOTS = 16
+
+    def __init__(self, eng):
+        import threading
+        import torch
+        self.lock = threading.Lock()
+        self.side = torch.cuda.Stream(eng.device)
+        self.pinned = None
+        self.counts = torch.empty((self.SLOTS, 3), dtype=torch.int32).pin_memory()
+        self.slot_events = [None] * self.SLOTS
+        self.next = 0
+
+    def counter_slot(self):
+        """A pinned int32[3] that no queued copy still writes."""
+        with self.lock:
+            k = self.next
+            self.next = (k + 1) % self.SLOTS
+            if self.slot_events[k] is not None:
+                self.slot_events[k].synchronize()
+            return k, self.counts[k]
+
+    def staging(self, nbytes):
+        import torch
+        if self.pinned is None or self.pinned.numel() < nbytes:
+            self.pinned = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8).pin_memory()
+        return self.pinned
+
+
+def _sift_host(eng):
+    host = getattr(eng, "_sift_host", None)
+    if host is None:
+        host = eng._sift_host = _SiftHost(eng)
+    return host
+
+
 class SiftDetection:
     """A ``detectAndCompute`` queued on the device: nothing has been waited for yet.
     ``result()`` waits, checks the counters and returns (keypoints as a KP_DTYPE array in
     OpenCV's order, descriptors float32 [K][128] on the device, values 0..255)."""
 
-    _copy_streams = {}
-
-    def __init__(self, counts, kpts, desc, max_keypoints, keep):
+    def __init__(self, counts, kpts, desc, max_keypoints, keep, eng):
         import torch
         self.counts, self.kpts, self.desc, self.max_keypoints = counts, kpts, desc, max_keypoints
         self.keep = keep                    # buffers the queued kernels still read
         self._out = None
-        # the counters travel to pinned memory behind this frame's kernels; `done` marks that
-        # point, so result() waits for THIS frame only, not for whatever was queued after it
-        self.host_counts = torch.empty(3, dtype=torch.int32).pin_memory()
+        self.host = _sift_host(eng)
+        # the counters travel to pinned memory (a slot of the engine's ring) behind this frame's
+        # kernels; `done` marks that point, so result() waits for THIS frame only, not for
+        # whatever was queued after it
+        slot, self.host_counts = self.host.counter_slot()
         self.host_counts.copy_(counts, non_blocking=True)
         self.done = torch.cuda.Event()
         self.done.record(torch.cuda.current_stream(counts.device))
+        self.host.slot_events[slot] = self.done
 
     def result(self):
         import torch
@@ -237,20 +278,15 @@ class SiftDetection:
             if max(n_cand, n_kp) > self.max_keypoints:
                 raise _lib.PanoError(f"sift: {max(n_cand, n_kp)} keypoints exceed max_keypoints")
             # the keypoints on a stream of their own: a copy on the compute stream would queue
-            # behind the next frame's kernels
-            dev = self.kpts.device
-            if dev not in self._copy_streams:
-                self._copy_streams[dev] = (torch.cuda.Stream(dev),
-                                           torch.empty(self.max_keypoints * 32,
-                                                       dtype=torch.uint8).pin_memory())
-            side, pinned = self._copy_streams[dev]
-            if pinned.numel() < n_out * 32:
-                pinned = torch.empty(n_out * 32, dtype=torch.uint8).pin_memory()
-                self._copy_streams[dev] = (side, pinned)
-            with torch.cuda.stream(side):       # pinned: a DMA, no staging kernel on the GPU
-                pinned[:n_out * 32].copy_(self.kpts[:n_out * 32], non_blocking=True)
-            side.synchronize()
-            self._out = (pinned[:n_out * 32].numpy().view(KP_DTYPE).copy(), self.desc[:n_out])
+            # behind the next frame's kernels.  One staging buffer per engine: the lock keeps
+            # two results of this engine from sharing it
+            with self.host.lock:
+                pinned = self.host.staging(n_out * 32)
+                with torch.cuda.stream(self.host.side):   # pinned: a DMA, no staging kernel
+                    pinned[:n_out * 32].copy_(self.kpts[:n_out * 32], non_blocking=True)
+                self.host.side.synchronize()
+                kps = pinned[:n_out * 32].numpy().view(KP_DTYPE).copy()
+            self._out = (kps, self.desc[:n_out])
             self.keep = None
         return self._out
 
@@ -297,7 +333,8 @@ def sift_detect_async(frame, max_keypoints=1 << 18, pyramid=None, eng=None):
     _lib.check(lib.pano_sift_describe(eng.ctx(), _eng._ptr(gptr), _eng._ptr(dims),
                                       SIFT_FIRST_OCTAVE, _eng._ptr(cands), max_keypoints,
                                       _eng._ptr(counts[2:]), _eng._ptr(desc)), "pano_sift_describe")
-    return SiftDetection(counts, cands, desc, max_keypoints, (gauss, dog, dims, gptr, kpts, work))
+    return SiftDetection(counts, cands, desc, max_keypoints, (gauss, dog, dims, gptr, kpts, work),
+                         eng)
 
 
 def sift_detect_device(frame, max_keypoints=1 << 18, pyramid=None, eng=None):

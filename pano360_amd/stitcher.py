@@ -267,6 +267,22 @@ def stitch(regions, blender=no_blend, equalize=False, crop=False):
 
 
 # ---------------------------------------------------------------------- CLI
+IMAGE_EXTENSIONS = (".jpg", ".png", ".bmp", ".JPG", ".PNG", ".BMP")     # stitcher.py:411-412
+
+
+def ingest(path, shrink):
+    """The head of the reference's ``main`` (stitcher.py:415-421): every image of the
+    directory, in ``os.listdir`` order, as ``cv2.imread`` would return it (uint8 BGR), shrunk by
+    ``cv2.resize(im, None, fx=1/shrink, fy=1/shrink)`` when shrink > 1 - on the device.
+    Returns uint8 [h][w][3] device tensors."""
+    from PIL import Image as PilImage
+    from . import blend as _blend
+    files = [f for f in os.listdir(path) if any(f.endswith(ext) for ext in IMAGE_EXTENSIONS)]
+    imgs = [np.ascontiguousarray(np.asarray(PilImage.open(os.path.join(path, f)).convert("RGB"))
+                                 [..., ::-1]) for f in files]
+    return _blend.shrink_images(imgs, shrink)
+
+
 def main(argv=None):
     """Same command line as the reference (stitcher.py:390-451)."""
     parser = argparse.ArgumentParser(description="Stitch images.")
@@ -289,10 +305,28 @@ def main(argv=None):
         with open(cache, "rb") as fid:
             regions = pickle.load(fid)
     except IOError:
-        raise SystemExit(
-            f"{cache} not found: feature matching and bundle adjustment are outside "
-            "this build's scope; produce the camera cache with the reference "
-            "(it is the pickle written at stitcher.py:438-439) and re-run")
+        regions = None
+    # stitcher.py:415-421: list the directory (os.listdir order, the reference's extensions),
+    # read, shrink.  The reference does this before it looks at its caches and, with a
+    # ``ba_*.pkl`` present, never uses the result (the pickle carries the shrunk images); here
+    # the images are read only when something consumes them: a cache without pixels
+    # (``img=None`` records: cameras only, a few hundred bytes per frame) or no cache at all.
+    # Decoding is Pillow's, on the host; the resize runs on the device (``pano_resize_u8``)
+    # and the shrunk frames stay there for ``stitch``.
+    if regions is None or any(reg.img is None for reg in regions):
+        frames = ingest(args.path, args.shrink) if os.path.isdir(args.path) else []
+        if regions is None:
+            raise SystemExit(
+                f"{cache} not found ({len(frames)} images read and shrunk on the device): "
+                "feature matching and bundle adjustment are outside this build's scope; "
+                "produce the camera cache with the reference (it is the pickle written at "
+                "stitcher.py:438-439) and re-run")
+        if len(frames) != len(regions):
+            raise SystemExit(f"{cache} holds {len(regions)} cameras, {args.path} "
+                             f"{len(frames)} images")
+        for reg, frame in zip(regions, frames):
+            if reg.img is None:
+                reg.img = frame
 
     start = time.time()
     mosaic = stitch(regions, blender=BLENDERS[args.blend], equalize=args.equalize,

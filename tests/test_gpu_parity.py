@@ -650,6 +650,40 @@ def test_cli_plumbing_config_1(eng, oracle, tmp_path, monkeypatch):
         top.main([str(tmp_path / "nowhere"), "-b", "linear"])
 
 
+def test_cli_ingest_reads_and_shrinks_on_the_device(eng, oracle, tmp_path, monkeypatch):
+    """The head of the reference's main (stitcher.py:415-421): list, read, shrink.  With a
+    cameras-only cache (``img=None`` records) the CLI reads the directory in ``os.listdir``
+    order, shrinks the images on the device (``pano_resize_u8``) and stitches them: the mosaic
+    equals the oracle's on the images shrunk by the restated ``cv2.resize``."""
+    import os
+    import pickle
+    from PIL import Image as PilImage
+    import bundle_adj
+    import laplacian_oracle as lo
+    import stitcher as top
+    from pano360_amd import synth
+    imgs, rots, intrs = synth.make_scene(4, 400, 240, sweep_deg=70.0, jitter=0.01, seed=21,
+                                         kind="B")
+    small_intr = synth.make_cameras(4, 200, 120, sweep_deg=70.0)[1]
+    data = tmp_path / "RIG"
+    data.mkdir()
+    for i, im in enumerate(imgs):
+        PilImage.fromarray(np.ascontiguousarray(im[..., ::-1])).save(data / f"f{i}.png")   # imread: BGR
+    (data / "notes.txt").write_text("not an image")
+    order = [int(f[1]) for f in os.listdir(data) if f.endswith(".png")]
+    regions = [bundle_adj.Image(None, rots[i], small_intr[i]) for i in order]
+    with open(tmp_path / "ba_RIG_s2.0.pkl", "wb") as fid:
+        pickle.dump(regions, fid, protocol=pickle.HIGHEST_PROTOCOL)
+    monkeypatch.chdir(tmp_path)
+    got = top.main([str(data), "--shrink", "2", "--blend", "linear"])
+    shrunk = [lo.shrink(imgs[i], 2) for i in order]
+    want = oracle.stitch(shrunk, [rots[i] for i in order], [small_intr[i] for i in order], "linear")
+    assert np.array_equal(got, want)
+    os.remove(tmp_path / "ba_RIG_s2.0.pkl")
+    with pytest.raises(SystemExit, match="4 images read and shrunk"):
+        top.main([str(data), "--shrink", "2"])
+
+
 # ------------------------------------------------------------------- crop
 def test_crop_rectangles_bit_exact(eng, oracle):
     import torch

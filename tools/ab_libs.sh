@@ -7,7 +7,7 @@ mkdir -p gpurun_out/ab; LOG=gpurun_out/ab/log_$WL.txt; : > "$LOG"
 for r in $(seq "$REPS"); do
   for v in "$@"; do
     if [ "$v" = base ]; then LIB=""; else LIB=$PWD/build/variants/$v/libpano360_hip.so; fi
-    PANO_LIB=$LIB timeout -k 10 300 python bench.py --workload "$WL" --steps 20 --warmup 3 --no-cpu-baseline 2>gpurun_out/ab/err_$v.txt | python -c "
+    PANO_LIB=$LIB timeout -k 10 300 python bench.py --workload "$WL" --steps 20 --warmup 3 --no-cpu-baseline --no-secondary 2>gpurun_out/ab/err_$v.txt | python -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1]); k=d['kernel_ms_per_step']
 print('$v', d['ms_per_step'], k.get('blur_mfma_kernel', 0), k.get('multiband_compose_kernel', 0), k.get('warp_windows_kernel', 0))" >> "$LOG" || echo "$v FAILED" >> "$LOG"

@@ -15,7 +15,7 @@ echo "== smoke"
 timeout -k 10 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3 | tee "$OUT/smoke.log"
 for wl in cfg2 cfg3 cfg4; do
   echo "== bench $wl"
-  extra="--no-cpu-baseline"; [ "$MODE" = full ] && extra=""
+  extra="--no-cpu-baseline --no-secondary"; [ "$MODE" = full ] && extra="--no-secondary"
   timeout -k 10 900 python bench.py --workload $wl --steps 20 --warmup 3 $extra 2> "$OUT/bench_$wl.err" | tail -1 > "$OUT/bench_$wl.json"
   python - "$OUT/bench_$wl.json" <<'P'
 import json, sys
@@ -35,7 +35,7 @@ if [ "$MODE" = full ]; then
   echo "== rocprof"
   HERE=$PWD
   cd /tmp
-  timeout -k 10 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$HERE/$OUT/prof_cfg3" -- python3 "$HERE/bench.py" --steps 5 --warmup 2 --no-cpu-baseline > "$HERE/$OUT/rocprof.log" 2>&1
+  timeout -k 10 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$HERE/$OUT/prof_cfg3" -- python3 "$HERE/bench.py" --steps 5 --warmup 2 --no-cpu-baseline --no-secondary > "$HERE/$OUT/rocprof.log" 2>&1
   cd "$HERE"
   f=$(find "$OUT/prof_cfg3" -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cut -c1-160 "$f"
   find "$OUT/prof_cfg3" -name "*kernel_trace.csv" -size +20M -delete
