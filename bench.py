@@ -111,6 +111,7 @@ def algorithmic_bytes(plan, patches, n_levels, px_active):
             (p.area[1] - p.area[0]), (p.area[3] - p.area[2])) for p in patches]
     px_cols = px_active or sum(ah * aw for vh, vw, ah, aw in win)   # blurred / gathered pixels
     px_warp = sum(vh * vw for vh, vw, ah, aw in win)                # warped pixels (V)
+    px_rows = sum(vh * aw for vh, vw, ah, aw in win)                # row-pass pixels (VALU blur)
     return {
         # 3 float planes written + the frame bytes under the window (about 1:1 scale)
         "warp_windows_kernel": 12.0 * px_warp + 3.0 * px_warp,
@@ -123,8 +124,12 @@ def algorithmic_bytes(plan, patches, n_levels, px_active):
         # and owner map (2 B) read over V, L-1 blurred RGBA copies written over the active
         # tiles; the intermediate image never reaches memory
         "blur_mfma_kernel": 14.0 * px_warp + 16.0 * (n_levels - 1) * px_cols,
-    }, dict(px_warp=px_warp, px_cols=px_cols,
-            px_rows=sum(vh * aw for vh, vw, ah, aw in win))
+        # the float32 vector-ALU form (Engine(blur="valu")): the row pass reads the planes and
+        # the owner map over V and writes L-1 RGBA row-pass images (V rows x A columns), the
+        # column pass reads those and writes the blurred copies over A
+        "blur_rows_kernel": 14.0 * px_warp + 16.0 * (n_levels - 1) * px_rows,
+        "blur_cols_kernel": 16.0 * (n_levels - 1) * (px_rows + px_cols),
+    }, dict(px_warp=px_warp, px_cols=px_cols, px_rows=px_rows)
 
 
 def roofline_for(times, plan, patches, n_levels, steps, px_active, workload=None):
