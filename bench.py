@@ -391,7 +391,7 @@ def secondary_single_gpu(eng, fence):
     from pano360_amd import engine, synth
     out = {}
 
-    def stitches(name, steps, warmup, distinct=None, use=None):
+    def stitches(name, steps, warmup, distinct=None, use=None, cached=False):
         use = use or eng
         cfg = workload(name)
         rots, intrs = synth.make_cameras(cfg["n"], cfg["width"], cfg["height"],
@@ -404,7 +404,8 @@ def secondary_single_gpu(eng, fence):
         frames = [pool[i % k] for i in range(cfg["n"])]
 
         def step():
-            plan = engine.Plan(shapes, rots, intrs, True, NATIVE)
+            plan = (use.cached_plan(shapes, rots, intrs, True, NATIVE) if cached
+                    else engine.Plan(shapes, rots, intrs, True, NATIVE))
             mosaic, _, _, patches = use.stitch(frames, plan, "multiband", cfg["n_levels"])
             return plan, mosaic, list(patches)
         for _ in range(3):
@@ -439,6 +440,13 @@ def secondary_single_gpu(eng, fence):
             out[key] = {"error": repr(err)[:300]}
             torch.cuda.synchronize()
 
+    def cached():
+        entry = stitches("cfg3", 20, 3, cached=True)
+        entry["what"] = ("config 3 with the host geometry of the (unchanged) cameras kept from "
+                         "stitch to stitch (Engine.cached_plan) instead of recomputed per stitch as "
+                         "the reference does (stitcher.py:276-302) and as the headline does")
+        return entry
+    guarded("cfg3_plan_cached", cached)
     guarded("cfg2", lambda: stitches("cfg2", 20, 3))
 
     def cfg4(detect):

@@ -533,6 +533,66 @@ size_t pano_knn2_work_bytes(int nq, int nt, int d);
 int pano_knn2(pano_ctx *ctx, const float *query, int nq, const float *train, int nt, int d,
               float scale, void *work, int32_t *idx, float *dist, int *rescans);
 
+/* One multiband stitch of the mosaic columns [xs0, xs1), queued by ONE call
+ *                                                  stitcher.py:283-327 (equalize and crop aside)
+ * = pano_ownership_cameras, pano_owned_regions (+ its copy to the host), pano_interior_map,
+ * the one wait of a stitch, pano_layout_windows / pano_layout_place, the upload of the record
+ * table, [pano_blur_tiles,] pano_warp_windows, pano_multiband_blur, pano_multiband_compose in
+ * that order on the context's stream: the launch sequence of a stitch without a round trip
+ * through the caller's language per launch (a dozen ctypes calls cost 0.3 ms per stitch,
+ * as much as one GPU's share of the kernels when eight GPUs split a 4K panorama).
+ * The caller owns every buffer; `args` says where they are and how large:
+ *   cams               dev [n] records (frames NULL where not resident, see have)
+ *   rects, have        host int32 [n][4] = (y0, y1, x0, x1) / host uint8 [n] (or NULL)
+ *   [own0, own1)       columns to evaluate ownership on: the strip grown by what the interior
+ *                      test and the windows look at (the whole mosaic: 0, W)
+ *   taps, ntaps        host tap tables of the n_levels - 1 Gaussians (layout: pano_multiband_blur)
+ *   shortcut           1 = interior map on (pano_interior_map, the compose's interior pixels)
+ *   warp_need          1 = warp only the blocks anything reads (pano_blur_tiles), 0 = all of V,
+ *                      -1 = decide by the mean width of the rectangles A (>= 768 columns)
+ *   owner, valid       dev int16 / uint8 [H][W]: results
+ *   marks, regions     dev workspaces of pano_owned_regions; regions_host: PINNED host copy
+ *   block_owner, interior   dev workspaces of pano_interior_map
+ *   records_host       PINNED host pano_patch [cap_records], cap_records >= n * max_spans
+ *   table              dev pano_patch [cap_records]
+ *   planes, blurred, scratch (+ their sizes in floats), tile_flags, need (cap_tiles bytes each)
+ *   mosaic (+ optional mosaic_f32)   dev [H][W][3]: only columns [xs0, xs1) are written
+ * Returns PANO_OK; PANO_EGROW (positive, not an error) when an arena or the tile arrays are too
+ * small for this stitch: args->layout then says what is needed, everything up to the wait has
+ * been queued, and the call is repeated with resume = 1 after the caller has grown them; or a
+ * negative error (args->layout.missing > 0: a needed frame is not resident). */
+#define PANO_EGROW 1
+typedef struct pano_stitch_args {
+    const pano_camera *cams;
+    const int32_t *rects;
+    const uint8_t *have;
+    const double *sin_t, *cos_t, *tan_p;
+    const float *lut;
+    const float *taps;
+    const int32_t *ntaps;
+    int16_t *owner;
+    uint8_t *valid;
+    uint8_t *marks;
+    int32_t *regions;
+    int32_t *regions_host;
+    int16_t *block_owner;
+    uint8_t *interior;
+    pano_patch *records_host;
+    pano_patch *table;
+    float *planes, *blurred, *scratch;
+    uint8_t *tile_flags, *need;
+    uint8_t *mosaic;
+    float *mosaic_f32;
+    int64_t planes_floats, blurred_floats, scratch_floats;
+    int32_t n, H, W, xs0, xs1, own0, own1;
+    int32_t lut_stride, n_levels, radius, shortcut, warp_need, max_spans, min_gap;
+    int32_t cap_records, cap_tiles;
+    int32_t used_need;         /* out: 1 = the warp ran on the need flags */
+    int32_t reserved;
+    pano_layout layout;        /* out */
+} pano_stitch_args;
+int pano_stitch_multiband(pano_ctx *ctx, pano_stitch_args *args, int resume);
+
 #ifdef __cplusplus
 }
 #endif

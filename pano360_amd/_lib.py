@@ -47,6 +47,23 @@ class Layout(C.Structure):
                 ("max_ah", C.c_int32), ("missing", C.c_int32)]
 
 
+class StitchArgs(C.Structure):
+    """``pano_stitch_args`` of include/pano360.h."""
+    _fields_ = ([(k, C.c_void_p) for k in (
+        "cams", "rects", "have", "sin_t", "cos_t", "tan_p", "lut", "taps", "ntaps", "owner",
+        "valid", "marks", "regions", "regions_host", "block_owner", "interior", "records_host",
+        "table", "planes", "blurred", "scratch", "tile_flags", "need", "mosaic", "mosaic_f32")]
+        + [(k, C.c_int64) for k in ("planes_floats", "blurred_floats", "scratch_floats")]
+        + [(k, C.c_int32) for k in (
+            "n", "H", "W", "xs0", "xs1", "own0", "own1", "lut_stride", "n_levels", "radius",
+            "shortcut", "warp_need", "max_spans", "min_gap", "cap_records", "cap_tiles",
+            "used_need", "reserved")]
+        + [("layout", Layout)])
+
+
+EGROW = 1       # pano_stitch_multiband: an arena is too small, args.layout says what is needed
+
+
 class Pair(C.Structure):
     """``pano_pair`` of include/pano360.h (80 bytes)."""
     _fields_ = [("minv", C.c_double * 9), ("i", C.c_int32), ("j", C.c_int32)]
@@ -128,6 +145,7 @@ _SIGNATURES = {
     "pano_sift_sort_unique": (_i, [_vp, _vp, _i, _vp, _i, _vp, _vp, _vp]),
     "pano_knn2_work_bytes": (C.c_size_t, [_i, _i, _i]),
     "pano_knn2": (_i, [_vp, _vp, _i, _vp, _i, _i, C.c_float, _vp, _vp, _vp, _vp]),
+    "pano_stitch_multiband": (_i, [_vp, _vp, _i]),
 }
 EXPORTS = tuple(_SIGNATURES)
 

@@ -99,6 +99,10 @@ struct pano_ctx {
     int prepared_n, flags_n;
     std::vector<PanoTapSet> tap_sets;
     uint64_t tick;
+    // pano_stitch_multiband: the regions' copy has landed / the record table has left the
+    // caller's pinned buffer
+    hipEvent_t ev_regions, ev_upload;
+    bool upload_pending;
 };
 
 int pano_ctx_enter(pano_ctx *ctx);

@@ -201,10 +201,13 @@ class ShardedStitcher:
     comes back from the same call (rank 0), the last one from ``finish()``."""
 
     def __init__(self, eng, shapes, rots, intrs, n_levels, rank, world, max_resolution=10 ** 9,
-                 group=None, exchange="gather", depth=2):
+                 group=None, exchange="gather", depth=2, cache_plan=False):
         self.eng, self.rank, self.world, self.group = eng, rank, world, group
         self.shapes, self.rots, self.intrs = shapes, rots, intrs
         self.n_levels, self.max_resolution = n_levels, max_resolution
+        # cache_plan: the host geometry of the (unchanged) cameras is computed once and kept
+        # (Engine.cached_plan) instead of once per stitch as the reference does
+        self.cache_plan = cache_plan
         plan = _eng.Plan(shapes, rots, intrs, True, max_resolution)
         radius = max([_eng.gaussian_ksize(s) // 2 for s in _eng.level_sigmas(n_levels)],
                      default=0)
@@ -226,9 +229,13 @@ class ShardedStitcher:
         if ex is None:
             raise RuntimeError("ShardedStitcher(exchange=None) holds the strip geometry only "
                                "(emulate_on_one_device); step() needs an exchange mode")
-        plan = _eng.Plan(self.shapes, self.rots, self.intrs, True, self.max_resolution,
-                         table_cols=self.table_cols)
-        self.eng.upload_plan(plan)
+        if self.cache_plan:
+            plan = self.eng.cached_plan(self.shapes, self.rots, self.intrs, True,
+                                        self.max_resolution, self.table_cols)
+        else:
+            plan = _eng.Plan(self.shapes, self.rots, self.intrs, True, self.max_resolution,
+                             table_cols=self.table_cols)
+            self.eng.upload_plan(plan)
         ex.recycle()
         _, _, _, patches = self.eng.multiband_fused(
             frames, plan, self.n_levels, frame_ids=self.my_frames, strip=self.strip,

@@ -9,6 +9,7 @@ resolution), :283-302 (mosaic shape, patch rectangles, angle grids), :218
 (level sigmas); OpenCV's getGaussianKernel for the taps (host, 33..97 floats).
 """
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -539,6 +540,19 @@ class FusedPatches:
         self.table = PatchTable.from_layout(rec, lay, eng)
         return self
 
+    @classmethod
+    def from_records(cls, rec, lay, table_dev, arenas):
+        """Records laid out and uploaded by ``pano_stitch_multiband`` (a host copy of them)."""
+        self = cls.__new__(cls)
+        self.planes, self.blurred, self.scratch = arenas
+        self._area = self._window = None
+        table = PatchTable.__new__(PatchTable)
+        table.host, table.n, table.n_tiles, table.dev = rec, len(rec), int(lay.n_tiles), table_dev
+        table.max_vw, table.max_vh, table.max_aw, table.max_ah = (
+            int(lay.max_vw), int(lay.max_vh), int(lay.max_aw), int(lay.max_ah))
+        self.table = table
+        return self
+
     def _rectangles(self):
         if self._area is None:
             h = self.table.host
@@ -666,6 +680,11 @@ class Engine:
         self.overlap_prepare = side_stream in (1, 2)
         self.warp_need = "auto"     # "auto" | True | False: see multiband_fused
         self._cam_template = None
+        # the whole launch sequence of a fused stitch in one native call (pano_stitch_multiband);
+        # False: launch by launch from here (the same entry points; what the side streams use)
+        self.native_stitch = side_stream == 0 and os.environ.get("PANO_NATIVE_STITCH", "1") != "0"
+        self._stitch_ws = {}
+        self._plans = {}
 
     def __del__(self):
         ctx, self._ctx = getattr(self, "_ctx", None), None
@@ -755,6 +774,24 @@ class Engine:
         return [im.to(self.device) if isinstance(im, torch.Tensor) else
                 torch.from_numpy(np.ascontiguousarray(im, np.uint8)).to(self.device)
                 for im in imgs]
+
+    def cached_plan(self, shapes, rots, intrs, padded, max_resolution, table_cols=None):
+        """The uploaded ``Plan`` of these cameras, kept from stitch to stitch: a rig that does
+        not move stitches every time step with the same geometry, and the float64 plan is a
+        fifth of a 4K stitch's time on the host.  Keyed on the VALUES (shapes, rotations,
+        calibrations, padding, resolution cap, table columns); the reference recomputes all of
+        it per stitch (stitcher.py:276-302), which is what ``Plan(...)`` per stitch does."""
+        key = (tuple(tuple(int(v) for v in sh) for sh in shapes),
+               np.asarray(rots, np.float64).tobytes(), np.asarray(intrs, np.float64).tobytes(),
+               bool(padded), float(max_resolution),
+               None if table_cols is None else (int(table_cols[0]), int(table_cols[1])))
+        plan = self._plans.get(key)
+        if plan is None:
+            if len(self._plans) >= 8:
+                self._plans.pop(next(iter(self._plans)))
+            plan = self._plans[key] = self.upload_plan(
+                Plan(shapes, rots, intrs, padded, max_resolution, table_cols))
+        return plan
 
     def upload_plan(self, plan):
         """Trig tables to the device: one asynchronous copy out of a pinned staging
@@ -1013,6 +1050,9 @@ class Engine:
         # stitch to stitch; the projections and rectangles are filled column-wise
         key = (tuple(plan.shapes),
                tuple(sorted((i, f.data_ptr()) for i, f in frames.items())) if frames else ())
+        kept = getattr(plan, "_cams", None)
+        if kept is not None and kept[0] == key and kept[1] is self:
+            return kept[2]                  # same plan object, same frames: the table is up
         if self._cam_template is None or self._cam_template[0] != key:
             rec = np.zeros(plan.n, dtype=CAMERA_DTYPE)
             for i in range(plan.n):
@@ -1027,7 +1067,9 @@ class Engine:
         rects = np.asarray(plan.rects, np.int32)
         rec["y0"], rec["x0"] = rects[:, 0], rects[:, 2]
         rec["h"], rec["w"] = rects[:, 1] - rects[:, 0], rects[:, 3] - rects[:, 2]
-        return self.to_device(rec)
+        dev = self.to_device(rec)
+        plan._cams = (key, self, dev)
+        return dev
 
     def ownership_cameras(self, plan, strip=None, out=None, cams=None):
         """owner / valid of the mosaic (or of the column strip [xs0, xs1)) from the
@@ -1113,6 +1155,9 @@ class Engine:
         ids = list(range(plan.n)) if frame_ids is None else list(frame_ids)
         have = dict(zip(ids, frames))
         cams = self.camera_table(plan, have)
+        if self.native_stitch:
+            return self._stitch_native(plan, cams, have, n_levels, want_float, (c0, c1), ext,
+                                       shortcut, luts, mosaic_out)
         owner, valid = self.ownership_cameras(plan, strip=ext, cams=cams)
         # one record per (patch, span of columns it owns): spans farther apart than
         # 2R keep disjoint rectangles A, so a pixel still meets a patch at most once.
@@ -1163,6 +1208,102 @@ class Engine:
         mosaic, fl = self.blur_and_compose(table, owner, valid, plan.shape, n_levels,
                                            want_float, (c0, c1), interior, cams, plan, luts,
                                            out=early, prepared=prepared, mosaic_out=mosaic_out)
+        return mosaic, fl, valid, patches
+
+    def _stitch_workspace(self, H, W, n, max_spans):
+        """Buffers of the native stitch that no caller sees, kept per mosaic shape."""
+        torch = _torch()
+        key = (H, W, n, max_spans)
+        ws = self._stitch_ws.get(key)
+        if ws is None:
+            if len(self._stitch_ws) >= 4:
+                self._stitch_ws.clear()
+            ib = self.interior_block
+            shape8 = ((H + ib - 1) // ib, (W + ib - 1) // ib)
+            dev = self.device
+            stride = 5 + 2 * max_spans
+            cap = n * max_spans
+            ws = dict(
+                marks=torch.empty((n, W), dtype=torch.uint8, device=dev),
+                regions=torch.empty((n, stride), dtype=torch.int32, device=dev),
+                regions_host=torch.empty((n, stride), dtype=torch.int32).pin_memory(),
+                bown=torch.empty((2,) + shape8, dtype=torch.int16, device=dev),
+                interior=torch.empty(shape8, dtype=torch.uint8, device=dev),
+                records_host=torch.empty(cap * PATCH_DTYPE.itemsize, dtype=torch.uint8).pin_memory(),
+                table=torch.empty(cap * PATCH_DTYPE.itemsize, dtype=torch.uint8, device=dev),
+                cap=cap, tiles=None, need=None, cap_tiles=0, have=np.zeros(n, np.uint8),
+                args=_lib.StitchArgs())
+            self._stitch_ws[key] = ws
+        return ws
+
+    def _stitch_native(self, plan, cams, have, n_levels, want_float, strip, ext, shortcut, luts,
+                       mosaic_out):
+        """``multiband_fused`` through ``pano_stitch_multiband``: one native call queues the
+        whole stitch (and waits once, for the owned regions)."""
+        torch = _torch()
+        H, W = plan.shape
+        taps, ntaps, n_blur, radius = self.blur_tables(n_levels)
+        max_spans = 4
+        ws = self._stitch_workspace(H, W, plan.n, max_spans)
+        a = ws["args"]
+        owner = torch.empty((H, W), dtype=torch.int16, device=self.device)
+        valid = torch.empty((H, W), dtype=torch.uint8, device=self.device)
+        mosaic = (mosaic_out if mosaic_out is not None else
+                  torch.empty((H, W, 3), dtype=torch.uint8, device=self.device))
+        fl = (torch.empty((H, W, 3), dtype=torch.float32, device=self.device)
+              if want_float else None)
+        resident = ws["have"]
+        resident[:] = 0
+        resident[[i for i in have if 0 <= i < plan.n]] = 1
+        rects32 = np.ascontiguousarray(plan.rects, np.int32)
+        lut, lut_stride = self._lut_args(luts)
+        ptr = lambda t: t.data_ptr() if t is not None else None   # noqa: E731
+        a.cams, a.rects, a.have = ptr(cams), rects32.ctypes.data, resident.ctypes.data
+        a.sin_t, a.cos_t, a.tan_p = (ptr(t) for t in plan.dev)
+        a.lut, a.lut_stride = lut, lut_stride
+        a.taps, a.ntaps = taps.ctypes.data, C.cast(ntaps, C.c_void_p)
+        a.owner, a.valid, a.mosaic, a.mosaic_f32 = ptr(owner), ptr(valid), ptr(mosaic), ptr(fl)
+        a.marks, a.regions, a.regions_host = ptr(ws["marks"]), ptr(ws["regions"]), ptr(ws["regions_host"])
+        a.block_owner, a.interior = ptr(ws["bown"]), ptr(ws["interior"])
+        a.records_host, a.table, a.cap_records = ptr(ws["records_host"]), ptr(ws["table"]), ws["cap"]
+        a.n, a.H, a.W = plan.n, H, W
+        a.xs0, a.xs1, a.own0, a.own1 = strip[0], strip[1], ext[0], ext[1]
+        a.n_levels, a.radius, a.shortcut = n_levels, radius, 1 if shortcut else 0
+        a.warp_need = {True: 1, False: 0}.get(self.warp_need, -1)
+        a.max_spans, a.min_gap = max_spans, 2 * radius + 2
+        resume = 0
+        while True:
+            arenas = [self._arenas.get(k) for k in ("planes", "blurred", "scratch")]
+            for k, t in zip(("planes", "blurred", "scratch"), arenas):
+                setattr(a, k, ptr(t))
+                setattr(a, k + "_floats", t.numel() - 64 if t is not None else 0)
+            a.tile_flags, a.need, a.cap_tiles = ptr(ws["tiles"]), ptr(ws["need"]), ws["cap_tiles"]
+            status = self.lib.pano_stitch_multiband(self.ctx(), C.byref(a), resume)
+            if status != _lib.EGROW:
+                break
+            lay = a.layout                  # grow what is too small, then resume behind the wait
+            self.arena("planes", int(lay.planes_floats) + 64)
+            self.arena("blurred", int(lay.blurred_floats) + 64)
+            self.arena("scratch", int(lay.scratch_floats) + 64)
+            if lay.n_tiles > ws["cap_tiles"]:
+                ws["cap_tiles"] = int(lay.n_tiles * 1.25) + 64
+                ws["tiles"] = torch.empty(ws["cap_tiles"], dtype=torch.uint8, device=self.device)
+                ws["need"] = torch.empty(ws["cap_tiles"], dtype=torch.uint8, device=self.device)
+            resume = 1
+        if status != 0:
+            if a.layout.missing:
+                rec = ws["records_host"].numpy().view(PATCH_DTYPE)[:a.layout.n_records]
+                missing = sorted({int(i) for i in rec["index"] if not resident[int(i)]})
+                raise _lib.PanoError(f"frames {missing} are needed for columns [{strip[0]}, "
+                                     f"{strip[1]}) but are not resident on this device")
+            _lib.check(status, "pano_stitch_multiband")
+        lay = a.layout
+        rec = ws["records_host"].numpy().view(PATCH_DTYPE)[:lay.n_records].copy()
+        patches = FusedPatches.from_records(
+            rec, lay, ws["table"][:lay.n_records * PATCH_DTYPE.itemsize],
+            tuple(self._arenas.get(k) for k in ("planes", "blurred", "scratch")))
+        if n_blur:
+            self.last_tiles = (patches.table, ws["tiles"] if shortcut else None)
         return mosaic, fl, valid, patches
 
     def blend_fused(self, frames, plan, linear, frame_ids=None, strip=None, luts=None):
