@@ -40,6 +40,10 @@ class _HostEngine:
     def upload_plan(self, plan):
         return plan
 
+    def cached_plan(self, shapes, rots, intrs, padded, max_resolution, table_cols=None):
+        self.cached = getattr(self, "cached", 0) + 1        # Engine.cached_plan's signature
+        return engine.Plan(shapes, rots, intrs, padded, max_resolution, table_cols)
+
     def multiband_fused(self, frames, plan, n_levels, frame_ids=None, strip=None,
                         mosaic_out=None, **_):
         assert tuple(mosaic_out.shape[:2]) == self.shape == tuple(plan.shape)
@@ -54,7 +58,7 @@ def _scene():
     return [(90, 160)] * 5, rots, intrs
 
 
-def _worker(rank, world, port, mode, depth, result):
+def _worker(rank, world, port, mode, depth, result, cache_plan=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -63,7 +67,7 @@ def _worker(rank, world, port, mode, depth, result):
         eng = _HostEngine(shape)
         # the bench's strips step: ShardedStitcher over the process group, K steps, finish
         st = pdist.ShardedStitcher(eng, shapes, rots, intrs, 5, rank, world, exchange=mode,
-                                   depth=depth)
+                                   depth=depth, cache_plan=cache_plan)
         assert st.exchange.world == dist.get_world_size() == world
         got = []
         for _ in range(5):
@@ -73,6 +77,7 @@ def _worker(rank, world, port, mode, depth, result):
         last = st.finish()
         if last is not None:
             got.append(last.clone())
+        assert getattr(eng, "cached", 0) == (5 if cache_plan else 0)
         if rank == 0:
             ok = len(got) == 5 and all(torch.equal(m, eng.truth(k)) for k, m in enumerate(got))
             result.put(bool(ok))
@@ -105,6 +110,23 @@ def test_sharded_steps_over_gloo(mode, depth, world):
     result = ctx.SimpleQueue()
     mp.spawn(_worker, args=(world, _free_port(), mode, depth, result), nprocs=world, join=True)
     assert result.get() is True
+
+
+def test_sharded_steps_with_the_cached_plan_over_gloo():
+    """The same steps with the host geometry kept from stitch to stitch (bench.py's
+    `plan cached` figure): every step asks the engine's cache, the mosaics are the same."""
+    ctx = mp.get_context("spawn")
+    result = ctx.SimpleQueue()
+    mp.spawn(_worker, args=(2, _free_port(), "gather", 2, result, True), nprocs=2, join=True)
+    assert result.get() is True
+
+
+def test_exchange_without_a_mode_is_refused_in_step():
+    shapes, rots, intrs = _scene()
+    shape = engine.Plan(shapes, rots, intrs, True, 10 ** 9).shape
+    st = pdist.ShardedStitcher(_HostEngine(shape), shapes, rots, intrs, 5, 0, 2, exchange=None)
+    with pytest.raises(RuntimeError, match="geometry only"):
+        st.step(None)
 
 
 def test_exchange_world_1_needs_no_process_group():

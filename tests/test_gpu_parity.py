@@ -1022,6 +1022,46 @@ def test_shrink_matches_resize_oracle(eng, shrink):
     assert blend.shrink_images([img], 1)[0].shape == img.shape
 
 
+def test_native_stitch_equals_the_launch_by_launch_path(oracle):
+    """``pano_stitch_multiband`` (one native call per stitch: the default) against the same
+    entry points called one by one from Python: same mosaic, float mosaic, valid map and
+    records, bit for bit - whole mosaic, column strips (frames resident where needed only),
+    a first call whose arenas must grow (the EGROW / resume round trip) and a missing frame."""
+    import torch
+    from pano360_amd import _lib, engine, synth
+    imgs, rots, intrs = synth.make_scene(6, 320, 180, sweep_deg=100.0, jitter=0.01, seed=3, kind="B")
+    shapes = [im.shape[:2] for im in imgs]
+    native, plain = engine.Engine(), engine.Engine()
+    plain.native_stitch = False
+    assert native.native_stitch
+    for levels in (5, 3, 1):
+        for shortcut in (True, False):
+            out = []
+            for e in (native, plain):
+                plan = e.upload_plan(engine.Plan(shapes, rots, intrs, True, 10 ** 9))
+                mosaic, fl, valid, patches = e.multiband_fused(e.upload_frames(imgs), plan, levels,
+                                                               want_float=True, shortcut=shortcut)
+                out.append((mosaic.cpu(), fl.cpu(), valid.cpu(), patches.table.host.copy()))
+            assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1])
+            assert torch.equal(out[0][2], out[1][2])
+            for key in ("y0", "x0", "vy0", "vx0", "vh", "vw", "ay0", "ax0", "ah", "aw", "index",
+                        "tiles_off", "vpitch", "apitch"):
+                assert np.array_equal(out[0][3][key], out[1][3][key]), key
+    whole = out[0][0]
+    plan = native.upload_plan(engine.Plan(shapes, rots, intrs, True, 10 ** 9))
+    W = plan.shape[1]
+    target = torch.zeros(plan.shape + (3,), dtype=torch.uint8, device=native.device)
+    from pano360_amd import dist as pdist
+    for rank in range(3):
+        st = pdist.ShardedStitcher(native, shapes, rots, intrs, 1, rank, 3, exchange=None)
+        frames = native.upload_frames([imgs[i] for i in st.my_frames])
+        native.multiband_fused(frames, plan, 1, frame_ids=st.my_frames, strip=st.strip,
+                               mosaic_out=target)
+    assert torch.equal(target.cpu(), whole)
+    with pytest.raises(_lib.PanoError, match="not resident"):
+        native.multiband_fused(native.upload_frames(imgs[:2]), plan, 5, frame_ids=[0, 1])
+
+
 @pytest.mark.parametrize("mode", [1, 2])
 def test_side_stream_modes_give_the_same_mosaic(eng, mode):
     """``Engine(side_stream=...)``: 2 = the blur's tile flags and work list are made on a second

@@ -31,13 +31,17 @@ def test_library_exports_every_declared_symbol():
         src = os.path.join(tmp, "sz.c")
         with open(src, "w") as fid:
             fid.write('#include <stdio.h>\n#include "pano360.h"\nint main(void){'
-                      'printf("%zu %zu %zu", sizeof(pano_patch), sizeof(pano_camera), '
-                      'sizeof(pano_pair));return 0;}')
+                      'printf("%zu %zu %zu %zu %zu %zu", sizeof(pano_patch), sizeof(pano_camera), '
+                      'sizeof(pano_pair), sizeof(pano_stitch_args), sizeof(pano_layout), '
+                      '__builtin_offsetof(pano_stitch_args, layout));return 0;}')
         exe = os.path.join(tmp, "sz")
         subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), src, "-o", exe])
         sizes = [int(v) for v in subprocess.check_output([exe]).split()]
-    assert sizes == [ctypes.sizeof(_lib.Patch), ctypes.sizeof(_lib.Camera),
-                     ctypes.sizeof(_lib.Pair)] == [96, 120, 80]
+    assert sizes[:3] == [ctypes.sizeof(_lib.Patch), ctypes.sizeof(_lib.Camera),
+                         ctypes.sizeof(_lib.Pair)] == [96, 120, 80]
+    # the argument record of pano_stitch_multiband, field for field
+    assert sizes[3:] == [ctypes.sizeof(_lib.StitchArgs), ctypes.sizeof(_lib.Layout),
+                         _lib.StitchArgs.layout.offset]
 
 
 def test_header_constants_match_binding():
