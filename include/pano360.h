@@ -38,8 +38,9 @@
  * patch therefore carries two sub-rectangles, in patch-local coordinates:
  *   A = bounding box of its owned pixels grown by the largest radius R
  *       (clipped to the patch): where blurred copies exist and are gathered;
- *   V = A grown by R again (closed under the REFLECT_101 border rule): where
- *       the warped colour is needed as blur input.
+ *   V = A grown by R again (closed under the REFLECT_101 border rule, its
+ *       columns rounded outwards to multiples of 4 and clipped to the patch):
+ *       where the warped colour is needed as blur input.
  * Both default to the whole patch (the stage-level blender API).
  */
 #ifndef PANO360_H
@@ -159,12 +160,18 @@ int pano_interior_block(void);
  *                         rigorous bounds exclude; 0 = evaluate every camera
  *   PANO_OPT_BLUR_SEGMENTS  matrix-core blur: 1 (default) = when a launch has too few column
  *                         strips to fill the CUs (one GPU's share of a panorama, small
- *                         scenes) each strip is cut into vertical segments; 0 = never */
+ *                         scenes) each strip is cut into vertical segments; 0 = never
+ *   PANO_OPT_BLUR_LEAN    matrix-core blur: 1 (default) = the work items whose bands need no
+ *                         special case (no reflected columns, whole chunks, one reflection
+ *                         of the rows at most) run through a kernel with a short instruction
+ *                         stream, the rest through the general one; 0 = the general kernel
+ *                         for everything.  Same results bit for bit. */
 typedef struct pano_ctx pano_ctx;
 #define PANO_OPT_BLUR_KERNEL 0
 #define PANO_OPT_OWN_PRUNE 1
 #define PANO_OPT_BLUR_SEGMENTS 2
-#define PANO_OPT_COUNT 3
+#define PANO_OPT_BLUR_LEAN 3
+#define PANO_OPT_COUNT 4
 #define PANO_BLUR_MFMA 0
 #define PANO_BLUR_VALU 1
 int pano_ctx_create(int device, void *stream, pano_ctx **out);

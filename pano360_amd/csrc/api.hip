@@ -50,6 +50,7 @@ extern "C" int pano_ctx_create(int device, void *stream, pano_ctx **out) {
     ctx->opt[PANO_OPT_BLUR_KERNEL] = PANO_BLUR_MFMA;
     ctx->opt[PANO_OPT_OWN_PRUNE] = 1;
     ctx->opt[PANO_OPT_BLUR_SEGMENTS] = 1;
+    ctx->opt[PANO_OPT_BLUR_LEAN] = 1;
     *out = ctx;
     return PANO_OK;
 }
@@ -322,6 +323,12 @@ extern "C" int pano_layout_windows(int tile_grid, const int32_t *regions, int n,
             vy1 = vy1 > ay1 ? vy1 : ay1;
             vx0 = vx0 < ax0 ? vx0 : ax0;
             vx1 = vx1 > ax1 ? vx1 : ax1;
+            // both ends on multiples of 4 patch columns (the far one clipped to the patch): the
+            // blur stages its bands in aligned chunks of 4 columns, and a chunk is then inside V
+            // or outside it as a whole
+            vx0 &= ~3l;
+            vx1 = (vx1 + 3) & ~3l;
+            vx1 = vx1 < w ? vx1 : w;
             PANO_REQUIRE(k < cap, "pano_layout_windows: more than %d records", cap);
             if (have && !have[i]) ++lay.missing;
             pano_patch &r = records[k++];

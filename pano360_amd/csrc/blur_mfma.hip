@@ -153,6 +153,16 @@ struct MbGeom {
     int gx0, ntx, O0, O1;           // tile grid of rectangle A (patch coordinates / 32)
 };
 
+// A work item the lean kernel takes (blur_lean_kernel, below): its bands lie inside the patch
+// (no reflected columns), a chunk of 4 columns is inside window V or outside it as a whole,
+// and a row reflects at most once.
+__host__ __device__ static inline bool mb_item_regular(const pano_patch &p, int gx0, int tx0,
+                                                       int cm) {
+    const int X0 = gx0 + 32 * tx0;
+    return X0 - 16 * cm >= 0 && X0 + 64 + 16 * cm <= p.w && (p.vx0 & 3) == 0 &&
+           (((p.vx0 + p.vw) & 3) == 0 || p.vx0 + p.vw == p.w) && p.h >= 128;
+}
+
 __device__ __forceinline__ MbGeom mb_geom(const pano_patch &p) {
     MbGeom g;
     g.gx0 = (p.ax0 >> 5) << 5;
@@ -559,11 +569,10 @@ __global__ __launch_bounds__(128) void mb_tables_kernel(MbLevels L, unsigned cha
 }
 
 template <int GROUP>
-__global__ __launch_bounds__(MB_THREADS_OF(GROUP), 4 / GROUP) void blur_mfma_kernel(
-    const pano_patch *__restrict__ table, MbLevels L, const unsigned char *__restrict__ tables,
+__device__ __forceinline__ void mb_general(
+    const pano_patch *__restrict__ table, const MbLevels &L, const unsigned char *__restrict__ tables,
     const int16_t *__restrict__ owner, int W, const uint8_t *__restrict__ flags,
-    const int2 *__restrict__ items) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int2 *__restrict__ items, unsigned char *smem) {
     const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
     // the items - (record, first tile column of a pair) - are sorted by decreasing length
     // (mb_sort_kernel), so the hardware's in-order dispatch starts the long strips first
@@ -672,6 +681,461 @@ __global__ __launch_bounds__(MB_THREADS_OF(GROUP), 4 / GROUP) void blur_mfma_ker
         case 2: mb_body<2, GROUP>(p, ch, out_level, live, s_tx, s_ty, sh, owner, W, ntaps >> 1, tx0); break;
         case 3: mb_body<3, GROUP>(p, ch, out_level, live, s_tx, s_ty, sh, owner, W, ntaps >> 1, tx0); break;
         default: mb_body<4, GROUP>(p, ch, out_level, live, s_tx, s_ty, sh, owner, W, ntaps >> 1, tx0); break;
+    }
+}
+
+template <int GROUP>
+__global__ __launch_bounds__(MB_THREADS_OF(GROUP), 4 / GROUP) void blur_mfma_kernel(
+    const pano_patch *__restrict__ table, MbLevels L, const unsigned char *__restrict__ tables,
+    const int16_t *__restrict__ owner, int W, const uint8_t *__restrict__ flags,
+    const int2 *__restrict__ items) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    mb_general<GROUP>(table, L, tables, owner, W, flags, items, smem);
+}
+
+
+// =====================================================================================
+// The same blur with a lean instruction stream, for the work items it fits.
+//
+// blur_mfma_kernel above handles every case inside its step - bands whose rows reflect
+// several times, chunks that straddle the window's or the patch's edge, tiles wanted or not
+// one by one, a variable number of finished tiles per step - and pays for that generality on
+// every step: ~790 instructions per wave and 32-row step for 34 matrix products (counters of
+// rounds 2 and 3), 11 cycles each; the ablations of profiles/r03/notes.md show no unit and no
+// wait to blame, only the length of that stream.  This kernel runs the same arithmetic, tile
+// for tile and product for product (results are bit-identical, tests compare them), on the
+// items where all of that is static - "regular" items, mb_item_regular - and leaves the rest to
+// the kernel above (the host launches both over the same work list; each skips the other's
+// items):
+//  * the bands an item steps through are listed once, compacted, in LDS (band index and the
+//    two tile columns' wanted bits in one word): no search for the next wanted band, no
+//    flag words read and re-read inside the step;
+//  * a band's chunks are whole (window V ends on multiples of 4 columns, include/pano360.h)
+//    and its rows reflect at most once: a chunk's address is its row's offset plus a constant,
+//    which threads stage which chunk is wave-uniform;
+//  * the column pass adds a band's contribution to ALL tiles within reach (the unwanted ones
+//    are never stored; an item's inner bands want all of them anyway) with the accumulators
+//    addressed statically - one variant of the pass per value of t mod (2 DMAX + 1) - and a
+//    tile's first contribution takes a zero C operand instead of a cleared accumulator;
+//  * exactly one tile per step can finish, and it is stored at the start of the next step
+//    (behind that step's barriers, in front of its fetch): no bookkeeping of finished ranges.
+#ifndef MB_LEAN
+#define MB_LEAN 1
+#endif
+
+template <int C, int U>
+__device__ __forceinline__ void ml_colpass(f32x16 (&acc)[2 * ((C + 1) / 2) + 1],
+                                           const half8 (&m_hi)[2], const half8 (&m_lo)[2],
+                                           const half8 *s_ty, const int lane) {
+    constexpr int DMAX = (C + 1) / 2, NB = 2 * DMAX + 1;
+    constexpr int Z = C & 1;            // the outermost half-blocks are zero (odd C), not stored
+    f32x16 zero;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) zero[q] = 0.0f;
+#pragma unroll
+    for (int d = -DMAX; d <= DMAX; ++d) {
+        const int k = ((U - d) % NB + NB) % NB;          // tile t - d lives in accumulator k
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            if (Z && ((d == -DMAX && s == 0) || (d == DMAX && s == 1))) continue;
+            const half8 *ty = s_ty + (((d + DMAX) * 2 + s - Z) * 2) * 64 + lane;
+            const half8 t_hi = ty[0], t_lo = ty[64];
+            // the band's first contribution to tile t + DMAX starts its sum
+            const bool first = d == -DMAX && s == Z;
+            acc[k] = __builtin_amdgcn_mfma_f32_32x32x16_f16(t_hi, m_hi[s], first ? zero : acc[k], 0, 0, 0);
+            acc[k] = __builtin_amdgcn_mfma_f32_32x32x16_f16(t_lo, m_hi[s], acc[k], 0, 0, 0);
+            acc[k] = __builtin_amdgcn_mfma_f32_32x32x16_f16(t_hi, m_lo[s], acc[k], 0, 0, 0);
+        }
+    }
+}
+
+// Tile o of this wave's column (accumulator `a`) to its plane.
+__device__ __forceinline__ void ml_store(const f32x16 &a, const int o, const int lane,
+                                         const pano_patch &p, const __amdgpu_buffer_rsrc_t plane,
+                                         const int px0) {
+    const int n = lane & 31, h = lane >> 5;
+    const int ax = px0 + n - p.ax0, row0 = 32 * o + 4 * h - p.ay0;
+    const int rowstep = p.apitch * 4;
+    const unsigned base = (unsigned)(row0 * p.apitch + ax) * 4u;
+    const bool inside = 32 * o >= p.ay0 && 32 * o + 32 <= p.ay0 + p.ah && px0 >= p.ax0 &&
+                        px0 + 32 <= p.ax0 + p.aw;               // wave-uniform
+    if (inside) {
+        float v[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) v[q] = a[q] * MB_OUT_SCALE;
+#pragma unroll
+        for (int q = 0; q < 16; ++q)
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[q]), plane, base,
+                                                  ((q & 3) + 8 * (q >> 2)) * rowstep, 0);
+    } else {
+        const bool col_in = (unsigned)ax < (unsigned)p.aw;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int dy = (q & 3) + 8 * (q >> 2);
+            const bool in = col_in && (unsigned)(row0 + dy) < (unsigned)p.ah;
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(a[q] * MB_OUT_SCALE), plane,
+                                                  in ? base + (unsigned)(dy * rowstep) : 0x80000000u,
+                                                  0, 0);
+        }
+    }
+}
+
+template <int C, bool SHARP>
+__device__ __forceinline__ void ml_body(const pano_patch &p, const int ch, const int out_level,
+                                        const bool live, const half8 *s_tx, const half8 *s_ty,
+                                        const MbShared &sh, const uint32_t *list, const int nlist,
+                                        const int16_t *__restrict__ owner_, const int W,
+                                        const int tx0) {
+    constexpr int KS = 2 + 2 * C, DMAX = (C + 1) / 2, NB = 2 * DMAX + 1;
+    constexpr int THREADS = MB_THREADS_OF(4), ITS = MB_ITS_OF(4);
+    constexpr unsigned OOB = 0x80000000u;
+    constexpr bool sharp = SHARP;                        // stitcher.py:207-208: the 0 / 1 mask
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, n = lane & 31, h = lane >> 5;
+    const int tile = wv & 1;
+    const MbGeom g = mb_geom(p);
+    const int X0 = g.gx0 + 32 * tx0, px0 = X0 + 32 * tile;
+    const int BW = MB_XT + 32 * sh.CM, CPR = BW >> 2, NCH = 32 * CPR;
+    const int my_lo = g.O0 - DMAX, my_hi = g.O1 + DMAX;
+
+    f32x16 acc[NB];
+    const __amdgpu_buffer_rsrc_t dst = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)(p.blurred + (size_t)(out_level * 4 + ch) * p.ah * p.apitch), 0, p.ah * p.apitch * 4,
+        0x00020000);
+    const gci16 owner = (gci16)owner_;
+
+    // this thread's chunks: band row, LDS slot, and the column part of the address (a chunk
+    // is inside V or outside it as a whole).  Whether chunk `it` exists is wave-uniform: a
+    // band has 512 + 256 CM chunks and 256 threads are four waves.
+    int c_rr[ITS], c_lds[ITS];
+    unsigned c_col[ITS];         // colour: byte offset in a plane row; mask: mosaic column; or OOB
+    bool c_has[ITS];
+#pragma unroll
+    for (int it = 0; it < ITS; ++it) {
+        const int grp = tid + THREADS * it;
+        const int rr = grp / CPR, c4 = grp - rr * CPR;
+        c_has[it] = __builtin_amdgcn_readfirstlane((wv << 6) + THREADS * it) < NCH;
+        const int vc = X0 - 16 * sh.CM + 4 * c4 - p.vx0;     // first column, in V
+        const bool col_ok = vc >= 0 && vc + 4 <= p.vw;
+        c_rr[it] = rr;
+        c_lds[it] = rr * sh.P + 4 * c4;
+        c_col[it] = sharp ? (col_ok ? (unsigned)(p.x0 + p.vx0 + vc) : OOB)
+                          : (col_ok ? (unsigned)vc * 4u : OOB);
+    }
+    // One band in flight.  Its loads are issued in front of the previous tile's stores and
+    // are NOT known to the compiler (inline asm): the compiler waits for a load's data with
+    // s_waitcnt vmcnt(0) wherever the count of younger operations varies with the path - i.e.
+    // here, for the band AND for the sixteen stores that follow it in the queue, every step
+    // (counters: the waves of this kernel were parked 67 % of their cycles, the kernel took
+    // 0.89 ms where it now takes 0.71).  The wait is placed by hand instead: everything but the
+    // stores issued behind the loads.
+    typedef unsigned uint4v __attribute__((ext_vector_type(4)));
+    typedef int int4v __attribute__((ext_vector_type(4)));
+    uint4v pf[ITS];
+    unsigned pm = 0;                                      // mask: bit it = the chunk's samples exist
+    const unsigned long long src_base =
+        (unsigned long long)(sharp ? p.planes : p.planes + (size_t)ch * p.vh * p.vpitch);
+    int4v rs;                                            // the plane as a buffer descriptor, word by word
+    rs[0] = __builtin_amdgcn_readfirstlane((int)(src_base & 0xffffffffull));
+    rs[1] = __builtin_amdgcn_readfirstlane((int)((src_base >> 32) & 0xffffull));
+    rs[2] = __builtin_amdgcn_readfirstlane(p.vh * p.vpitch * 4);
+    rs[3] = 0x00020000;
+    auto fetch = [&](const int t) {
+        if (sharp) pm = 0;
+#pragma unroll
+        for (int it = 0; it < ITS; ++it) {
+            if (!c_has[it]) continue;                    // wave-uniform
+            const int prow = 32 * t + c_rr[it];
+            const int ry = prow < 0 ? -prow : (prow >= p.h ? 2 * p.h - 2 - prow : prow);
+            const int vr = ry - p.vy0;
+            const bool ok = (unsigned)vr < (unsigned)p.vh && c_col[it] != OOB;
+            if (!sharp) {
+                const unsigned voff = ok ? (unsigned)vr * (unsigned)p.vpitch * 4u + c_col[it] : OOB;
+                asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen"
+                             : "=v"(pf[it])
+                             : "v"(voff), "s"(rs)
+                             : "memory");
+            } else {
+                const gci16 at = owner + ((size_t)(unsigned)(p.y0 + (ok ? ry : 0)) * (unsigned)W +
+                                          (ok ? c_col[it] : (unsigned)p.x0));
+                unsigned e0, e1, e2, e3;
+                asm volatile("global_load_sshort %0, %4, off\n\t"
+                             "global_load_sshort %1, %4, off offset:2\n\t"
+                             "global_load_sshort %2, %4, off offset:4\n\t"
+                             "global_load_sshort %3, %4, off offset:6"
+                             : "=&v"(e0), "=&v"(e1), "=&v"(e2), "=&v"(e3)
+                             : "v"(at)
+                             : "memory");
+                pf[it][0] = e0;
+                pf[it][1] = e1;
+                pf[it][2] = e2;
+                pf[it][3] = e3;
+                pm |= ok ? 1u << it : 0u;
+            }
+        }
+    };
+    // `behind` = the sixteen stores of a tile were issued behind the band's loads
+    auto commit = [&](const bool behind) {
+        static_assert(ITS == 3, "the hand-placed waits name three chunks");
+        if (behind)
+            asm volatile("s_waitcnt vmcnt(16)" : "+v"(pf[0]), "+v"(pf[1]), "+v"(pf[2])::"memory");
+        else
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(pf[0]), "+v"(pf[1]), "+v"(pf[2])::"memory");
+#pragma unroll
+        for (int it = 0; it < ITS; ++it) {
+            if (!c_has[it]) continue;
+            half4 hi, lo;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float v = __uint_as_float(pf[it][j]);
+                if (sharp) v = (int)pf[it][j] == p.index && ((pm >> it) & 1u) ? 1.0f : 0.0f;
+                _Float16 a, b;
+                split16(v * MB_IN_SCALE, a, b);
+                hi[j] = a;
+                lo[j] = b;
+            }
+            *(half4 *)(sh.hi + c_lds[it]) = hi;
+            if (!sharp) *(half4 *)(sh.lo + c_lds[it]) = lo;      // the mask has no low part
+        }
+    };
+    auto rowpass = [&](f32x16 &mid) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) mid[q] = 0.0f;
+        const int o = n * sh.P + 16 * (sh.CM - C) + 32 * tile + 8 * h;
+        const _Float16 *arow = sh.hi + o, *brow = sh.lo + o;
+        half8 a_hi[2], a_lo[2], b_hi[2], b_lo[2];
+        auto operands = [&](const int s, const int b) {
+            a_hi[b] = *(const half8 *)(arow + 16 * s);
+            b_hi[b] = s_tx[(s * 2) * 64 + lane];
+            b_lo[b] = s_tx[(s * 2 + 1) * 64 + lane];
+            if (!sharp) a_lo[b] = *(const half8 *)(brow + 16 * s);
+        };
+        operands(0, 0);
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const int cur = s & 1;
+            if (s + 1 < KS) operands(s + 1, cur ^ 1);
+            mid = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi[cur], b_hi[cur], mid, 0, 0, 0);
+            mid = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi[cur], b_lo[cur], mid, 0, 0, 0);
+            if (!sharp)
+                mid = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo[cur], b_hi[cur], mid, 0, 0, 0);
+#if MB_SCHED
+            __builtin_amdgcn_sched_group_barrier(0x100, sharp ? 3 : 4, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, sharp ? 2 : 3, 0);
+#endif
+        }
+    };
+    // a list word: band index (16 bits, signed) | tile column 0's wanted bits << 16 | column 1's << 24
+    // (bit d + 2 = tile t - d is wanted, d = -2 .. 2)
+    auto word_at = [&](const int i) -> unsigned {
+        return (unsigned)__builtin_amdgcn_readfirstlane((int)list[i]);
+    };
+    auto band_of = [](const unsigned w) { return (int)(short)(w & 0xffffu); };
+    const unsigned keep = live ? 0x1fu : 0u;
+    auto bits_of = [&](const unsigned w) { return (w >> (16 + 8 * tile)) & keep; };
+
+    if (nlist <= 0) return;                               // uniform
+    // A wanted tile needs every band within DMAX of it, so the listed bands come in RUNS of
+    // consecutive bands and no tile outlives a run.  Inside a run the accumulator of a tile
+    // is given by the tile's position in the run mod NB, and the loop over a run is unrolled
+    // NB times: every step addresses the accumulators statically, with no join of differently
+    // numbered variants behind it (a switch on t mod NB made the compiler move the 80
+    // accumulator registers around at every step: 0.97 ms against 0.89).
+    int i = 0;
+    unsigned word = word_at(0);
+    fetch(band_of(word));
+    int prev_o = 0, prev_u = 0;
+    bool prev_store = false, behind = false;
+    auto store_prev = [&]() {                            // reads the accumulators, writes none
+        if (!prev_store) return;                         // wave-uniform
+        switch (prev_u) {
+#define ML_STORE_CASE(UU)                                                          \
+    case UU:                                                                       \
+        if constexpr (UU < NB) ml_store(acc[(UU + DMAX + 1) % NB], prev_o, lane, p, dst, px0); \
+        break;
+            ML_STORE_CASE(0) ML_STORE_CASE(1) ML_STORE_CASE(2) ML_STORE_CASE(3) ML_STORE_CASE(4)
+#undef ML_STORE_CASE
+        }
+        prev_store = false;
+    };
+    // One step with the run position u_c static; false = the run (or the list) ends here.
+    auto step = [&](auto u_c) -> bool {
+        constexpr int U = decltype(u_c)::value;
+        const int t = band_of(word);
+        const unsigned inf = bits_of(word);
+        const bool more = i + 1 < nlist;
+        const unsigned next = more ? word_at(i + 1) : 0u;
+        lds_barrier();                                   // everybody finished reading the band
+        commit(behind);
+        lds_barrier();
+        if (more) fetch(band_of(next));                  // in FRONT of the stores: see `fetch`
+        behind = prev_store;
+        store_prev();                                    // the tile last step's band completed
+        if (t >= my_lo && t <= my_hi && (inf & (DMAX == 1 ? 0x0eu : 0x1fu))) {
+            f32x16 mid;
+            rowpass(mid);
+            half8 m_hi[2], m_lo[2];
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    _Float16 a, b;
+                    split16(mid[8 * s + j] * MB_MID_SCALE, a, b);
+                    m_hi[s][j] = a;
+                    m_lo[s][j] = b;
+                }
+            ml_colpass<C, U>(acc, m_hi, m_lo, s_ty, lane);
+        }
+        prev_store = (inf >> (DMAX + 2)) & 1u;           // tile t - DMAX is wanted: complete now
+        prev_o = t - DMAX;
+        prev_u = U;
+        word = next;
+        ++i;
+        return more && band_of(next) == t + 1;
+    };
+    while (i < nlist) {                                  // one run per trip
+        // (nothing of the previous run is alive: say so, else the accumulators are carried
+        // from every exit below to here)
+#pragma unroll
+        for (int k = 0; k < NB; ++k)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[k][q] = 0.0f;
+        for (;;) {
+            if (!step(std::integral_constant<int, 0>{})) break;
+            if (!step(std::integral_constant<int, 1>{})) break;
+            if (!step(std::integral_constant<int, 2>{})) break;
+            if constexpr (NB > 3) {
+                if (!step(std::integral_constant<int, 3>{})) break;
+                if (!step(std::integral_constant<int, 4>{})) break;
+            }
+        }
+        behind |= prev_store;                            // (behind the next band's loads, if any)
+        store_prev();                                    // the run's last tile, before the reset
+    }
+}
+
+__global__ __launch_bounds__(MB_THREADS_OF(4), 1) void blur_lean_kernel(
+    const pano_patch *__restrict__ table, MbLevels L, const unsigned char *__restrict__ tables,
+    const int16_t *__restrict__ owner, int W, const uint8_t *__restrict__ flags,
+    const int2 *__restrict__ items) {
+    constexpr int GROUP = 4;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
+    const int ngroups = (L.n + GROUP - 1) / GROUP;
+    const int per = 8 * ngroups, blk = blockIdx.x / per, within = blockIdx.x - blk * per;
+    const int grp = within >> 3, pair = blk * 8 + (within & 7);
+    const int ch = pair & 3, slot = pair >> 2;
+    const int2 item = items[slot];
+    if (item.x < 0) return;                                                     // uniform
+    const int pid = item.x & 0xffff, tx0 = item.x >> 16;
+    const pano_patch p = table[pid];
+    const MbGeom g = mb_geom(p);
+    const int l0 = GROUP * grp, nl = L.n - l0 < GROUP ? L.n - l0 : GROUP;
+    // the group's reach, and whether this item is one of ours
+    MbShared sh;
+    sh.CM = 1;
+    for (int k = 0; k < nl; ++k) {
+        const int ck = mb_c_of(L.ntaps[l0 + k]);
+        sh.CM = ck > sh.CM ? ck : sh.CM;
+    }
+    if (!mb_item_regular(p, g.gx0, tx0, sh.CM)) {                               // uniform
+        // not one of ours: the general path, in this same workgroup (a second launch over the
+        // list, every workgroup of which returns at once for a regular item, cost 0.31 ms on
+        // config 3: 5120 workgroups of 512 threads and 128 KB of LDS each, one per CU at a time)
+        mb_general<GROUP>(table, L, tables, owner, W, flags, items, smem);
+        return;
+    }
+    const int n_seg = item.y >> 16, seg = (item.y >> 12) & 15, nty_all = g.O1 - g.O0 + 1;
+    const int o_begin = n_seg > 1 ? nty_all * seg / n_seg : 0;
+    const int o_end = n_seg > 1 ? nty_all * (seg + 1) / n_seg : nty_all;
+    const int q = __builtin_amdgcn_readfirstlane(wv >> 1);
+    const int lv = mb_level_of_pair(nl, q);
+    const bool live = lv >= 0;
+    const int level = l0 + (live ? lv : 0);
+    const int ntaps = L.ntaps[level], c = mb_c_of(ntaps);
+    int dmax_of[GROUP], rel = 0, my_tx = 0, my_ty = 0;
+    for (int k = 0; k < GROUP; ++k) {
+        const int lk = mb_level_of_pair(nl, k);
+        dmax_of[k] = -1;
+        if (lk < 0) continue;
+        const int ck = mb_c_of(L.ntaps[l0 + lk]);
+        dmax_of[k] = (ck + 1) / 2;
+        if (k == q) {
+            my_tx = rel;
+            my_ty = rel + (2 + 2 * ck) * 2 * 1024;
+        }
+        rel += mb_table_bytes(L.ntaps[l0 + lk]);
+    }
+    sh.P = mb_pitch_of(sh.CM);
+    sh.hi = (_Float16 *)smem;
+    sh.lo = sh.hi + 32 * sh.P;
+    sh.need = (uint8_t *)(sh.lo + 32 * sh.P);
+    sh.any = sh.need + 2 * MB_NEED_LEN;
+    sh.info = (uint16_t *)(sh.any + MB_NEED_LEN);
+    sh.col = (short *)(sh.info + 2 * MB_NEED_LEN);
+    uint32_t *list = (uint32_t *)sh.info;                // [MB_NEED_LEN] words: same bytes
+    my_tx += mb_fixed_bytes(sh.CM);
+    my_ty += mb_fixed_bytes(sh.CM);
+    const int dmaxm = (sh.CM + 1) / 2;
+    sh.t_lo = g.O0 - dmaxm;
+    sh.t_hi = g.O1 + dmaxm;
+    if (live) {
+        const uint4 *from = (const uint4 *)(tables + L.tab_off[level]);
+        uint4 *to = (uint4 *)(smem + my_tx);
+        const int n16 = mb_table_bytes(ntaps) >> 4;
+        for (int i = tid & 127; i < n16; i += 128) to[i] = from[i];
+    }
+    const int X0 = g.gx0 + 32 * tx0;
+    const int nty = g.O1 - g.O0 + 1;
+    if (wv < 2) {
+        const int txg = ((X0 - g.gx0) >> 5) + wv;
+        for (int i = lane; i < nty + 2 * MB_NEED_PAD; i += 64) {
+            const int o = i - MB_NEED_PAD;
+            bool v = txg < g.ntx && o >= o_begin && o < o_end;
+            if (v && flags) v = flags[p.tiles_off + o * g.ntx + txg] != 0;
+            sh.need[wv * MB_NEED_LEN + i] = v ? 1 : 0;
+        }
+    }
+    int *const s_count = (int *)sh.any;                  // (the `any` flags are not used here)
+    __syncthreads();
+    // the bands some wave wants, in order, compacted: one wave, 64 bands per round
+    if (wv == 0) {
+        int count = 0;
+        for (int base = 0; base <= sh.t_hi - sh.t_lo; base += 64) {
+            const int i = base + lane, t = sh.t_lo + i;
+            const int o = t - g.O0 + MB_NEED_PAD;                    // index of tile t into need[]
+            bool any = false;
+            unsigned w = 0;
+            if (i <= sh.t_hi - sh.t_lo) {
+                for (int k = 0; k < GROUP; ++k)
+                    for (int d = -dmax_of[k]; d <= dmax_of[k]; ++d)
+                        any |= (sh.need[o - d] | sh.need[MB_NEED_LEN + o - d]) != 0;
+                for (int col = 0; col < 2; ++col)
+                    for (int d = -2; d <= 2; ++d)
+                        w |= (sh.need[col * MB_NEED_LEN + o - d] ? 1u : 0u) << (16 + 8 * col + d + 2);
+                w |= (unsigned)(unsigned short)(short)t;
+            }
+            const unsigned long long bal = __ballot(any);
+            if (any) list[count + __popcll(bal & ((1ull << lane) - 1ull))] = w;
+            count += __popcll(bal);
+        }
+        if (lane == 0) *s_count = count;
+    }
+    __syncthreads();
+    const int nlist = *s_count;
+    const half8 *s_tx = (const half8 *)(smem + my_tx), *s_ty = (const half8 *)(smem + my_ty);
+    const int out_level = L.out[level];
+    switch (c) {                                         // wave-uniform
+#define ML_BODY(CC)                                                                            \
+    if (ch == 3)                                                                               \
+        ml_body<CC, true>(p, ch, out_level, live, s_tx, s_ty, sh, list, nlist, owner, W, tx0); \
+    else                                                                                       \
+        ml_body<CC, false>(p, ch, out_level, live, s_tx, s_ty, sh, list, nlist, owner, W, tx0); \
+    break;
+        case 1: ML_BODY(1)
+        case 2: ML_BODY(2)
+        case 3: ML_BODY(3)
+        default: ML_BODY(4)
+#undef ML_BODY
     }
 }
 
@@ -1001,6 +1465,8 @@ int pano_blur_mfma_opt_in(void) {
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     PANO_HIP(hipFuncSetAttribute((const void *)blur_mfma_kernel<4>,
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    PANO_HIP(hipFuncSetAttribute((const void *)blur_lean_kernel,
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     return PANO_OK;
 }
 
@@ -1083,6 +1549,18 @@ static int launch_levels(pano_ctx *ctx, const pano_patch *table, int n, int max_
     PANO_REQUIRE((long long)cap * 4 * ngroups < (1ll << 31), "pano_multiband_blur: %d work items",
                  cap);
     dim3 grid((unsigned)cap * 4 * ngroups, 1, 1);
+    // Groups of four levels with real apertures: the kernel that runs the regular items
+    // through the lean path (and the others through the general one).
+    int lean = MB_LEAN && ctx->opt[PANO_OPT_BLUR_LEAN] && group == 4 ? 1 : 0;
+    for (int i = 0; i < cnt; ++i)
+        if (L.ntaps[i] < 3) lean = 0;
+    if (lean) {
+        PANO_TIMED(PK_BLUR_MFMA, stream,
+                   hipLaunchKernelGGL(blur_lean_kernel, grid, dim3(MB_THREADS_OF(4)), lds,
+                                      stream, table, L, tables, owner, W, flags, sorted));
+        PANO_LAUNCH_CHECK("blur_lean_kernel");
+        return PANO_OK;
+    }
     if (group == 2)
         PANO_TIMED(PK_BLUR_MFMA, stream,
                    hipLaunchKernelGGL(blur_mfma_kernel<2>, grid, dim3(MB_THREADS_OF(2)), lds, stream,

@@ -386,7 +386,9 @@ def windows_for(box, rect, radius, strip=None):
             return None
     vy0, vy1 = reflect_closed(ay0 - radius, ay1 + radius, h)
     vx0, vx1 = reflect_closed(ax0 - radius, ax1 + radius, w)
-    return (ay0, ay1, ax0, ax1), (min(vy0, ay0), max(vy1, ay1), min(vx0, ax0), max(vx1, ax1))
+    # V's columns end on multiples of 4 (clipped to the patch): include/pano360.h, "Windows"
+    vx0, vx1 = min(vx0, ax0) & ~3, min((max(vx1, ax1) + 3) & ~3, w)
+    return (ay0, ay1, ax0, ax1), (min(vy0, ay0), max(vy1, ay1), vx0, vx1)
 
 
 def _reflect_closed_many(lo, hi, n):
@@ -421,8 +423,9 @@ def windows_for_many(boxes, rects, radius, strip=None):
     vy0, vy1 = _reflect_closed_many(ay0 - radius, ay1 + radius, h)
     vx0, vx1 = _reflect_closed_many(ax0 - radius, ax1 + radius, w)
     area = np.stack([ay0, ay1, ax0, ax1], axis=1)
-    window = np.stack([np.minimum(vy0, ay0), np.maximum(vy1, ay1), np.minimum(vx0, ax0),
-                       np.maximum(vx1, ax1)], axis=1)
+    vx0 = np.minimum(vx0, ax0) & ~3
+    vx1 = np.minimum((np.maximum(vx1, ax1) + 3) & ~3, w)
+    window = np.stack([np.minimum(vy0, ay0), np.maximum(vy1, ay1), vx0, vx1], axis=1)
     return keep, area, window
 
 

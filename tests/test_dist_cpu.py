@@ -182,7 +182,8 @@ def test_windows_for_strip_clipping():
     area, win = engine.windows_for(box, rect, 43)
     assert area == (0, 100, 57, 243)
     area, win = engine.windows_for(box, rect, 43, strip=(1150, 1300))
-    assert area == (0, 100, 150, 243) and win[2] == 150 - 43 and win[3] == 243 + 43
+    # V: A grown by the radius, its columns rounded outwards to multiples of 4
+    assert area == (0, 100, 150, 243) and win[2] == (150 - 43) & ~3 and win[3] == (243 + 43 + 3) & ~3
     assert engine.windows_for(box, rect, 43, strip=(1243, 2000)) is None
     assert engine.windows_for(box, rect, 43, strip=(0, 1057)) is None
     area, _ = engine.windows_for(box, rect, 43, strip=(0, 1058))

@@ -1022,6 +1022,48 @@ def test_shrink_matches_resize_oracle(eng, shrink):
     assert blend.shrink_images([img], 1)[0].shape == img.shape
 
 
+@pytest.mark.parametrize("scene", ["sweep", "jitter", "closed", "tall"])
+def test_lean_blur_kernel_equals_the_general_kernel(scene):
+    """``blur_lean_kernel`` (option PANO_OPT_BLUR_LEAN, default on) takes the work items whose
+    bands need no special case and runs the same products in the same order as the general
+    kernel: every blurred plane it writes, the float mosaic and the uint8 mosaic are the
+    general kernel's bit for bit - interior shortcut on and off, L = 5 and 3, strips (vertical
+    segments of the items) included."""
+    import torch
+    from pano360_amd import _lib, engine, synth
+    if scene == "sweep":
+        imgs, rots, intrs = synth.make_scene(6, 640, 360, sweep_deg=100.0, seed=1, kind="A")
+    elif scene == "jitter":
+        imgs, rots, intrs = synth.make_scene(7, 480, 270, sweep_deg=120.0, jitter=0.02, seed=2, kind="B")
+    elif scene == "closed":
+        imgs, rots, intrs = synth.make_scene(12, 320, 240, step_deg=30.0, seed=3, kind="A")
+    else:
+        imgs, rots, intrs = synth.make_scene(4, 300, 700, sweep_deg=50.0, jitter=0.01, seed=4, kind="B")
+    shapes = [im.shape[:2] for im in imgs]
+    eng = engine.Engine()
+    frames = eng.upload_frames(imgs)
+    for levels, shortcut, strip in ((5, True, None), (5, False, None), (3, True, None), (5, True, 0.4)):
+        got = []
+        for lean in (1, 1, 0):              # (the first run only makes the arenas exist)
+            eng.set_option(_lib.OPT_BLUR_LEAN, lean)
+            plan = eng.upload_plan(engine.Plan(shapes, rots, intrs, True, 10 ** 9))
+            W = plan.shape[1]
+            cols = None if strip is None else (int(W * strip), int(W * (strip + 0.3)))
+            for name in ("blurred", "planes"):
+                if name in eng._arenas and eng._arenas[name] is not None:
+                    eng._arenas[name].zero_()
+            mosaic, fl, valid, patches = eng.multiband_fused(frames, plan, levels, want_float=True,
+                                                            shortcut=shortcut, strip=cols)
+            c0, c1 = cols if cols else (0, W)
+            got.append((mosaic[:, c0:c1].cpu(), fl[:, c0:c1].cpu(), eng._arenas["blurred"].clone().cpu()))
+        got = got[1:]
+        assert torch.equal(got[0][0], got[1][0]), (scene, levels, shortcut, strip)
+        assert torch.equal(got[0][1], got[1][1]), (scene, levels, shortcut, strip)
+        assert got[0][2].numel() == got[1][2].numel()
+        assert torch.equal(got[0][2].view(torch.int32), got[1][2].view(torch.int32))
+    eng.set_option(_lib.OPT_BLUR_LEAN, 1)
+
+
 def test_native_stitch_equals_the_launch_by_launch_path(oracle):
     """``pano_stitch_multiband`` (one native call per stitch: the default) against the same
     entry points called one by one from Python: same mosaic, float mosaic, valid map and

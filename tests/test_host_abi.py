@@ -190,7 +190,7 @@ def test_windows_for():
     assert windows_for((5, 4, 0, 0), rect, 43) is None          # owns nothing
     area, win = windows_for((10, 109, 300, 349), rect, 43)
     assert area == (0, 100, 57, 193)
-    assert win == (0, 100, 14, 236)
+    assert win == (0, 100, 12, 236)                   # 57 - 43 = 14 -> 12, 193 + 43 = 236: multiples of 4
     area, win = windows_for((10, 109, 200, 230), rect, 43)      # touches the left edge
     assert area == (0, 100, 0, 74) and win[2] == 0 and win[3] >= 74 + 43
     # tiny patch: everything reflects several times -> whole patch
