@@ -722,6 +722,12 @@ __global__ __launch_bounds__(MB_THREADS_OF(GROUP), 4 / GROUP) void blur_mfma_ker
 #ifndef MB_LEAN
 #define MB_LEAN 1
 #endif
+// 1: the lean path keeps TWO band buffers in LDS and one barrier per step: while a wave
+// multiplies band t it stages its share of band t + 1 into the other buffer and fetches band
+// t + 2, in the shadow of its own (and its SIMD partner's) matrix products
+#ifndef ML_OVERLAP
+#define ML_OVERLAP 1
+#endif
 
 template <int C, int U>
 __device__ __forceinline__ void ml_colpass(f32x16 (&acc)[2 * ((C + 1) / 2) + 1],
@@ -785,11 +791,13 @@ __device__ __forceinline__ void ml_body(const pano_patch &p, const int ch, const
                                         const bool live, const half8 *s_tx, const half8 *s_ty,
                                         const MbShared &sh, const uint32_t *list, const int nlist,
                                         const int16_t *__restrict__ owner_, const int W,
-                                        const int tx0) {
+                                        const int tx0, const int second) {
     constexpr int KS = 2 + 2 * C, DMAX = (C + 1) / 2, NB = 2 * DMAX + 1;
     constexpr int THREADS = MB_THREADS_OF(4), ITS = MB_ITS_OF(4);
     constexpr unsigned OOB = 0x80000000u;
     constexpr bool sharp = SHARP;                        // stitcher.py:207-208: the 0 / 1 mask
+    // halfs from band buffer 0 to band buffer 1 (ML_OVERLAP)
+    const int bstride = second;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, n = lane & 31, h = lane >> 5;
     const int tile = wv & 1;
     const MbGeom g = mb_geom(p);
@@ -820,6 +828,14 @@ __device__ __forceinline__ void ml_body(const pano_patch &p, const int ch, const
         c_lds[it] = rr * sh.P + 4 * c4;
         c_col[it] = sharp ? (col_ok ? (unsigned)(p.x0 + p.vx0 + vc) : OOB)
                           : (col_ok ? (unsigned)vc * 4u : OOB);
+#if ML_OVERLAP
+        // staged without branches: a chunk that does not exist is fetched from nowhere and
+        // written to a scratch slot (the column map's bytes, which this path does not use)
+        if (!c_has[it]) {
+            c_col[it] = OOB;
+            c_lds[it] = (int)((_Float16 *)sh.col - sh.hi) + 4 * (tid & 15);
+        }
+#endif
     }
     // One band in flight.  Its loads are issued in front of the previous tile's stores and
     // are NOT known to the compiler (inline asm): the compiler waits for a load's data with
@@ -843,7 +859,7 @@ __device__ __forceinline__ void ml_body(const pano_patch &p, const int ch, const
         if (sharp) pm = 0;
 #pragma unroll
         for (int it = 0; it < ITS; ++it) {
-            if (!c_has[it]) continue;                    // wave-uniform
+            if (!ML_OVERLAP && !c_has[it]) continue;     // wave-uniform
             const int prow = 32 * t + c_rr[it];
             const int ry = prow < 0 ? -prow : (prow >= p.h ? 2 * p.h - 2 - prow : prow);
             const int vr = ry - p.vy0;
@@ -874,15 +890,17 @@ __device__ __forceinline__ void ml_body(const pano_patch &p, const int ch, const
         }
     };
     // `behind` = the sixteen stores of a tile were issued behind the band's loads
-    auto commit = [&](const bool behind) {
+    auto arrived = [&](const bool behind) {
         static_assert(ITS == 3, "the hand-placed waits name three chunks");
         if (behind)
             asm volatile("s_waitcnt vmcnt(16)" : "+v"(pf[0]), "+v"(pf[1]), "+v"(pf[2])::"memory");
         else
             asm volatile("s_waitcnt vmcnt(0)" : "+v"(pf[0]), "+v"(pf[1]), "+v"(pf[2])::"memory");
+    };
+    auto commit = [&](const int buf) {
 #pragma unroll
         for (int it = 0; it < ITS; ++it) {
-            if (!c_has[it]) continue;
+            if (!ML_OVERLAP && !c_has[it]) continue;
             half4 hi, lo;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -893,14 +911,16 @@ __device__ __forceinline__ void ml_body(const pano_patch &p, const int ch, const
                 hi[j] = a;
                 lo[j] = b;
             }
-            *(half4 *)(sh.hi + c_lds[it]) = hi;
-            if (!sharp) *(half4 *)(sh.lo + c_lds[it]) = lo;      // the mask has no low part
+            // (a scratch slot's low part lands 8 bytes further on, not a band further)
+            const int at = c_lds[it] + (ML_OVERLAP && !c_has[it] ? 0 : buf * bstride);
+            *(half4 *)(sh.hi + at) = hi;
+            if (!sharp) *(half4 *)(sh.hi + at + (ML_OVERLAP && !c_has[it] ? 64 : 32 * sh.P)) = lo;
         }
     };
-    auto rowpass = [&](f32x16 &mid) {
+    auto rowpass = [&](f32x16 &mid, const int buf) {
 #pragma unroll
         for (int q = 0; q < 16; ++q) mid[q] = 0.0f;
-        const int o = n * sh.P + 16 * (sh.CM - C) + 32 * tile + 8 * h;
+        const int o = buf * bstride + n * sh.P + 16 * (sh.CM - C) + 32 * tile + 8 * h;
         const _Float16 *arow = sh.hi + o, *brow = sh.lo + o;
         half8 a_hi[2], a_lo[2], b_hi[2], b_lo[2];
         auto operands = [&](const int s, const int b) {
@@ -942,7 +962,6 @@ __device__ __forceinline__ void ml_body(const pano_patch &p, const int ch, const
     // accumulator registers around at every step: 0.97 ms against 0.89).
     int i = 0;
     unsigned word = word_at(0);
-    fetch(band_of(word));
     int prev_o = 0, prev_u = 0;
     bool prev_store = false, behind = false;
     auto store_prev = [&]() {                            // reads the accumulators, writes none
@@ -957,6 +976,61 @@ __device__ __forceinline__ void ml_body(const pano_patch &p, const int ch, const
         }
         prev_store = false;
     };
+    auto split_mid = [&](const f32x16 &mid, half8 (&m_hi)[2], half8 (&m_lo)[2]) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                _Float16 a, b;
+                split16(mid[8 * s + j] * MB_MID_SCALE, a, b);
+                m_hi[s][j] = a;
+                m_lo[s][j] = b;
+            }
+    };
+#if ML_OVERLAP
+    // Band i is staged in buffer par, band i + 1 is in flight in the registers.
+    int par = 0;
+    fetch(band_of(word));
+    arrived(false);
+    commit(0);
+    {
+        const unsigned w1 = nlist > 1 ? word_at(1) : 0u;
+        fetch(nlist > 1 ? band_of(w1) : -100000);        // (a band that does not exist: zeros)
+    }
+    auto step = [&](auto u_c) -> bool {
+        constexpr int U = decltype(u_c)::value;
+        const int t = band_of(word);
+        const unsigned inf = bits_of(word);
+        const bool more = i + 1 < nlist;
+        const unsigned next = more ? word_at(i + 1) : 0u;
+        const int t2 = i + 2 < nlist ? band_of(word_at(i + 2)) : -100000;
+        lds_barrier();              // band i is whole; nobody reads the other buffer any more
+        behind = prev_store;
+        store_prev();                                    // the tile last step's band completed
+        if (t >= my_lo && t <= my_hi && (inf & (DMAX == 1 ? 0x0eu : 0x1fu))) {
+            f32x16 mid;
+            rowpass(mid, par);
+            arrived(behind);                             // band i + 1: fetched a step ago
+            commit(1 - par);
+            fetch(t2);
+            half8 m_hi[2], m_lo[2];
+            split_mid(mid, m_hi, m_lo);
+            ml_colpass<C, U>(acc, m_hi, m_lo, s_ty, lane);
+        } else {
+            arrived(behind);
+            commit(1 - par);
+            fetch(t2);
+        }
+        prev_store = (inf >> (DMAX + 2)) & 1u;           // tile t - DMAX is wanted: complete now
+        prev_o = t - DMAX;
+        prev_u = U;
+        word = next;
+        par ^= 1;
+        ++i;
+        return more && band_of(next) == t + 1;
+    };
+#else
+    fetch(band_of(word));
     // One step with the run position u_c static; false = the run (or the list) ends here.
     auto step = [&](auto u_c) -> bool {
         constexpr int U = decltype(u_c)::value;
@@ -965,24 +1039,17 @@ __device__ __forceinline__ void ml_body(const pano_patch &p, const int ch, const
         const bool more = i + 1 < nlist;
         const unsigned next = more ? word_at(i + 1) : 0u;
         lds_barrier();                                   // everybody finished reading the band
-        commit(behind);
+        arrived(behind);
+        commit(0);
         lds_barrier();
         if (more) fetch(band_of(next));                  // in FRONT of the stores: see `fetch`
         behind = prev_store;
         store_prev();                                    // the tile last step's band completed
         if (t >= my_lo && t <= my_hi && (inf & (DMAX == 1 ? 0x0eu : 0x1fu))) {
             f32x16 mid;
-            rowpass(mid);
+            rowpass(mid, 0);
             half8 m_hi[2], m_lo[2];
-#pragma unroll
-            for (int s = 0; s < 2; ++s)
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    _Float16 a, b;
-                    split16(mid[8 * s + j] * MB_MID_SCALE, a, b);
-                    m_hi[s][j] = a;
-                    m_lo[s][j] = b;
-                }
+            split_mid(mid, m_hi, m_lo);
             ml_colpass<C, U>(acc, m_hi, m_lo, s_ty, lane);
         }
         prev_store = (inf >> (DMAX + 2)) & 1u;           // tile t - DMAX is wanted: complete now
@@ -992,6 +1059,7 @@ __device__ __forceinline__ void ml_body(const pano_patch &p, const int ch, const
         ++i;
         return more && band_of(next) == t + 1;
     };
+#endif
     while (i < nlist) {                                  // one run per trip
         // (nothing of the previous run is alive: say so, else the accumulators are carried
         // from every exit below to here)
@@ -1008,7 +1076,9 @@ __device__ __forceinline__ void ml_body(const pano_patch &p, const int ch, const
                 if (!step(std::integral_constant<int, 4>{})) break;
             }
         }
+#if !ML_OVERLAP
         behind |= prev_store;                            // (behind the next band's loads, if any)
+#endif
         store_prev();                                    // the run's last tile, before the reset
     }
 }
@@ -1127,9 +1197,9 @@ __global__ __launch_bounds__(MB_THREADS_OF(4), 1) void blur_lean_kernel(
     switch (c) {                                         // wave-uniform
 #define ML_BODY(CC)                                                                            \
     if (ch == 3)                                                                               \
-        ml_body<CC, true>(p, ch, out_level, live, s_tx, s_ty, sh, list, nlist, owner, W, tx0); \
+        ml_body<CC, true>(p, ch, out_level, live, s_tx, s_ty, sh, list, nlist, owner, W, tx0, second); \
     else                                                                                       \
-        ml_body<CC, false>(p, ch, out_level, live, s_tx, s_ty, sh, list, nlist, owner, W, tx0); \
+        ml_body<CC, false>(p, ch, out_level, live, s_tx, s_ty, sh, list, nlist, owner, W, tx0, second); \
     break;
         case 1: ML_BODY(1)
         case 2: ML_BODY(2)
@@ -1554,9 +1624,23 @@ static int launch_levels(pano_ctx *ctx, const pano_patch *table, int n, int max_
     int lean = MB_LEAN && ctx->opt[PANO_OPT_BLUR_LEAN] && group == 4 ? 1 : 0;
     for (int i = 0; i < cnt; ++i)
         if (L.ntaps[i] < 3) lean = 0;
+    int lds_lean = lds;
+    if (ML_OVERLAP) {            // + the second band buffer, behind the largest group's tables
+        lds_lean = 0;
+        for (int gidx = 0; gidx < ngroups; ++gidx) {
+            int bytes = 0, cm = 1;
+            for (int i = group * gidx; i < cnt && i < group * (gidx + 1); ++i) {
+                bytes += mb_table_bytes(L.ntaps[i]);
+                cm = mb_c_of(L.ntaps[i]) > cm ? mb_c_of(L.ntaps[i]) : cm;
+            }
+            bytes = (bytes + mb_fixed_bytes(cm) + 15) / 16 * 16 + 2 * 32 * mb_pitch_of(cm) * 2;
+            lds_lean = bytes > lds_lean ? bytes : lds_lean;
+        }
+        if (lds_lean > 160 * 1024) lean = 0;             // (apertures above 97 taps: the general kernel)
+    }
     if (lean) {
         PANO_TIMED(PK_BLUR_MFMA, stream,
-                   hipLaunchKernelGGL(blur_lean_kernel, grid, dim3(MB_THREADS_OF(4)), lds,
+                   hipLaunchKernelGGL(blur_lean_kernel, grid, dim3(MB_THREADS_OF(4)), lds_lean,
                                       stream, table, L, tables, owner, W, flags, sorted));
         PANO_LAUNCH_CHECK("blur_lean_kernel");
         return PANO_OK;
