@@ -1194,6 +1194,8 @@ __global__ __launch_bounds__(MB_THREADS_OF(4), 1) void blur_lean_kernel(
     const int nlist = *s_count;
     const half8 *s_tx = (const half8 *)(smem + my_tx), *s_ty = (const half8 *)(smem + my_ty);
     const int out_level = L.out[level];
+    // the second band buffer lies behind the group's tables (the host sized the LDS for it)
+    const int second = (mb_fixed_bytes(sh.CM) + rel + 15) / 16 * 8;     // halfs from sh.hi
     switch (c) {                                         // wave-uniform
 #define ML_BODY(CC)                                                                            \
     if (ch == 3)                                                                               \
