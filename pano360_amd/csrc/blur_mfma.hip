@@ -797,7 +797,7 @@ __device__ __forceinline__ void ml_body(const pano_patch &p, const int ch, const
     constexpr unsigned OOB = 0x80000000u;
     constexpr bool sharp = SHARP;                        // stitcher.py:207-208: the 0 / 1 mask
     // halfs from band buffer 0 to band buffer 1 (ML_OVERLAP)
-    const int bstride = second;
+    const int bstride = __builtin_amdgcn_readfirstlane(second);
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, n = lane & 31, h = lane >> 5;
     const int tile = wv & 1;
     const MbGeom g = mb_geom(p);
@@ -828,14 +828,6 @@ __device__ __forceinline__ void ml_body(const pano_patch &p, const int ch, const
         c_lds[it] = rr * sh.P + 4 * c4;
         c_col[it] = sharp ? (col_ok ? (unsigned)(p.x0 + p.vx0 + vc) : OOB)
                           : (col_ok ? (unsigned)vc * 4u : OOB);
-#if ML_OVERLAP
-        // staged without branches: a chunk that does not exist is fetched from nowhere and
-        // written to a scratch slot (the column map's bytes, which this path does not use)
-        if (!c_has[it]) {
-            c_col[it] = OOB;
-            c_lds[it] = (int)((_Float16 *)sh.col - sh.hi) + 4 * (tid & 15);
-        }
-#endif
     }
     // One band in flight.  Its loads are issued in front of the previous tile's stores and
     // are NOT known to the compiler (inline asm): the compiler waits for a load's data with
@@ -859,7 +851,7 @@ __device__ __forceinline__ void ml_body(const pano_patch &p, const int ch, const
         if (sharp) pm = 0;
 #pragma unroll
         for (int it = 0; it < ITS; ++it) {
-            if (!ML_OVERLAP && !c_has[it]) continue;     // wave-uniform
+            if (!c_has[it]) continue;                    // wave-uniform
             const int prow = 32 * t + c_rr[it];
             const int ry = prow < 0 ? -prow : (prow >= p.h ? 2 * p.h - 2 - prow : prow);
             const int vr = ry - p.vy0;
@@ -900,7 +892,7 @@ __device__ __forceinline__ void ml_body(const pano_patch &p, const int ch, const
     auto commit = [&](const int buf) {
 #pragma unroll
         for (int it = 0; it < ITS; ++it) {
-            if (!ML_OVERLAP && !c_has[it]) continue;
+            if (!c_has[it]) continue;
             half4 hi, lo;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -911,16 +903,15 @@ __device__ __forceinline__ void ml_body(const pano_patch &p, const int ch, const
                 hi[j] = a;
                 lo[j] = b;
             }
-            // (a scratch slot's low part lands 8 bytes further on, not a band further)
-            const int at = c_lds[it] + (ML_OVERLAP && !c_has[it] ? 0 : buf * bstride);
+            const int at = c_lds[it] + buf;
             *(half4 *)(sh.hi + at) = hi;
-            if (!sharp) *(half4 *)(sh.hi + at + (ML_OVERLAP && !c_has[it] ? 64 : 32 * sh.P)) = lo;
+            if (!sharp) *(half4 *)(sh.lo + at) = lo;     // the mask has no low part
         }
     };
     auto rowpass = [&](f32x16 &mid, const int buf) {
 #pragma unroll
         for (int q = 0; q < 16; ++q) mid[q] = 0.0f;
-        const int o = buf * bstride + n * sh.P + 16 * (sh.CM - C) + 32 * tile + 8 * h;
+        const int o = buf + n * sh.P + 16 * (sh.CM - C) + 32 * tile + 8 * h;
         const _Float16 *arow = sh.hi + o, *brow = sh.lo + o;
         half8 a_hi[2], a_lo[2], b_hi[2], b_lo[2];
         auto operands = [&](const int s, const int b) {
@@ -988,8 +979,9 @@ __device__ __forceinline__ void ml_body(const pano_patch &p, const int ch, const
             }
     };
 #if ML_OVERLAP
-    // Band i is staged in buffer par, band i + 1 is in flight in the registers.
-    int par = 0;
+    // Band i is staged in the buffer at off_cur (halfs from sh.hi), band i + 1 is in flight in
+    // the registers and goes to the buffer at off_nxt.
+    int off_cur = __builtin_amdgcn_readfirstlane(0), off_nxt = bstride;
     fetch(band_of(word));
     arrived(false);
     commit(0);
@@ -1004,28 +996,33 @@ __device__ __forceinline__ void ml_body(const pano_patch &p, const int ch, const
         const bool more = i + 1 < nlist;
         const unsigned next = more ? word_at(i + 1) : 0u;
         const int t2 = i + 2 < nlist ? band_of(word_at(i + 2)) : -100000;
+        // (the two offsets swap every step; kept opaque, or the compiler unrolls the run loop
+        // once more to make them constants and spills 1500 registers doing so)
+        off_cur = __builtin_amdgcn_readfirstlane(off_cur);
+        off_nxt = __builtin_amdgcn_readfirstlane(off_nxt);
+        asm volatile("" : "+s"(off_cur), "+s"(off_nxt));
         lds_barrier();              // band i is whole; nobody reads the other buffer any more
         behind = prev_store;
         store_prev();                                    // the tile last step's band completed
+        arrived(behind);                                 // band i + 1: fetched a step ago
+        commit(off_nxt);
+        fetch(t2);
         if (t >= my_lo && t <= my_hi && (inf & (DMAX == 1 ? 0x0eu : 0x1fu))) {
             f32x16 mid;
-            rowpass(mid, par);
-            arrived(behind);                             // band i + 1: fetched a step ago
-            commit(1 - par);
-            fetch(t2);
+            rowpass(mid, off_cur);
             half8 m_hi[2], m_lo[2];
             split_mid(mid, m_hi, m_lo);
             ml_colpass<C, U>(acc, m_hi, m_lo, s_ty, lane);
-        } else {
-            arrived(behind);
-            commit(1 - par);
-            fetch(t2);
         }
         prev_store = (inf >> (DMAX + 2)) & 1u;           // tile t - DMAX is wanted: complete now
         prev_o = t - DMAX;
         prev_u = U;
         word = next;
-        par ^= 1;
+        {
+            const int tmp = off_cur;
+            off_cur = off_nxt;
+            off_nxt = tmp;
+        }
         ++i;
         return more && band_of(next) == t + 1;
     };
