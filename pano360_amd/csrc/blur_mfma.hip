@@ -756,15 +756,19 @@ __device__ __forceinline__ void ml_colpass(f32x16 (&acc)[2 * ((C + 1) / 2) + 1],
 }
 
 // Tile o of this wave's column (accumulator `a`) to its plane.
+// ALWAYS sixteen store instructions: with `wanted` false every one of them gets an offset
+// beyond the plane and the hardware drops it.  (A step then issues the same number of memory
+// operations on every path, and the compiler can count: it waits for a band's loads with
+// s_waitcnt vmcnt(16), leaving the stores in flight, instead of vmcnt(0).)
 __device__ __forceinline__ void ml_store(const f32x16 &a, const int o, const int lane,
                                          const pano_patch &p, const __amdgpu_buffer_rsrc_t plane,
-                                         const int px0) {
+                                         const int px0, const bool wanted) {
     const int n = lane & 31, h = lane >> 5;
     const int ax = px0 + n - p.ax0, row0 = 32 * o + 4 * h - p.ay0;
     const int rowstep = p.apitch * 4;
-    const unsigned base = (unsigned)(row0 * p.apitch + ax) * 4u;
-    const bool inside = 32 * o >= p.ay0 && 32 * o + 32 <= p.ay0 + p.ah && px0 >= p.ax0 &&
-                        px0 + 32 <= p.ax0 + p.aw;               // wave-uniform
+    const unsigned base = wanted ? (unsigned)(row0 * p.apitch + ax) * 4u : 0x80000000u;
+    const bool inside = !wanted || (32 * o >= p.ay0 && 32 * o + 32 <= p.ay0 + p.ah &&
+                                    px0 >= p.ax0 && px0 + 32 <= p.ax0 + p.aw);     // wave-uniform
     if (inside) {
         float v[16];
 #pragma unroll
@@ -829,17 +833,19 @@ __device__ __forceinline__ void ml_body(const pano_patch &p, const int ch, const
         c_col[it] = sharp ? (col_ok ? (unsigned)(p.x0 + p.vx0 + vc) : OOB)
                           : (col_ok ? (unsigned)vc * 4u : OOB);
     }
-    // One band in flight.  Its loads are issued in front of the previous tile's stores and
-    // are NOT known to the compiler (inline asm): the compiler waits for a load's data with
-    // s_waitcnt vmcnt(0) wherever the count of younger operations varies with the path - i.e.
-    // here, for the band AND for the sixteen stores that follow it in the queue, every step
-    // (counters: the waves of this kernel were parked 67 % of their cycles, the kernel took
-    // 0.89 ms where it now takes 0.71).  The wait is placed by hand instead: everything but the
-    // stores issued behind the loads.
+    // A step fetches the NEXT band right behind its barrier, in front of the previous tile's
+    // sixteen stores (always sixteen: ml_store), and stages it at its end, behind the two matrix
+    // passes.  The wait in front of the staging must cover the loads and NOT the stores behind
+    // them: a store to HBM takes longer than a step to be acknowledged, and waves that wait for
+    // theirs every step are parked 67 % of their cycles (0.89 ms; 0.71 with the stores left in
+    // flight).  The compiler cannot express that - with loads and stores pending on the one
+    // counter it always waits for vmcnt(0) - so the loads are inline asm (invisible to its wait
+    // insertion) and the wait is placed by hand: s_waitcnt vmcnt(16).  The loaded registers
+    // must then not live across a join of the control flow, or the register allocator may copy
+    // them while the loads are in flight (it did, when they lived from one step into the next):
+    // here they are fetched and consumed inside one step.
     typedef unsigned uint4v __attribute__((ext_vector_type(4)));
     typedef int int4v __attribute__((ext_vector_type(4)));
-    uint4v pf[ITS];
-    unsigned pm = 0;                                      // mask: bit it = the chunk's samples exist
     const unsigned long long src_base =
         (unsigned long long)(sharp ? p.planes : p.planes + (size_t)ch * p.vh * p.vpitch);
     int4v rs;                                            // the plane as a buffer descriptor, word by word
@@ -847,8 +853,12 @@ __device__ __forceinline__ void ml_body(const pano_patch &p, const int ch, const
     rs[1] = __builtin_amdgcn_readfirstlane((int)((src_base >> 32) & 0xffffull));
     rs[2] = __builtin_amdgcn_readfirstlane(p.vh * p.vpitch * 4);
     rs[3] = 0x00020000;
-    auto fetch = [&](const int t) {
-        if (sharp) pm = 0;
+    struct Band {                   // a band in flight: the loads' destination registers
+        uint4v v[ITS];              // colour: one 16-byte load per chunk
+        unsigned e[ITS][4];         // mask: four owner-map entries per chunk
+    };
+    auto fetch = [&](Band &pf, unsigned &pm, const int t) {
+        pm = 0;                                          // mask: bit it = the chunk's samples exist
 #pragma unroll
         for (int it = 0; it < ITS; ++it) {
             if (!c_has[it]) continue;                    // wave-uniform
@@ -859,45 +869,53 @@ __device__ __forceinline__ void ml_body(const pano_patch &p, const int ch, const
             if (!sharp) {
                 const unsigned voff = ok ? (unsigned)vr * (unsigned)p.vpitch * 4u + c_col[it] : OOB;
                 asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen"
-                             : "=v"(pf[it])
+                             : "=v"(pf.v[it])
                              : "v"(voff), "s"(rs)
                              : "memory");
             } else {
                 const gci16 at = owner + ((size_t)(unsigned)(p.y0 + (ok ? ry : 0)) * (unsigned)W +
                                           (ok ? c_col[it] : (unsigned)p.x0));
-                unsigned e0, e1, e2, e3;
+                // (straight into the registers the wait below names: a copy of a register
+                // whose load is still in flight copies stale bits)
                 asm volatile("global_load_sshort %0, %4, off\n\t"
                              "global_load_sshort %1, %4, off offset:2\n\t"
                              "global_load_sshort %2, %4, off offset:4\n\t"
                              "global_load_sshort %3, %4, off offset:6"
-                             : "=&v"(e0), "=&v"(e1), "=&v"(e2), "=&v"(e3)
+                             : "=&v"(pf.e[it][0]), "=&v"(pf.e[it][1]), "=&v"(pf.e[it][2]),
+                               "=&v"(pf.e[it][3])
                              : "v"(at)
                              : "memory");
-                pf[it][0] = e0;
-                pf[it][1] = e1;
-                pf[it][2] = e2;
-                pf[it][3] = e3;
                 pm |= ok ? 1u << it : 0u;
             }
         }
     };
-    // `behind` = the sixteen stores of a tile were issued behind the band's loads
-    auto arrived = [&](const bool behind) {
+    // `behind`: sixteen stores were issued behind the loads (they stay in flight)
+    auto commit = [&](Band &pf, const unsigned pm, const int buf, const bool behind) {
         static_assert(ITS == 3, "the hand-placed waits name three chunks");
-        if (behind)
-            asm volatile("s_waitcnt vmcnt(16)" : "+v"(pf[0]), "+v"(pf[1]), "+v"(pf[2])::"memory");
-        else
-            asm volatile("s_waitcnt vmcnt(0)" : "+v"(pf[0]), "+v"(pf[1]), "+v"(pf[2])::"memory");
-    };
-    auto commit = [&](const int buf) {
+#define ML_WAIT(N)                                                                             \
+    if (sharp)                                                                                 \
+        asm volatile("s_waitcnt vmcnt(" #N ")"                                                 \
+                     : "+v"(pf.e[0][0]), "+v"(pf.e[0][1]), "+v"(pf.e[0][2]), "+v"(pf.e[0][3]), \
+                       "+v"(pf.e[1][0]), "+v"(pf.e[1][1]), "+v"(pf.e[1][2]), "+v"(pf.e[1][3]), \
+                       "+v"(pf.e[2][0]), "+v"(pf.e[2][1]), "+v"(pf.e[2][2]), "+v"(pf.e[2][3])  \
+                     :                                                                         \
+                     : "memory");                                                              \
+    else                                                                                       \
+        asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(pf.v[0]), "+v"(pf.v[1]), "+v"(pf.v[2])::"memory")
+        if (behind) {
+            ML_WAIT(16);
+        } else {
+            ML_WAIT(0);
+        }
+#undef ML_WAIT
 #pragma unroll
         for (int it = 0; it < ITS; ++it) {
             if (!c_has[it]) continue;
             half4 hi, lo;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                float v = __uint_as_float(pf[it][j]);
-                if (sharp) v = (int)pf[it][j] == p.index && ((pm >> it) & 1u) ? 1.0f : 0.0f;
+                float v = sharp ? 0.0f : __uint_as_float(pf.v[it][j]);
+                if (sharp) v = (int)pf.e[it][j] == p.index && ((pm >> it) & 1u) ? 1.0f : 0.0f;
                 _Float16 a, b;
                 split16(v * MB_IN_SCALE, a, b);
                 hi[j] = a;
@@ -954,13 +972,13 @@ __device__ __forceinline__ void ml_body(const pano_patch &p, const int ch, const
     int i = 0;
     unsigned word = word_at(0);
     int prev_o = 0, prev_u = 0;
-    bool prev_store = false, behind = false;
+    bool prev_store = false;
     auto store_prev = [&]() {                            // reads the accumulators, writes none
-        if (!prev_store) return;                         // wave-uniform
         switch (prev_u) {
-#define ML_STORE_CASE(UU)                                                          \
-    case UU:                                                                       \
-        if constexpr (UU < NB) ml_store(acc[(UU + DMAX + 1) % NB], prev_o, lane, p, dst, px0); \
+#define ML_STORE_CASE(UU)                                                                      \
+    case UU:                                                                                   \
+        if constexpr (UU < NB)                                                                 \
+            ml_store(acc[(UU + DMAX + 1) % NB], prev_o, lane, p, dst, px0, prev_store);        \
         break;
             ML_STORE_CASE(0) ML_STORE_CASE(1) ML_STORE_CASE(2) ML_STORE_CASE(3) ML_STORE_CASE(4)
 #undef ML_STORE_CASE
@@ -978,35 +996,32 @@ __device__ __forceinline__ void ml_body(const pano_patch &p, const int ch, const
                 m_lo[s][j] = b;
             }
     };
-#if ML_OVERLAP
-    // Band i is staged in the buffer at off_cur (halfs from sh.hi), band i + 1 is in flight in
-    // the registers and goes to the buffer at off_nxt.
-    int off_cur = __builtin_amdgcn_readfirstlane(0), off_nxt = bstride;
-    fetch(band_of(word));
-    arrived(false);
-    commit(0);
+    // Band i is staged in the buffer at off_cur (halfs from sh.hi); the step stages band i + 1
+    // in the buffer at off_nxt.  ML_OVERLAP 0: one buffer, two barriers per step.
+    int off_cur = __builtin_amdgcn_readfirstlane(0), off_nxt = ML_OVERLAP ? bstride : off_cur;
     {
-        const unsigned w1 = nlist > 1 ? word_at(1) : 0u;
-        fetch(nlist > 1 ? band_of(w1) : -100000);        // (a band that does not exist: zeros)
+        Band pf;
+        unsigned pm;
+        fetch(pf, pm, band_of(word));
+        commit(pf, pm, off_cur, false);
     }
+    // One step with the run position u_c static; false = the run (or the list) ends here.
     auto step = [&](auto u_c) -> bool {
         constexpr int U = decltype(u_c)::value;
         const int t = band_of(word);
         const unsigned inf = bits_of(word);
         const bool more = i + 1 < nlist;
         const unsigned next = more ? word_at(i + 1) : 0u;
-        const int t2 = i + 2 < nlist ? band_of(word_at(i + 2)) : -100000;
         // (the two offsets swap every step; kept opaque, or the compiler unrolls the run loop
-        // once more to make them constants and spills 1500 registers doing so)
+        // once more to make them constants)
         off_cur = __builtin_amdgcn_readfirstlane(off_cur);
         off_nxt = __builtin_amdgcn_readfirstlane(off_nxt);
         asm volatile("" : "+s"(off_cur), "+s"(off_nxt));
         lds_barrier();              // band i is whole; nobody reads the other buffer any more
-        behind = prev_store;
+        Band pf;
+        unsigned pm;
+        fetch(pf, pm, more ? band_of(next) : -100000);   // (no such band: zeros)
         store_prev();                                    // the tile last step's band completed
-        arrived(behind);                                 // band i + 1: fetched a step ago
-        commit(off_nxt);
-        fetch(t2);
         if (t >= my_lo && t <= my_hi && (inf & (DMAX == 1 ? 0x0eu : 0x1fu))) {
             f32x16 mid;
             rowpass(mid, off_cur);
@@ -1014,6 +1029,8 @@ __device__ __forceinline__ void ml_body(const pano_patch &p, const int ch, const
             split_mid(mid, m_hi, m_lo);
             ml_colpass<C, U>(acc, m_hi, m_lo, s_ty, lane);
         }
+        if (!ML_OVERLAP) lds_barrier();                  // everybody finished reading the band
+        commit(pf, pm, off_nxt, true);
         prev_store = (inf >> (DMAX + 2)) & 1u;           // tile t - DMAX is wanted: complete now
         prev_o = t - DMAX;
         prev_u = U;
@@ -1026,37 +1043,6 @@ __device__ __forceinline__ void ml_body(const pano_patch &p, const int ch, const
         ++i;
         return more && band_of(next) == t + 1;
     };
-#else
-    fetch(band_of(word));
-    // One step with the run position u_c static; false = the run (or the list) ends here.
-    auto step = [&](auto u_c) -> bool {
-        constexpr int U = decltype(u_c)::value;
-        const int t = band_of(word);
-        const unsigned inf = bits_of(word);
-        const bool more = i + 1 < nlist;
-        const unsigned next = more ? word_at(i + 1) : 0u;
-        lds_barrier();                                   // everybody finished reading the band
-        arrived(behind);
-        commit(0);
-        lds_barrier();
-        if (more) fetch(band_of(next));                  // in FRONT of the stores: see `fetch`
-        behind = prev_store;
-        store_prev();                                    // the tile last step's band completed
-        if (t >= my_lo && t <= my_hi && (inf & (DMAX == 1 ? 0x0eu : 0x1fu))) {
-            f32x16 mid;
-            rowpass(mid, 0);
-            half8 m_hi[2], m_lo[2];
-            split_mid(mid, m_hi, m_lo);
-            ml_colpass<C, U>(acc, m_hi, m_lo, s_ty, lane);
-        }
-        prev_store = (inf >> (DMAX + 2)) & 1u;           // tile t - DMAX is wanted: complete now
-        prev_o = t - DMAX;
-        prev_u = U;
-        word = next;
-        ++i;
-        return more && band_of(next) == t + 1;
-    };
-#endif
     while (i < nlist) {                                  // one run per trip
         // (nothing of the previous run is alive: say so, else the accumulators are carried
         // from every exit below to here)
@@ -1073,10 +1059,7 @@ __device__ __forceinline__ void ml_body(const pano_patch &p, const int ch, const
                 if (!step(std::integral_constant<int, 4>{})) break;
             }
         }
-#if !ML_OVERLAP
-        behind |= prev_store;                            // (behind the next band's loads, if any)
-#endif
-        store_prev();                                    // the run's last tile, before the reset
+        if (prev_store) store_prev();                    // the run's last tile, before the reset
     }
 }
 
