@@ -92,6 +92,7 @@ extern "C" int pano_ctx_destroy(pano_ctx *ctx) {
     for (PanoTapSet &ts : ctx->tap_sets) tap_set_free(ts);
     if (ctx->item_buf) (void)hipFree(ctx->item_buf);
     if (ctx->item_counter) (void)hipFree(ctx->item_counter);
+    if (ctx->sift_raw) (void)hipFree(ctx->sift_raw);
     if (ctx->ev_regions) (void)hipEventDestroy(ctx->ev_regions);
     if (ctx->ev_upload) (void)hipEventDestroy(ctx->ev_upload);
     delete ctx;

@@ -103,6 +103,9 @@ struct pano_ctx {
     // caller's pinned buffer
     hipEvent_t ev_regions, ev_upload;
     bool upload_pending;
+    // pano_sift_extrema: the list of scale-space extrema between its two kernels (+ its counter)
+    uint32_t *sift_raw;
+    size_t sift_raw_cap;
 };
 
 int pano_ctx_enter(pano_ctx *ctx);
