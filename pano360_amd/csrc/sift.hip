@@ -219,6 +219,21 @@ __global__ __launch_bounds__(256) void sift_scan_kernel(const float *__restrict_
     if (r_begin >= r_end) return;                        // wave-uniform
     const bool mine = lane >= 1 && lane <= 62 && c < cols - SIFT_BORDER;
     const size_t plane = (size_t)rows * cols;
+    // the wave's extrema are collected in LDS and appended to the list 192 or more at a time:
+    // one returning atomic per (row, layer) with an extremum - seven in ten of them - was a
+    // million atomics on one word per 4K frame and set the kernel's duration (2.0 ms)
+    __shared__ uint32_t s_found[4][256];
+    uint32_t *found = s_found[wave];
+    int n_found = 0;                                     // wave-uniform
+    auto flush = [&]() {
+        if (n_found == 0) return;
+        int base = 0;
+        if (lane == 0) base = atomicAdd(raw_count, n_found);
+        base = __shfl(base, 0, 64);
+        for (int k = lane; k < n_found; k += 64)
+            if (base + k < cap) raw[base + k] = found[k];
+        n_found = 0;
+    };
     float hmx[NL][3], hmn[NL][3], ctr[NL][3];
     auto load_row = [&](const int y, auto slot_c) {
         constexpr int S = decltype(slot_c)::value;
@@ -250,11 +265,11 @@ __global__ __launch_bounds__(256) void sift_scan_kernel(const float *__restrict_
                              ((val > 0.0f && val >= M) || (val < 0.0f && val <= m));
             const unsigned long long bal = __ballot(ext);
             if (bal) {                                   // wave-uniform
-                int base = 0;
-                if (lane == 0) base = atomicAdd(raw_count, __popcll(bal));
-                base = __shfl(base, 0, 64);
-                const int at = base + __popcll(bal & ((1ull << lane) - 1ull));
-                if (ext && at < cap) raw[at] = (uint32_t)l << 28 | (uint32_t)y << 14 | (uint32_t)c;
+                if (ext)
+                    found[n_found + __popcll(bal & ((1ull << lane) - 1ull))] =
+                        (uint32_t)l << 28 | (uint32_t)y << 14 | (uint32_t)c;
+                n_found += __popcll(bal);
+                if (n_found > 192) flush();              // room for one more ballot of 64
             }
         }
     };
@@ -271,6 +286,7 @@ __global__ __launch_bounds__(256) void sift_scan_kernel(const float *__restrict_
         load_row(y + 3, s1{});
         eval_row(y + 2, s0{});
     }
+    flush();
 }
 
 __global__ __launch_bounds__(256) void sift_refine_kernel(
