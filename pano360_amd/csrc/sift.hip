@@ -390,14 +390,23 @@ __global__ __launch_bounds__(64) void sift_describe_kernel(
     const float *const *__restrict__ gauss, const int *__restrict__ dims, int first_octave,
     const pano_sift_keypoint *__restrict__ kpts, int n_cap, const int *__restrict__ n_dev,
     float *__restrict__ desc) {
-    constexpr int d = SIFT_D, nb = SIFT_N, HL = (d + 2) * (d + 2) * (nb + 2);
+    constexpr int d = SIFT_D, nb = SIFT_N;
     // The votes are summed in 64-bit fixed point (2^-24 units) with integer LDS atomics.  LDS
     // FLOAT atomics run far below the integer rate on gfx950: with ds_add_f32 the eight votes
     // of a sample were 84 % of the kernel (11.3 ms for the 135 k keypoints of a 4K frame, 1.8 ms
     // with the votes dropped, 2.9 ms with ds_add_u64; eight interleaved copies of a float
     // histogram against same-address conflicts: 9.4 ms).  The sums no longer depend on the
     // order of the additions; a vote is rounded to 6e-8, far below the final 8-bit rounding.
-    __shared__ unsigned long long hist[HL];              // two's complement sums
+    // A sample's eight votes go to two neighbouring orientation bins of four (row, column)
+    // cells: the two bins of a cell are summed by ONE 64-bit atomic, as two 32-bit fixed-point
+    // numbers side by side.  For that a cell keeps its ten bins twice, as pairs: (0,1) (2,3) ..
+    // (8,9) and (1,2) (3,4) .. (7,8); a vote pair (o, o + 1) goes to the first set when o is
+    // even, to the second when it is odd, and a bin's sum is the sum of its two homes.  The
+    // unit 2^-k is chosen per keypoint so that no 32-bit half can overflow: a bin collects at
+    // most the samples of 2 x 2 cells, 36 scl^2 of them, each at most 361 (255 sqrt 2).
+    // (Eight 64-bit atomics per sample: 2.85 ms for the 135 k keypoints of a 4K frame.)
+    constexpr int PAIRS = 9, CELLS = (d + 2) * (d + 2);
+    __shared__ unsigned long long hist[CELLS * PAIRS];
     const int lane = threadIdx.x;
     const int n = n_dev ? min(*n_dev, n_cap) : n_cap;   // the count may still be on the device
     for (int idx = blockIdx.x; idx < n; idx += gridDim.x) {
@@ -421,7 +430,11 @@ __global__ __launch_bounds__(64) void sift_describe_kernel(
         radius = min(radius, (int)sqrt((double)cols * cols + (double)rows * rows));
         cos_t = __fdiv_rn(cos_t, hist_width);
         sin_t = __fdiv_rn(sin_t, hist_width);
-        for (int t = lane; t < HL; t += 64) hist[t] = 0;
+        // 2^kbits units: 36 scl^2 samples x 361 x 2^kbits < 2^31
+        int kbits = 31 - (int)ceilf(log2f(36.0f * fmaxf(scl * scl, 1.0f) * 361.0f));
+        kbits = kbits > 24 ? 24 : (kbits < 0 ? 0 : kbits);
+        const float to_fixed = exp2f((float)kbits), from_fixed = exp2f(-(float)kbits);
+        for (int t = lane; t < CELLS * PAIRS; t += 64) hist[t] = 0;
         __syncthreads();
         const int side = 2 * radius + 1;
         // t / side without an integer divide per sample: exact for t < 2^22 (side < 2048)
@@ -458,30 +471,38 @@ __global__ __launch_bounds__(64) void sift_describe_kernel(
             const float v101 = v_rc10 * obin, v100 = v_rc10 - v101;
             const float v011 = v_rc01 * obin, v010 = v_rc01 - v011;
             const float v001 = v_rc00 * obin, v000 = v_rc00 - v001;
-            const int at = ((r0 + 1) * (d + 2) + c0 + 1) * (nb + 2) + o0;
-            auto vote = [&](const int where, const float v) {
-                atomicAdd(&hist[where], (unsigned long long)(long long)rintf(v * SIFT_VOTE_SCALE));
+            // pair index of (o0, o0 + 1) inside a cell: even o0 -> 0 .. 3 (.. 4), odd -> 5 .. 8
+            const int pair = (o0 & 1) ? 5 + (o0 >> 1) : (o0 >> 1);
+            const int cell = (r0 + 1) * (d + 2) + c0 + 1;
+            auto vote = [&](const int which, const float lo, const float hi) {
+                const unsigned long long a = (unsigned long long)(unsigned)(int)fmaxf(rintf(lo * to_fixed), 0.0f);
+                const unsigned long long b = (unsigned long long)(unsigned)(int)fmaxf(rintf(hi * to_fixed), 0.0f);
+                atomicAdd(&hist[which * PAIRS + pair], a | b << 32);
             };
-            vote(at, v000);
-            vote(at + 1, v001);
-            vote(at + (nb + 2), v010);
-            vote(at + (nb + 3), v011);
-            vote(at + (d + 2) * (nb + 2), v100);
-            vote(at + (d + 2) * (nb + 2) + 1, v101);
-            vote(at + (d + 3) * (nb + 2), v110);
-            vote(at + (d + 3) * (nb + 2) + 1, v111);
+            vote(cell, v000, v001);
+            vote(cell + 1, v010, v011);
+            vote(cell + (d + 2), v100, v101);
+            vote(cell + (d + 3), v110, v111);
         }
         __syncthreads();
         // circular orientation bins, then the 4 x 4 x 8 vector (two entries per lane)
         float v[2];
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
-            const int q = lane + 64 * e, cell = q / nb, kk = q % nb;
-            const int i = cell / d, j = cell % d;
-            const int at = ((i + 1) * (d + 2) + (j + 1)) * (nb + 2);
-            long long sum = (long long)hist[at + kk];
-            if (kk < 2) sum += (long long)hist[at + nb + kk];
-            v[e] = (float)sum * (1.0f / SIFT_VOTE_SCALE);
+            const int q = lane + 64 * e, cell_q = q / nb, kk = q % nb;
+            const int i = cell_q / d, j = cell_q % d;
+            const unsigned long long *h = hist + ((i + 1) * (d + 2) + (j + 1)) * PAIRS;
+            // bin b of a cell: low or high half of pair b >> 1 of the even set, and of the odd
+            // set (pairs (1,2) (3,4) (5,6) (7,8) at 5 .. 8)
+            auto bin = [&](const int b) -> long long {
+                long long sum = (long long)((h[b >> 1] >> (32 * (b & 1))) & 0xffffffffull);
+                if (b >= 1 && b <= 8)
+                    sum += (long long)((h[5 + ((b - 1) >> 1)] >> (32 * ((b - 1) & 1))) & 0xffffffffull);
+                return sum;
+            };
+            long long sum = bin(kk);
+            if (kk < 2) sum += bin(nb + kk);
+            v[e] = (float)sum * from_fixed;
         }
         float nrm2 = v[0] * v[0] + v[1] * v[1];
 #pragma unroll
