@@ -289,7 +289,8 @@ def run_cfg4(args, eng, rank, world, steps=None, warmup=None, detect=None):
             job, state["job"] = state.get("job"), features.sift_detect_async(frame, pyramid=pyr,
                                                                            eng=eng)
             if job is not None:
-                state["n_kp"] = len(job.result()[0])
+                state["kps"] = job.result()[0]
+                state["n_kp"] = len(state["kps"])
             return pyr, state.get("n_kp")
         return pyr, None
 
@@ -306,8 +307,44 @@ def run_cfg4(args, eng, rank, world, steps=None, warmup=None, detect=None):
     elapsed, (pyr, n_kp), times = timed_steps(eng, step, steps, warmup, fence)
     job = state.get("job")
     if job is not None:                      # the last frame's keypoints are still in flight
-        state["n_kp"] = n_kp = len(job.result()[0])
+        state["kps"] = job.result()[0]
+        state["n_kp"] = n_kp = len(state["kps"])
+    SIFT_KPS["last"] = state.get("kps")
     return elapsed, pyr, n_kp, times, (w, h)
+
+
+SIFT_KPS = {}      # the keypoints of the last detected frame (run_cfg4 -> cfg4_line)
+
+
+def sift_backend_roofline(kps, times, steps):
+    """SURVEY 8d's measure of the SIFT back end: keypoints per second, and for the two
+    gather-bound kernels the algorithmic bytes = (window area) x 4 B summed over the keypoints
+    (orientation: radius round(4.5 scl), descriptor: radius round(3 scl sqrt 2 x 2.5), scl = the
+    keypoint's scale inside its octave) over the kernel's time."""
+    import numpy as np
+    if kps is None or not len(kps):
+        return None
+    octave = (kps["octave"] & 255).astype(np.int64)
+    octave = np.where(octave < 128, octave, octave - 256)
+    scale = np.where(octave >= 0, 1.0 / (1 << np.maximum(octave, 0)), (1 << np.maximum(-octave, 0)))
+    scl = kps["size"].astype(np.float64) * scale * 0.5
+    side_o = 2 * np.rint(4.5 * scl) + 1
+    side_d = 2 * np.rint(3.0 * scl * np.sqrt(2.0) * 2.5) + 1
+    out = {"keypoints_per_frame": int(len(kps)),
+           "note": "gather-bound kernels: algorithmic bytes = window area x 4 B per keypoint "
+                   "(SURVEY 8d); one wave per keypoint, every sample reads four neighbours of the "
+                   "Gaussian layer through L1 / L2"}
+    for key, side, kern in (("orient", side_o, "sift_orient_kernel"),
+                            ("describe", side_d, "sift_describe_kernel")):
+        nbytes = float((side * side * 4.0).sum())
+        entry = {"window_bytes_per_keypoint": nbytes / len(kps), "GB_per_frame": nbytes / 1e9}
+        if kern in times and times[kern][0] > 0:
+            ms = times[kern][0] / steps
+            entry.update(ms_per_frame=ms, achieved_GBps=nbytes / (ms * 1e-3) / 1e9,
+                         frac_of_hbm_peak=nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                         keypoints_per_s=len(kps) / (ms * 1e-3))
+        out[key] = entry
+    return out
 
 
 class _Steps:
@@ -350,6 +387,9 @@ def cfg4_line(args, world, elapsed, pyr, n_kp, times, size):
     }
     if n_kp is not None:
         out["config"]["keypoints_per_frame"] = n_kp
+        out["sift"] = sift_backend_roofline(SIFT_KPS.get("last"), times, args.steps)
+        if out["sift"]:
+            out["sift"]["keypoints_per_s_end_to_end"] = n_kp * world / (ms * 1e-3)
     name = max(times, key=lambda k: times[k][0]) if times else None
     out["roofline"] = dict(kernel=name or "scale space (all launches)", bound="hbm",
                            achieved=algo / (ms * 1e-3) / 1e9, peak=HBM_PEAK_GBPS, unit="GB/s",
