@@ -713,10 +713,10 @@ __global__ __launch_bounds__(MB_THREADS_OF(GROUP), 4 / GROUP) void blur_mfma_ker
 //  * a band's chunks are whole (window V ends on multiples of 4 columns, include/pano360.h)
 //    and its rows reflect at most once: a chunk's address is its row's offset plus a constant,
 //    which threads stage which chunk is wave-uniform;
-//  * the column pass adds a band's contribution to ALL tiles within reach (the unwanted ones
-//    are never stored; an item's inner bands want all of them anyway) with the accumulators
-//    addressed statically - one variant of the pass per value of t mod (2 DMAX + 1) - and a
-//    tile's first contribution takes a zero C operand instead of a cleared accumulator;
+//  * the column pass addresses the accumulators statically: inside a run of consecutive bands
+//    a tile's accumulator is its position in the run mod (2 DMAX + 1) and the run loop is
+//    unrolled that many times; a tile's first contribution takes a zero C operand instead of
+//    a cleared accumulator (unwanted tiles are skipped by wave-uniform tests, as above);
 //  * exactly one tile per step can finish, and it is stored at the start of the next step
 //    (behind that step's barriers, in front of its fetch): no bookkeeping of finished ranges.
 #ifndef MB_LEAN
@@ -732,7 +732,7 @@ __global__ __launch_bounds__(MB_THREADS_OF(GROUP), 4 / GROUP) void blur_mfma_ker
 template <int C, int U>
 __device__ __forceinline__ void ml_colpass(f32x16 (&acc)[2 * ((C + 1) / 2) + 1],
                                            const half8 (&m_hi)[2], const half8 (&m_lo)[2],
-                                           const half8 *s_ty, const int lane) {
+                                           const half8 *s_ty, const int lane, const unsigned inf) {
     constexpr int DMAX = (C + 1) / 2, NB = 2 * DMAX + 1;
     constexpr int Z = C & 1;            // the outermost half-blocks are zero (odd C), not stored
     f32x16 zero;
@@ -741,6 +741,9 @@ __device__ __forceinline__ void ml_colpass(f32x16 (&acc)[2 * ((C + 1) / 2) + 1],
 #pragma unroll
     for (int d = -DMAX; d <= DMAX; ++d) {
         const int k = ((U - d) % NB + NB) % NB;          // tile t - d lives in accumulator k
+        // an unwanted tile is never stored: its products are skipped (wave-uniform; at the
+        // ends of a run and along ragged seams that is a quarter of the column pass)
+        if (!((inf >> (d + 2)) & 1u)) continue;
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             if (Z && ((d == -DMAX && s == 0) || (d == DMAX && s == 1))) continue;
@@ -1027,7 +1030,7 @@ __device__ __forceinline__ void ml_body(const pano_patch &p, const int ch, const
             rowpass(mid, off_cur);
             half8 m_hi[2], m_lo[2];
             split_mid(mid, m_hi, m_lo);
-            ml_colpass<C, U>(acc, m_hi, m_lo, s_ty, lane);
+            ml_colpass<C, U>(acc, m_hi, m_lo, s_ty, lane, inf);
         }
         if (!ML_OVERLAP) lds_barrier();                  // everybody finished reading the band
         commit(pf, pm, off_nxt, true);
