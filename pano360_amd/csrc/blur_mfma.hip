@@ -725,14 +725,9 @@ __global__ __launch_bounds__(MB_THREADS_OF(GROUP), 4 / GROUP) void blur_mfma_ker
 // 1: the lean path keeps TWO band buffers in LDS and one barrier per step: while a wave
 // multiplies band t it stages its share of band t + 1 into the other buffer and fetches band
 // t + 2, in the shadow of its own (and its SIMD partner's) matrix products
-// 2: as 1, and the band in flight lands in twelve vector registers the compiler does not
-// know (v240 .. v251: the kernel is compiled for 240, and the loads and the moves that read
-// them are inline asm), so that it can stay in flight from one step into the next without the
-// register allocator copying it half-loaded (see `fetch`)
 #ifndef ML_OVERLAP
-#define ML_OVERLAP 2
+#define ML_OVERLAP 1
 #endif
-#define ML_RESERVED_VGPRS 240
 
 template <int C, int U>
 __device__ __forceinline__ void ml_colpass(f32x16 (&acc)[2 * ((C + 1) / 2) + 1],
@@ -897,80 +892,6 @@ __device__ __forceinline__ void ml_body(const pano_patch &p, const int ch, const
             }
         }
     };
-    // ML_OVERLAP 2: chunk `it` of the band in flight lives in v[240 + 4 it : 243 + 4 it]
-#define ML_LOADS(IT, R0, R1, R2, R3)                                                             \
-    if (it == IT) {                                                                              \
-        if (!sharp)                                                                              \
-            asm volatile("buffer_load_dwordx4 v[" #R0 ":" #R3 "], %0, %1, 0 offen"               \
-                         :                                                                       \
-                         : "v"(voff), "s"(rs)                                                    \
-                         : "memory", "v" #R0, "v" #R1, "v" #R2, "v" #R3);                        \
-        else                                                                                     \
-            asm volatile("global_load_sshort v" #R0 ", %0, off\n\t"                              \
-                         "global_load_sshort v" #R1 ", %0, off offset:2\n\t"                     \
-                         "global_load_sshort v" #R2 ", %0, off offset:4\n\t"                     \
-                         "global_load_sshort v" #R3 ", %0, off offset:6"                         \
-                         :                                                                       \
-                         : "v"(at)                                                               \
-                         : "memory", "v" #R0, "v" #R1, "v" #R2, "v" #R3);                        \
-    }
-#define ML_TAKE(IT, R0, R1, R2, R3)                                                              \
-    if (it == IT)                                                                                \
-        asm volatile("v_mov_b32 %0, v" #R0 "\n\tv_mov_b32 %1, v" #R1 "\n\tv_mov_b32 %2, v" #R2    \
-                     "\n\tv_mov_b32 %3, v" #R3                                                   \
-                     : "=v"(e[0]), "=v"(e[1]), "=v"(e[2]), "=v"(e[3])                            \
-                     :                                                                           \
-                     : "memory");
-    unsigned pm_flight = 0;                              // the mask bits of the band in flight
-    auto fetch_reserved = [&](const int t) {
-        pm_flight = 0;
-#pragma unroll
-        for (int it = 0; it < ITS; ++it) {
-            if (!c_has[it]) continue;                    // wave-uniform
-            const int prow = 32 * t + c_rr[it];
-            const int ry = prow < 0 ? -prow : (prow >= p.h ? 2 * p.h - 2 - prow : prow);
-            const int vr = ry - p.vy0;
-            const bool ok = (unsigned)vr < (unsigned)p.vh && c_col[it] != OOB;
-            const unsigned voff = ok ? (unsigned)vr * (unsigned)p.vpitch * 4u + c_col[it] : OOB;
-            const gci16 at = owner + ((size_t)(unsigned)(p.y0 + (ok ? ry : 0)) * (unsigned)W +
-                                      (ok && sharp ? c_col[it] : (unsigned)p.x0));
-            ML_LOADS(0, 240, 241, 242, 243)
-            ML_LOADS(1, 244, 245, 246, 247)
-            ML_LOADS(2, 248, 249, 250, 251)
-            pm_flight |= ok ? 1u << it : 0u;
-        }
-    };
-    // waits for the band in flight - everything but the N youngest memory operations, the
-    // stores issued behind its loads - and stages it
-    auto commit_reserved = [&](const int buf, const bool behind) {
-        if (behind)
-            asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-        else
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-        for (int it = 0; it < ITS; ++it) {
-            if (!c_has[it]) continue;
-            unsigned e[4];
-            ML_TAKE(0, 240, 241, 242, 243)
-            ML_TAKE(1, 244, 245, 246, 247)
-            ML_TAKE(2, 248, 249, 250, 251)
-            half4 hi, lo;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                float v = __uint_as_float(e[j]);
-                if (sharp) v = (int)e[j] == p.index && ((pm_flight >> it) & 1u) ? 1.0f : 0.0f;
-                _Float16 a, b;
-                split16(v * MB_IN_SCALE, a, b);
-                hi[j] = a;
-                lo[j] = b;
-            }
-            const int at = c_lds[it] + buf;
-            *(half4 *)(sh.hi + at) = hi;
-            if (!sharp) *(half4 *)(sh.lo + at) = lo;     // the mask has no low part
-        }
-    };
-#undef ML_LOADS
-#undef ML_TAKE
     // `behind`: sixteen stores were issued behind the loads (they stay in flight)
     auto commit = [&](Band &pf, const unsigned pm, const int buf, const bool behind) {
         static_assert(ITS == 3, "the hand-placed waits name three chunks");
@@ -1081,48 +1002,6 @@ __device__ __forceinline__ void ml_body(const pano_patch &p, const int ch, const
     // Band i is staged in the buffer at off_cur (halfs from sh.hi); the step stages band i + 1
     // in the buffer at off_nxt.  ML_OVERLAP 0: one buffer, two barriers per step.
     int off_cur = __builtin_amdgcn_readfirstlane(0), off_nxt = ML_OVERLAP ? bstride : off_cur;
-#if ML_OVERLAP == 2
-    // Band i is staged at off_cur, band i + 1 is in flight in the reserved registers: a step
-    // stores the previous tile, waits for band i + 1 (fetched a whole step ago; the sixteen
-    // stores just issued stay in flight), stages it at off_nxt, fetches band i + 2 and only then
-    // runs its two passes over band i.
-    fetch_reserved(band_of(word));
-    commit_reserved(off_cur, false);
-    fetch_reserved(nlist > 1 ? band_of(word_at(1)) : -100000);           // (no such band: zeros)
-    auto step = [&](auto u_c) -> bool {
-        constexpr int U = decltype(u_c)::value;
-        const int t = band_of(word);
-        const unsigned inf = bits_of(word);
-        const bool more = i + 1 < nlist;
-        const unsigned next = more ? word_at(i + 1) : 0u;
-        const int t2 = i + 2 < nlist ? band_of(word_at(i + 2)) : -100000;
-        off_cur = __builtin_amdgcn_readfirstlane(off_cur);
-        off_nxt = __builtin_amdgcn_readfirstlane(off_nxt);
-        asm volatile("" : "+s"(off_cur), "+s"(off_nxt));
-        lds_barrier();              // band i is whole; nobody reads the other buffer any more
-        store_prev();               // sixteen stores, wanted or dropped, behind band i + 1's loads
-        commit_reserved(off_nxt, true);
-        fetch_reserved(t2);
-        if (t >= my_lo && t <= my_hi && (inf & (DMAX == 1 ? 0x0eu : 0x1fu))) {
-            f32x16 mid;
-            rowpass(mid, off_cur);
-            half8 m_hi[2], m_lo[2];
-            split_mid(mid, m_hi, m_lo);
-            ml_colpass<C, U>(acc, m_hi, m_lo, s_ty, lane, inf);
-        }
-        prev_store = (inf >> (DMAX + 2)) & 1u;           // tile t - DMAX is wanted: complete now
-        prev_o = t - DMAX;
-        prev_u = U;
-        word = next;
-        {
-            const int tmp = off_cur;
-            off_cur = off_nxt;
-            off_nxt = tmp;
-        }
-        ++i;
-        return more && band_of(next) == t + 1;
-    };
-#else
     {
         Band pf;
         unsigned pm;
@@ -1167,7 +1046,6 @@ __device__ __forceinline__ void ml_body(const pano_patch &p, const int ch, const
         ++i;
         return more && band_of(next) == t + 1;
     };
-#endif
     while (i < nlist) {                                  // one run per trip
         // (nothing of the previous run is alive: say so, else the accumulators are carried
         // from every exit below to here)
@@ -1188,11 +1066,7 @@ __device__ __forceinline__ void ml_body(const pano_patch &p, const int ch, const
     }
 }
 
-__global__ __launch_bounds__(MB_THREADS_OF(4), 1)
-#if ML_OVERLAP == 2
-__attribute__((amdgpu_num_vgpr(ML_RESERVED_VGPRS)))
-#endif
-void blur_lean_kernel(
+__global__ __launch_bounds__(MB_THREADS_OF(4), 1) void blur_lean_kernel(
     const pano_patch *__restrict__ table, MbLevels L, const unsigned char *__restrict__ tables,
     const int16_t *__restrict__ owner, int W, const uint8_t *__restrict__ flags,
     const int2 *__restrict__ items) {
