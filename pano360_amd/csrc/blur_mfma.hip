@@ -728,15 +728,6 @@ __global__ __launch_bounds__(MB_THREADS_OF(GROUP), 4 / GROUP) void blur_mfma_ker
 #ifndef ML_OVERLAP
 #define ML_OVERLAP 1
 #endif
-// 1: waves 4-7 - the group's two lightest levels, or no level at all in a group of fewer than
-// three - stage the whole band (five or six chunks per thread), waves 0-3 none of it;
-// 0: every thread stages two or three chunks (ML_SWAP: which half takes the third)
-#ifndef ML_STAGE_LIGHT
-#define ML_STAGE_LIGHT 1
-#endif
-#ifndef ML_SWAP
-#define ML_SWAP 256
-#endif
 
 template <int C, int U>
 __device__ __forceinline__ void ml_colpass(f32x16 (&acc)[2 * ((C + 1) / 2) + 1],
@@ -809,9 +800,7 @@ __device__ __forceinline__ void ml_body(const pano_patch &p, const int ch, const
                                         const int16_t *__restrict__ owner_, const int W,
                                         const int tx0, const int second) {
     constexpr int KS = 2 + 2 * C, DMAX = (C + 1) / 2, NB = 2 * DMAX + 1;
-    // chunks per staging thread: 512 + 256 CM chunks per band, staged by 512 or by 256 threads
-    constexpr int THREADS = ML_STAGE_LIGHT ? 256 : MB_THREADS_OF(4);
-    constexpr int ITS = ML_STAGE_LIGHT ? 6 : MB_ITS_OF(4);
+    constexpr int THREADS = MB_THREADS_OF(4), ITS = MB_ITS_OF(4);
     constexpr unsigned OOB = 0x80000000u;
     constexpr bool sharp = SHARP;                        // stitcher.py:207-208: the 0 / 1 mask
     // halfs from band buffer 0 to band buffer 1 (ML_OVERLAP)
@@ -837,18 +826,11 @@ __device__ __forceinline__ void ml_body(const pano_patch &p, const int ch, const
     bool c_has[ITS];
 #pragma unroll
     for (int it = 0; it < ITS; ++it) {
-        // (waves 4-7 work on the group's two lightest levels: they take the larger share of
-        // the band, the chunks beyond the first 1024)
-#if ML_STAGE_LIGHT
-        const int grp = (tid & 255) + THREADS * it;
+        // (waves 4-7 work on the group's two lightest levels, or on none: they take the larger
+        // share of the band - the chunks beyond the first 1024; 0.722 -> 0.709 ms)
+        const int grp = (tid ^ 256) + THREADS * it;
         const int rr = grp / CPR, c4 = grp - rr * CPR;
-        c_has[it] = __builtin_amdgcn_readfirstlane(wv) >= 4 &&
-                    __builtin_amdgcn_readfirstlane(((wv & 3) << 6) + THREADS * it) < NCH;
-#else
-        const int grp = (tid ^ ML_SWAP) + THREADS * it;
-        const int rr = grp / CPR, c4 = grp - rr * CPR;
-        c_has[it] = __builtin_amdgcn_readfirstlane(((wv << 6) ^ ML_SWAP) + THREADS * it) < NCH;
-#endif
+        c_has[it] = __builtin_amdgcn_readfirstlane(((wv << 6) ^ 256) + THREADS * it) < NCH;
         const int vc = X0 - 16 * sh.CM + 4 * c4 - p.vx0;     // first column, in V
         const bool col_ok = vc >= 0 && vc + 4 <= p.vw;
         c_rr[it] = rr;
@@ -914,23 +896,6 @@ __device__ __forceinline__ void ml_body(const pano_patch &p, const int ch, const
     };
     // `behind`: sixteen stores were issued behind the loads (they stay in flight)
     auto commit = [&](Band &pf, const unsigned pm, const int buf, const bool behind) {
-#if ML_STAGE_LIGHT
-#define ML_WAIT(N)                                                                             \
-    if (sharp)                                                                                 \
-        asm volatile("s_waitcnt vmcnt(" #N ")"                                                 \
-                     : "+v"(pf.e[0][0]), "+v"(pf.e[0][1]), "+v"(pf.e[0][2]), "+v"(pf.e[0][3]), \
-                       "+v"(pf.e[1][0]), "+v"(pf.e[1][1]), "+v"(pf.e[1][2]), "+v"(pf.e[1][3]), \
-                       "+v"(pf.e[2][0]), "+v"(pf.e[2][1]), "+v"(pf.e[2][2]), "+v"(pf.e[2][3]), \
-                       "+v"(pf.e[3][0]), "+v"(pf.e[3][1]), "+v"(pf.e[3][2]), "+v"(pf.e[3][3]), \
-                       "+v"(pf.e[4][0]), "+v"(pf.e[4][1]), "+v"(pf.e[4][2]), "+v"(pf.e[4][3]), \
-                       "+v"(pf.e[5][0]), "+v"(pf.e[5][1]), "+v"(pf.e[5][2]), "+v"(pf.e[5][3])  \
-                     :                                                                         \
-                     : "memory");                                                              \
-    else                                                                                       \
-        asm volatile("s_waitcnt vmcnt(" #N ")"                                                 \
-                     : "+v"(pf.v[0]), "+v"(pf.v[1]), "+v"(pf.v[2]), "+v"(pf.v[3]),             \
-                       "+v"(pf.v[4]), "+v"(pf.v[5])::"memory")
-#else
         static_assert(ITS == 3, "the hand-placed waits name three chunks");
 #define ML_WAIT(N)                                                                             \
     if (sharp)                                                                                 \
@@ -942,7 +907,6 @@ __device__ __forceinline__ void ml_body(const pano_patch &p, const int ch, const
                      : "memory");                                                              \
     else                                                                                       \
         asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(pf.v[0]), "+v"(pf.v[1]), "+v"(pf.v[2])::"memory")
-#endif
         if (behind) {
             ML_WAIT(16);
         } else {
