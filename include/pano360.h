@@ -165,13 +165,18 @@ int pano_interior_block(void);
  *                         special case (no reflected columns, whole chunks, one reflection
  *                         of the rows at most) run through a kernel with a short instruction
  *                         stream, the rest through the general one; 0 = the general kernel
- *                         for everything.  Same results bit for bit. */
+ *                         for everything.  Same results bit for bit.
+ *   PANO_OPT_STITCH_STREAMS  pano_stitch_multiband: 1 (default) = the interior map runs beside
+ *                         the region search, and the blur's tile flags and work list beside
+ *                         the warp, on a second stream the context owns (ordered by events);
+ *                         0 = everything on the context's stream.  Same results. */
 typedef struct pano_ctx pano_ctx;
 #define PANO_OPT_BLUR_KERNEL 0
 #define PANO_OPT_OWN_PRUNE 1
 #define PANO_OPT_BLUR_SEGMENTS 2
 #define PANO_OPT_BLUR_LEAN 3
-#define PANO_OPT_COUNT 4
+#define PANO_OPT_STITCH_STREAMS 4
+#define PANO_OPT_COUNT 5
 #define PANO_BLUR_MFMA 0
 #define PANO_BLUR_VALU 1
 int pano_ctx_create(int device, void *stream, pano_ctx **out);

@@ -51,6 +51,7 @@ extern "C" int pano_ctx_create(int device, void *stream, pano_ctx **out) {
     ctx->opt[PANO_OPT_OWN_PRUNE] = 1;
     ctx->opt[PANO_OPT_BLUR_SEGMENTS] = 1;
     ctx->opt[PANO_OPT_BLUR_LEAN] = 1;
+    ctx->opt[PANO_OPT_STITCH_STREAMS] = 1;
     *out = ctx;
     return PANO_OK;
 }
@@ -93,6 +94,12 @@ extern "C" int pano_ctx_destroy(pano_ctx *ctx) {
     if (ctx->item_buf) (void)hipFree(ctx->item_buf);
     if (ctx->item_counter) (void)hipFree(ctx->item_counter);
     if (ctx->sift_raw) (void)hipFree(ctx->sift_raw);
+    if (ctx->side) {
+        (void)hipStreamSynchronize(ctx->side);
+        (void)hipStreamDestroy(ctx->side);
+    }
+    if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+    if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
     if (ctx->ev_regions) (void)hipEventDestroy(ctx->ev_regions);
     if (ctx->ev_upload) (void)hipEventDestroy(ctx->ev_upload);
     delete ctx;

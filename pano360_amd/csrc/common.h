@@ -101,7 +101,8 @@ struct pano_ctx {
     uint64_t tick;
     // pano_stitch_multiband: the regions' copy has landed / the record table has left the
     // caller's pinned buffer
-    hipEvent_t ev_regions, ev_upload;
+    hipEvent_t ev_regions, ev_upload, ev_fork, ev_join;
+    hipStream_t side;               // second stream of pano_stitch_multiband
     bool upload_pending;
     // pano_sift_extrema: the list of scale-space extrema between its two kernels (+ its counter)
     uint32_t *sift_raw;

@@ -5,8 +5,21 @@
 static int ensure_events(pano_ctx *ctx) {
     if (!ctx->ev_regions) PANO_HIP(hipEventCreateWithFlags(&ctx->ev_regions, hipEventDisableTiming));
     if (!ctx->ev_upload) PANO_HIP(hipEventCreateWithFlags(&ctx->ev_upload, hipEventDisableTiming));
+    if (!ctx->ev_fork) PANO_HIP(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+    if (!ctx->ev_join) PANO_HIP(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
+    if (!ctx->side) PANO_HIP(hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
     return PANO_OK;
 }
+
+// Runs `call` with the context targeted at its side stream.
+#define ON_SIDE(ctx, call)                  \
+    do {                                    \
+        const hipStream_t main_ = (ctx)->stream; \
+        (ctx)->stream = (ctx)->side;        \
+        const int rc_side_ = (call);        \
+        (ctx)->stream = main_;              \
+        if (rc_side_) return rc_side_;      \
+    } while (0)
 
 extern "C" int pano_stitch_multiband(pano_ctx *ctx, pano_stitch_args *a, int resume) {
     PANO_ENTER(ctx, "pano_stitch_multiband");
@@ -39,6 +52,17 @@ extern "C" int pano_stitch_multiband(pano_ctx *ctx, pano_stitch_args *a, int res
         if (int rc = pano_ownership_cameras(ctx, a->cams, a->n, a->H, a->W, a->own0, a->own1,
                                             a->sin_t, a->cos_t, a->tan_p, a->owner, a->valid))
             return rc;
+        // Two small chains depend on the owner map only - the interior map and the region
+        // search - and two more on the record table only - the warp and the blur's tile flags
+        // and work list: the context's side stream takes one of each pair (the short kernels of
+        // a config-3 stitch were 0.15 ms of a 2.0 ms timeline, plus the gaps between them).
+        const bool forked = ctx->opt[PANO_OPT_STITCH_STREAMS] != 0;
+        if (forked && interior) {
+            PANO_HIP(hipEventRecord(ctx->ev_fork, s));
+            PANO_HIP(hipStreamWaitEvent(ctx->side, ctx->ev_fork, 0));
+            ON_SIDE(ctx, pano_interior_map(ctx, a->owner, a->H, a->W, a->own0, a->own1, a->radius,
+                                           a->block_owner, a->interior));
+        }
         // one record per (camera, span of columns it owns): the spans' search, its copy to the host
         if (int rc = pano_owned_regions(ctx, a->owner, a->H, a->W, a->own0, a->own1, a->n,
                                         a->min_gap, a->max_spans, a->marks, a->regions))
@@ -48,7 +72,7 @@ extern "C" int pano_stitch_multiband(pano_ctx *ctx, pano_stitch_args *a, int res
         PANO_HIP(hipEventRecord(ctx->ev_regions, s));
         // the interior map needs the owner map only: queued before the wait, it keeps the GPU
         // busy while the host lays out the windows
-        if (interior)
+        if (interior && !forked)
             if (int rc = pano_interior_map(ctx, a->owner, a->H, a->W, a->own0, a->own1, a->radius,
                                            a->block_owner, a->interior))
                 return rc;
@@ -95,16 +119,32 @@ extern "C" int pano_stitch_multiband(pano_ctx *ctx, pano_stitch_args *a, int res
             on = sum / nr >= 768.0;
         }
         if (on) {
+            if (ctx->opt[PANO_OPT_STITCH_STREAMS] != 0) {        // the interior map is the side stream's
+                PANO_HIP(hipEventRecord(ctx->ev_join, ctx->side));
+                PANO_HIP(hipStreamWaitEvent(s, ctx->ev_join, 0));
+            }
             if (int rc = pano_blur_tiles(ctx, a->table, nr, lay.max_aw, lay.max_ah, a->W, a->radius,
                                          a->interior, a->tile_flags, a->need))
                 return rc;
             a->used_need = 1;
         }
     }
+    const bool fork2 = ctx->opt[PANO_OPT_STITCH_STREAMS] != 0 && interior && n_blur && nr &&
+                       !a->used_need && tile_grid == 32 && a->tile_flags;
+    if (fork2) {            // the blur's tile flags and sorted work list beside the warp
+        PANO_HIP(hipStreamWaitEvent(ctx->side, ctx->ev_upload, 0));      // the record table
+        ON_SIDE(ctx, pano_multiband_blur_prepare(ctx, a->table, nr, lay.max_aw, lay.max_ah, a->W,
+                                                 a->interior, a->tile_flags));
+        PANO_HIP(hipEventRecord(ctx->ev_join, ctx->side));
+    } else if (ctx->opt[PANO_OPT_STITCH_STREAMS] != 0 && interior) {
+        PANO_HIP(hipEventRecord(ctx->ev_join, ctx->side));               // the interior map
+    }
     if (int rc = pano_warp_windows(ctx, a->cams, a->table, nr, lay.max_vw, lay.max_vh, a->sin_t,
                                    a->cos_t, a->tan_p, a->lut, a->lut_stride,
                                    a->used_need ? a->need : nullptr))
         return rc;
+    if (ctx->opt[PANO_OPT_STITCH_STREAMS] != 0 && interior)
+        PANO_HIP(hipStreamWaitEvent(s, ctx->ev_join, 0));
     if (n_blur)
         if (int rc = pano_multiband_blur(ctx, a->table, nr, lay.max_aw, lay.max_vh, lay.max_ah,
                                          a->owner, a->W, a->taps, (const int *)a->ntaps, n_blur,

@@ -686,6 +686,8 @@ class Engine:
         # the whole launch sequence of a fused stitch in one native call (pano_stitch_multiband);
         # False: launch by launch from here (the same entry points; what the side streams use)
         self.native_stitch = side_stream == 0 and os.environ.get("PANO_NATIVE_STITCH", "1") != "0"
+        if os.environ.get("PANO_STITCH_STREAMS", "1") == "0":       # (A/B timing)
+            self.set_option(_lib.OPT_STITCH_STREAMS, 0)
         self._stitch_ws = {}
         self._plans = {}
 

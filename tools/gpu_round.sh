@@ -4,7 +4,7 @@
 #   tools/gpu_round.sh <tag> [quick]
 set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
-OUT=gpurun_out/${1:-r02}
+OUT=gpurun_out/${1:-r03}
 MODE=${2:-full}
 mkdir -p "$OUT"
 export TMPDIR=/tmp
