@@ -45,6 +45,10 @@ extern "C" int pano_stitch_multiband(pano_ctx *ctx, pano_stitch_args *a, int res
                  "pano_stitch_multiband: interior map without its buffers");
     const hipStream_t s = (hipStream_t)stream;
     if (int rc = ensure_events(ctx)) return rc;
+    // the second stream pays on large mosaics only (config 3: 1.975 -> 1.945 ms per stitch;
+    // config 2, 7.9 MP: 0.527 -> 0.537: the forks and joins cost more than the overlap gives)
+    const bool two_streams = ctx->opt[PANO_OPT_STITCH_STREAMS] != 0 &&
+                             (long long)a->H * (a->own1 - a->own0) >= (1ll << 24);
     const int tile_grid = pano_blur_tile_grid(ctx);
     const int stride = 5 + 2 * a->max_spans;
 
@@ -56,7 +60,7 @@ extern "C" int pano_stitch_multiband(pano_ctx *ctx, pano_stitch_args *a, int res
         // search - and two more on the record table only - the warp and the blur's tile flags
         // and work list: the context's side stream takes one of each pair (the short kernels of
         // a config-3 stitch were 0.15 ms of a 2.0 ms timeline, plus the gaps between them).
-        const bool forked = ctx->opt[PANO_OPT_STITCH_STREAMS] != 0;
+        const bool forked = two_streams;
         if (forked && interior) {
             PANO_HIP(hipEventRecord(ctx->ev_fork, s));
             PANO_HIP(hipStreamWaitEvent(ctx->side, ctx->ev_fork, 0));
@@ -119,7 +123,7 @@ extern "C" int pano_stitch_multiband(pano_ctx *ctx, pano_stitch_args *a, int res
             on = sum / nr >= 768.0;
         }
         if (on) {
-            if (ctx->opt[PANO_OPT_STITCH_STREAMS] != 0) {        // the interior map is the side stream's
+            if (two_streams) {                                   // the interior map is the side stream's
                 PANO_HIP(hipEventRecord(ctx->ev_join, ctx->side));
                 PANO_HIP(hipStreamWaitEvent(s, ctx->ev_join, 0));
             }
@@ -129,22 +133,21 @@ extern "C" int pano_stitch_multiband(pano_ctx *ctx, pano_stitch_args *a, int res
             a->used_need = 1;
         }
     }
-    const bool fork2 = ctx->opt[PANO_OPT_STITCH_STREAMS] != 0 && interior && n_blur && nr &&
+    const bool fork2 = two_streams && interior && n_blur && nr &&
                        !a->used_need && tile_grid == 32 && a->tile_flags;
     if (fork2) {            // the blur's tile flags and sorted work list beside the warp
         PANO_HIP(hipStreamWaitEvent(ctx->side, ctx->ev_upload, 0));      // the record table
         ON_SIDE(ctx, pano_multiband_blur_prepare(ctx, a->table, nr, lay.max_aw, lay.max_ah, a->W,
                                                  a->interior, a->tile_flags));
         PANO_HIP(hipEventRecord(ctx->ev_join, ctx->side));
-    } else if (ctx->opt[PANO_OPT_STITCH_STREAMS] != 0 && interior) {
+    } else if (two_streams && interior) {
         PANO_HIP(hipEventRecord(ctx->ev_join, ctx->side));               // the interior map
     }
     if (int rc = pano_warp_windows(ctx, a->cams, a->table, nr, lay.max_vw, lay.max_vh, a->sin_t,
                                    a->cos_t, a->tan_p, a->lut, a->lut_stride,
                                    a->used_need ? a->need : nullptr))
         return rc;
-    if (ctx->opt[PANO_OPT_STITCH_STREAMS] != 0 && interior)
-        PANO_HIP(hipStreamWaitEvent(s, ctx->ev_join, 0));
+    if (two_streams && interior) PANO_HIP(hipStreamWaitEvent(s, ctx->ev_join, 0));
     if (n_blur)
         if (int rc = pano_multiband_blur(ctx, a->table, nr, lay.max_aw, lay.max_vh, lay.max_ah,
                                          a->owner, a->W, a->taps, (const int *)a->ntaps, n_blur,
