@@ -180,6 +180,18 @@ __device__ __forceinline__ AlphaBound alpha_bound(const pano_camera *cam, const 
 #ifndef OWN_ROWS
 #define OWN_ROWS 16
 #endif
+// A workgroup takes OWN_SUB sub-tiles of 64 x OWN_ROWS pixels, one above the other: the camera
+// list is built once for all of them and wave w bounds the listed cameras on sub-tile w, a
+// camera per lane, without a barrier of its own (the set-up of a 64 x 16 tile - list, ranges,
+// bounds, five barriers and their dependent loads - was 0.10 of the kernel's 0.21 ms on
+// config 3, profiles/r03/probes/ownership_noeval_ablation.patch; with one set-up per four
+// sub-tiles the waves bound four sub-tiles in the time of one).
+#define OWN_SUB 4
+#define OWN_TILE_ROWS (OWN_ROWS * OWN_SUB)
+
+__device__ __forceinline__ bool tile_inside(const pano_camera *cam, int x0, int x1, int y0, int y1) {
+    return x0 >= cam->x0 && x1 <= cam->x0 + cam->w && y0 >= cam->y0 && y1 <= cam->y0 + cam->h;
+}
 
 __global__ __launch_bounds__(256) void ownership_cameras_kernel(
     const pano_camera *__restrict__ cams, int n, int H, int W, int xs0, int xs1,
@@ -187,21 +199,26 @@ __global__ __launch_bounds__(256) void ownership_cameras_kernel(
     const double *__restrict__ tan_p, int16_t *__restrict__ owner,
     uint8_t *__restrict__ valid, int prune) {
     __shared__ CamList sh;
-    __shared__ double s_rng[6];
-    __shared__ float s_wmax[4];
-    __shared__ int s_keep[OWN_LIST];
-    const int tid = threadIdx.y * 64 + threadIdx.x, lane = threadIdx.x, wave = threadIdx.y;
-    const int bx0 = xs0 + blockIdx.x * 64, by0 = blockIdx.y * OWN_ROWS;
-    const int bx1 = min(bx0 + 64, xs1), by1 = min(by0 + OWN_ROWS, H);
+    __shared__ int s_keep[OWN_SUB][OWN_LIST];
+    __shared__ float s_hi[OWN_SUB][OWN_LIST];      // upper bounds, lists of more than 64 cameras only
+    __shared__ int s_ncand[OWN_SUB];
+    __shared__ float s_low[OWN_SUB];
+    const int lane = threadIdx.x, wave = threadIdx.y;
+    const int bx0 = xs0 + blockIdx.x * 64, by0 = blockIdx.y * OWN_TILE_ROWS;
+    const int bx1 = min(bx0 + 64, xs1), by1 = min(by0 + OWN_TILE_ROWS, H);
     const int listed = build_camera_list(sh, cams, n, bx0, bx1, by0, by1);
-    int ncand = listed < 0 ? n : listed;
-    const int *list = sh.list;
+    const bool pruned = listed > 1 && prune;
 
-    if (listed > 1 && prune) {
-        // ranges of the ray components over the tile (wave 0: columns, wave 1: rows)
-        if (wave == 0) {
+    if (pruned) {
+        // wave w = sub-tile w: ranges of the ray components over its columns and rows (every
+        // lane ends up with all six), then one listed camera per lane
+        const int sy0 = by0 + OWN_ROWS * wave, sy1 = min(sy0 + OWN_ROWS, H);
+        int nc = 0;
+        float L = 0.0f;
+        if (sy0 < H) {                                           // wave-uniform
             const int xc = min(bx0 + lane, bx1 - 1);
             double lo_s = sin_t[xc], hi_s = lo_s, lo_c = cos_t[xc], hi_c = lo_c;
+            double lo_t = tan_p[min(sy0 + (lane & (OWN_ROWS - 1)), sy1 - 1)], hi_t = lo_t;
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) {
                 lo_s = fmin(lo_s, __shfl_xor(lo_s, off, 64));
@@ -209,102 +226,99 @@ __global__ __launch_bounds__(256) void ownership_cameras_kernel(
                 lo_c = fmin(lo_c, __shfl_xor(lo_c, off, 64));
                 hi_c = fmax(hi_c, __shfl_xor(hi_c, off, 64));
             }
-            if (lane == 0) {
-                s_rng[0] = lo_s; s_rng[1] = hi_s; s_rng[4] = lo_c; s_rng[5] = hi_c;
-            }
-        } else if (wave == 1) {
-            const double tv = tan_p[min(by0 + (lane & (OWN_ROWS - 1)), by1 - 1)];
-            double lo_t = tv, hi_t = tv;
 #pragma unroll
             for (int off = OWN_ROWS / 2; off > 0; off >>= 1) {
                 lo_t = fmin(lo_t, __shfl_xor(lo_t, off, 64));
                 hi_t = fmax(hi_t, __shfl_xor(hi_t, off, 64));
             }
-            if (lane == 0) {
-                s_rng[2] = lo_t; s_rng[3] = hi_t;
+            const double rng[6] = {lo_s, hi_s, lo_t, hi_t, lo_c, hi_c};
+            for (int base = 0; base < listed; base += 64) {
+                const int k = base + lane;
+                AlphaBound bnd = {0.0f, -1.0f};
+                if (k < listed) {
+                    const pano_camera *cam = cams + sh.list[k];
+                    bnd = alpha_bound(cam, rng);
+                    // A lower bound beats other cameras on EVERY pixel of the tile only if this camera
+                    // is a candidate on every pixel, i.e. the tile lies inside its patch rectangle
+                    // (stitcher.py:289-297).  The rectangle of a frame across the +-pi seam stops short
+                    // of the mosaic's ends (its range comes from border samples, :107-122), although
+                    // the frame itself reaches them: found by the full-size config 5 test, where such
+                    // a camera's bound pruned the only candidate of the last 32 columns.
+                    if (!tile_inside(cam, bx0, bx1, sy0, sy1)) bnd.lo = 0.0f;
+                    s_hi[wave][k] = bnd.hi;
+                }
+                L = fmaxf(L, bnd.lo);
             }
-        }
-        __syncthreads();
-        AlphaBound bnd = {0.0f, -1.0f};
-        if (tid < listed) {
-            const pano_camera *cam = cams + sh.list[tid];
-            bnd = alpha_bound(cam, s_rng);
-            // A lower bound beats other cameras on EVERY pixel of the tile only if this camera
-            // is a candidate on every pixel, i.e. the tile lies inside its patch rectangle
-            // (stitcher.py:289-297).  The rectangle of a frame across the +-pi seam stops short
-            // of the mosaic's ends (its range comes from border samples, :107-122), although
-            // the frame itself reaches them: found by the full-size config 5 test, where such
-            // a camera's bound pruned the only candidate of the last 32 columns.
-            if (!(bx0 >= cam->x0 && bx1 <= cam->x0 + cam->w && by0 >= cam->y0 &&
-                  by1 <= cam->y0 + cam->h))
-                bnd.lo = 0.0f;
-        }
-        float wmax = bnd.lo;
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) wmax = fmaxf(wmax, __shfl_xor(wmax, off, 64));
-        if (lane == 0) s_wmax[wave] = wmax;
-        __syncthreads();
-        const float L = fmaxf(fmaxf(s_wmax[0], s_wmax[1]), fmaxf(s_wmax[2], s_wmax[3]));
-        const bool keep = tid < listed && bnd.hi >= L;
-        const unsigned long long bal = __ballot(keep);
-        if (lane == 0) sh.wave[wave] = __popcll(bal);
-        __syncthreads();
-        int off = 0;
-        for (int w = 0; w < wave; ++w) off += sh.wave[w];
-        off += __popcll(bal & ((1ull << lane) - 1ull));
-        if (keep) s_keep[off] = sh.list[tid];                 // order preserved: first maximum wins
-        ncand = sh.wave[0] + sh.wave[1] + sh.wave[2] + sh.wave[3];
-        list = s_keep;
-        __syncthreads();
-        // One survivor with a positive lower bound: its alpha is positive on every pixel
-        // of the tile and above every other camera's, so it owns the whole tile and no
-        // pixel needs evaluating - provided the tile lies inside its patch rectangle
-        // (outside it the camera is no candidate, stitcher.py:289-297).
-        if (ncand == 1 && L > 0.0f) {
-            const int i = s_keep[0];
-            const pano_camera *cam = cams + i;
-            if (bx0 >= cam->x0 && bx1 <= cam->x0 + cam->w && by0 >= cam->y0 &&
-                by1 <= cam->y0 + cam->h) {
-                const int x = bx0 + lane;
-                if (x < xs1)
-                    for (int y = by0 + wave; y < by1; y += 4) {
-                        owner[(size_t)y * W + x] = (int16_t)i;
-                        valid[(size_t)y * W + x] = 1;
-                    }
-                return;
+            for (int off = 32; off > 0; off >>= 1) L = fmaxf(L, __shfl_xor(L, off, 64));
+            // the survivors, order preserved: the first maximum wins (s_hi: this lane's own writes)
+            for (int base = 0; base < listed; base += 64) {
+                const int k = base + lane;
+                const bool keep = k < listed && s_hi[wave][k] >= L;
+                const unsigned long long bal = __ballot(keep);
+                if (keep) s_keep[wave][nc + __popcll(bal & ((1ull << lane) - 1ull))] = sh.list[k];
+                nc += __popcll(bal);
             }
         }
+        if (lane == 0) {
+            s_ncand[wave] = nc;
+            s_low[wave] = L;
+        }
+        __syncthreads();
     }
 
     const int x = bx0 + lane;
     if (x >= xs1) return;
     const double s = sin_t[x], c = cos_t[x];
 #pragma unroll 1
-    for (int r = 0; r < OWN_ROWS / 4; ++r) {
-        const int y = by0 + 4 * r + wave;
-        if (y >= H) break;
-        const double t = tan_p[y];
-        float best = 0.0f;
-        int who = -1;
-        bool any = false;
-        for (int k = 0; k < ncand; ++k) {
-            const int i = listed < 0 ? k : __builtin_amdgcn_readfirstlane(list[k]);
-            const pano_camera *cam = cams + i;
-            const int px = x - cam->x0, py = y - cam->y0;
-            if ((unsigned)px >= (unsigned)cam->w || (unsigned)py >= (unsigned)cam->h) continue;
-            float fx, fy;
-            const int sw = cam->sw, sh_ = cam->sh;
-            if (map_pixel(cam->proj, s, c, t, sw, sh_, fx, fy)) continue;   // alpha * 0
-            any = true;
-            const Taps tp = make_taps(fx, fy, sw, sh_);
-            const float a = alpha_at(cam->hat_x, cam->hat_y, tp);
-            if (a > best) {          // strict: the first maximum keeps the pixel
-                best = a;
-                who = i;
+    for (int sub = 0; sub < OWN_SUB; ++sub) {
+        const int sy0 = by0 + OWN_ROWS * sub, sy1 = min(sy0 + OWN_ROWS, H);
+        if (sy0 >= H) break;
+        const int *list = sh.list;
+        int ncand = listed < 0 ? n : listed;
+        if (pruned) {
+            list = s_keep[sub];
+            ncand = s_ncand[sub];
+            // One survivor with a positive lower bound: its alpha is positive on every pixel
+            // of the tile and above every other camera's, so it owns the whole tile and no
+            // pixel needs evaluating - provided the tile lies inside its patch rectangle
+            // (outside it the camera is no candidate, stitcher.py:289-297).
+            if (ncand == 1 && s_low[sub] > 0.0f) {
+                const int i = __builtin_amdgcn_readfirstlane(list[0]);
+                if (tile_inside(cams + i, bx0, bx1, sy0, sy1)) {
+                    for (int y = sy0 + wave; y < sy1; y += 4) {
+                        owner[(size_t)y * W + x] = (int16_t)i;
+                        valid[(size_t)y * W + x] = 1;
+                    }
+                    continue;
+                }
             }
         }
-        owner[(size_t)y * W + x] = (int16_t)who;
-        valid[(size_t)y * W + x] = any ? 1 : 0;
+#pragma unroll 1
+        for (int y = sy0 + wave; y < sy1; y += 4) {
+            const double t = tan_p[y];
+            float best = 0.0f;
+            int who = -1;
+            bool any = false;
+            for (int k = 0; k < ncand; ++k) {
+                const int i = listed < 0 ? k : __builtin_amdgcn_readfirstlane(list[k]);
+                const pano_camera *cam = cams + i;
+                const int px = x - cam->x0, py = y - cam->y0;
+                if ((unsigned)px >= (unsigned)cam->w || (unsigned)py >= (unsigned)cam->h) continue;
+                float fx, fy;
+                const int sw = cam->sw, sh_ = cam->sh;
+                if (map_pixel(cam->proj, s, c, t, sw, sh_, fx, fy)) continue;   // alpha * 0
+                any = true;
+                const Taps tp = make_taps_unmasked(fx, fy, sw, sh_);
+                const float a = alpha_at(cam->hat_x, cam->hat_y, tp);
+                if (a > best) {          // strict: the first maximum keeps the pixel
+                    best = a;
+                    who = i;
+                }
+            }
+            owner[(size_t)y * W + x] = (int16_t)who;
+            valid[(size_t)y * W + x] = any ? 1 : 0;
+        }
     }
 }
 
@@ -396,7 +410,7 @@ __global__ __launch_bounds__(256) void blend_cameras_kernel(
         const int sw = cam->sw, sh_ = cam->sh;
         if (map_pixel(cam->proj, s, c, t, sw, sh_, fx, fy)) continue;
         any = true;
-        const Taps tp = make_taps(fx, fy, sw, sh_);
+        const Taps tp = make_taps_unmasked(fx, fy, sw, sh_);
         const TapBytes tb = load_taps(cam->frame, sw, tp);
         float rgb[3];
         const float *__restrict__ gl = lut + (size_t)i * 256;
@@ -629,7 +643,7 @@ __global__ __launch_bounds__(256) void compose_interior_kernel(
     const int sw = cam->sw, sh = cam->sh;
     float fx, fy;
     map_pixel(cam->proj, ia.sin_t[x], ia.cos_t[x], ia.tan_p[y], sw, sh, fx, fy);
-    const Taps tp = make_taps(fx, fy, sw, sh);
+    const Taps tp = make_taps_unmasked(fx, fy, sw, sh);          // an owned pixel is unmasked
     const TapBytes tb = load_taps(cam->frame, sw, tp);
     const size_t g = ((size_t)y * W + x) * 3;
 #pragma unroll
@@ -686,8 +700,17 @@ __global__ __launch_bounds__(256) void multiband_compose_kernel(
             const int sw = cam->sw, sh = cam->sh;
             float fx, fy;
             map_pixel(cam->proj, ia.sin_t[x], ia.cos_t[x], ia.tan_p[y], sw, sh, fx, fy);
-            const Taps tp = make_taps(fx, fy, sw, sh);
-            const TapBytes tb = load_taps(cam->frame, sw, tp);
+            // an owned pixel is unmasked; where the whole wave samples away from the frame's
+            // last row and column the taps need no border handling at all
+            Taps tp = tap_base(fx, fy);
+            TapBytes tb;
+            if (__ballot(!taps_interior(tp, sw, sh)) == 0ull) {
+                tb = load_taps_interior(cam->frame, sw, tp);
+            } else {
+                tp.x1 = min(tp.x1, sw - 1);
+                tp.y1 = min(tp.y1, sh - 1);
+                tb = load_taps(cam->frame, sw, tp);
+            }
             const size_t g = ((size_t)y * W + x) * 3;
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
@@ -861,7 +884,7 @@ extern "C" int pano_ownership_cameras(pano_ctx *ctx, const pano_camera *cams, in
     // option PANO_OPT_OWN_PRUNE = 0 evaluates every listed camera at every pixel (A/B and
     // the exactness tests compare the two)
     const int prune = ctx->opt[PANO_OPT_OWN_PRUNE] != 0;
-    dim3 block(64, 4), grid(ceil_div(xs1 - xs0, 64), ceil_div(H, OWN_ROWS));
+    dim3 block(64, 4), grid(ceil_div(xs1 - xs0, 64), ceil_div(H, OWN_TILE_ROWS));
     PANO_TIMED(PK_OWNERSHIP_CAMS, (hipStream_t)stream,
                hipLaunchKernelGGL(ownership_cameras_kernel, grid, block, 0,
                                   (hipStream_t)stream, cams, n, H, W, xs0, xs1, sin_t, cos_t,

@@ -10,20 +10,53 @@ struct Taps {
 };
 
 // cv2.remap's coordinate handling (INTER_BITS = 5), see include/pano360.h.
-__device__ __forceinline__ Taps make_taps(float px, float py, int sw, int sh) {
+// tap_base: the sample position in fixed point before any border handling - x0 / y0 the
+// integer parts (saturated like remap's short coordinates), x1 / y1 their successors - and
+// the four table weights.
+__device__ __forceinline__ Taps tap_base(float px, float py) {
     int sx = cv_round(px * 32.0f), sy = cv_round(py * 32.0f);
     int fx = sx & 31, fy = sy & 31;
-    int ix = sat16(sx >> 5), iy = sat16(sy >> 5);
     Taps t;
-    t.x0 = reflect_edge(ix, sw);
-    t.x1 = reflect_edge(ix + 1, sw);
-    t.y0 = reflect_edge(iy, sh);
-    t.y1 = reflect_edge(iy + 1, sh);
+    t.x0 = sat16(sx >> 5);
+    t.y0 = sat16(sy >> 5);
+    t.x1 = t.x0 + 1;
+    t.y1 = t.y0 + 1;
     float ax = (float)fx * (1.0f / 32.0f), ay = (float)fy * (1.0f / 32.0f);
     t.w00 = (1.0f - ay) * (1.0f - ax);
     t.w01 = (1.0f - ay) * ax;
     t.w10 = ay * (1.0f - ax);
     t.w11 = ay * ax;
+    return t;
+}
+
+// BORDER_REFLECT on the four coordinates of tap_base.
+__device__ __forceinline__ void reflect_taps(Taps &t, int sw, int sh) {
+    t.x1 = reflect_edge(t.x0 + 1, sw);
+    t.x0 = reflect_edge(t.x0, sw);
+    t.y1 = reflect_edge(t.y0 + 1, sh);
+    t.y0 = reflect_edge(t.y0, sh);
+}
+
+__device__ __forceinline__ Taps make_taps(float px, float py, int sw, int sh) {
+    Taps t = tap_base(px, py);
+    reflect_taps(t, sw, sh);
+    return t;
+}
+
+// All four taps of tap_base lie in the frame: no border handling, the two taps of a row are
+// neighbours, the rows follow each other.
+__device__ __forceinline__ bool taps_interior(const Taps &t, int sw, int sh) {
+    return (unsigned)t.x0 < (unsigned)(sw - 1) && (unsigned)t.y0 < (unsigned)(sh - 1);
+}
+
+// Taps of a pixel map_pixel did NOT mask: 0 <= px <= sw - 1 and 0 <= py <= sh - 1, so
+// x0 = (round(32 px)) >> 5 lies in [0, sw - 1] and only its successor can leave the
+// frame, by one; BORDER_REFLECT maps sw to sw - 1.  Same taps as make_taps without its
+// four range tests (each hides a modulo the compiler has to branch around).
+__device__ __forceinline__ Taps make_taps_unmasked(float px, float py, int sw, int sh) {
+    Taps t = tap_base(px, py);
+    t.x1 = min(t.x1, sw - 1);
+    t.y1 = min(t.y1, sh - 1);
     return t;
 }
 
@@ -57,11 +90,13 @@ __device__ __forceinline__ TapBytes load_taps(const uint8_t *__restrict__ frame,
                                               const Taps &tp) {
     TapBytes t;
     const frame_ptr base = (frame_ptr)frame;
-    const frame_ptr rows[2] = {base + (size_t)tp.y0 * sw * 3, base + (size_t)tp.y1 * sw * 3};
+    // (frames are smaller than 2^32 bytes: both sides are below 32768 pixels)
+    const uint32_t pitch = (uint32_t)sw * 3u;
+    const frame_ptr rows[2] = {base + (uint32_t)tp.y0 * pitch, base + (uint32_t)tp.y1 * pitch};
     const bool pair = tp.x1 == tp.x0 + 1;
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
-        const frame_ptr a = rows[r] + tp.x0 * 3;
+        const frame_ptr a = rows[r] + (uint32_t)tp.x0 * 3u;
         if (pair) {
             const uint32_t lo = *(frame_ptr32)a;
             const uint32_t hi = *(frame_ptr16)(a + 4);
@@ -72,13 +107,36 @@ __device__ __forceinline__ TapBytes load_taps(const uint8_t *__restrict__ frame,
             t.v[2 * r + 1][1] = hi & 255u;
             t.v[2 * r + 1][2] = hi >> 8;
         } else {
-            const frame_ptr b = rows[r] + tp.x1 * 3;
+            const frame_ptr b = rows[r] + (uint32_t)tp.x1 * 3u;
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
                 t.v[2 * r][k] = a[k];
                 t.v[2 * r + 1][k] = b[k];
             }
         }
+    }
+    return t;
+}
+
+// The taps of a pixel whose four taps lie in the frame (taps_interior): one 4-byte and one
+// 2-byte load per row at a 32-bit offset from the frame's (wave-uniform) base.
+__device__ __forceinline__ TapBytes load_taps_interior(const uint8_t *__restrict__ frame, int sw,
+                                                       const Taps &tp) {
+    TapBytes t;
+    const frame_ptr base = (frame_ptr)frame;
+    const uint32_t pitch = (uint32_t)sw * 3u;
+    const uint32_t o0 = (uint32_t)tp.y0 * pitch + (uint32_t)tp.x0 * 3u;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const frame_ptr a = base + (r ? o0 + pitch : o0);
+        const uint32_t lo = *(frame_ptr32)a;
+        const uint32_t hi = *(frame_ptr16)(a + 4);
+        t.v[2 * r][0] = lo & 255u;
+        t.v[2 * r][1] = (lo >> 8) & 255u;
+        t.v[2 * r][2] = (lo >> 16) & 255u;
+        t.v[2 * r + 1][0] = lo >> 24;
+        t.v[2 * r + 1][1] = hi & 255u;
+        t.v[2 * r + 1][2] = hi >> 8;
     }
     return t;
 }

@@ -111,24 +111,44 @@ __global__ __launch_bounds__(256) void warp_windows_kernel(
         t[j] = tan_p[p.y0 + p.vy0 + min(y0 + 4 * j, p.vh - 1)];
     Taps tp[WARP_ROWS];
     TapBytes tb[WARP_ROWS];
+    bool inner = true;
 #pragma unroll
     for (int j = 0; j < WARP_ROWS; ++j) {
         float px, py;
         map_pixel(cam->proj, s, c, t[j], sw, sh, px, py);
-        tp[j] = make_taps(px, py, sw, sh);
+        tp[j] = tap_base(px, py);
+        inner &= taps_interior(tp[j], sw, sh);
     }
+    // Nearly every wave lies inside its frame with all its pixels' taps: then there is no
+    // border to reflect at and the taps of a pixel are neighbours (the kernel is bound by its
+    // vector instructions - 160 per pixel, 77 % of the issue cycles - not by its loads; the
+    // four range tests of the general path and the branches around their modulos were 30 of
+    // them).  The decision is per wave, so neither path runs under a partial mask.
+    if (__ballot(!inner) == 0ull) {
 #pragma unroll
-    for (int j = 0; j < WARP_ROWS; ++j) tb[j] = load_taps(cam->frame, sw, tp[j]);
+        for (int j = 0; j < WARP_ROWS; ++j) tb[j] = load_taps_interior(cam->frame, sw, tp[j]);
+    } else {
+#pragma unroll
+        for (int j = 0; j < WARP_ROWS; ++j) {
+            reflect_taps(tp[j], sw, sh);
+            tb[j] = load_taps(cam->frame, sw, tp[j]);
+        }
+    }
+    // offsets inside a plane fit 32 bits (pano_layout_windows checks it); the three bases are
+    // wave-uniform
+    typedef __attribute__((address_space(1))) float *plane_ptr;
     const size_t plane = (size_t)p.vh * p.vpitch;
+    const plane_ptr out[3] = {(plane_ptr)p.planes, (plane_ptr)p.planes + plane,
+                              (plane_ptr)p.planes + 2 * plane};
 #pragma unroll
     for (int j = 0; j < WARP_ROWS; ++j) {
         const int y = y0 + 4 * j;
         if (y >= p.vh) break;
-        const size_t o = (size_t)y * p.vpitch + x;
+        const uint32_t o = (uint32_t)y * (uint32_t)p.vpitch + (uint32_t)x;
 #pragma unroll
         for (int k = 0; k < 3; ++k)
-            p.planes[k * plane + o] = lerp4(s_lut[tb[j].v[0][k]], s_lut[tb[j].v[1][k]],
-                                            s_lut[tb[j].v[2][k]], s_lut[tb[j].v[3][k]], tp[j]);
+            out[k][o] = lerp4(s_lut[tb[j].v[0][k]], s_lut[tb[j].v[1][k]],
+                                       s_lut[tb[j].v[2][k]], s_lut[tb[j].v[3][k]], tp[j]);
     }
 }
 
