@@ -260,6 +260,16 @@ int pano_owned_regions(pano_ctx *ctx, const int16_t *owner, int H, int W, int xs
                        int n, int min_gap, int max_spans, uint8_t *marks,
                        int32_t *regions);
 
+/* pano_ownership_cameras and pano_owned_regions in one pass over the mosaic
+ * (stitcher.py:196-204, 266-271 and the bookkeeping of the sharp masks of
+ * :207-208): the ownership kernel leaves the cameras' boxes and column marks
+ * behind while the owners are in its registers.  Same owner, valid and regions
+ * as the two calls in sequence. */
+int pano_ownership_regions(pano_ctx *ctx, const pano_camera *cams, int n, int H, int W,
+                           int xs0, int xs1, const double *sin_t, const double *cos_t,
+                           const double *tan_p, int16_t *owner, uint8_t *valid,
+                           int min_gap, int max_spans, uint8_t *marks, int32_t *regions);
+
 /* The n_levels-1 Gaussian blurs of every patch  stitcher.py:207-208, 218, 226
  * (cv2.GaussianBlur(warped, (0,0), 4*sqrt(2k+1)) with the alpha channel
  * replaced by the sharp mask owner == index), evaluated on rectangle A of each

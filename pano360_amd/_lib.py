@@ -107,6 +107,8 @@ _SIGNATURES = {
     "pano_ownership": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     "pano_ownership_cameras": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "pano_owned_regions": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
+    "pano_ownership_regions": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp,
+                                    _i, _i, _vp, _vp]),
     "pano_multiband_blur": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _i, _vp, C.POINTER(C.c_int), _i,
                                  _vp, _vp]),
     "pano_multiband_blur_prepare": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),

@@ -106,6 +106,17 @@ extern "C" int pano_ctx_destroy(pano_ctx *ctx) {
     return PANO_OK;
 }
 
+// The context's second stream and the events that fork work onto it and join it (made on
+// first use: pano_stitch_multiband, and the fifth / sixth level of pano_multiband_blur).
+int pano_ctx_side_stream(pano_ctx *ctx) {
+    if (!ctx->ev_regions) PANO_HIP(hipEventCreateWithFlags(&ctx->ev_regions, hipEventDisableTiming));
+    if (!ctx->ev_upload) PANO_HIP(hipEventCreateWithFlags(&ctx->ev_upload, hipEventDisableTiming));
+    if (!ctx->ev_fork) PANO_HIP(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+    if (!ctx->ev_join) PANO_HIP(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
+    if (!ctx->side) PANO_HIP(hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
+    return PANO_OK;
+}
+
 extern "C" int pano_ctx_set_stream(pano_ctx *ctx, void *stream) {
     PANO_REQUIRE(ctx, "pano_ctx_set_stream: null context");
     ctx->stream = (hipStream_t)stream;

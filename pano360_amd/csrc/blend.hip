@@ -189,6 +189,19 @@ __device__ __forceinline__ AlphaBound alpha_bound(const pano_camera *cam, const 
 #define OWN_SUB 4
 #define OWN_TILE_ROWS (OWN_ROWS * OWN_SUB)
 
+// Grows a camera's box in memory.  Thousands of workgroups meet on the 16 bytes of a camera (a
+// read-modify-write per value and workgroup made the kernel twice as slow: they queue up at one
+// cache line), but nearly all of them bring nothing new: the box is read first - a stale value
+// only errs towards a redundant atomic, the fields move one way - and only what grows it is sent.
+__device__ __forceinline__ void box_merge(int32_t *g, int ymin, int ymax, int xmin, int xmax) {
+    const int c0 = __atomic_load_n(&g[0], __ATOMIC_RELAXED), c1 = __atomic_load_n(&g[1], __ATOMIC_RELAXED);
+    const int c2 = __atomic_load_n(&g[2], __ATOMIC_RELAXED), c3 = __atomic_load_n(&g[3], __ATOMIC_RELAXED);
+    if (ymin < c0) atomicMin(&g[0], ymin);
+    if (ymax > c1) atomicMax(&g[1], ymax);
+    if (xmin < c2) atomicMin(&g[2], xmin);
+    if (xmax > c3) atomicMax(&g[3], xmax);
+}
+
 __device__ __forceinline__ bool tile_inside(const pano_camera *cam, int x0, int x1, int y0, int y1) {
     return x0 >= cam->x0 && x1 <= cam->x0 + cam->w && y0 >= cam->y0 && y1 <= cam->y0 + cam->h;
 }
@@ -197,28 +210,44 @@ __global__ __launch_bounds__(256) void ownership_cameras_kernel(
     const pano_camera *__restrict__ cams, int n, int H, int W, int xs0, int xs1,
     const double *__restrict__ sin_t, const double *__restrict__ cos_t,
     const double *__restrict__ tan_p, int16_t *__restrict__ owner,
-    uint8_t *__restrict__ valid, int prune) {
+    uint8_t *__restrict__ valid, int prune, int32_t *__restrict__ boxes, int box_stride,
+    uint8_t *__restrict__ marks) {
     __shared__ CamList sh;
+    __shared__ int s_box[OWN_LIST][4];             // region search: {ymin, ymax, xmin, xmax} per listed camera
+    __shared__ short s_pos[OWN_SUB][OWN_LIST];     // a survivor's position in the list
     __shared__ int s_keep[OWN_SUB][OWN_LIST];
-    __shared__ float s_hi[OWN_SUB][OWN_LIST];      // upper bounds, lists of more than 64 cameras only
+    __shared__ float s_hi[4][OWN_LIST];            // [wave] upper bounds, lists of more than 64 cameras only
     __shared__ int s_ncand[OWN_SUB];
     __shared__ float s_low[OWN_SUB];
     const int lane = threadIdx.x, wave = threadIdx.y;
     const int bx0 = xs0 + blockIdx.x * 64, by0 = blockIdx.y * OWN_TILE_ROWS;
     const int bx1 = min(bx0 + 64, xs1), by1 = min(by0 + OWN_TILE_ROWS, H);
+    if (marks) {                                               // (the list's barriers publish it)
+        int *b = s_box[wave * 64 + lane];
+        b[0] = b[2] = 0x7fffffff;
+        b[1] = b[3] = -1;
+    }
     const int listed = build_camera_list(sh, cams, n, bx0, bx1, by0, by1);
     const bool pruned = listed > 1 && prune;
 
     if (pruned) {
-        // wave w = sub-tile w: ranges of the ray components over its columns and rows (every
-        // lane ends up with all six), then one listed camera per lane
-        const int sy0 = by0 + OWN_ROWS * wave, sy1 = min(sy0 + OWN_ROWS, H);
-        int nc = 0;
-        float L = 0.0f;
-        if (sy0 < H) {                                           // wave-uniform
+        // A group of G = 16, 32 or 64 lanes takes one sub-tile, a listed camera per lane: with
+        // the dozen cameras of a 5-degree sweep one wave bounds all four sub-tiles in a single
+        // pass (the bound is ~250 double-precision instructions whatever the number of live lanes).
+        const int G = listed <= 16 ? 16 : (listed <= 32 ? 32 : 64);          // block-uniform
+        // (a workgroup's wave w sits on SIMD w: the one or two working waves rotate with the
+        // workgroup so that the bounds do not all queue on SIMD 0)
+        const int slot = (wave - (int)(blockIdx.x + blockIdx.y)) & 3;
+        const int sub = slot * (64 / G) + lane / G, k0 = lane & (G - 1);
+        const int sy0 = by0 + OWN_ROWS * sub, sy1 = min(sy0 + OWN_ROWS, H);
+        const bool live = sub < OWN_SUB && sy0 < H;
+        if (__ballot(live) != 0ull) {                                        // wave-uniform
+            // ranges of the ray components over the sub-tile's columns and rows (every lane of
+            // the group ends up with all six)
             const int xc = min(bx0 + lane, bx1 - 1);
             double lo_s = sin_t[xc], hi_s = lo_s, lo_c = cos_t[xc], hi_c = lo_c;
-            double lo_t = tan_p[min(sy0 + (lane & (OWN_ROWS - 1)), sy1 - 1)], hi_t = lo_t;
+            const int yr = live ? min(sy0 + (lane & (OWN_ROWS - 1)), sy1 - 1) : by0;
+            double lo_t = tan_p[yr], hi_t = lo_t;
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) {
                 lo_s = fmin(lo_s, __shfl_xor(lo_s, off, 64));
@@ -232,10 +261,11 @@ __global__ __launch_bounds__(256) void ownership_cameras_kernel(
                 hi_t = fmax(hi_t, __shfl_xor(hi_t, off, 64));
             }
             const double rng[6] = {lo_s, hi_s, lo_t, hi_t, lo_c, hi_c};
-            for (int base = 0; base < listed; base += 64) {
-                const int k = base + lane;
+            float L = 0.0f, hi = -1.0f;
+            for (int base = 0; base < listed; base += 64) {                  // one trip unless G = 64
+                const int k = base + k0;
                 AlphaBound bnd = {0.0f, -1.0f};
-                if (k < listed) {
+                if (live && k < listed) {
                     const pano_camera *cam = cams + sh.list[k];
                     bnd = alpha_bound(cam, rng);
                     // A lower bound beats other cameras on EVERY pixel of the tile only if this camera
@@ -245,31 +275,60 @@ __global__ __launch_bounds__(256) void ownership_cameras_kernel(
                     // the frame itself reaches them: found by the full-size config 5 test, where such
                     // a camera's bound pruned the only candidate of the last 32 columns.
                     if (!tile_inside(cam, bx0, bx1, sy0, sy1)) bnd.lo = 0.0f;
-                    s_hi[wave][k] = bnd.hi;
+                    if (listed > 64) s_hi[wave][k] = bnd.hi;
                 }
+                hi = bnd.hi;
                 L = fmaxf(L, bnd.lo);
             }
 #pragma unroll
-            for (int off = 32; off > 0; off >>= 1) L = fmaxf(L, __shfl_xor(L, off, 64));
-            // the survivors, order preserved: the first maximum wins (s_hi: this lane's own writes)
+            for (int off = 32; off > 0; off >>= 1)
+                if (off < G) L = fmaxf(L, __shfl_xor(L, off, 64));
+            // the survivors, order preserved: the first maximum wins
+            const int shift = (lane / G) * G;                                // G = 64: 0
+            const unsigned long long gmask = G == 64 ? ~0ull : ((1ull << G) - 1ull);
+            int nc = 0;
             for (int base = 0; base < listed; base += 64) {
-                const int k = base + lane;
-                const bool keep = k < listed && s_hi[wave][k] >= L;
-                const unsigned long long bal = __ballot(keep);
-                if (keep) s_keep[wave][nc + __popcll(bal & ((1ull << lane) - 1ull))] = sh.list[k];
+                const int k = base + k0;
+                if (listed > 64) hi = k < listed ? s_hi[wave][k] : -1.0f;    // this lane's own writes
+                const bool keep = live && k < listed && hi >= L;
+                const unsigned long long bal = (__ballot(keep) >> shift) & gmask;
+                if (keep) {
+                    const int at = nc + __popcll(bal & ((1ull << k0) - 1ull));
+                    s_keep[sub][at] = sh.list[k];
+                    s_pos[sub][at] = (short)k;
+                }
                 nc += __popcll(bal);
             }
-        }
-        if (lane == 0) {
-            s_ncand[wave] = nc;
-            s_low[wave] = L;
+            if (live && k0 == 0) {
+                s_ncand[sub] = nc;
+                s_low[sub] = L;
+            }
         }
         __syncthreads();
     }
 
     const int x = bx0 + lane;
-    if (x >= xs1) return;
-    const double s = sin_t[x], c = cos_t[x];
+    const bool in_strip = x < xs1;
+    const int xc = in_strip ? x : xs1 - 1;
+    const double s = sin_t[xc], c = cos_t[xc];
+    // Region search (pano_owned_regions' boxes and column marks) while the owners are in
+    // registers: a thread follows the run of rows its column's current owner holds and hands a
+    // finished run - at a change of owner, and once at the end - to the workgroup's box of that
+    // camera in LDS (a wave-wide exchange per row cost as much as the separate kernel).
+    int run_o = -1, run_pos = 0, run_y0 = 0, run_y1 = 0;
+    auto flush = [&]() {
+        if (run_o < 0 || !in_strip) return;
+        marks[(size_t)run_o * W + x] = 1;
+        if (listed >= 0) {
+            int *b = s_box[run_pos];
+            atomicMin(&b[0], run_y0);
+            atomicMax(&b[1], run_y1);
+            atomicMin(&b[2], x);
+            atomicMax(&b[3], x);
+        } else {                             // more cameras than the list holds: straight to memory
+            box_merge(boxes + (size_t)box_stride * run_o, run_y0, run_y1, x, x);
+        }
+    };
 #pragma unroll 1
     for (int sub = 0; sub < OWN_SUB; ++sub) {
         const int sy0 = by0 + OWN_ROWS * sub, sy1 = min(sy0 + OWN_ROWS, H);
@@ -286,9 +345,19 @@ __global__ __launch_bounds__(256) void ownership_cameras_kernel(
             if (ncand == 1 && s_low[sub] > 0.0f) {
                 const int i = __builtin_amdgcn_readfirstlane(list[0]);
                 if (tile_inside(cams + i, bx0, bx1, sy0, sy1)) {
-                    for (int y = sy0 + wave; y < sy1; y += 4) {
-                        owner[(size_t)y * W + x] = (int16_t)i;
-                        valid[(size_t)y * W + x] = 1;
+                    if (in_strip)
+                        for (int y = sy0 + wave; y < sy1; y += 4) {
+                            owner[(size_t)y * W + x] = (int16_t)i;
+                            valid[(size_t)y * W + x] = 1;
+                        }
+                    if (marks && sy0 + wave < sy1) {
+                        if (run_o != i) {
+                            flush();
+                            run_o = i;
+                            run_pos = s_pos[sub][0];
+                            run_y0 = sy0 + wave;
+                        }
+                        run_y1 = sy0 + wave + ((sy1 - 1 - sy0 - wave) & ~3);     // this wave's last row
                     }
                     continue;
                 }
@@ -298,12 +367,12 @@ __global__ __launch_bounds__(256) void ownership_cameras_kernel(
         for (int y = sy0 + wave; y < sy1; y += 4) {
             const double t = tan_p[y];
             float best = 0.0f;
-            int who = -1;
+            int who = -1, who_k = 0;
             bool any = false;
             for (int k = 0; k < ncand; ++k) {
                 const int i = listed < 0 ? k : __builtin_amdgcn_readfirstlane(list[k]);
                 const pano_camera *cam = cams + i;
-                const int px = x - cam->x0, py = y - cam->y0;
+                const int px = xc - cam->x0, py = y - cam->y0;
                 if ((unsigned)px >= (unsigned)cam->w || (unsigned)py >= (unsigned)cam->h) continue;
                 float fx, fy;
                 const int sw = cam->sw, sh_ = cam->sh;
@@ -314,11 +383,32 @@ __global__ __launch_bounds__(256) void ownership_cameras_kernel(
                 if (a > best) {          // strict: the first maximum keeps the pixel
                     best = a;
                     who = i;
+                    who_k = k;
                 }
             }
-            owner[(size_t)y * W + x] = (int16_t)who;
-            valid[(size_t)y * W + x] = any ? 1 : 0;
+            if (in_strip) {
+                owner[(size_t)y * W + x] = (int16_t)who;
+                valid[(size_t)y * W + x] = any ? 1 : 0;
+            }
+            if (marks) {
+                if (who != run_o) {
+                    flush();
+                    run_o = who;
+                    run_pos = pruned && who >= 0 ? s_pos[sub][who_k] : who_k;
+                    run_y0 = y;
+                }
+                run_y1 = y;
+            }
         }
+    }
+    if (!marks) return;
+    flush();
+    __syncthreads();
+    // the workgroup's boxes into the cameras'
+    const int tid = wave * 64 + lane;
+    if (tid < listed) {
+        const int *b = s_box[tid];
+        if (b[1] >= b[0]) box_merge(boxes + (size_t)box_stride * sh.list[tid], b[0], b[1], b[2], b[3]);
     }
 }
 
@@ -888,7 +978,8 @@ extern "C" int pano_ownership_cameras(pano_ctx *ctx, const pano_camera *cams, in
     PANO_TIMED(PK_OWNERSHIP_CAMS, (hipStream_t)stream,
                hipLaunchKernelGGL(ownership_cameras_kernel, grid, block, 0,
                                   (hipStream_t)stream, cams, n, H, W, xs0, xs1, sin_t, cos_t,
-                                  tan_p, owner, valid, prune));
+                                  tan_p, owner, valid, prune, (int32_t *)nullptr, 0,
+                                  (uint8_t *)nullptr));
     PANO_LAUNCH_CHECK("ownership_cameras_kernel");
     return PANO_OK;
 }
@@ -1003,6 +1094,43 @@ extern "C" int pano_owned_regions(pano_ctx *ctx, const int16_t *owner, int H, in
                hipLaunchKernelGGL(owned_boxes_kernel, grid, block, 0, s, owner, H, W, xs0, xs1,
                                   regions, stride, marks));
     PANO_LAUNCH_CHECK("owned_boxes_kernel");
+    PANO_TIMED(PK_OWNED_SPANS, s,
+               hipLaunchKernelGGL(owned_spans_kernel, dim3(n), dim3(64), 0, s, marks, W, xs0, xs1,
+                                  min_gap, max_spans, stride, regions));
+    PANO_LAUNCH_CHECK("owned_spans_kernel");
+    return PANO_OK;
+}
+
+// pano_ownership_cameras + pano_owned_regions in one pass over the mosaic: the ownership
+// kernel leaves each camera's bounding box and column marks behind while the owners are
+// still in its registers (the separate box kernel re-read the owner map three times and sat,
+// with its launch gaps, between the ownership and the one host wait of a stitch).
+extern "C" int pano_ownership_regions(pano_ctx *ctx, const pano_camera *cams, int n, int H, int W,
+                                      int xs0, int xs1, const double *sin_t, const double *cos_t,
+                                      const double *tan_p, int16_t *owner, uint8_t *valid,
+                                      int min_gap, int max_spans, uint8_t *marks,
+                                      int32_t *regions) {
+    PANO_ENTER(ctx, "pano_ownership_regions");
+    if (int rc = check_table(cams, n, H, W, "pano_ownership_regions")) return rc;
+    PANO_REQUIRE(sin_t && cos_t && tan_p && owner && valid && marks && regions,
+                 "pano_ownership_regions: null pointer");
+    PANO_REQUIRE(xs0 >= 0 && xs1 <= W && xs0 <= xs1, "pano_ownership_regions: bad strip [%d, %d)", xs0, xs1);
+    PANO_REQUIRE(max_spans >= 1 && min_gap >= 0, "pano_ownership_regions: bad argument");
+    if (n == 0) return PANO_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const int stride = 5 + 2 * max_spans;
+    PANO_HIP(hipMemsetAsync(marks, 0, (size_t)n * W, s));
+    hipLaunchKernelGGL(init_regions_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, s, regions, n,
+                       stride);
+    PANO_LAUNCH_CHECK("init_regions_kernel");
+    if (xs0 == xs1) return PANO_OK;
+    const int prune = ctx->opt[PANO_OPT_OWN_PRUNE] != 0;
+    dim3 block(64, 4), grid(ceil_div(xs1 - xs0, 64), ceil_div(H, OWN_TILE_ROWS));
+    PANO_TIMED(PK_OWNERSHIP_CAMS, s,
+               hipLaunchKernelGGL(ownership_cameras_kernel, grid, block, 0, s, cams, n, H, W, xs0,
+                                  xs1, sin_t, cos_t, tan_p, owner, valid, prune, regions, stride,
+                                  marks));
+    PANO_LAUNCH_CHECK("ownership_cameras_kernel");
     PANO_TIMED(PK_OWNED_SPANS, s,
                hipLaunchKernelGGL(owned_spans_kernel, dim3(n), dim3(64), 0, s, marks, W, xs0, xs1,
                                   min_gap, max_spans, stride, regions));

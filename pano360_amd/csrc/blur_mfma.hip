@@ -1673,11 +1673,32 @@ int pano_launch_blur_mfma(pano_ctx *ctx, const pano_patch *table, int n, int max
         // four levels as one group of four, the rest in a launch of their own (small workgroups,
         // several per CU): the band is staged twice per item instead of three times.  Config 5
         // (five levels): 8.9-9.05 ms against 9.2 ms as 2 + 2 + 1 in one launch.
+        // The two launches touch different planes and fill the chip differently - eight-wave
+        // workgroups, one per CU, against four-wave ones of which a CU holds two - so the second
+        // goes to the context's side stream: on one GPU it fills the first one's tail, on a column
+        // strip of an 8-GPU run (a few dozen work items, far fewer workgroups than CUs) the two
+        // run side by side.
+        // (not while kernels are being timed: the two launches' events would span each other)
+        const bool beside = ctx->opt[PANO_OPT_STITCH_STREAMS] != 0 && !ctx->timing_on;
+        const hipStream_t main_stream = ctx->stream;
+        if (beside) {
+            if (int rc = pano_ctx_side_stream(ctx)) return rc;
+            PANO_HIP(hipEventRecord(ctx->ev_fork, main_stream));
+            PANO_HIP(hipStreamWaitEvent(ctx->side, ctx->ev_fork, 0));
+        }
         if (int rc = launch_levels(ctx, table, n, max_aw, owner, W, host_taps, ntaps, 0, 4, rmax, 4,
                                    flags))
             return rc;
-        return launch_levels(ctx, table, n, max_aw, owner, W, host_taps, ntaps, 4, n_blur - 4, rmax, 2,
-                             flags);
+        if (beside) ctx->stream = ctx->side;
+        const int rc2 = launch_levels(ctx, table, n, max_aw, owner, W, host_taps, ntaps, 4, n_blur - 4,
+                                      rmax, 2, flags);
+        ctx->stream = main_stream;
+        if (rc2) return rc2;
+        if (beside) {
+            PANO_HIP(hipEventRecord(ctx->ev_join, ctx->side));
+            PANO_HIP(hipStreamWaitEvent(main_stream, ctx->ev_join, 0));
+        }
+        return PANO_OK;
     }
     const int group = narrow && (n_blur <= 2 || n_blur == 5 || n_blur == 6) ? 2 : 4;
     return launch_levels(ctx, table, n, max_aw, owner, W, host_taps, ntaps, 0, n_blur, rmax, group,

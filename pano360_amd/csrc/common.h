@@ -110,6 +110,7 @@ struct pano_ctx {
 };
 
 int pano_ctx_enter(pano_ctx *ctx);
+int pano_ctx_side_stream(pano_ctx *ctx);     // makes ctx->side and the fork / join events
 // Device copy of a host tap table set (and, with `tables`, its matrix-core operand tables'
 // buffer, `table_bytes` long, `*fresh` = it was just allocated and must be filled).
 int pano_ctx_tap_set(pano_ctx *ctx, const float *taps, const int *ntaps, int n, size_t table_bytes,

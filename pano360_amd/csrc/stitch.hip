@@ -2,15 +2,6 @@
 // (stitcher.py:283-327 without equalize / crop) queued from C++.  No kernel of its own.
 #include "common.h"
 
-static int ensure_events(pano_ctx *ctx) {
-    if (!ctx->ev_regions) PANO_HIP(hipEventCreateWithFlags(&ctx->ev_regions, hipEventDisableTiming));
-    if (!ctx->ev_upload) PANO_HIP(hipEventCreateWithFlags(&ctx->ev_upload, hipEventDisableTiming));
-    if (!ctx->ev_fork) PANO_HIP(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
-    if (!ctx->ev_join) PANO_HIP(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
-    if (!ctx->side) PANO_HIP(hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
-    return PANO_OK;
-}
-
 // Runs `call` with the context targeted at its side stream.
 #define ON_SIDE(ctx, call)                  \
     do {                                    \
@@ -44,22 +35,37 @@ extern "C" int pano_stitch_multiband(pano_ctx *ctx, pano_stitch_args *a, int res
     PANO_REQUIRE(!interior || (a->block_owner && a->interior),
                  "pano_stitch_multiband: interior map without its buffers");
     const hipStream_t s = (hipStream_t)stream;
-    if (int rc = ensure_events(ctx)) return rc;
+    if (int rc = pano_ctx_side_stream(ctx)) return rc;
     // the second stream pays on large mosaics only (config 3: 1.975 -> 1.945 ms per stitch;
     // config 2, 7.9 MP: 0.527 -> 0.537: the forks and joins cost more than the overlap gives)
-    const bool two_streams = ctx->opt[PANO_OPT_STITCH_STREAMS] != 0 &&
-                             (long long)a->H * (a->own1 - a->own0) >= (1ll << 24);
+    const bool big = (long long)a->H * (a->own1 - a->own0) >= (1ll << 24);
+    const bool two_streams = ctx->opt[PANO_OPT_STITCH_STREAMS] != 0 && big;
     const int tile_grid = pano_blur_tile_grid(ctx);
     const int stride = 5 + 2 * a->max_spans;
 
     if (!resume) {
-        if (int rc = pano_ownership_cameras(ctx, a->cams, a->n, a->H, a->W, a->own0, a->own1,
-                                            a->sin_t, a->cos_t, a->tan_p, a->owner, a->valid))
-            return rc;
+        // ownership and, in the same pass, one record per (camera, span of columns it owns):
+        // boxes and column marks from the ownership kernel, the spans' search, its copy to the host
+        // (in one pass on mosaics of 16 MP and more: config 5 16.12 -> 15.99 ms, config 3 even;
+        // on the 8 MP of config 2 the longer ownership kernel costs what the box kernel saved)
+        if (big) {
+            if (int rc = pano_ownership_regions(ctx, a->cams, a->n, a->H, a->W, a->own0, a->own1,
+                                                a->sin_t, a->cos_t, a->tan_p, a->owner, a->valid,
+                                                a->min_gap, a->max_spans, a->marks, a->regions))
+                return rc;
+        } else {
+            if (int rc = pano_ownership_cameras(ctx, a->cams, a->n, a->H, a->W, a->own0, a->own1,
+                                                a->sin_t, a->cos_t, a->tan_p, a->owner, a->valid))
+                return rc;
+            if (int rc = pano_owned_regions(ctx, a->owner, a->H, a->W, a->own0, a->own1, a->n,
+                                            a->min_gap, a->max_spans, a->marks, a->regions))
+                return rc;
+        }
         // Two small chains depend on the owner map only - the interior map and the region
-        // search - and two more on the record table only - the warp and the blur's tile flags
-        // and work list: the context's side stream takes one of each pair (the short kernels of
-        // a config-3 stitch were 0.15 ms of a 2.0 ms timeline, plus the gaps between them).
+        // search's tail - and two more on the record table only - the warp and the blur's tile
+        // flags and work list: the context's side stream takes one of each pair (the short
+        // kernels of a config-3 stitch were 0.15 ms of a 2.0 ms timeline, plus the gaps between
+        // them).
         const bool forked = two_streams;
         if (forked && interior) {
             PANO_HIP(hipEventRecord(ctx->ev_fork, s));
@@ -67,10 +73,6 @@ extern "C" int pano_stitch_multiband(pano_ctx *ctx, pano_stitch_args *a, int res
             ON_SIDE(ctx, pano_interior_map(ctx, a->owner, a->H, a->W, a->own0, a->own1, a->radius,
                                            a->block_owner, a->interior));
         }
-        // one record per (camera, span of columns it owns): the spans' search, its copy to the host
-        if (int rc = pano_owned_regions(ctx, a->owner, a->H, a->W, a->own0, a->own1, a->n,
-                                        a->min_gap, a->max_spans, a->marks, a->regions))
-            return rc;
         PANO_HIP(hipMemcpyAsync(a->regions_host, a->regions, (size_t)a->n * stride * sizeof(int32_t),
                                 hipMemcpyDeviceToHost, s));
         PANO_HIP(hipEventRecord(ctx->ev_regions, s));

@@ -1095,6 +1095,25 @@ class Engine:
             "pano_ownership_cameras")
         return owner, valid
 
+    def ownership_regions(self, plan, strip=None, min_gap=0, max_spans=4, cams=None):
+        """ownership_cameras and the region search in one pass over the mosaic
+        (pano_ownership_regions): owner, valid, and the device arrays regions
+        [n][5 + 2 max_spans] and marks [n][W] of pano_owned_regions."""
+        torch = _torch()
+        H, W = plan.shape
+        owner = torch.empty((H, W), dtype=torch.int16, device=self.device)
+        valid = torch.empty((H, W), dtype=torch.uint8, device=self.device)
+        marks = torch.empty((plan.n, W), dtype=torch.uint8, device=self.device)
+        regions = torch.empty((plan.n, 5 + 2 * max_spans), dtype=torch.int32, device=self.device)
+        xs0, xs1 = strip if strip is not None else (0, W)
+        if cams is None:
+            cams = self.camera_table(plan)
+        _lib.check(self.lib.pano_ownership_regions(
+            self.ctx(), _ptr(cams), plan.n, H, W, xs0, xs1, _ptr(plan.dev[0]), _ptr(plan.dev[1]),
+            _ptr(plan.dev[2]), _ptr(owner), _ptr(valid), min_gap, max_spans, _ptr(marks),
+            _ptr(regions)), "pano_ownership_regions")
+        return owner, valid, regions, marks
+
     def owned_regions_async(self, owner, n, strip=None, min_gap=0, max_spans=4):
         """Queues the region search and its device->host copy (pinned), returns a function
         that waits for it: host arrays boxes [n][4] = (ymin, ymax, xmin, xmax) and a list,

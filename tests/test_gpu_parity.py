@@ -339,6 +339,60 @@ def test_ownership_bounds_against_exhaustive_evaluation(eng, seed):
     assert (owner_all >= 0).any() and (owner_all < 0).any()
 
 
+@pytest.mark.parametrize("case", ["sweep", "tilted", "dense", "crowd", "strip"])
+def test_ownership_with_regions_equals_the_two_calls(eng, case):
+    """pano_ownership_regions (boxes and column marks out of the ownership kernel) against
+    pano_ownership_cameras followed by pano_owned_regions: same owner, valid, regions and
+    marks - with and without pruning, on a strip, with more candidates per sub-tile than the
+    kernel keeps boxes for in LDS (dense), and with more cameras than its list holds (crowd)."""
+    import torch
+    from pano360_amd import _lib, bundle_adj, engine, synth
+    rng = np.random.default_rng(11)
+    strip = None
+    if case in ("sweep", "strip"):
+        n, w, h = 8, 240, 136
+        rots, intrs = synth.make_cameras(n, w, h, sweep_deg=150.0, jitter=0.01, seed=3)
+    elif case == "tilted":
+        n, w, h = 9, 160, 120
+        rots = np.stack([bundle_adj.rotation_to_mat(
+            [rng.normal(0, 0.15), 0.3 * (i - 4), rng.normal(0, 0.15)]) for i in range(n)])
+        intrs = np.stack([bundle_adj.intrinsics(synth.focal_for(w))] * n).astype(np.float64)
+    elif case == "dense":
+        n, w, h = 40, 96, 64
+        rots, intrs = synth.make_cameras(n, w, h, step_deg=2.0, jitter=0.003, seed=1)
+    else:
+        n, w, h = 300, 48, 32
+        rots, intrs = synth.make_cameras(n, w, h, step_deg=0.2, jitter=0.002, seed=4)
+    plan = eng.upload_plan(engine.Plan([(h, w)] * n, rots, intrs, True, 10 ** 9))
+    W = plan.shape[1]
+    if case == "strip":
+        strip = (W // 3 + 5, 2 * W // 3 + 1)
+    for prune in (1, 0):
+        eng.set_option(_lib.OPT_OWN_PRUNE, prune)
+        try:
+            owner_a, valid_a = eng.ownership_cameras(plan, strip=strip)
+            wait = eng.owned_regions_async(owner_a, n, strip=strip, min_gap=7, max_spans=3)
+            regions_a = wait.raw().copy()
+            owner_b, valid_b, regions_b, marks_b = eng.ownership_regions(
+                plan, strip=strip, min_gap=7, max_spans=3)
+            torch.cuda.synchronize()
+        finally:
+            eng.set_option(_lib.OPT_OWN_PRUNE, 1)
+        c0, c1 = strip if strip else (0, W)
+        assert torch.equal(owner_a[:, c0:c1], owner_b[:, c0:c1])
+        assert torch.equal(valid_a[:, c0:c1], valid_b[:, c0:c1])
+        regions_b = regions_b.cpu().numpy()
+        own = owner_b[:, c0:c1].cpu().numpy()
+        for i in range(n):
+            cnt = regions_a[i, 4]
+            assert regions_b[i, 4] == cnt
+            assert np.array_equal(regions_a[i, :5 + 2 * cnt], regions_b[i, :5 + 2 * cnt]), (case, i)
+            cols = np.nonzero((own == i).any(axis=0))[0] + c0
+            got = np.nonzero(marks_b[i].cpu().numpy())[0]
+            assert np.array_equal(cols, got)
+        assert (regions_b[:, 4] > 0).sum() >= min(n, 3)
+
+
 @pytest.mark.parametrize("case", ["dense", "tilted", "wide", "identical"])
 def test_ownership_pruning_is_exact(eng, case):
     """The camera-driven kernel samples alpha only where an upper bound says the
