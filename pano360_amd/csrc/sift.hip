@@ -52,6 +52,49 @@ __device__ __forceinline__ float fast_atan2(float y, float x) {
     return a;
 }
 
+// The same polynomial for the window samples of the orientation and descriptor kernels, with
+// the quotient min / max formed once, by the hardware reciprocal (1 ulp; the polynomial itself
+// is good to 0.3 degrees, and a sample's votes are continuous in its angle), instead of one
+// correctly rounded division per branch: 25 vector instructions fewer per sample.
+__device__ __forceinline__ float fast_atan2_sample(float y, float x) {
+    const float p1 = (float)(0.9997878412794807 * 57.29577951308232);
+    const float p3 = (float)(-0.3258083974640975 * 57.29577951308232);
+    const float p5 = (float)(0.1555786518463281 * 57.29577951308232);
+    const float p7 = (float)(-0.04432655554792128 * 57.29577951308232);
+    const float ax = fabsf(x), ay = fabsf(y);
+    const float lo = fminf(ax, ay), hi = fmaxf(ax, ay);
+    const float c = lo * __builtin_amdgcn_rcpf(hi + 2.220446049250313e-16f), c2 = c * c;
+    float a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    if (ax < ay) a = 90.0f - a;
+    if (x < 0.0f) a = 180.0f - a;
+    if (y < 0.0f) a = 360.0f - a;
+    return a;
+}
+
+// exp and sqrt of a sample's weight and gradient magnitude: the hardware's (v_exp_f32 on
+// x log2 e, v_sqrt_f32: 1 ulp) instead of the library's range-checked forms - the arguments
+// are bounded (weights of a window, gradients of an image in [0, 255]).
+__device__ __forceinline__ float exp_sample(float x) {
+    return __builtin_amdgcn_exp2f(x * 1.4426950408889634f);
+}
+__device__ __forceinline__ float sqrt_sample(float x) { return __builtin_amdgcn_sqrtf(x); }
+
+// The four neighbours of octave pixel (y, x), read at 32-bit offsets from the layer's base.
+typedef const __attribute__((address_space(1))) float *layer_ptr;
+
+// The orientation and descriptor kernels give every WAVE its own keypoint and its own LDS
+// arrays; waves of a workgroup never talk to each other, so nothing needs s_barrier - a wave's
+// LDS instructions execute in issue order, and this keeps the compiler from reordering them
+// across the points where lanes read what other lanes wrote.  (As one-wave workgroups that
+// called __syncthreads() the kernels ran at two waves per SIMD - SQ_WAVE_CYCLES over the busy
+// time - and spent four fifths of their cycles waiting for their gathers.)
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+#define SIFT_WAVES 4                     // waves (keypoints in flight) per workgroup
+
 // Matx33f::solve(b, DECOMP_LU): float Gaussian elimination with partial pivoting
 __device__ __forceinline__ bool solve3(float a[3][3], float b[3], float x[3]) {
 #pragma unroll
@@ -305,26 +348,54 @@ __global__ __launch_bounds__(256) void sift_refine_kernel(
     }
 }
 
-// One wave per candidate (blockDim 64).
-__global__ __launch_bounds__(64) void sift_orient_kernel(
+// One wave per candidate (blockDim 64).  A wave keeps the keypoints it finds (candidate index
+// and angle) in LDS and reserves their slots in the output list a batch at a time: one
+// returning atomic per candidate on the list's single counter - 100 k of them queuing on one
+// address - kept every wave waiting (the kernel issued vector instructions in a quarter of its
+// cycles; profiles/r03/pmc_cfg4_detect_summary.txt).
+#define SIFT_ORI_VOTE_SCALE 1048576.0f   // 2^-20 units: a vote (< 361) fits 32 bits
+#define SIFT_ORI_BATCH 96
+__global__ __launch_bounds__(64 * SIFT_WAVES) void sift_orient_kernel(
     const float *const *__restrict__ gauss, const int *__restrict__ dims, int n_layers,
     const pano_sift_keypoint *__restrict__ cands, const int *__restrict__ n_cands, int max_cands,
     pano_sift_keypoint *__restrict__ kpts, int *__restrict__ count, int max_kpts) {
-    __shared__ unsigned long long votes[SIFT_ORI_BINS];      // fixed point, as in the descriptor
-    __shared__ float temp[SIFT_ORI_BINS + 4];
-    __shared__ float hist[SIFT_ORI_BINS];
+    __shared__ unsigned long long s_votes[SIFT_WAVES][SIFT_ORI_BINS];   // fixed point, as in the descriptor
+    __shared__ float s_temp[SIFT_WAVES][SIFT_ORI_BINS + 4];
+    __shared__ float s_hist[SIFT_WAVES][SIFT_ORI_BINS];
+    __shared__ int s_out_idx[SIFT_WAVES][SIFT_ORI_BATCH + SIFT_ORI_BINS];
+    __shared__ float s_out_angle[SIFT_WAVES][SIFT_ORI_BATCH + SIFT_ORI_BINS];
+    __shared__ int s_out_base[SIFT_WAVES];
     const int total = min(*n_cands, max_cands);
-    const int lane = threadIdx.x;
-    for (int idx = blockIdx.x; idx < total; idx += gridDim.x) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    unsigned long long *votes = s_votes[wv];
+    float *temp = s_temp[wv], *hist = s_hist[wv], *out_angle = s_out_angle[wv];
+    int *out_idx = s_out_idx[wv];
+    int n_out = 0;                                           // wave-uniform
+    auto flush = [&]() {
+        if (n_out == 0) return;
+        if (lane == 0) s_out_base[wv] = atomicAdd(count, n_out);
+        wave_sync();
+        const int base = s_out_base[wv];
+        for (int i = lane; i < n_out; i += 64) {
+            if (base + i < max_kpts) {
+                pano_sift_keypoint out = cands[out_idx[i]];
+                out.angle = out_angle[i];
+                kpts[base + i] = out;
+            }
+        }
+        wave_sync();
+        n_out = 0;
+    };
+    for (int idx = blockIdx.x * SIFT_WAVES + wv; idx < total; idx += gridDim.x * SIFT_WAVES) {
         const pano_sift_keypoint k = cands[idx];
         const int octv = k.octave & 255, layer = (k.octave >> 8) & 255;
         const int rows = dims[2 * octv], cols = dims[2 * octv + 1];
-        const float *__restrict__ img = gauss[octv] + (size_t)layer * rows * cols;
+        const layer_ptr img = (layer_ptr)(gauss[octv] + (size_t)layer * rows * cols);
         const float scl = __fdiv_rn(k.size * 0.5f, (float)(1 << octv));
         const int radius = (int)rintf(4.5f * scl);
         const float sig = 1.5f * scl, expf_scale = __fdiv_rn(-1.0f, 2.0f * sig * sig);
         if (lane < SIFT_ORI_BINS) votes[lane] = 0;
-        __syncthreads();
+        wave_sync();
         const int side = 2 * radius + 1;
         // t / side without an integer divide per sample: exact for t < 2^22 (side < 2048)
         const float inv_side = __fdiv_rn(1.0f, (float)side);
@@ -337,21 +408,31 @@ __global__ __launch_bounds__(64) void sift_orient_kernel(
             const int i = row - radius, j = col - radius;
             const int y = k.r + i, x = k.c + j;
             if (y <= 0 || y >= rows - 1 || x <= 0 || x >= cols - 1) continue;
-            const float dx = img[(size_t)y * cols + x + 1] - img[(size_t)y * cols + x - 1];
-            const float dy = img[(size_t)(y - 1) * cols + x] - img[(size_t)(y + 1) * cols + x];
-            const float w = expf((float)(i * i + j * j) * expf_scale);
-            const float ori = fast_atan2(dy, dx), mag = sqrtf(dx * dx + dy * dy);
+            const uint32_t o = (uint32_t)y * (uint32_t)cols + (uint32_t)x;   // a layer is below 2^31 pixels
+#ifdef SIFT_ABL_NOLOAD
+            const float dx = (float)(o & 7) - 3.5f, dy = (float)((o >> 3) & 7) - 3.3f;
+#else
+            const float dx = img[o + 1] - img[o - 1];
+            const float dy = img[o - (uint32_t)cols] - img[o + (uint32_t)cols];
+#endif
+            const float w = exp_sample((float)(i * i + j * j) * expf_scale);
+            const float ori = fast_atan2_sample(dy, dx), mag = sqrt_sample(dx * dx + dy * dy);
             int bin = (int)rintf((SIFT_ORI_BINS / 360.0f) * ori);
             if (bin >= SIFT_ORI_BINS) bin -= SIFT_ORI_BINS;
             if (bin < 0) bin += SIFT_ORI_BINS;
-            atomicAdd(&votes[bin], (unsigned long long)(long long)rintf(w * mag * SIFT_VOTE_SCALE));
+            const unsigned vote = (unsigned)fmaxf(__builtin_fmaf(w * mag, SIFT_ORI_VOTE_SCALE, 0.5f), 0.0f);
+#ifdef SIFT_ABL_NOVOTE
+            if (vote == 0x7fffffffu) votes[bin] = vote;
+#else
+            atomicAdd(&votes[bin], (unsigned long long)vote);
+#endif
         }
-        __syncthreads();
+        wave_sync();
         if (lane < SIFT_ORI_BINS + 4) {                  // circular padding of two bins either side
             const int b = (lane + SIFT_ORI_BINS - 2) % SIFT_ORI_BINS;
-            temp[lane] = (float)(long long)votes[b] * (1.0f / SIFT_VOTE_SCALE);
+            temp[lane] = (float)(long long)votes[b] * (1.0f / SIFT_ORI_VOTE_SCALE);
         }
-        __syncthreads();
+        wave_sync();
         float h = 0.0f;
         if (lane < SIFT_ORI_BINS) {
             const int t = lane + 2;
@@ -362,7 +443,9 @@ __global__ __launch_bounds__(64) void sift_orient_kernel(
         float omax = h;
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) omax = fmaxf(omax, __shfl_xor(omax, off, 64));
-        __syncthreads();
+        wave_sync();
+        bool peak = false;
+        float angle = 0.0f;
         if (lane < SIFT_ORI_BINS) {
             const int l = lane > 0 ? lane - 1 : SIFT_ORI_BINS - 1;
             const int r2 = lane < SIFT_ORI_BINS - 1 ? lane + 1 : 0;
@@ -370,23 +453,27 @@ __global__ __launch_bounds__(64) void sift_orient_kernel(
             if (h > hl && h > hr && h >= omax * 0.8f) {
                 float bin = (float)lane + __fdiv_rn(0.5f * (hl - hr), hl - 2.0f * h + hr);
                 bin = bin < 0.0f ? SIFT_ORI_BINS + bin : (bin >= SIFT_ORI_BINS ? bin - SIFT_ORI_BINS : bin);
-                float angle = 360.0f - (360.0f / SIFT_ORI_BINS) * bin;
+                angle = 360.0f - (360.0f / SIFT_ORI_BINS) * bin;
                 if (fabsf(angle - 360.0f) < 1.1920929e-07f) angle = 0.0f;
-                const int slot = atomicAdd(count, 1);
-                if (slot < max_kpts) {
-                    pano_sift_keypoint out = k;
-                    out.angle = angle;
-                    kpts[slot] = out;
-                }
+                peak = true;
             }
         }
-        __syncthreads();
+        const unsigned long long found = __ballot(peak);
+        if (peak) {
+            const int at = n_out + __popcll(found & ((1ull << lane) - 1ull));
+            out_idx[at] = idx;
+            out_angle[at] = angle;
+        }
+        n_out += __popcll(found);
+        wave_sync();
+        if (n_out >= SIFT_ORI_BATCH) flush();            // (at most SIFT_ORI_BINS more next time)
     }
+    flush();
 }
 
 // One wave per keypoint.  kpts hold full-resolution coordinates (after the halving for
 // first octave -1) and the adjusted packed octave, as SIFT::detectAndCompute returns them.
-__global__ __launch_bounds__(64) void sift_describe_kernel(
+__global__ __launch_bounds__(64 * SIFT_WAVES) void sift_describe_kernel(
     const float *const *__restrict__ gauss, const int *__restrict__ dims, int first_octave,
     const pano_sift_keypoint *__restrict__ kpts, int n_cap, const int *__restrict__ n_dev,
     float *__restrict__ desc) {
@@ -406,10 +493,11 @@ __global__ __launch_bounds__(64) void sift_describe_kernel(
     // most the samples of 2 x 2 cells, 36 scl^2 of them, each at most 361 (255 sqrt 2).
     // (Eight 64-bit atomics per sample: 2.85 ms for the 135 k keypoints of a 4K frame.)
     constexpr int PAIRS = 9, CELLS = (d + 2) * (d + 2);
-    __shared__ unsigned long long hist[CELLS * PAIRS];
-    const int lane = threadIdx.x;
+    __shared__ unsigned long long s_hist[SIFT_WAVES][CELLS * PAIRS];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    unsigned long long *hist = s_hist[wv];
     const int n = n_dev ? min(*n_dev, n_cap) : n_cap;   // the count may still be on the device
-    for (int idx = blockIdx.x; idx < n; idx += gridDim.x) {
+    for (int idx = blockIdx.x * SIFT_WAVES + wv; idx < n; idx += gridDim.x * SIFT_WAVES) {
         const pano_sift_keypoint k = kpts[idx];
         int octave = k.octave & 255;
         const int layer = (k.octave >> 8) & 255;
@@ -417,7 +505,7 @@ __global__ __launch_bounds__(64) void sift_describe_kernel(
         const float scale = octave >= 0 ? __fdiv_rn(1.0f, (float)(1 << octave)) : (float)(1 << -octave);
         const int o = octave - first_octave;
         const int rows = dims[2 * o], cols = dims[2 * o + 1];
-        const float *__restrict__ img = gauss[o] + (size_t)layer * rows * cols;
+        const layer_ptr img = (layer_ptr)(gauss[o] + (size_t)layer * rows * cols);
         float ori = 360.0f - k.angle;
         if (fabsf(ori - 360.0f) < 1.1920929e-07f) ori = 0.0f;
         const float scl = k.size * scale * 0.5f;
@@ -435,7 +523,7 @@ __global__ __launch_bounds__(64) void sift_describe_kernel(
         kbits = kbits > 24 ? 24 : (kbits < 0 ? 0 : kbits);
         const float to_fixed = exp2f((float)kbits), from_fixed = exp2f(-(float)kbits);
         for (int t = lane; t < CELLS * PAIRS; t += 64) hist[t] = 0;
-        __syncthreads();
+        wave_sync();
         const int side = 2 * radius + 1;
         // t / side without an integer divide per sample: exact for t < 2^22 (side < 2048)
         const float inv_side = __fdiv_rn(1.0f, (float)side);
@@ -452,11 +540,18 @@ __global__ __launch_bounds__(64) void sift_describe_kernel(
             if (!(rbin > -1.0f && rbin < d && cbin > -1.0f && cbin < d && r > 0 && r < rows - 1 &&
                   c > 0 && c < cols - 1))
                 continue;
-            const float dx = img[(size_t)r * cols + c + 1] - img[(size_t)r * cols + c - 1];
-            const float dy = img[(size_t)(r - 1) * cols + c] - img[(size_t)(r + 1) * cols + c];
-            const float w = expf((c_rot * c_rot + r_rot * r_rot) * exp_scale);
-            float obin = (fast_atan2(dy, dx) - ori) * bins_per_rad;
-            const float mag = sqrtf(dx * dx + dy * dy) * w;
+            const uint32_t at = (uint32_t)r * (uint32_t)cols + (uint32_t)c;   // a layer is below 2^31 pixels
+#ifdef SIFT_ABL_NOLOAD
+            const float dx = (float)(at & 7) - 3.5f, dy = (float)((at >> 3) & 7) - 3.3f;
+#else
+            const float dx = img[at + 1] - img[at - 1];
+            const float dy = img[at - (uint32_t)cols] - img[at + (uint32_t)cols];
+#endif
+            const float w = exp_sample((c_rot * c_rot + r_rot * r_rot) * exp_scale);
+            float obin = (fast_atan2_sample(dy, dx) - ori) * bins_per_rad;
+            // the magnitude in the histogram's fixed-point unit from here on: the eight votes
+            // are then one add and one conversion each
+            const float mag = sqrt_sample(dx * dx + dy * dy) * w * to_fixed;
             const int r0 = (int)floorf(rbin), c0 = (int)floorf(cbin);
             int o0 = (int)floorf(obin);
             rbin -= r0;
@@ -475,16 +570,20 @@ __global__ __launch_bounds__(64) void sift_describe_kernel(
             const int pair = (o0 & 1) ? 5 + (o0 >> 1) : (o0 >> 1);
             const int cell = (r0 + 1) * (d + 2) + c0 + 1;
             auto vote = [&](const int which, const float lo, const float hi) {
-                const unsigned long long a = (unsigned long long)(unsigned)(int)fmaxf(rintf(lo * to_fixed), 0.0f);
-                const unsigned long long b = (unsigned long long)(unsigned)(int)fmaxf(rintf(hi * to_fixed), 0.0f);
+                const unsigned long long a = (unsigned)fmaxf(lo + 0.5f, 0.0f);
+                const unsigned long long b = (unsigned)fmaxf(hi + 0.5f, 0.0f);
+#ifdef SIFT_ABL_NOVOTE
+                if ((a | b << 32) == 0x7fffffffffull) hist[which * PAIRS + pair] = a;
+#else
                 atomicAdd(&hist[which * PAIRS + pair], a | b << 32);
+#endif
             };
             vote(cell, v000, v001);
             vote(cell + 1, v010, v011);
             vote(cell + (d + 2), v100, v101);
             vote(cell + (d + 3), v110, v111);
         }
-        __syncthreads();
+        wave_sync();
         // circular orientation bins, then the 4 x 4 x 8 vector (two entries per lane)
         float v[2];
 #pragma unroll
@@ -519,7 +618,7 @@ __global__ __launch_bounds__(64) void sift_describe_kernel(
             const float q = rintf(v[e] * s);
             desc[(size_t)idx * (d * d * nb) + lane + 64 * e] = fminf(fmaxf(q, 0.0f), 255.0f);
         }
-        __syncthreads();
+        wave_sync();
     }
 }
 
@@ -576,9 +675,9 @@ extern "C" int pano_sift_orient(pano_ctx *ctx, const float *const *gauss, const 
     PANO_ENTER(ctx, "pano_sift_orient");
     PANO_REQUIRE(gauss && dims && cands && n_cands && kpts && count, "pano_sift_orient: null pointer");
     PANO_REQUIRE(max_cands > 0 && max_kpts > 0 && n_layers >= 1, "pano_sift_orient: bad argument");
-    const int blocks = max_cands < 16384 ? max_cands : 16384;
+    const int blocks = ceil_div(max_cands < 16384 ? max_cands : 16384, SIFT_WAVES);
     PANO_TIMED(PK_SIFT_ORIENT, (hipStream_t)stream,
-               hipLaunchKernelGGL(sift_orient_kernel, dim3(blocks), dim3(64), 0, (hipStream_t)stream,
+               hipLaunchKernelGGL(sift_orient_kernel, dim3(blocks), dim3(64 * SIFT_WAVES), 0, (hipStream_t)stream,
                                   gauss, dims, n_layers, cands, n_cands, max_cands, kpts, count,
                                   max_kpts));
     PANO_LAUNCH_CHECK("sift_orient_kernel");
@@ -592,9 +691,9 @@ extern "C" int pano_sift_describe(pano_ctx *ctx, const float *const *gauss, cons
     PANO_REQUIRE(gauss && dims && (n == 0 || (kpts && desc)), "pano_sift_describe: null pointer");
     PANO_REQUIRE(n >= 0, "pano_sift_describe: bad count");
     if (n == 0) return PANO_OK;
-    const int blocks = n < 65535 ? n : 65535;
+    const int blocks = ceil_div(n < 65536 ? n : 65536, SIFT_WAVES);
     PANO_TIMED(PK_SIFT_DESCRIBE, (hipStream_t)stream,
-               hipLaunchKernelGGL(sift_describe_kernel, dim3(blocks), dim3(64), 0,
+               hipLaunchKernelGGL(sift_describe_kernel, dim3(blocks), dim3(64 * SIFT_WAVES), 0,
                                   (hipStream_t)stream, gauss, dims, first_octave, kpts, n, n_dev, desc));
     PANO_LAUNCH_CHECK("sift_describe_kernel");
     return PANO_OK;
