@@ -493,9 +493,17 @@ __global__ __launch_bounds__(64 * SIFT_WAVES) void sift_describe_kernel(
     // most the samples of 2 x 2 cells, 36 scl^2 of them, each at most 361 (255 sqrt 2).
     // (Eight 64-bit atomics per sample: 2.85 ms for the 135 k keypoints of a 4K frame.)
     constexpr int PAIRS = 9, CELLS = (d + 2) * (d + 2);
-    __shared__ unsigned long long s_hist[SIFT_WAVES][CELLS * PAIRS];
+    // SIFT_HCOPIES copies of a wave's histogram, one per group of 64 / SIFT_HCOPIES lanes: the 64
+    // samples of a step are neighbours in the window and mostly vote into the same two or three
+    // cells - same-address atomics, which the LDS serialises
+#ifndef SIFT_HCOPIES
+#define SIFT_HCOPIES 2
+#endif
+    constexpr int HSIZE = CELLS * PAIRS;
+    __shared__ unsigned long long s_hist[SIFT_WAVES][SIFT_HCOPIES * HSIZE];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     unsigned long long *hist = s_hist[wv];
+    unsigned long long *mine = hist + (lane / (64 / SIFT_HCOPIES)) * HSIZE;
     const int n = n_dev ? min(*n_dev, n_cap) : n_cap;   // the count may still be on the device
     for (int idx = blockIdx.x * SIFT_WAVES + wv; idx < n; idx += gridDim.x * SIFT_WAVES) {
         const pano_sift_keypoint k = kpts[idx];
@@ -522,7 +530,7 @@ __global__ __launch_bounds__(64 * SIFT_WAVES) void sift_describe_kernel(
         int kbits = 31 - (int)ceilf(log2f(36.0f * fmaxf(scl * scl, 1.0f) * 361.0f));
         kbits = kbits > 24 ? 24 : (kbits < 0 ? 0 : kbits);
         const float to_fixed = exp2f((float)kbits), from_fixed = exp2f(-(float)kbits);
-        for (int t = lane; t < CELLS * PAIRS; t += 64) hist[t] = 0;
+        for (int t = lane; t < SIFT_HCOPIES * HSIZE; t += 64) hist[t] = 0;
         wave_sync();
         const int side = 2 * radius + 1;
         // t / side without an integer divide per sample: exact for t < 2^22 (side < 2048)
@@ -575,7 +583,7 @@ __global__ __launch_bounds__(64 * SIFT_WAVES) void sift_describe_kernel(
 #ifdef SIFT_ABL_NOVOTE
                 if ((a | b << 32) == 0x7fffffffffull) hist[which * PAIRS + pair] = a;
 #else
-                atomicAdd(&hist[which * PAIRS + pair], a | b << 32);
+                atomicAdd(&mine[which * PAIRS + pair], a | b << 32);
 #endif
             };
             vote(cell, v000, v001);
@@ -594,9 +602,14 @@ __global__ __launch_bounds__(64 * SIFT_WAVES) void sift_describe_kernel(
             // bin b of a cell: low or high half of pair b >> 1 of the even set, and of the odd
             // set (pairs (1,2) (3,4) (5,6) (7,8) at 5 .. 8)
             auto bin = [&](const int b) -> long long {
-                long long sum = (long long)((h[b >> 1] >> (32 * (b & 1))) & 0xffffffffull);
-                if (b >= 1 && b <= 8)
-                    sum += (long long)((h[5 + ((b - 1) >> 1)] >> (32 * ((b - 1) & 1))) & 0xffffffffull);
+                long long sum = 0;
+#pragma unroll
+                for (int cp = 0; cp < SIFT_HCOPIES; ++cp) {
+                    const unsigned long long *hc = h + cp * HSIZE;
+                    sum += (long long)((hc[b >> 1] >> (32 * (b & 1))) & 0xffffffffull);
+                    if (b >= 1 && b <= 8)
+                        sum += (long long)((hc[5 + ((b - 1) >> 1)] >> (32 * ((b - 1) & 1))) & 0xffffffffull);
+                }
                 return sum;
             };
             long long sum = bin(kk);

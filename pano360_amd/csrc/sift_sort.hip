@@ -8,9 +8,12 @@
 // and shift the octave byte.
 //
 // On the host this was np.lexsort over six keys: 54 of the 69 ms of a 4K frame's
-// detectAndCompute (135 k keypoints).  Here: six stable least-significant-key-first radix
-// passes over (32-bit key, index) pairs - rocPRIM's device radix sort through hipCUB, the
-// library sort for a plain sort - with hand-written kernels around them that build the
+// detectAndCompute (135 k keypoints).  Here: ONE stable radix sort of (64-bit key, index)
+// pairs on the two leading keys, x and y - rocPRIM's device radix sort through hipCUB, the
+// library sort for a plain sort - and a kernel that orders the short runs of keypoints sharing
+// a position by the other four keys (a stable insertion sort per run: the same order as six
+// stable least-significant-key-first passes, which is what round 2 ran - a hundred launches
+// per frame, 0.6 ms of launch latency); hand-written kernels around them build the
 // order-preserving integer keys, flag the duplicates and compact the survivors.
 #include <hipcub/hipcub.hpp>
 
@@ -25,37 +28,56 @@ __device__ __forceinline__ uint32_t ordered(float v) {
     return (b & 0x80000000u) ? ~b : b | 0x80000000u;
 }
 
-// key of pass `which` (0 = least significant): octave desc, response desc, angle, size
-// desc, y, x
+// the leading keys x, y as one 64-bit key, and the identity permutation
 __global__ __launch_bounds__(256) void sift_keys_kernel(const pano_sift_keypoint *__restrict__ kp,
-                                                        const uint32_t *__restrict__ idx, int n,
-                                                        const int *__restrict__ n_dev, int which,
-                                                        uint32_t *__restrict__ keys) {
+                                                        int n, const int *__restrict__ n_dev,
+                                                        uint64_t *__restrict__ keys,
+                                                        uint32_t *__restrict__ idx) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    // slots past the device-side count hold nothing: the largest key in every pass keeps them
-    // at the end (the passes are stable)
-    const uint32_t src = idx ? idx[i] : (uint32_t)i;
-    if (n_dev && (int)src >= min(*n_dev, n)) {
-        keys[i] = 0xffffffffu;
+    idx[i] = (uint32_t)i;
+    // slots past the device-side count hold nothing: the largest key keeps them at the end
+    if (n_dev && i >= min(*n_dev, n)) {
+        keys[i] = ~0ull;
         return;
     }
-    const pano_sift_keypoint k = kp[src];
-    uint32_t key;
-    switch (which) {
-        case 0: key = ~((uint32_t)k.octave ^ 0x80000000u); break;      // signed, descending
-        case 1: key = ~ordered(k.response); break;
-        case 2: key = ordered(k.angle); break;
-        case 3: key = ~ordered(k.size); break;
-        case 4: key = ordered(k.y); break;
-        default: key = ordered(k.x); break;
-    }
-    keys[i] = key;
+    const pano_sift_keypoint k = kp[i];
+    keys[i] = (uint64_t)ordered(k.x) << 32 | ordered(k.y);
 }
 
-__global__ __launch_bounds__(256) void sift_iota_kernel(uint32_t *__restrict__ idx, int n) {
+// a < b in the order of the four trailing keys: size descending, angle, response descending,
+// octave descending (equal: keep the arrival order - the sort is stable)
+__device__ __forceinline__ bool sift_tail_less(const pano_sift_keypoint &a, const pano_sift_keypoint &b) {
+    const uint32_t as = ~ordered(a.size), bs = ~ordered(b.size);
+    if (as != bs) return as < bs;
+    const uint32_t aa = ordered(a.angle), ba = ordered(b.angle);
+    if (aa != ba) return aa < ba;
+    const uint32_t ar = ~ordered(a.response), br = ~ordered(b.response);
+    if (ar != br) return ar < br;
+    const uint32_t ao = ~((uint32_t)a.octave ^ 0x80000000u), bo = ~((uint32_t)b.octave ^ 0x80000000u);
+    return ao < bo;
+}
+
+// The thread at the head of a run of equal (x, y) keys orders the run by the trailing keys.
+__global__ __launch_bounds__(256) void sift_runs_kernel(const pano_sift_keypoint *__restrict__ kp,
+                                                        const uint64_t *__restrict__ keys, int n,
+                                                        uint32_t *__restrict__ idx) {
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < n) idx[i] = (uint32_t)i;
+    if (i >= n) return;
+    const uint64_t key = keys[i];
+    if (key == ~0ull || (i > 0 && keys[i - 1] == key) || i + 1 >= n || keys[i + 1] != key) return;
+    int end = i + 2;
+    while (end < n && keys[end] == key) ++end;
+    for (int a = i + 1; a < end; ++a) {                  // stable insertion sort of idx[i .. end)
+        const uint32_t cur = idx[a];
+        const pano_sift_keypoint kc = kp[cur];
+        int b = a;
+        while (b > i && sift_tail_less(kc, kp[idx[b - 1]])) {
+            idx[b] = idx[b - 1];
+            --b;
+        }
+        idx[b] = cur;
+    }
 }
 
 // 1 = the first of its (x, y, size, angle) group in sorted order
@@ -101,15 +123,16 @@ struct SortLayout {
 SortLayout sort_layout(int n) {
     SortLayout L = {};
     size_t sort_bytes = 0, scan_bytes = 0;
+    uint64_t *k64 = nullptr;
     uint32_t *ku = nullptr;
     int *iu = nullptr;
-    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, sort_bytes, ku, ku, ku, ku, n);   // size queries
+    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, sort_bytes, k64, k64, ku, ku, n);   // size queries
     (void)hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, iu, iu, n);
     L.temp_bytes = ((sort_bytes > scan_bytes ? sort_bytes : scan_bytes) + 255) & ~(size_t)255;
     const size_t arr = ((size_t)n * 4 + 255) & ~(size_t)255;
-    L.keys_a = L.temp_bytes;
-    L.keys_b = L.keys_a + arr;
-    L.idx_a = L.keys_b + arr;
+    L.keys_a = L.temp_bytes;                            // 64-bit keys: two arrays' worth each
+    L.keys_b = L.keys_a + 2 * arr;
+    L.idx_a = L.keys_b + 2 * arr;
     L.idx_b = L.idx_a + arr;
     L.flags = L.idx_b + arr;
     L.pos = L.flags + arr;
@@ -136,22 +159,19 @@ extern "C" int pano_sift_sort_unique(pano_ctx *ctx, const pano_sift_keypoint *kp
                  first_octave);
     const SortLayout L = sort_layout(n);
     unsigned char *base = (unsigned char *)work;
-    uint32_t *keys_a = (uint32_t *)(base + L.keys_a), *keys_b = (uint32_t *)(base + L.keys_b);
-    uint32_t *idx_a = (uint32_t *)(base + L.idx_a), *idx_b = (uint32_t *)(base + L.idx_b);
+    uint64_t *keys_a = (uint64_t *)(base + L.keys_a), *keys_b = (uint64_t *)(base + L.keys_b);
+    uint32_t *idx_b = (uint32_t *)(base + L.idx_a), *idx_a = (uint32_t *)(base + L.idx_b);
     int *flags = (int *)(base + L.flags), *pos = (int *)(base + L.pos);
     const dim3 grid(ceil_div(n, 256)), block(256);
-    hipLaunchKernelGGL(sift_iota_kernel, grid, block, 0, s, idx_a, n);
-    PANO_LAUNCH_CHECK("sift_iota_kernel");
-    for (int which = 0; which < 6; ++which) {
-        hipLaunchKernelGGL(sift_keys_kernel, grid, block, 0, s, kpts, idx_a, n, n_dev, which, keys_a);
-        PANO_LAUNCH_CHECK("sift_keys_kernel");
+    hipLaunchKernelGGL(sift_keys_kernel, grid, block, 0, s, kpts, n, n_dev, keys_a, idx_b);
+    PANO_LAUNCH_CHECK("sift_keys_kernel");
+    {
         size_t temp = L.temp_bytes;
-        PANO_HIP(hipcub::DeviceRadixSort::SortPairs(base, temp, keys_a, keys_b, idx_a, idx_b, n, 0,
-                                                    32, s));
-        uint32_t *t = idx_a;
-        idx_a = idx_b;
-        idx_b = t;
+        PANO_HIP(hipcub::DeviceRadixSort::SortPairs(base, temp, keys_a, keys_b, idx_b, idx_a, n, 0,
+                                                    64, s));
     }
+    hipLaunchKernelGGL(sift_runs_kernel, grid, block, 0, s, kpts, keys_b, n, idx_a);
+    PANO_LAUNCH_CHECK("sift_runs_kernel");
     hipLaunchKernelGGL(sift_flags_kernel, grid, block, 0, s, kpts, idx_a, n, n_dev, flags);
     PANO_LAUNCH_CHECK("sift_flags_kernel");
     size_t temp = L.temp_bytes;
