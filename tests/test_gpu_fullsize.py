@@ -537,6 +537,59 @@ def test_cfg3_full_size_strips_equal_whole(eng, world):
             assert torch.equal(plain[:, c0:c1], whole[:, c0:c1]), (world, rank)
 
 
+def test_cfg4_keypoints_of_a_4k_frame_against_a_windowed_oracle(eng):
+    """BASELINE config 4 at full size: keypoints and descriptors of a 3840 x 2160 frame.  No
+    CPU oracle finishes a 4K frame (135 k keypoints through NumPy loops), but SIFT is local: a
+    keypoint of the first octaves whose whole support - the blur chain below its layer, its
+    orientation and descriptor windows - stays inside a 192 x 192 crop comes out of the crop
+    exactly as out of the frame (the crop starts on a multiple of 64, so the 2x base and the
+    nearest-neighbour halvings pick the same samples).  The oracle runs on two crops; inside
+    their cores the frame's keypoints must be the crops' (count within 3 %, 97 % matched in
+    position, size and angle, descriptors of the matched within the small-size bound)."""
+    import sift_oracle
+    import sift_pyramid as sp
+    from pano360_amd import features, synth
+    from test_gpu_parity import _match_keypoints
+    tile = synth.make_frame(2, 960, 540, "B")
+    img = np.ascontiguousarray(np.tile(tile, (4, 4, 1)))
+    assert img.shape == (2160, 3840, 3)
+    frame = eng.upload_frames([img])[0]
+    got, desc = features.sift_detect_device(frame)
+    desc = desc.cpu().numpy()
+    assert len(got) > 20000
+    size, margin = 192, 48
+    total_want = total_got = 0
+    for y0, x0 in ((1024, 2048), (448, 3584)):
+        crop = img[y0:y0 + size, x0:x0 + size]
+        g_or, d_or = sp.sift_pyramid(crop)
+        want_k, want_d = sift_oracle.detect_and_compute(g_or, d_or)
+        want = np.zeros(len(want_k), features.KP_DTYPE)
+        for i, k in enumerate(want_k):
+            want[i] = (k["x"], k["y"], k["size"], k["angle"], k["response"], k["octave"], k["r"], k["c"])
+
+        def core(k, ox, oy):
+            low = ((k["octave"] & 255) == 255) | ((k["octave"] & 255) == 0)      # octaves -1 and 0
+            return (low & (k["x"] - ox >= margin) & (k["x"] - ox < size - margin) &
+                    (k["y"] - oy >= margin) & (k["y"] - oy < size - margin))
+        keep_w = core(want, 0, 0)
+        want, want_d = want[keep_w], want_d[keep_w]
+        keep_g = core(got, x0, y0)
+        sub, sub_d = got[keep_g].copy(), desc[keep_g]
+        sub["x"] -= x0
+        sub["y"] -= y0
+        assert len(want) > 40
+        pairs = _match_keypoints(sub, want)
+        assert len(pairs) >= 0.97 * len(want), (len(pairs), len(want), len(sub))
+        gi, wi = np.array(pairs).T
+        # octave and layer; the third byte is the refined offset inside the layer, which moves
+        # with the scale space's float tolerance
+        assert np.array_equal(sub["octave"][gi] & 0xffff, want["octave"][wi] & 0xffff)
+        assert np.abs(sub_d[gi] - want_d[wi]).mean() < 0.5
+        total_want += len(want)
+        total_got += len(sub)
+    assert abs(total_got - total_want) <= 0.03 * total_want + 2, (total_got, total_want)
+
+
 @pytest.mark.parametrize("n", [0, 1, 2, 1000, 70001])
 def test_sift_sort_unique_on_device_equals_the_host_lexsort(eng, n):
     """``pano_sift_sort_unique`` against ``features.sift_sort_unique`` (np.lexsort + duplicate
