@@ -26,10 +26,11 @@
 #define SS_TW 64
 #define SS_TH 32
 #define SS_RMAX 16
-#define SS_IN_W 128                 // floats per tile row in LDS: a multiple of 64 keeps the row
-                                    // pass's 16-byte reads of four rows at once conflict-free
-#define SS_MID_W 96                 // row-pass image: two rows apart = 0 mod 64 banks, so the
-                                    // column pass's 16-byte reads of two row pairs do not collide
+#define SS_IN_W 132                 // floats per tile row in LDS: 4 banks past a multiple of 64, so the
+                                    // 16 lanes of a 16-byte read group - four rows, four 64-byte
+                                    // strides in each - start on 16 different multiples of 4 banks
+#define SS_MID_W 68                 // row-pass image: the same skew for the row pass's 16-byte stores;
+                                    // the column pass reads 256 contiguous bytes per half wave
 #define SS_NTAP 40                  // 3 leading zeros + 33 taps, rounded up to the trip of 4
 
 struct SsTaps {
@@ -123,31 +124,35 @@ __global__ __launch_bounds__(256) void scale_step_kernel(const float *__restrict
     // from one aligned 16-byte LDS read (window = the previous read + this one)
     constexpr int TRIPS = NT ? (NT + ((4 - ((NT >> 1) & 3)) & 3) + 3) / 4 : 0;
     if (NT) {
-        // 8 adjacent outputs per thread: TRIPS + 2 reads of 16 bytes feed 8 x 4 TRIPS FMAs
-        for (int i = tid; i < ih * (SS_TW / 8); i += 256) {
-            const int ty = i >> 3, q = (i & 7) * 8;
+        // 16 adjacent outputs per thread: TRIPS + 4 reads of 16 bytes feed 16 x 4 TRIPS FMAs
+        // (8 outputs from TRIPS + 2 reads: 20 bytes of LDS per output for 27 taps, now 12; the
+        // kernel is bound by its LDS traffic)
+        for (int i = tid; i < ih * (SS_TW / 16); i += 256) {
+            const int ty = i >> 2, q = (i & 3) * 16;
             const float4 *row = (const float4 *)(s_in + ty * SS_IN_W + q);
-            float4 win[TRIPS + 2];
+            float4 win[TRIPS + 4];
 #pragma unroll
-            for (int k = 0; k < TRIPS + 2; ++k) win[k] = row[k];
-            float a[8];
+            for (int k = 0; k < TRIPS + 4; ++k) win[k] = row[k];
+            float a[16];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) a[j] = 0.f;
+            for (int j = 0; j < 16; ++j) a[j] = 0.f;
 #pragma unroll
             for (int k = 0; k < TRIPS; ++k) {
-                const float e[12] = {win[k].x,     win[k].y,     win[k].z,     win[k].w,
+                const float e[20] = {win[k].x,     win[k].y,     win[k].z,     win[k].w,
                                      win[k + 1].x, win[k + 1].y, win[k + 1].z, win[k + 1].w,
-                                     win[k + 2].x, win[k + 2].y, win[k + 2].z, win[k + 2].w};
+                                     win[k + 2].x, win[k + 2].y, win[k + 2].z, win[k + 2].w,
+                                     win[k + 3].x, win[k + 3].y, win[k + 3].z, win[k + 3].w,
+                                     win[k + 4].x, win[k + 4].y, win[k + 4].z, win[k + 4].w};
 #pragma unroll
                 for (int tt = 0; tt < 4; ++tt) {
                     const float wt = taps.w[4 * k + tt];
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) a[j] = __builtin_fmaf(wt, e[j + tt], a[j]);
+                    for (int j = 0; j < 16; ++j) a[j] = __builtin_fmaf(wt, e[j + tt], a[j]);
                 }
             }
             float4 *m = (float4 *)(s_mid + ty * SS_MID_W + q);
-            m[0] = make_float4(a[0], a[1], a[2], a[3]);
-            m[1] = make_float4(a[4], a[5], a[6], a[7]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) m[j] = make_float4(a[4 * j], a[4 * j + 1], a[4 * j + 2], a[4 * j + 3]);
         }
     } else {
         for (int i = tid; i < ih * (SS_TW / 4); i += 256) {
@@ -183,7 +188,52 @@ __global__ __launch_bounds__(256) void scale_step_kernel(const float *__restrict
     }
     __syncthreads();
 
-    // ---- column pass: 64 columns x 32 rows; a thread makes 4 adjacent columns x 2 stacked rows
+    // ---- column pass: 64 columns x 32 rows
+    if (NT) {
+        // a thread makes 2 adjacent columns x 4 stacked rows from NT + 3 reads of 8 bytes (a
+        // half wave = 32 column pairs of one row group = 256 contiguous bytes: conflict-free):
+        // 2 (NT + 3) bytes of LDS per output where 4 columns x 2 rows took 2 (NT + 1) x 2
+        const int cq = (tid & 31) * 2, cy = (tid >> 5) * 4;
+        const float *col = s_mid + cy * SS_MID_W + cq;
+        float2 v[NT + 3];
+#pragma unroll
+        for (int k = 0; k < NT + 3; ++k) v[k] = *(const float2 *)(col + k * SS_MID_W);
+        float2 acc[4];
+#pragma unroll
+        for (int o = 0; o < 4; ++o) acc[o] = make_float2(0.f, 0.f);
+#pragma unroll
+        for (int k = 0; k < NT; ++k) {
+            const float wk = taps.w[lead + k];
+#pragma unroll
+            for (int o = 0; o < 4; ++o) {
+                acc[o].x = __builtin_fmaf(wk, v[k + o].x, acc[o].x);
+                acc[o].y = __builtin_fmaf(wk, v[k + o].y, acc[o].y);
+            }
+        }
+        const int x = x0 + cq;
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+            const int y = y0 + cy + o;
+            if (y >= h || x >= w) break;
+            const size_t at = (size_t)y * w + x;
+            // the input's centre: r + lead is a multiple of 4, cq even: one aligned 8-byte read
+            const float2 c = *(const float2 *)(s_in + (cy + o + r) * SS_IN_W + cq + r + lead);
+            const float2 d = make_float2(acc[o].x - c.x, acc[o].y - c.y);
+            if (x + 2 <= w && (w & 1) == 0) {
+                *(float2 *)(out + at) = acc[o];
+                if (dog) *(float2 *)(dog + at) = d;
+            } else {
+                out[at] = acc[o].x;
+                if (dog) dog[at] = d.x;
+                if (x + 1 < w) {
+                    out[at + 1] = acc[o].y;
+                    if (dog) dog[at + 1] = d.y;
+                }
+            }
+        }
+        return;
+    }
+    // (looped form) a thread makes 4 adjacent columns x 2 stacked rows
     // from 16-byte LDS reads and stores 16 bytes per row
     const int cq = (tid & 15) * 4, cy = (tid >> 4) * 2;
     float4 acc0 = make_float4(0.f, 0.f, 0.f, 0.f), acc1 = acc0;
@@ -194,16 +244,7 @@ __global__ __launch_bounds__(256) void scale_step_kernel(const float *__restrict
         a.z = __builtin_fmaf(wk, v.z, a.z);
         a.w = __builtin_fmaf(wk, v.w, a.w);
     };
-    if (NT) {
-        float4 v[NT + 1];
-#pragma unroll
-        for (int k = 0; k < NT + 1; ++k) v[k] = *(const float4 *)(col + k * SS_MID_W);
-#pragma unroll
-        for (int k = 0; k < NT; ++k) {
-            fma4(taps.w[lead + k], v[k], acc0);
-            fma4(taps.w[lead + k], v[k + 1], acc1);
-        }
-    } else {
+    {
         float4 lo = *(const float4 *)col;
         for (int k = 0; k < nt; ++k) {
             const float4 hi = *(const float4 *)(col + (k + 1) * SS_MID_W);
