@@ -18,17 +18,21 @@
 // pre-scaled by powers of two so that lo stays a normal number) and a product is
 // three MFMAs, hi*hi + hi*lo + lo*hi, accumulated in float32; the dropped lo*lo
 // term is 2^-22 relative.  Measured against the float32 oracle the blurred
-// planes agree to ~2e-7.
+// planes agree to 6.6e-7 absolute (the tests' bound is 1e-6; the float32-product vector-ALU
+// kernels of blur.hip reach 7.7e-7).
 //
-// Work decomposition: a workgroup (4 waves) owns 128 columns of one record,
-// channel and level and slides down the rows 32 at a time.  Per step it stages
-// one 32-row band of the input (converted to hi/lo float16 once, shared by the
-// waves, whose 32-column outputs need overlapping inputs), each wave makes its
-// 32 x 32 tile of Mid and adds its contribution to the 2*dmax+1 output tiles
-// within reach (live accumulators, rotated), and the tile that just received
-// its last contribution is stored.  Tiles are anchored at multiples of 32 in
+// Work decomposition: a workgroup = GROUP levels x 2 adjacent tile columns (MB_XT = 64 output
+// columns: a work-list item) of one record and channel; GROUP = 4: eight waves, a wave pair per
+// level, one workgroup per CU; GROUP = 2: four waves, two workgroups per CU.  It slides down
+// the rows 32 at a time.  Per step it stages one 32-row band of the input (converted to hi/lo
+// float16 once, shared by the group's levels and the two tile columns, whose outputs need
+// overlapping inputs), each wave makes its 32 x 32 tile of Mid and adds its contribution to
+// the 2*dmax+1 output tiles within reach (live accumulators, rotated), and the tile that
+// just received its last contribution is stored.  Tiles are anchored at multiples of 32 in
 // patch coordinates, so a pixel's sum does not depend on how the rectangle A was
 // cut (column strips, windows): results are bit-identical across decompositions.
+// blur_lean_kernel (further down) runs the regular work items through a leaner instruction
+// stream with two band buffers; this kernel keeps the irregular ones.
 //
 // Activity: with an interior map only the 32 x 32 tiles that hold a pixel the
 // collapse will gather are produced (flags, one byte per tile).
