@@ -169,14 +169,26 @@ int pano_interior_block(void);
  *   PANO_OPT_STITCH_STREAMS  pano_stitch_multiband: 1 (default) = the interior map runs beside
  *                         the region search, and the blur's tile flags and work list beside
  *                         the warp, on a second stream the context owns (ordered by events);
- *                         0 = everything on the context's stream.  Same results. */
+ *                         0 = everything on the context's stream.  Same results.
+ *   PANO_OPT_STITCH_ASYNC  pano_stitch_multiband: 1 (default) = when the previous stitch of
+ *                         the same shape went through, the record table is laid out by a
+ *                         kernel and the warp, blur and collapse are queued behind it at
+ *                         once, sized by what the previous layout needed (plus slack); the
+ *                         host then waits for the layout's summary while the GPU works, and
+ *                         only if this layout needed more (or an arena is too small) the
+ *                         stitch is laid out again on the host and its tail queued a second
+ *                         time.  0 = always the host layout (the GPU idles ~0.1 ms per
+ *                         stitch while the regions travel to the host and the table back).
+ *                         Same results.  (2 = as 1 with launch bounds the layout is sure to
+ *                         exceed: the tests' way into the fallback.) */
 typedef struct pano_ctx pano_ctx;
 #define PANO_OPT_BLUR_KERNEL 0
 #define PANO_OPT_OWN_PRUNE 1
 #define PANO_OPT_BLUR_SEGMENTS 2
 #define PANO_OPT_BLUR_LEAN 3
 #define PANO_OPT_STITCH_STREAMS 4
-#define PANO_OPT_COUNT 5
+#define PANO_OPT_STITCH_ASYNC 5
+#define PANO_OPT_COUNT 6
 #define PANO_BLUR_MFMA 0
 #define PANO_BLUR_VALU 1
 int pano_ctx_create(int device, void *stream, pano_ctx **out);
@@ -614,6 +626,9 @@ typedef struct pano_stitch_args {
     pano_layout layout;        /* out */
 } pano_stitch_args;
 int pano_stitch_multiband(pano_ctx *ctx, pano_stitch_args *args, int resume);
+/* How many stitches of this context went through on the device-side layout
+ * (PANO_OPT_STITCH_ASYNC) and how many of those attempts fell back to the host layout. */
+int pano_stitch_counts(const pano_ctx *ctx, int *device_layouts, int *fallbacks);
 
 #ifdef __cplusplus
 }

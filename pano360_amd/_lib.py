@@ -21,6 +21,7 @@ TAP_LEAD = 7
 TAP_PAD = 40
 # pano_ctx options (include/pano360.h)
 OPT_BLUR_KERNEL, OPT_OWN_PRUNE, OPT_BLUR_SEGMENTS, OPT_BLUR_LEAN, OPT_STITCH_STREAMS = 0, 1, 2, 3, 4
+OPT_STITCH_ASYNC = 5
 BLUR_MFMA, BLUR_VALU = 0, 1
 
 
@@ -148,6 +149,7 @@ _SIGNATURES = {
     "pano_knn2_work_bytes": (C.c_size_t, [_i, _i, _i]),
     "pano_knn2": (_i, [_vp, _vp, _i, _vp, _i, _i, C.c_float, _vp, _vp, _vp, _vp]),
     "pano_stitch_multiband": (_i, [_vp, _vp, _i]),
+    "pano_stitch_counts": (_i, [_vp, _vp, _vp]),
 }
 EXPORTS = tuple(_SIGNATURES)
 

@@ -7,6 +7,7 @@
 #include <vector>
 
 #include "common.h"
+#include "layout.h"
 
 static thread_local char g_error[512] = "";
 
@@ -52,6 +53,7 @@ extern "C" int pano_ctx_create(int device, void *stream, pano_ctx **out) {
     ctx->opt[PANO_OPT_BLUR_SEGMENTS] = 1;
     ctx->opt[PANO_OPT_BLUR_LEAN] = 1;
     ctx->opt[PANO_OPT_STITCH_STREAMS] = 1;
+    ctx->opt[PANO_OPT_STITCH_ASYNC] = 1;
     *out = ctx;
     return PANO_OK;
 }
@@ -94,6 +96,10 @@ extern "C" int pano_ctx_destroy(pano_ctx *ctx) {
     if (ctx->item_buf) (void)hipFree(ctx->item_buf);
     if (ctx->item_counter) (void)hipFree(ctx->item_counter);
     if (ctx->sift_raw) (void)hipFree(ctx->sift_raw);
+    if (ctx->lay_sum_dev) (void)hipFree(ctx->lay_sum_dev);
+    if (ctx->lay_sum_host) (void)hipHostFree(ctx->lay_sum_host);
+    if (ctx->lay_rects_dev) (void)hipFree(ctx->lay_rects_dev);
+    if (ctx->lay_have_dev) (void)hipFree(ctx->lay_have_dev);
     if (ctx->side) {
         (void)hipStreamSynchronize(ctx->side);
         (void)hipStreamDestroy(ctx->side);
@@ -129,6 +135,8 @@ extern "C" int pano_ctx_set_option(pano_ctx *ctx, int option, int value) {
     if (option == PANO_OPT_BLUR_KERNEL)
         PANO_REQUIRE(value == PANO_BLUR_MFMA || value == PANO_BLUR_VALU,
                      "pano_ctx_set_option: blur kernel %d", value);
+    else if (option == PANO_OPT_STITCH_ASYNC)
+        PANO_REQUIRE(value >= 0 && value <= 2, "pano_ctx_set_option: option %d takes 0, 1 or 2", option);
     else
         PANO_REQUIRE(value == 0 || value == 1, "pano_ctx_set_option: option %d takes 0 or 1", option);
     ctx->opt[option] = value;
@@ -276,32 +284,6 @@ extern "C" int pano_timing_read(pano_ctx *ctx, int kid, double *total_ms, int *l
 // Between the region search and the warp the host sits on the critical path of a stitch:
 // the GPU idles until the record table is uploaded.  This is that table's construction
 // (include/pano360.h, "Windows"), one call instead of a hundred small array operations.
-static void reflect_closed(long lo, long hi, long n, long &a, long &b) {
-    // smallest [a, b) inside [0, n) holding reflect_101(p, n) for every p in [lo, hi)
-    if (n == 1) {
-        a = 0;
-        b = 1;
-        return;
-    }
-    if (lo < -(n - 1) || hi > 2 * n - 1) {      // a second reflection could occur
-        a = 0;
-        b = n;
-        return;
-    }
-    a = lo > 0 ? lo : 0;
-    b = hi < n ? hi : n;
-    if (lo < 0) {                               // p in [lo, 0) lands on [1, -lo]
-        a = a < 1 ? a : 1;
-        b = b > 1 - lo ? b : 1 - lo;
-    }
-    if (hi > n) {                               // p in [n, hi) lands on [2n-1-hi, n-2]
-        a = a < 2 * n - 1 - hi ? a : 2 * n - 1 - hi;
-        b = b > n - 1 ? b : n - 1;
-    }
-    a = a > 0 ? a : 0;
-    b = b < n ? b : n;
-}
-
 extern "C" int pano_layout_windows(int tile_grid, const int32_t *regions, int n, int max_spans,
                                    const int32_t *rects, const uint8_t *have, int radius,
                                    int xs0, int xs1, int n_blur, pano_patch *records, int cap,
@@ -318,73 +300,28 @@ extern "C" int pano_layout_windows(int tile_grid, const int32_t *regions, int n,
     int k = 0;
     for (int i = 0; i < n; ++i) {
         const int32_t *rg = regions + (size_t)i * stride;
-        const long ymin = rg[0], ymax = rg[1];
-        const long y0 = rects[4 * i], y1 = rects[4 * i + 1], x0 = rects[4 * i + 2],
-                   x1 = rects[4 * i + 3];
-        const long h = y1 - y0, w = x1 - x0;
         const int spans = rg[4] < max_spans ? rg[4] : max_spans;
         for (int sp = 0; sp < spans; ++sp) {
-            const long xmin = rg[5 + 2 * sp], xmax = rg[6 + 2 * sp];
-            if (ymax < ymin || xmax < xmin) continue;
-            long ay0 = ymin - y0 - radius, ay1 = ymax - y0 + 1 + radius;
-            long ax0 = xmin - x0 - radius, ax1 = xmax - x0 + 1 + radius;
-            ay0 = ay0 > 0 ? ay0 : 0;
-            ay1 = ay1 < h ? ay1 : h;
-            ax0 = ax0 > 0 ? ax0 : 0;
-            ax1 = ax1 < w ? ax1 : w;
-            ax0 = ax0 > xs0 - x0 ? ax0 : xs0 - x0;       // one GPU's share of the mosaic
-            ax1 = ax1 < xs1 - x0 ? ax1 : xs1 - x0;
-            if (ax1 <= ax0) continue;
-            long vy0, vy1, vx0, vx1;
-            reflect_closed(ay0 - radius, ay1 + radius, h, vy0, vy1);
-            reflect_closed(ax0 - radius, ax1 + radius, w, vx0, vx1);
-            vy0 = vy0 < ay0 ? vy0 : ay0;
-            vy1 = vy1 > ay1 ? vy1 : ay1;
-            vx0 = vx0 < ax0 ? vx0 : ax0;
-            vx1 = vx1 > ax1 ? vx1 : ax1;
-            // both ends on multiples of 4 patch columns (the far one clipped to the patch): the
-            // blur stages its bands in aligned chunks of 4 columns, and a chunk is then inside V
-            // or outside it as a whole
-            vx0 &= ~3l;
-            vx1 = (vx1 + 3) & ~3l;
-            vx1 = vx1 < w ? vx1 : w;
+            pano_patch rec;
+            LayoutSizes sz;
+            if (!layout_record(rg, sp, rects + 4 * i, i, radius, xs0, xs1, n_blur, grid32, rec, sz))
+                continue;
             PANO_REQUIRE(k < cap, "pano_layout_windows: more than %d records", cap);
             if (have && !have[i]) ++lay.missing;
             pano_patch &r = records[k++];
-            r = pano_patch{};
-            r.y0 = (int)y0, r.x0 = (int)x0, r.h = (int)h, r.w = (int)w;
-            r.index = i;
-            r.vy0 = (int)vy0, r.vx0 = (int)vx0, r.vh = (int)(vy1 - vy0), r.vw = (int)(vx1 - vx0);
-            r.ay0 = (int)ay0, r.ax0 = (int)ax0, r.ah = (int)(ay1 - ay0), r.aw = (int)(ax1 - ax0);
-            r.vpitch = (r.vw + 3) & ~3;
-            long lead = 0, bsz, ssz = 0, ntile;
-            if (grid32) {
-                // 32-column tile rows anchored at multiples of 32 in patch coordinates: 128-byte
-                // rows with the anchor column on a 128-byte boundary are one cache line each
-                r.apitch = (r.aw + 31) & ~31;
-                lead = r.ax0 & 31;
-                bsz = (long)n_blur * 4 * r.ah * r.apitch + 32;
-                ntile = (long)(((r.ax0 + r.aw - 1) >> 5) - (r.ax0 >> 5) + 1) *
-                        (((r.ay0 + r.ah - 1) >> 5) - (r.ay0 >> 5) + 1);
-            } else {
-                r.apitch = (r.aw + 3) & ~3;
-                bsz = (long)n_blur * 4 * r.ah * r.apitch;
-                ssz = (long)n_blur * 4 * r.vh * r.apitch;
-                ntile = (long)((r.aw + 63) / 64) * ((r.ah + 127) / 128);
-            }
-            // the blur addresses a plane through a buffer descriptor with 32-bit byte offsets
-            PANO_REQUIRE((long)r.vh * r.vpitch * 4 < (1l << 31) && (long)r.ah * r.apitch * 4 < (1l << 31),
+            r = rec;
+            PANO_REQUIRE(layout_record_fits(r),
                          "pano_layout_windows: a plane of record %d exceeds 2 GiB", k - 1);
             // arena offsets in floats, turned into addresses by pano_layout_place
             r.planes = (float *)(uintptr_t)planes;
-            r.blurred = (float *)(uintptr_t)(blurred + lead);
+            r.blurred = (float *)(uintptr_t)(blurred + sz.lead);
             r.scratch = (float *)(uintptr_t)scratch;
             PANO_REQUIRE(tiles < (1l << 31), "pano_layout_windows: tile count overflow");
             r.tiles_off = (int)tiles;
-            planes += 3l * r.vh * r.vpitch;
-            blurred += bsz;
-            scratch += ssz;
-            tiles += ntile;
+            planes += sz.planes;
+            blurred += sz.blurred;
+            scratch += sz.scratch;
+            tiles += sz.tiles;
             lay.max_vw = r.vw > lay.max_vw ? r.vw : lay.max_vw;
             lay.max_vh = r.vh > lay.max_vh ? r.vh : lay.max_vh;
             lay.max_aw = r.aw > lay.max_aw ? r.aw : lay.max_aw;

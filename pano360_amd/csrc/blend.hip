@@ -787,6 +787,9 @@ __global__ __launch_bounds__(256) void multiband_compose_kernel(
         if (ia.part == 2) return;                // compose_interior_kernel wrote it
         const int own = owner[(size_t)y * W + x];
         auto shade = [&](const pano_camera *cam, const float *__restrict__ gl) {
+            // queued before the host has seen the layout's summary (device-side layout): a
+            // camera whose frame is not resident is skipped here and reported by the caller
+            if (!cam->frame) return;
             const int sw = cam->sw, sh = cam->sh;
             float fx, fy;
             map_pixel(cam->proj, ia.sin_t[x], ia.cos_t[x], ia.tan_p[y], sw, sh, fx, fy);

@@ -84,6 +84,8 @@ struct PanoTapSet {                 // one set of Gaussian apertures (pano_multi
     hipStream_t built_on;           // the stream those were queued on
 };
 
+struct LayoutSummary;               // layout.h
+
 struct pano_ctx {
     int device;
     hipStream_t stream;
@@ -104,6 +106,21 @@ struct pano_ctx {
     hipEvent_t ev_regions, ev_upload, ev_fork, ev_join;
     hipStream_t side;               // second stream of pano_stitch_multiband
     bool upload_pending;
+    // pano_stitch_multiband without its host round trip (stitch.hip): the device-side layout's
+    // summary (device / pinned host), device copies of the patch rectangles and resident flags
+    // (and the host values they were made from), and what the previous stitch's layout needed:
+    // the next one's launch bounds
+    LayoutSummary *lay_sum_dev, *lay_sum_host;
+    int32_t *lay_rects_dev;
+    uint8_t *lay_have_dev;
+    int lay_cap_n;
+    std::vector<int32_t> lay_rects_host;
+    std::vector<uint8_t> lay_have_host;
+    pano_layout lay_prev;
+    int lay_prev_sig[12];
+    bool lay_prev_valid;
+    int lay_prev_used_need;
+    int lay_count[2];               // stitches that went through on the device layout / fell back
     // pano_sift_extrema: the list of scale-space extrema between its two kernels (+ its counter)
     uint32_t *sift_raw;
     size_t sift_raw_cap;

@@ -1,6 +1,149 @@
 // One multiband stitch per native call: the launch sequence of Engine.multiband_fused
 // (stitcher.py:283-327 without equalize / crop) queued from C++.  No kernel of its own.
+#include <string.h>
+
 #include "common.h"
+#include "layout.h"
+
+
+// ---- the window layout on the device --------------------------------------------------
+// pano_layout_windows + pano_layout_place as a kernel (one workgroup): the record table goes
+// from the owned regions straight into `table`, and the warp, blur and collapse can be queued
+// behind it without the regions travelling to the host and the table back (0.1 ms per stitch
+// during which the GPU had nothing to do).  Those launches are sized on the host by what the
+// PREVIOUS layout needed (`b_*`, with slack); this kernel checks that the present one fits
+// them and the arenas and otherwise empties the table - every consumer skips an empty record -
+// and says so in the summary, which the host reads while the GPU works and answers with the
+// host layout and a second round of launches.
+#define LAY_THREADS 512
+__global__ __launch_bounds__(LAY_THREADS) void layout_windows_kernel(
+    const int32_t *__restrict__ regions, const int32_t *__restrict__ rects,
+    const uint8_t *__restrict__ have, int n, int max_spans, int radius, int xs0, int xs1,
+    int n_blur, int grid32, float *planes, float *blurred, float *scratch, long cap_planes,
+    long cap_blurred, long cap_scratch, int cap_tiles, int want_tiles, int b_nr, int b_vw,
+    int b_vh, int b_aw, int b_ah, pano_patch *__restrict__ table,
+    LayoutSummary *__restrict__ summary) {
+    __shared__ long s_planes[LAY_THREADS], s_blurred[LAY_THREADS], s_scratch[LAY_THREADS];
+    __shared__ int s_tiles[LAY_THREADS], s_slot[LAY_THREADS];
+    __shared__ long s_run[4];                       // planes, blurred, scratch, tiles so far
+    __shared__ int s_count, s_max[4], s_missing, s_bad;
+    const int tid = threadIdx.x, stride = 5 + 2 * max_spans;
+    if (tid == 0) {
+        s_run[0] = s_run[1] = s_run[2] = s_run[3] = 0;
+        s_count = s_missing = s_bad = 0;
+        s_max[0] = s_max[1] = s_max[2] = s_max[3] = 0;
+    }
+    __syncthreads();
+    const int total = n * max_spans;
+    for (int base = 0; base < total; base += LAY_THREADS) {
+        const int c = base + tid, i = c / max_spans, sp = c - i * max_spans;
+        pano_patch rec = pano_patch{};
+        LayoutSizes sz = LayoutSizes{};
+        bool ok = false;
+        if (c < total) {
+            const int32_t *rg = regions + (size_t)i * stride;
+            const int spans = rg[4] < max_spans ? rg[4] : max_spans;
+            if (sp < spans)
+                ok = layout_record(rg, sp, rects + 4 * i, i, radius, xs0, xs1, n_blur, grid32 != 0,
+                                   rec, sz);
+        }
+        s_slot[tid] = ok ? 1 : 0;
+        s_planes[tid] = sz.planes;
+        s_blurred[tid] = sz.blurred;
+        s_scratch[tid] = sz.scratch;
+        s_tiles[tid] = (int)(sz.tiles < (1l << 30) ? sz.tiles : (1l << 30));
+        if (ok) {
+            atomicMax(&s_max[0], rec.vw);
+            atomicMax(&s_max[1], rec.vh);
+            atomicMax(&s_max[2], rec.aw);
+            atomicMax(&s_max[3], rec.ah);
+            if (have && !have[i]) atomicAdd(&s_missing, 1);
+            if (!layout_record_fits(rec)) atomicOr(&s_bad, 8);
+        }
+        __syncthreads();
+        if (tid == 0) {                             // the chunk's offsets, in candidate order
+            long pl = s_run[0], bl = s_run[1], sc = s_run[2], tl = s_run[3];
+            int k = s_count;
+            for (int t = 0; t < LAY_THREADS; ++t) {
+                if (!s_slot[t]) {
+                    s_slot[t] = -1;
+                    continue;
+                }
+                const long dp = s_planes[t], db = s_blurred[t], ds = s_scratch[t];
+                const int dt = s_tiles[t];
+                s_slot[t] = k++;
+                s_planes[t] = pl;
+                s_blurred[t] = bl;
+                s_scratch[t] = sc;
+                s_tiles[t] = (int)(tl < (1l << 30) ? tl : (1l << 30));
+                pl += dp, bl += db, sc += ds, tl += dt;
+            }
+            s_run[0] = pl, s_run[1] = bl, s_run[2] = sc, s_run[3] = tl;
+            s_count = k;
+        }
+        __syncthreads();
+        const int k = s_slot[tid];
+        if (k >= 0 && k < b_nr) {
+            rec.planes = planes + s_planes[tid];
+            rec.blurred = blurred ? blurred + s_blurred[tid] + sz.lead : nullptr;
+            rec.scratch = scratch ? scratch + s_scratch[tid] : nullptr;
+            rec.tiles_off = s_tiles[tid];
+            table[k] = rec;
+        }
+        __syncthreads();
+    }
+    const int nr = s_count;
+    const long need_planes = s_run[0], need_blurred = s_run[1] + 32, need_scratch = s_run[2];
+    int why = s_bad;
+    if (need_planes > cap_planes || (n_blur > 0 && nr > 0 && (need_blurred > cap_blurred ||
+                                                              need_scratch > cap_scratch)) ||
+        (want_tiles && s_run[3] > cap_tiles))
+        why |= 1;
+    if (s_max[0] > b_vw || s_max[1] > b_vh || s_max[2] > b_aw || s_max[3] > b_ah) why |= 2;
+    if (nr > b_nr) why |= 4;
+    if (s_missing) why |= 16;
+    // records the launches cover beyond the real ones - or all of them - are empty
+    for (int k = (why ? 0 : nr) + tid; k < b_nr; k += LAY_THREADS) table[k] = pano_patch{};
+    if (tid == 0) {
+        LayoutSummary out;
+        out.planes_floats = need_planes;
+        out.blurred_floats = need_blurred;
+        out.scratch_floats = need_scratch;
+        out.n_records = nr;
+        out.n_tiles = (int)(s_run[3] < (1l << 30) ? s_run[3] : (1l << 30));
+        out.max_vw = s_max[0], out.max_vh = s_max[1], out.max_aw = s_max[2], out.max_ah = s_max[3];
+        out.missing = s_missing;
+        out.ok = why == 0;
+        out.why = why;
+        out.pad = 0;
+        *summary = out;
+    }
+}
+
+static int ensure_layout_buffers(pano_ctx *ctx, int n) {
+    if (!ctx->lay_sum_dev) PANO_HIP(hipMalloc((void **)&ctx->lay_sum_dev, sizeof(LayoutSummary)));
+    if (!ctx->lay_sum_host)
+        PANO_HIP(hipHostMalloc((void **)&ctx->lay_sum_host, sizeof(LayoutSummary), hipHostMallocDefault));
+    if (n > ctx->lay_cap_n) {
+        PANO_HIP(hipStreamSynchronize(ctx->stream));            // a queued kernel may still read them
+        if (ctx->lay_rects_dev) PANO_HIP(hipFree(ctx->lay_rects_dev));
+        if (ctx->lay_have_dev) PANO_HIP(hipFree(ctx->lay_have_dev));
+        ctx->lay_rects_dev = nullptr;
+        ctx->lay_have_dev = nullptr;
+        PANO_HIP(hipMalloc((void **)&ctx->lay_rects_dev, (size_t)n * 4 * sizeof(int32_t)));
+        PANO_HIP(hipMalloc((void **)&ctx->lay_have_dev, (size_t)n));
+        ctx->lay_cap_n = n;
+        ctx->lay_rects_host.clear();
+        ctx->lay_have_host.clear();
+    }
+    return PANO_OK;
+}
+
+static void stitch_signature(const pano_stitch_args *a, int *sig) {
+    const int v[12] = {a->n, a->H, a->W, a->xs0, a->xs1, a->own0, a->own1, a->n_levels,
+                       a->radius, a->max_spans, a->shortcut, a->min_gap};
+    for (int k = 0; k < 12; ++k) sig[k] = v[k];
+}
 
 // Runs `call` with the context targeted at its side stream.
 #define ON_SIDE(ctx, call)                  \
@@ -11,6 +154,81 @@
         (ctx)->stream = main_;              \
         if (rc_side_) return rc_side_;      \
     } while (0)
+
+// Everything behind the record table: its upload (host layout) or nothing (device layout),
+// the tile flags / warp-need flags, the warp, the blur's work list, the blur, the collapse.
+// `lay`: the layout, or - device layout - the bounds the launches are sized by.
+static int queue_tail(pano_ctx *ctx, pano_stitch_args *a, const pano_layout &lay, bool device_table,
+                      int need_choice, bool two_streams, bool interior, int n_blur, int tile_grid) {
+    const hipStream_t s = ctx->stream;
+    const bool use_blur = n_blur > 0 && lay.n_records > 0;
+    const int nr = lay.n_records;
+    if (!device_table) {
+        if (lay.planes_floats > a->planes_floats || (use_blur && lay.blurred_floats > a->blurred_floats) ||
+            (use_blur && lay.scratch_floats > a->scratch_floats) ||
+            (interior && lay.n_tiles > a->cap_tiles))
+            return PANO_EGROW;
+        PANO_REQUIRE(lay.planes_floats == 0 || a->planes, "pano_stitch_multiband: no plane arena");
+        if (int rc = pano_layout_place(a->records_host, lay.n_records, a->planes, a->blurred, a->scratch))
+            return rc;
+        if (nr) {
+            PANO_HIP(hipMemcpyAsync(a->table, a->records_host, (size_t)nr * sizeof(pano_patch),
+                                    hipMemcpyHostToDevice, s));
+            PANO_HIP(hipEventRecord(ctx->ev_upload, s));
+            ctx->upload_pending = true;
+        }
+    }
+    // Warp only what is read: worth it when the rectangles are wide against the blur's reach
+    // (8 x 1080p: -4 %; on 32 x 4K nearly every tile is within reach)
+    a->used_need = 0;
+    if (interior && tile_grid == 32 && nr && a->tile_flags && a->need) {
+        bool on = need_choice == 1;
+        if (need_choice < 0) {
+            double sum = 0.0;
+            for (int k = 0; k < nr; ++k) sum += a->records_host[k].aw;
+            on = sum / nr >= 768.0;
+        }
+        if (on) {
+            if (two_streams) {                                   // the interior map is the side stream's
+                PANO_HIP(hipEventRecord(ctx->ev_join, ctx->side));
+                PANO_HIP(hipStreamWaitEvent(s, ctx->ev_join, 0));
+            }
+            if (int rc = pano_blur_tiles(ctx, a->table, nr, lay.max_aw, lay.max_ah, a->W, a->radius,
+                                         a->interior, a->tile_flags, a->need))
+                return rc;
+            a->used_need = 1;
+        }
+    }
+    const bool fork2 = two_streams && interior && n_blur && nr &&
+                       !a->used_need && tile_grid == 32 && a->tile_flags;
+    if (fork2) {            // the blur's tile flags and sorted work list beside the warp
+        if (device_table) {                                      // behind the layout kernel
+            PANO_HIP(hipEventRecord(ctx->ev_upload, s));
+        }
+        PANO_HIP(hipStreamWaitEvent(ctx->side, ctx->ev_upload, 0));      // the record table
+        ON_SIDE(ctx, pano_multiband_blur_prepare(ctx, a->table, nr, lay.max_aw, lay.max_ah, a->W,
+                                                 a->interior, a->tile_flags));
+        PANO_HIP(hipEventRecord(ctx->ev_join, ctx->side));
+    } else if (two_streams && interior) {
+        PANO_HIP(hipEventRecord(ctx->ev_join, ctx->side));               // the interior map
+    }
+    if (int rc = pano_warp_windows(ctx, a->cams, a->table, nr, lay.max_vw, lay.max_vh, a->sin_t,
+                                   a->cos_t, a->tan_p, a->lut, a->lut_stride,
+                                   a->used_need ? a->need : nullptr))
+        return rc;
+    if (two_streams && interior) PANO_HIP(hipStreamWaitEvent(s, ctx->ev_join, 0));
+    if (n_blur)
+        if (int rc = pano_multiband_blur(ctx, a->table, nr, lay.max_aw, lay.max_vh, lay.max_ah,
+                                         a->owner, a->W, a->taps, (const int *)a->ntaps, n_blur,
+                                         interior ? a->interior : nullptr,
+                                         interior ? a->tile_flags : nullptr))
+            return rc;
+    return pano_multiband_compose(ctx, a->table, nr, a->H, a->W, a->xs0, a->xs1, a->n_levels,
+                                  a->owner, a->valid, interior ? a->interior : nullptr,
+                                  interior ? a->cams : nullptr, interior ? a->sin_t : nullptr,
+                                  interior ? a->cos_t : nullptr, interior ? a->tan_p : nullptr,
+                                  a->lut, a->lut_stride, a->mosaic, a->mosaic_f32, 0);
+}
 
 extern "C" int pano_stitch_multiband(pano_ctx *ctx, pano_stitch_args *a, int resume) {
     PANO_ENTER(ctx, "pano_stitch_multiband");
@@ -42,8 +260,43 @@ extern "C" int pano_stitch_multiband(pano_ctx *ctx, pano_stitch_args *a, int res
     const bool two_streams = ctx->opt[PANO_OPT_STITCH_STREAMS] != 0 && big;
     const int tile_grid = pano_blur_tile_grid(ctx);
     const int stride = 5 + 2 * a->max_spans;
+    int sig[12];
+    stitch_signature(a, sig);
 
     if (!resume) {
+        // The layout on the device (option PANO_OPT_STITCH_ASYNC): for the default form of the
+        // stitch - interior shortcut, matrix-core blur - once a stitch of this shape has gone
+        // through and left its layout's needs behind.
+        bool spec = ctx->opt[PANO_OPT_STITCH_ASYNC] != 0 && interior && tile_grid == 32 &&
+                    ctx->lay_prev_valid && memcmp(sig, ctx->lay_prev_sig, sizeof(sig)) == 0 &&
+                    ctx->lay_prev.n_records > 0 && a->planes && a->blurred && a->tile_flags;
+        pano_layout bound = ctx->lay_prev;
+        if (spec) {
+            if (int rc = ensure_layout_buffers(ctx, a->n)) return rc;
+            // rectangles and resident flags for the layout kernel: uploaded when they changed,
+            // in front of the ownership kernel (off the critical path)
+            const size_t nrect = (size_t)a->n * 4;
+            if (ctx->lay_rects_host.size() != nrect ||
+                memcmp(ctx->lay_rects_host.data(), a->rects, nrect * sizeof(int32_t)) != 0) {
+                ctx->lay_rects_host.assign(a->rects, a->rects + nrect);
+                PANO_HIP(hipMemcpyAsync(ctx->lay_rects_dev, ctx->lay_rects_host.data(),
+                                        nrect * sizeof(int32_t), hipMemcpyHostToDevice, s));
+            }
+            std::vector<uint8_t> have(a->n, 1);
+            if (a->have) have.assign(a->have, a->have + a->n);
+            if (ctx->lay_have_host != have) {
+                ctx->lay_have_host = have;
+                PANO_HIP(hipMemcpyAsync(ctx->lay_have_dev, ctx->lay_have_host.data(), (size_t)a->n,
+                                        hipMemcpyHostToDevice, s));
+            }
+            // launch bounds: what the previous layout needed, with slack for cameras that move
+            bound.n_records = bound.n_records + 2 < a->cap_records ? bound.n_records + 2 : a->cap_records;
+            bound.max_vw += 64, bound.max_vh += 64, bound.max_aw += 64, bound.max_ah += 64;
+            if (ctx->opt[PANO_OPT_STITCH_ASYNC] == 2) {          // tests: bounds this layout exceeds
+                bound.n_records = ctx->lay_prev.n_records - 1;
+                bound.max_vw = ctx->lay_prev.max_vw - 1;
+            }
+        }
         // ownership and, in the same pass, one record per (camera, span of columns it owns):
         // boxes and column marks from the ownership kernel, the spans' search, its copy to the host
         // (in one pass on mosaics of 16 MP and more: config 5 16.12 -> 15.99 ms, config 3 even;
@@ -73,12 +326,64 @@ extern "C" int pano_stitch_multiband(pano_ctx *ctx, pano_stitch_args *a, int res
             ON_SIDE(ctx, pano_interior_map(ctx, a->owner, a->H, a->W, a->own0, a->own1, a->radius,
                                            a->block_owner, a->interior));
         }
+        bool interior_queued = forked && interior;
+        if (spec) {
+            if (ctx->upload_pending) {                           // records_host may be in use
+                PANO_HIP(hipEventSynchronize(ctx->ev_upload));
+                ctx->upload_pending = false;
+            }
+            uintptr_t bbase = (uintptr_t)a->blurred;             // as pano_layout_place aligns it
+            bbase += (uintptr_t)(-(intptr_t)bbase) % 128;
+            hipLaunchKernelGGL(layout_windows_kernel, dim3(1), dim3(LAY_THREADS), 0, s, a->regions,
+                               ctx->lay_rects_dev, ctx->lay_have_dev, a->n, a->max_spans, a->radius,
+                               a->xs0, a->xs1, n_blur, 1, a->planes, (float *)bbase, a->scratch,
+                               (long)a->planes_floats, (long)a->blurred_floats,
+                               (long)a->scratch_floats, a->cap_tiles, 1, bound.n_records,
+                               bound.max_vw, bound.max_vh, bound.max_aw, bound.max_ah, a->table,
+                               ctx->lay_sum_dev);
+            PANO_LAUNCH_CHECK("layout_windows_kernel");
+            PANO_HIP(hipMemcpyAsync(ctx->lay_sum_host, ctx->lay_sum_dev, sizeof(LayoutSummary),
+                                    hipMemcpyDeviceToHost, s));
+            PANO_HIP(hipMemcpyAsync(a->records_host, a->table,
+                                    (size_t)bound.n_records * sizeof(pano_patch),
+                                    hipMemcpyDeviceToHost, s));
+            PANO_HIP(hipEventRecord(ctx->ev_regions, s));
+            if (interior && !interior_queued) {
+                if (int rc = pano_interior_map(ctx, a->owner, a->H, a->W, a->own0, a->own1,
+                                               a->radius, a->block_owner, a->interior))
+                    return rc;
+                interior_queued = true;
+            }
+            if (int rc = queue_tail(ctx, a, bound, true, ctx->lay_prev_used_need, two_streams, interior,
+                                    n_blur, tile_grid))
+                return rc;
+            PANO_HIP(hipEventSynchronize(ctx->ev_regions));      // the GPU is in the warp by now
+            const LayoutSummary sum = *ctx->lay_sum_host;
+            a->layout.planes_floats = sum.planes_floats;
+            a->layout.blurred_floats = sum.blurred_floats;
+            a->layout.scratch_floats = sum.scratch_floats;
+            a->layout.n_records = sum.n_records, a->layout.n_tiles = sum.n_tiles;
+            a->layout.max_vw = sum.max_vw, a->layout.max_vh = sum.max_vh;
+            a->layout.max_aw = sum.max_aw, a->layout.max_ah = sum.max_ah;
+            a->layout.missing = sum.missing;
+            if (sum.ok) {
+                ctx->lay_prev = a->layout;
+                ctx->lay_prev_used_need = a->used_need;
+                ++ctx->lay_count[0];
+                return PANO_OK;
+            }
+            ++ctx->lay_count[1];
+            // this layout needs more than the launches covered (or an arena is too small): the
+            // table was emptied, the queued tail did nothing; lay it out on the host and queue
+            // the tail again
+            ctx->lay_prev_valid = false;
+        }
         PANO_HIP(hipMemcpyAsync(a->regions_host, a->regions, (size_t)a->n * stride * sizeof(int32_t),
                                 hipMemcpyDeviceToHost, s));
         PANO_HIP(hipEventRecord(ctx->ev_regions, s));
         // the interior map needs the owner map only: queued before the wait, it keeps the GPU
         // busy while the host lays out the windows
-        if (interior && !forked)
+        if (interior && !interior_queued)
             if (int rc = pano_interior_map(ctx, a->owner, a->H, a->W, a->own0, a->own1, a->radius,
                                            a->block_owner, a->interior))
                 return rc;
@@ -98,67 +403,20 @@ extern "C" int pano_stitch_multiband(pano_ctx *ctx, pano_stitch_args *a, int res
             return PANO_EINVAL;
         }
     }
-    const pano_layout &lay = a->layout;
-    const bool use_blur = n_blur > 0 && lay.n_records > 0;
-    if (lay.planes_floats > a->planes_floats || (use_blur && lay.blurred_floats > a->blurred_floats) ||
-        (use_blur && lay.scratch_floats > a->scratch_floats) ||
-        (interior && lay.n_tiles > a->cap_tiles))
-        return PANO_EGROW;
-    PANO_REQUIRE(lay.planes_floats == 0 || a->planes, "pano_stitch_multiband: no plane arena");
-    if (int rc = pano_layout_place(a->records_host, lay.n_records, a->planes, a->blurred, a->scratch))
-        return rc;
-    const int nr = lay.n_records;
-    if (nr) {
-        PANO_HIP(hipMemcpyAsync(a->table, a->records_host, (size_t)nr * sizeof(pano_patch),
-                                hipMemcpyHostToDevice, s));
-        PANO_HIP(hipEventRecord(ctx->ev_upload, s));
-        ctx->upload_pending = true;
+    const int rc = queue_tail(ctx, a, a->layout, false, a->warp_need, two_streams, interior, n_blur,
+                              tile_grid);
+    if (rc == PANO_OK) {                     // what this layout needed: the next stitch's bounds
+        ctx->lay_prev = a->layout;
+        memcpy(ctx->lay_prev_sig, sig, sizeof(sig));
+        ctx->lay_prev_used_need = a->used_need;
+        ctx->lay_prev_valid = true;
     }
-    // Warp only what is read: worth it when the rectangles are wide against the blur's reach
-    // (8 x 1080p: -4 %; on 32 x 4K nearly every tile is within reach)
-    a->used_need = 0;
-    if (interior && tile_grid == 32 && nr && a->tile_flags && a->need) {
-        bool on = a->warp_need == 1;
-        if (a->warp_need < 0) {
-            double sum = 0.0;
-            for (int k = 0; k < nr; ++k) sum += a->records_host[k].aw;
-            on = sum / nr >= 768.0;
-        }
-        if (on) {
-            if (two_streams) {                                   // the interior map is the side stream's
-                PANO_HIP(hipEventRecord(ctx->ev_join, ctx->side));
-                PANO_HIP(hipStreamWaitEvent(s, ctx->ev_join, 0));
-            }
-            if (int rc = pano_blur_tiles(ctx, a->table, nr, lay.max_aw, lay.max_ah, a->W, a->radius,
-                                         a->interior, a->tile_flags, a->need))
-                return rc;
-            a->used_need = 1;
-        }
-    }
-    const bool fork2 = two_streams && interior && n_blur && nr &&
-                       !a->used_need && tile_grid == 32 && a->tile_flags;
-    if (fork2) {            // the blur's tile flags and sorted work list beside the warp
-        PANO_HIP(hipStreamWaitEvent(ctx->side, ctx->ev_upload, 0));      // the record table
-        ON_SIDE(ctx, pano_multiband_blur_prepare(ctx, a->table, nr, lay.max_aw, lay.max_ah, a->W,
-                                                 a->interior, a->tile_flags));
-        PANO_HIP(hipEventRecord(ctx->ev_join, ctx->side));
-    } else if (two_streams && interior) {
-        PANO_HIP(hipEventRecord(ctx->ev_join, ctx->side));               // the interior map
-    }
-    if (int rc = pano_warp_windows(ctx, a->cams, a->table, nr, lay.max_vw, lay.max_vh, a->sin_t,
-                                   a->cos_t, a->tan_p, a->lut, a->lut_stride,
-                                   a->used_need ? a->need : nullptr))
-        return rc;
-    if (two_streams && interior) PANO_HIP(hipStreamWaitEvent(s, ctx->ev_join, 0));
-    if (n_blur)
-        if (int rc = pano_multiband_blur(ctx, a->table, nr, lay.max_aw, lay.max_vh, lay.max_ah,
-                                         a->owner, a->W, a->taps, (const int *)a->ntaps, n_blur,
-                                         interior ? a->interior : nullptr,
-                                         interior ? a->tile_flags : nullptr))
-            return rc;
-    return pano_multiband_compose(ctx, a->table, nr, a->H, a->W, a->xs0, a->xs1, a->n_levels,
-                                  a->owner, a->valid, interior ? a->interior : nullptr,
-                                  interior ? a->cams : nullptr, interior ? a->sin_t : nullptr,
-                                  interior ? a->cos_t : nullptr, interior ? a->tan_p : nullptr,
-                                  a->lut, a->lut_stride, a->mosaic, a->mosaic_f32, 0);
+    return rc;
+}
+
+extern "C" int pano_stitch_counts(const pano_ctx *ctx, int *device_layouts, int *fallbacks) {
+    PANO_REQUIRE(ctx && device_layouts && fallbacks, "pano_stitch_counts: null pointer");
+    *device_layouts = ctx->lay_count[0];
+    *fallbacks = ctx->lay_count[1];
+    return PANO_OK;
 }

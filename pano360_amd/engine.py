@@ -717,6 +717,14 @@ class Engine:
         if option == _lib.OPT_BLUR_KERNEL:
             self.tile_grid = int(self.lib.pano_blur_tile_grid(self._ctx))
 
+    def stitch_counts(self):
+        """(stitches that went through on the device-side layout, attempts that fell back to
+        the host layout) of this engine's context."""
+        ok, back = C.c_int(0), C.c_int(0)
+        _lib.check(self.lib.pano_stitch_counts(self._ctx, C.byref(ok), C.byref(back)),
+                   "pano_stitch_counts")
+        return ok.value, back.value
+
     def timing(self, on):
         _lib.check(self.lib.pano_timing_enable(self._ctx, 1 if on else 0), "pano_timing_enable")
 

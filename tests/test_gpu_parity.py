@@ -339,6 +339,61 @@ def test_ownership_bounds_against_exhaustive_evaluation(eng, seed):
     assert (owner_all >= 0).any() and (owner_all < 0).any()
 
 
+@pytest.mark.parametrize("scene", ["cfg2_like", "closed_sweep", "strips"])
+def test_stitch_with_the_layout_on_the_device_equals_the_host_layout(eng, scene):
+    """pano_stitch_multiband lays the record table out with a kernel and queues the warp, blur
+    and collapse behind it at once, sized by the previous stitch's layout (option
+    PANO_OPT_STITCH_ASYNC); the host checks the layout's summary afterwards.  Same mosaic,
+    valid mask and records as with the host layout: on repeated stitches (the device layout is
+    used from the second on), with cameras that move a little between stitches (inside the
+    bounds' slack), with bounds the layout exceeds (option value 2: the tail is queued again
+    from the host layout) and on column strips."""
+    import torch
+    from pano360_amd import _lib, engine, synth
+    if scene == "closed_sweep":
+        n, w, h, kw = 24, 160, 96, dict(step_deg=15.0)
+    else:
+        n, w, h, kw = 8, 480, 270, dict(sweep_deg=140.0)
+    imgs = [synth.make_frame(i, w, h, "A") for i in range(n)]
+    frames = eng.upload_frames(imgs)
+
+    def run(rots, intrs, mode, strip=None):
+        eng.set_option(_lib.OPT_STITCH_ASYNC, mode)
+        try:
+            plan = eng.upload_plan(engine.Plan([(h, w)] * n, rots, intrs, True, 10 ** 9))
+            mosaic, _, valid, patches = eng.multiband_fused(frames, plan, 5, strip=strip)
+            torch.cuda.synchronize()
+            return mosaic.clone(), valid.clone(), patches.table.host.copy()
+        finally:
+            eng.set_option(_lib.OPT_STITCH_ASYNC, 1)
+
+    rots, intrs = synth.make_cameras(n, w, h, jitter=0.004, seed=1, **kw)
+    W = engine.Plan([(h, w)] * n, rots, intrs, True, 10 ** 9).shape[1]
+    strip = (W // 4 + 3, W // 2 + 1) if scene == "strips" else None
+    want = run(rots, intrs, 0, strip)
+    before = eng.stitch_counts()
+    keys = ("index", "vy0", "vx0", "vh", "vw", "ay0", "ax0", "ah", "aw", "vpitch", "apitch", "tiles_off")
+    for mode in (1, 1, 1, 2, 1):
+        got = run(rots, intrs, mode, strip)
+        c0, c1 = strip if strip else (0, W)
+        assert torch.equal(got[0][:, c0:c1], want[0][:, c0:c1]), mode
+        assert torch.equal(got[1][:, c0:c1], want[1][:, c0:c1]), mode
+        assert len(got[2]) == len(want[2])
+        for key in keys:
+            assert np.array_equal(got[2][key], want[2][key]), (mode, key)
+    after = eng.stitch_counts()
+    assert after[0] - before[0] == 4 and after[1] - before[1] == 1, (before, after)
+    if scene == "cfg2_like":
+        # cameras that move a little: the same mosaic shape is not guaranteed, so only stitches
+        # that keep it run through the device layout; every result is checked against mode 0
+        rng = np.random.default_rng(0)
+        for step in range(4):
+            r2 = rots.copy()
+            r2[rng.integers(n)] = synth.make_cameras(n, w, h, jitter=0.004, seed=10 + step, **kw)[0][0]
+            a, b = run(r2, intrs, 1, strip), run(r2, intrs, 0, strip)
+            assert a[0].shape == b[0].shape and torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+
+
 @pytest.mark.parametrize("case", ["sweep", "tilted", "dense", "crowd", "strip"])
 def test_ownership_with_regions_equals_the_two_calls(eng, case):
     """pano_ownership_regions (boxes and column marks out of the ownership kernel) against
