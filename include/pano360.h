@@ -170,17 +170,18 @@ int pano_interior_block(void);
  *                         the region search, and the blur's tile flags and work list beside
  *                         the warp, on a second stream the context owns (ordered by events);
  *                         0 = everything on the context's stream.  Same results.
- *   PANO_OPT_STITCH_ASYNC  pano_stitch_multiband: 1 (default) = when the previous stitch of
- *                         the same shape went through, the record table is laid out by a
- *                         kernel and the warp, blur and collapse are queued behind it at
- *                         once, sized by what the previous layout needed (plus slack); the
- *                         host then waits for the layout's summary while the GPU works, and
- *                         only if this layout needed more (or an arena is too small) the
- *                         stitch is laid out again on the host and its tail queued a second
- *                         time.  0 = always the host layout (the GPU idles ~0.1 ms per
- *                         stitch while the regions travel to the host and the table back).
- *                         Same results.  (2 = as 1 with launch bounds the layout is sure to
- *                         exceed: the tests' way into the fallback.) */
+ *   PANO_OPT_STITCH_ASYNC  pano_stitch_multiband: 1 = when the previous stitch of the same
+ *                         shape went through, the record table is laid out by a kernel and
+ *                         the warp, blur and collapse are queued behind it at once, sized by
+ *                         what the previous layout needed (plus slack); the host then waits
+ *                         for the layout's summary while the GPU works, and only if this
+ *                         layout needed more (or an arena is too small) the stitch is laid
+ *                         out again on the host and its tail queued a second time.
+ *                         0 (default) = always the host layout: measured, the round trip it
+ *                         saves is already covered by the side stream's kernels (DESIGN.md
+ *                         section 4.14), so the simpler path is the default.  Same results.
+ *                         (2 = as 1 with launch bounds the layout is sure to exceed: the
+ *                         tests' way into the fallback.) */
 typedef struct pano_ctx pano_ctx;
 #define PANO_OPT_BLUR_KERNEL 0
 #define PANO_OPT_OWN_PRUNE 1

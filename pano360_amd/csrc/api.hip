@@ -53,7 +53,7 @@ extern "C" int pano_ctx_create(int device, void *stream, pano_ctx **out) {
     ctx->opt[PANO_OPT_BLUR_SEGMENTS] = 1;
     ctx->opt[PANO_OPT_BLUR_LEAN] = 1;
     ctx->opt[PANO_OPT_STITCH_STREAMS] = 1;
-    ctx->opt[PANO_OPT_STITCH_ASYNC] = 1;
+    ctx->opt[PANO_OPT_STITCH_ASYNC] = 0;
     *out = ctx;
     return PANO_OK;
 }
@@ -96,7 +96,6 @@ extern "C" int pano_ctx_destroy(pano_ctx *ctx) {
     if (ctx->item_buf) (void)hipFree(ctx->item_buf);
     if (ctx->item_counter) (void)hipFree(ctx->item_counter);
     if (ctx->sift_raw) (void)hipFree(ctx->sift_raw);
-    if (ctx->lay_sum_dev) (void)hipFree(ctx->lay_sum_dev);
     if (ctx->lay_sum_host) (void)hipHostFree(ctx->lay_sum_host);
     if (ctx->lay_rects_dev) (void)hipFree(ctx->lay_rects_dev);
     if (ctx->lay_have_dev) (void)hipFree(ctx->lay_have_dev);
@@ -108,6 +107,7 @@ extern "C" int pano_ctx_destroy(pano_ctx *ctx) {
     if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
     if (ctx->ev_regions) (void)hipEventDestroy(ctx->ev_regions);
     if (ctx->ev_upload) (void)hipEventDestroy(ctx->ev_upload);
+    if (ctx->ev_copy) (void)hipEventDestroy(ctx->ev_copy);
     delete ctx;
     return PANO_OK;
 }
@@ -119,6 +119,7 @@ int pano_ctx_side_stream(pano_ctx *ctx) {
     if (!ctx->ev_upload) PANO_HIP(hipEventCreateWithFlags(&ctx->ev_upload, hipEventDisableTiming));
     if (!ctx->ev_fork) PANO_HIP(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
     if (!ctx->ev_join) PANO_HIP(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
+    if (!ctx->ev_copy) PANO_HIP(hipEventCreateWithFlags(&ctx->ev_copy, hipEventDisableTiming));
     if (!ctx->side) PANO_HIP(hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
     return PANO_OK;
 }

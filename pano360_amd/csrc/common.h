@@ -103,14 +103,14 @@ struct pano_ctx {
     uint64_t tick;
     // pano_stitch_multiband: the regions' copy has landed / the record table has left the
     // caller's pinned buffer
-    hipEvent_t ev_regions, ev_upload, ev_fork, ev_join;
+    hipEvent_t ev_regions, ev_upload, ev_fork, ev_join, ev_copy;
     hipStream_t side;               // second stream of pano_stitch_multiband
     bool upload_pending;
     // pano_stitch_multiband without its host round trip (stitch.hip): the device-side layout's
     // summary (device / pinned host), device copies of the patch rectangles and resident flags
     // (and the host values they were made from), and what the previous stitch's layout needed:
     // the next one's launch bounds
-    LayoutSummary *lay_sum_dev, *lay_sum_host;
+    LayoutSummary *lay_sum_host;    // pinned: the layout kernel writes it, the host reads it
     int32_t *lay_rects_dev;
     uint8_t *lay_have_dev;
     int lay_cap_n;

@@ -409,23 +409,15 @@ __global__ __launch_bounds__(64 * SIFT_WAVES) void sift_orient_kernel(
             const int y = k.r + i, x = k.c + j;
             if (y <= 0 || y >= rows - 1 || x <= 0 || x >= cols - 1) continue;
             const uint32_t o = (uint32_t)y * (uint32_t)cols + (uint32_t)x;   // a layer is below 2^31 pixels
-#ifdef SIFT_ABL_NOLOAD
-            const float dx = (float)(o & 7) - 3.5f, dy = (float)((o >> 3) & 7) - 3.3f;
-#else
             const float dx = img[o + 1] - img[o - 1];
             const float dy = img[o - (uint32_t)cols] - img[o + (uint32_t)cols];
-#endif
             const float w = exp_sample((float)(i * i + j * j) * expf_scale);
             const float ori = fast_atan2_sample(dy, dx), mag = sqrt_sample(dx * dx + dy * dy);
             int bin = (int)rintf((SIFT_ORI_BINS / 360.0f) * ori);
             if (bin >= SIFT_ORI_BINS) bin -= SIFT_ORI_BINS;
             if (bin < 0) bin += SIFT_ORI_BINS;
             const unsigned vote = (unsigned)fmaxf(__builtin_fmaf(w * mag, SIFT_ORI_VOTE_SCALE, 0.5f), 0.0f);
-#ifdef SIFT_ABL_NOVOTE
-            if (vote == 0x7fffffffu) votes[bin] = vote;
-#else
             atomicAdd(&votes[bin], (unsigned long long)vote);
-#endif
         }
         wave_sync();
         if (lane < SIFT_ORI_BINS + 4) {                  // circular padding of two bins either side
@@ -549,12 +541,8 @@ __global__ __launch_bounds__(64 * SIFT_WAVES) void sift_describe_kernel(
                   c > 0 && c < cols - 1))
                 continue;
             const uint32_t at = (uint32_t)r * (uint32_t)cols + (uint32_t)c;   // a layer is below 2^31 pixels
-#ifdef SIFT_ABL_NOLOAD
-            const float dx = (float)(at & 7) - 3.5f, dy = (float)((at >> 3) & 7) - 3.3f;
-#else
             const float dx = img[at + 1] - img[at - 1];
             const float dy = img[at - (uint32_t)cols] - img[at + (uint32_t)cols];
-#endif
             const float w = exp_sample((c_rot * c_rot + r_rot * r_rot) * exp_scale);
             float obin = (fast_atan2_sample(dy, dx) - ori) * bins_per_rad;
             // the magnitude in the histogram's fixed-point unit from here on: the eight votes
@@ -580,11 +568,7 @@ __global__ __launch_bounds__(64 * SIFT_WAVES) void sift_describe_kernel(
             auto vote = [&](const int which, const float lo, const float hi) {
                 const unsigned long long a = (unsigned)fmaxf(lo + 0.5f, 0.0f);
                 const unsigned long long b = (unsigned)fmaxf(hi + 0.5f, 0.0f);
-#ifdef SIFT_ABL_NOVOTE
-                if ((a | b << 32) == 0x7fffffffffull) hist[which * PAIRS + pair] = a;
-#else
                 atomicAdd(&mine[which * PAIRS + pair], a | b << 32);
-#endif
             };
             vote(cell, v000, v001);
             vote(cell + 1, v010, v011);

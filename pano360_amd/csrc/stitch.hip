@@ -61,25 +61,48 @@ __global__ __launch_bounds__(LAY_THREADS) void layout_windows_kernel(
             if (!layout_record_fits(rec)) atomicOr(&s_bad, 8);
         }
         __syncthreads();
-        if (tid == 0) {                             // the chunk's offsets, in candidate order
+        if (tid < 64) {
+            // the chunk's offsets, in candidate order: wave 0 scans the slots 64 at a time
+            // (a single thread walking them made this kernel 30 us long)
             long pl = s_run[0], bl = s_run[1], sc = s_run[2], tl = s_run[3];
             int k = s_count;
-            for (int t = 0; t < LAY_THREADS; ++t) {
-                if (!s_slot[t]) {
-                    s_slot[t] = -1;
-                    continue;
+            const int cnt = min(LAY_THREADS, total - base);
+            for (int t0 = 0; t0 < cnt; t0 += 64) {
+                const int t = t0 + tid;
+                const int has = s_slot[t];
+                long v[4] = {has ? s_planes[t] : 0, has ? s_blurred[t] : 0, has ? s_scratch[t] : 0,
+                             has ? (long)s_tiles[t] : 0};
+                int one = has;
+                const long own[4] = {v[0], v[1], v[2], v[3]};
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) {
+                    const int o1 = __shfl_up(one, off, 64);
+                    long o[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) o[q] = __shfl_up(v[q], off, 64);
+                    if (tid >= off) {
+                        one += o1;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) v[q] += o[q];
+                    }
                 }
-                const long dp = s_planes[t], db = s_blurred[t], ds = s_scratch[t];
-                const int dt = s_tiles[t];
-                s_slot[t] = k++;
-                s_planes[t] = pl;
-                s_blurred[t] = bl;
-                s_scratch[t] = sc;
-                s_tiles[t] = (int)(tl < (1l << 30) ? tl : (1l << 30));
-                pl += dp, bl += db, sc += ds, tl += dt;
+                s_slot[t] = has ? k + one - 1 : -1;
+                s_planes[t] = pl + v[0] - own[0];
+                s_blurred[t] = bl + v[1] - own[1];
+                s_scratch[t] = sc + v[2] - own[2];
+                const long toff = tl + v[3] - own[3];
+                s_tiles[t] = (int)(toff < (1l << 30) ? toff : (1l << 30));
+                k += __shfl(one, 63, 64);
+                pl += __shfl(v[0], 63, 64);
+                bl += __shfl(v[1], 63, 64);
+                sc += __shfl(v[2], 63, 64);
+                tl += __shfl(v[3], 63, 64);
             }
-            s_run[0] = pl, s_run[1] = bl, s_run[2] = sc, s_run[3] = tl;
-            s_count = k;
+            for (int t = cnt + tid; t < LAY_THREADS; t += 64) s_slot[t] = -1;
+            if (tid == 0) {
+                s_run[0] = pl, s_run[1] = bl, s_run[2] = sc, s_run[3] = tl;
+                s_count = k;
+            }
         }
         __syncthreads();
         const int k = s_slot[tid];
@@ -121,7 +144,6 @@ __global__ __launch_bounds__(LAY_THREADS) void layout_windows_kernel(
 }
 
 static int ensure_layout_buffers(pano_ctx *ctx, int n) {
-    if (!ctx->lay_sum_dev) PANO_HIP(hipMalloc((void **)&ctx->lay_sum_dev, sizeof(LayoutSummary)));
     if (!ctx->lay_sum_host)
         PANO_HIP(hipHostMalloc((void **)&ctx->lay_sum_host, sizeof(LayoutSummary), hipHostMallocDefault));
     if (n > ctx->lay_cap_n) {
@@ -340,14 +362,16 @@ extern "C" int pano_stitch_multiband(pano_ctx *ctx, pano_stitch_args *a, int res
                                (long)a->planes_floats, (long)a->blurred_floats,
                                (long)a->scratch_floats, a->cap_tiles, 1, bound.n_records,
                                bound.max_vw, bound.max_vh, bound.max_aw, bound.max_ah, a->table,
-                               ctx->lay_sum_dev);
+                               ctx->lay_sum_host);
             PANO_LAUNCH_CHECK("layout_windows_kernel");
-            PANO_HIP(hipMemcpyAsync(ctx->lay_sum_host, ctx->lay_sum_dev, sizeof(LayoutSummary),
-                                    hipMemcpyDeviceToHost, s));
+            // the summary goes straight into pinned host memory; the caller's copy of the records
+            // leaves through the side stream: nothing stands between this kernel and the warp
+            PANO_HIP(hipEventRecord(ctx->ev_regions, s));
+            PANO_HIP(hipStreamWaitEvent(ctx->side, ctx->ev_regions, 0));
             PANO_HIP(hipMemcpyAsync(a->records_host, a->table,
                                     (size_t)bound.n_records * sizeof(pano_patch),
-                                    hipMemcpyDeviceToHost, s));
-            PANO_HIP(hipEventRecord(ctx->ev_regions, s));
+                                    hipMemcpyDeviceToHost, ctx->side));
+            PANO_HIP(hipEventRecord(ctx->ev_copy, ctx->side));
             if (interior && !interior_queued) {
                 if (int rc = pano_interior_map(ctx, a->owner, a->H, a->W, a->own0, a->own1,
                                                a->radius, a->block_owner, a->interior))
@@ -358,6 +382,7 @@ extern "C" int pano_stitch_multiband(pano_ctx *ctx, pano_stitch_args *a, int res
                                     n_blur, tile_grid))
                 return rc;
             PANO_HIP(hipEventSynchronize(ctx->ev_regions));      // the GPU is in the warp by now
+            PANO_HIP(hipEventSynchronize(ctx->ev_copy));
             const LayoutSummary sum = *ctx->lay_sum_host;
             a->layout.planes_floats = sum.planes_floats;
             a->layout.blurred_floats = sum.blurred_floats;

@@ -688,6 +688,8 @@ class Engine:
         self.native_stitch = side_stream == 0 and os.environ.get("PANO_NATIVE_STITCH", "1") != "0"
         if os.environ.get("PANO_STITCH_STREAMS", "1") == "0":       # (A/B timing)
             self.set_option(_lib.OPT_STITCH_STREAMS, 0)
+        if os.environ.get("PANO_STITCH_ASYNC", "0") == "1":         # (A/B timing)
+            self.set_option(_lib.OPT_STITCH_ASYNC, 1)
         self._stitch_ws = {}
         self._plans = {}
 

@@ -365,7 +365,7 @@ def test_stitch_with_the_layout_on_the_device_equals_the_host_layout(eng, scene)
             torch.cuda.synchronize()
             return mosaic.clone(), valid.clone(), patches.table.host.copy()
         finally:
-            eng.set_option(_lib.OPT_STITCH_ASYNC, 1)
+            eng.set_option(_lib.OPT_STITCH_ASYNC, 0)
 
     rots, intrs = synth.make_cameras(n, w, h, jitter=0.004, seed=1, **kw)
     W = engine.Plan([(h, w)] * n, rots, intrs, True, 10 ** 9).shape[1]

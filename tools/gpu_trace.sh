@@ -2,7 +2,7 @@
 # kernel timeline of one cfg3 stitch (rocprofv3 --kernel-trace)
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 HERE=$PWD; OUT=$HERE/gpurun_out/${1:-trace}; mkdir -p "$OUT"; export TMPDIR=/tmp; cd /tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof" -- python3 "$HERE/bench.py" --steps 5 --warmup 2 --no-cpu-baseline --no-secondary > "$OUT/rocprof.log" 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof" -- python3 "$HERE/bench.py" --workload ${2:-cfg3} --steps 5 --warmup 2 --no-cpu-baseline --no-secondary > "$OUT/rocprof.log" 2>&1
 cd "$HERE"
 python3 - "$OUT" <<'P'
 import csv, glob, sys
