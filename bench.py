@@ -46,8 +46,8 @@ NATIVE = 10 ** 9                # MAX_RESOLUTION that never caps
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="cfg3",
                     choices=["cfg2", "cfg3", "cfg5", "cfg4", "tiny"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
