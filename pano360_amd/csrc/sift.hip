@@ -400,10 +400,13 @@ __global__ __launch_bounds__(64 * SIFT_WAVES) void sift_orient_kernel(
         // t / side without an integer divide per sample: exact for t < 2^22 (side < 2048)
         const float inv_side = __fdiv_rn(1.0f, (float)side);
         const bool small = side < 2048;
-        for (int t = lane; t < side * side; t += 64) {
-            int row = small ? (int)(((float)t + 0.5f) * inv_side) : t / side;
-            int col = t - row * side;
-            if (col < 0) { --row; col += side; }
+        // a lane's samples are 64 apart in row-major order: (row, col) advance by 64 = q side + rem
+        int row = lane / side, col = lane - row * side;
+        const int q64 = 64 / side, rem64 = 64 - q64 * side;
+        (void)inv_side;
+        (void)small;
+        for (int t = lane; t < side * side; t += 64, row += q64, col += rem64) {
+#pragma clang fp contract(fast)              // the window samples' arithmetic may fuse (tolerance-tested)
             if (col >= side) { ++row; col -= side; }
             const int i = row - radius, j = col - radius;
             const int y = k.r + i, x = k.c + j;
@@ -489,7 +492,7 @@ __global__ __launch_bounds__(64 * SIFT_WAVES) void sift_describe_kernel(
     // samples of a step are neighbours in the window and mostly vote into the same two or three
     // cells - same-address atomics, which the LDS serialises
 #ifndef SIFT_HCOPIES
-#define SIFT_HCOPIES 2
+#define SIFT_HCOPIES 1                   // (2 or 4 copies against same-address atomics: no faster)
 #endif
     constexpr int HSIZE = CELLS * PAIRS;
     __shared__ unsigned long long s_hist[SIFT_WAVES][SIFT_HCOPIES * HSIZE];
@@ -528,10 +531,13 @@ __global__ __launch_bounds__(64 * SIFT_WAVES) void sift_describe_kernel(
         // t / side without an integer divide per sample: exact for t < 2^22 (side < 2048)
         const float inv_side = __fdiv_rn(1.0f, (float)side);
         const bool small = side < 2048;
-        for (int t = lane; t < side * side; t += 64) {
-            int row = small ? (int)(((float)t + 0.5f) * inv_side) : t / side;
-            int col = t - row * side;
-            if (col < 0) { --row; col += side; }
+        // a lane's samples are 64 apart in row-major order: (row, col) advance by 64 = q side + rem
+        int row = lane / side, col = lane - row * side;
+        const int q64 = 64 / side, rem64 = 64 - q64 * side;
+        (void)inv_side;
+        (void)small;
+        for (int t = lane; t < side * side; t += 64, row += q64, col += rem64) {
+#pragma clang fp contract(fast)              // the window samples' arithmetic may fuse (tolerance-tested)
             if (col >= side) { ++row; col -= side; }
             const int i = row - radius, j = col - radius;
             const float c_rot = j * cos_t - i * sin_t, r_rot = j * sin_t + i * cos_t;
