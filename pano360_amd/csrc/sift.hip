@@ -57,6 +57,7 @@ __device__ __forceinline__ float fast_atan2(float y, float x) {
 // is good to 0.3 degrees, and a sample's votes are continuous in its angle), instead of one
 // correctly rounded division per branch: 25 vector instructions fewer per sample.
 __device__ __forceinline__ float fast_atan2_sample(float y, float x) {
+#pragma clang fp contract(fast)
     const float p1 = (float)(0.9997878412794807 * 57.29577951308232);
     const float p3 = (float)(-0.3258083974640975 * 57.29577951308232);
     const float p5 = (float)(0.1555786518463281 * 57.29577951308232);
@@ -81,6 +82,11 @@ __device__ __forceinline__ float sqrt_sample(float x) { return __builtin_amdgcn_
 
 // The four neighbours of octave pixel (y, x), read at 32-bit offsets from the layer's base.
 typedef const __attribute__((address_space(1))) float *layer_ptr;
+// pixel at BYTE offset `off` of a layer (a layer is below 2^32 bytes; a 32-bit byte offset from a
+// scalar base is one address operand, a 64-bit index is an add with carry per load)
+__device__ __forceinline__ float layer_at(layer_ptr img, uint32_t off) {
+    return *(layer_ptr)((const __attribute__((address_space(1))) char *)img + off);
+}
 
 // The orientation and descriptor kernels give every WAVE its own keypoint and its own LDS
 // arrays; waves of a workgroup never talk to each other, so nothing needs s_barrier - a wave's
@@ -388,7 +394,8 @@ __global__ __launch_bounds__(64 * SIFT_WAVES) void sift_orient_kernel(
     };
     for (int idx = blockIdx.x * SIFT_WAVES + wv; idx < total; idx += gridDim.x * SIFT_WAVES) {
         const pano_sift_keypoint k = cands[idx];
-        const int octv = k.octave & 255, layer = (k.octave >> 8) & 255;
+        const int packed = __builtin_amdgcn_readfirstlane(k.octave);     // the wave's keypoint: scalars
+        const int octv = packed & 255, layer = (packed >> 8) & 255;
         const int rows = dims[2 * octv], cols = dims[2 * octv + 1];
         const layer_ptr img = (layer_ptr)(gauss[octv] + (size_t)layer * rows * cols);
         const float scl = __fdiv_rn(k.size * 0.5f, (float)(1 << octv));
@@ -411,9 +418,9 @@ __global__ __launch_bounds__(64 * SIFT_WAVES) void sift_orient_kernel(
             const int i = row - radius, j = col - radius;
             const int y = k.r + i, x = k.c + j;
             if (y <= 0 || y >= rows - 1 || x <= 0 || x >= cols - 1) continue;
-            const uint32_t o = (uint32_t)y * (uint32_t)cols + (uint32_t)x;   // a layer is below 2^31 pixels
-            const float dx = img[o + 1] - img[o - 1];
-            const float dy = img[o - (uint32_t)cols] - img[o + (uint32_t)cols];
+            const uint32_t o = ((uint32_t)y * (uint32_t)cols + (uint32_t)x) << 2, pitch = (uint32_t)cols << 2;
+            const float dx = layer_at(img, o + 4u) - layer_at(img, o - 4u);
+            const float dy = layer_at(img, o - pitch) - layer_at(img, o + pitch);
             const float w = exp_sample((float)(i * i + j * j) * expf_scale);
             const float ori = fast_atan2_sample(dy, dx), mag = sqrt_sample(dx * dx + dy * dy);
             int bin = (int)rintf((SIFT_ORI_BINS / 360.0f) * ori);
@@ -502,8 +509,11 @@ __global__ __launch_bounds__(64 * SIFT_WAVES) void sift_describe_kernel(
     const int n = n_dev ? min(*n_dev, n_cap) : n_cap;   // the count may still be on the device
     for (int idx = blockIdx.x * SIFT_WAVES + wv; idx < n; idx += gridDim.x * SIFT_WAVES) {
         const pano_sift_keypoint k = kpts[idx];
-        int octave = k.octave & 255;
-        const int layer = (k.octave >> 8) & 255;
+        // (the keypoint is the wave's: its octave, layer and with them the layer's base address
+        // and size are scalars - the compiler cannot see that through threadIdx)
+        const int packed = __builtin_amdgcn_readfirstlane(k.octave);
+        int octave = packed & 255;
+        const int layer = (packed >> 8) & 255;
         octave = octave < 128 ? octave : (-128 | octave);
         const float scale = octave >= 0 ? __fdiv_rn(1.0f, (float)(1 << octave)) : (float)(1 << -octave);
         const int o = octave - first_octave;
@@ -546,9 +556,9 @@ __global__ __launch_bounds__(64 * SIFT_WAVES) void sift_describe_kernel(
             if (!(rbin > -1.0f && rbin < d && cbin > -1.0f && cbin < d && r > 0 && r < rows - 1 &&
                   c > 0 && c < cols - 1))
                 continue;
-            const uint32_t at = (uint32_t)r * (uint32_t)cols + (uint32_t)c;   // a layer is below 2^31 pixels
-            const float dx = img[at + 1] - img[at - 1];
-            const float dy = img[at - (uint32_t)cols] - img[at + (uint32_t)cols];
+            const uint32_t at = ((uint32_t)r * (uint32_t)cols + (uint32_t)c) << 2, pitch = (uint32_t)cols << 2;
+            const float dx = layer_at(img, at + 4u) - layer_at(img, at - 4u);
+            const float dy = layer_at(img, at - pitch) - layer_at(img, at + pitch);
             const float w = exp_sample((c_rot * c_rot + r_rot * r_rot) * exp_scale);
             float obin = (fast_atan2_sample(dy, dx) - ori) * bins_per_rad;
             // the magnitude in the histogram's fixed-point unit from here on: the eight votes
