@@ -622,6 +622,20 @@ __global__ __launch_bounds__(256) void block_owner_kernel(const int16_t *__restr
     if (x0 >= xs0 && (x0 + IB < W ? x0 + IB : W) <= xs1) {
         o = owner[(size_t)y0 * W + x0];
         const bool whole = x0 + IB <= W && (W & 1) == 0;      // rows 4-byte aligned, IB in range
+        if (x0 + IB <= W && y0 + IB <= H) {
+            // all rows' owners at once, IB = 4 of them per 8-byte load at any (2-byte) alignment:
+            // a loop that stops at the first mixed row is a chain of dependent loads, and with an
+            // odd mosaic width (config 5: 46 079) it went pixel by pixel - 0.41 ms for 228 MP
+            static_assert(IB == 4, "one 8-byte load per block row");
+            typedef uint64_t u64_any __attribute__((aligned(2)));
+            const uint64_t o16 = (uint16_t)o;
+            const uint64_t all = o16 | o16 << 16 | o16 << 32 | o16 << 48;
+            uint64_t diff = 0;
+#pragma unroll
+            for (int dy = 0; dy < IB; ++dy)
+                diff |= *(const u64_any *)(owner + (size_t)(y0 + dy) * W + x0) ^ all;
+            if (diff) o = -2;
+        } else
         for (int dy = 0; dy < IB && o != -2; ++dy) {
             const int y = y0 + dy;
             if (y >= H) break;
@@ -661,32 +675,37 @@ __global__ __launch_bounds__(256) void interior_tile_kernel(const int16_t *__res
                                                             uint8_t *__restrict__ interior) {
     __shared__ int16_t s_own[(IT_H + 2 * IT_REACH_MAX) * (IT_W + 2 * IT_REACH_MAX)];
     __shared__ int16_t s_col[IT_H * (IT_W + 2 * IT_REACH_MAX)];
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int bx0 = blockIdx.x * IT_W, by0 = blockIdx.y * IT_H;
     const int tw = IT_W + 2 * reach, th = IT_H + 2 * reach;
+    // (rows by wave, columns by lane: an index i = ty * tw + tx split by division cost twenty
+    // instructions per element, more than the loads it addressed)
     // -3 marks a position beyond the mosaic
-    for (int i = tid; i < tw * th; i += 256) {
-        const int ty = i / tw, tx = i - ty * tw;
-        const int y = by0 - reach + ty, x = bx0 - reach + tx;
-        s_own[i] = (y >= 0 && y < H8 && x >= 0 && x < W8) ? bown[(size_t)y * W8 + x] : (int16_t)-3;
+    for (int ty = wave; ty < th; ty += 4) {
+        const int y = by0 - reach + ty;
+        const bool row_in = y >= 0 && y < H8;
+        for (int tx = lane; tx < tw; tx += 64) {
+            const int x = bx0 - reach + tx;
+            s_own[ty * tw + tx] = (row_in && x >= 0 && x < W8) ? bown[(size_t)y * W8 + x] : (int16_t)-3;
+        }
     }
     __syncthreads();
     // (no early exit: a loop that stops at the first mismatch is a chain of dependent LDS reads,
     // one latency each; unconditional reads are independent and stream)
-    for (int i = tid; i < IT_H * tw; i += 256) {
-        const int ry = i / tw, tx = i - ry * tw;
-        const int o = s_own[(ry + reach) * tw + tx];
-        bool same = true;
+    for (int ry = wave; ry < IT_H; ry += 4)
+        for (int tx = lane; tx < tw; tx += 64) {
+            const int o = s_own[(ry + reach) * tw + tx];
+            bool same = true;
 #pragma unroll 8
-        for (int d = 0; d <= 2 * reach; ++d) {
-            const int v = s_own[(ry + d) * tw + tx];
-            same &= (v == o) | (v == -3);
+            for (int d = 0; d <= 2 * reach; ++d) {
+                const int v = s_own[(ry + d) * tw + tx];
+                same &= (v == o) | (v == -3);
+            }
+            s_col[ry * tw + tx] = (int16_t)(o >= 0 && !same ? -2 : o);  // -3 stays -3
         }
-        s_col[i] = (int16_t)(o >= 0 && !same ? -2 : o);  // -3 stays -3
-    }
     __syncthreads();
-    for (int i = tid; i < IT_H * IT_W; i += 256) {
-        const int ry = i / IT_W, rx = i - ry * IT_W;
+    for (int ry = wave; ry < IT_H; ry += 4) {
+        const int rx = lane;
         const int y = by0 + ry, x = bx0 + rx;
         if (y >= H8 || x >= W8) continue;
         const int16_t *row = s_col + ry * tw + rx;       // row[d] = column x - reach + d
