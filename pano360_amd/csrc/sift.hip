@@ -4,21 +4,26 @@
 // xfeatures2d/src/sift.cpp is restated with the SIFT_create() defaults - parity
 // unpinned, checked against the SIFT oracle under oracle/ (an independent NumPy restatement).
 //
-//   sift_extrema_kernel   findScaleSpaceExtrema + adjustLocalExtrema: one thread per DoG
-//                         pixel and layer; the 26-neighbour test first, the (rare) Newton
-//                         refinement, contrast and edge tests in the same thread;
-//                         survivors are appended to a candidate list.
+//   sift_scan_kernel +    findScaleSpaceExtrema + adjustLocalExtrema: the 26-neighbour test as a
+//   sift_refine_kernel    stream over the DoG rows (a load per lane and layer, the triples from
+//                         the neighbouring lanes' registers), the extrema listed per wave in LDS;
+//                         the Newton refinement, contrast and edge tests on the listed ones
+//                         (sift_extrema_kernel: the same per thread, for other layer counts).
 //   sift_orient_kernel    calcOrientationHist: one wave per candidate, the lanes walk the
 //                         (2r+1)^2 window and add into a 36-bin LDS histogram; smoothing
 //                         and peak picking emit one keypoint per dominant orientation.
 //   sift_describe_kernel  calcSIFTDescriptor: one wave per keypoint, trilinear votes into
 //                         the 6 x 6 x 10 LDS histogram, then clip / scale / saturate.
 //
-// Lists are filled with atomics, so their order varies from run to run; the host sorts
-// keypoints the way KeyPointsFilter::removeDuplicatedSorted does before describing them.
+// The orientation and descriptor kernels run four such waves per workgroup, each with its
+// own keypoint and LDS arrays and no barrier between them (wave_sync below).
+// Lists are filled with atomics, so their order varies from run to run; sift_sort.hip sorts
+// the keypoints the way KeyPointsFilter::removeDuplicatedSorted does before they are described.
 // The histograms (orientation, descriptor) are summed in 64-bit fixed point with integer LDS
 // atomics: independent of the order of the additions, and several times faster than LDS float
-// atomics on gfx950 (see sift_describe_kernel).
+// atomics on gfx950 (see sift_describe_kernel).  The window samples' arithmetic uses the
+// hardware's exp / sqrt / reciprocal and fused multiply-adds (tolerance-tested against the
+// oracle, as everything here).
 #include <type_traits>
 
 #include "common.h"
