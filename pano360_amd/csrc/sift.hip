@@ -259,17 +259,23 @@ __global__ __launch_bounds__(256) void sift_extrema_kernel(
 // column), which sift_refine_kernel then works through, one thread per entry.  (One thread
 // per sample with the refinement inside it took 1.58 ms for the DoG planes of a 4K frame, more
 // than building the scale space.)
-#define SIFT_SCAN_SEG 96
+#ifndef SIFT_SCAN_WAVES
+#define SIFT_SCAN_WAVES 4096        // a launch's rows are cut until it has this many waves (if it can)
+#endif
 template <int NL>                   // DoG layers of the octave = layers per octave + 2
 __global__ __launch_bounds__(256) void sift_scan_kernel(const float *__restrict__ dog, int rows,
-                                                        int cols, float threshold,
+                                                        int cols, float threshold, int seg_rows,
                                                         uint32_t *__restrict__ raw,
                                                         int *__restrict__ raw_count, int cap) {
     const int lane = threadIdx.x, wave = threadIdx.y;
     const int c = SIFT_BORDER + 62 * (int)blockIdx.x + lane - 1, cl = min(c, cols - 1);
     const int seg = (int)blockIdx.y * 4 + wave;
-    const int r_begin = SIFT_BORDER + seg * SIFT_SCAN_SEG;
-    const int r_end = min(r_begin + SIFT_SCAN_SEG, rows - SIFT_BORDER);
+    // A wave walks `seg_rows` rows of its 62 columns, a chain of dependent row loads: 96 rows a
+    // wave made every octave's launch last a hundred load latencies, however small the octave
+    // (0.85 ms for the eleven octaves of a 4K frame); the host cuts the rows until the launch
+    // has a few thousand waves.
+    const int r_begin = SIFT_BORDER + seg * seg_rows;
+    const int r_end = min(r_begin + seg_rows, rows - SIFT_BORDER);
     if (r_begin >= r_end) return;                        // wave-uniform
     const bool mine = lane >= 1 && lane <= 62 && c < cols - SIFT_BORDER;
     const size_t plane = (size_t)rows * cols;
@@ -664,11 +670,16 @@ extern "C" int pano_sift_extrema(pano_ctx *ctx, const float *dog, int rows, int 
         }
         int *raw_count = (int *)(ctx->sift_raw + ctx->sift_raw_cap);
         PANO_HIP(hipMemsetAsync(raw_count, 0, sizeof(int), s));
+        int seg_rows = 96;
+        while (seg_rows > 12 && (long)ceil_div(cols - 2 * SIFT_BORDER, 62) *
+                                    ceil_div(rows - 2 * SIFT_BORDER, seg_rows) < SIFT_SCAN_WAVES)
+            seg_rows /= 2;
         dim3 block(64, 4), grid(ceil_div(cols - 2 * SIFT_BORDER, 62),
-                                ceil_div(rows - 2 * SIFT_BORDER, 4 * SIFT_SCAN_SEG));
+                                ceil_div(rows - 2 * SIFT_BORDER, 4 * seg_rows));
         PANO_TIMED(PK_SIFT_EXTREMA, s, {
             hipLaunchKernelGGL(sift_scan_kernel<5>, grid, block, 0, s, dog, rows, cols,
-                               (float)threshold, ctx->sift_raw, raw_count, (int)ctx->sift_raw_cap);
+                               (float)threshold, seg_rows, ctx->sift_raw, raw_count,
+                               (int)ctx->sift_raw_cap);
             hipLaunchKernelGGL(sift_refine_kernel, dim3(512), dim3(256), 0, s, dog, rows, cols, octave,
                                n_layers, contrast_thr, edge_thr, sigma, ctx->sift_raw, raw_count,
                                (int)ctx->sift_raw_cap, cands, count, max_cands);
