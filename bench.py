@@ -310,6 +310,11 @@ def run_cfg4(args, eng, rank, world, steps=None, warmup=None, detect=None):
     for _ in range(2):
         step()
     fence()
+    # (as in main(): the cyclic collector's full pass - tens of ms over all of torch and numpy -
+    # would land in one of the few timed steps; everything alive here is long-lived)
+    import gc
+    gc.collect()
+    gc.freeze()
     elapsed, (pyr, n_kp), times = timed_steps(eng, step, steps, warmup, fence)
     job = state.get("job")
     if job is not None:                      # the last frame's keypoints are still in flight
