@@ -315,7 +315,7 @@ extern "C" int pano_stitch_multiband(pano_ctx *ctx, pano_stitch_args *a, int res
             bound.n_records = bound.n_records + 2 < a->cap_records ? bound.n_records + 2 : a->cap_records;
             bound.max_vw += 64, bound.max_vh += 64, bound.max_aw += 64, bound.max_ah += 64;
             if (ctx->opt[PANO_OPT_STITCH_ASYNC] == 2) {          // tests: bounds this layout exceeds
-                bound.n_records = ctx->lay_prev.n_records - 1;
+                bound.n_records = ctx->lay_prev.n_records > 1 ? ctx->lay_prev.n_records - 1 : 1;
                 bound.max_vw = ctx->lay_prev.max_vw - 1;
             }
         }
