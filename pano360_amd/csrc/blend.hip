@@ -667,17 +667,25 @@ __global__ __launch_bounds__(256) void block_owner_kernel(const int16_t *__restr
 // then along the rows of that - and both passes run out of one LDS tile: 64 x 16 blocks per
 // workgroup with a halo of `reach` blocks, so the block owners are read from memory 3-4 times
 // instead of 2 (2 reach + 1) times.
+// A window holds one owner exactly when every two neighbours in it agree (positions beyond the
+// mosaic, -3, agree with anything: they lie outside all valid ones, never between two), so a
+// pass is one bit per pair of neighbours - a 64-bit word per tile column, two ballots per tile
+// row - and a window test is a shift and a compare instead of 2 reach + 1 LDS reads (61 k reads
+// per workgroup at reach 12: 47 us of a config-3 stitch's side chain).
 #define IT_W 64
 #define IT_H 16
 #define IT_REACH_MAX 20
+__device__ __forceinline__ bool agree(int a, int b) { return a == b || a == -3 || b == -3; }
+
 __global__ __launch_bounds__(256) void interior_tile_kernel(const int16_t *__restrict__ bown,
                                                             int H8, int W8, int reach,
                                                             uint8_t *__restrict__ interior) {
     __shared__ int16_t s_own[(IT_H + 2 * IT_REACH_MAX) * (IT_W + 2 * IT_REACH_MAX)];
     __shared__ int16_t s_col[IT_H * (IT_W + 2 * IT_REACH_MAX)];
+    __shared__ unsigned long long s_vmask[IT_W + 2 * IT_REACH_MAX];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int bx0 = blockIdx.x * IT_W, by0 = blockIdx.y * IT_H;
-    const int tw = IT_W + 2 * reach, th = IT_H + 2 * reach;
+    const int tw = IT_W + 2 * reach, th = IT_H + 2 * reach;          // th <= 56: a column's bits fit a word
     // (rows by wave, columns by lane: an index i = ty * tw + tx split by division cost twenty
     // instructions per element, more than the loads it addressed)
     // -3 marks a position beyond the mosaic
@@ -690,30 +698,39 @@ __global__ __launch_bounds__(256) void interior_tile_kernel(const int16_t *__res
         }
     }
     __syncthreads();
-    // (no early exit: a loop that stops at the first mismatch is a chain of dependent LDS reads,
-    // one latency each; unconditional reads are independent and stream)
+    // down the columns: bit ty of a column's word = rows ty and ty + 1 agree
+    for (int tx = tid; tx < tw; tx += 256) {
+        unsigned long long m = 0;
+        int prev = s_own[tx];
+#pragma unroll 8
+        for (int ty = 0; ty + 1 < th; ++ty) {
+            const int cur = s_own[(ty + 1) * tw + tx];
+            m |= (unsigned long long)agree(prev, cur) << ty;
+            prev = cur;
+        }
+        s_vmask[tx] = m;
+    }
+    __syncthreads();
+    const unsigned long long full = (1ull << (2 * reach)) - 1ull;     // 2 reach <= 40 pairs
     for (int ry = wave; ry < IT_H; ry += 4)
         for (int tx = lane; tx < tw; tx += 64) {
             const int o = s_own[(ry + reach) * tw + tx];
-            bool same = true;
-#pragma unroll 8
-            for (int d = 0; d <= 2 * reach; ++d) {
-                const int v = s_own[(ry + d) * tw + tx];
-                same &= (v == o) | (v == -3);
-            }
+            const bool same = ((s_vmask[tx] >> ry) & full) == full;
             s_col[ry * tw + tx] = (int16_t)(o >= 0 && !same ? -2 : o);  // -3 stays -3
         }
     __syncthreads();
+    // along the rows of that: a row's pairs as two ballots, a pixel's window as a shift
     for (int ry = wave; ry < IT_H; ry += 4) {
-        const int rx = lane;
-        const int y = by0 + ry, x = bx0 + rx;
+        const int16_t *row = s_col + ry * tw;
+        const int a0 = row[lane], a1 = row[min(lane + 1, tw - 1)];
+        const int b0 = row[min(lane + 64, tw - 1)], b1 = row[min(lane + 65, tw - 1)];
+        const unsigned long long lo = __ballot(lane + 1 < tw && agree(a0, a1));
+        const unsigned long long hi = __ballot(lane + 65 < tw && agree(b0, b1));
+        const int y = by0 + ry, x = bx0 + lane;
         if (y >= H8 || x >= W8) continue;
-        const int16_t *row = s_col + ry * tw + rx;       // row[d] = column x - reach + d
-        const int o = row[reach];
-        bool in = o >= 0;
-#pragma unroll 8
-        for (int d = 0; d <= 2 * reach; ++d) in &= (row[d] == o) | (row[d] == -3);
-        interior[(size_t)y * W8 + x] = in ? 1 : 0;
+        const unsigned long long win = lane == 0 ? lo : (lo >> lane) | (hi << (64 - lane));
+        const int o = row[lane + reach];
+        interior[(size_t)y * W8 + x] = (o >= 0 && (win & full) == full) ? 1 : 0;
     }
 }
 
