@@ -1218,8 +1218,22 @@ __global__ __launch_bounds__(256) void tile_flags32_kernel(const pano_patch *__r
     const int bx0 = (p.x0 + x0) / PANO_INTERIOR_BLOCK, bx1 = (p.x0 + x1 - 1) / PANO_INTERIOR_BLOCK;
     const int by0 = (p.y0 + y0) / PANO_INTERIOR_BLOCK, by1 = (p.y0 + y1 - 1) / PANO_INTERIOR_BLOCK;
     bool active = false;
-    for (int by = by0; by <= by1; ++by)
-        for (int bx = bx0; bx <= bx1; ++bx) active |= interior[(size_t)by * W8 + bx] == 0;
+    static_assert(PANO_INTERIOR_BLOCK == 4, "a 32-pixel tile spans at most nine interior blocks");
+    if (bx0 + 8 <= W8) {
+        // a tile row's (at most nine) map bytes as one 8-byte load at any alignment, plus the
+        // ninth: 81 byte loads per tile were the kernel (its bytes are 0 or 1)
+        typedef uint64_t u64_any __attribute__((aligned(1)));
+        const int nb = bx1 - bx0 + 1;                                    // 1 .. 9
+        const uint64_t ones = nb >= 8 ? 0x0101010101010101ull : (0x0101010101010101ull >> (8 * (8 - nb)));
+        for (int by = by0; by <= by1; ++by) {
+            const uint8_t *row = interior + (size_t)by * W8 + bx0;
+            active |= (*(const u64_any *)row & ones) != ones;
+            if (nb == 9) active |= row[8] == 0;
+        }
+    } else {
+        for (int by = by0; by <= by1; ++by)
+            for (int bx = bx0; bx <= bx1; ++bx) active |= interior[(size_t)by * W8 + bx] == 0;
+    }
     flags[p.tiles_off + ty * g.ntx + tx] = active ? 1 : 0;
 }
 
@@ -1265,6 +1279,14 @@ __global__ __launch_bounds__(256) void mb_items_kernel(const pano_patch *__restr
     const MbGeom g = mb_geom(p);
     const int nty = g.O1 - g.O0 + 1;
     const uint8_t *rec = flags ? flags + p.tiles_off : nullptr;
+    // the record's flags once into LDS (when they fit): the scans below read every flag half a
+    // dozen times in short dependent loads - 25 us alone, 130 us beside the warp
+    __shared__ uint8_t s_flags[16384];
+    if (rec && nty * g.ntx <= (int)sizeof(s_flags)) {
+        for (int i = tid; i < nty * g.ntx; i += 256) s_flags[i] = rec[i];
+        __syncthreads();
+        rec = s_flags;
+    }
     int count = 0;
     bool covered = false;                                // column 0 of this chunk is in a pair
     for (int c0 = 0; c0 < g.ntx; c0 += 64) {
