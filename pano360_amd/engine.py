@@ -681,7 +681,8 @@ class Engine:
         self.side = torch.cuda.Stream(self.device)
         self.overlap_interior = side_stream == 1
         self.overlap_prepare = side_stream in (1, 2)
-        self.warp_need = "auto"     # "auto" | True | False: see multiband_fused
+        self.warp_need = {"1": True, "0": False}.get(os.environ.get("PANO_WARP_NEED", ""), "auto")
+        # ("auto" | True | False: see multiband_fused; the environment switch is for A/B timing)
         self._cam_template = None
         # the whole launch sequence of a fused stitch in one native call (pano_stitch_multiband);
         # False: launch by launch from here (the same entry points; what the side streams use)
