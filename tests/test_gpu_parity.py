@@ -1301,3 +1301,26 @@ def test_edge_case_scenes(eng, oracle, case):
     for kind in ("linear", "none"):
         got = eng.stitch(frames, plan_l, kind)[0].cpu().numpy()
         assert np.array_equal(got, oracle.stitch(imgs, rots, intrs, kind, max_resolution=mr)), kind
+
+
+def test_owned_regions_on_a_mosaic_wider_than_one_span_chunk(eng):
+    """pano_owned_regions on a 70 000-column owner map: owned_spans_kernel ballots the column
+    marks 65 536 columns at a time (its LDS words), so a wider mosaic takes a second chunk with
+    the run bookkeeping carried across - and init_regions_kernel clears 4 x 70 000 marks."""
+    import torch
+    H, W, n = 6, 70000, 4
+    own = np.full((H, W), -1, np.int16)
+    own[:, 10:300] = 0
+    own[1:4, 65000:65530] = 1
+    own[2:5, 65530:66000] = 2          # camera 2's run crosses column 65 536
+    own[0:2, 69990:70000] = 3
+    own[3, 40000] = 3                  # a second, far span of camera 3
+    owner = torch.from_numpy(own).to(eng.device)
+    boxes, spans = eng.owned_regions(owner, n, min_gap=5, max_spans=4)
+    for i in range(n):
+        ys, xs = np.nonzero(own == i)
+        assert tuple(boxes[i]) == (ys.min(), ys.max(), xs.min(), xs.max())
+    assert [tuple(s) for s in spans[0]] == [(10, 299)]
+    assert [tuple(s) for s in spans[1]] == [(65000, 65529)]
+    assert [tuple(s) for s in spans[2]] == [(65530, 65999)]
+    assert [tuple(s) for s in spans[3]] == [(40000, 40000), (69990, 69999)]
