@@ -16,14 +16,31 @@
 // output pixel, 16-B lanes where the layout allows.
 #include "common.h"
 
-// (B*1868 + G*9617 + R*4899 + 2^13) >> 14, then to float (scale 1)
+// (B*1868 + G*9617 + R*4899 + 2^13) >> 14, then to float (scale 1).  Four pixels per thread:
+// their twelve bytes as three 4-byte loads, sixteen bytes out (three byte loads and a 4-byte
+// store per pixel ran at 1.9 TB/s).
+__device__ __forceinline__ float grey_of(uint32_t b, uint32_t g, uint32_t r) {
+    return (float)(int)((b * 1868u + g * 9617u + r * 4899u + (1u << 13)) >> 14);
+}
 __global__ __launch_bounds__(256) void gray_u8_kernel(const uint8_t *__restrict__ bgr,
                                                       size_t npix, float *__restrict__ out) {
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t q = (size_t)blockIdx.x * 256 + threadIdx.x, i = 4 * q;
     if (i >= npix) return;
-    const uint8_t *p = bgr + i * 3;
-    const int v = (p[0] * 1868 + p[1] * 9617 + p[2] * 4899 + (1 << 13)) >> 14;
-    out[i] = (float)v;
+    if (i + 4 <= npix && ((uintptr_t)bgr & 3) == 0 && ((uintptr_t)out & 15) == 0) {
+        const uint32_t *p = (const uint32_t *)(bgr + 3 * i);           // 12 q bytes: 4-byte aligned
+        const uint32_t w0 = p[0], w1 = p[1], w2 = p[2];
+        float4 v;
+        v.x = grey_of(w0 & 255u, (w0 >> 8) & 255u, (w0 >> 16) & 255u);
+        v.y = grey_of(w0 >> 24, w1 & 255u, (w1 >> 8) & 255u);
+        v.z = grey_of((w1 >> 16) & 255u, w1 >> 24, w2 & 255u);
+        v.w = grey_of((w2 >> 8) & 255u, (w2 >> 16) & 255u, w2 >> 24);
+        *(float4 *)(out + i) = v;
+        return;
+    }
+    for (size_t k = i; k < npix && k < i + 4; ++k) {
+        const uint8_t *p = bgr + k * 3;
+        out[k] = grey_of(p[0], p[1], p[2]);
+    }
 }
 
 // resize(src, Size(2w, 2h), INTER_LINEAR): source coordinate (d + 0.5)/2 - 0.5,
@@ -85,7 +102,7 @@ extern "C" int pano_gray_u8(pano_ctx *ctx, const uint8_t *bgr, int h, int w, flo
     PANO_ENTER(ctx, "pano_gray_u8");
     PANO_REQUIRE(bgr && out && h > 0 && w > 0, "pano_gray_u8: bad argument");
     const size_t n = (size_t)h * w;
-    hipLaunchKernelGGL(gray_u8_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+    hipLaunchKernelGGL(gray_u8_kernel, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0,
                        (hipStream_t)stream, bgr, n, out);
     PANO_LAUNCH_CHECK("gray_u8_kernel");
     return PANO_OK;
