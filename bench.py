@@ -285,19 +285,38 @@ def run_cfg4(args, eng, rank, world, steps=None, warmup=None, detect=None):
     w, h = 3840, 2160
     pool = [eng.upload_frames([synth.make_frame(1000 * rank + i, w, h, "B")])[0] for i in range(4)]
     state = dict(i=0)
+    # Frames in flight: a frame's scale space is a chain of ~70 dependent launches whose last
+    # eight octaves are a few workgroups each (0.2 of its 1.1 ms): with a second engine on a
+    # second stream the next frame's large octaves fill the chip meanwhile (PANO_CFG4_STREAMS=1:
+    # one frame at a time).
+    n_streams = max(1, int(os.environ.get("PANO_CFG4_STREAMS", "2")))
+    from pano360_amd import engine as _engine
+    lanes = [(eng, torch.cuda.current_stream(eng.device))]
+    for _ in range(n_streams - 1):
+        s2 = torch.cuda.Stream(eng.device)
+        with torch.cuda.stream(s2):
+            lanes.append((_engine.Engine(eng.device), s2))
+    torch.cuda.synchronize()
 
     def step():
-        frame = pool[state["i"] % len(pool)]
+        k = state["i"]
+        frame = pool[k % len(pool)]
         state["i"] += 1
-        pyr = features.sift_pyramid_device(frame, eng=eng)
-        if detect:
-            # queued without waiting; the previous frame's keypoints are fetched meanwhile
-            job, state["job"] = state.get("job"), features.sift_detect_async(frame, pyramid=pyr,
-                                                                           eng=eng)
-            if job is not None:
-                state["kps"] = job.result()[0]
-                state["n_kp"] = len(state["kps"])
-            return pyr, state.get("n_kp")
+        # (the instrumented pass runs one frame at a time: events on two streams span each other)
+        lane = 0 if state.get("serial") else k % len(lanes)
+        use, stream = lanes[lane]
+        with torch.cuda.stream(stream):
+            pyr = features.sift_pyramid_device(frame, eng=use)
+            if detect:
+                # queued without waiting; the keypoints of the frame this lane took before are
+                # fetched meanwhile
+                key = ("job", lane)
+                job, state[key] = state.get(key), features.sift_detect_async(frame, pyramid=pyr,
+                                                                           eng=use)
+                if job is not None:
+                    state["kps"] = job.result()[0]
+                    state["n_kp"] = len(state["kps"])
+                return pyr, state.get("n_kp")
         return pyr, None
 
     def fence():
@@ -315,11 +334,25 @@ def run_cfg4(args, eng, rank, world, steps=None, warmup=None, detect=None):
     import gc
     gc.collect()
     gc.freeze()
-    elapsed, (pyr, n_kp), times = timed_steps(eng, step, steps, warmup, fence)
-    job = state.get("job")
-    if job is not None:                      # the last frame's keypoints are still in flight
-        state["kps"] = job.result()[0]
-        state["n_kp"] = n_kp = len(state["kps"])
+    class AllLanes:                          # timing on / off and the kernels' times over every lane
+        def timing(self, on):
+            state["serial"] = bool(on)
+            for use, _ in lanes:
+                use.timing(on)
+
+        def kernel_times(self):
+            total = {}
+            for use, _ in lanes:
+                for name, (ms, count) in use.kernel_times().items():
+                    have = total.get(name, (0.0, 0))
+                    total[name] = (have[0] + ms, have[1] + count)
+            return total
+    elapsed, (pyr, n_kp), times = timed_steps(AllLanes(), step, steps, warmup, fence)
+    for lane in range(len(lanes)):           # the last frames' keypoints are still in flight
+        job = state.get(("job", lane))
+        if job is not None:
+            state["kps"] = job.result()[0]
+            state["n_kp"] = n_kp = len(state["kps"])
     SIFT_KPS["last"] = state.get("kps")
     return elapsed, pyr, n_kp, times, (w, h)
 
@@ -389,7 +422,10 @@ def cfg4_line(args, world, elapsed, pyr, n_kp, times, size):
                                f"and GPU" + (", + keypoints and descriptors" if args.detect else ""),
                    "frames_per_step": world, "gauss_megapixels": g_px / 1e6,
                    "dog_megapixels": d_px / 1e6,
-                   "parallelism": "independent frames, one per GPU (replicas only)"},
+                   "frames_in_flight": max(1, int(os.environ.get("PANO_CFG4_STREAMS", "2"))),
+                   "parallelism": "independent frames, one per GPU (replicas only); on a GPU "
+                                  "consecutive frames alternate between two streams (a frame's "
+                                  "small octaves are a chain of few-workgroup launches)"},
         "kernel_ms_per_step": {k: v[0] / args.steps for k, v in sorted(times.items())},
         "instrumented_ms_per_step": INSTRUMENTED.get("seconds", 0.0) / args.steps * 1e3,
         "instrumentation": "ms_per_step / value: K steps with no instrumentation inside; "
