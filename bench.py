@@ -204,6 +204,7 @@ def cpu_baseline(cfg):
 
 
 INSTRUMENTED = {}      # seconds of the instrumented pass of the last timed_steps call
+IN_FLIGHT = {"n": 1}   # stitches in flight of the headline measurement (run_sets)
 
 
 def timed_steps(eng, step, steps, warmup, fence, finish=None):
@@ -534,12 +535,19 @@ def secondary_single_gpu(eng, fence):
                          "the reference does (stitcher.py:276-302) and as the headline does")
         return entry
     guarded("cfg3_plan_cached", cached)
+
+    def one_in_flight():
+        entry = stitches("cfg3", 20, 3)
+        entry["what"] = ("config 3 one stitch at a time on one engine and stream (the headline keeps "
+                         "two consecutive stitches in flight)")
+        return entry
+    guarded("cfg3_one_in_flight", one_in_flight)
     guarded("cfg2", lambda: stitches("cfg2", 20, 3))
 
     def cfg4(detect):
-        steps = 8 if detect else 12
-        elapsed, pyr, n_kp, times, size = run_cfg4(None, eng, 0, 1, steps, 2, detect)
-        line = cfg4_line(_Steps(steps, 2, detect), 1, elapsed, pyr, n_kp, times, size)
+        steps = 16 if detect else 20            # (two frames in flight: a few frames per lane to warm up)
+        elapsed, pyr, n_kp, times, size = run_cfg4(None, eng, 0, 1, steps, 4, detect)
+        line = cfg4_line(_Steps(steps, 4, detect), 1, elapsed, pyr, n_kp, times, size)
         keep = ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "kernel_ms_per_step",
                 "instrumented_ms_per_step", "roofline", "sift")
         entry = {k_: line[k_] for k_ in keep if k_ in line}
@@ -640,17 +648,48 @@ def main():
         nothing crosses a GPU (replicas; the N = 1 path)."""
         my_set = pdist.assign_sets(world, rank, world)[0]
         frames = upload(my_set, range(cfg["n"]))
+        # Stitches in flight: consecutive stitches alternate between engines on streams of their
+        # own, so that one stitch's kernels fill the GPU while the other's regions travel to the
+        # host and its table back (0.1 ms of a config-3 stitch during which the GPU had one short
+        # kernel to run).  Two for mosaics of 16 - 128 MP (config 3: 1.83 -> 1.715 ms per stitch;
+        # config 2 and config 5 gain nothing); PANO_SETS_IN_FLIGHT overrides.
+        mp = engine.Plan(shapes, rots, intrs, True, NATIVE).shape
+        default_lanes = 2 if (1 << 24) <= mp[0] * mp[1] < (1 << 27) else 1
+        IN_FLIGHT["n"] = max(1, int(os.environ.get("PANO_SETS_IN_FLIGHT", default_lanes)))
+        lanes = [(eng, torch.cuda.current_stream(eng.device))]
+        for _ in range(IN_FLIGHT["n"] - 1):
+            s2 = torch.cuda.Stream(eng.device)
+            with torch.cuda.stream(s2):
+                lanes.append((engine.Engine(eng.device), s2))
+        state = dict(i=0, serial=False)
+
+        class AllLanes:                      # timing and kernel times over every lane
+            def timing(self, on):
+                state["serial"] = bool(on)   # (events on two streams would span each other)
+                for use, _ in lanes:
+                    use.timing(on)
+
+            def kernel_times(self):
+                total = {}
+                for use, _ in lanes:
+                    for name, (ms, count) in use.kernel_times().items():
+                        have = total.get(name, (0.0, 0))
+                        total[name] = (have[0] + ms, have[1] + count)
+                return total
 
         def step():
-            plan = engine.Plan(shapes, rots, intrs, True, NATIVE)
-            mosaic, _, _, patches = eng.stitch(frames, plan, "multiband", n_levels)
+            use, stream = lanes[0 if state["serial"] else state["i"] % len(lanes)]
+            state["i"] += 1
+            with torch.cuda.stream(stream):
+                plan = engine.Plan(shapes, rots, intrs, True, NATIVE)
+                mosaic, _, _, patches = use.stitch(frames, plan, "multiband", n_levels)
             # keep only the window geometry: holding the arenas across steps would make
             # the allocator carve out fresh gigabytes every step
             return plan, mosaic, list(patches)
-        for _ in range(3):
+        for _ in range(3 * len(lanes)):
             step()
         fence()
-        elapsed, (plan, _, patches), times = timed_steps(eng, step, args.steps, args.warmup,
+        elapsed, (plan, _, patches), times = timed_steps(AllLanes(), step, args.steps, args.warmup,
                                                          fence)
         return pdist.max_over_ranks(elapsed, reduce_device), plan, patches, times
 
@@ -680,6 +719,11 @@ def main():
                    f"data-path collective")
         else:
             how = "one image set per step on one GPU"
+        if not strips and IN_FLIGHT["n"] > 1:
+            how += (f"; {IN_FLIGHT['n']} consecutive stitches in flight per GPU (alternating "
+                    f"engines / streams: ms_per_step is the time per stitch of the pipelined "
+                    f"sequence, one stitch's latency is about {IN_FLIGHT['n']} times that; "
+                    f"secondary.cfg3_one_in_flight: one at a time)")
         warped = sum((p.window[1] - p.window[0]) * (p.window[3] - p.window[2]) for p in patches)
         blurred = sum((p.area[1] - p.area[0]) * (p.area[3] - p.area[2]) for p in patches)
         out = {
@@ -705,6 +749,7 @@ def main():
                 "frames": cfg["n"], "mosaic": list(plan.shape),
                 "patch_megapixels": P / 1e6, "source_megapixels": S / 1e6,
                 "mosaic_megapixels": M / 1e6,
+                "stitches_in_flight": 1 if strips else IN_FLIGHT["n"],
                 "parallelism": how,
             },
             # `value` counts the reference's patch pixels P (every stage of the reference is
