@@ -632,15 +632,45 @@ def main():
     def run_strips(exchange):
         """ONE panorama (image set 0) split into column strips, one per rank; the finished
         strips are composed on rank 0 (strong scaling)."""
-        runner = pdist.ShardedStitcher(eng, shapes, rots, intrs, n_levels, rank, world,
-                                       exchange=exchange, depth=2)
+        # two stitches in flight per rank (PANO_STRIPS_IN_FLIGHT, default 2): consecutive
+        # stitches alternate between two engines, each with a stream and exchange buffers of its
+        # own - one stitch's kernels cover the other's host round trip and launch gaps, which at
+        # eight ranks are a fifth of a strip's time (tools/strip_floor.py: 0.48 -> 0.36 ms)
+        n_lanes = max(1, int(os.environ.get("PANO_STRIPS_IN_FLIGHT", "2")))
+        IN_FLIGHT["strips"] = n_lanes
+        engines = [eng] + [engine.Engine(eng.device) for _ in range(n_lanes - 1)]
+        runner = pdist.ShardedStitcher(engines if n_lanes > 1 else eng, shapes, rots, intrs,
+                                       n_levels, rank, world, exchange=exchange,
+                                       depth=max(2, n_lanes))
         frames = upload(0, runner.my_frames)
-        for _ in range(3):        # setup: first-touch allocations of the workspaces
+        serial = dict(on=False)
+
+        class AllLanes:                      # timing and kernel times over every lane
+            def timing(self, on):
+                serial["on"] = bool(on)
+                for use in engines:
+                    use.timing(on)
+
+            def kernel_times(self):
+                total = {}
+                for use in engines:
+                    for name, (ms, count) in use.kernel_times().items():
+                        have = total.get(name, (0.0, 0))
+                        total[name] = (have[0] + ms, have[1] + count)
+                return total
+
+        def strips_step():
+            # (the per-kernel pass - events around every launch - keeps to the first lane: events
+            # on two streams would span each other; the lanes alternate by the step count)
+            if serial["on"] and runner.count % len(runner.lanes):
+                runner.count += len(runner.lanes) - runner.count % len(runner.lanes)
+            return runner.step(frames)
+        for _ in range(3 * n_lanes):      # setup: first-touch allocations of the workspaces
             runner.step(frames)
         runner.finish()
         fence()
         elapsed, (plan, _, patches), times = timed_steps(
-            eng, lambda: runner.step(frames), args.steps, args.warmup, fence, runner.finish)
+            AllLanes(), strips_step, args.steps, args.warmup, fence, runner.finish)
         return pdist.max_over_ranks(elapsed, reduce_device), plan, patches, times, runner
 
     def run_sets():
@@ -713,7 +743,8 @@ def main():
         if strips:
             how = (f"one image set per step, its mosaic split into {world} column strips (one "
                    f"per GPU, frames resident where needed), finished uint8 strips composed on "
-                   f"rank 0 over RCCL by {args.exchange}, overlapped with the next stitch")
+                   f"rank 0 over RCCL by {args.exchange}, overlapped with the next stitch; "
+                   f"{IN_FLIGHT.get('strips', 1)} consecutive stitches in flight per rank")
         elif world > 1:
             how = (f"{world} independent image sets per step, one per GPU (replicas), no "
                    f"data-path collective")
@@ -749,7 +780,7 @@ def main():
                 "frames": cfg["n"], "mosaic": list(plan.shape),
                 "patch_megapixels": P / 1e6, "source_megapixels": S / 1e6,
                 "mosaic_megapixels": M / 1e6,
-                "stitches_in_flight": 1 if strips else IN_FLIGHT["n"],
+                "stitches_in_flight": IN_FLIGHT.get("strips", 1) if strips else IN_FLIGHT["n"],
                 "parallelism": how,
             },
             # `value` counts the reference's patch pixels P (every stage of the reference is

@@ -202,7 +202,14 @@ class ShardedStitcher:
 
     def __init__(self, eng, shapes, rots, intrs, n_levels, rank, world, max_resolution=10 ** 9,
                  group=None, exchange="gather", depth=2, cache_plan=False):
-        self.eng, self.rank, self.world, self.group = eng, rank, world, group
+        # ``eng``: one engine, or a list of them - "lanes": consecutive stitches then alternate
+        # between the engines, each on a stream of its own with its own exchange buffers, so
+        # that one stitch's kernels cover the other's host round trip (on a column strip of a
+        # world-8 run the kernels are 0.45 ms and that round trip plus the launches' gaps 0.1).
+        # Every buffer of a lane is only ever touched in its lane's stream order; the ranks
+        # alternate alike, so their collectives are issued in the same order everywhere.
+        engines = list(eng) if isinstance(eng, (list, tuple)) else [eng]
+        self.eng, self.rank, self.world, self.group = engines[0], rank, world, group
         self.shapes, self.rots, self.intrs = shapes, rots, intrs
         self.n_levels, self.max_resolution = n_levels, max_resolution
         # cache_plan: the host geometry of the (unchanged) cameras is computed once and kept
@@ -218,37 +225,69 @@ class ShardedStitcher:
         # mosaic columns whose sin / cos this rank's kernels read: the strip, the reach of the
         # interior test around it (ownership) and one radius more (windows V), generously
         self.table_cols = (self.strip[0] - 4 * radius - 64, self.strip[1] + 4 * radius + 64)
-        # exchange=None: geometry only (emulation of the ranks on one device)
-        self.exchange = (StripExchange(plan.shape, self.bounds, rank, world, eng.device,
-                                       exchange, group, depth) if exchange else None)
+        self.depth = max(int(depth), 1)
+        lane_depth = self.depth          # (every lane can hold the whole pipeline: any pattern of lanes)
+        self.lanes = []
+        for i, use in enumerate(engines):
+            stream = None
+            if i > 0 and str(getattr(use, "device", "cpu")).startswith("cuda"):
+                import torch
+                stream = torch.cuda.Stream(use.device)
+            # exchange=None: geometry only (emulation of the ranks on one device)
+            ex = (StripExchange(plan.shape, self.bounds, rank, world, use.device, exchange, group,
+                                lane_depth) if exchange else None)
+            self.lanes.append((use, stream, ex))
+        self.exchange = self.lanes[0][2]
+        self.count = 0
+        self.order = []                 # lanes of the stitches whose mosaics are still to come
+
+    @staticmethod
+    def _on(stream):
+        import contextlib
+        if stream is None:
+            return contextlib.nullcontext()
+        import torch
+        return torch.cuda.stream(stream)
+
+    def _collect_oldest(self):
+        use, stream, ex = self.lanes[self.order.pop(0)]
+        with self._on(stream):
+            return ex.collect()
 
     def step(self, frames):
-        """frames[j] = device tensor of camera my_frames[j].  Returns (plan, the previous
-        step's mosaic on rank 0 / None, this rank's patches)."""
-        ex = self.exchange
-        if ex is None:
+        """frames[j] = device tensor of camera my_frames[j].  Returns (plan, the mosaic of the
+        stitch ``depth - 1`` steps back on rank 0 / None, this rank's patches)."""
+        if self.exchange is None:
             raise RuntimeError("ShardedStitcher(exchange=None) holds the strip geometry only "
                                "(emulate_on_one_device); step() needs an exchange mode")
-        if self.cache_plan:
-            plan = self.eng.cached_plan(self.shapes, self.rots, self.intrs, True,
-                                        self.max_resolution, self.table_cols)
-        else:
-            plan = _eng.Plan(self.shapes, self.rots, self.intrs, True, self.max_resolution,
-                             table_cols=self.table_cols)
-            self.eng.upload_plan(plan)
-        ex.recycle()
-        _, _, _, patches = self.eng.multiband_fused(
-            frames, plan, self.n_levels, frame_ids=self.my_frames, strip=self.strip,
-            mosaic_out=ex.target())
-        ex.submit()
+        lane = self.count % len(self.lanes)
+        self.count += 1
+        use, stream, ex = self.lanes[lane]
+        with self._on(stream):
+            if self.cache_plan:
+                plan = use.cached_plan(self.shapes, self.rots, self.intrs, True,
+                                       self.max_resolution, self.table_cols)
+            else:
+                plan = _eng.Plan(self.shapes, self.rots, self.intrs, True, self.max_resolution,
+                                 table_cols=self.table_cols)
+                use.upload_plan(plan)
+            ex.recycle()
+            _, _, _, patches = use.multiband_fused(
+                frames, plan, self.n_levels, frame_ids=self.my_frames, strip=self.strip,
+                mosaic_out=ex.target())
+            ex.submit()
+        self.order.append(lane)
         # the exchange just started runs behind the next stitch's kernels; what is handed
-        # back is the stitch before it (depth 1: this one, synchronously)
-        previous = ex.collect() if len(ex.inflight) > ex.depth - 1 else None
+        # back is the stitch depth - 1 steps before it (depth 1: this one, synchronously)
+        previous = self._collect_oldest() if len(self.order) > self.depth - 1 else None
         return plan, previous, list(patches)          # window geometry only, not the arenas
 
     def finish(self):
         """Completes the exchanges in flight; the last stitch's mosaic on rank 0."""
-        return self.exchange.drain()
+        last = None
+        while self.order:
+            last = self._collect_oldest()
+        return last
 
 
 def emulate_on_one_device(eng, imgs, rots, intrs, n_levels, world, max_resolution=10 ** 9):

@@ -29,8 +29,17 @@ class _HostEngine:
     nothing else - what Engine.multiband_fused(strip=, mosaic_out=) does with kernels."""
     device = "cpu"
 
-    def __init__(self, shape):
-        self.shape, self.k = shape, 0
+    def __init__(self, shape, clock=None):
+        self.shape = shape
+        self.clock = clock if clock is not None else [0]     # shared by the engines of one stitcher
+
+    @property
+    def k(self):
+        return self.clock[0]
+
+    @k.setter
+    def k(self, value):
+        self.clock[0] = value
 
     def truth(self, k):
         H, W = self.shape
@@ -58,17 +67,18 @@ def _scene():
     return [(90, 160)] * 5, rots, intrs
 
 
-def _worker(rank, world, port, mode, depth, result, cache_plan=False):
+def _worker(rank, world, port, mode, depth, result, cache_plan=False, lanes=1):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         shapes, rots, intrs = _scene()
         shape = engine.Plan(shapes, rots, intrs, True, 10 ** 9).shape
         eng = _HostEngine(shape)
+        engines = [eng] + [_HostEngine(shape, eng.clock) for _ in range(lanes - 1)]
         # the bench's strips step: ShardedStitcher over the process group, K steps, finish
-        st = pdist.ShardedStitcher(eng, shapes, rots, intrs, 5, rank, world, exchange=mode,
-                                   depth=depth, cache_plan=cache_plan)
-        assert st.exchange.world == dist.get_world_size() == world
+        st = pdist.ShardedStitcher(engines if lanes > 1 else eng, shapes, rots, intrs, 5, rank,
+                                   world, exchange=mode, depth=depth, cache_plan=cache_plan)
+        assert st.exchange.world == dist.get_world_size() == world and len(st.lanes) == lanes
         got = []
         for _ in range(5):
             _, previous, _ = st.step(frames=None)
@@ -77,7 +87,7 @@ def _worker(rank, world, port, mode, depth, result, cache_plan=False):
         last = st.finish()
         if last is not None:
             got.append(last.clone())
-        assert getattr(eng, "cached", 0) == (5 if cache_plan else 0)
+        assert sum(getattr(e, "cached", 0) for e in engines) == (5 if cache_plan else 0)
         if rank == 0:
             ok = len(got) == 5 and all(torch.equal(m, eng.truth(k)) for k, m in enumerate(got))
             result.put(bool(ok))
@@ -109,6 +119,20 @@ def test_sharded_steps_over_gloo(mode, depth, world):
     ctx = mp.get_context("spawn")
     result = ctx.SimpleQueue()
     mp.spawn(_worker, args=(world, _free_port(), mode, depth, result), nprocs=world, join=True)
+    assert result.get() is True
+
+
+@pytest.mark.parametrize("mode,depth,world,lanes", [("gather", 2, 2, 2), ("reduce", 2, 3, 2),
+                                                    ("gather", 1, 2, 2), ("reduce", 2, 2, 3),
+                                                    ("gather", 1, 3, 3)])
+def test_sharded_steps_with_stitches_in_flight_over_gloo(mode, depth, world, lanes):
+    """The same steps with consecutive stitches alternating between several engines, each with
+    exchange buffers of its own (bench.py's strips with two stitches in flight per rank): rank 0
+    still composes the known mosaic of every step, in order, whatever the pipeline depth."""
+    ctx = mp.get_context("spawn")
+    result = ctx.SimpleQueue()
+    mp.spawn(_worker, args=(world, _free_port(), mode, depth, result, False, lanes), nprocs=world,
+             join=True)
     assert result.get() is True
 
 

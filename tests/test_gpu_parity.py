@@ -723,6 +723,14 @@ def test_sharded_stitcher_world_1_equals_stitch(eng):
     assert st2.step(frames)[1] is None
     assert torch.equal(st2.step(frames)[1], whole)
     assert torch.equal(st2.finish(), whole)
+    # two stitches in flight: consecutive steps alternate between two engines, each on a stream
+    # and with exchange buffers of its own (bench.py's strips); every mosaic is the same
+    st3 = pdist.ShardedStitcher([eng, engine.Engine(eng.device)], shapes, rots, intrs, 5, 0, 1,
+                                depth=2)
+    assert len(st3.lanes) == 2 and st3.lanes[1][1] is not None
+    got = [st3.step(frames)[1] for _ in range(5)] + [st3.finish()]
+    torch.cuda.synchronize()
+    assert got[0] is None and all(torch.equal(m, whole) for m in got[1:])
     with pytest.raises(Exception):       # a needed frame that is not resident
         eng.multiband_fused(eng.upload_frames(imgs[:2]), eng.upload_plan(plan), 5,
                             frame_ids=[0, 1])

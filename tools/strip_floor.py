@@ -19,6 +19,12 @@ rots, intrs = synth.make_cameras(cfg["n"], cfg["width"], cfg["height"],
                                  sweep_deg=cfg.get("sweep_deg"), step_deg=cfg.get("step_deg"))
 shapes = [(cfg["height"], cfg["width"])] * cfg["n"]
 eng = engine.Engine()
+LANES = [(eng, torch.cuda.current_stream(eng.device))]
+for _ in range(max(1, int(os.environ.get("PANO_SETS_IN_FLIGHT", "1"))) - 1):
+    _s = torch.cuda.Stream(eng.device)
+    with torch.cuda.stream(_s):
+        LANES.append((engine.Engine(eng.device), _s))
+COUNT = [0, False]
 pool = {}
 import gc  # noqa: E402
 gc.collect()
@@ -37,15 +43,22 @@ for world in worlds:
         out = torch.zeros(engine.Plan(shapes, rots, intrs, True, 10 ** 9).shape + (3,),
                           dtype=torch.uint8, device=eng.device)
 
+        # PANO_SETS_IN_FLIGHT=2: consecutive stitches alternate between two engines / streams
+        # (timing(True), the per-kernel pass, goes back to one)
         def step():
-            if os.environ.get("PANO_PLAN_CACHED", "0") != "0":
-                plan = eng.cached_plan(shapes, rots, intrs, True, 10 ** 9, st.table_cols)
-            else:
-                plan = engine.Plan(shapes, rots, intrs, True, 10 ** 9, table_cols=st.table_cols)
-                eng.upload_plan(plan)
-            eng.multiband_fused(frames, plan, cfg["n_levels"], frame_ids=st.my_frames,
-                                strip=st.strip, mosaic_out=out)
-        for _ in range(3):
+            use, stream = LANES[COUNT[0] % len(LANES)] if not COUNT[1] else LANES[0]
+            COUNT[0] += 1
+            with torch.cuda.stream(stream):
+                if os.environ.get("PANO_PLAN_CACHED", "0") != "0":
+                    plan = use.cached_plan(shapes, rots, intrs, True, 10 ** 9, st.table_cols)
+                else:
+                    plan = engine.Plan(shapes, rots, intrs, True, 10 ** 9, table_cols=st.table_cols)
+                    use.upload_plan(plan)
+                use.multiband_fused(frames, plan, cfg["n_levels"], frame_ids=st.my_frames,
+                                    strip=st.strip, mosaic_out=OUTS[(COUNT[0] - 1) % len(LANES)] if not COUNT[1] else out)
+        OUTS = [out] + [torch.zeros_like(out) for _ in LANES[1:]]
+        COUNT[1] = False
+        for _ in range(3 * len(LANES)):
             step()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -53,6 +66,7 @@ for world in worlds:
             step()
         torch.cuda.synchronize()
         ms = (time.perf_counter() - t0) / 20 * 1e3
+        COUNT[1] = True
         eng.timing(True)                 # second pass: the kernels' own times (events serialise
         for _ in range(20):              # what the first pass ran side by side)
             step()
