@@ -629,7 +629,7 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    def run_strips(exchange):
+    def run_strips(exchange, cache_plan=False):
         """ONE panorama (image set 0) split into column strips, one per rank; the finished
         strips are composed on rank 0 (strong scaling)."""
         # two stitches in flight per rank (PANO_STRIPS_IN_FLIGHT, default 2): consecutive
@@ -641,7 +641,7 @@ def main():
         engines = [eng] + [engine.Engine(eng.device) for _ in range(n_lanes - 1)]
         runner = pdist.ShardedStitcher(engines if n_lanes > 1 else eng, shapes, rots, intrs,
                                        n_levels, rank, world, exchange=exchange,
-                                       depth=max(2, n_lanes))
+                                       depth=max(2, n_lanes), cache_plan=cache_plan)
         frames = upload(0, runner.my_frames)
         serial = dict(on=False)
 
@@ -894,6 +894,17 @@ def main():
                 out["secondary"][f"strips_{other}"] = {
                     "ms_per_step": e2 / args.steps * 1e3,
                     "value": p2.patch_pixels / e2 * args.steps / 1e6}
+            # the same strips with the host geometry of the (unchanged) cameras kept from stitch
+            # to stitch: at eight ranks the per-stitch NumPy plan (0.36 ms on every rank, the
+            # same on all) is longer than a strip's kernels
+            e3, p3, _, _, _ = run_strips(args.exchange, cache_plan=True)
+            if rank == 0:
+                out["secondary"]["strips_plan_cached"] = {
+                    "ms_per_step": e3 / args.steps * 1e3,
+                    "value": p3.patch_pixels / e3 * args.steps / 1e6,
+                    "what": "the headline's strips with Engine.cached_plan (the cameras do not "
+                            "change between the steps; the headline recomputes the plan per "
+                            "stitch as the reference does)"}
         except Exception as err:       # noqa: BLE001
             if dog.cancel() and rank == 0:
                 out["secondary"]["error"] = repr(err)[:300]
