@@ -532,7 +532,8 @@ def secondary_single_gpu(eng, fence):
         entry = stitches("cfg3", 20, 3, cached=True)
         entry["what"] = ("config 3 with the host geometry of the (unchanged) cameras kept from "
                          "stitch to stitch (Engine.cached_plan) instead of recomputed per stitch as "
-                         "the reference does (stitcher.py:276-302) and as the headline does")
+                         "the reference does (stitcher.py:276-302) and as the headline does; one "
+                         "stitch at a time (compare with cfg3_one_in_flight)")
         return entry
     guarded("cfg3_plan_cached", cached)
 
