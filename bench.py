@@ -62,6 +62,14 @@ def parse():
                          "BASELINE configs and the float32 vector-ALU blur; N > 1: the other "
                          "exchange, replicas)")
     ap.add_argument("--secondary-timeout", type=float, default=180.0)
+    ap.add_argument("--in-flight", type=int, default=0,
+                    help="consecutive stitches kept in flight per GPU (engines on streams of their "
+                         "own); 0 = choose by mosaic size (two for 16 - 128 MP: config 3), 1 = one "
+                         "stitch at a time (ms_per_step is then one stitch's latency)")
+    ap.add_argument("--busy-seconds", type=float, default=None,
+                    help="after the measurements keep stitching for this long (untimed), so that a "
+                         "sampler polling the GPU every few seconds sees it busy; default 6 for "
+                         "the plain one-GPU config-3 run, else 0")
     ap.add_argument("--detect", action="store_true",
                     help="cfg4: time detectAndCompute (keypoints + descriptors) too")
     return ap.parse_args()
@@ -85,13 +93,9 @@ def pmc_traffic(name, workload=None):
         if workload is not None and table.get("workload") != workload:
             continue                       # counters of another workload say nothing here
         per = table.get("bytes_per_launch", {})
-        # the timing registry's "blur_mfma_kernel" covers the launches the profiler lists as
-        # blur_lean_kernel (regular and irregular items of the first four levels) and
-        # blur_mfma_kernel (a fifth / sixth level's launch)
-        names = [k for k in {"blur_mfma_kernel": ("blur_lean_kernel", "blur_mfma_kernel")}.get(name, (name,))
-                 if k in per]
-        if names:
-            return sum(per[k] for k in names), os.path.relpath(path, ROOT)
+        # (kernel names as the profiler prints them: the timing registry uses the same ones)
+        if name in per:
+            return per[name], os.path.relpath(path, ROOT)
     return None, None
 
 
@@ -108,7 +112,10 @@ def measured_traffic(times, steps, workload):
     return total if seen else None
 
 
-def algorithmic_bytes(plan, patches, n_levels, px_active):
+BLUR_KERNELS = ("blur_lean_kernel", "blur_mfma_kernel")      # as rocprofv3 names them
+
+
+def algorithmic_bytes(plan, patches, n_levels, px_active, times=None):
     """Algorithmic HBM bytes per step of each big kernel: every logical
     array the kernel consumes or produces counted once, on the pixels this run really
     processed (windows V / rectangles A / active tiles), not on the reference's P."""
@@ -118,7 +125,19 @@ def algorithmic_bytes(plan, patches, n_levels, px_active):
     px_cols = px_active or sum(ah * aw for vh, vw, ah, aw in win)   # blurred / gathered pixels
     px_warp = sum(vh * vw for vh, vw, ah, aw in win)                # warped pixels (V)
     px_rows = sum(vh * aw for vh, vw, ah, aw in win)                # row-pass pixels (VALU blur)
+    # The matrix-core blur: blur_lean_kernel takes (up to) four levels, a fifth / sixth level
+    # goes through blur_mfma_kernel in a launch of its own.  Algorithmic bytes: the colour
+    # planes (12 B) and the owner map (2 B) read ONCE over V - charged to the launch that runs,
+    # or to the lean one when both do (the second launch's re-staging of the bands is traffic,
+    # not algorithm) - and each level's blurred RGBA copy written once over the active tiles.
+    n_blur = n_levels - 1
+    both = times is not None and all(k in times for k in BLUR_KERNELS)
+    lean_levels = min(n_blur, 4) if both else n_blur
+    blur = {"blur_lean_kernel": 14.0 * px_warp + 16.0 * lean_levels * px_cols,
+            "blur_mfma_kernel": (16.0 * (n_blur - lean_levels) * px_cols if both
+                                 else 14.0 * px_warp + 16.0 * n_blur * px_cols)}
     return {
+        **blur,
         # 3 float planes written + the frame bytes under the window (about 1:1 scale)
         "warp_windows_kernel": 12.0 * px_warp + 3.0 * px_warp,
         # no pixel data read: owner (2 B) + valid (1 B) written per mosaic pixel
@@ -126,10 +145,6 @@ def algorithmic_bytes(plan, patches, n_levels, px_active):
         "owned_boxes_kernel": 2.0 * M,
         # warped colour + L-1 blurred RGBA per gathered pixel; owner/valid read, u8 out
         "multiband_compose_kernel": (12.0 + 16.0 * (n_levels - 1)) * px_cols + 6.0 * M,
-        # fused row + column pass of every level on the matrix cores: colour planes (12 B)
-        # and owner map (2 B) read over V, L-1 blurred RGBA copies written over the active
-        # tiles; the intermediate image never reaches memory
-        "blur_mfma_kernel": 14.0 * px_warp + 16.0 * (n_levels - 1) * px_cols,
         # the float32 vector-ALU form (Engine(blur="valu")): the row pass reads the planes and
         # the owner map over V and writes L-1 RGBA row-pass images (V rows x A columns), the
         # column pass reads those and writes the blurred copies over A
@@ -143,7 +158,7 @@ def roofline_for(times, plan, patches, n_levels, steps, px_active, workload=None
     time-weighted fraction over the three kernels that move the pixels (warp, blur,
     collapse)."""
     from pano360_amd import engine
-    per_step, px = algorithmic_bytes(plan, patches, n_levels, px_active)
+    per_step, px = algorithmic_bytes(plan, patches, n_levels, px_active, times)
     name = max(times, key=lambda k: times[k][0])
     total_ms, launches = times[name]
     avg_s = total_ms / launches * 1e-3
@@ -153,7 +168,7 @@ def roofline_for(times, plan, patches, n_levels, steps, px_active, workload=None
     out = dict(kernel=name, bound="hbm", achieved=achieved, peak=HBM_PEAK_GBPS,
                unit="GB/s", frac=achieved / HBM_PEAK_GBPS, traffic=traffic,
                traffic_source=source, avg_launch_ms=avg_s * 1e3, launches=launches)
-    if name == "blur_mfma_kernel":
+    if name in BLUR_KERNELS:
         flop = steps * sum(2.0 * t * 4 * (px["px_rows"] + px["px_cols"]) for t in taps)
         out["note"] = ("split-float16 Toeplitz products on the matrix cores (3 MFMAs per "
                        "float32-accurate product); %.1f TFLOP/s of useful float32-equivalent "
@@ -167,27 +182,30 @@ def roofline_for(times, plan, patches, n_levels, steps, px_active, workload=None
         return dict(kernels=have, achieved=bytes_sum / secs / 1e9,
                     frac=bytes_sum / secs / 1e9 / HBM_PEAK_GBPS, ms_per_step=secs / steps * 1e3,
                     GB_per_step=bytes_sum / steps / 1e9, note=note)
-    agg = together(("warp_windows_kernel", "blur_mfma_kernel", "multiband_compose_kernel"),
+    agg = together(("warp_windows_kernel",) + BLUR_KERNELS + ("multiband_compose_kernel",),
                    "algorithmic bytes of the three pixel-moving kernels / their summed time")
     if agg:
         out["weighted"] = agg
+        out["weighted_frac"] = agg["frac"]
     # north_star's target is stated on "the multiband blend": its two kernels together
-    agg = together(("blur_mfma_kernel", "blur_rows_kernel", "blur_cols_kernel",
-                    "multiband_compose_kernel"),
+    agg = together(BLUR_KERNELS + ("blur_rows_kernel", "blur_cols_kernel",
+                                   "multiband_compose_kernel"),
                    "the multiband blend (stitcher.py:186-241) = Gaussian levels + band build and "
                    "collapse: algorithmic bytes of its kernels / their summed time")
     if agg:
         out["multiband_blend"] = agg
+        out["blend_frac"] = agg["frac"]          # (a scalar beside `frac`: north_star's >= 0.40)
     return out
 
 
 def cpu_baseline(cfg):
     """The CPU oracle (C + OpenMP restatement of the reference path) timed on
-    this host on a bounded sample: the first 4 frames of the same sweep."""
+    this host on a bounded sample: the first 8 frames of the same sweep (BASELINE.md §3's
+    reduced instance: same frame size and yaw step, N = 8; ~10 s on the GPU box's cores)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import pano_oracle as po
     from pano360_amd import synth
-    n = min(4, cfg["n"])
+    n = min(8, cfg["n"])
     step = cfg.get("step_deg") or cfg["sweep_deg"] / (cfg["n"] - 1)
     imgs, rots, intrs = synth.make_scene(n, cfg["width"], cfg["height"], step_deg=step,
                                          seed=0, kind="A")
@@ -200,9 +218,13 @@ def cpu_baseline(cfg):
                 sample=f"first {n} of the {cfg['n']} frames ({cfg['width']}x{cfg['height']}, "
                        f"{step:.2f} deg/step), multiband L={cfg['n_levels']}, native "
                        f"resolution, {px / 1e6:.1f} MP of patches in {dt:.1f} s; oracle = "
-                       f"oracle/pano_oracle.c (gcc -O2 -fopenmp), {os.cpu_count()} host CPUs")
+                       f"oracle/pano_oracle.c (gcc -O2 -fopenmp: a multi-threaded C port, "
+                       f"faster than the reference's single-threaded NumPy glue around OpenCV), "
+                       f"{os.cpu_count()} host CPUs; cv2 is not installed on this pool, so the "
+                       f"reference itself cannot be timed here")
 
 
+COMM = {}              # what the process group saw (pano360_amd.dist.describe_job), every line carries it
 INSTRUMENTED = {}      # seconds of the instrumented pass of the last timed_steps call
 IN_FLIGHT = {"n": 1}   # stitches in flight of the headline measurement (run_sets)
 
@@ -572,8 +594,32 @@ def secondary_single_gpu(eng, fence):
     return out
 
 
+def self_launch(args):
+    """``python bench.py --gpus N`` without a launcher: start the N ranks as a CHILD process
+    (``python -m torch.distributed.run``, one rank per GPU) before this process has touched the
+    GPU - it never does - relay the child's output (rank 0's JSON line) and return its exit
+    code.  Nothing is exec'ed and no process that initialised the GPU starts another."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:                        # a free rendezvous port
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+           f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")    # dmabuf IPC (RCCL across processes)
+    child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    for line in child.stdout:                            # rank 0's line, as it comes
+        sys.stdout.write(line)
+        sys.stdout.flush()
+    return child.wait()
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args))
     import torch
     from pano360_amd import dist as pdist
     from pano360_amd import engine, synth
@@ -582,8 +628,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for N > 1")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch N ranks for --gpus N "
+                         "(or give --gpus N alone: bench.py starts them itself)")
     # PANO_DIST_BACKEND=gloo lets several ranks share one GPU for a dry run of the
     # multi-rank path on a 1-GPU box; the real launch is one rank per GPU over RCCL
     backend = os.environ.get("PANO_DIST_BACKEND", "nccl")
@@ -600,6 +646,7 @@ def main():
 
     eng = engine.Engine(f"cuda:{local}")
     reduce_device = eng.device if backend == "nccl" else "cpu"
+    COMM.update(pdist.describe_job(eng.device, reduce_device))
 
     if args.workload == "cfg4":
         elapsed, pyr, n_kp, times, size = run_cfg4(args, eng, rank, world)
@@ -686,7 +733,8 @@ def main():
         # config 2 and config 5 gain nothing); PANO_SETS_IN_FLIGHT overrides.
         mp = engine.Plan(shapes, rots, intrs, True, NATIVE).shape
         default_lanes = 2 if (1 << 24) <= mp[0] * mp[1] < (1 << 27) else 1
-        IN_FLIGHT["n"] = max(1, int(os.environ.get("PANO_SETS_IN_FLIGHT", default_lanes)))
+        IN_FLIGHT["n"] = max(1, int(os.environ.get("PANO_SETS_IN_FLIGHT",
+                                                   args.in_flight or default_lanes)))
         lanes = [(eng, torch.cuda.current_stream(eng.device))]
         for _ in range(IN_FLIGHT["n"] - 1):
             s2 = torch.cuda.Stream(eng.device)
@@ -762,11 +810,20 @@ def main():
             "metric": "blended megapixels/sec (multiband)",
             "value": sets_per_step * P / (ms * 1e-3) / 1e6,
             "unit": "MP/s",
-            "n_gpus": world, "world_size": dist.get_world_size() if dist is not None else 1,
+            "value_counts": "reference-equivalent patch pixels: the pixels P the reference's "
+                            "algorithm warps and blends for this image set (SURVEY §8d) per second; "
+                            "the kernels warp and blur far fewer (processed.*), exactly",
+            "n_gpus": world, "world_size": COMM.get("world_size", 1),
+            "comm": dict(COMM),
             "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms,
             # one stitch = one image set; with replicas a step holds several
             "ms_per_stitch": ms / sets_per_step,
+            # ms_per_step is THROUGHPUT time (pipelined when stitches_in_flight > 1); one
+            # stitch's latency is about in_flight x that
+            "stitches_in_flight": IN_FLIGHT.get("strips", 1) if strips else IN_FLIGHT["n"],
+            "latency_ms_estimate": ms / sets_per_step * (IN_FLIGHT.get("strips", 1) if strips
+                                                         else IN_FLIGHT["n"]),
             "higher_is_better": True,
             "scaling": "strong" if strips else "weak",
             "vs_baseline": None,
@@ -791,6 +848,7 @@ def main():
                 "warped_megapixels_rank0": warped / 1e6,
                 "blurred_megapixels_rank0": blurred / 1e6,
                 "warped_MPps_rank0": warped / (ms * 1e-3) / 1e6,
+                "warped_MPps": warped / (ms * 1e-3) / 1e6 * (1 if strips or world == 1 else world),
                 "mosaic_MPps": sets_per_step * M / (ms * 1e-3) / 1e6,
                 "input_MPps": sets_per_step * S / (ms * 1e-3) / 1e6,
             },
@@ -820,6 +878,9 @@ def main():
         }
         if world > 1:
             out["scaling_note"] = "unmeasured on multi-GPU hardware by the builder (1-GPU boxes)"
+            # north_star's >= 6 x at 8 GPUs: config 5 (the 120 x 8K roofline run) is the config
+            # that claim is made on; a config-3 strip at eight ranks is host-bound
+            out["scaling_claim_config"] = "cfg5"
         if frames_rank0 is not None:
             out["frames_on_rank0"] = frames_rank0
         return out
@@ -831,6 +892,20 @@ def main():
             out["cpu_baseline"] = cpu_baseline(cfg)
         if world == 1 and not args.no_secondary and args.workload == "cfg3":
             out["secondary"] = secondary_single_gpu(eng, fence)
+        busy = args.busy_seconds
+        if busy is None:
+            busy = 6.0 if world == 1 and args.workload == "cfg3" else 0.0
+        if busy > 0 and world == 1:
+            # untimed: the driver samples GPU utilisation every ~5 s and the timed region is 0.03 s
+            frames = upload(0, range(cfg["n"]))
+            t_end, n_busy = time.perf_counter() + busy, 0
+            while time.perf_counter() < t_end:
+                for _ in range(50):
+                    eng.stitch(frames, engine.Plan(shapes, rots, intrs, True, NATIVE), "multiband",
+                               n_levels)
+                torch.cuda.synchronize()
+                n_busy += 50
+            out["busy_loop"] = {"seconds": busy, "stitches": n_busy, "timed": False}
         if world > 1 and not args.no_secondary and args.workload != "cfg5":
             dog = Watchdog(args.secondary_timeout, rank, out)
             dog.start()

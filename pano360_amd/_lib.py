@@ -62,6 +62,7 @@ class StitchArgs(C.Structure):
         + [("layout", Layout)])
 
 
+EINVAL = -1     # PANO_EINVAL
 EGROW = 1       # pano_stitch_multiband: an arena is too small, args.layout says what is needed
 
 

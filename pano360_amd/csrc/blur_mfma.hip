@@ -1652,7 +1652,7 @@ static int launch_levels(pano_ctx *ctx, const pano_patch *table, int n, int max_
         if (lds_lean > 160 * 1024) lean = 0;             // (apertures above 97 taps: the general kernel)
     }
     if (lean) {
-        PANO_TIMED(PK_BLUR_MFMA, stream,
+        PANO_TIMED(PK_BLUR_LEAN, stream,
                    hipLaunchKernelGGL(blur_lean_kernel, grid, dim3(MB_THREADS_OF(4)), lds_lean,
                                       stream, table, L, tables, owner, W, flags, sorted));
         PANO_LAUNCH_CHECK("blur_lean_kernel");

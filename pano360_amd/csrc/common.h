@@ -65,6 +65,7 @@ enum PanoKernelId {
     PK_COMPOSE_INTERIOR,
     PK_SCALE_STEP,
     PK_KNN2,
+    PK_BLUR_LEAN,
     PK_COUNT
 };
 // ---- the context (include/pano360.h: pano_ctx) ------------------------------------

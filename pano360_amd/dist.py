@@ -46,6 +46,30 @@ def max_over_ranks(seconds, device="cpu", group=None):
     return t.item()
 
 
+def describe_job(device="cpu", reduce_device="cpu", group=None):
+    """What the process group saw, for the bench line: world size, backend, every rank's
+    device (index and name, gathered) and the checksum of a one-element all-reduce - the sum
+    of (rank + 1) over the ranks, which must be world (world + 1) / 2 on every rank.  A job
+    without a process group describes itself alone."""
+    import torch
+    import torch.distributed as dist
+    name = str(device)
+    if str(device).startswith("cuda") and torch.cuda.is_available():
+        idx = torch.device(device).index or 0
+        name = f"cuda:{idx} {torch.cuda.get_device_name(idx)}"
+    if not (dist.is_available() and dist.is_initialized()):
+        return dict(world_size=1, backend=None, devices=[name], allreduce_checksum=1,
+                    allreduce_expected=1)
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    t = torch.tensor([float(rank + 1)], dtype=torch.float64, device=reduce_device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    names = [None] * world
+    dist.all_gather_object(names, name, group=group)
+    return dict(world_size=world, backend=dist.get_backend(group), devices=names,
+                allreduce_checksum=int(round(t.item())),
+                allreduce_expected=world * (world + 1) // 2)
+
+
 def strip_bounds(width, world):
     """Column boundaries c_0 = 0 <= c_1 <= ... <= c_world = width, equal widths."""
     return [int(round(width * r / world)) for r in range(world + 1)]
@@ -236,6 +260,11 @@ class ShardedStitcher:
             # exchange=None: geometry only (emulation of the ranks on one device)
             ex = (StripExchange(plan.shape, self.bounds, rank, world, use.device, exchange, group,
                                 lane_depth) if exchange else None)
+            if stream is not None:
+                # the exchange buffers were zero-filled on the constructing stream: the lane's
+                # first write must come behind those fills
+                import torch
+                stream.wait_stream(torch.cuda.current_stream(use.device))
             self.lanes.append((use, stream, ex))
         self.exchange = self.lanes[0][2]
         self.count = 0
@@ -252,11 +281,24 @@ class ShardedStitcher:
     def _collect_oldest(self):
         use, stream, ex = self.lanes[self.order.pop(0)]
         with self._on(stream):
-            return ex.collect()
+            mosaic = ex.collect()
+        if stream is not None:
+            # collect()'s copies were queued on the lane's private stream: order the caller's
+            # current stream behind them, so that `mosaic.cpu()` or a kernel on the caller's
+            # stream never reads a half-written buffer
+            import torch
+            torch.cuda.current_stream(use.device).wait_stream(stream)
+        return mosaic
 
     def step(self, frames):
         """frames[j] = device tensor of camera my_frames[j].  Returns (plan, the mosaic of the
-        stitch ``depth - 1`` steps back on rank 0 / None, this rank's patches)."""
+        stitch ``depth - 1`` steps back on rank 0 / None, this rank's patches).
+
+        Stream contract: every lane works on a stream of its own; the mosaic handed back is
+        ordered behind the CALLER's current stream (the caller's stream waits for the lane's
+        copies before this returns), so work the caller queues on its current stream - or a
+        ``.cpu()`` - sees the finished mosaic.  The buffer stays valid until its lane has
+        taken ``depth`` more stitches."""
         if self.exchange is None:
             raise RuntimeError("ShardedStitcher(exchange=None) holds the strip geometry only "
                                "(emulate_on_one_device); step() needs an exchange mode")
@@ -283,7 +325,8 @@ class ShardedStitcher:
         return plan, previous, list(patches)          # window geometry only, not the arenas
 
     def finish(self):
-        """Completes the exchanges in flight; the last stitch's mosaic on rank 0."""
+        """Completes the exchanges in flight; the last stitch's mosaic on rank 0 (same stream
+        contract as ``step``: ordered behind the caller's current stream)."""
         last = None
         while self.order:
             last = self._collect_oldest()

@@ -899,10 +899,23 @@ class Engine:
         table, flags = getattr(self, "last_tiles", (None, None))
         if table is None:
             return 0
+        host = table.host
         if flags is None:
-            host = table.host
             return int((host["ah"].astype(np.int64) * host["aw"]).sum())
-        return int(flags[:table.n_tiles].to(_torch().int64).sum().item()) * 1024
+        if self.tile_grid == 32:
+            return int(flags[:table.n_tiles].to(_torch().int64).sum().item()) * 1024
+        # the vector-ALU kernels (Engine(blur="valu")) flag 64 x 128 column tiles of A
+        on = flags.cpu().numpy()
+        total = 0
+        for rec in host:
+            ntx, nty = (int(rec["aw"]) + 63) // 64, (int(rec["ah"]) + 127) // 128
+            if ntx * nty == 0:
+                continue
+            grid = on[int(rec["tiles_off"]):int(rec["tiles_off"]) + ntx * nty].reshape(nty, ntx)
+            wx = np.minimum(64, int(rec["aw"]) - 64 * np.arange(ntx))
+            wy = np.minimum(128, int(rec["ah"]) - 128 * np.arange(nty))
+            total += int((grid.astype(np.int64) * wy[:, None] * wx[None, :]).sum())
+        return total
 
     def compose_interior_async(self, owner, shape, strip, interior, cams, plan, luts,
                                want_float=False, mosaic_out=None):
@@ -1307,6 +1320,7 @@ class Engine:
         a.warp_need = {True: 1, False: 0}.get(self.warp_need, -1)
         a.max_spans, a.min_gap = max_spans, 2 * radius + 2
         resume = 0
+        a.layout.missing = a.layout.n_records = 0   # (an early failure must not read a previous stitch's)
         while True:
             arenas = [self._arenas.get(k) for k in ("planes", "blurred", "scratch")]
             for k, t in zip(("planes", "blurred", "scratch"), arenas):
@@ -1326,7 +1340,7 @@ class Engine:
                 ws["need"] = torch.empty(ws["cap_tiles"], dtype=torch.uint8, device=self.device)
             resume = 1
         if status != 0:
-            if a.layout.missing:
+            if status == _lib.EINVAL and a.layout.missing:
                 rec = ws["records_host"].numpy().view(PATCH_DTYPE)[:a.layout.n_records]
                 missing = sorted({int(i) for i in rec["index"] if not resident[int(i)]})
                 raise _lib.PanoError(f"frames {missing} are needed for columns [{strip[0]}, "

@@ -276,11 +276,19 @@ def ingest(path, shrink):
     ``cv2.resize(im, None, fx=1/shrink, fy=1/shrink)`` when shrink > 1 - on the device.
     Returns uint8 [h][w][3] device tensors."""
     from PIL import Image as PilImage
+    from PIL import ImageOps
     from . import blend as _blend
     files = [f for f in os.listdir(path) if any(f.endswith(ext) for ext in IMAGE_EXTENSIONS)]
-    imgs = [np.ascontiguousarray(np.asarray(PilImage.open(os.path.join(path, f)).convert("RGB"))
-                                 [..., ::-1]) for f in files]
-    return _blend.shrink_images(imgs, shrink)
+
+    def read(name):
+        # cv2.imread's defaults: the EXIF orientation applied (a phone's rotated JPEG arrives
+        # upright, with its shape swapped), 8 bits, three channels: 16-bit images are scaled
+        # down to 8 bits and an alpha channel is dropped, as IMREAD_COLOR does
+        im = ImageOps.exif_transpose(PilImage.open(os.path.join(path, name)))
+        if im.mode in ("I;16", "I;16B", "I;16L", "I"):
+            im = PilImage.fromarray((np.asarray(im).astype(np.uint32) >> 8).astype(np.uint8))
+        return np.ascontiguousarray(np.asarray(im.convert("RGB"))[..., ::-1])
+    return _blend.shrink_images([read(f) for f in files], shrink)
 
 
 def main(argv=None):
@@ -313,14 +321,14 @@ def main(argv=None):
     # (``img=None`` records: cameras only, a few hundred bytes per frame) or no cache at all.
     # Decoding is Pillow's, on the host; the resize runs on the device (``pano_resize_u8``)
     # and the shrunk frames stay there for ``stitch``.
-    if regions is None or any(reg.img is None for reg in regions):
+    if regions is None:
+        # (before anything is decoded or uploaded)
+        raise SystemExit(
+            f"{cache} not found: feature matching and bundle adjustment are outside this "
+            "build's scope; produce the camera cache with the reference (it is the pickle "
+            "written at stitcher.py:438-439) and re-run")
+    if any(reg.img is None for reg in regions):
         frames = ingest(args.path, args.shrink) if os.path.isdir(args.path) else []
-        if regions is None:
-            raise SystemExit(
-                f"{cache} not found ({len(frames)} images read and shrunk on the device): "
-                "feature matching and bundle adjustment are outside this build's scope; "
-                "produce the camera cache with the reference (it is the pickle written at "
-                "stitcher.py:438-439) and re-run")
         if len(frames) != len(regions):
             raise SystemExit(f"{cache} holds {len(regions)} cameras, {args.path} "
                              f"{len(frames)} images")

@@ -797,7 +797,21 @@ def test_cli_ingest_reads_and_shrinks_on_the_device(eng, oracle, tmp_path, monke
     want = oracle.stitch(shrunk, [rots[i] for i in order], [small_intr[i] for i in order], "linear")
     assert np.array_equal(got, want)
     os.remove(tmp_path / "ba_RIG_s2.0.pkl")
-    with pytest.raises(SystemExit, match="4 images read and shrunk"):
+    # a JPEG whose EXIF orientation says "rotated": cv2.imread applies the tag (its default),
+    # so does the ingest - the frame arrives upright with its shape swapped
+    from pano360_amd import stitcher as product
+    rot = tmp_path / "ROT"
+    rot.mkdir()
+    exif = PilImage.Exif()
+    exif[0x0112] = 6                          # rotate 90 degrees clockwise to display
+    PilImage.fromarray(np.ascontiguousarray(imgs[0][..., ::-1])).save(rot / "a.png", exif=exif)
+    frame = product.ingest(str(rot), 1)[0]
+    assert tuple(frame.shape) == (400, 240, 3)
+    assert np.array_equal(frame.cpu().numpy(), np.rot90(imgs[0], -1))
+    os.remove(tmp_path / "ba_RIG_s2.0.pkl")
+    # without the camera cache nothing is decoded or uploaded: the exit comes first
+    monkeypatch.setattr(product, "ingest", lambda *a: pytest.fail("ingest before the cache check"))
+    with pytest.raises(SystemExit, match="not found"):
         top.main([str(data), "--shrink", "2"])
 
 
