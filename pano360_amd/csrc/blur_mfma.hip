@@ -85,12 +85,12 @@ typedef const GLOBAL_AS float4u *gcf32x4;
 
 #ifdef MB_STAMP
 // phase timers (timing experiments only): [wave 0 | wave 4][phase] summed cycles, and counts
-__device__ unsigned long long g_mb_stamps[2][12];
+__device__ unsigned long long g_mb_stamps[4][12];
 #define STAMP(k)                                                                         \
     do {                                                                                 \
         if (stamped) {                                                                   \
             const unsigned long long now_ = __builtin_readcyclecounter();               \
-            if (lane == 0) atomicAdd(&g_mb_stamps[wv >> 2][k], now_ - tlast);            \
+            if (lane == 0) atomicAdd(&g_mb_stamps[(wv >> 2) & 1][k], now_ - tlast);      \
             tlast = __builtin_readcyclecounter();                                        \
         }                                                                                \
     } while (0)
@@ -508,7 +508,7 @@ __device__ __forceinline__ void mb_body(const pano_patch &p, const int ch, const
             STAMP(7);                                    // column pass
         }
 #ifdef MB_STAMP
-        if (stamped && lane == 0) atomicAdd(&g_mb_stamps[wv >> 2][11], 1ull);
+        if (stamped && lane == 0) atomicAdd(&g_mb_stamps[(wv >> 2) & 1][11], 1ull);
 #endif
         // bands up to the next wanted one only complete tiles
         const int upto = t1 < my_hi + 1 ? t1 : my_hi + 1;
@@ -1072,6 +1072,557 @@ __device__ __forceinline__ void ml_body(const pano_patch &p, const int ch, const
     }
 }
 
+// =====================================================================================
+// Round 4: the lean step as ONE basic block (MB_STREAM, default on; 0 = ml_body above).
+//
+// ml_body's step is a chain of phases - fetch, store, row pass, split, column pass, commit -
+// each behind wave-uniform branches (chunk exists? tile inside A? tile wanted? band wanted?),
+// so every phase is a basic block of its own and the compiler cannot move one phase's
+// vector instructions under another phase's matrix products: the two waves of a SIMD, in
+// lockstep behind the one barrier per step, issue their vector phases together (matrix pipe
+// idle) and their product chains together (vector issue idle).  A 32x32x16 product holds the
+// SIMD's vector issue for 8 of its 32 cycles (MI355X_MICROARCH.md): 24 cycles of every
+// product are free for other instructions of the SAME wave if they stand next to it in
+// program order.  Here the irregular cases are turned into DATA, so that a step is a short
+// scalar prologue and one straight-line block the scheduler can interleave:
+//   * every thread stages exactly 2.5 chunks (two 16-byte loads and one 8-byte load; a slot a
+//     narrower band does not fill repeats the thread's first chunk): no per-slot "chunk
+//     exists" branches;
+//   * a band whose 32 rows lie inside the patch and inside V (89 % of config 3's) gets its
+//     load offsets by ONE add per slot (row-independent part + 32 t pitch); the others take a
+//     branch in the prologue that computes the same three offsets the long way;
+//   * the finished tile is always stored by sixteen stores whose per-lane base is beyond the
+//     plane for lanes outside A's columns and for tiles nobody wants; only a tile cut by A's
+//     top or bottom row takes the masked path, in the prologue;
+//   * the column pass computes every tile within reach, wanted or not (85 % are; an unwanted
+//     tile's accumulator is never stored); a wave that wants nothing of a band skips both
+//     passes as a whole;
+//   * f32 -> (hi, lo) float16 is two instructions per value (v_fma_mixlo/hi_f16: hi =
+//     f16(v s), lo = f16(fma(v, s, -hi)), the same bits as ml_body's (v s) - hi: the
+//     difference is exact in float32), written into packed halves directly;
+//   * the column pass runs k-half-major (all tiles' first half-blocks, then their second):
+//     the second half of Mid is split under the first half's products.  Each accumulator
+//     still receives its products in ml_body's order: results are bit-identical.
+#ifndef MB_STREAM
+#define MB_STREAM 1
+#endif
+
+// (hi, lo) float16 pairs of floats scaled by the power of two s: hi = f16(v s), lo = f16(v s - hi),
+// two instructions per value (the compiler's own selection takes 3.5: it forms hi a second time
+// for the packed word).  v_fma_mix{lo,hi}_f16 writes one half of its destination and keeps the
+// other; a half written by one instruction is read two instructions later at the earliest
+// (forwarding of partial writes), and the trailing s_nop covers the reader that follows.
+// AFTER_MFMA: the inputs are the result of a matrix product that may still be in flight - the
+// compiler does not see into the statement, so the wait states it would insert are written out.
+template <bool AFTER_MFMA>
+__device__ __forceinline__ void ms_split4(const float a0, const float b0, const float a1,
+                                          const float b1, const float s, unsigned &h0,
+                                          unsigned &l0, unsigned &h1, unsigned &l1) {
+    if (AFTER_MFMA)
+        asm("s_nop 11\n\t"
+            "v_fma_mixlo_f16 %0, %4, %8, 0\n\t"
+            "v_fma_mixlo_f16 %2, %6, %8, 0\n\t"
+            "v_fma_mixhi_f16 %0, %5, %8, 0\n\t"
+            "v_fma_mixhi_f16 %2, %7, %8, 0\n\t"
+            "v_fma_mixlo_f16 %1, %4, %8, -%0 op_sel_hi:[0,0,1]\n\t"
+            "v_fma_mixlo_f16 %3, %6, %8, -%2 op_sel_hi:[0,0,1]\n\t"
+            "v_fma_mixhi_f16 %1, %5, %8, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+            "v_fma_mixhi_f16 %3, %7, %8, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+            "s_nop 0"
+            : "=&v"(h0), "=&v"(l0), "=&v"(h1), "=&v"(l1)
+            : "v"(a0), "v"(b0), "v"(a1), "v"(b1), "s"(s));
+    else
+    asm("v_fma_mixlo_f16 %0, %4, %8, 0\n\t"
+        "v_fma_mixlo_f16 %2, %6, %8, 0\n\t"
+        "v_fma_mixhi_f16 %0, %5, %8, 0\n\t"
+        "v_fma_mixhi_f16 %2, %7, %8, 0\n\t"
+        "v_fma_mixlo_f16 %1, %4, %8, -%0 op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixlo_f16 %3, %6, %8, -%2 op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixhi_f16 %1, %5, %8, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixhi_f16 %3, %7, %8, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+        "s_nop 0"
+        : "=&v"(h0), "=&v"(l0), "=&v"(h1), "=&v"(l1)
+        : "v"(a0), "v"(b0), "v"(a1), "v"(b1), "s"(s));
+}
+__device__ __forceinline__ void ms_split2(const float a, const float b, const float s, unsigned &h,
+                                          unsigned &l) {
+    asm("v_fma_mixlo_f16 %0, %2, %4, 0\n\t"
+        "v_fma_mixhi_f16 %0, %3, %4, 0\n\t"
+        "s_nop 0\n\t"
+        "v_fma_mixlo_f16 %1, %2, %4, -%0 op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixhi_f16 %1, %3, %4, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+        "s_nop 0"
+        : "=&v"(h), "=&v"(l)
+        : "v"(a), "v"(b), "s"(s));
+}
+
+template <int C, bool SHARP>
+__device__ __forceinline__ void ms_body(const pano_patch &p, const int ch, const int out_level,
+                                        const bool live, const half8 *s_tx, const half8 *s_ty,
+                                        const MbShared &sh, const uint32_t *list, const int nlist,
+                                        const int16_t *__restrict__ owner_, const int W,
+                                        const int tx0, const int second) {
+    constexpr int KS = 2 + 2 * C, DMAX = (C + 1) / 2, NB = 2 * DMAX + 1, Z = C & 1;
+    constexpr unsigned OOB = 0x80000000u;
+    typedef unsigned uint4v __attribute__((ext_vector_type(4)));
+    typedef unsigned uint2v __attribute__((ext_vector_type(2)));
+    typedef int int4v __attribute__((ext_vector_type(4)));
+    typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+    const int bstride = __builtin_amdgcn_readfirstlane(second);
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, n = lane & 31, h = lane >> 5;
+    const int tile = __builtin_amdgcn_readfirstlane(wv & 1);
+    const MbGeom g = mb_geom(p);
+    const int X0 = g.gx0 + 32 * tx0, px0 = X0 + 32 * tile;
+    const int P = sh.P, CM = sh.CM;
+    const int BW = MB_XT + 32 * CM, CPR = BW >> 2, NCH = 32 * CPR;
+    const int my_lo = g.O0 - DMAX, my_hi = g.O1 + DMAX;
+
+    f32x16 acc[NB];
+    const __amdgpu_buffer_rsrc_t dst = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)(p.blurred + (size_t)(out_level * 4 + ch) * p.ah * p.apitch), 0, p.ah * p.apitch * 4,
+        0x00020000);
+
+    // ---- this thread's 2.5 chunks ------------------------------------------------------
+    // slot 0, 1: chunk tid, 512 + tid (four columns, 16 bytes); slot 2: half (tid & 1) of chunk
+    // 1024 + tid / 2 (two columns).  c_off: the row-independent part of the load offset (colour:
+    // bytes into the plane; mask: bytes into the owner map), c_lds: where the hi halfs go.
+    // A slot beyond the band (a group whose reach is less than 3 K-steps has fewer chunks)
+    // repeats slot 0's chunk: the same bytes land on the same LDS halfs twice, no traffic
+    // beyond the L1.
+    int c_rr[3], c_lds[3];
+    unsigned c_off[3];
+    bool c_ok[3];
+#pragma unroll
+    for (int it = 0; it < 3; ++it) {
+        int c = it < 2 ? tid + 512 * it : 1024 + (tid >> 1);
+        int half = it == 2 ? (tid & 1) : 0;
+        if (c >= NCH) {
+            c = tid;
+            half = 0;
+        }
+        const int rr = c / CPR, c4 = c - rr * CPR;
+        const int colv = X0 - 16 * CM + 4 * c4 - p.vx0;          // the chunk's first column, in V
+        const int vc = colv + 2 * half;
+        c_ok[it] = colv >= 0 && colv + 4 <= p.vw;
+        c_rr[it] = rr;
+        c_lds[it] = (rr * P + 4 * c4 + 2 * half) * 2;
+        if (SHARP)
+            c_off[it] = c_ok[it] ? (unsigned)((p.y0 + rr) * W + p.x0 + p.vx0 + vc) * 2u : 0u;
+        else
+            c_off[it] = c_ok[it] ? (unsigned)((rr - p.vy0) * p.vpitch + vc) * 4u : OOB;
+    }
+    // bands [row_lo, row_hi): inside the patch and inside V, no reflection
+    const int row_lo = p.vy0 > 0 ? p.vy0 : 0;
+    const int row_hi = p.vy0 + p.vh < p.h ? p.vy0 + p.vh : p.h;
+    const unsigned long long src_base =
+        (unsigned long long)(SHARP ? (const void *)owner_
+                                   : (const void *)(p.planes + (size_t)ch * p.vh * p.vpitch));
+    int4v rs;                                            // colour: the plane as a buffer descriptor
+    rs[0] = __builtin_amdgcn_readfirstlane((int)(src_base & 0xffffffffull));
+    rs[1] = __builtin_amdgcn_readfirstlane((int)((src_base >> 32) & 0xffffull));
+    rs[2] = __builtin_amdgcn_readfirstlane(p.vh * p.vpitch * 4);
+    rs[3] = 0x00020000;
+    uint2v sbase2;                                       // mask: the owner map's address (scalar pair)
+    sbase2[0] = (unsigned)__builtin_amdgcn_readfirstlane((int)(src_base & 0xffffffffull));
+    sbase2[1] = (unsigned)__builtin_amdgcn_readfirstlane((int)(src_base >> 32));
+
+    struct Band {                   // a band in flight: the loads' destination registers
+        uint4v v0, v1;              // colour
+        uint2v v2;
+        unsigned e[10];             // mask: owner-map entries (4 + 4 + 2)
+    };
+    // The loads are inline assembly (the compiler's wait insertion must not see them: with the
+    // previous tile's stores pending on the same counter it would wait for vmcnt(0)), issued and
+    // consumed inside one step (see ml_body).
+    auto issue = [&](Band &pf, const unsigned (&voff)[3]) {
+        if (!SHARP) {
+            // (s_nop 4: the descriptor may have come back from a spill lane by v_readlane just
+            // before, and a vector-memory instruction may read a scalar register a vector
+            // instruction wrote only five wait states later - the compiler does not look into
+            // the statement)
+            asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(pf.v0) : "v"(voff[0]), "s"(rs) : "memory");
+            asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(pf.v1) : "v"(voff[1]), "s"(rs) : "memory");
+            asm volatile("buffer_load_dwordx2 %0, %1, %2, 0 offen" : "=v"(pf.v2) : "v"(voff[2]), "s"(rs) : "memory");
+        } else {
+            asm volatile("s_nop 4\n\t"
+                         "global_load_sshort %0, %4, %5\n\t"
+                         "global_load_sshort %1, %4, %5 offset:2\n\t"
+                         "global_load_sshort %2, %4, %5 offset:4\n\t"
+                         "global_load_sshort %3, %4, %5 offset:6"
+                         : "=&v"(pf.e[0]), "=&v"(pf.e[1]), "=&v"(pf.e[2]), "=&v"(pf.e[3])
+                         : "v"(voff[0]), "s"(sbase2) : "memory");
+            asm volatile("global_load_sshort %0, %4, %5\n\t"
+                         "global_load_sshort %1, %4, %5 offset:2\n\t"
+                         "global_load_sshort %2, %4, %5 offset:4\n\t"
+                         "global_load_sshort %3, %4, %5 offset:6"
+                         : "=&v"(pf.e[4]), "=&v"(pf.e[5]), "=&v"(pf.e[6]), "=&v"(pf.e[7])
+                         : "v"(voff[1]), "s"(sbase2) : "memory");
+            asm volatile("global_load_sshort %0, %2, %3\n\t"
+                         "global_load_sshort %1, %2, %3 offset:2"
+                         : "=&v"(pf.e[8]), "=&v"(pf.e[9])
+                         : "v"(voff[2]), "s"(sbase2) : "memory");
+        }
+    };
+    // registers -> LDS, in pieces (so that a piece fits the shadow of one matrix product):
+    //   commit_wait<N>: waits for the band's loads, not for the N stores issued behind them;
+    //   commit_piece<K>, K = 0 .. 2: slot K's values converted and written.
+    auto commit_wait = [&](Band &pf, auto n_c) {
+        constexpr int N = decltype(n_c)::value;
+        if (SHARP)
+            asm volatile("s_waitcnt vmcnt(%10)"
+                         : "+v"(pf.e[0]), "+v"(pf.e[1]), "+v"(pf.e[2]), "+v"(pf.e[3]), "+v"(pf.e[4]),
+                           "+v"(pf.e[5]), "+v"(pf.e[6]), "+v"(pf.e[7]), "+v"(pf.e[8]), "+v"(pf.e[9])
+                         : "n"(N) : "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(%3)" : "+v"(pf.v0), "+v"(pf.v1), "+v"(pf.v2) : "n"(N) : "memory");
+    };
+    const int lo_bytes_c = 32 * P * 2;
+    auto commit_piece = [&](Band &pf, const int (&okv)[3], const int buf, const int k) {
+        unsigned char *const base = (unsigned char *)sh.hi + 2 * buf;
+        if (!SHARP) {
+            const float in_scale = __builtin_bit_cast(
+                float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, MB_IN_SCALE)));
+            if (k < 2) {
+                const uint4v v = k ? pf.v1 : pf.v0;
+                unsigned h0, l0, h1, l1;
+                ms_split4<false>(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]),
+                                 __uint_as_float(v[3]), in_scale, h0, l0, h1, l1);
+                const uint2v hi = {h0, h1}, lo = {l0, l1};
+                *(uint2v *)(base + c_lds[k]) = hi;
+                *(uint2v *)(base + c_lds[k] + lo_bytes_c) = lo;
+            } else {
+                unsigned h2, l2;
+                ms_split2(__uint_as_float(pf.v2[0]), __uint_as_float(pf.v2[1]), in_scale, h2, l2);
+                *(unsigned *)(base + c_lds[2]) = h2;
+                *(unsigned *)(base + c_lds[2] + lo_bytes_c) = l2;
+            }
+        } else {                                         // stitcher.py:207-208: the 0 / 1 mask, no low part
+            const _Float16 one = (_Float16)MB_IN_SCALE, zero = (_Float16)0.0f;
+            if (k < 2) {
+                half4 hi;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) hi[j] = (int)pf.e[4 * k + j] == okv[k] ? one : zero;
+                *(half4 *)(base + c_lds[k]) = hi;
+            } else {
+                half2v h2;
+                h2[0] = (int)pf.e[8] == okv[2] ? one : zero;
+                h2[1] = (int)pf.e[9] == okv[2] ? one : zero;
+                *(half2v *)(base + c_lds[2]) = h2;
+            }
+        }
+    };
+    auto word_at = [&](const int i) -> unsigned {
+        return (unsigned)__builtin_amdgcn_readfirstlane((int)list[i]);
+    };
+    auto band_of = [](const unsigned w) { return (int)(short)(w & 0xffffu); };
+    const unsigned keep = live ? 0x1fu : 0u;
+    auto bits_of = [&](const unsigned w) { return (w >> (16 + 8 * tile)) & keep; };
+    if (nlist <= 0) return;                               // uniform
+
+    // store geometry: per lane the column part of a tile's offset (beyond the plane outside A)
+    const int ax = px0 + n - p.ax0;
+    const unsigned s_lane = (unsigned)ax < (unsigned)p.aw ? (unsigned)(4 * h * p.apitch + ax) * 4u : OOB;
+    const int rowstep = p.apitch * 4;
+    // operand addresses that do not change: this lane's band row / Toeplitz columns
+    const int a_lane = (n * P + 16 * (CM - C) + 32 * tile + 8 * h) * 2;        // bytes from sh.hi
+    const int lo_bytes = 32 * P * 2;
+
+    int i = 0;
+    unsigned word = word_at(0);
+    int prev_o = 0, prev_u = 0;
+    bool prev_store = false;
+    auto store_prev_generic = [&]() {                    // the run's last tile (outside the step)
+        switch (prev_u) {
+#define MS_STORE_CASE(UU)                                                                      \
+    case UU:                                                                                   \
+        if constexpr (UU < NB)                                                                 \
+            ml_store(acc[(UU + DMAX + 1) % NB], prev_o, lane, p, dst, px0, prev_store);        \
+        break;
+            MS_STORE_CASE(0) MS_STORE_CASE(1) MS_STORE_CASE(2) MS_STORE_CASE(3) MS_STORE_CASE(4)
+#undef MS_STORE_CASE
+        }
+        prev_store = false;
+    };
+    // the offsets of band tb's chunks (and, for the mask, the owner value that counts as "ours")
+    auto offsets = [&](const int tb, const bool exists, unsigned (&voff)[3], int (&okv)[3]) {
+        const bool inside = exists && 32 * tb >= row_lo && 32 * tb + 32 <= row_hi;     // uniform
+        if (inside) {
+            const unsigned s_off = (unsigned)(32 * tb) * (unsigned)(SHARP ? W * 2 : p.vpitch * 4);
+#pragma unroll
+            for (int it = 0; it < 3; ++it) {
+                voff[it] = c_off[it] + s_off;            // (beyond the plane stays beyond it)
+                okv[it] = c_ok[it] ? p.index : -2;
+            }
+        } else {
+#pragma unroll
+            for (int it = 0; it < 3; ++it) {
+                const int prow = 32 * tb + c_rr[it];
+                const int ry = prow < 0 ? -prow : (prow >= p.h ? 2 * p.h - 2 - prow : prow);
+                const int vr = ry - p.vy0;
+                const bool ok = exists && c_ok[it] && (unsigned)vr < (unsigned)p.vh;
+                if (SHARP)
+                    voff[it] = ok ? c_off[it] + (unsigned)(ry - c_rr[it]) * (unsigned)(W * 2) : 0u;
+                else
+                    voff[it] = ok ? c_off[it] + (unsigned)(ry - c_rr[it]) * (unsigned)(p.vpitch * 4) : OOB;
+                okv[it] = ok ? p.index : -2;
+            }
+        }
+    };
+#ifdef MB_STAMP
+    // phase timers (timing experiments only): waves 0, 2, 4, 6 of a sample of colour workgroups
+#ifndef MB_STAMP_CH
+#define MB_STAMP_CH 0
+#endif
+    const bool stamped = (wv & 1) == 0 && ch == MB_STAMP_CH && (blockIdx.x >> 2) % 7 == 3;
+    unsigned long long tlast = __builtin_readcyclecounter();
+#define MS_STAMP(k)                                                                      \
+    do {                                                                                 \
+        if (stamped) {                                                                   \
+            const unsigned long long now_ = __builtin_readcyclecounter();               \
+            if (lane == 0) atomicAdd(&g_mb_stamps[wv >> 1][k], now_ - tlast);            \
+            tlast = __builtin_readcyclecounter();                                        \
+        }                                                                                \
+    } while (0)
+#else
+#define MS_STAMP(k) do { } while (0)
+#endif
+    int off_cur = __builtin_amdgcn_readfirstlane(0), off_nxt = bstride;
+    {
+        Band pf;
+        unsigned voff[3];
+        int okv[3];
+        offsets(band_of(word), true, voff, okv);
+        issue(pf, voff);
+        commit_wait(pf, std::integral_constant<int, 0>{});      // (no stores behind these loads)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) commit_piece(pf, okv, off_cur, k);
+    }
+    auto step = [&](auto u_c) -> bool {
+        constexpr int U = decltype(u_c)::value;
+        constexpr int KP = (U + DMAX) % NB;              // the tile last step's band completed
+        const int t = band_of(word);
+        const unsigned inf = bits_of(word);
+        const bool more = i + 1 < nlist;
+        const unsigned next = more ? word_at(i + 1) : 0u;
+        off_cur = __builtin_amdgcn_readfirstlane(off_cur);
+        off_nxt = __builtin_amdgcn_readfirstlane(off_nxt);
+        asm volatile("" : "+s"(off_cur), "+s"(off_nxt));
+        MS_STAMP(0);                // the step's scalar head
+        lds_barrier();              // band i is whole; nobody reads the other buffer any more
+        MS_STAMP(1);                // waiting at the barrier
+        // ---- prologue: the next band's load offsets, the finished tile's store base
+        Band pf;
+        unsigned voff[3];
+        int okv[3];
+        offsets(band_of(next), more, voff, okv);
+        const int o = prev_o;
+        const bool rows_in = 32 * o >= p.ay0 && 32 * o + 32 <= p.ay0 + p.ah;           // uniform
+        if (prev_store && !rows_in) {                    // cut by A's first or last row: rare
+            ml_store(acc[KP], o, lane, p, dst, px0, true);
+            prev_store = false;
+            // (its sixteen stores stand where the block's would: the block's are dropped below)
+        }
+        // (a lane outside A's columns: beyond the plane plus less than a plane stays beyond it)
+        const unsigned s_at = prev_store ? s_lane + (unsigned)((32 * o - p.ay0) * p.apitch) * 4u : OOB;
+        const bool work = t >= my_lo && t <= my_hi && inf != 0;                        // uniform
+        // ---- the block.  Its order is written out by hand and pinned: the scheduler may not
+        // move anything across a sched_barrier(0), so every product is followed by the few
+        // vector / memory instructions that are to issue in its shadow (a 32x32x16 product
+        // occupies the matrix pipe for 32 cycles and the SIMD's vector issue for 8 of them).
+#define MS_PIN() __builtin_amdgcn_sched_barrier(0)
+        auto block = [&](auto work_c) {
+            constexpr bool WORK = decltype(work_c)::value;
+            constexpr int PR = SHARP ? 2 : 3;            // products per k-step of the row pass
+            constexpr int BLK = NB - Z;                  // stored half-blocks per k half of the column pass
+            // the block's gaps (one behind every product), numbered through both passes
+            constexpr int GR = KS * PR, GC = 2 * BLK * 3, G = GR + GC;
+            constexpr int PER_R = (16 + GR - 1) / GR;    // scaled values per row-pass gap
+            constexpr int G_COMMIT = GR + BLK * 3;       // first gap of the column pass's second half
+            MS_STAMP(2);            // prologue
+            issue(pf, voff);
+            MS_PIN();
+            // (opaque: the same product with the literal stands in ml_store, and the compiler
+            // would compute the sixteen of them once, in front of the branch that leads here)
+            float out_scale = MB_OUT_SCALE;
+            asm("" : "+s"(out_scale));
+            // The finished tile: scaled during the first gaps, stored at an even pace over ALL the
+            // block's gaps.  (A CU passes one dword store instruction per ~11 cycles, 128 of them
+            // per step for its eight waves: issued back to back behind the barrier they made the
+            // row pass 2.5 - 3.3 k cycles long for 0.8 k cycles of products - phase timers,
+            // profiles/r04/notes.md.)
+            float sc[16];
+            auto store_gap = [](const int q) { return ((2 * q + 1) * G) / 32; };
+            auto fill = [&](const int g) {               // what issues in gap g's shadow
+                if (g < GR) {
+#pragma unroll
+                    for (int c = 0; c < PER_R; ++c) {
+                        const int q = g * PER_R + c;
+                        if (q < 16) sc[q] = acc[KP][q] * out_scale;
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < 16; ++q)
+                    if (store_gap(q) == g)
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(sc[q]), dst, s_at,
+                                                              ((q & 3) + 8 * (q >> 2)) * rowstep, 0);
+            };
+            constexpr int stores_before_commit = [] {
+                int n = 0;
+                for (int q = 0; q < 16; ++q) n += ((2 * q + 1) * G) / 32 < G_COMMIT ? 1 : 0;
+                return n;
+            }();
+            if constexpr (!WORK) {
+#pragma unroll
+                for (int g = 0; g < G; ++g) fill(g);
+                MS_PIN();
+                commit_wait(pf, std::integral_constant<int, 16>{});
+#pragma unroll
+                for (int k = 0; k < 3; ++k) commit_piece(pf, okv, off_nxt, k);
+            } else {
+                // row pass: the operands of k-step s + 1 are read while k-step s multiplies
+                const unsigned char *const arow = (const unsigned char *)sh.hi + a_lane + 2 * off_cur;
+                f32x16 mid;
+#pragma unroll
+                for (int q = 0; q < 16; ++q) mid[q] = 0.0f;
+                half8 a_hi[2], a_lo[2], b_hi[2], b_lo[2];
+                auto operands = [&](const int s, const int b) {
+                    a_hi[b] = *(const half8 *)(arow + 32 * s);
+                    b_hi[b] = s_tx[(s * 2) * 64 + lane];
+                    b_lo[b] = s_tx[(s * 2 + 1) * 64 + lane];
+                    if (!SHARP) a_lo[b] = *(const half8 *)(arow + lo_bytes + 32 * s);
+                };
+                operands(0, 0);
+#pragma unroll
+                for (int s = 0; s < KS; ++s) {
+                    const int cur = s & 1;
+                    if (s + 1 < KS) operands(s + 1, cur ^ 1);
+                    MS_PIN();
+#pragma unroll
+                    for (int m = 0; m < PR; ++m) {
+                        mid = __builtin_amdgcn_mfma_f32_32x32x16_f16(
+                            m == 2 ? a_lo[cur] : a_hi[cur], m == 1 ? b_lo[cur] : b_hi[cur], mid, 0, 0, 0);
+                        MS_PIN();
+                        fill(s * PR + m);
+                        MS_PIN();
+                    }
+                }
+                MS_STAMP(3);        // row pass
+                // column pass, k-half-major.  Block b = (half, d): two operand reads and three
+                // products; the operands of block b + 1 are read in front of block b's products;
+                // the second half of Mid is split under the first half's products, the next
+                // band is converted and written to LDS under the second half's.
+                unsigned m_hi[2][4], m_lo[2][4];          // eight float16 each: the B operands
+                auto operand_b = [](const unsigned (&w)[4]) {
+                    const uint4v v = {w[0], w[1], w[2], w[3]};
+                    return __builtin_bit_cast(half8, v);
+                };
+                const float mid_scale = __builtin_bit_cast(
+                    float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, MB_MID_SCALE)));
+                half8 t_hi[2], t_lo[2];
+                auto ty_read = [&](const int bb, const int buf) {       // bb = s2 * BLK + b
+                    const int s2 = bb / BLK, b = bb - s2 * BLK;
+                    const int d = -DMAX + b + (Z && s2 == 0 ? 1 : 0);
+                    const half8 *ty = s_ty + (((d + DMAX) * 2 + s2 - Z) * 2) * 64 + lane;
+                    t_hi[buf] = ty[0];
+                    t_lo[buf] = ty[64];
+                };
+                ty_read(0, 0);
+                MS_PIN();
+                ms_split4<true>(mid[0], mid[1], mid[2], mid[3], mid_scale, m_hi[0][0], m_lo[0][0],
+                                m_hi[0][1], m_lo[0][1]);
+                ms_split4<false>(mid[4], mid[5], mid[6], mid[7], mid_scale, m_hi[0][2], m_lo[0][2],
+                                 m_hi[0][3], m_lo[0][3]);
+                MS_PIN();
+                constexpr int GAPS_H = BLK * 3, PAIRS_PER = (4 + GAPS_H - 1) / GAPS_H;
+#pragma unroll
+                for (int bb = 0; bb < 2 * BLK; ++bb) {
+                    const int s2 = bb / BLK, b = bb - s2 * BLK, buf = bb & 1;
+                    const int d = -DMAX + b + (Z && s2 == 0 ? 1 : 0);
+                    const int k = ((U - d) % NB + NB) % NB;          // tile t - d lives in accumulator k
+                    const bool first = d == -DMAX && s2 == Z;        // starts tile t + DMAX's sum
+                    if (bb + 1 < 2 * BLK) ty_read(bb + 1, buf ^ 1);
+                    MS_PIN();
+#pragma unroll
+                    for (int m = 0; m < 3; ++m) {
+                        if (m == 0 && first) {
+                            f32x16 zero;
+#pragma unroll
+                            for (int q = 0; q < 16; ++q) zero[q] = 0.0f;
+                            acc[k] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
+                                t_hi[buf], operand_b(m_hi[s2]), zero, 0, 0, 0);
+                        } else {
+                            acc[k] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
+                                m == 1 ? t_lo[buf] : t_hi[buf],
+                                operand_b(m == 2 ? m_lo[s2] : m_hi[s2]), acc[k], 0, 0, 0);
+                        }
+                        MS_PIN();
+                        const int hg = b * 3 + m;                    // gap within this half
+                        if (s2 == 0) {
+#pragma unroll
+                            for (int c = 0; c < PAIRS_PER; ++c) {
+                                const int pr = hg * PAIRS_PER + c;
+                                if (pr < 4)
+                                    ms_split2(mid[8 + 2 * pr], mid[9 + 2 * pr], mid_scale, m_hi[1][pr],
+                                              m_lo[1][pr]);
+                            }
+                        } else {
+                            // (the loads were issued some 3 k cycles ago; the stores issued since
+                            // stay in flight)
+                            if (hg == 0)
+                                commit_wait(pf, std::integral_constant<int, stores_before_commit>{});
+                            if (hg < 3) commit_piece(pf, okv, off_nxt, hg);
+                        }
+                        fill(GR + s2 * GAPS_H + hg);
+                        MS_PIN();
+                    }
+                }
+                MS_STAMP(4);        // split + column pass (+ the next band's conversion)
+            }
+            MS_PIN();
+            MS_STAMP(5);
+#ifdef MB_STAMP
+            if (stamped && lane == 0) atomicAdd(&g_mb_stamps[wv >> 1][11], 1ull);
+#endif
+        };
+#ifdef MS_SKIP_IDLE
+        if (work)
+            block(std::true_type{});
+        else
+            block(std::false_type{});
+#else
+        (void)work;
+        block(std::true_type{});
+#endif
+        prev_store = (inf >> (DMAX + 2)) & 1u;           // tile t - DMAX is wanted: complete now
+        prev_o = t - DMAX;
+        prev_u = U;
+        word = next;
+        {
+            const int tmp = off_cur;
+            off_cur = off_nxt;
+            off_nxt = tmp;
+        }
+        ++i;
+        return more && band_of(next) == t + 1;
+    };
+    while (i < nlist) {                                  // one run per trip
+#pragma unroll
+        for (int k = 0; k < NB; ++k)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[k][q] = 0.0f;
+        for (;;) {
+            if (!step(std::integral_constant<int, 0>{})) break;
+            if (!step(std::integral_constant<int, 1>{})) break;
+            if (!step(std::integral_constant<int, 2>{})) break;
+            if constexpr (NB > 3) {
+                if (!step(std::integral_constant<int, 3>{})) break;
+                if (!step(std::integral_constant<int, 4>{})) break;
+            }
+        }
+        if (prev_store) store_prev_generic();            // the run's last tile, before the reset
+    }
+}
+
 __global__ __launch_bounds__(MB_THREADS_OF(4), 1) void blur_lean_kernel(
     const pano_patch *__restrict__ table, MbLevels L, const unsigned char *__restrict__ tables,
     const int16_t *__restrict__ owner, int W, const uint8_t *__restrict__ flags,
@@ -1185,12 +1736,17 @@ __global__ __launch_bounds__(MB_THREADS_OF(4), 1) void blur_lean_kernel(
     const int out_level = L.out[level];
     // the second band buffer lies behind the group's tables (the host sized the LDS for it)
     const int second = (mb_fixed_bytes(sh.CM) + rel + 15) / 16 * 8;     // halfs from sh.hi
+#if MB_STREAM
+#define ML_BODY_FN ms_body
+#else
+#define ML_BODY_FN ml_body
+#endif
     switch (c) {                                         // wave-uniform
 #define ML_BODY(CC)                                                                            \
     if (ch == 3)                                                                               \
-        ml_body<CC, true>(p, ch, out_level, live, s_tx, s_ty, sh, list, nlist, owner, W, tx0, second); \
+        ML_BODY_FN<CC, true>(p, ch, out_level, live, s_tx, s_ty, sh, list, nlist, owner, W, tx0, second); \
     else                                                                                       \
-        ml_body<CC, false>(p, ch, out_level, live, s_tx, s_ty, sh, list, nlist, owner, W, tx0, second); \
+        ML_BODY_FN<CC, false>(p, ch, out_level, live, s_tx, s_ty, sh, list, nlist, owner, W, tx0, second); \
     break;
         case 1: ML_BODY(1)
         case 2: ML_BODY(2)
@@ -1452,9 +2008,9 @@ static inline int mb_sorted_slots(int cap) { return (cap + MB_SEG_SLOTS + 1) & ~
 // after the PANO_TAP_LEAD ones.
 #ifdef MB_STAMP
 extern "C" int pano_debug_stamps(unsigned long long *out, int reset) {
-    if (out) PANO_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_mb_stamps), sizeof(unsigned long long) * 24));
+    if (out) PANO_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_mb_stamps), sizeof(unsigned long long) * 48));
     if (reset) {
-        unsigned long long zero[24] = {};
+        unsigned long long zero[48] = {};
         PANO_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_mb_stamps), zero, sizeof(zero)));
     }
     return PANO_OK;
@@ -1638,6 +2194,9 @@ static int launch_levels(pano_ctx *ctx, const pano_patch *table, int n, int max_
     for (int i = 0; i < cnt; ++i)
         if (L.ntaps[i] < 3) lean = 0;
     int lds_lean = lds;
+    if (MB_STREAM)               // (ms_body stages at most 1280 chunks per band: a reach of 3 K-steps)
+        for (int i = 0; i < cnt; ++i)
+            if (mb_c_of(L.ntaps[i]) > 3) lean = 0;
     if (ML_OVERLAP) {            // + the second band buffer, behind the largest group's tables
         lds_lean = 0;
         for (int gidx = 0; gidx < ngroups; ++gidx) {

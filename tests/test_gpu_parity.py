@@ -808,7 +808,6 @@ def test_cli_ingest_reads_and_shrinks_on_the_device(eng, oracle, tmp_path, monke
     frame = product.ingest(str(rot), 1)[0]
     assert tuple(frame.shape) == (400, 240, 3)
     assert np.array_equal(frame.cpu().numpy(), np.rot90(imgs[0], -1))
-    os.remove(tmp_path / "ba_RIG_s2.0.pkl")
     # without the camera cache nothing is decoded or uploaded: the exit comes first
     monkeypatch.setattr(product, "ingest", lambda *a: pytest.fail("ingest before the cache check"))
     with pytest.raises(SystemExit, match="not found"):

@@ -1,0 +1,11 @@
+#!/bin/bash
+# GPU parity tests, then an A/B of library variants on a workload:
+#   tools/gpu_visit_ab.sh <tag> <workload> <reps> base VARIANT...
+set -u
+cd "${GRAFT_REPO_ROOT:-/root/repo}"
+T=$1; WL=$2; REPS=$3; shift; shift; shift
+OUT=gpurun_out/$T
+mkdir -p "$OUT"
+timeout -k 10 1200 python -m pytest tests -m gpu -x -q > "$OUT/pytest_gpu.log" 2>&1; rc=$?; tail -15 "$OUT/pytest_gpu.log"
+[ $rc -ne 0 ] && echo "TESTS FAILED rc=$rc"
+tools/ab_libs.sh "$WL" "$REPS" "$@" | tee "$OUT/ab_$WL.txt"

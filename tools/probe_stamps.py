@@ -15,10 +15,18 @@ for it in range(3):
     plan = engine.Plan(shapes, rots, intrs, True, 10 ** 9)
     eng.stitch(frames, plan, "multiband", int(os.environ.get("LEVELS", "5")))
     torch.cuda.synchronize()
-    buf = (C.c_ulonglong * 24)()
+    buf = (C.c_ulonglong * 48)()
     lib.pano_debug_stamps(buf, 1)
-names = ["skeleton", "barrier 1", "conversion", "barrier 2", "stores", "fetch", "row pass", "column pass"]
-for w in range(2):
-    v = np.array(buf[12 * w:12 * w + 12], dtype=np.float64)
-    n = max(v[11], 1)
-    print("wave", 4 * w, "steps", int(v[11]), " ".join(f"{nm} {v[k] / n:.0f}" for k, nm in enumerate(names)), "| sum %.0f" % (v[:8].sum() / n))
+if os.environ.get("STAMP_FORM", "stream") == "stream":    # ms_body: waves 0, 2, 4, 6
+    names = ["head", "barrier", "prologue", "row pass + stores", "split + column pass", "wait + commit"]
+    for w in range(4):
+        v = np.array(buf[12 * w:12 * w + 12], dtype=np.float64)
+        n = max(v[11], 1)
+        print("wave", 2 * w, "steps", int(v[11]), " | ".join(f"{nm} {v[k] / n:.0f}" for k, nm in enumerate(names)),
+              "| sum %.0f" % (v[:6].sum() / n))
+else:
+    names = ["skeleton", "barrier 1", "conversion", "barrier 2", "stores", "fetch", "row pass", "column pass"]
+    for w in range(2):
+        v = np.array(buf[12 * w:12 * w + 12], dtype=np.float64)
+        n = max(v[11], 1)
+        print("wave", 4 * w, "steps", int(v[11]), " ".join(f"{nm} {v[k] / n:.0f}" for k, nm in enumerate(names)), "| sum %.0f" % (v[:8].sum() / n))
