@@ -576,7 +576,7 @@ template <int GROUP>
 __device__ __forceinline__ void mb_general(
     const pano_patch *__restrict__ table, const MbLevels &L, const unsigned char *__restrict__ tables,
     const int16_t *__restrict__ owner, int W, const uint8_t *__restrict__ flags,
-    const int2 *__restrict__ items, unsigned char *smem) {
+    const int2 *__restrict__ items, unsigned char *smem, const int work) {
     const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
     // the items - (record, first tile column of a pair) - are sorted by decreasing length
     // (mb_sort_kernel), so the hardware's in-order dispatch starts the long strips first
@@ -586,7 +586,7 @@ __device__ __forceinline__ void mb_general(
     // fetches find part of the band in that L2 (config 5, three groups: 15.2 -> 11.9 GB of reads
     // per launch, measured; one pass over the windows is 4.8 GB; the time did not change).
     const int ngroups = (L.n + GROUP - 1) / GROUP;
-    const int per = 8 * ngroups, blk = blockIdx.x / per, within = blockIdx.x - blk * per;
+    const int per = 8 * ngroups, blk = work / per, within = work - blk * per;
     const int grp = within >> 3, pair = blk * 8 + (within & 7);
     const int ch = pair & 3, slot = pair >> 2;
     const int2 item = items[slot];
@@ -694,7 +694,7 @@ __global__ __launch_bounds__(MB_THREADS_OF(GROUP), 4 / GROUP) void blur_mfma_ker
     const int16_t *__restrict__ owner, int W, const uint8_t *__restrict__ flags,
     const int2 *__restrict__ items) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    mb_general<GROUP>(table, L, tables, owner, W, flags, items, smem);
+    mb_general<GROUP>(table, L, tables, owner, W, flags, items, smem, (int)blockIdx.x);
 }
 
 
@@ -1234,7 +1234,14 @@ __device__ __forceinline__ void ms_body(const pano_patch &p, const int ch, const
     // The loads are inline assembly (the compiler's wait insertion must not see them: with the
     // previous tile's stores pending on the same counter it would wait for vmcnt(0)), issued and
     // consumed inside one step (see ml_body).
-    auto issue = [&](Band &pf, const unsigned (&voff)[3]) {
+    auto issue = [&](Band &pf, const unsigned (&voff_)[3]) {
+#ifdef MS_ABL_NOLOAD                                      // timing experiment: no band traffic
+        unsigned none[3] = {SHARP ? 0u : OOB, SHARP ? 0u : OOB, SHARP ? 0u : OOB};
+        const unsigned (&voff)[3] = none;
+        (void)voff_;
+#else
+        const unsigned (&voff)[3] = voff_;
+#endif
         if (!SHARP) {
             // (s_nop 4: the descriptor may have come back from a spill lane by v_readlane just
             // before, and a vector-memory instruction may read a scalar register a vector
@@ -1343,29 +1350,32 @@ __device__ __forceinline__ void ms_body(const pano_patch &p, const int ch, const
         }
         prev_store = false;
     };
-    // the offsets of band tb's chunks (and, for the mask, the owner value that counts as "ours")
-    auto offsets = [&](const int tb, const bool exists, unsigned (&voff)[3], int (&okv)[3]) {
-        const bool inside = exists && 32 * tb >= row_lo && 32 * tb + 32 <= row_hi;     // uniform
-        if (inside) {
-            const unsigned s_off = (unsigned)(32 * tb) * (unsigned)(SHARP ? W * 2 : p.vpitch * 4);
+    // The offsets of band tb's chunks (and, for the mask, the owner value that counts as "ours").
+    // A band whose 32 rows lie inside the patch and inside V: one add per slot; any other band
+    // (rows that reflect, rows beyond V, no band at all): the long way, under a branch.
+    auto band_inside = [&](const int tb, const bool exists) {
+        return exists && 32 * tb >= row_lo && 32 * tb + 32 <= row_hi;                  // uniform
+    };
+    auto offsets_fast = [&](const int tb, unsigned (&voff)[3], int (&okv)[3]) {
+        const unsigned s_off = (unsigned)(32 * tb) * (unsigned)(SHARP ? W * 2 : p.vpitch * 4);
 #pragma unroll
-            for (int it = 0; it < 3; ++it) {
-                voff[it] = c_off[it] + s_off;            // (beyond the plane stays beyond it)
-                okv[it] = c_ok[it] ? p.index : -2;
-            }
-        } else {
+        for (int it = 0; it < 3; ++it) {
+            voff[it] = c_off[it] + s_off;                // (beyond the plane stays beyond it)
+            okv[it] = c_ok[it] ? p.index : -2;
+        }
+    };
+    auto offsets_general = [&](const int tb, const bool exists, unsigned (&voff)[3], int (&okv)[3]) {
 #pragma unroll
-            for (int it = 0; it < 3; ++it) {
-                const int prow = 32 * tb + c_rr[it];
-                const int ry = prow < 0 ? -prow : (prow >= p.h ? 2 * p.h - 2 - prow : prow);
-                const int vr = ry - p.vy0;
-                const bool ok = exists && c_ok[it] && (unsigned)vr < (unsigned)p.vh;
-                if (SHARP)
-                    voff[it] = ok ? c_off[it] + (unsigned)(ry - c_rr[it]) * (unsigned)(W * 2) : 0u;
-                else
-                    voff[it] = ok ? c_off[it] + (unsigned)(ry - c_rr[it]) * (unsigned)(p.vpitch * 4) : OOB;
-                okv[it] = ok ? p.index : -2;
-            }
+        for (int it = 0; it < 3; ++it) {
+            const int prow = 32 * tb + c_rr[it];
+            const int ry = prow < 0 ? -prow : (prow >= p.h ? 2 * p.h - 2 - prow : prow);
+            const int vr = ry - p.vy0;
+            const bool ok = exists && c_ok[it] && (unsigned)vr < (unsigned)p.vh;
+            if (SHARP)
+                voff[it] = ok ? c_off[it] + (unsigned)(ry - c_rr[it]) * (unsigned)(W * 2) : 0u;
+            else
+                voff[it] = ok ? c_off[it] + (unsigned)(ry - c_rr[it]) * (unsigned)(p.vpitch * 4) : OOB;
+            okv[it] = ok ? p.index : -2;
         }
     };
 #ifdef MB_STAMP
@@ -1373,7 +1383,7 @@ __device__ __forceinline__ void ms_body(const pano_patch &p, const int ch, const
 #ifndef MB_STAMP_CH
 #define MB_STAMP_CH 0
 #endif
-    const bool stamped = (wv & 1) == 0 && ch == MB_STAMP_CH && (blockIdx.x >> 2) % 7 == 3;
+    const bool stamped = (wv & 1) == 0 && ch == MB_STAMP_CH && blockIdx.x % 7 == 3;
     unsigned long long tlast = __builtin_readcyclecounter();
 #define MS_STAMP(k)                                                                      \
     do {                                                                                 \
@@ -1387,15 +1397,28 @@ __device__ __forceinline__ void ms_body(const pano_patch &p, const int ch, const
 #define MS_STAMP(k) do { } while (0)
 #endif
     int off_cur = __builtin_amdgcn_readfirstlane(0), off_nxt = bstride;
+    // What a step finds prepared (by the step before it, in the shadow of its products; by the
+    // lines below for the first step): the offsets of the chunks it will fetch - band i + 1's -
+    // assuming that band lies inside (fetch_general: it does not, the step's head computes them
+    // the long way), and the finished tile's store base (store_edge: the tile is cut by A's
+    // first or last row, the head stores it under masks).
+    unsigned voff[3];
+    int okv[3];
+    unsigned next = nlist > 1 ? word_at(1) : 0u;        // band i + 1's word
+    unsigned s_at = OOB;
+    bool store_edge = false, fetch_general;
     {
         Band pf;
-        unsigned voff[3];
-        int okv[3];
-        offsets(band_of(word), true, voff, okv);
+        if (band_inside(band_of(word), true))
+            offsets_fast(band_of(word), voff, okv);
+        else
+            offsets_general(band_of(word), true, voff, okv);
         issue(pf, voff);
         commit_wait(pf, std::integral_constant<int, 0>{});      // (no stores behind these loads)
 #pragma unroll
         for (int k = 0; k < 3; ++k) commit_piece(pf, okv, off_cur, k);
+        offsets_fast(band_of(next), voff, okv);
+        fetch_general = !band_inside(band_of(next), nlist > 1);
     }
     auto step = [&](auto u_c) -> bool {
         constexpr int U = decltype(u_c)::value;
@@ -1403,33 +1426,30 @@ __device__ __forceinline__ void ms_body(const pano_patch &p, const int ch, const
         const int t = band_of(word);
         const unsigned inf = bits_of(word);
         const bool more = i + 1 < nlist;
-        const unsigned next = more ? word_at(i + 1) : 0u;
         off_cur = __builtin_amdgcn_readfirstlane(off_cur);
         off_nxt = __builtin_amdgcn_readfirstlane(off_nxt);
         asm volatile("" : "+s"(off_cur), "+s"(off_nxt));
         MS_STAMP(0);                // the step's scalar head
         lds_barrier();              // band i is whole; nobody reads the other buffer any more
         MS_STAMP(1);                // waiting at the barrier
-        // ---- prologue: the next band's load offsets, the finished tile's store base
+        // ---- the rare cases the previous step left to this one
         Band pf;
-        unsigned voff[3];
-        int okv[3];
-        offsets(band_of(next), more, voff, okv);
-        const int o = prev_o;
-        const bool rows_in = 32 * o >= p.ay0 && 32 * o + 32 <= p.ay0 + p.ah;           // uniform
-        if (prev_store && !rows_in) {                    // cut by A's first or last row: rare
-            ml_store(acc[KP], o, lane, p, dst, px0, true);
-            prev_store = false;
-            // (its sixteen stores stand where the block's would: the block's are dropped below)
-        }
-        // (a lane outside A's columns: beyond the plane plus less than a plane stays beyond it)
-        const unsigned s_at = prev_store ? s_lane + (unsigned)((32 * o - p.ay0) * p.apitch) * 4u : OOB;
+        unsigned nn = 0;                                 // the list word after next (prepare_next)
+        if (fetch_general) offsets_general(band_of(next), more, voff, okv);
+        if (store_edge)                                  // cut by A's first or last row
+            ml_store(acc[KP], prev_o, lane, p, dst, px0, true);
+        // (its sixteen stores stand in front of the block's, whose base is beyond the plane then)
         const bool work = t >= my_lo && t <= my_hi && inf != 0;                        // uniform
         // ---- the block.  Its order is written out by hand and pinned: the scheduler may not
         // move anything across a sched_barrier(0), so every product is followed by the few
         // vector / memory instructions that are to issue in its shadow (a 32x32x16 product
         // occupies the matrix pipe for 32 cycles and the SIMD's vector issue for 8 of them).
 #define MS_PIN() __builtin_amdgcn_sched_barrier(0)
+#ifdef MS_ABL_NOSTORE                                    // timing experiment: every store dropped
+#define MS_STORE_AT OOB
+#else
+#define MS_STORE_AT s_at
+#endif
         auto block = [&](auto work_c) {
             constexpr bool WORK = decltype(work_c)::value;
             constexpr int PR = SHARP ? 2 : 3;            // products per k-step of the row pass
@@ -1440,7 +1460,23 @@ __device__ __forceinline__ void ms_body(const pano_patch &p, const int ch, const
             constexpr int G_COMMIT = GR + BLK * 3;       // first gap of the column pass's second half
             MS_STAMP(2);            // prologue
             issue(pf, voff);
+            // the list word after next (wanted at the block's end: its latency is covered)
+            const bool more2 = i + 2 < nlist;
+            const unsigned nn_raw = list[more2 ? i + 2 : 0];
             MS_PIN();
+            // ---- what the NEXT step finds prepared (see above), computed in a product's shadow
+            auto prepare_next = [&]() {
+                const unsigned got = (unsigned)__builtin_amdgcn_readfirstlane((int)nn_raw);
+                nn = more2 ? got : 0u;                   // (a select, not a branch)
+                offsets_fast(band_of(nn), voff, okv);
+                fetch_general = !band_inside(band_of(nn), more2);
+                const bool wanted = (inf >> (DMAX + 2)) & 1u;        // tile t - DMAX: complete now
+                const int o = t - DMAX;
+                const bool rows_in = 32 * o >= p.ay0 && 32 * o + 32 <= p.ay0 + p.ah;   // uniform
+                store_edge = wanted && !rows_in;
+                // (a lane outside A's columns: beyond the plane plus less than a plane stays beyond it)
+                s_at = wanted && rows_in ? s_lane + (unsigned)((32 * o - p.ay0) * p.apitch) * 4u : OOB;
+            };
             // (opaque: the same product with the literal stands in ml_store, and the compiler
             // would compute the sixteen of them once, in front of the branch that leads here)
             float out_scale = MB_OUT_SCALE;
@@ -1463,7 +1499,7 @@ __device__ __forceinline__ void ms_body(const pano_patch &p, const int ch, const
 #pragma unroll
                 for (int q = 0; q < 16; ++q)
                     if (store_gap(q) == g)
-                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(sc[q]), dst, s_at,
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(sc[q]), dst, MS_STORE_AT,
                                                               ((q & 3) + 8 * (q >> 2)) * rowstep, 0);
             };
             constexpr int stores_before_commit = [] {
@@ -1478,6 +1514,7 @@ __device__ __forceinline__ void ms_body(const pano_patch &p, const int ch, const
                 commit_wait(pf, std::integral_constant<int, 16>{});
 #pragma unroll
                 for (int k = 0; k < 3; ++k) commit_piece(pf, okv, off_nxt, k);
+                prepare_next();
             } else {
                 // row pass: the operands of k-step s + 1 are read while k-step s multiplies
                 const unsigned char *const arow = (const unsigned char *)sh.hi + a_lane + 2 * off_cur;
@@ -1573,6 +1610,8 @@ __device__ __forceinline__ void ms_body(const pano_patch &p, const int ch, const
                             if (hg < 3) commit_piece(pf, okv, off_nxt, hg);
                         }
                         fill(GR + s2 * GAPS_H + hg);
+                        // (after this gap's store: the store's base is the one prepared for THIS step)
+                        if (s2 == 1 && hg == GAPS_H - 1) prepare_next();
                         MS_PIN();
                     }
                 }
@@ -1596,15 +1635,22 @@ __device__ __forceinline__ void ms_body(const pano_patch &p, const int ch, const
         prev_store = (inf >> (DMAX + 2)) & 1u;           // tile t - DMAX is wanted: complete now
         prev_o = t - DMAX;
         prev_u = U;
+        const bool run_on = more && band_of(next) == t + 1;
         word = next;
+        next = nn;
         {
             const int tmp = off_cur;
             off_cur = off_nxt;
             off_nxt = tmp;
         }
         ++i;
-        return more && band_of(next) == t + 1;
+        return run_on;
     };
+#ifdef MS_PRIO
+    // (experiment: the second-dispatched half of the workgroup loses every arbitration against
+    // its SIMD partners, MI355X_MICROARCH.md "Two waves per SIMD" item 4)
+    if (wv >= 4) __builtin_amdgcn_s_setprio(MS_PRIO);
+#endif
     while (i < nlist) {                                  // one run per trip
 #pragma unroll
         for (int k = 0; k < NB; ++k)
@@ -1620,60 +1666,52 @@ __device__ __forceinline__ void ms_body(const pano_patch &p, const int ch, const
             }
         }
         if (prev_store) store_prev_generic();            // the run's last tile, before the reset
+        s_at = OOB;                                      // (stored: nothing is left for the next run's first step)
+        store_edge = false;
     }
 }
 
+// One work unit = (work-list slot, channel).  The workgroups are persistent: each takes the next
+// unit off a counter until the list is through (`n_work` units; the list is sorted longest
+// first, so the units handed out last are the short ones and the launch ends evenly), and the
+// group's Toeplitz tables - 106 KB, the same for every unit - are copied into LDS once per
+// workgroup instead of once per unit (31 k cycles of a unit's ~250 k, a unit of a patch's
+// top or bottom edge lasting only ~80 k).  A unit the lean path does not take goes through the
+// general path, which lays the LDS out its own way: the tables are copied again after it.
 __global__ __launch_bounds__(MB_THREADS_OF(4), 1) void blur_lean_kernel(
     const pano_patch *__restrict__ table, MbLevels L, const unsigned char *__restrict__ tables,
     const int16_t *__restrict__ owner, int W, const uint8_t *__restrict__ flags,
-    const int2 *__restrict__ items) {
+    const int2 *__restrict__ items, int *__restrict__ work_counter, int n_work) {
     constexpr int GROUP = 4;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ int s_work;
     const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
-    const int ngroups = (L.n + GROUP - 1) / GROUP;
-    const int per = 8 * ngroups, blk = blockIdx.x / per, within = blockIdx.x - blk * per;
-    const int grp = within >> 3, pair = blk * 8 + (within & 7);
-    const int ch = pair & 3, slot = pair >> 2;
-    const int2 item = items[slot];
-    if (item.x < 0) return;                                                     // uniform
-    const int pid = item.x & 0xffff, tx0 = item.x >> 16;
-    const pano_patch p = table[pid];
-    const MbGeom g = mb_geom(p);
-    const int l0 = GROUP * grp, nl = L.n - l0 < GROUP ? L.n - l0 : GROUP;
-    // the group's reach, and whether this item is one of ours
+    // (the lean launch has one level group: unit = slot * 4 + channel)
+    const int nl = L.n < GROUP ? L.n : GROUP;
+    // the group's reach
     MbShared sh;
     sh.CM = 1;
     for (int k = 0; k < nl; ++k) {
-        const int ck = mb_c_of(L.ntaps[l0 + k]);
+        const int ck = mb_c_of(L.ntaps[k]);
         sh.CM = ck > sh.CM ? ck : sh.CM;
     }
-    if (!mb_item_regular(p, g.gx0, tx0, sh.CM)) {                               // uniform
-        // not one of ours: the general path, in this same workgroup (a second launch over the
-        // list, every workgroup of which returns at once for a regular item, cost 0.31 ms on
-        // config 3: 5120 workgroups of 512 threads and 128 KB of LDS each, one per CU at a time)
-        mb_general<GROUP>(table, L, tables, owner, W, flags, items, smem);
-        return;
-    }
-    const int n_seg = item.y >> 16, seg = (item.y >> 12) & 15, nty_all = g.O1 - g.O0 + 1;
-    const int o_begin = n_seg > 1 ? nty_all * seg / n_seg : 0;
-    const int o_end = n_seg > 1 ? nty_all * (seg + 1) / n_seg : nty_all;
     const int q = __builtin_amdgcn_readfirstlane(wv >> 1);
     const int lv = mb_level_of_pair(nl, q);
     const bool live = lv >= 0;
-    const int level = l0 + (live ? lv : 0);
+    const int level = live ? lv : 0;
     const int ntaps = L.ntaps[level], c = mb_c_of(ntaps);
     int dmax_of[GROUP], rel = 0, my_tx = 0, my_ty = 0;
     for (int k = 0; k < GROUP; ++k) {
         const int lk = mb_level_of_pair(nl, k);
         dmax_of[k] = -1;
         if (lk < 0) continue;
-        const int ck = mb_c_of(L.ntaps[l0 + lk]);
+        const int ck = mb_c_of(L.ntaps[lk]);
         dmax_of[k] = (ck + 1) / 2;
         if (k == q) {
             my_tx = rel;
             my_ty = rel + (2 + 2 * ck) * 2 * 1024;
         }
-        rel += mb_table_bytes(L.ntaps[l0 + lk]);
+        rel += mb_table_bytes(L.ntaps[lk]);
     }
     sh.P = mb_pitch_of(sh.CM);
     sh.hi = (_Float16 *)smem;
@@ -1686,73 +1724,110 @@ __global__ __launch_bounds__(MB_THREADS_OF(4), 1) void blur_lean_kernel(
     my_tx += mb_fixed_bytes(sh.CM);
     my_ty += mb_fixed_bytes(sh.CM);
     const int dmaxm = (sh.CM + 1) / 2;
-    sh.t_lo = g.O0 - dmaxm;
-    sh.t_hi = g.O1 + dmaxm;
-    if (live) {
-        const uint4 *from = (const uint4 *)(tables + L.tab_off[level]);
-        uint4 *to = (uint4 *)(smem + my_tx);
-        const int n16 = mb_table_bytes(ntaps) >> 4;
-        for (int i = tid & 127; i < n16; i += 128) to[i] = from[i];
-    }
-    const int X0 = g.gx0 + 32 * tx0;
-    const int nty = g.O1 - g.O0 + 1;
-    if (wv < 2) {
-        const int txg = ((X0 - g.gx0) >> 5) + wv;
-        for (int i = lane; i < nty + 2 * MB_NEED_PAD; i += 64) {
-            const int o = i - MB_NEED_PAD;
-            bool v = txg < g.ntx && o >= o_begin && o < o_end;
-            if (v && flags) v = flags[p.tiles_off + o * g.ntx + txg] != 0;
-            sh.need[wv * MB_NEED_LEN + i] = v ? 1 : 0;
-        }
-    }
     int *const s_count = (int *)sh.any;                  // (the `any` flags are not used here)
-    __syncthreads();
-    // the bands some wave wants, in order, compacted: one wave, 64 bands per round
-    if (wv == 0) {
-        int count = 0;
-        for (int base = 0; base <= sh.t_hi - sh.t_lo; base += 64) {
-            const int i = base + lane, t = sh.t_lo + i;
-            const int o = t - g.O0 + MB_NEED_PAD;                    // index of tile t into need[]
-            bool any = false;
-            unsigned w = 0;
-            if (i <= sh.t_hi - sh.t_lo) {
-                for (int k = 0; k < GROUP; ++k)
-                    for (int d = -dmax_of[k]; d <= dmax_of[k]; ++d)
-                        any |= (sh.need[o - d] | sh.need[MB_NEED_LEN + o - d]) != 0;
-                for (int col = 0; col < 2; ++col)
-                    for (int d = -2; d <= 2; ++d)
-                        w |= (sh.need[col * MB_NEED_LEN + o - d] ? 1u : 0u) << (16 + 8 * col + d + 2);
-                w |= (unsigned)(unsigned short)(short)t;
-            }
-            const unsigned long long bal = __ballot(any);
-            if (any) list[count + __popcll(bal & ((1ull << lane) - 1ull))] = w;
-            count += __popcll(bal);
-        }
-        if (lane == 0) *s_count = count;
-    }
-    __syncthreads();
-    const int nlist = *s_count;
     const half8 *s_tx = (const half8 *)(smem + my_tx), *s_ty = (const half8 *)(smem + my_ty);
     const int out_level = L.out[level];
     // the second band buffer lies behind the group's tables (the host sized the LDS for it)
     const int second = (mb_fixed_bytes(sh.CM) + rel + 15) / 16 * 8;     // halfs from sh.hi
+    bool tables_in = false;
+    for (;;) {
+        __syncthreads();                                 // the previous unit is through with the LDS
+        if (tid == 0) s_work = atomicAdd(work_counter, 1);
+        __syncthreads();
+        const int work = s_work;
+        if (work >= n_work) break;                                              // uniform
+        const int ch = work & 3, slot = work >> 2;
+        const int2 item = items[slot];
+        if (item.x < 0) break;                           // (the list's tail: empty slots only) uniform
+        const int pid = item.x & 0xffff, tx0 = item.x >> 16;
+        const pano_patch p = table[pid];
+        const MbGeom g = mb_geom(p);
+        if (!mb_item_regular(p, g.gx0, tx0, sh.CM)) {                           // uniform
+            // not one of ours: the general path, in this same workgroup
+            mb_general<GROUP>(table, L, tables, owner, W, flags, items, smem, work);
+            tables_in = false;
+            continue;
+        }
+        if (!tables_in) {
+            // this pair's Toeplitz tables (row pass, then column pass): every load of the copy
+            // issued before the first LDS store
+            if (live) {
+                const uint4 *from = (const uint4 *)(tables + L.tab_off[level]);
+                uint4 *to = (uint4 *)(smem + my_tx);
+                const int n16 = mb_table_bytes(ntaps) >> 4;
+                constexpr int DEPTH = 8;                 // 16-byte loads in flight per thread
+                for (int i0 = tid & 127; i0 < n16; i0 += 128 * DEPTH) {
+                    uint4 v[DEPTH];
+#pragma unroll
+                    for (int j = 0; j < DEPTH; ++j)
+                        if (i0 + 128 * j < n16) v[j] = from[i0 + 128 * j];
+#pragma unroll
+                    for (int j = 0; j < DEPTH; ++j)
+                        if (i0 + 128 * j < n16) to[i0 + 128 * j] = v[j];
+                }
+            }
+            tables_in = true;
+        }
+        const int n_seg = item.y >> 16, seg = (item.y >> 12) & 15, nty_all = g.O1 - g.O0 + 1;
+        const int o_begin = n_seg > 1 ? nty_all * seg / n_seg : 0;
+        const int o_end = n_seg > 1 ? nty_all * (seg + 1) / n_seg : nty_all;
+        sh.t_lo = g.O0 - dmaxm;
+        sh.t_hi = g.O1 + dmaxm;
+        const int X0 = g.gx0 + 32 * tx0;
+        const int nty = g.O1 - g.O0 + 1;
+        if (wv < 2) {
+            const int txg = ((X0 - g.gx0) >> 5) + wv;
+            for (int i = lane; i < nty + 2 * MB_NEED_PAD; i += 64) {
+                const int o = i - MB_NEED_PAD;
+                bool v = txg < g.ntx && o >= o_begin && o < o_end;
+                if (v && flags) v = flags[p.tiles_off + o * g.ntx + txg] != 0;
+                sh.need[wv * MB_NEED_LEN + i] = v ? 1 : 0;
+            }
+        }
+        __syncthreads();
+        // the bands some wave wants, in order, compacted: one wave, 64 bands per round
+        if (wv == 0) {
+            int count = 0;
+            for (int base = 0; base <= sh.t_hi - sh.t_lo; base += 64) {
+                const int i = base + lane, t = sh.t_lo + i;
+                const int o = t - g.O0 + MB_NEED_PAD;                    // index of tile t into need[]
+                bool any = false;
+                unsigned w = 0;
+                if (i <= sh.t_hi - sh.t_lo) {
+                    for (int k = 0; k < GROUP; ++k)
+                        for (int d = -dmax_of[k]; d <= dmax_of[k]; ++d)
+                            any |= (sh.need[o - d] | sh.need[MB_NEED_LEN + o - d]) != 0;
+                    for (int col = 0; col < 2; ++col)
+                        for (int d = -2; d <= 2; ++d)
+                            w |= (sh.need[col * MB_NEED_LEN + o - d] ? 1u : 0u) << (16 + 8 * col + d + 2);
+                    w |= (unsigned)(unsigned short)(short)t;
+                }
+                const unsigned long long bal = __ballot(any);
+                if (any) list[count + __popcll(bal & ((1ull << lane) - 1ull))] = w;
+                count += __popcll(bal);
+            }
+            if (lane == 0) *s_count = count;
+        }
+        __syncthreads();
+        const int nlist = *s_count;
 #if MB_STREAM
 #define ML_BODY_FN ms_body
 #else
 #define ML_BODY_FN ml_body
 #endif
-    switch (c) {                                         // wave-uniform
+        switch (c) {                                     // wave-uniform
 #define ML_BODY(CC)                                                                            \
     if (ch == 3)                                                                               \
         ML_BODY_FN<CC, true>(p, ch, out_level, live, s_tx, s_ty, sh, list, nlist, owner, W, tx0, second); \
     else                                                                                       \
         ML_BODY_FN<CC, false>(p, ch, out_level, live, s_tx, s_ty, sh, list, nlist, owner, W, tx0, second); \
     break;
-        case 1: ML_BODY(1)
-        case 2: ML_BODY(2)
-        case 3: ML_BODY(3)
-        default: ML_BODY(4)
+            case 1: ML_BODY(1)
+            case 2: ML_BODY(2)
+            case 3: ML_BODY(3)
+            default: ML_BODY(4)
 #undef ML_BODY
+        }
     }
 }
 
@@ -1996,7 +2071,10 @@ __global__ __launch_bounds__(256) void mb_sort_kernel(const int2 *__restrict__ i
     }
     for (int i = total + tid; i < scap; i += 256) sorted[i] = make_int2(-1, 0);
     __syncthreads();
-    if (tid == 0) *counter = 0;
+    if (tid == 0) {
+        counter[0] = 0;
+        counter[1] = 0;                                  // blur_lean_kernel's work counter
+    }
 }
 
 // slots of the sorted list: the items, room for their segments, rounded up to an even count
@@ -2080,9 +2158,9 @@ int pano_prepare_blur_mfma(pano_ctx *ctx, const pano_patch *table, int n, int ma
         PANO_HIP(hipMalloc((void **)&ctx->item_buf,
                            ((size_t)ctx->item_cap * 2 + MB_SEG_SLOTS + 2) * sizeof(int2)));
     }
-    if (!ctx->item_counter) {
-        PANO_HIP(hipMalloc((void **)&ctx->item_counter, sizeof(int)));
-        PANO_HIP(hipMemsetAsync(ctx->item_counter, 0, sizeof(int), stream));
+    if (!ctx->item_counter) {                            // [0]: items found, [1]: the lean kernel's work counter
+        PANO_HIP(hipMalloc((void **)&ctx->item_counter, 2 * sizeof(int)));
+        PANO_HIP(hipMemsetAsync(ctx->item_counter, 0, 2 * sizeof(int), stream));
     }
     hipLaunchKernelGGL(mb_items_kernel, dim3(n), dim3(256), 0, stream, table, flags, ctx->item_buf,
                        ctx->item_counter, cap);
@@ -2210,10 +2288,19 @@ static int launch_levels(pano_ctx *ctx, const pano_patch *table, int n, int max_
         }
         if (lds_lean > 160 * 1024) lean = 0;             // (apertures above 97 taps: the general kernel)
     }
-    if (lean) {
+    if (lean && ngroups == 1) {
+        // persistent workgroups, one per CU (the LDS admits no second one), taking work units
+        // off the counter mb_sort_kernel has just zeroed
+        static int cus_of[64];                           // (per device; asked once)
+        int &cus = cus_of[ctx->device & 63];
+        if (cus == 0)
+            PANO_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device));
+        const int n_work = cap * 4;
+        dim3 pgrid((unsigned)(n_work < cus ? n_work : cus), 1, 1);
         PANO_TIMED(PK_BLUR_LEAN, stream,
-                   hipLaunchKernelGGL(blur_lean_kernel, grid, dim3(MB_THREADS_OF(4)), lds_lean,
-                                      stream, table, L, tables, owner, W, flags, sorted));
+                   hipLaunchKernelGGL(blur_lean_kernel, pgrid, dim3(MB_THREADS_OF(4)), lds_lean,
+                                      stream, table, L, tables, owner, W, flags, sorted,
+                                      ctx->item_counter + 1, n_work));
         PANO_LAUNCH_CHECK("blur_lean_kernel");
         return PANO_OK;
     }

@@ -230,8 +230,12 @@ class ShardedStitcher:
         # between the engines, each on a stream of its own with its own exchange buffers, so
         # that one stitch's kernels cover the other's host round trip (on a column strip of a
         # world-8 run the kernels are 0.45 ms and that round trip plus the launches' gaps 0.1).
-        # Every buffer of a lane is only ever touched in its lane's stream order; the ranks
-        # alternate alike, so their collectives are issued in the same order everywhere.
+        # Every buffer of a lane is only ever touched in its lane's stream order.  Each lane
+        # exchanges over a process group (communicator) of its own: a collective only has to
+        # be issued in the same order as the other ranks' collectives ON ITS COMMUNICATOR, so
+        # whatever order the lanes' submissions reach RCCL in on different ranks - two user
+        # streams, skewed hosts - no lane's collective can pair with or wait behind another
+        # lane's (tests/test_dist_cpu.py drives the lanes from skewed threads to show it).
         engines = list(eng) if isinstance(eng, (list, tuple)) else [eng]
         self.eng, self.rank, self.world, self.group = engines[0], rank, world, group
         self.shapes, self.rots, self.intrs = shapes, rots, intrs
@@ -258,8 +262,14 @@ class ShardedStitcher:
                 import torch
                 stream = torch.cuda.Stream(use.device)
             # exchange=None: geometry only (emulation of the ranks on one device)
-            ex = (StripExchange(plan.shape, self.bounds, rank, world, use.device, exchange, group,
-                                lane_depth) if exchange else None)
+            lane_group = group
+            if exchange and world > 1 and len(engines) > 1:
+                import torch.distributed as dist
+                # (collective: every rank builds its lanes in the same order)
+                lane_group = dist.new_group(ranks=(dist.get_process_group_ranks(group)
+                                                   if group is not None else None))
+            ex = (StripExchange(plan.shape, self.bounds, rank, world, use.device, exchange,
+                                lane_group, lane_depth) if exchange else None)
             if stream is not None:
                 # the exchange buffers were zero-filled on the constructing stream: the lane's
                 # first write must come behind those fills

@@ -221,3 +221,68 @@ def test_assign_sets_round_robin():
             assert sorted(i for g in got for i in g) == list(range(n_sets))
             assert max(map(len, got)) - min(map(len, got)) <= 1
     assert pdist.max_over_ranks(1.25) == 1.25          # no process group: identity
+
+
+def _skewed_lanes_worker(rank, world, port, mode, result):
+    """Two lanes, each driven by a thread of its own, the threads skewed against each other
+    differently on every rank: rank r starts lane (r % 2) first and the other lane 0.3 s later,
+    so the ranks' submissions reach the backend in opposite lane orders."""
+    import threading
+    import time
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        shapes, rots, intrs = _scene()
+        shape = engine.Plan(shapes, rots, intrs, True, 10 ** 9).shape
+        eng = _HostEngine(shape)
+        st = pdist.ShardedStitcher([eng, _HostEngine(shape, eng.clock)], shapes, rots, intrs, 5,
+                                   rank, world, exchange=mode, depth=2)
+        groups = [ex.group for _, _, ex in st.lanes]
+        assert groups[0] is not groups[1] and None not in groups       # a communicator per lane
+        truth = eng.truth
+        got = {0: [], 1: []}
+        errors = []
+
+        def drive(lane, delay):
+            try:
+                time.sleep(delay)
+                ex = st.lanes[lane][2]
+                c0, c1 = ex.strip
+                for k in range(3):
+                    ex.recycle()
+                    ex.target()[:, c0:c1] = truth(10 * lane + k)[:, c0:c1]
+                    ex.submit()
+                    mosaic = ex.collect()
+                    if mosaic is not None:
+                        got[lane].append(mosaic.clone())
+                    time.sleep(0.05 * ((rank + lane) % 2))
+            except Exception as err:       # noqa: BLE001 - reported through the queue
+                errors.append(repr(err))
+        first = rank % 2
+        threads = [threading.Thread(target=drive, args=(first, 0.0)),
+                   threading.Thread(target=drive, args=(1 - first, 0.3))]
+        for th in threads:
+            th.start()
+        for th in threads:
+            th.join(60)
+        assert not errors and not any(th.is_alive() for th in threads), errors
+        if rank == 0:
+            ok = all(len(got[lane]) == 3 and
+                     all(torch.equal(m, truth(10 * lane + k)) for k, m in enumerate(got[lane]))
+                     for lane in (0, 1))
+            result.put(bool(ok))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode,world", [("gather", 2), ("reduce", 2), ("gather", 3)])
+def test_lanes_exchange_independently_when_driven_from_skewed_threads(mode, world):
+    """Each lane of a ShardedStitcher exchanges over a communicator of its own, so the order in
+    which different ranks issue lane 0's and lane 1's collectives does not matter: here every
+    rank drives its two lanes from two threads, and odd ranks start the lanes in the opposite
+    order of even ranks.  (On one shared communicator this pattern pairs lane 0's gather on one
+    rank with lane 1's on another - or waits for ever.)"""
+    ctx = mp.get_context("spawn")
+    result = ctx.SimpleQueue()
+    mp.spawn(_skewed_lanes_worker, args=(world, _free_port(), mode, result), nprocs=world, join=True)
+    assert result.get() is True

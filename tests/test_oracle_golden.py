@@ -294,3 +294,104 @@ def test_multiband_blur_levels_golden(oracle):
     for k, sigma in enumerate(g["blur_sigma"]):
         got = oracle.gaussian_blur(g["blur_in"], oracle.gaussian_ksize(sigma), sigma)
         assert np.array_equal(bits(got), bits(g[f"blur_out_{k}"])), k
+
+
+# ------------------------------------------------ third-party cross-checks of the cv2 restatement
+# oracle/cv2_shim.py restates remap / GaussianBlur / pyrDown from OpenCV's documented algorithm
+# (cv2 is not installable here: SURVEY.md 8c); the C oracle and the HIP kernels are compared with
+# it.  These tests pin the restatement itself against independent implementations that were
+# not written for this repo: scipy.ndimage (C code, float64 arithmetic) and torch's grid_sample.
+def _smooth_image(rng, h, w, c=None):
+    from scipy import ndimage
+    shape = (h, w) if c is None else (h, w, c)
+    img = rng.random(shape)
+    img = ndimage.gaussian_filter(img, sigma=(1.5, 1.5) + ((0,) if c else ()), mode="nearest")
+    return ((img - img.min()) / (img.max() - img.min())).astype(np.float32)
+
+
+def test_shim_remap_against_scipy_map_coordinates():
+    """cv2.remap(INTER_LINEAR, BORDER_REFLECT) (stitcher.py:315-316) = bilinear interpolation
+    with half-sample symmetric extension = scipy's map_coordinates(order=1, mode='reflect'),
+    once the coordinates lie on remap's 1/32-pixel grid (its fixed-point step is then exact)."""
+    import cv2_shim
+    from scipy import ndimage
+    rng = np.random.default_rng(11)
+    for (h, w) in ((37, 53), (8, 120), (64, 9)):
+        src = _smooth_image(rng, h, w, 4)
+        # coordinates on the 1/32 grid, up to three pixels beyond every edge (one reflection)
+        n = 4000
+        xs = rng.integers(-3 * 32, (w + 2) * 32, n).astype(np.float32) / np.float32(32)
+        ys = rng.integers(-3 * 32, (h + 2) * 32, n).astype(np.float32) / np.float32(32)
+        got = cv2_shim.remap(src, xs[None, :], ys[None, :], cv2_shim.INTER_LINEAR,
+                             borderMode=cv2_shim.BORDER_REFLECT)[0]
+        for ch in range(4):
+            want = ndimage.map_coordinates(src[..., ch].astype(np.float64),
+                                           [ys.astype(np.float64), xs.astype(np.float64)],
+                                           order=1, mode="reflect")
+            assert np.abs(got[:, ch] - want).max() <= 1e-6, (h, w, ch)
+
+
+def test_shim_remap_against_torch_grid_sample():
+    """The same inside the image, against torch.nn.functional.grid_sample (bilinear,
+    align_corners=True: pixel centres at integer coordinates)."""
+    import cv2_shim
+    import torch
+    rng = np.random.default_rng(12)
+    h, w = 41, 67
+    src = _smooth_image(rng, h, w, 3)
+    n = 5000
+    xs = rng.integers(0, (w - 1) * 32 + 1, n).astype(np.float32) / np.float32(32)
+    ys = rng.integers(0, (h - 1) * 32 + 1, n).astype(np.float32) / np.float32(32)
+    got = cv2_shim.remap(src, xs[None, :], ys[None, :], cv2_shim.INTER_LINEAR,
+                         borderMode=cv2_shim.BORDER_REFLECT)[0]
+    grid = torch.stack([torch.from_numpy(xs.astype(np.float64)) / (w - 1) * 2 - 1,
+                        torch.from_numpy(ys.astype(np.float64)) / (h - 1) * 2 - 1], dim=-1)
+    want = torch.nn.functional.grid_sample(
+        torch.from_numpy(src.astype(np.float64)).permute(2, 0, 1)[None], grid[None, None],
+        mode="bilinear", padding_mode="border", align_corners=True)[0, :, 0].T.numpy()
+    assert np.abs(got - want).max() <= 1e-6
+
+
+@pytest.mark.parametrize("sigma", [4.0, 4 * np.sqrt(3.0), 4 * np.sqrt(5.0), 4 * np.sqrt(7.0), 12.0])
+def test_shim_gaussian_blur_against_scipy_correlate1d(sigma):
+    """cv2.GaussianBlur(img, (0, 0), sigma) (stitcher.py:218, 226): aperture cvRound(8 sigma + 1) | 1,
+    taps exp(-x^2 / 2 sigma^2) normalised, separable, BORDER_REFLECT_101 = scipy's 'mirror'.
+    The taps are recomputed here in float64 from the formula, not taken from the shim."""
+    import cv2_shim
+    from scipy import ndimage
+    rng = np.random.default_rng(13)
+    img = _smooth_image(rng, 150, 131, 4)
+    ksize = int(round(sigma * 8 + 1)) | 1
+    assert cv2_shim.gaussian_ksize(sigma) == ksize
+    x = np.arange(ksize, dtype=np.float64) - (ksize - 1) / 2
+    taps = np.exp(-x * x / (2 * sigma * sigma))
+    taps /= taps.sum()
+    assert np.abs(cv2_shim.getGaussianKernel(ksize, sigma).ravel() - taps).max() <= 1e-8
+    got = cv2_shim.GaussianBlur(img, (0, 0), sigma)
+    want = ndimage.correlate1d(img.astype(np.float64), taps, axis=1, mode="mirror")
+    want = ndimage.correlate1d(want, taps, axis=0, mode="mirror")
+    assert np.abs(got - want).max() <= 1e-6
+    # ... and the same small image whose every row and column reflects (aperture > size)
+    small = _smooth_image(rng, 23, 17)
+    got = cv2_shim.GaussianBlur(small, (0, 0), sigma)
+    want = ndimage.correlate1d(ndimage.correlate1d(small.astype(np.float64), taps, axis=1, mode="mirror"),
+                               taps, axis=0, mode="mirror")
+    if ksize // 2 < min(small.shape):          # (scipy's 'mirror' reflects once, like REFLECT_101)
+        assert np.abs(got - want).max() <= 1e-6
+
+
+@pytest.mark.parametrize("shape", [(64, 48), (37, 53), (5, 120), (1, 9)])
+def test_shim_pyr_down_against_scipy_correlate1d(shape):
+    """cv2.pyrDown (features.py:155, blend.py:119): [1 4 6 4 1] / 16 along both axes with
+    REFLECT_101, even rows and columns kept."""
+    import cv2_shim
+    from scipy import ndimage
+    rng = np.random.default_rng(14)
+    img = _smooth_image(rng, max(shape[0], 4), max(shape[1], 4))[:shape[0], :shape[1]]
+    taps = np.array([1, 4, 6, 4, 1], np.float64) / 16
+    want = ndimage.correlate1d(ndimage.correlate1d(img.astype(np.float64), taps, axis=1, mode="mirror"),
+                               taps, axis=0, mode="mirror")[::2, ::2]
+    got = cv2_shim.pyrDown(img)
+    assert got.shape == want.shape
+    if min(shape) > 2:                          # (one reflection: what both definitions share)
+        assert np.abs(got - want).max() <= 1e-6
