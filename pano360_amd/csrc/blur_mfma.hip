@@ -1383,7 +1383,7 @@ __device__ __forceinline__ void ms_body(const pano_patch &p, const int ch, const
 #ifndef MB_STAMP_CH
 #define MB_STAMP_CH 0
 #endif
-    const bool stamped = (wv & 1) == 0 && ch == MB_STAMP_CH && blockIdx.x % 7 == 3;
+    const bool stamped = (wv & 1) == 0 && ch == MB_STAMP_CH && (blockIdx.x >> 2) % 7 == 3;
     unsigned long long tlast = __builtin_readcyclecounter();
 #define MS_STAMP(k)                                                                      \
     do {                                                                                 \
@@ -1671,47 +1671,57 @@ __device__ __forceinline__ void ms_body(const pano_patch &p, const int ch, const
     }
 }
 
-// One work unit = (work-list slot, channel).  The workgroups are persistent: each takes the next
-// unit off a counter until the list is through (`n_work` units; the list is sorted longest
-// first, so the units handed out last are the short ones and the launch ends evenly), and the
-// group's Toeplitz tables - 106 KB, the same for every unit - are copied into LDS once per
-// workgroup instead of once per unit (31 k cycles of a unit's ~250 k, a unit of a patch's
-// top or bottom edge lasting only ~80 k).  A unit the lean path does not take goes through the
-// general path, which lays the LDS out its own way: the tables are copied again after it.
 __global__ __launch_bounds__(MB_THREADS_OF(4), 1) void blur_lean_kernel(
     const pano_patch *__restrict__ table, MbLevels L, const unsigned char *__restrict__ tables,
     const int16_t *__restrict__ owner, int W, const uint8_t *__restrict__ flags,
-    const int2 *__restrict__ items, int *__restrict__ work_counter, int n_work) {
+    const int2 *__restrict__ items) {
     constexpr int GROUP = 4;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    __shared__ int s_work;
     const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
-    // (the lean launch has one level group: unit = slot * 4 + channel)
-    const int nl = L.n < GROUP ? L.n : GROUP;
-    // the group's reach
+    const int ngroups = (L.n + GROUP - 1) / GROUP;
+    const int per = 8 * ngroups, blk = blockIdx.x / per, within = blockIdx.x - blk * per;
+    const int grp = within >> 3, pair = blk * 8 + (within & 7);
+    const int ch = pair & 3, slot = pair >> 2;
+    const int2 item = items[slot];
+    if (item.x < 0) return;                                                     // uniform
+    const int pid = item.x & 0xffff, tx0 = item.x >> 16;
+    const pano_patch p = table[pid];
+    const MbGeom g = mb_geom(p);
+    const int l0 = GROUP * grp, nl = L.n - l0 < GROUP ? L.n - l0 : GROUP;
+    // the group's reach, and whether this item is one of ours
     MbShared sh;
     sh.CM = 1;
     for (int k = 0; k < nl; ++k) {
-        const int ck = mb_c_of(L.ntaps[k]);
+        const int ck = mb_c_of(L.ntaps[l0 + k]);
         sh.CM = ck > sh.CM ? ck : sh.CM;
     }
+    if (!mb_item_regular(p, g.gx0, tx0, sh.CM)) {                               // uniform
+        // not one of ours: the general path, in this same workgroup (a second launch over the
+        // list, every workgroup of which returns at once for a regular item, cost 0.31 ms on
+        // config 3: 5120 workgroups of 512 threads and 128 KB of LDS each, one per CU at a time)
+        mb_general<GROUP>(table, L, tables, owner, W, flags, items, smem, (int)blockIdx.x);
+        return;
+    }
+    const int n_seg = item.y >> 16, seg = (item.y >> 12) & 15, nty_all = g.O1 - g.O0 + 1;
+    const int o_begin = n_seg > 1 ? nty_all * seg / n_seg : 0;
+    const int o_end = n_seg > 1 ? nty_all * (seg + 1) / n_seg : nty_all;
     const int q = __builtin_amdgcn_readfirstlane(wv >> 1);
     const int lv = mb_level_of_pair(nl, q);
     const bool live = lv >= 0;
-    const int level = live ? lv : 0;
+    const int level = l0 + (live ? lv : 0);
     const int ntaps = L.ntaps[level], c = mb_c_of(ntaps);
     int dmax_of[GROUP], rel = 0, my_tx = 0, my_ty = 0;
     for (int k = 0; k < GROUP; ++k) {
         const int lk = mb_level_of_pair(nl, k);
         dmax_of[k] = -1;
         if (lk < 0) continue;
-        const int ck = mb_c_of(L.ntaps[lk]);
+        const int ck = mb_c_of(L.ntaps[l0 + lk]);
         dmax_of[k] = (ck + 1) / 2;
         if (k == q) {
             my_tx = rel;
             my_ty = rel + (2 + 2 * ck) * 2 * 1024;
         }
-        rel += mb_table_bytes(L.ntaps[lk]);
+        rel += mb_table_bytes(L.ntaps[l0 + lk]);
     }
     sh.P = mb_pitch_of(sh.CM);
     sh.hi = (_Float16 *)smem;
@@ -1724,110 +1734,83 @@ __global__ __launch_bounds__(MB_THREADS_OF(4), 1) void blur_lean_kernel(
     my_tx += mb_fixed_bytes(sh.CM);
     my_ty += mb_fixed_bytes(sh.CM);
     const int dmaxm = (sh.CM + 1) / 2;
+    sh.t_lo = g.O0 - dmaxm;
+    sh.t_hi = g.O1 + dmaxm;
+    if (live) {
+        const uint4 *from = (const uint4 *)(tables + L.tab_off[level]);
+        uint4 *to = (uint4 *)(smem + my_tx);
+        const int n16 = mb_table_bytes(ntaps) >> 4;
+        // (every load of a round issued before its first LDS store: 16 - 32 KB per wave pair)
+        constexpr int DEPTH = 8;
+        for (int i0 = tid & 127; i0 < n16; i0 += 128 * DEPTH) {
+            uint4 v[DEPTH];
+#pragma unroll
+            for (int j = 0; j < DEPTH; ++j)
+                if (i0 + 128 * j < n16) v[j] = from[i0 + 128 * j];
+#pragma unroll
+            for (int j = 0; j < DEPTH; ++j)
+                if (i0 + 128 * j < n16) to[i0 + 128 * j] = v[j];
+        }
+    }
+    const int X0 = g.gx0 + 32 * tx0;
+    const int nty = g.O1 - g.O0 + 1;
+    if (wv < 2) {
+        const int txg = ((X0 - g.gx0) >> 5) + wv;
+        for (int i = lane; i < nty + 2 * MB_NEED_PAD; i += 64) {
+            const int o = i - MB_NEED_PAD;
+            bool v = txg < g.ntx && o >= o_begin && o < o_end;
+            if (v && flags) v = flags[p.tiles_off + o * g.ntx + txg] != 0;
+            sh.need[wv * MB_NEED_LEN + i] = v ? 1 : 0;
+        }
+    }
     int *const s_count = (int *)sh.any;                  // (the `any` flags are not used here)
+    __syncthreads();
+    // the bands some wave wants, in order, compacted: one wave, 64 bands per round
+    if (wv == 0) {
+        int count = 0;
+        for (int base = 0; base <= sh.t_hi - sh.t_lo; base += 64) {
+            const int i = base + lane, t = sh.t_lo + i;
+            const int o = t - g.O0 + MB_NEED_PAD;                    // index of tile t into need[]
+            bool any = false;
+            unsigned w = 0;
+            if (i <= sh.t_hi - sh.t_lo) {
+                for (int k = 0; k < GROUP; ++k)
+                    for (int d = -dmax_of[k]; d <= dmax_of[k]; ++d)
+                        any |= (sh.need[o - d] | sh.need[MB_NEED_LEN + o - d]) != 0;
+                for (int col = 0; col < 2; ++col)
+                    for (int d = -2; d <= 2; ++d)
+                        w |= (sh.need[col * MB_NEED_LEN + o - d] ? 1u : 0u) << (16 + 8 * col + d + 2);
+                w |= (unsigned)(unsigned short)(short)t;
+            }
+            const unsigned long long bal = __ballot(any);
+            if (any) list[count + __popcll(bal & ((1ull << lane) - 1ull))] = w;
+            count += __popcll(bal);
+        }
+        if (lane == 0) *s_count = count;
+    }
+    __syncthreads();
+    const int nlist = *s_count;
     const half8 *s_tx = (const half8 *)(smem + my_tx), *s_ty = (const half8 *)(smem + my_ty);
     const int out_level = L.out[level];
     // the second band buffer lies behind the group's tables (the host sized the LDS for it)
     const int second = (mb_fixed_bytes(sh.CM) + rel + 15) / 16 * 8;     // halfs from sh.hi
-    bool tables_in = false;
-    for (;;) {
-        __syncthreads();                                 // the previous unit is through with the LDS
-        if (tid == 0) s_work = atomicAdd(work_counter, 1);
-        __syncthreads();
-        const int work = s_work;
-        if (work >= n_work) break;                                              // uniform
-        const int ch = work & 3, slot = work >> 2;
-        const int2 item = items[slot];
-        if (item.x < 0) break;                           // (the list's tail: empty slots only) uniform
-        const int pid = item.x & 0xffff, tx0 = item.x >> 16;
-        const pano_patch p = table[pid];
-        const MbGeom g = mb_geom(p);
-        if (!mb_item_regular(p, g.gx0, tx0, sh.CM)) {                           // uniform
-            // not one of ours: the general path, in this same workgroup
-            mb_general<GROUP>(table, L, tables, owner, W, flags, items, smem, work);
-            tables_in = false;
-            continue;
-        }
-        if (!tables_in) {
-            // this pair's Toeplitz tables (row pass, then column pass): every load of the copy
-            // issued before the first LDS store
-            if (live) {
-                const uint4 *from = (const uint4 *)(tables + L.tab_off[level]);
-                uint4 *to = (uint4 *)(smem + my_tx);
-                const int n16 = mb_table_bytes(ntaps) >> 4;
-                constexpr int DEPTH = 8;                 // 16-byte loads in flight per thread
-                for (int i0 = tid & 127; i0 < n16; i0 += 128 * DEPTH) {
-                    uint4 v[DEPTH];
-#pragma unroll
-                    for (int j = 0; j < DEPTH; ++j)
-                        if (i0 + 128 * j < n16) v[j] = from[i0 + 128 * j];
-#pragma unroll
-                    for (int j = 0; j < DEPTH; ++j)
-                        if (i0 + 128 * j < n16) to[i0 + 128 * j] = v[j];
-                }
-            }
-            tables_in = true;
-        }
-        const int n_seg = item.y >> 16, seg = (item.y >> 12) & 15, nty_all = g.O1 - g.O0 + 1;
-        const int o_begin = n_seg > 1 ? nty_all * seg / n_seg : 0;
-        const int o_end = n_seg > 1 ? nty_all * (seg + 1) / n_seg : nty_all;
-        sh.t_lo = g.O0 - dmaxm;
-        sh.t_hi = g.O1 + dmaxm;
-        const int X0 = g.gx0 + 32 * tx0;
-        const int nty = g.O1 - g.O0 + 1;
-        if (wv < 2) {
-            const int txg = ((X0 - g.gx0) >> 5) + wv;
-            for (int i = lane; i < nty + 2 * MB_NEED_PAD; i += 64) {
-                const int o = i - MB_NEED_PAD;
-                bool v = txg < g.ntx && o >= o_begin && o < o_end;
-                if (v && flags) v = flags[p.tiles_off + o * g.ntx + txg] != 0;
-                sh.need[wv * MB_NEED_LEN + i] = v ? 1 : 0;
-            }
-        }
-        __syncthreads();
-        // the bands some wave wants, in order, compacted: one wave, 64 bands per round
-        if (wv == 0) {
-            int count = 0;
-            for (int base = 0; base <= sh.t_hi - sh.t_lo; base += 64) {
-                const int i = base + lane, t = sh.t_lo + i;
-                const int o = t - g.O0 + MB_NEED_PAD;                    // index of tile t into need[]
-                bool any = false;
-                unsigned w = 0;
-                if (i <= sh.t_hi - sh.t_lo) {
-                    for (int k = 0; k < GROUP; ++k)
-                        for (int d = -dmax_of[k]; d <= dmax_of[k]; ++d)
-                            any |= (sh.need[o - d] | sh.need[MB_NEED_LEN + o - d]) != 0;
-                    for (int col = 0; col < 2; ++col)
-                        for (int d = -2; d <= 2; ++d)
-                            w |= (sh.need[col * MB_NEED_LEN + o - d] ? 1u : 0u) << (16 + 8 * col + d + 2);
-                    w |= (unsigned)(unsigned short)(short)t;
-                }
-                const unsigned long long bal = __ballot(any);
-                if (any) list[count + __popcll(bal & ((1ull << lane) - 1ull))] = w;
-                count += __popcll(bal);
-            }
-            if (lane == 0) *s_count = count;
-        }
-        __syncthreads();
-        const int nlist = *s_count;
 #if MB_STREAM
 #define ML_BODY_FN ms_body
 #else
 #define ML_BODY_FN ml_body
 #endif
-        switch (c) {                                     // wave-uniform
+    switch (c) {                                         // wave-uniform
 #define ML_BODY(CC)                                                                            \
     if (ch == 3)                                                                               \
         ML_BODY_FN<CC, true>(p, ch, out_level, live, s_tx, s_ty, sh, list, nlist, owner, W, tx0, second); \
     else                                                                                       \
         ML_BODY_FN<CC, false>(p, ch, out_level, live, s_tx, s_ty, sh, list, nlist, owner, W, tx0, second); \
     break;
-            case 1: ML_BODY(1)
-            case 2: ML_BODY(2)
-            case 3: ML_BODY(3)
-            default: ML_BODY(4)
+        case 1: ML_BODY(1)
+        case 2: ML_BODY(2)
+        case 3: ML_BODY(3)
+        default: ML_BODY(4)
 #undef ML_BODY
-        }
     }
 }
 
@@ -2071,10 +2054,7 @@ __global__ __launch_bounds__(256) void mb_sort_kernel(const int2 *__restrict__ i
     }
     for (int i = total + tid; i < scap; i += 256) sorted[i] = make_int2(-1, 0);
     __syncthreads();
-    if (tid == 0) {
-        counter[0] = 0;
-        counter[1] = 0;                                  // blur_lean_kernel's work counter
-    }
+    if (tid == 0) *counter = 0;
 }
 
 // slots of the sorted list: the items, room for their segments, rounded up to an even count
@@ -2158,9 +2138,9 @@ int pano_prepare_blur_mfma(pano_ctx *ctx, const pano_patch *table, int n, int ma
         PANO_HIP(hipMalloc((void **)&ctx->item_buf,
                            ((size_t)ctx->item_cap * 2 + MB_SEG_SLOTS + 2) * sizeof(int2)));
     }
-    if (!ctx->item_counter) {                            // [0]: items found, [1]: the lean kernel's work counter
-        PANO_HIP(hipMalloc((void **)&ctx->item_counter, 2 * sizeof(int)));
-        PANO_HIP(hipMemsetAsync(ctx->item_counter, 0, 2 * sizeof(int), stream));
+    if (!ctx->item_counter) {
+        PANO_HIP(hipMalloc((void **)&ctx->item_counter, sizeof(int)));
+        PANO_HIP(hipMemsetAsync(ctx->item_counter, 0, sizeof(int), stream));
     }
     hipLaunchKernelGGL(mb_items_kernel, dim3(n), dim3(256), 0, stream, table, flags, ctx->item_buf,
                        ctx->item_counter, cap);
@@ -2288,19 +2268,10 @@ static int launch_levels(pano_ctx *ctx, const pano_patch *table, int n, int max_
         }
         if (lds_lean > 160 * 1024) lean = 0;             // (apertures above 97 taps: the general kernel)
     }
-    if (lean && ngroups == 1) {
-        // persistent workgroups, one per CU (the LDS admits no second one), taking work units
-        // off the counter mb_sort_kernel has just zeroed
-        static int cus_of[64];                           // (per device; asked once)
-        int &cus = cus_of[ctx->device & 63];
-        if (cus == 0)
-            PANO_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device));
-        const int n_work = cap * 4;
-        dim3 pgrid((unsigned)(n_work < cus ? n_work : cus), 1, 1);
+    if (lean) {
         PANO_TIMED(PK_BLUR_LEAN, stream,
-                   hipLaunchKernelGGL(blur_lean_kernel, pgrid, dim3(MB_THREADS_OF(4)), lds_lean,
-                                      stream, table, L, tables, owner, W, flags, sorted,
-                                      ctx->item_counter + 1, n_work));
+                   hipLaunchKernelGGL(blur_lean_kernel, grid, dim3(MB_THREADS_OF(4)), lds_lean,
+                                      stream, table, L, tables, owner, W, flags, sorted));
         PANO_LAUNCH_CHECK("blur_lean_kernel");
         return PANO_OK;
     }
