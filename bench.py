@@ -501,7 +501,7 @@ def secondary_single_gpu(eng, fence):
     from pano360_amd import engine, synth
     out = {}
 
-    def stitches(name, steps, warmup, distinct=None, use=None, cached=False):
+    def stitches(name, steps, warmup, distinct=None, use=None, cached=False, in_flight=1):
         use = use or eng
         cfg = workload(name)
         rots, intrs = synth.make_cameras(cfg["n"], cfg["width"], cfg["height"],
@@ -513,15 +513,41 @@ def secondary_single_gpu(eng, fence):
                 for i in range(k)]
         frames = [pool[i % k] for i in range(cfg["n"])]
 
+        # in_flight > 1: consecutive stitches alternate between engines on streams of their own
+        # (as the headline does for config 3): one stitch's kernels cover the other's host work
+        lanes = [(use, torch.cuda.current_stream(use.device))]
+        for _ in range(in_flight - 1):
+            s2 = torch.cuda.Stream(use.device)
+            with torch.cuda.stream(s2):
+                lanes.append((engine.Engine(use.device), s2))
+        state = dict(i=0, serial=False)
+
+        class AllLanes:                      # timing and kernel times over every lane
+            def timing(self, on):
+                state["serial"] = bool(on)   # (events on two streams would span each other)
+                for e, _ in lanes:
+                    e.timing(on)
+
+            def kernel_times(self):
+                total = {}
+                for e, _ in lanes:
+                    for kname, (ms_, count) in e.kernel_times().items():
+                        have = total.get(kname, (0.0, 0))
+                        total[kname] = (have[0] + ms_, have[1] + count)
+                return total
+
         def step():
-            plan = (use.cached_plan(shapes, rots, intrs, True, NATIVE) if cached
-                    else engine.Plan(shapes, rots, intrs, True, NATIVE))
-            mosaic, _, _, patches = use.stitch(frames, plan, "multiband", cfg["n_levels"])
+            e, stream = lanes[0 if state["serial"] else state["i"] % len(lanes)]
+            state["i"] += 1
+            with torch.cuda.stream(stream):
+                plan = (e.cached_plan(shapes, rots, intrs, True, NATIVE) if cached
+                        else engine.Plan(shapes, rots, intrs, True, NATIVE))
+                mosaic, _, _, patches = e.stitch(frames, plan, "multiband", cfg["n_levels"])
             return plan, mosaic, list(patches)
-        for _ in range(3):
+        for _ in range(3 * len(lanes)):
             step()
         fence()
-        elapsed, (plan, _, patches), times = timed_steps(use, step, steps, warmup, fence)
+        elapsed, (plan, _, patches), times = timed_steps(AllLanes(), step, steps, warmup, fence)
         ms = elapsed / steps * 1e3
         P = plan.patch_pixels
         entry = {
@@ -530,6 +556,7 @@ def secondary_single_gpu(eng, fence):
                         + (f" ({k} distinct frames cycled through the cameras)" if distinct else ""),
             "metric": "blended megapixels/sec (multiband)", "value": P / (ms * 1e-3) / 1e6,
             "unit": "MP/s", "ms_per_step": ms, "steps": steps, "warmup": warmup,
+            "stitches_in_flight": len(lanes),
             "mosaic": list(plan.shape), "patch_megapixels": P / 1e6,
             "warped_megapixels": sum((p.window[1] - p.window[0]) * (p.window[3] - p.window[2])
                                      for p in patches) / 1e6,
@@ -539,7 +566,9 @@ def secondary_single_gpu(eng, fence):
                                      use.active_tile_pixels(), name),
         }
         del pool, frames
-        use._arenas.clear()
+        for e, _ in lanes:
+            e._arenas.clear()
+        del lanes[1:]
         torch.cuda.empty_cache()
         return entry
 
@@ -565,7 +594,9 @@ def secondary_single_gpu(eng, fence):
                          "two consecutive stitches in flight)")
         return entry
     guarded("cfg3_one_in_flight", one_in_flight)
-    guarded("cfg2", lambda: stitches("cfg2", 20, 3))
+    # (config 2's 0.44 ms of kernels are shorter than a stitch's host work: two in flight)
+    guarded("cfg2", lambda: stitches("cfg2", 40, 4, in_flight=2))
+    guarded("cfg2_one_in_flight", lambda: stitches("cfg2", 20, 3))
 
     def cfg4(detect):
         steps = 16 if detect else 20            # (two frames in flight: a few frames per lane to warm up)
@@ -729,10 +760,10 @@ def main():
         # Stitches in flight: consecutive stitches alternate between engines on streams of their
         # own, so that one stitch's kernels fill the GPU while the other's regions travel to the
         # host and its table back (0.1 ms of a config-3 stitch during which the GPU had one short
-        # kernel to run).  Two for mosaics of 16 - 128 MP (config 3: 1.83 -> 1.715 ms per stitch;
-        # config 2 and config 5 gain nothing); PANO_SETS_IN_FLIGHT overrides.
+        # kernel to run).  Two for mosaics of 4 - 128 MP (config 3: 1.83 -> 1.715 ms per stitch,
+        # config 2: 0.508 -> 0.473; config 5 gains nothing); PANO_SETS_IN_FLIGHT overrides.
         mp = engine.Plan(shapes, rots, intrs, True, NATIVE).shape
-        default_lanes = 2 if (1 << 24) <= mp[0] * mp[1] < (1 << 27) else 1
+        default_lanes = 2 if (1 << 22) <= mp[0] * mp[1] < (1 << 27) else 1
         IN_FLIGHT["n"] = max(1, int(os.environ.get("PANO_SETS_IN_FLIGHT",
                                                    args.in_flight or default_lanes)))
         lanes = [(eng, torch.cuda.current_stream(eng.device))]

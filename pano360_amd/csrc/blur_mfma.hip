@@ -1445,6 +1445,11 @@ __device__ __forceinline__ void ms_body(const pano_patch &p, const int ch, const
         // vector / memory instructions that are to issue in its shadow (a 32x32x16 product
         // occupies the matrix pipe for 32 cycles and the SIMD's vector issue for 8 of them).
 #define MS_PIN() __builtin_amdgcn_sched_barrier(0)
+// cache policy of the tile stores: 2 = nt (the blurred copies are written once and read by the
+// collapse a kernel later, long after they have left the L2: blur 0.697 -> 0.680 ms)
+#ifndef MS_STORE_AUX
+#define MS_STORE_AUX 2
+#endif
 #ifdef MS_ABL_NOSTORE                                    // timing experiment: every store dropped
 #define MS_STORE_AT OOB
 #else
@@ -1500,7 +1505,8 @@ __device__ __forceinline__ void ms_body(const pano_patch &p, const int ch, const
                 for (int q = 0; q < 16; ++q)
                     if (store_gap(q) == g)
                         __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(sc[q]), dst, MS_STORE_AT,
-                                                              ((q & 3) + 8 * (q >> 2)) * rowstep, 0);
+                                                              ((q & 3) + 8 * (q >> 2)) * rowstep,
+                                                              MS_STORE_AUX);
             };
             constexpr int stores_before_commit = [] {
                 int n = 0;
@@ -1521,18 +1527,25 @@ __device__ __forceinline__ void ms_body(const pano_patch &p, const int ch, const
                 f32x16 mid;
 #pragma unroll
                 for (int q = 0; q < 16; ++q) mid[q] = 0.0f;
-                half8 a_hi[2], a_lo[2], b_hi[2], b_lo[2];
+                // (MS_AHEAD k-steps of operands in flight: 1 = the next k-step's reads in front of
+                // this one's products)
+#ifndef MS_AHEAD
+#define MS_AHEAD 1
+#endif
+                constexpr int NBUF = MS_AHEAD + 1;
+                half8 a_hi[NBUF], a_lo[NBUF], b_hi[NBUF], b_lo[NBUF];
                 auto operands = [&](const int s, const int b) {
                     a_hi[b] = *(const half8 *)(arow + 32 * s);
                     b_hi[b] = s_tx[(s * 2) * 64 + lane];
                     b_lo[b] = s_tx[(s * 2 + 1) * 64 + lane];
                     if (!SHARP) a_lo[b] = *(const half8 *)(arow + lo_bytes + 32 * s);
                 };
-                operands(0, 0);
+#pragma unroll
+                for (int s = 0; s < MS_AHEAD && s < KS; ++s) operands(s, s % NBUF);
 #pragma unroll
                 for (int s = 0; s < KS; ++s) {
-                    const int cur = s & 1;
-                    if (s + 1 < KS) operands(s + 1, cur ^ 1);
+                    const int cur = s % NBUF;
+                    if (s + MS_AHEAD < KS) operands(s + MS_AHEAD, (s + MS_AHEAD) % NBUF);
                     MS_PIN();
 #pragma unroll
                     for (int m = 0; m < PR; ++m) {
