@@ -112,9 +112,14 @@ __host__ __device__ static inline int mb_c_of(int ntaps) {       // K-steps eith
 }
 // which of a group's levels the wave pair q works on: waves w and w + 4 share a SIMD, so
 // pairs q and q + 2 do: heavy levels (large radius) sit next to light ones
+// Five levels (blur_lean_kernel only): the heaviest three a pair each, the two lightest both on
+// the fourth pair (mb_second_level_of_pair), which works on them one after the other.
 __host__ __device__ static inline int mb_level_of_pair(int nl, int q) {
-    const int order[4][4] = {{0, -1, -1, -1}, {1, 0, -1, -1}, {2, 1, 0, -1}, {3, 2, 0, 1}};
+    const int order[5][4] = {{0, -1, -1, -1}, {1, 0, -1, -1}, {2, 1, 0, -1}, {3, 2, 0, 1}, {4, 3, 2, 1}};
     return q < 4 ? order[nl - 1][q] : -1;
+}
+__host__ __device__ static inline int mb_second_level_of_pair(int nl, int q) {
+    return nl == 5 && q == 3 ? 0 : -1;
 }
 // Column-pass Toeplitz blocks (d, s), d = -DMAX .. DMAX, s = 0, 1, hold tap[32 d + k - m + r] for
 // k in [16 s, 16 s + 16), m in [0, 32): block (-DMAX, 0) / (DMAX, 1) is all zeros when it lies
@@ -129,10 +134,23 @@ __host__ __device__ static inline int mb_fixed_bytes(int cm) {
     return 2 * 32 * mb_pitch_of(cm) * 2 + 2 * MB_NEED_LEN + MB_NEED_LEN + 4 * MB_NEED_LEN +
            (MB_PITCH4 + 8) * 2;
 }
+// Row-pass Toeplitz operand of a level, compact: the block of k-step s + 1 is the block of k-step
+// s shifted by 16 columns (B_s[k][n] = tap[16 (s - C) + k - n + r]), so all KS blocks are windows
+// of ONE table over m = n + 16 (KS - 1 - s), 0 <= m < 16 (KS + 1): [hi, lo][k half h][m] entries of
+// eight float16 (k = 8 h .. 8 h + 7).  A lane's entry for k-step s lies 256 (KS - 1 - s) bytes
+// past its entry for the last k-step - an immediate offset - and consecutive lanes read
+// consecutive 16-byte entries as before.  (KS + 1) KB per level instead of 2 KS.
+__host__ __device__ static inline int mb_tx_entries(int ks) { return 16 * (ks + 1); }
+__host__ __device__ static inline int mb_tx_bytes(int ks) { return 4 * mb_tx_entries(ks) * 16; }
+// index (in half8 entries from the level's table) of lane `lane`'s B operand for k-step s
+__host__ __device__ static inline int mb_tx_index(int ks, int lane, int s, int lo) {
+    const int nm = mb_tx_entries(ks);
+    return (2 * lo + (lane >> 5)) * nm + (lane & 31) + 16 * (ks - 1 - s);
+}
 __host__ __device__ static inline int mb_table_bytes(int ntaps) {
     const int c = mb_c_of(ntaps), ks = 2 + 2 * c, dmax = (c + 1) / 2, nb = 2 * dmax + 1, r = ntaps >> 1;
     const int blocks = 2 * nb - (mb_block_zero(-dmax, 0, r) ? 1 : 0) - (mb_block_zero(dmax, 1, r) ? 1 : 0);
-    return ks * 2 * 1024 + blocks * 2 * 1024;
+    return mb_tx_bytes(ks) + blocks * 2 * 1024;
 }
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for every
@@ -481,8 +499,8 @@ __device__ __forceinline__ void mb_body(const pano_patch &p, const int ch, const
             half8 a_hi[2], a_lo[2], b_hi[2], b_lo[2];
             auto operands = [&](const int s, const int buf) {
                 a_hi[buf] = *(const half8 *)(arow + 16 * s);
-                b_hi[buf] = s_tx[(s * 2) * 64 + lane];
-                b_lo[buf] = s_tx[(s * 2 + 1) * 64 + lane];
+                b_hi[buf] = s_tx[mb_tx_index(KS, lane, s, 0)];
+                b_lo[buf] = s_tx[mb_tx_index(KS, lane, s, 1)];
                 if (!alpha) a_lo[buf] = *(const half8 *)(brow + 16 * s);
             };
             operands(0, 0);
@@ -533,25 +551,26 @@ __device__ __forceinline__ void mb_body(const pano_patch &p, const int ch, const
 //   row pass     B[k][n] = tap[16 (s - C) + k - n + r],      s = 0 .. KS-1
 //   column pass  A[m][k] = tap[32 d + k - m + r], d = -DMAX .. DMAX, k in the order the
 //                row pass's accumulator registers hold Mid's rows
-// Layout per level: [s][hi, lo][lane] half8, then [d][s][hi, lo][lane] half8.
+// Layout per level: the compact row-pass table (mb_tx_index), then [d][s][hi, lo][lane] half8.
 __global__ __launch_bounds__(128) void mb_tables_kernel(MbLevels L, unsigned char *out) {
     __shared__ float w[MB_WLEN];
     const int level = blockIdx.x, ntaps = L.ntaps[level], r = ntaps >> 1;
     const int c = mb_c_of(ntaps), KS = 2 + 2 * c, DMAX = (c + 1) / 2, NB = 2 * DMAX + 1;
     for (int i = threadIdx.x; i <= ntaps; i += 128) w[i] = i < ntaps ? L.w[level][i] : 0.0f;
     __syncthreads();
-    half8 *tx = (half8 *)(out + L.tab_off[level]), *ty = tx + KS * 2 * 64;
-    for (int idx = threadIdx.x; idx < KS * 64; idx += 128) {
-        const int s = idx >> 6, l = idx & 63, nn = l & 31, hh = l >> 5;
+    half8 *tx = (half8 *)(out + L.tab_off[level]), *ty = (half8 *)(out + L.tab_off[level] + mb_tx_bytes(KS));
+    const int NM = mb_tx_entries(KS);
+    for (int idx = threadIdx.x; idx < 2 * NM; idx += 128) {
+        const int hh = idx / NM, m = idx - hh * NM;         // m = n + 16 (KS - 1 - s)
         half8 hi, lo;
         for (int j = 0; j < 8; ++j) {
             _Float16 a, b;
-            split16(tap_at(w, ntaps, 16 * (s - c) + 8 * hh + j - nn + r), a, b);
+            split16(tap_at(w, ntaps, 16 * (KS - 1 - c) + 8 * hh + j - m + r), a, b);
             hi[j] = a;
             lo[j] = b;
         }
-        tx[(s * 2) * 64 + l] = hi;
-        tx[(s * 2 + 1) * 64 + l] = lo;
+        tx[hh * NM + m] = hi;
+        tx[(2 + hh) * NM + m] = lo;
     }
     const int z0 = mb_block_zero(-DMAX, 0, r) ? 1 : 0;
     for (int idx = threadIdx.x; idx < NB * 2 * 64; idx += 128) {
@@ -618,7 +637,7 @@ __device__ __forceinline__ void mb_general(
         dmax_of[k] = (ck + 1) / 2;
         if (k == q) {
             my_tx = rel;
-            my_ty = rel + (2 + 2 * ck) * 2 * 1024;
+            my_ty = rel + mb_tx_bytes(2 + 2 * ck);
         }
         rel += mb_table_bytes(L.ntaps[l0 + lk]);
     }
@@ -943,8 +962,8 @@ __device__ __forceinline__ void ml_body(const pano_patch &p, const int ch, const
         half8 a_hi[2], a_lo[2], b_hi[2], b_lo[2];
         auto operands = [&](const int s, const int b) {
             a_hi[b] = *(const half8 *)(arow + 16 * s);
-            b_hi[b] = s_tx[(s * 2) * 64 + lane];
-            b_lo[b] = s_tx[(s * 2 + 1) * 64 + lane];
+            b_hi[b] = s_tx[mb_tx_index(KS, lane, s, 0)];
+            b_lo[b] = s_tx[mb_tx_index(KS, lane, s, 1)];
             if (!sharp) a_lo[b] = *(const half8 *)(brow + 16 * s);
         };
         operands(0, 0);
@@ -1156,13 +1175,21 @@ __device__ __forceinline__ void ms_split2(const float a, const float b, const fl
         : "v"(a), "v"(b), "s"(s));
 }
 
-template <int C, bool SHARP>
+// CB != 0: the wave pair works on TWO levels, C and then CB, from the same staged band (their
+// accumulators must rotate alike: equal DMAX) - five levels on the four wave pairs of a
+// workgroup, so that a sixth pyramid level (stitcher.py:186, n_levels = 6) does not cost a second
+// launch that stages every band again.
+template <int C, bool SHARP, int CB = 0>
 __device__ __forceinline__ void ms_body(const pano_patch &p, const int ch, const int out_level,
                                         const bool live, const half8 *s_tx, const half8 *s_ty,
                                         const MbShared &sh, const uint32_t *list, const int nlist,
                                         const int16_t *__restrict__ owner_, const int W,
-                                        const int tx0, const int second) {
+                                        const int tx0, const int second, const int out_level_b = 0,
+                                        const half8 *s_tx_b = nullptr,
+                                        const half8 *s_ty_b = nullptr) {
     constexpr int KS = 2 + 2 * C, DMAX = (C + 1) / 2, NB = 2 * DMAX + 1, Z = C & 1;
+    constexpr int KS_B = 2 + 2 * CB, Z_B = CB & 1;
+    static_assert(CB == 0 || 2 * ((CB + 1) / 2) + 1 == NB, "two levels of a wave: equal DMAX");
     constexpr unsigned OOB = 0x80000000u;
     typedef unsigned uint4v __attribute__((ext_vector_type(4)));
     typedef unsigned uint2v __attribute__((ext_vector_type(2)));
@@ -1177,10 +1204,14 @@ __device__ __forceinline__ void ms_body(const pano_patch &p, const int ch, const
     const int BW = MB_XT + 32 * CM, CPR = BW >> 2, NCH = 32 * CPR;
     const int my_lo = g.O0 - DMAX, my_hi = g.O1 + DMAX;
 
-    f32x16 acc[NB];
+    f32x16 acc[NB], acc_b[CB ? NB : 1];
     const __amdgpu_buffer_rsrc_t dst = __builtin_amdgcn_make_buffer_rsrc(
         (void *)(p.blurred + (size_t)(out_level * 4 + ch) * p.ah * p.apitch), 0, p.ah * p.apitch * 4,
         0x00020000);
+    const __amdgpu_buffer_rsrc_t dst_b = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)(p.blurred + (size_t)((CB ? out_level_b : out_level) * 4 + ch) * p.ah * p.apitch), 0,
+        p.ah * p.apitch * 4, 0x00020000);
+    (void)KS_B;
 
     // ---- this thread's 2.5 chunks ------------------------------------------------------
     // slot 0, 1: chunk tid, 512 + tid (four columns, 16 bytes); slot 2: half (tid & 1) of chunk
@@ -1342,8 +1373,11 @@ __device__ __forceinline__ void ms_body(const pano_patch &p, const int ch, const
         switch (prev_u) {
 #define MS_STORE_CASE(UU)                                                                      \
     case UU:                                                                                   \
-        if constexpr (UU < NB)                                                                 \
+        if constexpr (UU < NB) {                                                               \
             ml_store(acc[(UU + DMAX + 1) % NB], prev_o, lane, p, dst, px0, prev_store);        \
+            if constexpr (CB != 0)                                                             \
+                ml_store(acc_b[(UU + DMAX + 1) % NB], prev_o, lane, p, dst_b, px0, prev_store); \
+        }                                                                                      \
         break;
             MS_STORE_CASE(0) MS_STORE_CASE(1) MS_STORE_CASE(2) MS_STORE_CASE(3) MS_STORE_CASE(4)
 #undef MS_STORE_CASE
@@ -1436,8 +1470,10 @@ __device__ __forceinline__ void ms_body(const pano_patch &p, const int ch, const
         Band pf;
         unsigned nn = 0;                                 // the list word after next (prepare_next)
         if (fetch_general) offsets_general(band_of(next), more, voff, okv);
-        if (store_edge)                                  // cut by A's first or last row
+        if (store_edge) {                                // cut by A's first or last row
             ml_store(acc[KP], prev_o, lane, p, dst, px0, true);
+            if constexpr (CB != 0) ml_store(acc_b[CB ? KP : 0], prev_o, lane, p, dst_b, px0, true);
+        }
         // (its sixteen stores stand in front of the block's, whose base is beyond the plane then)
         const bool work = t >= my_lo && t <= my_hi && inf != 0;                        // uniform
         // ---- the block.  Its order is written out by hand and pinned: the scheduler may not
@@ -1458,11 +1494,14 @@ __device__ __forceinline__ void ms_body(const pano_patch &p, const int ch, const
         auto block = [&](auto work_c) {
             constexpr bool WORK = decltype(work_c)::value;
             constexpr int PR = SHARP ? 2 : 3;            // products per k-step of the row pass
-            constexpr int BLK = NB - Z;                  // stored half-blocks per k half of the column pass
-            // the block's gaps (one behind every product), numbered through both passes
-            constexpr int GR = KS * PR, GC = 2 * BLK * 3, G = GR + GC;
-            constexpr int PER_R = (16 + GR - 1) / GR;    // scaled values per row-pass gap
-            constexpr int G_COMMIT = GR + BLK * 3;       // first gap of the column pass's second half
+            // the block's gaps (one behind every product), numbered through the passes of the
+            // wave's level - or of its two levels, one after the other (CB)
+            constexpr int BLK_A = NB - Z, GR_A = KS * PR, GC_A = 2 * BLK_A * 3;
+            constexpr int BLK_B = CB ? NB - Z_B : 0, GR_B = CB ? KS_B * PR : 0, GC_B = 2 * BLK_B * 3;
+            constexpr int G = GR_A + GC_A + GR_B + GC_B;
+            constexpr int NSTORE = CB ? 32 : 16;         // values of the finished tile(s) per lane
+            constexpr int PER_R = (NSTORE + GR_A - 1) / GR_A;   // scaled values per gap of the first row pass
+            constexpr int G_COMMIT = GR_A + BLK_A * 3;   // first gap of the first column pass's second half
             MS_STAMP(2);            // prologue
             issue(pf, voff);
             // the list word after next (wanted at the block's end: its latency is covered)
@@ -1486,148 +1525,164 @@ __device__ __forceinline__ void ms_body(const pano_patch &p, const int ch, const
             // would compute the sixteen of them once, in front of the branch that leads here)
             float out_scale = MB_OUT_SCALE;
             asm("" : "+s"(out_scale));
-            // The finished tile: scaled during the first gaps, stored at an even pace over ALL the
-            // block's gaps.  (A CU passes one dword store instruction per ~11 cycles, 128 of them
-            // per step for its eight waves: issued back to back behind the barrier they made the
-            // row pass 2.5 - 3.3 k cycles long for 0.8 k cycles of products - phase timers,
+            // The finished tile(s): scaled during the first gaps, stored at an even pace over ALL
+            // the block's gaps.  (A CU passes one dword store instruction per ~11 cycles, 128 of
+            // them per step for its eight waves: issued back to back behind the barrier they made
+            // the row pass 2.5 - 3.3 k cycles long for 0.8 k cycles of products - phase timers,
             // profiles/r04/notes.md.)
-            float sc[16];
-            auto store_gap = [](const int q) { return ((2 * q + 1) * G) / 32; };
+            float sc[NSTORE];
+            auto store_gap = [](const int q) { return ((2 * q + 1) * G) / (2 * NSTORE); };
             auto fill = [&](const int g) {               // what issues in gap g's shadow
-                if (g < GR) {
+                if (g < GR_A) {
 #pragma unroll
                     for (int c = 0; c < PER_R; ++c) {
                         const int q = g * PER_R + c;
                         if (q < 16) sc[q] = acc[KP][q] * out_scale;
+                        if (CB && q >= 16 && q < NSTORE) sc[q] = acc_b[CB ? KP : 0][q & 15] * out_scale;
                     }
                 }
 #pragma unroll
-                for (int q = 0; q < 16; ++q)
+                for (int q = 0; q < NSTORE; ++q)
                     if (store_gap(q) == g)
-                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(sc[q]), dst, MS_STORE_AT,
-                                                              ((q & 3) + 8 * (q >> 2)) * rowstep,
-                                                              MS_STORE_AUX);
+                        __builtin_amdgcn_raw_buffer_store_b32(
+                            __float_as_uint(sc[q]), q < 16 ? dst : dst_b, MS_STORE_AT,
+                            (((q & 15) & 3) + 8 * ((q & 15) >> 2)) * rowstep, MS_STORE_AUX);
             };
             constexpr int stores_before_commit = [] {
                 int n = 0;
-                for (int q = 0; q < 16; ++q) n += ((2 * q + 1) * G) / 32 < G_COMMIT ? 1 : 0;
+                for (int q = 0; q < NSTORE; ++q) n += ((2 * q + 1) * G) / (2 * NSTORE) < G_COMMIT ? 1 : 0;
                 return n;
             }();
             if constexpr (!WORK) {
 #pragma unroll
                 for (int g = 0; g < G; ++g) fill(g);
                 MS_PIN();
-                commit_wait(pf, std::integral_constant<int, 16>{});
+                commit_wait(pf, std::integral_constant<int, NSTORE>{});
 #pragma unroll
                 for (int k = 0; k < 3; ++k) commit_piece(pf, okv, off_nxt, k);
                 prepare_next();
             } else {
-                // row pass: the operands of k-step s + 1 are read while k-step s multiplies
-                const unsigned char *const arow = (const unsigned char *)sh.hi + a_lane + 2 * off_cur;
-                f32x16 mid;
+                // One level's two passes.  G0: the level's first gap; COMMIT: the next band is
+                // converted and written to LDS under the second half of this level's column pass;
+                // LAST: the next step's scalars are prepared in this level's last gap.
+                auto level = [&](auto cc_c, auto g0_c, auto commit_c, auto last_c, f32x16 (&A)[NB],
+                                 const half8 *tx, const half8 *ty) {
+                    constexpr int CC = decltype(cc_c)::value, G0 = decltype(g0_c)::value;
+                    constexpr bool COMMIT = decltype(commit_c)::value, LAST = decltype(last_c)::value;
+                    constexpr int KSL = 2 + 2 * CC, DMAXL = (CC + 1) / 2, ZL = CC & 1, BLK = NB - ZL;
+                    static_assert(2 * DMAXL + 1 == NB, "a wave's levels share the accumulator rotation");
+                    // row pass: the operands of k-step s + 1 are read while k-step s multiplies
+                    const unsigned char *const arow =
+                        (const unsigned char *)sh.hi + (a_lane + 32 * (C - CC)) + 2 * off_cur;
+                    f32x16 mid;
 #pragma unroll
-                for (int q = 0; q < 16; ++q) mid[q] = 0.0f;
-                // (MS_AHEAD k-steps of operands in flight: 1 = the next k-step's reads in front of
-                // this one's products)
+                    for (int q = 0; q < 16; ++q) mid[q] = 0.0f;
+                    // (MS_AHEAD k-steps of operands in flight: 1 = the next k-step's reads in
+                    // front of this one's products)
 #ifndef MS_AHEAD
 #define MS_AHEAD 1
 #endif
-                constexpr int NBUF = MS_AHEAD + 1;
-                half8 a_hi[NBUF], a_lo[NBUF], b_hi[NBUF], b_lo[NBUF];
-                auto operands = [&](const int s, const int b) {
-                    a_hi[b] = *(const half8 *)(arow + 32 * s);
-                    b_hi[b] = s_tx[(s * 2) * 64 + lane];
-                    b_lo[b] = s_tx[(s * 2 + 1) * 64 + lane];
-                    if (!SHARP) a_lo[b] = *(const half8 *)(arow + lo_bytes + 32 * s);
-                };
+                    constexpr int NBUF = MS_AHEAD + 1;
+                    half8 a_hi[NBUF], a_lo[NBUF], b_hi[NBUF], b_lo[NBUF];
+                    auto operands = [&](const int s, const int b) {
+                        a_hi[b] = *(const half8 *)(arow + 32 * s);
+                        b_hi[b] = tx[mb_tx_index(KSL, lane, s, 0)];
+                        b_lo[b] = tx[mb_tx_index(KSL, lane, s, 1)];
+                        if (!SHARP) a_lo[b] = *(const half8 *)(arow + lo_bytes + 32 * s);
+                    };
 #pragma unroll
-                for (int s = 0; s < MS_AHEAD && s < KS; ++s) operands(s, s % NBUF);
+                    for (int s = 0; s < MS_AHEAD && s < KSL; ++s) operands(s, s % NBUF);
 #pragma unroll
-                for (int s = 0; s < KS; ++s) {
-                    const int cur = s % NBUF;
-                    if (s + MS_AHEAD < KS) operands(s + MS_AHEAD, (s + MS_AHEAD) % NBUF);
-                    MS_PIN();
-#pragma unroll
-                    for (int m = 0; m < PR; ++m) {
-                        mid = __builtin_amdgcn_mfma_f32_32x32x16_f16(
-                            m == 2 ? a_lo[cur] : a_hi[cur], m == 1 ? b_lo[cur] : b_hi[cur], mid, 0, 0, 0);
+                    for (int s = 0; s < KSL; ++s) {
+                        const int cur = s % NBUF;
+                        if (s + MS_AHEAD < KSL) operands(s + MS_AHEAD, (s + MS_AHEAD) % NBUF);
                         MS_PIN();
-                        fill(s * PR + m);
-                        MS_PIN();
-                    }
-                }
-                MS_STAMP(3);        // row pass
-                // column pass, k-half-major.  Block b = (half, d): two operand reads and three
-                // products; the operands of block b + 1 are read in front of block b's products;
-                // the second half of Mid is split under the first half's products, the next
-                // band is converted and written to LDS under the second half's.
-                unsigned m_hi[2][4], m_lo[2][4];          // eight float16 each: the B operands
-                auto operand_b = [](const unsigned (&w)[4]) {
-                    const uint4v v = {w[0], w[1], w[2], w[3]};
-                    return __builtin_bit_cast(half8, v);
-                };
-                const float mid_scale = __builtin_bit_cast(
-                    float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, MB_MID_SCALE)));
-                half8 t_hi[2], t_lo[2];
-                auto ty_read = [&](const int bb, const int buf) {       // bb = s2 * BLK + b
-                    const int s2 = bb / BLK, b = bb - s2 * BLK;
-                    const int d = -DMAX + b + (Z && s2 == 0 ? 1 : 0);
-                    const half8 *ty = s_ty + (((d + DMAX) * 2 + s2 - Z) * 2) * 64 + lane;
-                    t_hi[buf] = ty[0];
-                    t_lo[buf] = ty[64];
-                };
-                ty_read(0, 0);
-                MS_PIN();
-                ms_split4<true>(mid[0], mid[1], mid[2], mid[3], mid_scale, m_hi[0][0], m_lo[0][0],
-                                m_hi[0][1], m_lo[0][1]);
-                ms_split4<false>(mid[4], mid[5], mid[6], mid[7], mid_scale, m_hi[0][2], m_lo[0][2],
-                                 m_hi[0][3], m_lo[0][3]);
-                MS_PIN();
-                constexpr int GAPS_H = BLK * 3, PAIRS_PER = (4 + GAPS_H - 1) / GAPS_H;
 #pragma unroll
-                for (int bb = 0; bb < 2 * BLK; ++bb) {
-                    const int s2 = bb / BLK, b = bb - s2 * BLK, buf = bb & 1;
-                    const int d = -DMAX + b + (Z && s2 == 0 ? 1 : 0);
-                    const int k = ((U - d) % NB + NB) % NB;          // tile t - d lives in accumulator k
-                    const bool first = d == -DMAX && s2 == Z;        // starts tile t + DMAX's sum
-                    if (bb + 1 < 2 * BLK) ty_read(bb + 1, buf ^ 1);
-                    MS_PIN();
-#pragma unroll
-                    for (int m = 0; m < 3; ++m) {
-                        if (m == 0 && first) {
-                            f32x16 zero;
-#pragma unroll
-                            for (int q = 0; q < 16; ++q) zero[q] = 0.0f;
-                            acc[k] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
-                                t_hi[buf], operand_b(m_hi[s2]), zero, 0, 0, 0);
-                        } else {
-                            acc[k] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
-                                m == 1 ? t_lo[buf] : t_hi[buf],
-                                operand_b(m == 2 ? m_lo[s2] : m_hi[s2]), acc[k], 0, 0, 0);
+                        for (int m = 0; m < PR; ++m) {
+                            mid = __builtin_amdgcn_mfma_f32_32x32x16_f16(
+                                m == 2 ? a_lo[cur] : a_hi[cur], m == 1 ? b_lo[cur] : b_hi[cur], mid, 0, 0, 0);
+                            MS_PIN();
+                            fill(G0 + s * PR + m);
+                            MS_PIN();
                         }
-                        MS_PIN();
-                        const int hg = b * 3 + m;                    // gap within this half
-                        if (s2 == 0) {
+                    }
+                    if (G0 == 0) MS_STAMP(3);            // (first) row pass
+                    // column pass, k-half-major.  Block b = (half, d): two operand reads and three
+                    // products; the operands of block b + 1 are read in front of block b's
+                    // products; the second half of Mid is split under the first half's products.
+                    unsigned m_hi[2][4], m_lo[2][4];      // eight float16 each: the B operands
+                    auto operand_b = [](const unsigned (&w)[4]) {
+                        const uint4v v = {w[0], w[1], w[2], w[3]};
+                        return __builtin_bit_cast(half8, v);
+                    };
+                    const float mid_scale = __builtin_bit_cast(
+                        float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, MB_MID_SCALE)));
+                    half8 t_hi[2], t_lo[2];
+                    auto ty_read = [&](const int bb, const int buf) {       // bb = s2 * BLK + b
+                        const int s2 = bb / BLK, b = bb - s2 * BLK;
+                        const int d = -DMAXL + b + (ZL && s2 == 0 ? 1 : 0);
+                        const half8 *at = ty + (((d + DMAXL) * 2 + s2 - ZL) * 2) * 64 + lane;
+                        t_hi[buf] = at[0];
+                        t_lo[buf] = at[64];
+                    };
+                    ty_read(0, 0);
+                    MS_PIN();
+                    ms_split4<true>(mid[0], mid[1], mid[2], mid[3], mid_scale, m_hi[0][0], m_lo[0][0],
+                                    m_hi[0][1], m_lo[0][1]);
+                    ms_split4<false>(mid[4], mid[5], mid[6], mid[7], mid_scale, m_hi[0][2], m_lo[0][2],
+                                     m_hi[0][3], m_lo[0][3]);
+                    MS_PIN();
+                    constexpr int GAPS_H = BLK * 3, PAIRS_PER = (4 + GAPS_H - 1) / GAPS_H;
 #pragma unroll
-                            for (int c = 0; c < PAIRS_PER; ++c) {
-                                const int pr = hg * PAIRS_PER + c;
-                                if (pr < 4)
-                                    ms_split2(mid[8 + 2 * pr], mid[9 + 2 * pr], mid_scale, m_hi[1][pr],
-                                              m_lo[1][pr]);
+                    for (int bb = 0; bb < 2 * BLK; ++bb) {
+                        const int s2 = bb / BLK, b = bb - s2 * BLK, buf = bb & 1;
+                        const int d = -DMAXL + b + (ZL && s2 == 0 ? 1 : 0);
+                        const int k = ((U - d) % NB + NB) % NB;      // tile t - d lives in accumulator k
+                        const bool first = d == -DMAXL && s2 == ZL;  // starts tile t + DMAX's sum
+                        if (bb + 1 < 2 * BLK) ty_read(bb + 1, buf ^ 1);
+                        MS_PIN();
+#pragma unroll
+                        for (int m = 0; m < 3; ++m) {
+                            if (m == 0 && first) {
+                                f32x16 zero;
+#pragma unroll
+                                for (int q = 0; q < 16; ++q) zero[q] = 0.0f;
+                                A[k] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
+                                    t_hi[buf], operand_b(m_hi[s2]), zero, 0, 0, 0);
+                            } else {
+                                A[k] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
+                                    m == 1 ? t_lo[buf] : t_hi[buf],
+                                    operand_b(m == 2 ? m_lo[s2] : m_hi[s2]), A[k], 0, 0, 0);
                             }
-                        } else {
-                            // (the loads were issued some 3 k cycles ago; the stores issued since
-                            // stay in flight)
-                            if (hg == 0)
-                                commit_wait(pf, std::integral_constant<int, stores_before_commit>{});
-                            if (hg < 3) commit_piece(pf, okv, off_nxt, hg);
+                            MS_PIN();
+                            const int hg = b * 3 + m;                // gap within this half
+                            if (s2 == 0) {
+#pragma unroll
+                                for (int c = 0; c < PAIRS_PER; ++c) {
+                                    const int pr = hg * PAIRS_PER + c;
+                                    if (pr < 4)
+                                        ms_split2(mid[8 + 2 * pr], mid[9 + 2 * pr], mid_scale,
+                                                  m_hi[1][pr], m_lo[1][pr]);
+                                }
+                            } else if (COMMIT) {
+                                // (the loads were issued some 3 k cycles ago; the stores issued
+                                // since stay in flight)
+                                if (hg == 0)
+                                    commit_wait(pf, std::integral_constant<int, stores_before_commit>{});
+                                if (hg < 3) commit_piece(pf, okv, off_nxt, hg);
+                            }
+                            fill(G0 + KSL * PR + s2 * GAPS_H + hg);
+                            // (after this gap's store: the store's base is the one prepared for THIS step)
+                            if (LAST && s2 == 1 && hg == GAPS_H - 1) prepare_next();
+                            MS_PIN();
                         }
-                        fill(GR + s2 * GAPS_H + hg);
-                        // (after this gap's store: the store's base is the one prepared for THIS step)
-                        if (s2 == 1 && hg == GAPS_H - 1) prepare_next();
-                        MS_PIN();
                     }
-                }
+                };
+                level(std::integral_constant<int, C>{}, std::integral_constant<int, 0>{}, std::true_type{},
+                      std::integral_constant<bool, CB == 0>{}, acc, s_tx, s_ty);
+                if constexpr (CB != 0)
+                    level(std::integral_constant<int, CB>{}, std::integral_constant<int, GR_A + GC_A>{},
+                          std::false_type{}, std::true_type{}, acc_b, s_tx_b, s_ty_b);
                 MS_STAMP(4);        // split + column pass (+ the next band's conversion)
             }
             MS_PIN();
@@ -1668,7 +1723,10 @@ __device__ __forceinline__ void ms_body(const pano_patch &p, const int ch, const
 #pragma unroll
         for (int k = 0; k < NB; ++k)
 #pragma unroll
-            for (int q = 0; q < 16; ++q) acc[k][q] = 0.0f;
+            for (int q = 0; q < 16; ++q) {
+                acc[k][q] = 0.0f;
+                if (CB) acc_b[CB ? k : 0][q] = 0.0f;
+            }
         for (;;) {
             if (!step(std::integral_constant<int, 0>{})) break;
             if (!step(std::integral_constant<int, 1>{})) break;
@@ -1691,7 +1749,9 @@ __global__ __launch_bounds__(MB_THREADS_OF(4), 1) void blur_lean_kernel(
     constexpr int GROUP = 4;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
-    const int ngroups = (L.n + GROUP - 1) / GROUP;
+    // (five levels: ONE group of four wave pairs, the two lightest levels on one pair)
+    const bool five = MB_STREAM && L.n == 5;
+    const int ngroups = five ? 1 : (L.n + GROUP - 1) / GROUP;
     const int per = 8 * ngroups, blk = blockIdx.x / per, within = blockIdx.x - blk * per;
     const int grp = within >> 3, pair = blk * 8 + (within & 7);
     const int ch = pair & 3, slot = pair >> 2;
@@ -1700,7 +1760,7 @@ __global__ __launch_bounds__(MB_THREADS_OF(4), 1) void blur_lean_kernel(
     const int pid = item.x & 0xffff, tx0 = item.x >> 16;
     const pano_patch p = table[pid];
     const MbGeom g = mb_geom(p);
-    const int l0 = GROUP * grp, nl = L.n - l0 < GROUP ? L.n - l0 : GROUP;
+    const int l0 = GROUP * grp, nl = five ? 5 : (L.n - l0 < GROUP ? L.n - l0 : GROUP);
     // the group's reach, and whether this item is one of ours
     MbShared sh;
     sh.CM = 1;
@@ -1712,6 +1772,16 @@ __global__ __launch_bounds__(MB_THREADS_OF(4), 1) void blur_lean_kernel(
         // not one of ours: the general path, in this same workgroup (a second launch over the
         // list, every workgroup of which returns at once for a regular item, cost 0.31 ms on
         // config 3: 5120 workgroups of 512 threads and 128 KB of LDS each, one per CU at a time)
+        if (five) {
+            // (the general path takes four levels per workgroup: this one does both groups, one
+            // after the other; its work index = block of 8 pairs x groups + group x 8 + pair)
+            for (int gg = 0; gg < 2; ++gg) {
+                __syncthreads();
+                mb_general<GROUP>(table, L, tables, owner, W, flags, items, smem,
+                                  (pair >> 3) * 16 + gg * 8 + (pair & 7));
+            }
+            return;
+        }
         mb_general<GROUP>(table, L, tables, owner, W, flags, items, smem, (int)blockIdx.x);
         return;
     }
@@ -1723,7 +1793,9 @@ __global__ __launch_bounds__(MB_THREADS_OF(4), 1) void blur_lean_kernel(
     const bool live = lv >= 0;
     const int level = l0 + (live ? lv : 0);
     const int ntaps = L.ntaps[level], c = mb_c_of(ntaps);
-    int dmax_of[GROUP], rel = 0, my_tx = 0, my_ty = 0;
+    const int lv_b = mb_second_level_of_pair(nl, q);    // the pair's second level, or -1
+    const int level_b = l0 + (lv_b >= 0 ? lv_b : 0);
+    int dmax_of[GROUP], rel = 0, my_tx = 0, my_ty = 0, my_tx_b = 0, my_ty_b = 0;
     for (int k = 0; k < GROUP; ++k) {
         const int lk = mb_level_of_pair(nl, k);
         dmax_of[k] = -1;
@@ -1732,9 +1804,18 @@ __global__ __launch_bounds__(MB_THREADS_OF(4), 1) void blur_lean_kernel(
         dmax_of[k] = (ck + 1) / 2;
         if (k == q) {
             my_tx = rel;
-            my_ty = rel + (2 + 2 * ck) * 2 * 1024;
+            my_ty = rel + mb_tx_bytes(2 + 2 * ck);
         }
         rel += mb_table_bytes(L.ntaps[l0 + lk]);
+        const int lk2 = mb_second_level_of_pair(nl, k);
+        if (lk2 >= 0) {                                  // (equal DMAX: the host checked)
+            const int ck2 = mb_c_of(L.ntaps[l0 + lk2]);
+            if (k == q) {
+                my_tx_b = rel;
+                my_ty_b = rel + mb_tx_bytes(2 + 2 * ck2);
+            }
+            rel += mb_table_bytes(L.ntaps[l0 + lk2]);
+        }
     }
     sh.P = mb_pitch_of(sh.CM);
     sh.hi = (_Float16 *)smem;
@@ -1746,13 +1827,16 @@ __global__ __launch_bounds__(MB_THREADS_OF(4), 1) void blur_lean_kernel(
     uint32_t *list = (uint32_t *)sh.info;                // [MB_NEED_LEN] words: same bytes
     my_tx += mb_fixed_bytes(sh.CM);
     my_ty += mb_fixed_bytes(sh.CM);
+    my_tx_b += mb_fixed_bytes(sh.CM);
+    my_ty_b += mb_fixed_bytes(sh.CM);
     const int dmaxm = (sh.CM + 1) / 2;
     sh.t_lo = g.O0 - dmaxm;
     sh.t_hi = g.O1 + dmaxm;
+    for (int which = 0; which < (lv_b >= 0 ? 2 : 1); ++which)
     if (live) {
-        const uint4 *from = (const uint4 *)(tables + L.tab_off[level]);
-        uint4 *to = (uint4 *)(smem + my_tx);
-        const int n16 = mb_table_bytes(ntaps) >> 4;
+        const uint4 *from = (const uint4 *)(tables + L.tab_off[which ? level_b : level]);
+        uint4 *to = (uint4 *)(smem + (which ? my_tx_b : my_tx));
+        const int n16 = mb_table_bytes(L.ntaps[which ? level_b : level]) >> 4;
         // (every load of a round issued before its first LDS store: 16 - 32 KB per wave pair)
         constexpr int DEPTH = 8;
         for (int i0 = tid & 127; i0 < n16; i0 += 128 * DEPTH) {
@@ -1811,6 +1895,18 @@ __global__ __launch_bounds__(MB_THREADS_OF(4), 1) void blur_lean_kernel(
 #define ML_BODY_FN ms_body
 #else
 #define ML_BODY_FN ml_body
+#endif
+#if MB_STREAM
+    if (lv_b >= 0) {                                     // wave-uniform: levels of 2 and 1 K-steps' reach
+        const half8 *s_tx_b = (const half8 *)(smem + my_tx_b), *s_ty_b = (const half8 *)(smem + my_ty_b);
+        if (ch == 3)
+            ms_body<2, true, 1>(p, ch, out_level, live, s_tx, s_ty, sh, list, nlist, owner, W, tx0,
+                                second, L.out[level_b], s_tx_b, s_ty_b);
+        else
+            ms_body<2, false, 1>(p, ch, out_level, live, s_tx, s_ty, sh, list, nlist, owner, W, tx0,
+                                 second, L.out[level_b], s_tx_b, s_ty_b);
+        return;
+    }
 #endif
     switch (c) {                                         // wave-uniform
 #define ML_BODY(CC)                                                                            \
@@ -2262,6 +2358,11 @@ static int launch_levels(pano_ctx *ctx, const pano_patch *table, int n, int max_
     // Groups of four levels with real apertures: the kernel that runs the regular items
     // through the lean path (and the others through the general one).
     int lean = MB_LEAN && ctx->opt[PANO_OPT_BLUR_LEAN] && group == 4 ? 1 : 0;
+    // five levels in one group (blur_lean_kernel: the two lightest on one wave pair), when their
+    // reaches allow: 1 and 2 K-steps (equal DMAX) for the lightest two
+    const bool five = MB_STREAM && lean && cnt == 5 && mb_c_of(L.ntaps[0]) == 1 &&
+                      mb_c_of(L.ntaps[1]) == 2;
+    if (cnt > 4 && !five) lean = lean && false;          // (more than one group: the general kernel)
     for (int i = 0; i < cnt; ++i)
         if (L.ntaps[i] < 3) lean = 0;
     int lds_lean = lds;
@@ -2270,9 +2371,9 @@ static int launch_levels(pano_ctx *ctx, const pano_patch *table, int n, int max_
             if (mb_c_of(L.ntaps[i]) > 3) lean = 0;
     if (ML_OVERLAP) {            // + the second band buffer, behind the largest group's tables
         lds_lean = 0;
-        for (int gidx = 0; gidx < ngroups; ++gidx) {
+        for (int gidx = 0; gidx < (five ? 1 : ngroups); ++gidx) {
             int bytes = 0, cm = 1;
-            for (int i = group * gidx; i < cnt && i < group * (gidx + 1); ++i) {
+            for (int i = group * gidx; i < cnt && (five || i < group * (gidx + 1)); ++i) {
                 bytes += mb_table_bytes(L.ntaps[i]);
                 cm = mb_c_of(L.ntaps[i]) > cm ? mb_c_of(L.ntaps[i]) : cm;
             }
@@ -2282,6 +2383,7 @@ static int launch_levels(pano_ctx *ctx, const pano_patch *table, int n, int max_
         if (lds_lean > 160 * 1024) lean = 0;             // (apertures above 97 taps: the general kernel)
     }
     if (lean) {
+        if (five) grid = dim3((unsigned)cap * 4, 1, 1);   // one group
         PANO_TIMED(PK_BLUR_LEAN, stream,
                    hipLaunchKernelGGL(blur_lean_kernel, grid, dim3(MB_THREADS_OF(4)), lds_lean,
                                       stream, table, L, tables, owner, W, flags, sorted));
@@ -2325,6 +2427,13 @@ int pano_launch_blur_mfma(pano_ctx *ctx, const pano_patch *table, int n, int max
 #ifndef MB_SPLIT_LAUNCH
 #define MB_SPLIT_LAUNCH 1
 #endif
+#ifndef MB_FIVE_IN_ONE
+#define MB_FIVE_IN_ONE 1
+#endif
+    if (MB_STREAM && narrow && n_blur == 5 && ctx->opt[PANO_OPT_BLUR_LEAN] &&
+        mb_c_of(ntaps[0]) == 1 && mb_c_of(ntaps[1]) == 2 && ntaps[0] >= 3 && MB_FIVE_IN_ONE)
+        // six pyramid levels: all five Gaussian levels in ONE launch (every band staged once)
+        return launch_levels(ctx, table, n, max_aw, owner, W, host_taps, ntaps, 0, 5, rmax, 4, flags);
     if (MB_SPLIT_LAUNCH && narrow && (n_blur == 5 || n_blur == 6)) {
         // four levels as one group of four, the rest in a launch of their own (small workgroups,
         // several per CU): the band is staged twice per item instead of three times.  Config 5
