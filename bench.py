@@ -463,7 +463,10 @@ def cfg4_line(args, world, elapsed, pyr, n_kp, times, size):
     name = max(times, key=lambda k: times[k][0]) if times else None
     out["roofline"] = dict(kernel=name or "scale space (all launches)", bound="hbm",
                            achieved=algo / (ms * 1e-3) / 1e9, peak=HBM_PEAK_GBPS, unit="GB/s",
-                           frac=algo / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, traffic=None,
+                           frac=algo / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                           # counter bytes per frame of the timed kernels (the scale steps: 60 of a
+                           # frame's 70 launches), from the committed summary of this workload
+                           traffic=measured_traffic(times, args.steps, "cfg4") if times else None,
                            note="whole scale space of a frame: %.0f algorithmic bytes per input "
                                 "pixel (SURVEY §8d: ~375) / step time" % (algo / (w * h)))
     if name is not None:
