@@ -86,6 +86,7 @@ typedef const GLOBAL_AS float4u *gcf32x4;
 #ifdef MB_STAMP
 // phase timers (timing experiments only): [wave 0 | wave 4][phase] summed cycles, and counts
 __device__ unsigned long long g_mb_stamps[4][12];
+__device__ unsigned long long g_mb_setup[8];   // blur_lean_kernel: cycles of the set-up phases, and workgroups
 #define STAMP(k)                                                                         \
     do {                                                                                 \
         if (stamped) {                                                                   \
@@ -1749,6 +1750,17 @@ __global__ __launch_bounds__(MB_THREADS_OF(4), 1) void blur_lean_kernel(
     constexpr int GROUP = 4;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
+#ifdef MB_STAMP
+    unsigned long long ts_last = __builtin_readcyclecounter();
+#define MS_SETUP_STAMP(k)                                                               \
+    do {                                                                                \
+        const unsigned long long now_ = __builtin_readcyclecounter();                   \
+        if (tid == 0) atomicAdd(&g_mb_setup[k], now_ - ts_last);                        \
+        ts_last = now_;                                                                 \
+    } while (0)
+#else
+#define MS_SETUP_STAMP(k) do { } while (0)
+#endif
     // (five levels: ONE group of four wave pairs, the two lightest levels on one pair)
     const bool five = MB_STREAM && L.n == 5;
     const int ngroups = five ? 1 : (L.n + GROUP - 1) / GROUP;
@@ -1832,23 +1844,27 @@ __global__ __launch_bounds__(MB_THREADS_OF(4), 1) void blur_lean_kernel(
     const int dmaxm = (sh.CM + 1) / 2;
     sh.t_lo = g.O0 - dmaxm;
     sh.t_hi = g.O1 + dmaxm;
+    MS_SETUP_STAMP(0);                                   // item, record, geometry
     for (int which = 0; which < (lv_b >= 0 ? 2 : 1); ++which)
     if (live) {
         const uint4 *from = (const uint4 *)(tables + L.tab_off[which ? level_b : level]);
         uint4 *to = (uint4 *)(smem + (which ? my_tx_b : my_tx));
         const int n16 = mb_table_bytes(L.ntaps[which ? level_b : level]) >> 4;
-        // (every load of a round issued before its first LDS store: 16 - 32 KB per wave pair)
+        // Every load of a round issued before its first LDS store, and every one of them
+        // UNCONDITIONAL (an index past the table is clamped to its last entry, which is then
+        // written twice with the same bytes): a load under a branch is waited for on the spot,
+        // and thirteen such round trips were 21 k cycles of a workgroup's 35 k of set-up
+        // (phase timers, profiles/r04/notes.md).
         constexpr int DEPTH = 8;
         for (int i0 = tid & 127; i0 < n16; i0 += 128 * DEPTH) {
             uint4 v[DEPTH];
 #pragma unroll
-            for (int j = 0; j < DEPTH; ++j)
-                if (i0 + 128 * j < n16) v[j] = from[i0 + 128 * j];
+            for (int j = 0; j < DEPTH; ++j) v[j] = from[min(i0 + 128 * j, n16 - 1)];
 #pragma unroll
-            for (int j = 0; j < DEPTH; ++j)
-                if (i0 + 128 * j < n16) to[i0 + 128 * j] = v[j];
+            for (int j = 0; j < DEPTH; ++j) to[min(i0 + 128 * j, n16 - 1)] = v[j];
         }
     }
+    MS_SETUP_STAMP(1);                                   // table copy
     const int X0 = g.gx0 + 32 * tx0;
     const int nty = g.O1 - g.O0 + 1;
     if (wv < 2) {
@@ -1862,6 +1878,7 @@ __global__ __launch_bounds__(MB_THREADS_OF(4), 1) void blur_lean_kernel(
     }
     int *const s_count = (int *)sh.any;                  // (the `any` flags are not used here)
     __syncthreads();
+    MS_SETUP_STAMP(2);                                   // need flags + barrier (the table copy's LDS writes land)
     // the bands some wave wants, in order, compacted: one wave, 64 bands per round
     if (wv == 0) {
         int count = 0;
@@ -1871,12 +1888,16 @@ __global__ __launch_bounds__(MB_THREADS_OF(4), 1) void blur_lean_kernel(
             bool any = false;
             unsigned w = 0;
             if (i <= sh.t_hi - sh.t_lo) {
-                for (int k = 0; k < GROUP; ++k)
-                    for (int d = -dmax_of[k]; d <= dmax_of[k]; ++d)
-                        any |= (sh.need[o - d] | sh.need[MB_NEED_LEN + o - d]) != 0;
+                // (ten byte reads: the wanted bits of the two columns; a band is listed when a
+                // tile within the group's largest reach of it is wanted - the union of the pairs'
+                // windows, which the loop over the pairs used to read one by one)
+#pragma unroll
                 for (int col = 0; col < 2; ++col)
+#pragma unroll
                     for (int d = -2; d <= 2; ++d)
                         w |= (sh.need[col * MB_NEED_LEN + o - d] ? 1u : 0u) << (16 + 8 * col + d + 2);
+                const unsigned reach_bits = dmaxm >= 2 ? 0x1fu : 0x0eu;      // d = -dmaxm .. dmaxm
+                any = (((w >> 16) | (w >> 24)) & reach_bits) != 0;
                 w |= (unsigned)(unsigned short)(short)t;
             }
             const unsigned long long bal = __ballot(any);
@@ -1886,6 +1907,10 @@ __global__ __launch_bounds__(MB_THREADS_OF(4), 1) void blur_lean_kernel(
         if (lane == 0) *s_count = count;
     }
     __syncthreads();
+    MS_SETUP_STAMP(3);                                   // list
+#ifdef MB_STAMP
+    if (tid == 0) atomicAdd(&g_mb_setup[7], 1ull);
+#endif
     const int nlist = *s_count;
     const half8 *s_tx = (const half8 *)(smem + my_tx), *s_ty = (const half8 *)(smem + my_ty);
     const int out_level = L.out[level];
@@ -2175,10 +2200,14 @@ static inline int mb_sorted_slots(int cap) { return (cap + MB_SEG_SLOTS + 1) & ~
 // after the PANO_TAP_LEAD ones.
 #ifdef MB_STAMP
 extern "C" int pano_debug_stamps(unsigned long long *out, int reset) {
-    if (out) PANO_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_mb_stamps), sizeof(unsigned long long) * 48));
+    if (out) {
+        PANO_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_mb_stamps), sizeof(unsigned long long) * 48));
+        PANO_HIP(hipMemcpyFromSymbol(out + 48, HIP_SYMBOL(g_mb_setup), sizeof(unsigned long long) * 8));
+    }
     if (reset) {
         unsigned long long zero[48] = {};
         PANO_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_mb_stamps), zero, sizeof(zero)));
+        PANO_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_mb_setup), zero, sizeof(unsigned long long) * 8));
     }
     return PANO_OK;
 }

@@ -15,8 +15,12 @@ for it in range(3):
     plan = engine.Plan(shapes, rots, intrs, True, 10 ** 9)
     eng.stitch(frames, plan, "multiband", int(os.environ.get("LEVELS", "5")))
     torch.cuda.synchronize()
-    buf = (C.c_ulonglong * 48)()
+    buf = (C.c_ulonglong * 56)()
     lib.pano_debug_stamps(buf, 1)
+su = np.array(buf[48:56], dtype=np.float64)
+if su[7]:
+    print("set-up per regular workgroup (thread 0, cycles): item / geometry %.0f | table copy %.0f | need flags + barrier %.0f | "
+          "list %.0f  (%d workgroups)" % (su[0] / su[7], su[1] / su[7], su[2] / su[7], su[3] / su[7], int(su[7])))
 if os.environ.get("STAMP_FORM", "stream") == "stream":    # ms_body: waves 0, 2, 4, 6
     names = ["head", "barrier", "prologue", "row pass + stores", "split + column pass", "wait + commit"]
     for w in range(4):
