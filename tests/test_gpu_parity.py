@@ -1158,7 +1158,9 @@ def test_lean_blur_kernel_equals_the_general_kernel(scene):
     bands need no special case and runs the same products in the same order as the general
     kernel: every blurred plane it writes, the float mosaic and the uint8 mosaic are the
     general kernel's bit for bit - interior shortcut on and off, L = 5 and 3, strips (vertical
-    segments of the items) included."""
+    segments of the items) included; L = 6 puts five Gaussian levels into ONE launch with the two
+    lightest on one wave pair (against the general kernel's 2 + 2 + 1 split launches), L = 2 leaves
+    three wave pairs without a level."""
     import torch
     from pano360_amd import _lib, engine, synth
     if scene == "sweep":
@@ -1172,7 +1174,8 @@ def test_lean_blur_kernel_equals_the_general_kernel(scene):
     shapes = [im.shape[:2] for im in imgs]
     eng = engine.Engine()
     frames = eng.upload_frames(imgs)
-    for levels, shortcut, strip in ((5, True, None), (5, False, None), (3, True, None), (5, True, 0.4)):
+    for levels, shortcut, strip in ((5, True, None), (5, False, None), (3, True, None), (5, True, 0.4),
+                                    (6, True, None), (6, False, 0.3), (2, True, None)):
         got = []
         for lean in (1, 1, 0):              # (the first run only makes the arenas exist)
             eng.set_option(_lib.OPT_BLUR_LEAN, lean)
