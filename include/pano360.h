@@ -165,7 +165,10 @@ int pano_interior_block(void);
  *                         special case (no reflected columns, whole chunks, one reflection
  *                         of the rows at most) run through a kernel with a short instruction
  *                         stream, the rest through the general one; 0 = the general kernel
- *                         for everything.  Same results bit for bit.
+ *                         for everything.  Same results bit for bit.  With it on, the five
+ *                         Gaussian levels of a six-level pyramid (n_levels = 6) run in ONE
+ *                         launch (the two lightest levels on one wave pair); off, they split
+ *                         into launches of 2 + 2 + 1 levels that each stage the bands.
  *   PANO_OPT_STITCH_STREAMS  pano_stitch_multiband: 1 (default) = the interior map runs beside
  *                         the region search, and the blur's tile flags and work list beside
  *                         the warp, on a second stream the context owns (ordered by events);

@@ -100,6 +100,11 @@ def _worker(rank, world, port, mode, depth, result, cache_plan=False, lanes=1):
                                     "cpu", mode)
         # max-over-ranks timing reduction used by bench.py
         assert pdist.max_over_ranks(float(rank + 1)) == world
+        # what the bench line reports about the process group
+        seen = pdist.describe_job("cpu", "cpu")
+        assert seen["world_size"] == world and seen["backend"] == "gloo"
+        assert seen["allreduce_checksum"] == seen["allreduce_expected"] == world * (world + 1) // 2
+        assert seen["devices"] == ["cpu"] * world
         # image sets of a stream, dealt out over the ranks: each set exactly once
         mine = torch.zeros(7, dtype=torch.int64)
         mine[pdist.assign_sets(7, rank, world)] = 1
