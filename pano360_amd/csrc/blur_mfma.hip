@@ -1465,6 +1465,9 @@ __device__ __forceinline__ void ms_body(const pano_patch &p, const int ch, const
         off_nxt = __builtin_amdgcn_readfirstlane(off_nxt);
         asm volatile("" : "+s"(off_cur), "+s"(off_nxt));
         MS_STAMP(0);                // the step's scalar head
+#ifdef MS_ABL_HALF_BARRIERS         // timing experiment (results wrong): a barrier every second step
+        if (!(i & 1))
+#endif
         lds_barrier();              // band i is whole; nobody reads the other buffer any more
         MS_STAMP(1);                // waiting at the barrier
         // ---- the rare cases the previous step left to this one
