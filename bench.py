@@ -214,14 +214,18 @@ def cpu_baseline(cfg):
     t0 = time.time()
     po.stitch(imgs, rots, intrs, "multiband", cfg["n_levels"], max_resolution=NATIVE)
     dt = time.time() - t0
+    try:                                   # BASELINE.md section 3's probe: is the reference's own OpenCV here?
+        import cv2
+        provider = f"cv2 {cv2.__version__} importable ({cv2.getNumThreads()} threads), not used: the reference itself does not travel to this box"
+    except Exception:                      # noqa: BLE001
+        provider = "cv2 is not installed on this box, so the reference itself cannot be timed here"
     return dict(value=px / dt / 1e6, unit="MP/s", cores=po.max_threads(), kind="port",
                 sample=f"first {n} of the {cfg['n']} frames ({cfg['width']}x{cfg['height']}, "
                        f"{step:.2f} deg/step), multiband L={cfg['n_levels']}, native "
                        f"resolution, {px / 1e6:.1f} MP of patches in {dt:.1f} s; oracle = "
                        f"oracle/pano_oracle.c (gcc -O2 -fopenmp: a multi-threaded C port, "
                        f"faster than the reference's single-threaded NumPy glue around OpenCV), "
-                       f"{os.cpu_count()} host CPUs; cv2 is not installed on this pool, so the "
-                       f"reference itself cannot be timed here")
+                       f"{os.cpu_count()} host CPUs; {provider}")
 
 
 COMM = {}              # what the process group saw (pano360_amd.dist.describe_job), every line carries it
