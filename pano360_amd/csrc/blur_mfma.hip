@@ -1279,27 +1279,31 @@ __device__ __forceinline__ void ms_body(const pano_patch &p, const int ch, const
             // before, and a vector-memory instruction may read a scalar register a vector
             // instruction wrote only five wait states later - the compiler does not look into
             // the statement)
-            asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(pf.v0) : "v"(voff[0]), "s"(rs) : "memory");
-            asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(pf.v1) : "v"(voff[1]), "s"(rs) : "memory");
-            asm volatile("buffer_load_dwordx2 %0, %1, %2, 0 offen" : "=v"(pf.v2) : "v"(voff[2]), "s"(rs) : "memory");
+            // (ONE statement: nothing - no reload of the descriptor - can come between the wait
+            // states and the loads)
+            asm volatile("s_nop 4\n\t"
+                         "buffer_load_dwordx4 %0, %3, %6, 0 offen\n\t"
+                         "buffer_load_dwordx4 %1, %4, %6, 0 offen\n\t"
+                         "buffer_load_dwordx2 %2, %5, %6, 0 offen"
+                         : "=&v"(pf.v0), "=&v"(pf.v1), "=&v"(pf.v2)
+                         : "v"(voff[0]), "v"(voff[1]), "v"(voff[2]), "s"(rs)
+                         : "memory");
         } else {
             asm volatile("s_nop 4\n\t"
-                         "global_load_sshort %0, %4, %5\n\t"
-                         "global_load_sshort %1, %4, %5 offset:2\n\t"
-                         "global_load_sshort %2, %4, %5 offset:4\n\t"
-                         "global_load_sshort %3, %4, %5 offset:6"
-                         : "=&v"(pf.e[0]), "=&v"(pf.e[1]), "=&v"(pf.e[2]), "=&v"(pf.e[3])
-                         : "v"(voff[0]), "s"(sbase2) : "memory");
-            asm volatile("global_load_sshort %0, %4, %5\n\t"
-                         "global_load_sshort %1, %4, %5 offset:2\n\t"
-                         "global_load_sshort %2, %4, %5 offset:4\n\t"
-                         "global_load_sshort %3, %4, %5 offset:6"
-                         : "=&v"(pf.e[4]), "=&v"(pf.e[5]), "=&v"(pf.e[6]), "=&v"(pf.e[7])
-                         : "v"(voff[1]), "s"(sbase2) : "memory");
-            asm volatile("global_load_sshort %0, %2, %3\n\t"
-                         "global_load_sshort %1, %2, %3 offset:2"
-                         : "=&v"(pf.e[8]), "=&v"(pf.e[9])
-                         : "v"(voff[2]), "s"(sbase2) : "memory");
+                         "global_load_sshort %0, %10, %13\n\t"
+                         "global_load_sshort %1, %10, %13 offset:2\n\t"
+                         "global_load_sshort %2, %10, %13 offset:4\n\t"
+                         "global_load_sshort %3, %10, %13 offset:6\n\t"
+                         "global_load_sshort %4, %11, %13\n\t"
+                         "global_load_sshort %5, %11, %13 offset:2\n\t"
+                         "global_load_sshort %6, %11, %13 offset:4\n\t"
+                         "global_load_sshort %7, %11, %13 offset:6\n\t"
+                         "global_load_sshort %8, %12, %13\n\t"
+                         "global_load_sshort %9, %12, %13 offset:2"
+                         : "=&v"(pf.e[0]), "=&v"(pf.e[1]), "=&v"(pf.e[2]), "=&v"(pf.e[3]), "=&v"(pf.e[4]),
+                           "=&v"(pf.e[5]), "=&v"(pf.e[6]), "=&v"(pf.e[7]), "=&v"(pf.e[8]), "=&v"(pf.e[9])
+                         : "v"(voff[0]), "v"(voff[1]), "v"(voff[2]), "s"(sbase2)
+                         : "memory");
         }
     };
     // registers -> LDS, in pieces (so that a piece fits the shadow of one matrix product):
