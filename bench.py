@@ -112,7 +112,9 @@ def measured_traffic(times, steps, workload):
     return total if seen else None
 
 
-BLUR_KERNELS = ("blur_lean_kernel", "blur_mfma_kernel")      # as rocprofv3 names them
+# as rocprofv3 names them: the lean kernel (up to four levels), its five-level form (six pyramid
+# levels in one launch), the general kernel
+BLUR_KERNELS = ("blur_lean_kernel", "blur_lean5_kernel", "blur_mfma_kernel")
 
 
 def algorithmic_bytes(plan, patches, n_levels, px_active, times=None):
@@ -131,9 +133,10 @@ def algorithmic_bytes(plan, patches, n_levels, px_active, times=None):
     # or to the lean one when both do (the second launch's re-staging of the bands is traffic,
     # not algorithm) - and each level's blurred RGBA copy written once over the active tiles.
     n_blur = n_levels - 1
-    both = times is not None and all(k in times for k in BLUR_KERNELS)
+    both = times is not None and all(k in times for k in ("blur_lean_kernel", "blur_mfma_kernel"))
     lean_levels = min(n_blur, 4) if both else n_blur
     blur = {"blur_lean_kernel": 14.0 * px_warp + 16.0 * lean_levels * px_cols,
+            "blur_lean5_kernel": 14.0 * px_warp + 16.0 * n_blur * px_cols,
             "blur_mfma_kernel": (16.0 * (n_blur - lean_levels) * px_cols if both
                                  else 14.0 * px_warp + 16.0 * n_blur * px_cols)}
     return {

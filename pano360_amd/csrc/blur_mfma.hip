@@ -1750,12 +1750,17 @@ __device__ __forceinline__ void ms_body(const pano_patch &p, const int ch, const
     }
 }
 
-__global__ __launch_bounds__(MB_THREADS_OF(4), 1) void blur_lean_kernel(
-    const pano_patch *__restrict__ table, MbLevels L, const unsigned char *__restrict__ tables,
+// FIVE: the launch of five levels on four wave pairs.  It is a kernel of its own
+// (blur_lean5_kernel) because its two-level wave pair needs all 256 vector registers a wave can
+// have at two waves per SIMD, and a kernel's allocation is its largest path's: the four-level
+// kernel stays at 217, which leaves a SIMD's register file room for a third, small wave of
+// another kernel (the collapse of the other stitch in flight: 54 registers).
+template <bool FIVE>
+__device__ __forceinline__ void lean_kernel_body(
+    const pano_patch *__restrict__ table, const MbLevels &L, const unsigned char *__restrict__ tables,
     const int16_t *__restrict__ owner, int W, const uint8_t *__restrict__ flags,
-    const int2 *__restrict__ items) {
+    const int2 *__restrict__ items, unsigned char *smem) {
     constexpr int GROUP = 4;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
 #ifdef MB_STAMP
     unsigned long long ts_last = __builtin_readcyclecounter();
@@ -1769,7 +1774,7 @@ __global__ __launch_bounds__(MB_THREADS_OF(4), 1) void blur_lean_kernel(
 #define MS_SETUP_STAMP(k) do { } while (0)
 #endif
     // (five levels: ONE group of four wave pairs, the two lightest levels on one pair)
-    const bool five = MB_STREAM && L.n == 5;
+    constexpr bool five = FIVE;
     const int ngroups = five ? 1 : (L.n + GROUP - 1) / GROUP;
     const int per = 8 * ngroups, blk = blockIdx.x / per, within = blockIdx.x - blk * per;
     const int grp = within >> 3, pair = blk * 8 + (within & 7);
@@ -1929,6 +1934,7 @@ __global__ __launch_bounds__(MB_THREADS_OF(4), 1) void blur_lean_kernel(
 #define ML_BODY_FN ml_body
 #endif
 #if MB_STREAM
+    if constexpr (FIVE)
     if (lv_b >= 0) {                                     // wave-uniform: levels of 2 and 1 K-steps' reach
         const half8 *s_tx_b = (const half8 *)(smem + my_tx_b), *s_ty_b = (const half8 *)(smem + my_ty_b);
         if (ch == 3)
@@ -1954,6 +1960,24 @@ __global__ __launch_bounds__(MB_THREADS_OF(4), 1) void blur_lean_kernel(
 #undef ML_BODY
     }
 }
+
+__global__ __launch_bounds__(MB_THREADS_OF(4), 1) void blur_lean_kernel(
+    const pano_patch *__restrict__ table, MbLevels L, const unsigned char *__restrict__ tables,
+    const int16_t *__restrict__ owner, int W, const uint8_t *__restrict__ flags,
+    const int2 *__restrict__ items) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    lean_kernel_body<false>(table, L, tables, owner, W, flags, items, smem);
+}
+
+#if MB_STREAM
+__global__ __launch_bounds__(MB_THREADS_OF(4), 1) void blur_lean5_kernel(
+    const pano_patch *__restrict__ table, MbLevels L, const unsigned char *__restrict__ tables,
+    const int16_t *__restrict__ owner, int W, const uint8_t *__restrict__ flags,
+    const int2 *__restrict__ items) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    lean_kernel_body<true>(table, L, tables, owner, W, flags, items, smem);
+}
+#endif
 
 // One thread per 32 x 32 tile of every record: active = some interior-map block under the
 // tile (cut to A) is not interior.
@@ -2309,6 +2333,10 @@ int pano_blur_mfma_opt_in(void) {
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     PANO_HIP(hipFuncSetAttribute((const void *)blur_lean_kernel,
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+#if MB_STREAM
+    PANO_HIP(hipFuncSetAttribute((const void *)blur_lean5_kernel,
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+#endif
     return PANO_OK;
 }
 
@@ -2418,8 +2446,17 @@ static int launch_levels(pano_ctx *ctx, const pano_patch *table, int n, int max_
         }
         if (lds_lean > 160 * 1024) lean = 0;             // (apertures above 97 taps: the general kernel)
     }
+#if MB_STREAM
+    if (lean && five) {
+        grid = dim3((unsigned)cap * 4, 1, 1);            // one group
+        PANO_TIMED(PK_BLUR_LEAN5, stream,
+                   hipLaunchKernelGGL(blur_lean5_kernel, grid, dim3(MB_THREADS_OF(4)), lds_lean,
+                                      stream, table, L, tables, owner, W, flags, sorted));
+        PANO_LAUNCH_CHECK("blur_lean5_kernel");
+        return PANO_OK;
+    }
+#endif
     if (lean) {
-        if (five) grid = dim3((unsigned)cap * 4, 1, 1);   // one group
         PANO_TIMED(PK_BLUR_LEAN, stream,
                    hipLaunchKernelGGL(blur_lean_kernel, grid, dim3(MB_THREADS_OF(4)), lds_lean,
                                       stream, table, L, tables, owner, W, flags, sorted));

@@ -66,6 +66,7 @@ enum PanoKernelId {
     PK_SCALE_STEP,
     PK_KNN2,
     PK_BLUR_LEAN,
+    PK_BLUR_LEAN5,
     PK_COUNT
 };
 // ---- the context (include/pano360.h: pano_ctx) ------------------------------------
