@@ -114,10 +114,10 @@ def measured_traffic(times, steps, workload):
 
 # as rocprofv3 names them: the lean kernel (up to four levels), its five-level form (six pyramid
 # levels in one launch), the general kernel
-BLUR_KERNELS = ("blur_lean_kernel", "blur_lean5_kernel", "blur_mfma_kernel")
+BLUR_KERNELS = ("blur_lean_kernel", "blur_lean5_kernel", "blur_irregular_kernel", "blur_mfma_kernel")
 
 
-def algorithmic_bytes(plan, patches, n_levels, px_active, times=None):
+def algorithmic_bytes(plan, patches, n_levels, px_active, times=None, irregular_share=0.0):
     """Algorithmic HBM bytes per step of each big kernel: every logical
     array the kernel consumes or produces counted once, on the pixels this run really
     processed (windows V / rectangles A / active tiles), not on the reference's P."""
@@ -137,8 +137,16 @@ def algorithmic_bytes(plan, patches, n_levels, px_active, times=None):
     lean_levels = min(n_blur, 4) if both else n_blur
     blur = {"blur_lean_kernel": 14.0 * px_warp + 16.0 * lean_levels * px_cols,
             "blur_lean5_kernel": 14.0 * px_warp + 16.0 * n_blur * px_cols,
+            "blur_irregular_kernel": 0.0,
             "blur_mfma_kernel": (16.0 * (n_blur - lean_levels) * px_cols if both
                                  else 14.0 * px_warp + 16.0 * n_blur * px_cols)}
+    # the work items the lean kernels leave to blur_irregular_kernel (their share of the active
+    # tiles, Engine.irregular_tile_share): their bytes are that kernel's, not the lean kernel's
+    if times is not None and "blur_irregular_kernel" in times and irregular_share > 0:
+        for lean_name in ("blur_lean_kernel", "blur_lean5_kernel"):
+            if lean_name in times:
+                blur["blur_irregular_kernel"] = blur[lean_name] * irregular_share
+                blur[lean_name] *= 1.0 - irregular_share
     return {
         **blur,
         # 3 float planes written + the frame bytes under the window (about 1:1 scale)
@@ -156,12 +164,12 @@ def algorithmic_bytes(plan, patches, n_levels, px_active, times=None):
     }, dict(px_warp=px_warp, px_cols=px_cols, px_rows=px_rows)
 
 
-def roofline_for(times, plan, patches, n_levels, steps, px_active, workload=None):
+def roofline_for(times, plan, patches, n_levels, steps, px_active, workload=None, irregular_share=0.0):
     """Roofline entry of the kernel with the largest share of the timed region, plus the
     time-weighted fraction over the three kernels that move the pixels (warp, blur,
     collapse)."""
     from pano360_amd import engine
-    per_step, px = algorithmic_bytes(plan, patches, n_levels, px_active, times)
+    per_step, px = algorithmic_bytes(plan, patches, n_levels, px_active, times, irregular_share)
     name = max(times, key=lambda k: times[k][0])
     total_ms, launches = times[name]
     avg_s = total_ms / launches * 1e-3
@@ -170,6 +178,7 @@ def roofline_for(times, plan, patches, n_levels, steps, px_active, workload=None
     traffic, source = pmc_traffic(name, workload)
     out = dict(kernel=name, bound="hbm", achieved=achieved, peak=HBM_PEAK_GBPS,
                unit="GB/s", frac=achieved / HBM_PEAK_GBPS, traffic=traffic,
+               irregular_tile_share=irregular_share,
                traffic_source=source, avg_launch_ms=avg_s * 1e3, launches=launches)
     if name in BLUR_KERNELS:
         flop = steps * sum(2.0 * t * 4 * (px["px_rows"] + px["px_cols"]) for t in taps)
@@ -573,7 +582,8 @@ def secondary_single_gpu(eng, fence):
             "kernel_ms_per_step": {k_: v[0] / steps for k_, v in sorted(times.items())},
             "instrumented_ms_per_step": INSTRUMENTED.get("seconds", 0.0) / steps * 1e3,
             "roofline": roofline_for(times, plan, patches, cfg["n_levels"], steps,
-                                     use.active_tile_pixels(), name),
+                                     use.active_tile_pixels(), name,
+                                     use.irregular_tile_share(cfg["n_levels"])),
         }
         del pool, frames
         for e, _ in lanes:
@@ -915,7 +925,8 @@ def main():
                           "x launches per step, this rank's kernels"})(
                 measured_traffic(times, args.steps, args.workload) if world == 1 else None),
             "roofline": roofline_for(times, plan, patches, n_levels, args.steps,
-                                     eng.active_tile_pixels(), args.workload),
+                                     eng.active_tile_pixels(), args.workload,
+                                     eng.irregular_tile_share(n_levels)),
         }
         if world > 1:
             out["scaling_note"] = "unmeasured on multi-GPU hardware by the builder (1-GPU boxes)"

@@ -242,7 +242,8 @@ static const char *const g_kernel_names[PK_COUNT] = {
     "blend_cameras_kernel", "owned_spans_kernel",
     "block_owner_kernel", "tile_flags_kernel", "overlap_stats_kernel",
     "blur_mfma_kernel", "sift_extrema_kernel", "sift_orient_kernel", "sift_describe_kernel",
-    "compose_interior_kernel", "scale_step_kernel", "knn2_kernel", "blur_lean_kernel", "blur_lean5_kernel"};
+    "compose_interior_kernel", "scale_step_kernel", "knn2_kernel", "blur_lean_kernel", "blur_lean5_kernel",
+    "blur_irregular_kernel"};
 
 void pano_timing_edge(pano_ctx *ctx, int kid, hipStream_t stream, bool begin) {
     hipEvent_t ev;

@@ -1792,21 +1792,15 @@ __device__ __forceinline__ void lean_kernel_body(
         const int ck = mb_c_of(L.ntaps[l0 + k]);
         sh.CM = ck > sh.CM ? ck : sh.CM;
     }
+    // Not one of ours: blur_irregular_kernel takes it (MB_STREAM; beside this launch, on the
+    // context's side stream).  With the general path inside this kernel - the form of round 3:
+    // a second launch over the whole list cost 0.31 ms of idle workgroups - the kernel's
+    // allocation was the general path's: 220 vector registers against 184, 202 spilled scalars
+    // against 12, and the blur 5 % slower for code that 1 % of the work units run.
     if (!mb_item_regular(p, g.gx0, tx0, sh.CM)) {                               // uniform
-        // not one of ours: the general path, in this same workgroup (a second launch over the
-        // list, every workgroup of which returns at once for a regular item, cost 0.31 ms on
-        // config 3: 5120 workgroups of 512 threads and 128 KB of LDS each, one per CU at a time)
-        if (five) {
-            // (the general path takes four levels per workgroup: this one does both groups, one
-            // after the other; its work index = block of 8 pairs x groups + group x 8 + pair)
-            for (int gg = 0; gg < 2; ++gg) {
-                __syncthreads();
-                mb_general<GROUP>(table, L, tables, owner, W, flags, items, smem,
-                                  (pair >> 3) * 16 + gg * 8 + (pair & 7));
-            }
-            return;
-        }
+#if !MB_STREAM
         mb_general<GROUP>(table, L, tables, owner, W, flags, items, smem, (int)blockIdx.x);
+#endif
         return;
     }
     const int n_seg = item.y >> 16, seg = (item.y >> 12) & 15, nty_all = g.O1 - g.O0 + 1;
@@ -1979,6 +1973,64 @@ __global__ __launch_bounds__(MB_THREADS_OF(4), 1) void blur_lean5_kernel(
 }
 #endif
 
+#if MB_STREAM
+// The work units blur_lean_kernel / blur_lean5_kernel leave out (mb_item_regular false: bands
+// with reflected columns, ragged windows, short patches), through the general path.  A workgroup
+// takes a contiguous range of `per` (<= 512) units of the sorted list: its threads test one unit
+// each, and the irregular ones - a few dozen of config 3's 1 112 units, every unit of a small
+// scene - are then worked off one after the other by the whole workgroup.  (`per` units per
+// workgroup, unit = workgroup + k x workgroups.)
+template <bool FIVE>
+__global__ __launch_bounds__(MB_THREADS_OF(4), 1) void blur_irregular_kernel(
+    const pano_patch *__restrict__ table, MbLevels L, const unsigned char *__restrict__ tables,
+    const int16_t *__restrict__ owner, int W, const uint8_t *__restrict__ flags,
+    const int2 *__restrict__ items, int n_units, int per) {
+    constexpr int GROUP = 4;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
+    int cm = 1;
+    for (int k = 0; k < (FIVE ? 5 : (L.n < GROUP ? L.n : GROUP)); ++k) {
+        const int ck = mb_c_of(L.ntaps[k]);
+        cm = ck > cm ? ck : cm;
+    }
+    // (strided, not contiguous: the list is sorted by length, so the irregular units of one kind
+    // - the long ones along a patch's left and right edge - are neighbours in it, and a
+    // contiguous range handed one workgroup eight of them: 2.8 ms for config 3's dozen)
+    const int u = (int)blockIdx.x + tid * (int)gridDim.x;
+    bool mine = false;
+    if (tid < per && u < n_units) {
+        const int2 item = items[u >> 2];
+        if (item.x >= 0) {
+            const pano_patch p = table[item.x & 0xffff];
+            const MbGeom g = mb_geom(p);
+            mine = !mb_item_regular(p, g.gx0, item.x >> 16, cm);
+        }
+    }
+    unsigned long long *const s_words = (unsigned long long *)smem;     // [8]: a wave's ballot each
+    const unsigned long long bal = __ballot(mine);
+    if (lane == 0) s_words[wv] = bal;
+    __syncthreads();
+    unsigned long long words[8];
+#pragma unroll
+    for (int w = 0; w < 8; ++w) words[w] = s_words[w];
+    for (int w = 0; w < 8; ++w) {
+        unsigned long long m = words[w];                 // (the same on every thread)
+        while (m) {
+            const int b = __ffsll((long long)m) - 1;
+            m &= m - 1ull;
+            const int unit = __builtin_amdgcn_readfirstlane((int)blockIdx.x + (64 * w + b) * (int)gridDim.x);
+            // the general path takes four levels per workgroup and numbers its work units as
+            // block of 8 pairs x groups + group x 8 + pair: five levels are two of its groups
+            for (int gg = 0; gg < (FIVE ? 2 : 1); ++gg) {
+                __syncthreads();                         // the LDS is the previous unit's (or the ballots')
+                mb_general<GROUP>(table, L, tables, owner, W, flags, items, smem,
+                                  FIVE ? (unit >> 3) * 16 + gg * 8 + (unit & 7) : unit);
+            }
+        }
+    }
+}
+#endif
+
 // One thread per 32 x 32 tile of every record: active = some interior-map block under the
 // tile (cut to A) is not interior.
 __global__ __launch_bounds__(256) void tile_flags32_kernel(const pano_patch *__restrict__ table,
@@ -2138,26 +2190,39 @@ __global__ __launch_bounds__(256) void mb_items_kernel(const pano_patch *__restr
 #define MB_SEG_MAX 8
 #define MB_SEG_LEAD 8
 #define MB_SEG_SLOTS 192
+// An IRREGULAR item (mb_item_regular false for a group that reaches `cm` k-steps: the pairs along
+// a patch's left and right edge, whose bands hold reflected columns) goes through the general
+// path, at twice the cycles per band, and on the mosaic's outer edges such an item is a whole
+// column of tiles: three items of config 2's 115 were the blur's last 0.17 of 0.19 ms.  They are
+// cut into up to MB_SEG_MAX segments whatever S is.
 __global__ __launch_bounds__(256) void mb_sort_kernel(const int2 *__restrict__ items,
                                                       int *__restrict__ counter, int cap, int scap,
                                                       int wgs_per_item, int slots,
-                                                      int2 *__restrict__ sorted) {
+                                                      int2 *__restrict__ sorted,
+                                                      const pano_patch *__restrict__ table, int cm) {
     __shared__ int s_hist[MB_SORT_BINS];
-    __shared__ int s_lmax, s_lsum;
+    __shared__ int s_lmax, s_lsum, s_nirr, s_total;
     const int tid = threadIdx.x;
     const int n = min(*counter, cap);
-    int S = 1;
+    auto irregular = [&](const int2 it) {
+        if (cm <= 0) return false;
+        const pano_patch p = table[it.x & 0xffff];
+        return !mb_item_regular(p, (p.ax0 >> 5) << 5, it.x >> 16, cm);
+    };
+    int S = 1, S_irr = 1;
     if (slots > 0 && n > 0) {                                    // uniform
-        if (tid == 0) s_lmax = s_lsum = 0;
+        if (tid == 0) s_lmax = s_lsum = s_nirr = 0;
         __syncthreads();
-        int lmax = 0, lsum = 0;
+        int lmax = 0, lsum = 0, nirr = 0;
         for (int i = tid; i < n; i += 256) {
-            const int len = items[i].y;
-            lmax = max(lmax, len);
-            lsum += len;
+            const int2 it = items[i];
+            lmax = max(lmax, it.y);
+            lsum += it.y;
+            nirr += irregular(it) ? 1 : 0;
         }
         atomicMax(&s_lmax, lmax);
         atomicAdd(&s_lsum, lsum);
+        atomicAdd(&s_nirr, nirr);
         __syncthreads();
         const int Lmax = s_lmax, Lsum = s_lsum;
         auto model = [&](const int s) {
@@ -2175,20 +2240,35 @@ __global__ __launch_bounds__(256) void mb_sort_kernel(const int2 *__restrict__ i
                 S = s;
             }
         }
+        // the irregular items' own segment count: as many as the list's spare slots allow
+        const int n_irr = s_nirr;
+        if (n_irr > 0) {
+            const int spare = min(scap - n * S, MB_SEG_SLOTS - n * (S - 1));
+            S_irr = max(S, min(MB_SEG_MAX, 1 + max(spare, 0) / n_irr));
+        }
         __syncthreads();
     }
-    const int total = n * S;
-    auto entry = [&](const int i) {
-        const int2 it = items[i / S];
-        const int seg = i - (i / S) * S;
-        const int len = S == 1 ? it.y : (it.y + S - 1) / S + 4;
-        return make_int2(it.x, min(len, MB_SORT_BINS - 1) | seg << 12 | (S == 1 ? 0 : S) << 16);
+    // segments of item i: S, or for an irregular one up to S_irr of at least ~10 bands each
+    auto segments_of = [&](const int2 it) {
+        if (S_irr <= S || !irregular(it)) return S;
+        return max(S, min(S_irr, it.y / 10));
+    };
+    auto entry = [&](const int2 it, const int seg, const int ns) {
+        const int len = ns == 1 ? it.y : (it.y + ns - 1) / ns + 4;
+        return make_int2(it.x, min(len, MB_SORT_BINS - 1) | seg << 12 | (ns == 1 ? 0 : ns) << 16);
     };
     for (int i = tid; i < MB_SORT_BINS; i += 256) s_hist[i] = 0;
+    if (tid == 0) s_total = 0;
     __syncthreads();
-    for (int i = tid; i < total; i += 256)
-        atomicAdd(&s_hist[MB_SORT_BINS - 1 - (entry(i).y & 0xfff)], 1);                 // long first
+    for (int i = tid; i < n; i += 256) {
+        const int2 it = items[i];
+        const int ns = segments_of(it);
+        for (int seg = 0; seg < ns; ++seg)
+            atomicAdd(&s_hist[MB_SORT_BINS - 1 - (entry(it, seg, ns).y & 0xfff)], 1);   // long first
+        atomicAdd(&s_total, ns);
+    }
     __syncthreads();
+    const int total = s_total;
     // exclusive prefix over the bins: eight bins per thread, then a scan of the 256 sums
     __shared__ int s_part[256];
     constexpr int PER = MB_SORT_BINS / 256;
@@ -2213,9 +2293,13 @@ __global__ __launch_bounds__(256) void mb_sort_kernel(const int2 *__restrict__ i
         run += mine[j];
     }
     __syncthreads();
-    for (int i = tid; i < total; i += 256) {
-        const int2 e = entry(i);
-        sorted[atomicAdd(&s_hist[MB_SORT_BINS - 1 - (e.y & 0xfff)], 1)] = e;
+    for (int i = tid; i < n; i += 256) {
+        const int2 it = items[i];
+        const int ns = segments_of(it);
+        for (int seg = 0; seg < ns; ++seg) {
+            const int2 e = entry(it, seg, ns);
+            sorted[atomicAdd(&s_hist[MB_SORT_BINS - 1 - (e.y & 0xfff)], 1)] = e;
+        }
     }
     for (int i = total + tid; i < scap; i += 256) sorted[i] = make_int2(-1, 0);
     __syncthreads();
@@ -2270,6 +2354,7 @@ int pano_tiles_blur_mfma(pano_ctx *ctx, const pano_patch *table, int n, int max_
         return rc;
     ctx->flags_table = table;
     ctx->flags_n = n;
+    ctx->blur_cm = (radius + 15) / 16 < 1 ? 1 : (radius + 15) / 16;     // (for the work list's segments)
     if (warp_need) {
         const int cm = (radius + 15) / 16 < 1 ? 1 : (radius + 15) / 16;
         const int hx = (16 * cm + 31) / 32 + 1, vy = (cm + 1) / 2;
@@ -2318,7 +2403,8 @@ int pano_prepare_blur_mfma(pano_ctx *ctx, const pano_patch *table, int n, int ma
     hipLaunchKernelGGL(mb_sort_kernel, dim3(1), dim3(256), 0, stream, ctx->item_buf,
                        ctx->item_counter, cap, mb_sorted_slots(cap), 4,
                        ctx->opt[PANO_OPT_BLUR_SEGMENTS] ? 256 : 0,
-                       ctx->item_buf + ctx->item_cap);
+                       ctx->item_buf + ctx->item_cap, table,
+                       ctx->opt[PANO_OPT_BLUR_SEGMENTS] ? (ctx->blur_cm > 0 ? ctx->blur_cm : 3) : 0);
     PANO_LAUNCH_CHECK("mb_sort_kernel");
     ctx->prepared_table = table;
     ctx->prepared_n = n;
@@ -2335,6 +2421,10 @@ int pano_blur_mfma_opt_in(void) {
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 #if MB_STREAM
     PANO_HIP(hipFuncSetAttribute((const void *)blur_lean5_kernel,
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    PANO_HIP(hipFuncSetAttribute((const void *)blur_irregular_kernel<false>,
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    PANO_HIP(hipFuncSetAttribute((const void *)blur_irregular_kernel<true>,
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 #endif
     return PANO_OK;
@@ -2447,15 +2537,58 @@ static int launch_levels(pano_ctx *ctx, const pano_patch *table, int n, int max_
         if (lds_lean > 160 * 1024) lean = 0;             // (apertures above 97 taps: the general kernel)
     }
 #if MB_STREAM
-    if (lean && five) {
-        grid = dim3((unsigned)cap * 4, 1, 1);            // one group
-        PANO_TIMED(PK_BLUR_LEAN5, stream,
-                   hipLaunchKernelGGL(blur_lean5_kernel, grid, dim3(MB_THREADS_OF(4)), lds_lean,
-                                      stream, table, L, tables, owner, W, flags, sorted));
-        PANO_LAUNCH_CHECK("blur_lean5_kernel");
+    if (lean) {
+        // The irregular work units beside the regular ones: blur_irregular_kernel on the context's
+        // side stream (the two kernels write disjoint tiles), on this stream behind the lean
+        // kernel while kernels are being timed (the events of two streams would span each other).
+        const int n_units = cap * 4;
+        // (about eight units to test per workgroup; a scene whose every unit is irregular - small
+        // patches - then has one or two to work off per workgroup)
+        int wgs = ceil_div(n_units, 8);
+        wgs = wgs < 64 ? 64 : wgs;
+        if (ceil_div(n_units, wgs) > 512) wgs = ceil_div(n_units, 512);
+        const int per = ceil_div(n_units, wgs);
+        // (a small work list - config 2's thousand units - keeps to the one stream: the fork and
+        // the join cost its short blur more than the overlap gives, 0.504 against 0.475 ms per stitch)
+        const bool beside = ctx->opt[PANO_OPT_STITCH_STREAMS] != 0 && !ctx->timing_on &&
+                            stream == ctx->stream && n_units >= 4096;
+        hipStream_t other = stream;
+        if (beside) {
+            if (int rc = pano_ctx_side_stream(ctx)) return rc;
+            if (stream != ctx->side) {
+                other = ctx->side;
+                PANO_HIP(hipEventRecord(ctx->ev_fork, stream));
+                PANO_HIP(hipStreamWaitEvent(other, ctx->ev_fork, 0));
+            }
+        }
+        if (five) {
+            grid = dim3((unsigned)cap * 4, 1, 1);        // one group
+            PANO_TIMED(PK_BLUR_LEAN5, stream,
+                       hipLaunchKernelGGL(blur_lean5_kernel, grid, dim3(MB_THREADS_OF(4)), lds_lean,
+                                          stream, table, L, tables, owner, W, flags, sorted));
+            PANO_LAUNCH_CHECK("blur_lean5_kernel");
+            PANO_TIMED(PK_BLUR_IRREGULAR, other,
+                       hipLaunchKernelGGL(blur_irregular_kernel<true>, dim3(wgs),
+                                          dim3(MB_THREADS_OF(4)), lds, other, table, L, tables, owner,
+                                          W, flags, sorted, n_units, per));
+        } else {
+            PANO_TIMED(PK_BLUR_LEAN, stream,
+                       hipLaunchKernelGGL(blur_lean_kernel, grid, dim3(MB_THREADS_OF(4)), lds_lean,
+                                          stream, table, L, tables, owner, W, flags, sorted));
+            PANO_LAUNCH_CHECK("blur_lean_kernel");
+            PANO_TIMED(PK_BLUR_IRREGULAR, other,
+                       hipLaunchKernelGGL(blur_irregular_kernel<false>, dim3(wgs),
+                                          dim3(MB_THREADS_OF(4)), lds, other, table, L, tables, owner,
+                                          W, flags, sorted, n_units, per));
+        }
+        PANO_LAUNCH_CHECK("blur_irregular_kernel");
+        if (other != stream) {
+            PANO_HIP(hipEventRecord(ctx->ev_join, other));
+            PANO_HIP(hipStreamWaitEvent(stream, ctx->ev_join, 0));
+        }
         return PANO_OK;
     }
-#endif
+#else
     if (lean) {
         PANO_TIMED(PK_BLUR_LEAN, stream,
                    hipLaunchKernelGGL(blur_lean_kernel, grid, dim3(MB_THREADS_OF(4)), lds_lean,
@@ -2463,6 +2596,7 @@ static int launch_levels(pano_ctx *ctx, const pano_patch *table, int n, int max_
         PANO_LAUNCH_CHECK("blur_lean_kernel");
         return PANO_OK;
     }
+#endif
     if (group == 2)
         PANO_TIMED(PK_BLUR_MFMA, stream,
                    hipLaunchKernelGGL(blur_mfma_kernel<2>, grid, dim3(MB_THREADS_OF(2)), lds, stream,

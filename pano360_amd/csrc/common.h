@@ -67,6 +67,7 @@ enum PanoKernelId {
     PK_KNN2,
     PK_BLUR_LEAN,
     PK_BLUR_LEAN5,
+    PK_BLUR_IRREGULAR,
     PK_COUNT
 };
 // ---- the context (include/pano360.h: pano_ctx) ------------------------------------
@@ -98,6 +99,7 @@ struct pano_ctx {
     // flags the buffers currently hold
     int2 *item_buf;
     int *item_counter;
+    int blur_cm;                    // reach (k-steps) of the blur levels the next work list is for; 0 = unknown
     int item_cap;
     const pano_patch *prepared_table, *flags_table;
     int prepared_n, flags_n;
