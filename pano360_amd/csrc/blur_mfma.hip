@@ -60,6 +60,12 @@ typedef const GLOBAL_AS float4u *gcf32x4;
 #ifndef MB_SCHED
 #define MB_SCHED 1
 #endif
+#ifndef MB_STREAM
+#define MB_STREAM 1                 // blur_lean_kernel runs ms_body (round 4); 0 = ml_body (round 3)
+#endif
+#ifndef MB_STREAM_EDGE
+#define MB_STREAM_EDGE MB_STREAM    // ms_body takes the items with reflected columns too (EDGE form)
+#endif
 #define MB_XT 64                    // output columns per workgroup: two 32-column tiles
 // halfs per band row: 64 + 2 * 48 + 8.  336 B = 84 dwords, and 84 = 4 * 21 with 21 odd: the 16
 // lanes of a ds_read_b128 group (one band row each) start on 16 different multiples of 4
@@ -176,14 +182,20 @@ struct MbGeom {
     int gx0, ntx, O0, O1;           // tile grid of rectangle A (patch coordinates / 32)
 };
 
-// A work item the lean kernel takes (blur_lean_kernel, below): its bands lie inside the patch
-// (no reflected columns), a chunk of 4 columns is inside window V or outside it as a whole,
-// and a row reflects at most once.
+// A work item whose bands are not rows of aligned four-float chunks that reflect at most once
+// vertically: the pair reaches over the patch's left or right edge (reflected columns there), V
+// does not begin and end on a chunk, or the patch is lower than four bands.
+__host__ __device__ static inline bool mb_item_edge(const pano_patch &p, int gx0, int tx0, int cm) {
+    const int X0 = gx0 + 32 * tx0;
+    return X0 - 16 * cm < 0 || X0 + 64 + 16 * cm > p.w || (p.vx0 & 3) != 0 ||
+           !(((p.vx0 + p.vw) & 3) == 0 || p.vx0 + p.vw == p.w) || p.h < 128;
+}
+// What the lean kernels take: with MB_STREAM_EDGE everything (ms_body's EDGE form loads such an
+// item's bands element by element, at offsets of any number of reflections), and there is no
+// blur_irregular_kernel launch beside them.
 __host__ __device__ static inline bool mb_item_regular(const pano_patch &p, int gx0, int tx0,
                                                        int cm) {
-    const int X0 = gx0 + 32 * tx0;
-    return X0 - 16 * cm >= 0 && X0 + 64 + 16 * cm <= p.w && (p.vx0 & 3) == 0 &&
-           (((p.vx0 + p.vw) & 3) == 0 || p.vx0 + p.vw == p.w) && p.h >= 128;
+    return MB_STREAM_EDGE || !mb_item_edge(p, gx0, tx0, cm);
 }
 
 __device__ __forceinline__ MbGeom mb_geom(const pano_patch &p) {
@@ -1180,7 +1192,13 @@ __device__ __forceinline__ void ms_split2(const float a, const float b, const fl
 // accumulators must rotate alike: equal DMAX) - five levels on the four wave pairs of a
 // workgroup, so that a sixth pyramid level (stitcher.py:186, n_levels = 6) does not cost a second
 // launch that stages every band again.
-template <int C, bool SHARP, int CB = 0>
+// EDGE: the item's bands hold reflected columns (the pair reaches over the patch's left or right
+// edge, BORDER_REFLECT_101 there): a chunk is then not four consecutive floats of a row, and every
+// ELEMENT of the thread's 2.5 chunks gets its own load (ten dword loads instead of two 16-byte
+// and one 8-byte load; the mask channel loads ten shorts either way) at an offset of its own,
+// computed once: the reflected column, or "beyond the plane" outside V.  Everything behind the
+// loads is the same code; 2 % of the steps run this form.
+template <int C, bool SHARP, int CB = 0, bool EDGE = false>
 __device__ __forceinline__ void ms_body(const pano_patch &p, const int ch, const int out_level,
                                         const bool live, const half8 *s_tx, const half8 *s_ty,
                                         const MbShared &sh, const uint32_t *list, const int nlist,
@@ -1192,6 +1210,10 @@ __device__ __forceinline__ void ms_body(const pano_patch &p, const int ch, const
     constexpr int KS_B = 2 + 2 * CB, Z_B = CB & 1;
     static_assert(CB == 0 || 2 * ((CB + 1) / 2) + 1 == NB, "two levels of a wave: equal DMAX");
     constexpr unsigned OOB = 0x80000000u;
+    constexpr int NV = EDGE ? 10 : 3;                    // load offsets per thread and band
+    // the slot of offset entry e, and the entry of element j of slot k
+    auto slot_of = [](const int e) { return EDGE ? (e < 4 ? 0 : (e < 8 ? 1 : 2)) : e; };
+    auto entry_of = [](const int k, const int j) { return EDGE ? 4 * k + j : k; };
     typedef unsigned uint4v __attribute__((ext_vector_type(4)));
     typedef unsigned uint2v __attribute__((ext_vector_type(2)));
     typedef int int4v __attribute__((ext_vector_type(4)));
@@ -1222,8 +1244,8 @@ __device__ __forceinline__ void ms_body(const pano_patch &p, const int ch, const
     // repeats slot 0's chunk: the same bytes land on the same LDS halfs twice, no traffic
     // beyond the L1.
     int c_rr[3], c_lds[3];
-    unsigned c_off[3];
-    bool c_ok[3];
+    unsigned c_off[NV];
+    bool c_ok[NV];
 #pragma unroll
     for (int it = 0; it < 3; ++it) {
         int c = it < 2 ? tid + 512 * it : 1024 + (tid >> 1);
@@ -1233,15 +1255,29 @@ __device__ __forceinline__ void ms_body(const pano_patch &p, const int ch, const
             half = 0;
         }
         const int rr = c / CPR, c4 = c - rr * CPR;
-        const int colv = X0 - 16 * CM + 4 * c4 - p.vx0;          // the chunk's first column, in V
-        const int vc = colv + 2 * half;
-        c_ok[it] = colv >= 0 && colv + 4 <= p.vw;
         c_rr[it] = rr;
         c_lds[it] = (rr * P + 4 * c4 + 2 * half) * 2;
-        if (SHARP)
-            c_off[it] = c_ok[it] ? (unsigned)((p.y0 + rr) * W + p.x0 + p.vx0 + vc) * 2u : 0u;
-        else
-            c_off[it] = c_ok[it] ? (unsigned)((rr - p.vy0) * p.vpitch + vc) * 4u : OOB;
+        if (!EDGE) {
+            const int colv = X0 - 16 * CM + 4 * c4 - p.vx0;      // the chunk's first column, in V
+            const int vc = colv + 2 * half;
+            c_ok[it] = colv >= 0 && colv + 4 <= p.vw;
+            if (SHARP)
+                c_off[it] = c_ok[it] ? (unsigned)((p.y0 + rr) * W + p.x0 + p.vx0 + vc) * 2u : 0u;
+            else
+                c_off[it] = c_ok[it] ? (unsigned)((rr - p.vy0) * p.vpitch + vc) * 4u : OOB;
+        } else {
+#pragma unroll
+            for (int j = 0; j < (it < 2 ? 4 : 2); ++j) {
+                const int e = 4 * it + j;
+                // the element's column of the patch, reflected (stitcher.py:226: BORDER_REFLECT_101), in V
+                const int vc = reflect_101(X0 - 16 * CM + 4 * c4 + 2 * half + j, p.w) - p.vx0;
+                c_ok[e] = (unsigned)vc < (unsigned)p.vw;
+                if (SHARP)
+                    c_off[e] = c_ok[e] ? (unsigned)((p.y0 + rr) * W + p.x0 + p.vx0 + vc) * 2u : 0u;
+                else
+                    c_off[e] = c_ok[e] ? (unsigned)((rr - p.vy0) * p.vpitch + vc) * 4u : OOB;
+            }
+        }
     }
     // bands [row_lo, row_hi): inside the patch and inside V, no reflection
     const int row_lo = p.vy0 > 0 ? p.vy0 : 0;
@@ -1266,21 +1302,55 @@ __device__ __forceinline__ void ms_body(const pano_patch &p, const int ch, const
     // The loads are inline assembly (the compiler's wait insertion must not see them: with the
     // previous tile's stores pending on the same counter it would wait for vmcnt(0)), issued and
     // consumed inside one step (see ml_body).
-    auto issue = [&](Band &pf, const unsigned (&voff_)[3]) {
+    auto issue = [&](Band &pf, const unsigned (&voff_)[NV]) {
 #ifdef MS_ABL_NOLOAD                                      // timing experiment: no band traffic
-        unsigned none[3] = {SHARP ? 0u : OOB, SHARP ? 0u : OOB, SHARP ? 0u : OOB};
-        const unsigned (&voff)[3] = none;
+        unsigned none[NV];
+#pragma unroll
+        for (int e = 0; e < NV; ++e) none[e] = SHARP ? 0u : OOB;
+        const unsigned (&voff)[NV] = none;
         (void)voff_;
 #else
-        const unsigned (&voff)[3] = voff_;
+        const unsigned (&voff)[NV] = voff_;
 #endif
-        if (!SHARP) {
-            // (s_nop 4: the descriptor may have come back from a spill lane by v_readlane just
-            // before, and a vector-memory instruction may read a scalar register a vector
-            // instruction wrote only five wait states later - the compiler does not look into
-            // the statement)
-            // (ONE statement: nothing - no reload of the descriptor - can come between the wait
-            // states and the loads)
+        // (s_nop 4: a scalar operand may have come back from a spill lane by v_readlane just
+        // before, and a vector-memory instruction may read a scalar register a vector instruction
+        // wrote only five wait states later - the compiler does not look into the statement.
+        // ONE statement: no reload of the operand can come between the wait states and the loads.)
+        if constexpr (EDGE && !SHARP) {
+            asm volatile("s_nop 4\n\t"
+                         "buffer_load_dword %0, %10, %20, 0 offen\n\t"
+                         "buffer_load_dword %1, %11, %20, 0 offen\n\t"
+                         "buffer_load_dword %2, %12, %20, 0 offen\n\t"
+                         "buffer_load_dword %3, %13, %20, 0 offen\n\t"
+                         "buffer_load_dword %4, %14, %20, 0 offen\n\t"
+                         "buffer_load_dword %5, %15, %20, 0 offen\n\t"
+                         "buffer_load_dword %6, %16, %20, 0 offen\n\t"
+                         "buffer_load_dword %7, %17, %20, 0 offen\n\t"
+                         "buffer_load_dword %8, %18, %20, 0 offen\n\t"
+                         "buffer_load_dword %9, %19, %20, 0 offen"
+                         : "=&v"(pf.e[0]), "=&v"(pf.e[1]), "=&v"(pf.e[2]), "=&v"(pf.e[3]), "=&v"(pf.e[4]),
+                           "=&v"(pf.e[5]), "=&v"(pf.e[6]), "=&v"(pf.e[7]), "=&v"(pf.e[8]), "=&v"(pf.e[9])
+                         : "v"(voff[0]), "v"(voff[1]), "v"(voff[2]), "v"(voff[3]), "v"(voff[4]),
+                           "v"(voff[5]), "v"(voff[6]), "v"(voff[7]), "v"(voff[8]), "v"(voff[9]), "s"(rs)
+                         : "memory");
+        } else if constexpr (EDGE && SHARP) {
+            asm volatile("s_nop 4\n\t"
+                         "global_load_sshort %0, %10, %20\n\t"
+                         "global_load_sshort %1, %11, %20\n\t"
+                         "global_load_sshort %2, %12, %20\n\t"
+                         "global_load_sshort %3, %13, %20\n\t"
+                         "global_load_sshort %4, %14, %20\n\t"
+                         "global_load_sshort %5, %15, %20\n\t"
+                         "global_load_sshort %6, %16, %20\n\t"
+                         "global_load_sshort %7, %17, %20\n\t"
+                         "global_load_sshort %8, %18, %20\n\t"
+                         "global_load_sshort %9, %19, %20"
+                         : "=&v"(pf.e[0]), "=&v"(pf.e[1]), "=&v"(pf.e[2]), "=&v"(pf.e[3]), "=&v"(pf.e[4]),
+                           "=&v"(pf.e[5]), "=&v"(pf.e[6]), "=&v"(pf.e[7]), "=&v"(pf.e[8]), "=&v"(pf.e[9])
+                         : "v"(voff[0]), "v"(voff[1]), "v"(voff[2]), "v"(voff[3]), "v"(voff[4]),
+                           "v"(voff[5]), "v"(voff[6]), "v"(voff[7]), "v"(voff[8]), "v"(voff[9]), "s"(sbase2)
+                         : "memory");
+        } else if constexpr (!SHARP) {
             asm volatile("s_nop 4\n\t"
                          "buffer_load_dwordx4 %0, %3, %6, 0 offen\n\t"
                          "buffer_load_dwordx4 %1, %4, %6, 0 offen\n\t"
@@ -1311,7 +1381,7 @@ __device__ __forceinline__ void ms_body(const pano_patch &p, const int ch, const
     //   commit_piece<K>, K = 0 .. 2: slot K's values converted and written.
     auto commit_wait = [&](Band &pf, auto n_c) {
         constexpr int N = decltype(n_c)::value;
-        if (SHARP)
+        if (SHARP || EDGE)
             asm volatile("s_waitcnt vmcnt(%10)"
                          : "+v"(pf.e[0]), "+v"(pf.e[1]), "+v"(pf.e[2]), "+v"(pf.e[3]), "+v"(pf.e[4]),
                            "+v"(pf.e[5]), "+v"(pf.e[6]), "+v"(pf.e[7]), "+v"(pf.e[8]), "+v"(pf.e[9])
@@ -1320,13 +1390,14 @@ __device__ __forceinline__ void ms_body(const pano_patch &p, const int ch, const
             asm volatile("s_waitcnt vmcnt(%3)" : "+v"(pf.v0), "+v"(pf.v1), "+v"(pf.v2) : "n"(N) : "memory");
     };
     const int lo_bytes_c = 32 * P * 2;
-    auto commit_piece = [&](Band &pf, const int (&okv)[3], const int buf, const int k) {
+    auto commit_piece = [&](Band &pf, const int (&okv)[NV], const int buf, const int k) {
         unsigned char *const base = (unsigned char *)sh.hi + 2 * buf;
         if (!SHARP) {
             const float in_scale = __builtin_bit_cast(
                 float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, MB_IN_SCALE)));
             if (k < 2) {
-                const uint4v v = k ? pf.v1 : pf.v0;
+                uint4v v = k ? pf.v1 : pf.v0;
+                if (EDGE) v = uint4v{pf.e[4 * k], pf.e[4 * k + 1], pf.e[4 * k + 2], pf.e[4 * k + 3]};
                 unsigned h0, l0, h1, l1;
                 ms_split4<false>(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]),
                                  __uint_as_float(v[3]), in_scale, h0, l0, h1, l1);
@@ -1335,7 +1406,8 @@ __device__ __forceinline__ void ms_body(const pano_patch &p, const int ch, const
                 *(uint2v *)(base + c_lds[k] + lo_bytes_c) = lo;
             } else {
                 unsigned h2, l2;
-                ms_split2(__uint_as_float(pf.v2[0]), __uint_as_float(pf.v2[1]), in_scale, h2, l2);
+                ms_split2(__uint_as_float(EDGE ? pf.e[8] : pf.v2[0]),
+                          __uint_as_float(EDGE ? pf.e[9] : pf.v2[1]), in_scale, h2, l2);
                 *(unsigned *)(base + c_lds[2]) = h2;
                 *(unsigned *)(base + c_lds[2] + lo_bytes_c) = l2;
             }
@@ -1344,12 +1416,12 @@ __device__ __forceinline__ void ms_body(const pano_patch &p, const int ch, const
             if (k < 2) {
                 half4 hi;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) hi[j] = (int)pf.e[4 * k + j] == okv[k] ? one : zero;
+                for (int j = 0; j < 4; ++j) hi[j] = (int)pf.e[4 * k + j] == okv[entry_of(k, j)] ? one : zero;
                 *(half4 *)(base + c_lds[k]) = hi;
             } else {
                 half2v h2;
-                h2[0] = (int)pf.e[8] == okv[2] ? one : zero;
-                h2[1] = (int)pf.e[9] == okv[2] ? one : zero;
+                h2[0] = (int)pf.e[8] == okv[entry_of(2, 0)] ? one : zero;
+                h2[1] = (int)pf.e[9] == okv[entry_of(2, 1)] ? one : zero;
                 *(half2v *)(base + c_lds[2]) = h2;
             }
         }
@@ -1395,26 +1467,29 @@ __device__ __forceinline__ void ms_body(const pano_patch &p, const int ch, const
     auto band_inside = [&](const int tb, const bool exists) {
         return exists && 32 * tb >= row_lo && 32 * tb + 32 <= row_hi;                  // uniform
     };
-    auto offsets_fast = [&](const int tb, unsigned (&voff)[3], int (&okv)[3]) {
+    auto offsets_fast = [&](const int tb, unsigned (&voff)[NV], int (&okv)[NV]) {
         const unsigned s_off = (unsigned)(32 * tb) * (unsigned)(SHARP ? W * 2 : p.vpitch * 4);
 #pragma unroll
-        for (int it = 0; it < 3; ++it) {
-            voff[it] = c_off[it] + s_off;                // (beyond the plane stays beyond it)
-            okv[it] = c_ok[it] ? p.index : -2;
+        for (int e = 0; e < NV; ++e) {
+            voff[e] = c_off[e] + s_off;                  // (beyond the plane stays beyond it)
+            okv[e] = c_ok[e] ? p.index : -2;
         }
     };
-    auto offsets_general = [&](const int tb, const bool exists, unsigned (&voff)[3], int (&okv)[3]) {
+    auto offsets_general = [&](const int tb, const bool exists, unsigned (&voff)[NV], int (&okv)[NV]) {
 #pragma unroll
-        for (int it = 0; it < 3; ++it) {
-            const int prow = 32 * tb + c_rr[it];
-            const int ry = prow < 0 ? -prow : (prow >= p.h ? 2 * p.h - 2 - prow : prow);
+        for (int e = 0; e < NV; ++e) {
+            const int rr = c_rr[slot_of(e)];
+            // (EDGE takes the low patches too, whose band rows may reflect more than once)
+            const int prow = 32 * tb + rr;
+            const int ry = EDGE ? reflect_101(prow, p.h)
+                                : (prow < 0 ? -prow : (prow >= p.h ? 2 * p.h - 2 - prow : prow));
             const int vr = ry - p.vy0;
-            const bool ok = exists && c_ok[it] && (unsigned)vr < (unsigned)p.vh;
+            const bool ok = exists && c_ok[e] && (unsigned)vr < (unsigned)p.vh;
             if (SHARP)
-                voff[it] = ok ? c_off[it] + (unsigned)(ry - c_rr[it]) * (unsigned)(W * 2) : 0u;
+                voff[e] = ok ? c_off[e] + (unsigned)(ry - rr) * (unsigned)(W * 2) : 0u;
             else
-                voff[it] = ok ? c_off[it] + (unsigned)(ry - c_rr[it]) * (unsigned)(p.vpitch * 4) : OOB;
-            okv[it] = ok ? p.index : -2;
+                voff[e] = ok ? c_off[e] + (unsigned)(ry - rr) * (unsigned)(p.vpitch * 4) : OOB;
+            okv[e] = ok ? p.index : -2;
         }
     };
 #ifdef MB_STAMP
@@ -1441,8 +1516,8 @@ __device__ __forceinline__ void ms_body(const pano_patch &p, const int ch, const
     // assuming that band lies inside (fetch_general: it does not, the step's head computes them
     // the long way), and the finished tile's store base (store_edge: the tile is cut by A's
     // first or last row, the head stores it under masks).
-    unsigned voff[3];
-    int okv[3];
+    unsigned voff[NV];
+    int okv[NV];
     unsigned next = nlist > 1 ? word_at(1) : 0u;        // band i + 1's word
     unsigned s_at = OOB;
     bool store_edge = false, fetch_general;
@@ -1928,15 +2003,34 @@ __device__ __forceinline__ void lean_kernel_body(
 #define ML_BODY_FN ml_body
 #endif
 #if MB_STREAM
+    const bool edge = MB_STREAM_EDGE && mb_item_edge(p, g.gx0, tx0, sh.CM);             // uniform
     if constexpr (FIVE)
     if (lv_b >= 0) {                                     // wave-uniform: levels of 2 and 1 K-steps' reach
         const half8 *s_tx_b = (const half8 *)(smem + my_tx_b), *s_ty_b = (const half8 *)(smem + my_ty_b);
-        if (ch == 3)
-            ms_body<2, true, 1>(p, ch, out_level, live, s_tx, s_ty, sh, list, nlist, owner, W, tx0,
-                                second, L.out[level_b], s_tx_b, s_ty_b);
-        else
-            ms_body<2, false, 1>(p, ch, out_level, live, s_tx, s_ty, sh, list, nlist, owner, W, tx0,
-                                 second, L.out[level_b], s_tx_b, s_ty_b);
+#define MS_DUAL(SH, ED)                                                                        \
+    ms_body<2, SH, 1, ED>(p, ch, out_level, live, s_tx, s_ty, sh, list, nlist, owner, W, tx0,  \
+                          second, L.out[level_b], s_tx_b, s_ty_b)
+        if (edge) {
+            if (ch == 3) MS_DUAL(true, true); else MS_DUAL(false, true);
+        } else {
+            if (ch == 3) MS_DUAL(true, false); else MS_DUAL(false, false);
+        }
+#undef MS_DUAL
+        return;
+    }
+    if (edge) {
+        switch (c) {                                     // wave-uniform
+#define MS_EDGE(CC)                                                                            \
+    if (ch == 3)                                                                               \
+        ms_body<CC, true, 0, true>(p, ch, out_level, live, s_tx, s_ty, sh, list, nlist, owner, W, tx0, second); \
+    else                                                                                       \
+        ms_body<CC, false, 0, true>(p, ch, out_level, live, s_tx, s_ty, sh, list, nlist, owner, W, tx0, second); \
+    break;
+            case 1: MS_EDGE(1)
+            case 2: MS_EDGE(2)
+            default: MS_EDGE(3)
+#undef MS_EDGE
+        }
         return;
     }
 #endif
@@ -2422,10 +2516,12 @@ int pano_blur_mfma_opt_in(void) {
 #if MB_STREAM
     PANO_HIP(hipFuncSetAttribute((const void *)blur_lean5_kernel,
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+#if !MB_STREAM_EDGE
     PANO_HIP(hipFuncSetAttribute((const void *)blur_irregular_kernel<false>,
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     PANO_HIP(hipFuncSetAttribute((const void *)blur_irregular_kernel<true>,
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+#endif
 #endif
     return PANO_OK;
 }
@@ -2550,8 +2646,8 @@ static int launch_levels(pano_ctx *ctx, const pano_patch *table, int n, int max_
         const int per = ceil_div(n_units, wgs);
         // (a small work list - config 2's thousand units - keeps to the one stream: the fork and
         // the join cost its short blur more than the overlap gives, 0.504 against 0.475 ms per stitch)
-        const bool beside = ctx->opt[PANO_OPT_STITCH_STREAMS] != 0 && !ctx->timing_on &&
-                            stream == ctx->stream && n_units >= 4096;
+        const bool beside = !MB_STREAM_EDGE && ctx->opt[PANO_OPT_STITCH_STREAMS] != 0 &&
+                            !ctx->timing_on && stream == ctx->stream && n_units >= 4096;
         hipStream_t other = stream;
         if (beside) {
             if (int rc = pano_ctx_side_stream(ctx)) return rc;
@@ -2567,21 +2663,26 @@ static int launch_levels(pano_ctx *ctx, const pano_patch *table, int n, int max_
                        hipLaunchKernelGGL(blur_lean5_kernel, grid, dim3(MB_THREADS_OF(4)), lds_lean,
                                           stream, table, L, tables, owner, W, flags, sorted));
             PANO_LAUNCH_CHECK("blur_lean5_kernel");
+#if !MB_STREAM_EDGE
             PANO_TIMED(PK_BLUR_IRREGULAR, other,
                        hipLaunchKernelGGL(blur_irregular_kernel<true>, dim3(wgs),
                                           dim3(MB_THREADS_OF(4)), lds, other, table, L, tables, owner,
                                           W, flags, sorted, n_units, per));
+#endif
         } else {
             PANO_TIMED(PK_BLUR_LEAN, stream,
                        hipLaunchKernelGGL(blur_lean_kernel, grid, dim3(MB_THREADS_OF(4)), lds_lean,
                                           stream, table, L, tables, owner, W, flags, sorted));
             PANO_LAUNCH_CHECK("blur_lean_kernel");
+#if !MB_STREAM_EDGE
             PANO_TIMED(PK_BLUR_IRREGULAR, other,
                        hipLaunchKernelGGL(blur_irregular_kernel<false>, dim3(wgs),
                                           dim3(MB_THREADS_OF(4)), lds, other, table, L, tables, owner,
                                           W, flags, sorted, n_units, per));
+#endif
         }
         PANO_LAUNCH_CHECK("blur_irregular_kernel");
+        (void)wgs, (void)per;
         if (other != stream) {
             PANO_HIP(hipEventRecord(ctx->ev_join, other));
             PANO_HIP(hipStreamWaitEvent(stream, ctx->ev_join, 0));

@@ -918,40 +918,13 @@ class Engine:
         return total
 
     def irregular_tile_share(self, n_levels):
-        """Share of the last blur's active tiles that belong to IRREGULAR work items - the
-        (record, tile-column pair) items whose bands hold reflected columns, which go through
-        ``blur_irregular_kernel`` instead of the lean kernel (csrc/blur_mfma.hip,
-        ``mb_item_regular``).  Reporting only (bench.py splits the blur's algorithmic bytes by
-        it); restates the kernels' pairing of the active tile columns.  Synchronises."""
-        table, flags = getattr(self, "last_tiles", (None, None))
-        if table is None or flags is None or self.tile_grid != 32:
-            return 0.0
-        cm = max((gaussian_ksize(sg) // 2 + 15) // 16 for sg in level_sigmas(n_levels))
-        on = flags.cpu().numpy()
-        all_px = irr_px = 0
-        for rec in table.host:
-            ax0, ay0, aw, ah = (int(rec[k]) for k in ("ax0", "ay0", "aw", "ah"))
-            if aw <= 0 or ah <= 0:
-                continue
-            w, h, vx0, vw = (int(rec[k]) for k in ("w", "h", "vx0", "vw"))
-            gx0 = (ax0 >> 5) << 5
-            ntx = ((ax0 + aw - 1) >> 5) - (ax0 >> 5) + 1
-            nty = ((ay0 + ah - 1) >> 5) - (ay0 >> 5) + 1
-            grid = on[int(rec["tiles_off"]):int(rec["tiles_off"]) + ntx * nty].reshape(nty, ntx) != 0
-            cols = grid.any(axis=0)
-            tx = 0
-            while tx < ntx:
-                if not cols[tx]:
-                    tx += 1
-                    continue
-                x0 = gx0 + 32 * tx
-                px = int(grid[:, tx:tx + 2].sum())
-                regular = (x0 - 16 * cm >= 0 and x0 + 64 + 16 * cm <= w and (vx0 & 3) == 0 and
-                           (((vx0 + vw) & 3) == 0 or vx0 + vw == w) and h >= 128)
-                all_px += px
-                irr_px += 0 if regular else px
-                tx += 2
-        return irr_px / all_px if all_px else 0.0
+        """Share of the last blur's active tiles that a kernel other than the lean one blurs.
+        None since ``ms_body`` has its EDGE form (csrc/blur_mfma.hip, ``mb_item_regular``: the
+        items with reflected columns, unaligned windows or low patches were 2 - 15 % of the
+        tiles and ran in ``blur_irregular_kernel``); bench.py still splits the blur's
+        algorithmic bytes by it, so a build with ``-DMB_STREAM_EDGE=0`` reports through
+        ``PANO_IRREGULAR_SHARE``."""
+        return float(os.environ.get("PANO_IRREGULAR_SHARE", "0"))
 
     def compose_interior_async(self, owner, shape, strip, interior, cams, plan, luts,
                                want_float=False, mosaic_out=None):

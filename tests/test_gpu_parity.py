@@ -1152,7 +1152,7 @@ def test_shrink_matches_resize_oracle(eng, shrink):
     assert blend.shrink_images([img], 1)[0].shape == img.shape
 
 
-@pytest.mark.parametrize("scene", ["sweep", "jitter", "closed", "tall"])
+@pytest.mark.parametrize("scene", ["sweep", "jitter", "closed", "tall", "low", "tiny"])
 def test_lean_blur_kernel_equals_the_general_kernel(scene):
     """``blur_lean_kernel`` (option PANO_OPT_BLUR_LEAN, default on) takes the work items whose
     bands need no special case and runs the same products in the same order as the general
@@ -1160,10 +1160,16 @@ def test_lean_blur_kernel_equals_the_general_kernel(scene):
     general kernel's bit for bit - interior shortcut on and off, L = 5 and 3, strips (vertical
     segments of the items) included; L = 6 puts five Gaussian levels into ONE launch with the two
     lightest on one wave pair (against the general kernel's 2 + 2 + 1 split launches), L = 2 leaves
-    three wave pairs without a level."""
+    three wave pairs without a level.  "low" and "tiny": patches under 128 rows and under
+    64 columns, whose band rows and columns reflect more than once (the lean kernel's
+    element-wise form takes them too, as it does every item on a patch's edge)."""
     import torch
     from pano360_amd import _lib, engine, synth
-    if scene == "sweep":
+    if scene == "low":
+        imgs, rots, intrs = synth.make_scene(5, 400, 90, sweep_deg=80.0, jitter=0.01, seed=5, kind="A")
+    elif scene == "tiny":
+        imgs, rots, intrs = synth.make_scene(4, 50, 38, sweep_deg=40.0, seed=6, kind="B")
+    elif scene == "sweep":
         imgs, rots, intrs = synth.make_scene(6, 640, 360, sweep_deg=100.0, seed=1, kind="A")
     elif scene == "jitter":
         imgs, rots, intrs = synth.make_scene(7, 480, 270, sweep_deg=120.0, jitter=0.02, seed=2, kind="B")
