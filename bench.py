@@ -608,6 +608,70 @@ def secondary_single_gpu(eng, fence):
         return entry
     guarded("cfg3_plan_cached", cached)
 
+    def with_upload():
+        """Config 3 with the frames coming from the HOST every stitch (pinned memory, one copy per
+        frame on a copy stream into one of two device sets, the stitch of set i running while set
+        i + 1 arrives): the PCIe-inclusive rate DESIGN section 7 quotes beside the headline, whose
+        frames are resident when the timed region starts.  Never `value`."""
+        cfg = workload("cfg3")
+        n, w, h = cfg["n"], cfg["width"], cfg["height"]
+        rots, intrs = synth.make_cameras(n, w, h, sweep_deg=cfg.get("sweep_deg"),
+                                         step_deg=cfg.get("step_deg"))
+        shapes = [(h, w)] * n
+        host = torch.empty((n, h, w, 3), dtype=torch.uint8).pin_memory()
+        for i in range(n):
+            host[i] = torch.from_numpy(synth.make_frame(i, w, h, "A"))
+        sets = [torch.empty((n, h, w, 3), dtype=torch.uint8, device=eng.device) for _ in range(2)]
+        copy = torch.cuda.Stream(eng.device)
+        main = torch.cuda.current_stream(eng.device)
+        arrived = [torch.cuda.Event() for _ in range(2)]
+        released = [torch.cuda.Event() for _ in range(2)]
+
+        def upload(k):
+            with torch.cuda.stream(copy):
+                copy.wait_event(released[k])             # the stitch that last read this set
+                for i in range(n):
+                    sets[k][i].copy_(host[i], non_blocking=True)
+                arrived[k].record(copy)
+
+        def stitch(k):
+            main.wait_event(arrived[k])
+            plan = engine.Plan(shapes, rots, intrs, True, NATIVE)
+            out = eng.stitch(list(sets[k]), plan, "multiband", cfg["n_levels"])
+            released[k].record(main)
+            return plan, out
+
+        for k in range(2):
+            released[k].record(main)
+        # the copies alone
+        fence()
+        t0 = time.perf_counter()
+        for r in range(4):
+            upload(r & 1)
+            released[r & 1].record(copy)
+        torch.cuda.synchronize()
+        upload_ms = (time.perf_counter() - t0) / 4 * 1e3
+        # pipelined: set i + 1 arrives while set i is stitched
+        steps = 8
+        upload(0)
+        for r in range(2):                               # warm-up
+            upload((r + 1) & 1)
+            stitch(r & 1)
+        fence()
+        t0 = time.perf_counter()
+        for r in range(steps):
+            upload((r + 1) & 1)
+            plan, _ = stitch(r & 1)
+        fence()
+        ms = (time.perf_counter() - t0) / steps * 1e3
+        nbytes = host.numel()
+        return {"workload": "cfg3 with its 32 frames uploaded from pinned host memory every stitch, "
+                            "the upload of the next set overlapped with the stitch of this one",
+                "ms_per_step": ms, "value_MPps": plan.patch_pixels / ms * 1e-3,
+                "upload_ms": upload_ms, "upload_GBps": nbytes / upload_ms * 1e-6,
+                "upload_bytes": nbytes, "steps": steps}
+    guarded("cfg3_with_upload", with_upload)
+
     def one_in_flight():
         entry = stitches("cfg3", 20, 3)
         entry["what"] = ("config 3 one stitch at a time on one engine and stream (the headline keeps "
