@@ -161,11 +161,11 @@ int pano_interior_block(void);
  *   PANO_OPT_BLUR_SEGMENTS  matrix-core blur: 1 (default) = when a launch has too few column
  *                         strips to fill the CUs (one GPU's share of a panorama, small
  *                         scenes) each strip is cut into vertical segments; 0 = never
- *   PANO_OPT_BLUR_LEAN    matrix-core blur: 1 (default) = the work items whose bands need no
- *                         special case (no reflected columns, whole chunks, one reflection
- *                         of the rows at most) run through a kernel with a short instruction
- *                         stream, the rest through the general one; 0 = the general kernel
- *                         for everything.  Same results bit for bit.  With it on, the five
+ *   PANO_OPT_BLUR_LEAN    matrix-core blur: 1 (default) = a kernel with a short, hand-ordered
+ *                         instruction stream takes every work item (those whose bands hold
+ *                         reflected columns, unaligned windows or low patches load them
+ *                         element by element); 0 = the general kernel for everything.
+ *                         Same results bit for bit.  With it on, the five
  *                         Gaussian levels of a six-level pyramid (n_levels = 6) run in ONE
  *                         launch (the two lightest levels on one wave pair); off, they split
  *                         into launches of 2 + 2 + 1 levels that each stage the bands.
