@@ -70,6 +70,10 @@ def parse():
                     help="after the measurements keep stitching for this long (untimed), so that a "
                          "sampler polling the GPU every few seconds sees it busy; default 6 for "
                          "the plain one-GPU config-3 run, else 0")
+    ap.add_argument("--no-plan-cache", action="store_true",
+                    help="N > 1, strips: recompute the host geometry (engine.Plan) every stitch as the "
+                         "reference does (stitcher.py:276-302) instead of taking it out of the "
+                         "content-keyed memo (engine.PlanMemo; exact: same cameras -> same plan)")
     ap.add_argument("--detect", action="store_true",
                     help="cfg4: time detectAndCompute (keypoints + descriptors) too")
     return ap.parse_args()
@@ -84,10 +88,18 @@ def workload(name):
 
 def pmc_traffic(name, workload=None):
     """HBM bytes per launch of kernel `name` from the committed PMC summary of this
-    same command (profiles/<round>/pmc_traffic*.json, written from tools/pmc.sh
-    output: FETCH_SIZE x 2 + WRITE_SIZE, KiB -> bytes, per MI355X_MICROARCH.md)."""
+    same command (profiles/<round>/[final/]pmc_traffic*.json, written from tools/pmc.sh
+    output by tools/pmc_summary.py: reads = the L2's memory-side requests by size,
+    32 RDREQ_32B + 64 RDREQ_64B + 128 RDREQ_128B - FETCH_SIZE counts a 128-byte request at
+    64, profiles/r04/fetch_calib.json - writes = WRITE_SIZE KiB).  The newest round wins,
+    its closing visit (final/) before its earlier ones."""
     import glob
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "pmc_traffic*.json")))[::-1]:
+    found = glob.glob(os.path.join(ROOT, "profiles", "r*", "**", "pmc_traffic*.json"), recursive=True)
+    # the latest round first, and inside a round its closing visit (final/) before the earlier ones
+    def order(path):
+        rel = os.path.relpath(path, os.path.join(ROOT, "profiles")).split(os.sep)
+        return (rel[0], 1 if "final" in rel[1:-1] else 0, len(rel), rel[-1])
+    for path in sorted(found, key=order)[::-1]:
         with open(path) as fid:
             table = json.load(fid)
         if workload is not None and table.get("workload") != workload:
@@ -792,7 +804,7 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    def run_strips(exchange, cache_plan=False):
+    def run_strips(exchange, cache_plan=True):
         """ONE panorama (image set 0) split into column strips, one per rank; the finished
         strips are composed on rank 0 (strong scaling)."""
         # two stitches in flight per rank (PANO_STRIPS_IN_FLIGHT, default 2): consecutive
@@ -834,6 +846,7 @@ def main():
         fence()
         elapsed, (plan, _, patches), times = timed_steps(
             AllLanes(), strips_step, args.steps, args.warmup, fence, runner.finish)
+        runner.close()                    # the lanes' communicators (collective: every rank, same order)
         return pdist.max_over_ranks(elapsed, reduce_device), plan, patches, times, runner
 
     def run_sets():
@@ -885,6 +898,22 @@ def main():
         fence()
         elapsed, (plan, _, patches), times = timed_steps(AllLanes(), step, args.steps, args.warmup,
                                                          fence)
+        # the same K steps one stitch at a time on one engine and stream, no instrumentation: what a
+        # caller who hands in one image set and waits for its mosaic sees (the reference's timer,
+        # stitcher.py:441-444, brackets one stitch) - `ms_per_stitch_one_in_flight` of the line
+        IN_FLIGHT["one_ms"] = None
+        if len(lanes) > 1:
+            state["serial"] = True
+            for _ in range(2):
+                step()
+            fence()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                step()
+            fence()
+            IN_FLIGHT["one_ms"] = pdist.max_over_ranks(time.perf_counter() - t0,
+                                                       reduce_device) / args.steps * 1e3
+            state["serial"] = False
         return pdist.max_over_ranks(elapsed, reduce_device), plan, patches, times
 
     # Python's cyclic collector walks every live object (all of torch and numpy) when its
@@ -921,10 +950,31 @@ def main():
                     f"secondary.cfg3_one_in_flight: one at a time)")
         warped = sum((p.window[1] - p.window[0]) * (p.window[3] - p.window[2]) for p in patches)
         blurred = sum((p.area[1] - p.area[0]) * (p.area[3] - p.area[2]) for p in patches)
+        in_flight = IN_FLIGHT.get("strips", 1) if strips else IN_FLIGHT["n"]
+        timed_kernel_ms = sum(v[0] for v in times.values()) / args.steps
         out = {
             "metric": "blended megapixels/sec (multiband)",
             "value": sets_per_step * P / (ms * 1e-3) / 1e6,
             "unit": "MP/s",
+            # ---- the three qualifiers of `value` ----
+            # (a) WHAT is counted: the reference's patch pixels P, not the pixels the kernels touch
+            "value_kind": "reference_equivalent_px",
+            "processed_MPps": warped / (ms * 1e-3) / 1e6 * (1 if strips or world == 1 else world),
+            # (b) HOW it is timed: `pipelined` consecutive stitches in flight; one stitch alone beside it
+            "pipelined": in_flight,
+            "ms_per_stitch_one_in_flight": (None if strips else
+                                            (IN_FLIGHT.get("one_ms") if in_flight > 1
+                                             else ms / sets_per_step)),
+            # (c) the ARITHMETIC behind `dtype`: float32 storage and accumulation, every product of
+            # the Gaussian levels as three float16 matrix-core products of split operands (the
+            # dropped lo x lo term is 2^-22 relative); the strict-float32 blur's step time is
+            # lifted beside it from secondary.blur_valu_f32 when that ran
+            "arithmetic": "f16x3-split products, f32 accumulate (2^-22)",
+            "ms_per_step_strict_f32": None,
+            # share of the timed region the GPU spent inside the timed kernels (the kernels' HIP-event
+            # times of the instrumented pass, added up, over the headline's wall time per step):
+            # what a utilisation sampler would see if it sampled the timed region only
+            "duty_cycle": (timed_kernel_ms / ms) if ms > 0 else None,
             "value_counts": "reference-equivalent patch pixels: the pixels P the reference's "
                             "algorithm warps and blends for this image set (SURVEY §8d) per second; "
                             "the kernels warp and blur far fewer (processed.*), exactly",
@@ -1006,8 +1056,11 @@ def main():
         out = build_line(False, elapsed, plan, patches, times) if rank == 0 else None
         if rank == 0 and not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(cfg)
+            out["cpu_baseline"]["pipelined"] = False     # one stitch at a time, start to finish
         if world == 1 and not args.no_secondary and args.workload == "cfg3":
             out["secondary"] = secondary_single_gpu(eng, fence)
+            strict = out["secondary"].get("blur_valu_f32", {})
+            out["ms_per_step_strict_f32"] = strict.get("ms_per_step")
         busy = args.busy_seconds
         if busy is None:
             busy = 6.0 if world == 1 and args.workload == "cfg3" else 0.0
@@ -1027,7 +1080,7 @@ def main():
             dog.start()
             extra = {}
             try:
-                e2, p2, _, _, _ = run_strips(args.exchange)
+                e2, p2, _, _, _ = run_strips(args.exchange, cache_plan=not args.no_plan_cache)
                 extra[f"strips_{args.exchange}"] = {
                     "ms_per_step": e2 / args.steps * 1e3,
                     "value": p2.patch_pixels / e2 * args.steps / 1e6}
@@ -1062,7 +1115,8 @@ def main():
     dog = Watchdog(args.secondary_timeout, rank, fallback, key="strips_error")
     dog.start()
     try:
-        elapsed, plan, patches, times, runner = run_strips(args.exchange)
+        elapsed, plan, patches, times, runner = run_strips(args.exchange,
+                                                           cache_plan=not args.no_plan_cache)
     except Exception as err:           # noqa: BLE001 - see above
         if dog.cancel() and rank == 0 and fallback is not None:
             fallback["strips_error"] = repr(err)[:300]
@@ -1089,14 +1143,17 @@ def main():
             # the same strips with the host geometry of the (unchanged) cameras kept from stitch
             # to stitch: at eight ranks the per-stitch NumPy plan (0.36 ms on every rank, the
             # same on all) is longer than a strip's kernels
-            e3, p3, _, _, _ = run_strips(args.exchange, cache_plan=True)
+            e3, p3, _, _, _ = run_strips(args.exchange, cache_plan=bool(args.no_plan_cache))
             if rank == 0:
-                out["secondary"]["strips_plan_cached"] = {
+                key = "strips_plan_cached" if args.no_plan_cache else "strips_plan_per_stitch"
+                out["secondary"][key] = {
                     "ms_per_step": e3 / args.steps * 1e3,
                     "value": p3.patch_pixels / e3 * args.steps / 1e6,
-                    "what": "the headline's strips with Engine.cached_plan (the cameras do not "
-                            "change between the steps; the headline recomputes the plan per "
-                            "stitch as the reference does)"}
+                    "what": ("the headline's strips with the plan out of the content-keyed memo "
+                             "(engine.PlanMemo)" if args.no_plan_cache else
+                             "the headline's strips with the host geometry recomputed every stitch "
+                             "(engine.Plan per stitch, as stitcher.py:276-302 does; --no-plan-cache "
+                             "makes this the headline)")}
         except Exception as err:       # noqa: BLE001
             if dog.cancel() and rank == 0:
                 out["secondary"]["error"] = repr(err)[:300]

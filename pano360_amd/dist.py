@@ -88,11 +88,16 @@ class StripExchange:
     its strip into, ``submit()`` starts the (asynchronous) exchange of that buffer and
     returns at once, ``collect()`` returns the oldest finished mosaic (rank 0; ``None``
     elsewhere) - ``depth`` sets of buffers are cycled, so up to ``depth - 1`` exchanges are
-    in flight behind the stitch being computed.  ``world == 1`` needs no process group."""
+    in flight behind the stitch being computed.  ``world == 1`` needs no process group and
+    issues no collective - unless ``force_collective`` is set: then a one-rank process group
+    must be up and the very same ``dist.gather`` / ``dist.reduce`` calls run as at world N
+    (device buffers, ``async_op=True``, view lists, ``work.wait()``), which is how a one-GPU
+    box executes the RCCL branch (tests/test_gpu_parity.py)."""
 
     MODES = ("gather", "reduce")
 
-    def __init__(self, shape, bounds, rank, world, device, mode="gather", group=None, depth=2):
+    def __init__(self, shape, bounds, rank, world, device, mode="gather", group=None, depth=2,
+                 force_collective=False):
         import torch
         if mode not in self.MODES:
             raise ValueError(f"exchange {mode!r}: one of {self.MODES}")
@@ -101,7 +106,8 @@ class StripExchange:
         self.strip = (self.bounds[rank], self.bounds[rank + 1])
         self.mode, self.depth, self.device = mode, max(int(depth), 1), device
         self.host_staged = False
-        if world > 1:
+        self.collective = world > 1 or bool(force_collective)
+        if self.collective:
             import torch.distributed as dist
             if dist.get_world_size(group) != world:
                 raise ValueError(f"process group has {dist.get_world_size(group)} ranks, "
@@ -116,14 +122,14 @@ class StripExchange:
         # the collapse writes only its strip's columns: everything else stays zero for good
         # (reduce: rank 0's copy receives the sum in place and is wiped again in collect)
         self.full = [torch.zeros((self.H, self.W, 3), **u8)
-                     for _ in range(self.depth if mode == "reduce" or world == 1 else 1)]
-        if mode == "gather" and world > 1:
+                     for _ in range(self.depth if mode == "reduce" or not self.collective else 1)]
+        if mode == "gather" and self.collective:
             self.packed = [torch.zeros((self.H, self.pack_w, 3), **u8) for _ in range(self.depth)]
             self.parts = ([torch.empty((world, self.H, self.pack_w, 3), **u8)
                            for _ in range(self.depth)] if rank == 0 else None)
             self.mosaic = ([torch.empty((self.H, self.W, 3), **u8) for _ in range(self.depth)]
                            if rank == 0 else None)
-        if mode == "reduce" and world > 1:
+        if mode == "reduce" and self.collective:
             # rank 0 hands the sum out as a copy in a ring of its own, as the gather does: the
             # buffer that received it is wiped by recycle() at the very next step
             self.mosaic = ([torch.empty((self.H, self.W, 3), **u8) for _ in range(self.depth)]
@@ -143,7 +149,7 @@ class StripExchange:
         slot = self.slot
         self.slot = (self.slot + 1) % self.depth
         work = None
-        if self.world > 1:
+        if self.collective:
             import torch.distributed as dist
             if self.mode == "reduce":
                 buf = self.full[slot]
@@ -180,7 +186,7 @@ class StripExchange:
             work.wait()                  # orders the current stream behind the collective
         if self.rank != 0:
             return None
-        if self.world == 1:
+        if not self.collective:
             return self.full[slot]
         if self.mode == "reduce":
             self.mosaic[slot].copy_(self.full[slot])
@@ -198,7 +204,7 @@ class StripExchange:
         """reduce mode: on rank 0 the sum landed in this rank's strip buffer, and a backend may
         use the other ranks' buffers as workspace (gloo does): wipe the columns outside the
         strip before the buffer takes the next one (a memset, ~20 us for 100 MB)."""
-        if self.mode != "reduce" or self.world == 1:
+        if self.mode != "reduce" or not self.collective:
             return
         c0, c1 = self.strip
         buf = self.full[self.slot % len(self.full)]
@@ -225,23 +231,34 @@ class ShardedStitcher:
     comes back from the same call (rank 0), the last one from ``finish()``."""
 
     def __init__(self, eng, shapes, rots, intrs, n_levels, rank, world, max_resolution=10 ** 9,
-                 group=None, exchange="gather", depth=2, cache_plan=False):
+                 group=None, exchange="gather", depth=2, cache_plan=True,
+                 force_collective=False):
         # ``eng``: one engine, or a list of them - "lanes": consecutive stitches then alternate
         # between the engines, each on a stream of its own with its own exchange buffers, so
         # that one stitch's kernels cover the other's host round trip (on a column strip of a
         # world-8 run the kernels are 0.45 ms and that round trip plus the launches' gaps 0.1).
         # Every buffer of a lane is only ever touched in its lane's stream order.  Each lane
-        # exchanges over a process group (communicator) of its own: a collective only has to
-        # be issued in the same order as the other ranks' collectives ON ITS COMMUNICATOR, so
-        # whatever order the lanes' submissions reach RCCL in on different ranks - two user
-        # streams, skewed hosts - no lane's collective can pair with or wait behind another
-        # lane's (tests/test_dist_cpu.py drives the lanes from skewed threads to show it).
+        # exchanges over a process group (communicator) of its own, so that a lane's collective
+        # can only ever pair with the SAME lane's collective on the other ranks.  The lanes are
+        # driven in lock step - ``step`` takes them round-robin, the same on every rank - so every
+        # rank issues the collectives of all communicators in one global order; RCCL still needs
+        # that (device-side collectives of two communicators issued in different orders on
+        # different ranks can deadlock), separate communicators only rule out mis-pairing.  On
+        # gloo, whose collectives do not share a device queue, a test drives the lanes from
+        # skewed threads (tests/test_dist_cpu.py); that says nothing about RCCL.
+        # EVERY rank of the default group must construct the stitcher (``dist.new_group`` is
+        # collective over the default group, also for ranks outside ``group``), in the same
+        # order, and ``close()`` it to give the lane communicators back.
         engines = list(eng) if isinstance(eng, (list, tuple)) else [eng]
         self.eng, self.rank, self.world, self.group = engines[0], rank, world, group
         self.shapes, self.rots, self.intrs = shapes, rots, intrs
         self.n_levels, self.max_resolution = n_levels, max_resolution
-        # cache_plan: the host geometry of the (unchanged) cameras is computed once and kept
-        # (Engine.cached_plan) instead of once per stitch as the reference does
+        # cache_plan (default): the host geometry of the cameras comes out of the engine's
+        # content-keyed memo (Engine.cached_plan / engine.PlanMemo: same shapes, rotations,
+        # calibrations, padding, cap and table columns -> the plan the reference's per-stitch
+        # recomputation, stitcher.py:276-302, would produce again, bit for bit; a camera moved by
+        # one ulp misses).  At eight ranks the 0.36 ms of float64 NumPy - the same on every rank -
+        # are as long as a strip's kernels.  False: ``Plan(...)`` per stitch.
         self.cache_plan = cache_plan
         plan = _eng.Plan(shapes, rots, intrs, True, max_resolution)
         radius = max([_eng.gaussian_ksize(s) // 2 for s in _eng.level_sigmas(n_levels)],
@@ -256,6 +273,7 @@ class ShardedStitcher:
         self.depth = max(int(depth), 1)
         lane_depth = self.depth          # (every lane can hold the whole pipeline: any pattern of lanes)
         self.lanes = []
+        self._lane_groups = []
         for i, use in enumerate(engines):
             stream = None
             if i > 0 and str(getattr(use, "device", "cpu")).startswith("cuda"):
@@ -263,13 +281,14 @@ class ShardedStitcher:
                 stream = torch.cuda.Stream(use.device)
             # exchange=None: geometry only (emulation of the ranks on one device)
             lane_group = group
-            if exchange and world > 1 and len(engines) > 1:
+            if exchange and (world > 1 or force_collective) and len(engines) > 1:
                 import torch.distributed as dist
                 # (collective: every rank builds its lanes in the same order)
                 lane_group = dist.new_group(ranks=(dist.get_process_group_ranks(group)
                                                    if group is not None else None))
+                self._lane_groups.append(lane_group)
             ex = (StripExchange(plan.shape, self.bounds, rank, world, use.device, exchange,
-                                lane_group, lane_depth) if exchange else None)
+                                lane_group, lane_depth, force_collective) if exchange else None)
             if stream is not None:
                 # the exchange buffers were zero-filled on the constructing stream: the lane's
                 # first write must come behind those fills
@@ -341,6 +360,18 @@ class ShardedStitcher:
         while self.order:
             last = self._collect_oldest()
         return last
+
+    def close(self):
+        """Finishes what is in flight and destroys the lanes' communicators (collective: every
+        rank closes its stitcher, in the same order it built it).  The stitcher cannot step
+        afterwards."""
+        self.finish()
+        groups, self._lane_groups = self._lane_groups, []
+        if groups:
+            import torch.distributed as dist
+            for g in groups:
+                dist.destroy_process_group(g)
+        self.exchange = None
 
 
 def emulate_on_one_device(eng, imgs, rots, intrs, n_levels, world, max_resolution=10 ** 9):

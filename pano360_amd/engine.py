@@ -230,6 +230,42 @@ class Plan:
         return sum((y1 - y0) * (x1 - x0) for y0, y1, x0, x1 in self.rects)
 
 
+class PlanMemo:
+    """Content-keyed memo of ``Plan`` objects.  A plan is a pure function of the frame shapes,
+    the rotations and calibrations (every bit of every float64 entry), the padding flag, the
+    resolution cap and the trig-table columns - the key holds exactly those, as bytes, so a
+    hit hands back what ``Plan(...)`` would compute again (stitcher.py:276-302 does, per
+    stitch) and a camera that moved by one unit in the last place misses.  Host-only: the
+    engine stores uploaded plans in one (``Engine.cached_plan``)."""
+
+    def __init__(self, capacity=8):
+        self.capacity, self.plans, self.hits, self.misses = int(capacity), {}, 0, 0
+
+    @staticmethod
+    def key(shapes, rots, intrs, padded, max_resolution, table_cols=None):
+        return (tuple(tuple(int(v) for v in sh) for sh in shapes),
+                np.ascontiguousarray(rots, np.float64).tobytes(),
+                np.ascontiguousarray(intrs, np.float64).tobytes(),
+                bool(padded), float(max_resolution),
+                None if table_cols is None else (int(table_cols[0]), int(table_cols[1])))
+
+    def get(self, shapes, rots, intrs, padded, max_resolution, table_cols=None, make=None):
+        key = self.key(shapes, rots, intrs, padded, max_resolution, table_cols)
+        plan = self.plans.get(key)
+        if plan is not None:
+            self.hits += 1
+            return plan
+        self.misses += 1
+        if len(self.plans) >= self.capacity:
+            self.plans.pop(next(iter(self.plans)))          # the oldest entry
+        make = make or Plan
+        plan = self.plans[key] = make(shapes, rots, intrs, padded, max_resolution, table_cols)
+        return plan
+
+    def __len__(self):
+        return len(self.plans)
+
+
 # ------------------------------------------------------------------ exposure
 def find_gains(overlaps, sizes, stdn=0.1, stdg=2):
     """Gains minimising the mean-intensity discrepancies on the overlaps
@@ -692,7 +728,7 @@ class Engine:
         if os.environ.get("PANO_STITCH_ASYNC", "0") == "1":         # (A/B timing)
             self.set_option(_lib.OPT_STITCH_ASYNC, 1)
         self._stitch_ws = {}
-        self._plans = {}
+        self._plans = PlanMemo()
 
     def __del__(self):
         ctx, self._ctx = getattr(self, "_ctx", None), None
@@ -792,22 +828,13 @@ class Engine:
                 for im in imgs]
 
     def cached_plan(self, shapes, rots, intrs, padded, max_resolution, table_cols=None):
-        """The uploaded ``Plan`` of these cameras, kept from stitch to stitch: a rig that does
-        not move stitches every time step with the same geometry, and the float64 plan is a
-        fifth of a 4K stitch's time on the host.  Keyed on the VALUES (shapes, rotations,
-        calibrations, padding, resolution cap, table columns); the reference recomputes all of
-        it per stitch (stitcher.py:276-302), which is what ``Plan(...)`` per stitch does."""
-        key = (tuple(tuple(int(v) for v in sh) for sh in shapes),
-               np.asarray(rots, np.float64).tobytes(), np.asarray(intrs, np.float64).tobytes(),
-               bool(padded), float(max_resolution),
-               None if table_cols is None else (int(table_cols[0]), int(table_cols[1])))
-        plan = self._plans.get(key)
-        if plan is None:
-            if len(self._plans) >= 8:
-                self._plans.pop(next(iter(self._plans)))
-            plan = self._plans[key] = self.upload_plan(
-                Plan(shapes, rots, intrs, padded, max_resolution, table_cols))
-        return plan
+        """The uploaded ``Plan`` of these cameras, kept from stitch to stitch (``PlanMemo``): a
+        rig that does not move stitches every time step with the same geometry, and the float64
+        plan is a fifth of a 4K stitch's time on the host.  The reference recomputes all of it
+        per stitch (stitcher.py:276-302) - to the same values, the plan being a pure function of
+        what the memo is keyed on."""
+        return self._plans.get(shapes, rots, intrs, padded, max_resolution, table_cols,
+                               make=lambda *a: self.upload_plan(Plan(*a)))
 
     def upload_plan(self, plan):
         """Trig tables to the device: one asynchronous copy out of a pinned staging

@@ -169,6 +169,47 @@ def test_exchange_world_1_needs_no_process_group():
         assert torch.equal(st.finish(), eng.truth(1))
 
 
+def _forced_world1_worker(rank, world, port, result):
+    """One rank, a real (gloo) process group, the collectives FORCED: the very calls of a world-N
+    run - `dist.gather` on views of one buffer / `dist.reduce(uint8, SUM)`, `async_op=True`,
+    `work.wait()` - with two lanes on communicators of their own, then `close()`."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        shapes, rots, intrs = _scene()
+        shape = engine.Plan(shapes, rots, intrs, True, 10 ** 9).shape
+        ok = True
+        for mode in pdist.StripExchange.MODES:
+            eng = _HostEngine(shape)
+            st = pdist.ShardedStitcher([eng, _HostEngine(shape, eng.clock)], shapes, rots, intrs, 5,
+                                       0, 1, exchange=mode, depth=2, force_collective=True)
+            assert all(ex.collective and ex.group is not None for _, _, ex in st.lanes)
+            assert len(st._lane_groups) == 2
+            got = []
+            for _ in range(6):
+                previous = st.step(None)[1]
+                if previous is not None:
+                    got.append(previous.clone())
+            got.append(st.finish().clone())
+            ok &= len(got) == 6 and all(torch.equal(m, eng.truth(k)) for k, m in enumerate(got))
+            st.close()
+            assert not st._lane_groups
+            with pytest.raises(RuntimeError):
+                st.step(None)
+        result.put(bool(ok))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_forced_collectives_at_world_1_and_close():
+    """`force_collective=True` makes a one-rank run issue the world-N collectives (what the GPU
+    test does on RCCL, tests/test_a_rccl_world1.py); `close()` gives the lane communicators back."""
+    ctx = mp.get_context("spawn")
+    result = ctx.SimpleQueue()
+    mp.spawn(_forced_world1_worker, args=(1, _free_port(), result), nprocs=1, join=True)
+    assert result.get() is True
+
+
 def test_strip_bounds_cover_the_mosaic():
     for width in (1, 7, 64, 13760):
         for world in (1, 2, 3, 8):

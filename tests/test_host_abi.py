@@ -394,3 +394,50 @@ def test_stacked_border_product_equals_the_per_frame_dot():
         for i, hom in enumerate(homs[:5]):
             lo, hi = engine.range_from_border(shapes[i], hom)
             assert np.array_equal(lo, low[i]) and np.array_equal(hi, high[i])
+
+
+def test_plan_memo_is_keyed_on_every_bit_of_the_cameras():
+    """engine.PlanMemo (Engine.cached_plan, the default of the strips path): the same shapes,
+    rotations, calibrations, padding, cap and table columns hit - and hand back a plan equal to
+    a fresh ``Plan(...)``, which is what the reference recomputes per stitch
+    (stitcher.py:276-302) - and ONE entry of ONE matrix moved by one unit in the last place
+    misses, as do a changed cap, padding flag, shape and table range."""
+    import numpy as np
+    from pano360_amd import engine, synth
+    rots, intrs = synth.make_cameras(6, 160, 90, sweep_deg=100.0, jitter=0.01, seed=3)
+    shapes = [(90, 160)] * 6
+    memo = engine.PlanMemo()
+    made = []
+
+    def make(*a):
+        made.append(a)
+        return engine.Plan(*a)
+    first = memo.get(shapes, rots, intrs, True, 1400, None, make=make)
+    again = memo.get([tuple(s) for s in shapes], rots.copy(), intrs.copy(), True, 1400.0, None, make=make)
+    assert again is first and len(made) == 1 and (memo.hits, memo.misses) == (1, 1)
+    fresh = engine.Plan(shapes, rots, intrs, True, 1400)
+    assert fresh.shape == first.shape and fresh.rects == first.rects
+    for a, b in ((fresh.sin_t, first.sin_t), (fresh.cos_t, first.cos_t), (fresh.tan_p, first.tan_p),
+                 (np.asarray(fresh.projs), np.asarray(first.projs)), (fresh.resolution, first.resolution)):
+        assert np.array_equal(a, b)
+    # one ulp in one entry of one rotation / one calibration
+    for which in ("rot", "intr"):
+        r2, k2 = rots.copy(), intrs.copy()
+        target = r2 if which == "rot" else k2
+        target[4, 1, 1] = np.nextafter(target[4, 1, 1], np.inf)
+        assert memo.key(shapes, r2, k2, True, 1400) != memo.key(shapes, rots, intrs, True, 1400)
+        moved = memo.get(shapes, r2, k2, True, 1400, None, make=make)
+        assert moved is not first
+    assert len(made) == 3
+    # everything else a plan depends on
+    base = memo.key(shapes, rots, intrs, True, 1400)
+    assert memo.key(shapes, rots, intrs, False, 1400) != base
+    assert memo.key(shapes, rots, intrs, True, 1401) != base
+    assert memo.key([(90, 161)] + shapes[1:], rots, intrs, True, 1400) != base
+    assert memo.key(shapes, rots, intrs, True, 1400, (0, 64)) != base
+    assert memo.key(shapes, rots, intrs, True, 1400, (0, 64)) != memo.key(shapes, rots, intrs, True, 1400, (0, 65))
+    # the oldest entry leaves when the memo is full
+    small = engine.PlanMemo(capacity=2)
+    for cap in (1400, 1401, 1402):
+        small.get(shapes, rots, intrs, True, cap)
+    assert len(small) == 2 and small.key(shapes, rots, intrs, True, 1400) not in small.plans
