@@ -1054,13 +1054,18 @@ def main():
     if not strips:
         elapsed, plan, patches, times = run_sets()
         out = build_line(False, elapsed, plan, patches, times) if rank == 0 else None
-        if rank == 0 and not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(cfg)
-            out["cpu_baseline"]["pipelined"] = False     # one stitch at a time, start to finish
         if world == 1 and not args.no_secondary and args.workload == "cfg3":
             out["secondary"] = secondary_single_gpu(eng, fence)
             strict = out["secondary"].get("blur_valu_f32", {})
             out["ms_per_step_strict_f32"] = strict.get("ms_per_step")
+        # The CPU leg runs AFTER every GPU measurement: ten seconds of the oracle on all host
+        # threads leave the host slower for a while (round 5, two visits of one box: the
+        # secondaries that are bound by the host's launch rate measured 0.52 / 5.28 ms - config 2
+        # with two stitches in flight, config 4 with detection - right behind it and 0.44 / 3.03 ms
+        # without it, profiles/r05/notes.md; the driver's round-4 run had it in front: 4.94 ms).
+        if rank == 0 and not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(cfg)
+            out["cpu_baseline"]["pipelined"] = False     # one stitch at a time, start to finish
         busy = args.busy_seconds
         if busy is None:
             busy = 6.0 if world == 1 and args.workload == "cfg3" else 0.0

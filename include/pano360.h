@@ -156,8 +156,11 @@ int pano_interior_block(void);
  *                         (split float16 operands, float32 accumulate),
  *                         PANO_BLUR_VALU = separate row / column passes in float32
  *                         on the vector ALU (one FMA per tap)
- *   PANO_OPT_OWN_PRUNE    1 (default) = pano_ownership_cameras skips cameras that
- *                         rigorous bounds exclude; 0 = evaluate every camera
+ *   PANO_OPT_OWN_PRUNE    bit 0: 1 (default) = pano_ownership_cameras skips cameras that
+ *                         rigorous bounds exclude (per 64 x 16 sub-tile, the survivors again
+ *                         per 16 x 16 quarter); 0 = evaluate every camera at every pixel.
+ *                         bit 1: 2 = the one-level kernel of round 4 (bounds per 64 x 16
+ *                         sub-tile only; A/B and cross-check).  Same maps, bit for bit.
  *   PANO_OPT_BLUR_SEGMENTS  matrix-core blur: 1 (default) = when a launch has too few column
  *                         strips to fill the CUs (one GPU's share of a panorama, small
  *                         scenes) each strip is cut into vertical segments; 0 = never

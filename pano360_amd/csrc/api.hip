@@ -138,6 +138,8 @@ extern "C" int pano_ctx_set_option(pano_ctx *ctx, int option, int value) {
                      "pano_ctx_set_option: blur kernel %d", value);
     else if (option == PANO_OPT_STITCH_ASYNC)
         PANO_REQUIRE(value >= 0 && value <= 2, "pano_ctx_set_option: option %d takes 0, 1 or 2", option);
+    else if (option == PANO_OPT_OWN_PRUNE)
+        PANO_REQUIRE(value >= 0 && value <= 3, "pano_ctx_set_option: option %d takes 0 .. 3", option);
     else
         PANO_REQUIRE(value == 0 || value == 1, "pano_ctx_set_option: option %d takes 0 or 1", option);
     ctx->opt[option] = value;

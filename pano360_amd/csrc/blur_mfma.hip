@@ -2303,9 +2303,17 @@ __global__ __launch_bounds__(256) void mb_sort_kernel(const int2 *__restrict__ i
         const pano_patch p = table[it.x & 0xffff];
         return !mb_item_regular(p, (p.ax0 >> 5) << 5, it.x >> 16, cm);
     };
-    int S = 1, S_irr = 1;
+    // T: the segment length (bands) items are cut to, 0 = nothing is cut.  Items differ in length
+    // by a factor of six (13 - 82 bands on config 3): one segment COUNT for all of them (rounds
+    // 2 - 4) cut the short items into segments that were mostly lead while the long ones still set
+    // the launch's length; one segment LENGTH gives a long item many segments and a short one none
+    // (a world-8 strip of config 3: the blur 0.138 -> see profiles/r05/notes.md).
+    int T = 0, S_irr = 1;
+    constexpr int NCAND = 12;
+    __shared__ int s_segs[NCAND];
     if (slots > 0 && n > 0) {                                    // uniform
         if (tid == 0) s_lmax = s_lsum = s_nirr = 0;
+        if (tid < NCAND) s_segs[tid] = 0;
         __syncthreads();
         int lmax = 0, lsum = 0, nirr = 0;
         for (int i = tid; i < n; i += 256) {
@@ -2319,33 +2327,47 @@ __global__ __launch_bounds__(256) void mb_sort_kernel(const int2 *__restrict__ i
         atomicAdd(&s_nirr, nirr);
         __syncthreads();
         const int Lmax = s_lmax, Lsum = s_lsum;
-        auto model = [&](const int s) {
-            const int longest = (Lmax + s - 1) / s + MB_SEG_LEAD;
-            const int share = (int)(((long long)Lsum + (long long)n * s * MB_SEG_LEAD) *
-                                    wgs_per_item / slots);
-            return max(longest, share);
+        // candidate lengths: Lmax / 2 ... Lmax / 8 and a few absolute ones
+        auto cand = [&](const int c) {
+            const int t = c < 7 ? (Lmax + c + 1) / (c + 2) : 8 * (c - 5);        // .../2 ... /8, 16 ... 48
+            return max(t, 8);
         };
-        const int base = model(1);
+        for (int c = 0; c < NCAND; ++c) {
+            const int t = cand(c);
+            int segs = 0;
+            for (int i = tid; i < n; i += 256) segs += min(MB_SEG_MAX, (items[i].y + t - 1) / t);
+            if (segs) atomicAdd(&s_segs[c], segs);
+        }
+        __syncthreads();
+        const int base = max(Lmax + MB_SEG_LEAD,
+                             (int)(((long long)Lsum + (long long)n * MB_SEG_LEAD) * wgs_per_item / slots));
         int best = base;
-        for (int s = 2; s <= MB_SEG_MAX && n * s <= scap && n * s <= n + MB_SEG_SLOTS; ++s) {
-            const int m = model(s);
+        for (int c = 0; c < NCAND; ++c) {
+            const int t = cand(c), segs = s_segs[c];
+            if (t >= Lmax || segs <= n || segs > scap || segs > n + MB_SEG_SLOTS) continue;
+            const int longest = max(t, (Lmax + MB_SEG_MAX - 1) / MB_SEG_MAX) + MB_SEG_LEAD;
+            const int share = (int)(((long long)Lsum + (long long)segs * MB_SEG_LEAD) * wgs_per_item / slots);
+            const int m = max(longest, share);
             if (m < best && m * 100 <= base * 85) {
                 best = m;
-                S = s;
+                T = t;
             }
         }
         // the irregular items' own segment count: as many as the list's spare slots allow
+        // (builds with -DMB_STREAM_EDGE=0 only: the lean step takes every item otherwise)
         const int n_irr = s_nirr;
-        if (n_irr > 0) {
-            const int spare = min(scap - n * S, MB_SEG_SLOTS - n * (S - 1));
-            S_irr = max(S, min(MB_SEG_MAX, 1 + max(spare, 0) / n_irr));
+        if (n_irr > 0 && T == 0) {
+            const int spare = min(scap - n, MB_SEG_SLOTS);
+            S_irr = min(MB_SEG_MAX, 1 + max(spare, 0) / n_irr);
         }
         __syncthreads();
     }
-    // segments of item i: S, or for an irregular one up to S_irr of at least ~10 bands each
+    // segments of item i: its length over T, or for an irregular one up to S_irr of at least ~10
+    // bands each
     auto segments_of = [&](const int2 it) {
-        if (S_irr <= S || !irregular(it)) return S;
-        return max(S, min(S_irr, it.y / 10));
+        const int cut = T ? min(MB_SEG_MAX, (it.y + T - 1) / T) : 1;
+        if (S_irr <= cut || !irregular(it)) return cut;
+        return max(cut, min(S_irr, it.y / 10));
     };
     auto entry = [&](const int2 it, const int seg, const int ns) {
         const int len = ns == 1 ? it.y : (it.y + ns - 1) / ns + 4;

@@ -201,9 +201,10 @@ __device__ __forceinline__ int reflect_101(int p, int len) {
 // cvRound(float) the way x86 cvtss2si does it: ties to even, and the
 // "integer indefinite" 0x80000000 for NaN or anything outside int32.
 __device__ __forceinline__ int cv_round(float v) {
-    float r = rintf(v);
-    if (!(r >= -2147483648.0f && r < 2147483648.0f)) return (int)0x80000000;
-    return (int)r;
+    const float r = rintf(v);
+    // (one compare: |r| < 2^31 fails for NaN, for everything outside int32 and for -2^31 itself,
+    // whose conversion is that same bit pattern)
+    return fabsf(r) < 2147483648.0f ? (int)r : (int)0x80000000;
 }
 
 __device__ __forceinline__ int sat16(int v) {

@@ -71,12 +71,16 @@ __device__ __forceinline__ float lerp4(float v00, float v01, float v10, float v1
     return a;
 }
 
-// The four taps' uint8 RGB triples.  Away from the frame border the two taps of a
-// row are neighbours (x1 == x0 + 1): their six bytes are fetched with one 4-byte and
-// one 2-byte load (any alignment) instead of six byte loads - the sampling kernels are
-// bound by the number of memory instructions, not by bytes.
+// The four taps' uint8 RGB triples, as OFFSETS INTO A FLOAT TABLE (4 x the byte's value: what
+// every user does with a tap's byte is look its colour up in a 256-entry float table).  Away
+// from the frame border the two taps of a row are neighbours (x1 == x0 + 1): their six bytes
+// are fetched with one 4-byte and one 2-byte load (any alignment) instead of six byte loads -
+// the sampling kernels are bound by the number of their instructions, not by bytes - and a
+// byte leaves its dword already multiplied by four, in ONE instruction: `v_lshlrev_b32` with
+// an SDWA byte select on its operand (mask, shift and scale were three: 26 of the warp's 139
+// vector instructions per pixel, profiles/r05/warp_isa_breakdown.txt).
 struct TapBytes {
-    uint32_t v[4][3];               // [tap 00, 01, 10, 11][channel]
+    uint32_t v[4][3];               // [tap 00, 01, 10, 11][channel]: 4 * byte
 };
 typedef uint32_t u32_any __attribute__((aligned(1)));
 typedef uint16_t u16_any __attribute__((aligned(1)));
@@ -85,6 +89,36 @@ typedef uint16_t u16_any __attribute__((aligned(1)));
 typedef const __attribute__((address_space(1))) uint8_t *frame_ptr;
 typedef const __attribute__((address_space(1))) u32_any *frame_ptr32;
 typedef const __attribute__((address_space(1))) u16_any *frame_ptr16;
+
+#define PANO_BYTE_X4(B)                                                                        \
+    __device__ __forceinline__ uint32_t byte##B##_x4(uint32_t x) {                             \
+        uint32_t r;                                                                            \
+        asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD "               \
+            "src0_sel:DWORD src1_sel:BYTE_" #B                                                 \
+            : "=v"(r)                                                                          \
+            : "v"(2u), "v"(x));                                                                \
+        return r;                                                                              \
+    }
+PANO_BYTE_X4(0)
+PANO_BYTE_X4(1)
+PANO_BYTE_X4(2)
+PANO_BYTE_X4(3)
+#undef PANO_BYTE_X4
+
+// entry of a 256-float table at a TapBytes offset
+__device__ __forceinline__ float lut_at(const float *__restrict__ table, uint32_t off) {
+    return *(const float *)((const char *)table + off);
+}
+
+// a row's two neighbouring taps out of its six bytes: lo = bytes 0..3, hi = bytes 4..5
+__device__ __forceinline__ void unpack_row(TapBytes &t, int r, uint32_t lo, uint32_t hi) {
+    t.v[2 * r][0] = byte0_x4(lo);
+    t.v[2 * r][1] = byte1_x4(lo);
+    t.v[2 * r][2] = byte2_x4(lo);
+    t.v[2 * r + 1][0] = byte3_x4(lo);
+    t.v[2 * r + 1][1] = byte0_x4(hi);
+    t.v[2 * r + 1][2] = byte1_x4(hi);
+}
 
 __device__ __forceinline__ TapBytes load_taps(const uint8_t *__restrict__ frame, int sw,
                                               const Taps &tp) {
@@ -98,20 +132,13 @@ __device__ __forceinline__ TapBytes load_taps(const uint8_t *__restrict__ frame,
     for (int r = 0; r < 2; ++r) {
         const frame_ptr a = rows[r] + (uint32_t)tp.x0 * 3u;
         if (pair) {
-            const uint32_t lo = *(frame_ptr32)a;
-            const uint32_t hi = *(frame_ptr16)(a + 4);
-            t.v[2 * r][0] = lo & 255u;
-            t.v[2 * r][1] = (lo >> 8) & 255u;
-            t.v[2 * r][2] = (lo >> 16) & 255u;
-            t.v[2 * r + 1][0] = lo >> 24;
-            t.v[2 * r + 1][1] = hi & 255u;
-            t.v[2 * r + 1][2] = hi >> 8;
+            unpack_row(t, r, *(frame_ptr32)a, *(frame_ptr16)(a + 4));
         } else {
             const frame_ptr b = rows[r] + (uint32_t)tp.x1 * 3u;
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
-                t.v[2 * r][k] = a[k];
-                t.v[2 * r + 1][k] = b[k];
+                t.v[2 * r][k] = (uint32_t)a[k] << 2;
+                t.v[2 * r + 1][k] = (uint32_t)b[k] << 2;
             }
         }
     }
@@ -129,16 +156,17 @@ __device__ __forceinline__ TapBytes load_taps_interior(const uint8_t *__restrict
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
         const frame_ptr a = base + (r ? o0 + pitch : o0);
-        const uint32_t lo = *(frame_ptr32)a;
-        const uint32_t hi = *(frame_ptr16)(a + 4);
-        t.v[2 * r][0] = lo & 255u;
-        t.v[2 * r][1] = (lo >> 8) & 255u;
-        t.v[2 * r][2] = (lo >> 16) & 255u;
-        t.v[2 * r + 1][0] = lo >> 24;
-        t.v[2 * r + 1][1] = hi & 255u;
-        t.v[2 * r + 1][2] = hi >> 8;
+        unpack_row(t, r, *(frame_ptr32)a, *(frame_ptr16)(a + 4));
     }
     return t;
+}
+
+// table[i] of a double table in global memory whose base is wave-uniform (the trig tables of a
+// mosaic: i < 2^28): the index goes in as a 32-bit byte offset beside the scalar base instead of
+// a sign-extended 64-bit address per load (three vector instructions each).
+__device__ __forceinline__ double table_f64(const double *__restrict__ table, int i) {
+    typedef const __attribute__((address_space(1))) char *gbyte;
+    return *(const __attribute__((address_space(1))) double *)((gbyte)table + (uint32_t)i * 8u);
 }
 
 // ray = (sin theta, tan phi, cos theta); pixel = K R ray in double as an FMA
@@ -160,9 +188,13 @@ __device__ __forceinline__ bool map_pixel(const double *K, double s, double c, d
 
 // Bilinear sample of the alpha plane _add_weights would have stored:
 // float32(hat_y[y] * hat_x[x]) with the product taken in double.
-__device__ __forceinline__ float alpha_at(const double *__restrict__ hat_x,
-                                          const double *__restrict__ hat_y,
+__device__ __forceinline__ float alpha_at(const double *__restrict__ hat_x_,
+                                          const double *__restrict__ hat_y_,
                                           const Taps &tp) {
+    // (the hat tables live in global memory; a pointer read out of a camera record that was
+    // staged in LDS is generic to the compiler and would load through the flat path)
+    typedef const __attribute__((address_space(1))) double *hat_ptr;
+    const hat_ptr hat_x = (hat_ptr)hat_x_, hat_y = (hat_ptr)hat_y_;
     const double hy0 = hat_y[tp.y0], hy1 = hat_y[tp.y1];
     const double hx0 = hat_x[tp.x0], hx1 = hat_x[tp.x1];
     return lerp4((float)(hy0 * hx0), (float)(hy0 * hx1), (float)(hy1 * hx0),

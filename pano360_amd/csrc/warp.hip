@@ -104,11 +104,11 @@ __global__ __launch_bounds__(256) void warp_windows_kernel(
     const pano_camera *cam = cams + p.index;
     const int sw = cam->sw, sh = cam->sh;
     const int gx = p.x0 + p.vx0 + x;
-    const double s = sin_t[gx], c = cos_t[gx];
+    const double s = table_f64(sin_t, gx), c = table_f64(cos_t, gx);
     double t[WARP_ROWS];
 #pragma unroll
     for (int j = 0; j < WARP_ROWS; ++j)
-        t[j] = tan_p[p.y0 + p.vy0 + min(y0 + 4 * j, p.vh - 1)];
+        t[j] = table_f64(tan_p, p.y0 + p.vy0 + min(y0 + 4 * j, p.vh - 1));
     Taps tp[WARP_ROWS];
     TapBytes tb[WARP_ROWS];
     bool inner = true;
@@ -124,6 +124,16 @@ __global__ __launch_bounds__(256) void warp_windows_kernel(
     // vector instructions - 160 per pixel, 77 % of the issue cycles - not by its loads; the
     // four range tests of the general path and the branches around their modulos were 30 of
     // them).  The decision is per wave, so neither path runs under a partial mask.
+#ifdef WARP_ABL_NOLOAD                          // timing experiment (results wrong): no frame reads
+    if (true) {
+#pragma unroll
+        for (int j = 0; j < WARP_ROWS; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int k = 0; k < 3; ++k) tb[j].v[q][k] = ((uint32_t)(tp[j].x0 + q + k) & 255u) << 2;
+    } else
+#endif
     if (__ballot(!inner) == 0ull) {
 #pragma unroll
         for (int j = 0; j < WARP_ROWS; ++j) tb[j] = load_taps_interior(cam->frame, sw, tp[j]);
@@ -136,19 +146,33 @@ __global__ __launch_bounds__(256) void warp_windows_kernel(
     }
     // offsets inside a plane fit 32 bits (pano_layout_windows checks it); the three bases are
     // wave-uniform
+    // (a plane is below 2 GiB - layout_record_fits - so a pixel's BYTE offset fits 32 bits: the
+    // stores take the wave-uniform plane base as scalar operand and one 32-bit offset register
+    // for all three planes, instead of a 64-bit address computed per store)
     typedef __attribute__((address_space(1))) float *plane_ptr;
+    typedef __attribute__((address_space(1))) char *byte_ptr;
     const size_t plane = (size_t)p.vh * p.vpitch;
-    const plane_ptr out[3] = {(plane_ptr)p.planes, (plane_ptr)p.planes + plane,
-                              (plane_ptr)p.planes + 2 * plane};
+    const byte_ptr out[3] = {(byte_ptr)p.planes, (byte_ptr)(p.planes + plane),
+                             (byte_ptr)(p.planes + 2 * plane)};
 #pragma unroll
     for (int j = 0; j < WARP_ROWS; ++j) {
         const int y = y0 + 4 * j;
         if (y >= p.vh) break;
-        const uint32_t o = (uint32_t)y * (uint32_t)p.vpitch + (uint32_t)x;
+        const uint32_t o = ((uint32_t)y * (uint32_t)p.vpitch + (uint32_t)x) * 4u;
 #pragma unroll
-        for (int k = 0; k < 3; ++k)
-            out[k][o] = lerp4(s_lut[tb[j].v[0][k]], s_lut[tb[j].v[1][k]],
-                                       s_lut[tb[j].v[2][k]], s_lut[tb[j].v[3][k]], tp[j]);
+        for (int k = 0; k < 3; ++k) {
+#ifdef WARP_ABL_NOLUT                           // timing experiment (results wrong): no table look-ups
+            const float v = lerp4(__uint_as_float(tb[j].v[0][k]), __uint_as_float(tb[j].v[1][k]),
+                                  __uint_as_float(tb[j].v[2][k]), __uint_as_float(tb[j].v[3][k]), tp[j]);
+#else
+            const float v = lerp4(lut_at(s_lut, tb[j].v[0][k]), lut_at(s_lut, tb[j].v[1][k]),
+                                  lut_at(s_lut, tb[j].v[2][k]), lut_at(s_lut, tb[j].v[3][k]), tp[j]);
+#endif
+#ifdef WARP_ABL_NOSTORE                         // timing experiment (results wrong): (almost) no stores
+            if (v == 12345.0f)
+#endif
+            *(plane_ptr)(out[k] + o) = v;
+        }
     }
 }
 

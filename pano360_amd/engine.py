@@ -703,7 +703,9 @@ class Engine:
         if blur not in ("mfma", "valu"):
             raise ValueError(f"blur kernel {blur!r}: 'mfma' or 'valu'")
         self.set_option(_lib.OPT_BLUR_KERNEL, _lib.BLUR_VALU if blur == "valu" else _lib.BLUR_MFMA)
-        self.set_option(_lib.OPT_OWN_PRUNE, 1 if own_prune else 0)
+        # (PANO_OWN_PRUNE: A/B timing of the ownership kernels - 3 = round 4's one-level kernel)
+        self.set_option(_lib.OPT_OWN_PRUNE, int(os.environ.get("PANO_OWN_PRUNE", "1")) if own_prune
+                        else 0)
         self.tile_grid = int(self.lib.pano_blur_tile_grid(self._ctx))
         self.interior_block = int(self.lib.pano_interior_block())
         lut = np.arange(256, dtype=np.float32) / np.float32(255)   # stitcher.py:259

@@ -360,12 +360,15 @@ def test_cfg5_full_size_properties(eng, oracle):
     from pano360_amd import _lib
     eng.upload_plan(plan)
     pruned, pruned_valid = (v.clone() for v in eng.ownership_cameras(plan))
-    eng.set_option(_lib.OPT_OWN_PRUNE, 0)
     try:
+        eng.set_option(_lib.OPT_OWN_PRUNE, 3)              # round 4's kernel: one level of bounds
+        one_level, one_level_valid = (v.clone() for v in eng.ownership_cameras(plan))
+        eng.set_option(_lib.OPT_OWN_PRUNE, 0)
         exact, exact_valid = eng.ownership_cameras(plan)
     finally:
         eng.set_option(_lib.OPT_OWN_PRUNE, 1)
     assert torch.equal(pruned, exact) and torch.equal(pruned_valid, exact_valid)
+    assert torch.equal(one_level, exact) and torch.equal(one_level_valid, exact_valid)
     assert int((exact[200:4700, plan.shape[1] - 32:] == -1).sum()) == 0
     # strips of a world-8 run: first, a middle and the last rank (the last one holds the seam)
     world = 8
@@ -458,22 +461,21 @@ def test_full_size_multiband_windows_against_oracle(eng, oracle, name):
     mosaic depends on the patches within the largest Gaussian radius R of it only: the oracle's
     multiband_blend on the patches cut to a 288 x 288 window (its blur reflecting at the cut)
     equals the reference's on the whole mosaic on the window shrunk by R from every cut side.
-    uint8 within one level (the stated bound of the multiband path), interior shortcut on."""
+    Two passes, interior shortcut on:
+    * noise frames (pixel set A, the stress set): uint8 within one level, the stated bound of the
+      multiband path, and at most 0.4 % of a window's values off by that level (measured 0.08 %);
+    * smooth frames (pixel set B, SURVEY 8d's set for the float criterion): the FLOAT mosaic
+      before the uint8 truncation within 1e-4 relative L2 of the oracle's on every window, and the
+      uint8 mosaic within one level."""
     from pano360_amd import engine, synth
     cfg = synth.CONFIGS[name]
     n, w, h, levels = cfg["n"], cfg["width"], cfg["height"], cfg["n_levels"]
     rots, intrs = synth.make_cameras(n, w, h, sweep_deg=cfg.get("sweep_deg"),
                                      step_deg=cfg.get("step_deg"))
     shapes = [(h, w)] * n
-    host = [synth.make_frame(i, w, h, "A") for i in range(4)]
-    imgs = [host[i % 4] for i in range(n)]
-    base = eng.upload_frames(host)
-    frames = [base[i % 4] for i in range(n)]
     plan = engine.Plan(shapes, rots, intrs, True, 10 ** 9)
     H, W = plan.shape
-    mosaic, _, valid, _ = eng.stitch(frames, plan, "multiband", levels)
-    mosaic = mosaic.cpu().numpy()
-    owner = eng.ownership_cameras(plan)[0].cpu().numpy()
+    owner = eng.ownership_cameras(eng.upload_plan(plan))[0].cpu().numpy()
     R = max(engine.gaussian_ksize(s) // 2 for s in engine.level_sigmas(levels))
     S = 288
     seams = np.nonzero(np.diff(owner[H // 2]))[0]
@@ -482,22 +484,41 @@ def test_full_size_multiband_windows_against_oracle(eng, oracle, name):
     windows = [(H // 2 - S // 2, H // 2 + S // 2, mid, mid + S),      # a seam in the middle
                (H // 2, H // 2 + S, W - S, W), (H // 2, H // 2 + S, 0, S),     # both ends
                (0, S, mid, mid + S), (H - S, H, W - S, W)]                     # top, a corner
-    cache, worst, total = {}, 0, 0
-    for win in windows:
-        wy0, wy1, wx0, wx1 = win
-        _, patches, shape = _oracle_window(oracle, imgs, cache, rots, intrs, True, win)
-        ref = oracle.multiband_blend(patches, shape, levels)
-        iy0, iy1 = (R if wy0 > 0 else 0), S - (R if wy1 < H else 0)
-        ix0, ix1 = (R if wx0 > 0 else 0), S - (R if wx1 < W else 0)
-        got = mosaic[wy0:wy1, wx0:wx1][iy0:iy1, ix0:ix1].astype(np.int32)
-        diff = np.abs(got - ref[iy0:iy1, ix0:ix1].astype(np.int32))
-        assert diff.max() <= 1, (win, int(diff.max()), int((diff > 1).sum()))
-        assert ref[iy0:iy1, ix0:ix1].max() > 0
-        worst = max(worst, float((diff > 0).mean()))
-        total += diff.size
-    print(f"{name} full size, multiband windows: {total} values compared, at most "
-          f"{100 * worst:.3f} % of a window differ by one level")
-    assert worst < 0.02
+    del owner
+    for kind, distinct in (("A", 4), ("B", 2)):
+        host = [synth.make_frame(i, w, h, kind) for i in range(distinct)]
+        imgs = [host[i % distinct] for i in range(n)]
+        base = eng.upload_frames(host)
+        frames = [base[i % distinct] for i in range(n)]
+        mosaic, fl, _, _ = eng.stitch(frames, plan, "multiband", levels, want_float=kind == "B")
+        mosaic = mosaic.cpu().numpy()
+        cache, worst, total, worst_rel = {}, 0, 0, 0.0
+        for win in windows:
+            wy0, wy1, wx0, wx1 = win
+            _, patches, shape = _oracle_window(oracle, imgs, cache, rots, intrs, True, win)
+            iy0, iy1 = (R if wy0 > 0 else 0), S - (R if wy1 < H else 0)
+            ix0, ix1 = (R if wx0 > 0 else 0), S - (R if wx1 < W else 0)
+            if kind == "B":
+                ref, ref_f = oracle.multiband_blend(patches, shape, levels, return_float=True)
+                got_f = fl[wy0:wy1, wx0:wx1].cpu().numpy()[iy0:iy1, ix0:ix1]
+                want_f = ref_f[iy0:iy1, ix0:ix1]
+                rel = float(np.linalg.norm(got_f.astype(np.float64) - want_f)
+                            / np.linalg.norm(want_f.astype(np.float64)))
+                assert rel <= 1e-4, (name, win, rel)          # float mosaic, pixel set B
+                worst_rel = max(worst_rel, rel)
+            else:
+                ref = oracle.multiband_blend(patches, shape, levels)
+            got = mosaic[wy0:wy1, wx0:wx1][iy0:iy1, ix0:ix1].astype(np.int32)
+            diff = np.abs(got - ref[iy0:iy1, ix0:ix1].astype(np.int32))
+            assert diff.max() <= 1, (kind, win, int(diff.max()), int((diff > 1).sum()))
+            assert ref[iy0:iy1, ix0:ix1].max() > 0
+            worst = max(worst, float((diff > 0).mean()))
+            total += diff.size
+        print(f"{name} full size, multiband windows, pixel set {kind}: {total} values compared, at "
+              f"most {100 * worst:.3f} % of a window differ by one level"
+              + (f", float mosaic rel-L2 at most {worst_rel:.2e}" if kind == "B" else ""))
+        assert worst < 0.004                    # five times the measured 0.0008
+        del mosaic, fl, frames, base, host, imgs, cache
 
 
 @pytest.mark.parametrize("world", [8, 5])

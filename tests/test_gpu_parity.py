@@ -290,8 +290,14 @@ def test_ownership_from_cameras_equals_ownership_from_planes(eng, name):
     plan = eng.upload_plan(engine.Plan([im.shape[:2] for im in imgs], rots, intrs, True, mr))
     patches, _ = eng.warp_all(eng.upload_frames(imgs), plan)
     owner_b, valid_b = eng.ownership(engine.patch_table(patches, eng), plan.shape)
-    owner_a, valid_a = eng.ownership_cameras(plan)
-    assert torch.equal(owner_a, owner_b) and torch.equal(valid_a, valid_b)
+    from pano360_amd import _lib
+    try:
+        for opt in (3, 1):        # one level of bounds (round 4's kernel), two levels (the default)
+            eng.set_option(_lib.OPT_OWN_PRUNE, opt)
+            owner_a, valid_a = eng.ownership_cameras(plan)
+            assert torch.equal(owner_a, owner_b) and torch.equal(valid_a, valid_b), opt
+    finally:
+        eng.set_option(_lib.OPT_OWN_PRUNE, 1)
     assert np.array_equal(valid_a.cpu().numpy().astype(bool), g["mb_valid"])
     # column strips (the multi-GPU split) tile the same map
     W = plan.shape[1]
@@ -328,14 +334,19 @@ def test_ownership_bounds_against_exhaustive_evaluation(eng, seed):
     cap = (10 ** 9, 700, 180)[seed % 3]
     plan = eng.upload_plan(engine.Plan([(h, w)] * n, rots, intrs, seed % 2 == 0, cap))
     from pano360_amd import _lib
-    eng.set_option(_lib.OPT_OWN_PRUNE, 0)                 # every camera at every pixel
+    # option bits: 1 = prune by bounds, 2 = the one-level kernel of round 4.  Every camera at
+    # every pixel (0, and 2 through the other kernel's evaluation loop) against both pruned forms
+    got = {}
     try:
-        owner_all, valid_all = eng.ownership_cameras(plan)
+        for opt in (0, 2, 3, 1):
+            eng.set_option(_lib.OPT_OWN_PRUNE, opt)
+            got[opt] = tuple(v.clone() for v in eng.ownership_cameras(plan))
         torch.cuda.synchronize()
     finally:
         eng.set_option(_lib.OPT_OWN_PRUNE, 1)
-    owner, valid = eng.ownership_cameras(plan)
-    assert torch.equal(owner, owner_all) and torch.equal(valid, valid_all)
+    owner_all, valid_all = got[0]
+    for opt in (1, 2, 3):
+        assert torch.equal(got[opt][0], owner_all) and torch.equal(got[opt][1], valid_all), opt
     assert (owner_all >= 0).any() and (owner_all < 0).any()
 
 
@@ -422,7 +433,7 @@ def test_ownership_with_regions_equals_the_two_calls(eng, case):
     W = plan.shape[1]
     if case == "strip":
         strip = (W // 3 + 5, 2 * W // 3 + 1)
-    for prune in (1, 0):
+    for prune in (1, 0, 3):
         eng.set_option(_lib.OPT_OWN_PRUNE, prune)
         try:
             owner_a, valid_a = eng.ownership_cameras(plan, strip=strip)
@@ -477,8 +488,14 @@ def test_ownership_pruning_is_exact(eng, case):
     plan = eng.upload_plan(engine.Plan([(h, w)] * n, rots, intrs, True, 10 ** 9))
     patches, _ = eng.warp_all(eng.upload_frames(imgs), plan)
     owner_b, valid_b = eng.ownership(engine.patch_table(patches, eng), plan.shape)
-    owner_a, valid_a = eng.ownership_cameras(plan)
-    assert torch.equal(owner_a, owner_b) and torch.equal(valid_a, valid_b)
+    from pano360_amd import _lib
+    try:
+        for opt in (3, 1):        # one level of bounds (round 4's kernel), two levels (the default)
+            eng.set_option(_lib.OPT_OWN_PRUNE, opt)
+            owner_a, valid_a = eng.ownership_cameras(plan)
+            assert torch.equal(owner_a, owner_b) and torch.equal(valid_a, valid_b), opt
+    finally:
+        eng.set_option(_lib.OPT_OWN_PRUNE, 1)
     if case == "identical":
         assert int(owner_a.max()) == 0           # ties go to the first index
     if case == "dense":

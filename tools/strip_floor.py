@@ -12,8 +12,12 @@ import torch  # noqa: E402
 from pano360_amd import dist as pdist  # noqa: E402
 from pano360_amd import engine, synth  # noqa: E402
 
-name = sys.argv[1] if len(sys.argv) > 1 else "cfg3"
-worlds = [int(v) for v in sys.argv[2:]] or [1, 2, 4, 8]
+import json  # noqa: E402
+argv = [a for a in sys.argv[1:] if not a.startswith("--json=")]
+JSON_OUT = next((a[7:] for a in sys.argv[1:] if a.startswith("--json=")), None)
+name = argv[0] if argv else "cfg3"
+worlds = [int(v) for v in argv[1:]] or [1, 2, 4, 8]
+ROWS = []
 cfg = dict(synth.CONFIGS[name])
 rots, intrs = synth.make_cameras(cfg["n"], cfg["width"], cfg["height"],
                                  sweep_deg=cfg.get("sweep_deg"), step_deg=cfg.get("step_deg"))
@@ -76,6 +80,8 @@ for world in worlds:
         eng.timing(False)
         if ms > worst[0]:
             worst = (ms, rank, kern, len(frames), {k: round(v[0] / 20, 3) for k, v in times.items()})
+    ROWS.append(dict(world=world, rank=worst[1], ms_per_stitch=worst[0], kernel_ms=worst[2],
+                     frames_resident=worst[3], kernels=worst[4]))
     sys.stdout.flush()
     print(f"world {world}: slowest of ranks sampled = rank {worst[1]}: {worst[0]:.3f} ms per stitch "
           f"(timed kernels {worst[2]:.3f} ms, {worst[3]} frames resident) {worst[4]}")
@@ -83,3 +89,17 @@ t0 = time.perf_counter()
 for _ in range(50):
     engine.Plan(shapes, rots, intrs, True, 10 ** 9)
 print("Plan alone: %.3f ms" % ((time.perf_counter() - t0) / 50 * 1e3))
+if JSON_OUT:
+    # appended to: one visit runs this tool once per (lanes, plan) setting
+    entry = dict(config=name, lanes=len(LANES), plan_cached=os.environ.get("PANO_PLAN_CACHED", "0") != "0",
+                 stitch_async=os.environ.get("PANO_STITCH_ASYNC", "0"),
+                 what="rank r of world N emulated on ONE GPU: its strip's kernels only, no exchange; "
+                      "wall ms per stitch of 20 stitches, slowest of ranks 0, N/2, N-1",
+                 rows=ROWS)
+    have = []
+    if os.path.exists(JSON_OUT):
+        with open(JSON_OUT) as fid:
+            have = json.load(fid)
+    have.append(entry)
+    with open(JSON_OUT, "w") as fid:
+        json.dump(have, fid, indent=1)
