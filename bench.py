@@ -552,6 +552,10 @@ def secondary_single_gpu(eng, fence):
             with torch.cuda.stream(s2):
                 lanes.append((engine.Engine(use.device), s2))
         state = dict(i=0, serial=False)
+        # with the plan out of the memo every stitch repeats the previous one's Plan object: the
+        # engine queues it with the verified layout and does not wait (Engine.trust_layouts)
+        for e, _ in lanes:
+            e.trust_layouts(bool(cached))
 
         class AllLanes:                      # timing and kernel times over every lane
             def timing(self, on):
@@ -599,6 +603,9 @@ def secondary_single_gpu(eng, fence):
         }
         del pool, frames
         for e, _ in lanes:
+            if cached:
+                e.verify_trusted()
+            e.trust_layouts(False)
             e._arenas.clear()
         del lanes[1:]
         torch.cuda.empty_cache()
@@ -613,9 +620,10 @@ def secondary_single_gpu(eng, fence):
 
     def cached():
         entry = stitches("cfg3", 20, 3, cached=True)
-        entry["what"] = ("config 3 with the host geometry of the (unchanged) cameras kept from "
-                         "stitch to stitch (Engine.cached_plan) instead of recomputed per stitch as "
-                         "the reference does (stitcher.py:276-302) and as the headline does; one "
+        entry["what"] = ("config 3 with the host geometry of the (unchanged) cameras out of the "
+                         "content-keyed memo (Engine.cached_plan) instead of recomputed per stitch as "
+                         "the reference does (stitcher.py:276-302) and as the headline does, and "
+                         "with trusted layouts (Engine.trust_layouts: no wait inside the stitch); one "
                          "stitch at a time (compare with cfg3_one_in_flight)")
         return entry
     guarded("cfg3_plan_cached", cached)
@@ -693,6 +701,14 @@ def secondary_single_gpu(eng, fence):
     # (config 2's 0.44 ms of kernels are shorter than a stitch's host work: two in flight)
     guarded("cfg2", lambda: stitches("cfg2", 40, 4, in_flight=2))
     guarded("cfg2_one_in_flight", lambda: stitches("cfg2", 20, 3))
+
+    def cfg2_cached():
+        entry = stitches("cfg2", 40, 4, cached=True)
+        entry["what"] = ("config 2 one stitch at a time with the plan out of the content-keyed memo "
+                         "(engine.PlanMemo) and trusted layouts (Engine.trust_layouts): the host "
+                         "neither recomputes the geometry nor waits inside the stitch; every kernel runs")
+        return entry
+    guarded("cfg2_plan_cached", cfg2_cached)
 
     def cfg4(detect):
         steps = 16 if detect else 20            # (two frames in flight: a few frames per lane to warm up)

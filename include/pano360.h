@@ -629,10 +629,22 @@ typedef struct pano_stitch_args {
     int32_t lut_stride, n_levels, radius, shortcut, warp_need, max_spans, min_gap;
     int32_t cap_records, cap_tiles;
     int32_t used_need;         /* out: 1 = the warp ran on the need flags */
-    int32_t reserved;
+    int32_t trust_layout;      /* in: 1 = the caller vouches that cameras (matrices, rectangles),
+                                * strip and resident frames are those of this context's previous
+                                * stitch (with PANO_OPT_STITCH_ASYNC on): the stitch is queued with
+                                * that stitch's verified layout and NOBODY WAITS - the call returns
+                                * when everything is queued.  out: 2 = it did, 0 = it took the
+                                * waiting path (first stitch of a shape, option off, ...).  Every
+                                * kernel still runs; what is trusted is only that the same cameras
+                                * give the same layout, which pano_stitch_verify checks. */
     pano_layout layout;        /* out */
 } pano_stitch_args;
 int pano_stitch_multiband(pano_ctx *ctx, pano_stitch_args *args, int resume);
+/* Compares the layout summary of the last trusted stitch with the verified layout it was queued
+ * with (waits for that stitch's layout kernel); PANO_EINVAL when they differ - the promise of
+ * args->trust_layout did not hold and the trusted mosaics since the last check are void.  A no-op
+ * without trusted stitches pending; the next untrusted pano_stitch_multiband calls it itself. */
+int pano_stitch_verify(pano_ctx *ctx);
 /* How many stitches of this context went through on the device-side layout
  * (PANO_OPT_STITCH_ASYNC) and how many of those attempts fell back to the host layout. */
 int pano_stitch_counts(const pano_ctx *ctx, int *device_layouts, int *fallbacks);

@@ -58,7 +58,7 @@ class StitchArgs(C.Structure):
         + [(k, C.c_int32) for k in (
             "n", "H", "W", "xs0", "xs1", "own0", "own1", "lut_stride", "n_levels", "radius",
             "shortcut", "warp_need", "max_spans", "min_gap", "cap_records", "cap_tiles",
-            "used_need", "reserved")]
+            "used_need", "trust_layout")]
         + [("layout", Layout)])
 
 
@@ -151,6 +151,7 @@ _SIGNATURES = {
     "pano_knn2": (_i, [_vp, _vp, _i, _vp, _i, _i, C.c_float, _vp, _vp, _vp, _vp]),
     "pano_stitch_multiband": (_i, [_vp, _vp, _i]),
     "pano_stitch_counts": (_i, [_vp, _vp, _vp]),
+    "pano_stitch_verify": (_i, [_vp]),
 }
 EXPORTS = tuple(_SIGNATURES)
 

@@ -445,28 +445,47 @@ __global__ __launch_bounds__(256) void ownership_cameras_l1_kernel(
 #define OW_CAMS 32          // camera records staged in LDS
 #define OW_QLIST 8          // survivors of a sub-tile that are bounded again per quarter
 #ifndef OW_ILP
-#define OW_ILP 2            // independent pixels per lane in the evaluation
+#define OW_ILP 4            // independent pixels per lane in the evaluation
 #endif
 #define OW_EVAL (-3)        // qfill: evaluate the quarter's pixels
 #define OW_NOBODY (-1)      // qfill / tile: no candidate: owner -1, valid 0
 #define OW_UNOWNED (-2)     // tile: a candidate is unmasked but its alpha is 0: owner -1, valid 1
 
 #ifdef OW_STAMP
-// phase timers (timing experiments only, tools/probe_own_stamps.py): thread 0 of every workgroup
-// adds the cycles between consecutive stamps; [14] = workgroups, [15] = evaluated quarters
-__device__ unsigned long long g_ow_stamps[16];
+// phase timers (timing experiments only, tools/probe_own_stamps.py): thread 0 of every
+// OW_STAMP_STRIDE-th workgroup writes the cycles between consecutive stamps into a row of its own
+// (plain stores: atomics on shared counters, one per stamp and workgroup, made the kernel 4.5 x
+// slower and timed mostly themselves); [14] = 1, [15] = evaluated quarters
+#define OW_STAMP_ROWS 2048
+#define OW_STAMP_STRIDE 4
+__device__ unsigned long long g_ow_stamps[OW_STAMP_ROWS][16];
+#define OW_STAMP_ROW()                                                                       \
+    (((blockIdx.y * gridDim.x + blockIdx.x) % OW_STAMP_STRIDE == 0 &&                        \
+      (blockIdx.y * gridDim.x + blockIdx.x) / OW_STAMP_STRIDE < OW_STAMP_ROWS &&             \
+      threadIdx.x == 0 && threadIdx.y == 0)                                                  \
+         ? (int)((blockIdx.y * gridDim.x + blockIdx.x) / OW_STAMP_STRIDE)                    \
+         : -1)
 #define OW_STAMP_AT(k)                                                      \
     do {                                                                    \
-        if (threadIdx.x == 0 && threadIdx.y == 0) {                         \
+        const int row_ = OW_STAMP_ROW();                                    \
+        if (row_ >= 0) {                                                    \
             const unsigned long long now_ = __builtin_readcyclecounter();   \
-            atomicAdd(&g_ow_stamps[k], now_ - ow_last);                     \
+            g_ow_stamps[row_][k] = now_ - ow_last;                          \
             ow_last = __builtin_readcyclecounter();                         \
         }                                                                   \
     } while (0)
 extern "C" int pano_debug_own_stamps(unsigned long long *out, int reset) {
-    if (out) PANO_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ow_stamps), sizeof(unsigned long long) * 16));
+    // out[16]: the sampled workgroups' rows added up ([14] = how many)
+    if (out) {
+        static unsigned long long host[OW_STAMP_ROWS][16];
+        PANO_HIP(hipMemcpyFromSymbol(host, HIP_SYMBOL(g_ow_stamps), sizeof(host)));
+        for (int k = 0; k < 16; ++k) out[k] = 0;
+        for (int r = 0; r < OW_STAMP_ROWS; ++r)
+            if (host[r][14])
+                for (int k = 0; k < 16; ++k) out[k] += host[r][k];
+    }
     if (reset) {
-        unsigned long long zero[16] = {};
+        static unsigned long long zero[OW_STAMP_ROWS][16];
         PANO_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_ow_stamps), zero, sizeof(zero)));
     }
     return PANO_OK;
@@ -631,7 +650,7 @@ __device__ __forceinline__ void own_tile(OwnShared &S, int (*__restrict__ s_box)
     __syncthreads();
     OW_STAMP_AT(6);
 #ifdef OW_STAMP
-    if (tid == 0) atomicAdd(&g_ow_stamps[15], (unsigned long long)S.n_eval);
+    if (OW_STAMP_ROW() >= 0) g_ow_stamps[OW_STAMP_ROW()][15] = (unsigned long long)S.n_eval;
 #endif
     // an item = 16 columns x 4 OW_ILP rows of a quarter: lane -> column lane & 15, rows
     // (lane >> 4) + 4 j of the item's rows, OW_ILP independent pixels in flight per lane
@@ -710,28 +729,41 @@ __device__ __forceinline__ void own_tile(OwnShared &S, int (*__restrict__ s_box)
         }
     };
     const int rows = by1 - by0;
+    // four of the wave's rows at a time: their LDS reads leave together (one row per trip was a
+    // chain of two dependent LDS reads and two stores, 440 cycles a row, a fifth of the
+    // workgroup's life: profiles/r05/own_stamps_*.txt)
 #pragma unroll 1
-    for (int row = wave; row < rows; row += 4) {
-        int who = S.qfill[(row >> 4) * 4 + (lane >> 4)];
+    for (int row0 = wave; row0 < rows; row0 += 16) {
+        int who[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int row = min(row0 + 4 * u, OW_TH - 1);
+            who[u] = S.qfill[(row >> 4) * 4 + (lane >> 4)];
 #ifdef OW_ABL_NOEVAL
-        if (who == OW_EVAL) who = OW_NOBODY;         // (the tile was not filled in)
+            if (who[u] == OW_EVAL) who[u] = OW_NOBODY;      // (the tile was not filled in)
 #else
-        if (who == OW_EVAL) who = S.town[row][lane];
+            if (who[u] == OW_EVAL) who[u] = S.town[row][lane];
 #endif
-        const bool any = who >= 0 || who == OW_UNOWNED;
-        if (who < 0) who = -1;
-        const int y = by0 + row;
-        if (in_strip) {
-            owner[(size_t)y * W + x] = (int16_t)who;
-            valid[(size_t)y * W + x] = any ? 1 : 0;
         }
-        if (marks) {
-            if (who != run_o) {
-                flush();
-                run_o = who;
-                run_y0 = y;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int row = row0 + 4 * u;
+            if (row >= rows) break;
+            const bool any = who[u] >= 0 || who[u] == OW_UNOWNED;
+            const int w = who[u] < 0 ? -1 : who[u];
+            const int y = by0 + row;
+            if (in_strip) {
+                owner[(size_t)y * W + x] = (int16_t)w;
+                valid[(size_t)y * W + x] = any ? 1 : 0;
             }
-            run_y1 = y;
+            if (marks) {
+                if (w != run_o) {
+                    flush();
+                    run_o = w;
+                    run_y0 = y;
+                }
+                run_y1 = y;
+            }
         }
     }
     OW_STAMP_AT(8);
@@ -766,7 +798,7 @@ __global__ __launch_bounds__(256) void ownership_cameras_kernel(
     unsigned long long ow_last = 0;
 #ifdef OW_STAMP
     ow_last = __builtin_readcyclecounter();
-    if (tid == 0) atomicAdd(&g_ow_stamps[14], 1ull);
+    if (OW_STAMP_ROW() >= 0) g_ow_stamps[OW_STAMP_ROW()][14] = 1ull;
 #endif
     if (marks && tid < NL) {
         int *b = s_box[tid];
@@ -1338,6 +1370,16 @@ __global__ __launch_bounds__(256) void multiband_compose_kernel(
         const size_t vo = (size_t)(ay + p.ay0 - p.vy0) * p.vpitch + (ax + p.ax0 - p.vx0);
         const size_t aplane = (size_t)p.ah * p.apitch, ao = (size_t)ay * p.apitch + ax;
         float hi[3], ha = 0.0f;                 // the copy that gets the minus
+#ifdef COMPOSE_ABL_ALIGNED
+        // timing experiment (results wrong): the wave's reads of the blurred copies start on a
+        // 128-byte line (tiles are anchored at multiples of 32 patch columns, which the layout puts
+        // on line boundaries) - its 256 contiguous bytes are then two whole lines instead of parts
+        // of three - to see what the lines fetched twice by neighbouring blocks cost
+        const size_t ao_al = ao - min(ao, (size_t)((xs0 + (int)blockIdx.x * 64 - p.x0) & 31));
+#define COMPOSE_AO ao_al
+#else
+#define COMPOSE_AO ao
+#endif
 #pragma unroll
         for (int c = 0; c < 3; ++c) hi[c] = p.planes[c * vplane + vo];
         if (L == 1) ha = owner[(size_t)y * W + x] == p.index ? 1.0f : 0.0f;   // sharp alpha (:208)
@@ -1345,7 +1387,7 @@ __global__ __launch_bounds__(256) void multiband_compose_kernel(
         for (int k = 0; k < L; ++k) {
             float rgb[3], a;
             if (k < L - 1) {
-                const float *b = p.blurred + (size_t)k * 4 * aplane + ao;
+                const float *b = p.blurred + (size_t)k * 4 * aplane + COMPOSE_AO;
                 a = b[3 * aplane];
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {

@@ -123,6 +123,8 @@ struct pano_ctx {
     pano_layout lay_prev;
     int lay_prev_sig[12];
     bool lay_prev_valid;
+    bool lay_prev_verified;         // lay_prev was read back (device summary) or made on the host
+    bool trusted_pending;           // a trusted stitch's summary has not been compared yet
     int lay_prev_used_need;
     int lay_count[2];               // stitches that went through on the device layout / fell back
     // pano_sift_extrema: the list of scale-space extrema between its two kernels (+ its counter)

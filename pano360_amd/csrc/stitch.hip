@@ -1,5 +1,6 @@
 // One multiband stitch per native call: the launch sequence of Engine.multiband_fused
 // (stitcher.py:283-327 without equalize / crop) queued from C++.  No kernel of its own.
+#include <stdlib.h>
 #include <string.h>
 
 #include "common.h"
@@ -293,6 +294,14 @@ extern "C" int pano_stitch_multiband(pano_ctx *ctx, pano_stitch_args *a, int res
                     ctx->lay_prev_valid && memcmp(sig, ctx->lay_prev_sig, sizeof(sig)) == 0 &&
                     ctx->lay_prev.n_records > 0 && a->planes && a->blurred && a->tile_flags;
         pano_layout bound = ctx->lay_prev;
+        // a trusted stitch (args->trust_layout = 1, see below) needs the verified layout of the
+        // same shape; its summary is checked first if one is still pending
+        const bool want_trust = a->trust_layout == 1;
+        a->trust_layout = 0;
+        if (ctx->trusted_pending && !(want_trust && spec))
+            if (int rc = pano_stitch_verify(ctx)) return rc;
+        const bool trusted = want_trust && spec && ctx->lay_prev_verified &&
+                             ctx->opt[PANO_OPT_STITCH_ASYNC] == 1;
         if (spec) {
             if (int rc = ensure_layout_buffers(ctx, a->n)) return rc;
             // rectangles and resident flags for the layout kernel: uploaded when they changed,
@@ -312,8 +321,11 @@ extern "C" int pano_stitch_multiband(pano_ctx *ctx, pano_stitch_args *a, int res
                                         hipMemcpyHostToDevice, s));
             }
             // launch bounds: what the previous layout needed, with slack for cameras that move
-            bound.n_records = bound.n_records + 2 < a->cap_records ? bound.n_records + 2 : a->cap_records;
-            bound.max_vw += 64, bound.max_vh += 64, bound.max_aw += 64, bound.max_ah += 64;
+            // (a trusted stitch repeats that layout exactly)
+            if (!trusted) {
+                bound.n_records = bound.n_records + 2 < a->cap_records ? bound.n_records + 2 : a->cap_records;
+                bound.max_vw += 64, bound.max_vh += 64, bound.max_aw += 64, bound.max_ah += 64;
+            }
             if (ctx->opt[PANO_OPT_STITCH_ASYNC] == 2) {          // tests: bounds this layout exceeds
                 bound.n_records = ctx->lay_prev.n_records > 1 ? ctx->lay_prev.n_records - 1 : 1;
                 bound.max_vw = ctx->lay_prev.max_vw - 1;
@@ -323,7 +335,12 @@ extern "C" int pano_stitch_multiband(pano_ctx *ctx, pano_stitch_args *a, int res
         // boxes and column marks from the ownership kernel, the spans' search, its copy to the host
         // (in one pass on mosaics of 16 MP and more: config 5 16.12 -> 15.99 ms, config 3 even;
         // on the 8 MP of config 2 the longer ownership kernel costs what the box kernel saved)
-        if (big) {
+        // (since round 5's ownership kernel the one pass is as fast or faster on every size: config 2
+        // 0.449 / 0.451 ms per stitch, a world-8 strip of config 3 0.321 against 0.331 - the box
+        // kernel's 30 us are a quarter of a strip's ownership; PANO_REGIONS_FUSED = 0: A/B timing)
+        static const char *const fused_env = getenv("PANO_REGIONS_FUSED");
+        const bool fused_regions = fused_env ? fused_env[0] == '1' : true;
+        if (fused_regions) {
             if (int rc = pano_ownership_regions(ctx, a->cams, a->n, a->H, a->W, a->own0, a->own1,
                                                 a->sin_t, a->cos_t, a->tan_p, a->owner, a->valid,
                                                 a->min_gap, a->max_spans, a->marks, a->regions))
@@ -367,11 +384,13 @@ extern "C" int pano_stitch_multiband(pano_ctx *ctx, pano_stitch_args *a, int res
             // the summary goes straight into pinned host memory; the caller's copy of the records
             // leaves through the side stream: nothing stands between this kernel and the warp
             PANO_HIP(hipEventRecord(ctx->ev_regions, s));
-            PANO_HIP(hipStreamWaitEvent(ctx->side, ctx->ev_regions, 0));
-            PANO_HIP(hipMemcpyAsync(a->records_host, a->table,
-                                    (size_t)bound.n_records * sizeof(pano_patch),
-                                    hipMemcpyDeviceToHost, ctx->side));
-            PANO_HIP(hipEventRecord(ctx->ev_copy, ctx->side));
+            if (!trusted) {
+                PANO_HIP(hipStreamWaitEvent(ctx->side, ctx->ev_regions, 0));
+                PANO_HIP(hipMemcpyAsync(a->records_host, a->table,
+                                        (size_t)bound.n_records * sizeof(pano_patch),
+                                        hipMemcpyDeviceToHost, ctx->side));
+                PANO_HIP(hipEventRecord(ctx->ev_copy, ctx->side));
+            }
             if (interior && !interior_queued) {
                 if (int rc = pano_interior_map(ctx, a->owner, a->H, a->W, a->own0, a->own1,
                                                a->radius, a->block_owner, a->interior))
@@ -381,6 +400,20 @@ extern "C" int pano_stitch_multiband(pano_ctx *ctx, pano_stitch_args *a, int res
             if (int rc = queue_tail(ctx, a, bound, true, ctx->lay_prev_used_need, two_streams, interior,
                                     n_blur, tile_grid))
                 return rc;
+            if (trusted) {
+                // The caller vouches that cameras, rectangles, strip and resident frames are those
+                // of this context's previous stitch, whose layout was read and verified: the owner
+                // map, the regions and so the layout are functions of exactly those, the kernels
+                // were queued with that layout's own bounds, and nobody waits - the summary this
+                // stitch's layout kernel writes is compared with the verified one at the next
+                // untrusted call or in pano_stitch_verify.
+                a->layout = ctx->lay_prev;
+                a->used_need = ctx->lay_prev_used_need;
+                a->trust_layout = 2;                             // out: went through without a wait
+                ctx->trusted_pending = true;
+                ++ctx->lay_count[0];
+                return PANO_OK;
+            }
             PANO_HIP(hipEventSynchronize(ctx->ev_regions));      // the GPU is in the warp by now
             PANO_HIP(hipEventSynchronize(ctx->ev_copy));
             const LayoutSummary sum = *ctx->lay_sum_host;
@@ -394,6 +427,7 @@ extern "C" int pano_stitch_multiband(pano_ctx *ctx, pano_stitch_args *a, int res
             if (sum.ok) {
                 ctx->lay_prev = a->layout;
                 ctx->lay_prev_used_need = a->used_need;
+                ctx->lay_prev_verified = true;
                 ++ctx->lay_count[0];
                 return PANO_OK;
             }
@@ -402,6 +436,7 @@ extern "C" int pano_stitch_multiband(pano_ctx *ctx, pano_stitch_args *a, int res
             // table was emptied, the queued tail did nothing; lay it out on the host and queue
             // the tail again
             ctx->lay_prev_valid = false;
+            ctx->lay_prev_verified = false;
         }
         PANO_HIP(hipMemcpyAsync(a->regions_host, a->regions, (size_t)a->n * stride * sizeof(int32_t),
                                 hipMemcpyDeviceToHost, s));
@@ -435,8 +470,37 @@ extern "C" int pano_stitch_multiband(pano_ctx *ctx, pano_stitch_args *a, int res
         memcpy(ctx->lay_prev_sig, sig, sizeof(sig));
         ctx->lay_prev_used_need = a->used_need;
         ctx->lay_prev_valid = true;
+        ctx->lay_prev_verified = true;       // laid out on the host from this stitch's own regions
     }
     return rc;
+}
+
+// The summary the LAST trusted stitch's layout kernel wrote against the verified layout those
+// stitches were queued with: the same cameras give the same regions and the same layout, so a
+// difference means the caller's promise (args->trust_layout) did not hold - the mosaics of the
+// trusted stitches since the last verification are then void (PANO_EINVAL).  Waits for that
+// stitch's layout kernel (an event long past when mosaics are collected a stitch later).
+extern "C" int pano_stitch_verify(pano_ctx *ctx) {
+    PANO_REQUIRE(ctx, "pano_stitch_verify: null context");
+    if (!ctx->trusted_pending) return PANO_OK;
+    if (int rc = pano_ctx_enter(ctx)) return rc;
+    PANO_HIP(hipEventSynchronize(ctx->ev_regions));
+    ctx->trusted_pending = false;
+    const LayoutSummary sum = *ctx->lay_sum_host;
+    const pano_layout &v = ctx->lay_prev;
+    const bool same = sum.ok && sum.planes_floats == v.planes_floats &&
+                      sum.blurred_floats == v.blurred_floats && sum.scratch_floats == v.scratch_floats &&
+                      sum.n_records == v.n_records && sum.n_tiles == v.n_tiles &&
+                      sum.max_vw == v.max_vw && sum.max_vh == v.max_vh && sum.max_aw == v.max_aw &&
+                      sum.max_ah == v.max_ah && sum.missing == 0;
+    if (!same) {
+        ctx->lay_prev_valid = ctx->lay_prev_verified = false;
+        pano_set_error("pano_stitch_verify: a trusted stitch laid out %d records (ok %d, why %d) where "
+                       "the verified layout has %d: the cameras were not those of the verified stitch",
+                       sum.n_records, sum.ok, sum.why, v.n_records);
+        return PANO_EINVAL;
+    }
+    return PANO_OK;
 }
 
 extern "C" int pano_stitch_counts(const pano_ctx *ctx, int *device_layouts, int *fallbacks) {

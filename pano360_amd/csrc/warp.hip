@@ -171,7 +171,11 @@ __global__ __launch_bounds__(256) void warp_windows_kernel(
 #ifdef WARP_ABL_NOSTORE                         // timing experiment (results wrong): (almost) no stores
             if (v == 12345.0f)
 #endif
+#ifdef WARP_NT_STORE                            // A/B: the planes streamed past the caches
+            __builtin_nontemporal_store(v, (plane_ptr)(out[k] + o));
+#else
             *(plane_ptr)(out[k] + o) = v;
+#endif
         }
     }
 }

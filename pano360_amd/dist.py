@@ -26,6 +26,8 @@ kernels of stitch k + 1; buffers are allocated once and cycled.
 path, no collective): the secondary throughput figure of ``bench.py``.
 """
 
+import os
+
 from . import engine as _eng
 
 
@@ -294,6 +296,11 @@ class ShardedStitcher:
                 # first write must come behind those fills
                 import torch
                 stream.wait_stream(torch.cuda.current_stream(use.device))
+            # with the plan out of the memo a lane's stitch repeats its previous one's Plan
+            # object: the engine then queues it with the verified layout and does not wait
+            # (Engine.trust_layouts; checked when the mosaic is collected)
+            if cache_plan and exchange and hasattr(use, "trust_layouts"):
+                use.trust_layouts(os.environ.get("PANO_TRUST_LAYOUT", "1") != "0")
             self.lanes.append((use, stream, ex))
         self.exchange = self.lanes[0][2]
         self.count = 0
@@ -309,6 +316,8 @@ class ShardedStitcher:
 
     def _collect_oldest(self):
         use, stream, ex = self.lanes[self.order.pop(0)]
+        if getattr(use, "trust_layout", False):
+            use.verify_trusted()        # (that stitch's layout kernel finished a stitch ago)
         with self._on(stream):
             mosaic = ex.collect()
         if stream is not None:

@@ -405,6 +405,55 @@ def test_stitch_with_the_layout_on_the_device_equals_the_host_layout(eng, scene)
             assert a[0].shape == b[0].shape and torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
 
 
+@pytest.mark.parametrize("strip_case", [False, True])
+def test_trusted_stitches_equal_waiting_ones_and_a_broken_promise_is_caught(strip_case):
+    """Engine.trust_layouts: a stitch that repeats the previous one's Plan object (a PlanMemo hit)
+    is queued with that stitch's verified layout and the native call does not wait
+    (pano_stitch_args.trust_layout).  Every kernel still runs, so with NEW pixels in the frames
+    the mosaics equal those of an engine that waits, stitch for stitch; verify_trusted accepts
+    them.  A Plan of other cameras smuggled in under the kept signature is caught by
+    verify_trusted, and the engine then stitches correctly again."""
+    import torch
+    from pano360_amd import _lib, engine, synth
+    n, w, h = 8, 480, 270
+    rots, intrs = synth.make_cameras(n, w, h, sweep_deg=140.0, jitter=0.004, seed=1)
+    shapes = [(h, w)] * n
+    waiting, trusting = engine.Engine("cuda:0"), engine.Engine("cuda:0").trust_layouts(True)
+    W = engine.Plan(shapes, rots, intrs, True, 10 ** 9).shape[1]
+    strip = (W // 4 + 3, W // 2 + 1) if strip_case else None
+    c0, c1 = strip if strip else (0, W)
+    ids = list(range(n))
+    took = []
+    for k in range(5):
+        frames = waiting.upload_frames([synth.make_frame(100 * k + i, w, h, "A") for i in range(n)])
+        plan_w = waiting.cached_plan(shapes, rots, intrs, True, 10 ** 9)
+        want, _, want_valid, _ = waiting.multiband_fused(frames, plan_w, 5, frame_ids=ids, strip=strip)
+        plan_t = trusting.cached_plan(shapes, rots, intrs, True, 10 ** 9)
+        got, _, got_valid, patches = trusting.multiband_fused(frames, plan_t, 5, frame_ids=ids, strip=strip)
+        took.append(trusting._stitch_ws[next(iter(trusting._stitch_ws))]["args"].trust_layout)
+        torch.cuda.synchronize()
+        assert torch.equal(got[:, c0:c1], want[:, c0:c1]), k
+        assert torch.equal(got_valid[:, c0:c1], want_valid[:, c0:c1]), k
+        assert len(patches) > 0
+        trusting.verify_trusted()
+    # the first stitch laid out on the host, the second on the device and waited (it verifies the
+    # device layout), from the third on nobody waits
+    assert took[0] == 0 and took[-1] == 2 and took.count(2) >= 3, took
+    # a broken promise: other cameras under the kept signature
+    rots2, _ = synth.make_cameras(n, w, h, sweep_deg=100.0, jitter=0.004, seed=2)
+    other = trusting.upload_plan(engine.Plan(shapes, rots2, intrs, True, 10 ** 9))
+    if other.shape == plan_t.shape:
+        sig, _, kept = trusting._trusted
+        trusting._trusted = ((id(other),) + sig[1:], other, kept)
+        trusting.multiband_fused(frames, other, 5, frame_ids=ids, strip=strip)
+        with pytest.raises(_lib.PanoError, match="verified"):
+            trusting.verify_trusted()
+    # ... after which the engine lays out from scratch and is right again
+    got, _, got_valid, _ = trusting.multiband_fused(frames, plan_t, 5, frame_ids=ids, strip=strip)
+    torch.cuda.synchronize()
+    assert torch.equal(got[:, c0:c1], want[:, c0:c1]) and torch.equal(got_valid[:, c0:c1], want_valid[:, c0:c1])
+
+
 @pytest.mark.parametrize("case", ["sweep", "tilted", "dense", "crowd", "strip"])
 def test_ownership_with_regions_equals_the_two_calls(eng, case):
     """pano_ownership_regions (boxes and column marks out of the ownership kernel) against

@@ -27,7 +27,7 @@ for _ in range(3):
 torch.cuda.synchronize()
 if has:
     buf = (C.c_ulonglong * 16)()
-    lib.pano_debug_own_stamps(buf, 1)
+    lib.pano_debug_own_stamps(buf, 1)       # rows cleared: the LAST launch's samples are read below
 eng.timing(True)
 reps = 10
 for _ in range(reps):
@@ -42,6 +42,6 @@ if has:
     wgs = max(v[14], 1)
     names = ["camera list", "records + ranges -> LDS", "level-1 bounds", "survivors", "level-2 bounds",
              "quarter decisions", "evaluation list", "evaluation", "write-out + runs", "box merge"]
-    print("workgroups per launch %d, evaluated quarters per workgroup %.2f of 16" % (wgs / reps, v[15] / wgs))
+    print("sampled workgroups %d, evaluated quarters per workgroup %.2f" % (wgs, v[15] / wgs))
     print("cycles per workgroup (thread 0): " + " | ".join(f"{nm} {v[k] / wgs:.0f}" for k, nm in enumerate(names))
           + " | sum %.0f" % (v[:10].sum() / wgs))

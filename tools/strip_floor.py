@@ -28,6 +28,9 @@ for _ in range(max(1, int(os.environ.get("PANO_SETS_IN_FLIGHT", "1"))) - 1):
     _s = torch.cuda.Stream(eng.device)
     with torch.cuda.stream(_s):
         LANES.append((engine.Engine(eng.device), _s))
+if os.environ.get("PANO_PLAN_CACHED", "0") != "0" and os.environ.get("PANO_TRUST_LAYOUT", "1") != "0":
+    for _e, _ in LANES:      # as ShardedStitcher does with the plan out of the memo
+        _e.trust_layouts(True)
 COUNT = [0, False]
 pool = {}
 import gc  # noqa: E402
@@ -93,6 +96,7 @@ if JSON_OUT:
     # appended to: one visit runs this tool once per (lanes, plan) setting
     entry = dict(config=name, lanes=len(LANES), plan_cached=os.environ.get("PANO_PLAN_CACHED", "0") != "0",
                  stitch_async=os.environ.get("PANO_STITCH_ASYNC", "0"),
+                 trusted_layouts=bool(LANES[0][0].trust_layout),
                  what="rank r of world N emulated on ONE GPU: its strip's kernels only, no exchange; "
                       "wall ms per stitch of 20 stitches, slowest of ranks 0, N/2, N-1",
                  rows=ROWS)
