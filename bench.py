@@ -111,6 +111,38 @@ def pmc_traffic(name, workload=None):
     return None, None
 
 
+def scaling_projection(workload):
+    """The committed strip-floor emulation of this workload (tools/strip_floor.py: rank r of a
+    world-N strips run on ONE GPU, its strip's kernels only, no exchange): ms per stitch and rank at
+    world 1, 2, 4, 8 and the factors they project.  A projection from one GPU, not a measurement
+    of N; the newest round's file with worlds 1 and 8 wins."""
+    import glob
+    best = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", f"strip_floor_{workload}*.json"))):
+        try:
+            with open(path) as fid:
+                entries = json.load(fid)
+        except (OSError, ValueError):
+            continue
+        for entry in entries if isinstance(entries, list) else []:
+            rows = {int(r["world"]): float(r["ms_per_stitch"]) for r in entry.get("rows", [])}
+            if 1 in rows and 8 in rows:
+                key = (os.path.relpath(path, ROOT).split(os.sep)[1], -rows[8])
+                if best is None or key > best[0]:
+                    best = (key, path, entry, rows)
+    if best is None:
+        return None
+    _, path, entry, rows = best
+    return {"source": os.path.relpath(path, ROOT), "emulated_on_one_gpu": True,
+            "exchange": "excluded (uint8 strips gathered over xGMI behind the next stitch)",
+            "lanes_per_rank": entry.get("lanes"), "plan_from_memo": entry.get("plan_cached"),
+            "trusted_layouts": entry.get("trusted_layouts"),
+            "ms_per_stitch_and_rank": {str(w): rows[w] for w in sorted(rows)},
+            "factor_vs_world_1": {str(w): rows[1] / rows[w] for w in sorted(rows) if w > 1},
+            "note": "slowest of ranks 0, N/2, N-1, each emulated alone on one MI355X; unmeasured on "
+                    "multi-GPU hardware"}
+
+
 def measured_traffic(times, steps, workload):
     """HBM bytes per step over all timed kernels, from the committed PMC summary of this
     workload (per-launch bytes x launches per step); None when there is no summary."""
@@ -823,11 +855,13 @@ def main():
     def run_strips(exchange, cache_plan=True):
         """ONE panorama (image set 0) split into column strips, one per rank; the finished
         strips are composed on rank 0 (strong scaling)."""
-        # two stitches in flight per rank (PANO_STRIPS_IN_FLIGHT, default 2): consecutive
-        # stitches alternate between two engines, each with a stream and exchange buffers of its
-        # own - one stitch's kernels cover the other's host round trip and launch gaps, which at
-        # eight ranks are a fifth of a strip's time (tools/strip_floor.py: 0.48 -> 0.36 ms)
-        n_lanes = max(1, int(os.environ.get("PANO_STRIPS_IN_FLIGHT", "2")))
+        # three stitches in flight per rank (PANO_STRIPS_IN_FLIGHT): consecutive stitches go
+        # round three engines, each with a stream and exchange buffers of its own - a strip's
+        # kernels are a chain of a dozen dependent launches that under-fill the chip (the blur of a
+        # world-8 strip is ~150 workgroups), and with the plan out of the memo the host queues a
+        # stitch without waiting (trusted layouts), so the lanes' chains interleave on the GPU
+        # (tools/strip_floor.py, world 8: 0.42 / 0.32 / 0.29 ms with one / two / three lanes)
+        n_lanes = max(1, int(os.environ.get("PANO_STRIPS_IN_FLIGHT", "3")))
         IN_FLIGHT["strips"] = n_lanes
         engines = [eng] + [engine.Engine(eng.device) for _ in range(n_lanes - 1)]
         runner = pdist.ShardedStitcher(engines if n_lanes > 1 else eng, shapes, rots, intrs,
@@ -1058,6 +1092,9 @@ def main():
                                      eng.active_tile_pixels(), args.workload,
                                      eng.irregular_tile_share(n_levels)),
         }
+        projection = scaling_projection(args.workload)
+        if projection is not None:
+            out["scaling_projection"] = projection
         if world > 1:
             out["scaling_note"] = "unmeasured on multi-GPU hardware by the builder (1-GPU boxes)"
             # north_star's >= 6 x at 8 GPUs: config 5 (the 120 x 8K roofline run) is the config

@@ -156,13 +156,48 @@ _SIGNATURES = {
 EXPORTS = tuple(_SIGNATURES)
 
 
-def build(force=False):
-    """Compile the HIP sources in-tree (hipcc cross-compiles without a GPU)."""
+def sources_digest():
+    """sha256 over everything the library is compiled from (csrc/*.hip, *.h, the Makefile,
+    include/pano360.h), names included."""
+    import hashlib
     src = os.path.join(_HERE, "csrc")
-    cmd = ["make", "-C", src, "-s", "-j4"]
-    if force:
-        cmd.append("-B")
+    files = sorted(os.path.join(src, f) for f in os.listdir(src)
+                   if f.endswith((".hip", ".h")) or f == "Makefile")
+    files.append(os.path.join(os.path.dirname(_HERE), "include", "pano360.h"))
+    h = hashlib.sha256()
+    for path in files:
+        h.update(os.path.basename(path).encode() + b"\0")
+        with open(path, "rb") as fid:
+            h.update(fid.read())
+    return h.hexdigest()
+
+
+BUILD_RECORD = os.path.join(_HERE, "csrc", ".build_stamp")
+
+
+def build(force=False):
+    """Compile the HIP sources in-tree (hipcc cross-compiles without a GPU).  `make` alone trusts
+    file times, which a checkout or a copied tree does not keep: the objects are therefore
+    stamped with the digest of the sources they were built from, and a tree whose stamp is missing
+    or differs is rebuilt from scratch (`make -B`).  The stamp says what happened
+    (`csrc/.build_stamp`: digest, mode "full" | "incremental" | "up to date")."""
+    import json
+    src = os.path.join(_HERE, "csrc")
+    digest = sources_digest()
+    have = None
+    try:
+        with open(BUILD_RECORD) as fid:
+            have = json.load(fid).get("sources_sha256")
+    except (OSError, ValueError):
+        pass
+    full = force or have != digest or not os.path.exists(LIB_PATH)
+    before = os.path.getmtime(LIB_PATH) if os.path.exists(LIB_PATH) else None
+    cmd = ["make", "-C", src, "-s", "-j4"] + (["-B"] if full else [])
     subprocess.check_call(cmd)
+    after = os.path.getmtime(LIB_PATH)
+    mode = "full" if full else ("incremental" if after != before else "up to date")
+    with open(BUILD_RECORD, "w") as fid:
+        json.dump({"sources_sha256": digest, "mode": mode}, fid)
     return LIB_PATH
 
 

@@ -437,11 +437,6 @@ __global__ __launch_bounds__(256) void ownership_cameras_l1_kernel(
 //   store - with the region search (boxes, column marks) in the same pass.
 #define OW_T 64            // tile width = a wave's lanes
 #define OW_Q 16
-#ifndef OW_SUBS
-#define OW_SUBS 8           // sub-tiles (64 x 16) per workgroup: the tile is 64 x (16 OW_SUBS) pixels
-#endif
-#define OW_TH (OW_Q * OW_SUBS)
-#define OW_NQ (4 * OW_SUBS) // quarters per tile
 #define OW_CAMS 32          // camera records staged in LDS
 #define OW_QLIST 8          // survivors of a sub-tile that are bounded again per quarter
 #ifndef OW_ILP
@@ -494,405 +489,26 @@ extern "C" int pano_debug_own_stamps(unsigned long long *out, int reset) {
 #define OW_STAMP_AT(k) do { } while (0)
 #endif
 
-struct OwnShared {
-    CamList cl;
-    pano_camera cam[OW_CAMS];
-    double sn[OW_T], cs[OW_T], tn[OW_TH];        // the tile's columns / rows (clamped to the strip / H)
-    double rq[4][4];                            // per quarter column: s_lo, s_hi, c_lo, c_hi
-    double rall[4];                             // the same over all 64 columns
-    double rsub[OW_SUBS][2];                        // per sub-tile (16 rows): t_lo, t_hi
-    int low1[OW_SUBS], ncand[OW_SUBS];                    // level 1: largest lower bound (float bits), survivors
-    float hi2[OW_NQ][OW_QLIST];                    // level 2: upper bounds of the sub-tile's survivors
-    int low2[OW_NQ];
-    short qlist[OW_NQ][OW_QLIST];                  // level 2: survivors' list positions, in order
-    int qn[OW_NQ];                               // their number; -1: the sub-tile's list; -2: the whole list
-    int qfill[OW_NQ];                             // camera that owns the whole quarter, OW_NOBODY or OW_EVAL
-    int evalq[OW_NQ], n_eval;
-    short town[OW_TH][OW_T];                     // evaluated quarters: owner, OW_NOBODY or OW_UNOWNED
-    // behind it, sized by the host from NL = min(n, OWN_LIST) (own_shared_bytes):
-    //   int box[NL][4]      region search, by camera index
-    //   float hi[OW_SUBS][NL]  level 1: upper bounds by list position
-    //   short keep[OW_SUBS][NL] level 1: survivors' list positions, in order
-};
-static inline size_t own_shared_bytes(int n) {
-    const size_t nl = (size_t)(n < OWN_LIST ? n : OWN_LIST);
-    return sizeof(OwnShared) + nl * (16 + 4 * OW_SUBS + 2 * OW_SUBS) + 16;
-}
-
-// MODE: where a listed camera's record is read - 0 global memory, 1 LDS by list position,
-// 2 LDS by camera index (two pointers a compiler cannot tell apart go through the flat path, so
-// the tile's code exists once per mode)
-template <int MODE>
-__device__ __forceinline__ void own_tile(OwnShared &S, int (*__restrict__ s_box)[4],
-                                         float *__restrict__ s_hi, short *__restrict__ s_keep, int NL,
-                                         const pano_camera *__restrict__ cams, int n,
-                                         int H, int W, int bx0, int bx1, int by0, int by1,
-                                         int listed, int prune, int vt, int16_t *__restrict__ owner,
-                                         uint8_t *__restrict__ valid, int32_t *__restrict__ boxes,
-                                         int box_stride, uint8_t *__restrict__ marks,
-                                         unsigned long long ow_last) {
-    const int lane = threadIdx.x, wave = threadIdx.y, tid = wave * 64 + lane;
-    (void)ow_last;
-    // position in the list -> camera record / camera index (listed < 0: the list overflowed, a
-    // "position" is the camera's index and all n cameras are walked)
-    auto index_at = [&](int pos) -> int { return listed < 0 ? pos : S.cl.list[pos]; };
-    auto cam_at = [&](int pos) -> const pano_camera * {
-        if (MODE == 1) return &S.cam[pos];
-        if (MODE == 2) return &S.cam[index_at(pos)];
-        return cams + index_at(pos);
-    };
-
-    if (listed == 0) {
-        if (tid < OW_NQ) S.qfill[tid] = OW_NOBODY;
-        __syncthreads();
-    } else if (prune && listed > 0) {
-        // ---- level 1: every listed camera on every 64 x 16 sub-tile --------------------------------
-        for (int t = vt; t < OW_SUBS * listed; t += 256) {
-            const int sub = t / listed, k = t - sub * listed;
-            const int sy0 = by0 + OW_Q * sub, sy1 = min(sy0 + OW_Q, H);
-            float hi = -1.0f;
-            if (sy0 < H) {
-                const double rng[6] = {S.rall[0], S.rall[1], S.rsub[sub][0], S.rsub[sub][1],
-                                       S.rall[2], S.rall[3]};
-                const pano_camera *cam = cam_at(k);
-                const AlphaBound bnd = alpha_bound(cam, rng);
-                hi = bnd.hi;
-                // a lower bound beats the other cameras on EVERY pixel only if this camera is a
-                // candidate on every pixel: the tile lies inside its patch rectangle (see above)
-                if (bnd.lo > 0.0f && tile_inside(cam, bx0, bx1, sy0, sy1))
-                    atomicMax(&S.low1[sub], __float_as_int(bnd.lo));
-            }
-            s_hi[sub * NL + k] = hi;
-        }
-        __syncthreads();
-        OW_STAMP_AT(2);
-        for (int sub = wave; sub < OW_SUBS; sub += 4) {
-            // survivors of a sub-tile, order preserved: the first maximum wins
-            const float L = __int_as_float(S.low1[sub]);
-            int nc = 0;
-            for (int base = 0; base < listed; base += 64) {
-                const int k = base + lane;
-                const bool keep = k < listed && s_hi[sub * NL + k] >= L;
-                const unsigned long long bal = __ballot(keep);
-                if (keep) s_keep[sub * NL + nc + __popcll(bal & ((1ull << lane) - 1ull))] = (short)k;
-                nc += __popcll(bal);
-            }
-            if (lane == 0) S.ncand[sub] = nc;
-        }
-        __syncthreads();
-        OW_STAMP_AT(3);
-        // ---- level 2: a sub-tile's survivors on its four 16 x 16 quarters ---------------------------
-        int off[OW_SUBS + 1];
-        off[0] = 0;
-#pragma unroll
-        for (int sub = 0; sub < OW_SUBS; ++sub) {
-            const int nc = S.ncand[sub];
-            const bool again = by0 + OW_Q * sub < H && nc >= 1 && nc <= OW_QLIST;
-            off[sub + 1] = off[sub] + (again ? 4 * nc : 0);
-        }
-        for (int t = vt; t < off[OW_SUBS]; t += 256) {
-            int sub = 0;
-#pragma unroll
-            for (int u = 1; u < OW_SUBS; ++u) sub += t >= off[u] ? 1 : 0;
-            const int nc = S.ncand[sub], r = t - off[sub], q = r / nc, j = r - q * nc;
-            const int sy0 = by0 + OW_Q * sub, sy1 = min(sy0 + OW_Q, H);
-            const int qx0 = bx0 + OW_Q * q, qx1 = min(qx0 + OW_Q, bx1);
-            float hi = -1.0f;
-            if (qx0 < bx1) {
-                const double rng[6] = {S.rq[q][0], S.rq[q][1], S.rsub[sub][0], S.rsub[sub][1],
-                                       S.rq[q][2], S.rq[q][3]};
-                const pano_camera *cam = cam_at(s_keep[sub * NL + j]);
-                const AlphaBound bnd = alpha_bound(cam, rng);
-                hi = bnd.hi;
-                if (bnd.lo > 0.0f && tile_inside(cam, qx0, qx1, sy0, sy1))
-                    atomicMax(&S.low2[sub * 4 + q], __float_as_int(bnd.lo));
-            }
-            S.hi2[sub * 4 + q][j] = hi;
-        }
-        __syncthreads();
-        OW_STAMP_AT(4);
-        if (tid < OW_NQ) {
-            const int sub = tid >> 2, q = tid & 3, nc = S.ncand[sub];
-            const int sy0 = by0 + OW_Q * sub, sy1 = min(sy0 + OW_Q, H);
-            const int qx0 = bx0 + OW_Q * q, qx1 = min(qx0 + OW_Q, bx1);
-            int fill = OW_EVAL, qn = -1;
-            if (sy0 >= H || qx0 >= bx1 || nc == 0) {
-                fill = OW_NOBODY;                    // (outside the tile's part of the mosaic: never stored)
-            } else if (nc <= OW_QLIST) {
-                const float L = __int_as_float(S.low2[tid]);
-                qn = 0;
-                for (int j = 0; j < nc; ++j)
-                    if (S.hi2[tid][j] >= L) S.qlist[tid][qn++] = s_keep[sub * NL + j];
-                if (qn == 0) {
-                    fill = OW_NOBODY;                // every survivor is masked on the whole quarter
-                } else if (qn == 1 && L > 0.0f) {
-                    // one survivor with a positive lower bound: unmasked, above every other camera
-                    // and a candidate (the bound counted only inside its rectangle) on every pixel
-                    const int pos = S.qlist[tid][0];
-                    if (tile_inside(cam_at(pos), qx0, qx1, sy0, sy1)) fill = index_at(pos);
-                }
-            }
-            S.qn[tid] = qn;
-            S.qfill[tid] = fill;
-        }
-        __syncthreads();
-        OW_STAMP_AT(5);
-    }
-    // ---- the quarters that need their pixels evaluated ---------------------------------------------
-    if (wave == 0) {
-        static_assert(OW_NQ <= 64, "one ballot lists the quarters to evaluate");
-        const bool e = lane < OW_NQ && S.qfill[lane] == OW_EVAL && by0 + OW_Q * (lane >> 2) < H &&
-                       bx0 + OW_Q * (lane & 3) < bx1;
-        const unsigned long long bal = __ballot(e);
-        if (e) S.evalq[__popcll(bal & ((1ull << lane) - 1ull))] = lane;
-        if (lane == 0) S.n_eval = __popcll(bal);
-    }
-    __syncthreads();
-    OW_STAMP_AT(6);
-#ifdef OW_STAMP
-    if (OW_STAMP_ROW() >= 0) g_ow_stamps[OW_STAMP_ROW()][15] = (unsigned long long)S.n_eval;
-#endif
-    // an item = 16 columns x 4 OW_ILP rows of a quarter: lane -> column lane & 15, rows
-    // (lane >> 4) + 4 j of the item's rows, OW_ILP independent pixels in flight per lane
-    constexpr int PER_Q = 4 / OW_ILP;
-#ifdef OW_ABL_NOEVAL                                         // timing experiment (results wrong)
-    const int n_items = 0;
-#else
-    const int n_items = PER_Q * S.n_eval;
-#endif
-#pragma unroll 1
-    for (int item = wave; item < n_items; item += 4) {
-        const int qid = S.evalq[item / PER_Q], sub = qid >> 2, q = qid & 3;
-        const int col = OW_Q * q + (lane & (OW_Q - 1));
-        const int row0 = OW_Q * sub + 4 * OW_ILP * (item % PER_Q) + (lane >> 4);
-        const int xc = min(bx0 + col, bx1 - 1);
-        const double s = S.sn[col], c = S.cs[col];
-        double t[OW_ILP];
-        int y[OW_ILP], who[OW_ILP];
-        float best[OW_ILP];
-        bool any[OW_ILP];
-#pragma unroll
-        for (int j = 0; j < OW_ILP; ++j) {
-            t[j] = S.tn[row0 + 4 * j];
-            y[j] = min(by0 + row0 + 4 * j, by1 - 1);
-            best[j] = 0.0f;
-            who[j] = -1;
-            any[j] = false;
-        }
-        const int mode = S.qn[qid];
-        const int ncand = mode >= 0 ? mode : (mode == -1 ? S.ncand[sub] : (listed < 0 ? n : listed));
-        for (int k = 0; k < ncand; ++k) {
-            const int pos = __builtin_amdgcn_readfirstlane(
-                mode >= 0 ? (int)S.qlist[qid][k] : (mode == -1 ? (int)s_keep[sub * NL + k] : k));
-            const pano_camera *cam = cam_at(pos);
-            const int i = index_at(pos);
-            const int px = xc - cam->x0, sw = cam->sw, sh_ = cam->sh;
-            const bool in_x = (unsigned)px < (unsigned)cam->w;
-#pragma unroll
-            for (int j = 0; j < OW_ILP; ++j) {
-                const int py = y[j] - cam->y0;
-                float fx, fy;
-                // (masked pixels run the arithmetic too: the lanes of a wave share the instruction
-                // stream, and a branch per pixel would put the OW_ILP chains one behind the other)
-                const bool m = map_pixel(cam->proj, s, c, t[j], sw, sh_, fx, fy);
-                const bool ok = in_x && (unsigned)py < (unsigned)cam->h && !m;
-                const Taps tp = make_taps_unmasked(ok ? fx : 0.0f, ok ? fy : 0.0f, sw, sh_);
-                const float a = alpha_at(cam->hat_x, cam->hat_y, tp);
-                any[j] |= ok;
-                if (ok && a > best[j]) {         // strict: the first maximum keeps the pixel
-                    best[j] = a;
-                    who[j] = i;
-                }
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < OW_ILP; ++j)
-            S.town[row0 + 4 * j][col] = (short)(who[j] >= 0 ? who[j] : (any[j] ? OW_UNOWNED : OW_NOBODY));
-    }
-    __syncthreads();
-    OW_STAMP_AT(7);
-    // ---- the tile leaves in whole rows; boxes and column marks in the same pass ------------------------
-    const int x = bx0 + lane;
-    const bool in_strip = x < bx1;
-    int run_o = -1, run_y0 = 0, run_y1 = 0;
-    auto flush = [&]() {
-        if (run_o < 0 || !in_strip) return;
-        marks[(size_t)run_o * W + x] = 1;
-        if (n <= OWN_LIST) {
-            int *b = s_box[run_o];
-            atomicMin(&b[0], run_y0);
-            atomicMax(&b[1], run_y1);
-            atomicMin(&b[2], x);
-            atomicMax(&b[3], x);
-        } else {                             // more cameras than the LDS boxes hold: straight to memory
-            box_merge(boxes + (size_t)box_stride * run_o, run_y0, run_y1, x, x);
-        }
-    };
-    const int rows = by1 - by0;
-    // four of the wave's rows at a time: their LDS reads leave together (one row per trip was a
-    // chain of two dependent LDS reads and two stores, 440 cycles a row, a fifth of the
-    // workgroup's life: profiles/r05/own_stamps_*.txt)
-#pragma unroll 1
-    for (int row0 = wave; row0 < rows; row0 += 16) {
-        int who[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int row = min(row0 + 4 * u, OW_TH - 1);
-            who[u] = S.qfill[(row >> 4) * 4 + (lane >> 4)];
-#ifdef OW_ABL_NOEVAL
-            if (who[u] == OW_EVAL) who[u] = OW_NOBODY;      // (the tile was not filled in)
-#else
-            if (who[u] == OW_EVAL) who[u] = S.town[row][lane];
-#endif
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int row = row0 + 4 * u;
-            if (row >= rows) break;
-            const bool any = who[u] >= 0 || who[u] == OW_UNOWNED;
-            const int w = who[u] < 0 ? -1 : who[u];
-            const int y = by0 + row;
-            if (in_strip) {
-                owner[(size_t)y * W + x] = (int16_t)w;
-                valid[(size_t)y * W + x] = any ? 1 : 0;
-            }
-            if (marks) {
-                if (w != run_o) {
-                    flush();
-                    run_o = w;
-                    run_y0 = y;
-                }
-                run_y1 = y;
-            }
-        }
-    }
-    OW_STAMP_AT(8);
-    if (!marks) return;
-    flush();
-    __syncthreads();
-    if (n <= OWN_LIST && tid < n) {
-        const int *b = s_box[tid];
-        if (b[1] >= b[0]) box_merge(boxes + (size_t)box_stride * tid, b[0], b[1], b[2], b[3]);
-    }
-    OW_STAMP_AT(9);
-}
-
-__global__ __launch_bounds__(256) void ownership_cameras_kernel(
-    const pano_camera *__restrict__ cams, int n, int H, int W, int xs0, int xs1,
-    const double *__restrict__ sin_t, const double *__restrict__ cos_t,
-    const double *__restrict__ tan_p, int16_t *__restrict__ owner,
-    uint8_t *__restrict__ valid, int prune, int32_t *__restrict__ boxes, int box_stride,
-    uint8_t *__restrict__ marks) {
-    extern __shared__ __align__(16) unsigned char own_smem[];
-    OwnShared &S = *(OwnShared *)own_smem;
-    const int NL = min(n, OWN_LIST);
-    int (*s_box)[4] = (int (*)[4])(own_smem + ((sizeof(OwnShared) + 15) & ~(size_t)15));
-    float *s_hi = (float *)(s_box + NL);
-    short *s_keep = (short *)(s_hi + OW_SUBS * NL);
-    const int lane = threadIdx.x, wave = threadIdx.y, tid = wave * 64 + lane;
-    const int bx0 = xs0 + blockIdx.x * OW_T, by0 = blockIdx.y * OW_TH;
-    const int bx1 = min(bx0 + OW_T, xs1), by1 = min(by0 + OW_TH, H);
-    // (a workgroup's wave w sits on SIMD w: the few threads of the bound passes rotate with the
-    // workgroup so that they do not all queue on SIMD 0)
-    const int vt = (tid + 64 * (int)((blockIdx.x + blockIdx.y) & 3)) & 255;
-    unsigned long long ow_last = 0;
-#ifdef OW_STAMP
-    ow_last = __builtin_readcyclecounter();
-    if (OW_STAMP_ROW() >= 0) g_ow_stamps[OW_STAMP_ROW()][14] = 1ull;
-#endif
-    if (marks && tid < NL) {
-        int *b = s_box[tid];
-        b[0] = b[2] = 0x7fffffff;
-        b[1] = b[3] = -1;
-    }
-    // Everything the tile reads from memory leaves now, together with the rectangles the list is
-    // built from: the tile's trigonometry (wave 0 the columns, wave 1 the rows) and, when there
-    // are few cameras, all their records (pano_camera = 30 dwords; else the listed ones follow)
-    constexpr int DW = (int)(sizeof(pano_camera) / 4);
-    const bool all_cams = n <= OW_CAMS;
-    uint32_t rec_dw[(OW_CAMS * DW + 255) / 256];
-    if (all_cams) {
-#pragma unroll
-        for (int r = 0; r < (OW_CAMS * DW + 255) / 256; ++r) {
-            const int d = tid + 256 * r;
-            rec_dw[r] = d < n * DW ? ((const uint32_t *)cams)[d] : 0u;
-        }
-    }
-    double tv = 0.0, tw = 0.0;
-    if (wave == 0) {
-        const int xc = min(bx0 + lane, bx1 - 1);
-        tv = table_f64(sin_t, xc);
-        tw = table_f64(cos_t, xc);
-    }
-    double trow[OW_TH / 64 > 0 ? OW_TH / 64 : 1];
-    if (wave == 1) {
-#pragma unroll
-        for (int r = 0; r < OW_TH / 64; ++r) trow[r] = table_f64(tan_p, min(by0 + 64 * r + lane, by1 - 1));
-    }
-    const int listed = build_camera_list(S.cl, cams, n, bx0, bx1, by0, by1);
-    OW_STAMP_AT(0);
-    const int mode = all_cams ? 2 : (listed >= 0 && listed <= OW_CAMS ? 1 : 0);
-    uint32_t *dst = (uint32_t *)S.cam;
-    if (all_cams) {
-#pragma unroll
-        for (int r = 0; r < (OW_CAMS * DW + 255) / 256; ++r) {
-            const int d = tid + 256 * r;
-            if (d < n * DW) dst[d] = rec_dw[r];
-        }
-    } else if (mode == 1) {
-        for (int d = tid; d < listed * DW; d += 256) {
-            const int rec = d / DW, w = d - rec * DW;
-            dst[d] = ((const uint32_t *)(cams + S.cl.list[rec]))[w];
-        }
-    }
-    if (wave == 0) {
-        S.sn[lane] = tv;
-        S.cs[lane] = tw;
-        double lo_s = tv, hi_s = tv, lo_c = tw, hi_c = tw;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            lo_s = fmin(lo_s, __shfl_xor(lo_s, off, 64));
-            hi_s = fmax(hi_s, __shfl_xor(hi_s, off, 64));
-            lo_c = fmin(lo_c, __shfl_xor(lo_c, off, 64));
-            hi_c = fmax(hi_c, __shfl_xor(hi_c, off, 64));
-            if (off == OW_Q / 2 && (lane & (OW_Q - 1)) == 0) {
-                double *r = S.rq[lane / OW_Q];
-                r[0] = lo_s, r[1] = hi_s, r[2] = lo_c, r[3] = hi_c;
-            }
-        }
-        if (lane == 0) S.rall[0] = lo_s, S.rall[1] = hi_s, S.rall[2] = lo_c, S.rall[3] = hi_c;
-    } else if (wave == 1) {
-        static_assert(OW_TH % 64 == 0, "whole waves of rows");
-#pragma unroll
-        for (int r = 0; r < OW_TH / 64; ++r) {
-            S.tn[64 * r + lane] = trow[r];
-            double lo_t = trow[r], hi_t = trow[r];
-#pragma unroll
-            for (int off = 1; off < OW_Q; off <<= 1) {
-                lo_t = fmin(lo_t, __shfl_xor(lo_t, off, 64));
-                hi_t = fmax(hi_t, __shfl_xor(hi_t, off, 64));
-            }
-            if ((lane & (OW_Q - 1)) == 0)
-                S.rsub[4 * r + lane / OW_Q][0] = lo_t, S.rsub[4 * r + lane / OW_Q][1] = hi_t;
-        }
-    } else if (wave == 2 && lane < OW_NQ) {
-        S.low2[lane] = 0;
-        S.qn[lane] = -2;
-        S.qfill[lane] = OW_EVAL;
-        if (lane < OW_SUBS) S.low1[lane] = 0, S.ncand[lane] = 0;
-    }
-    __syncthreads();
-    OW_STAMP_AT(1);
-#define OW_CALL(M)                                                                                  \
-    own_tile<M>(S, s_box, s_hi, s_keep, NL, cams, n, H, W, bx0, bx1, by0, by1, listed, prune, vt,  \
-                owner, valid, boxes, box_stride, marks, ow_last)
-    if (mode == 2)
-        OW_CALL(2);
-    else if (mode == 1)
-        OW_CALL(1);
-    else
-        OW_CALL(0);
-#undef OW_CALL
+// Two tile heights: 64 x 128 (eight sub-tiles: one camera list, one staging, one pair of bound
+// passes per workgroup - 9 % faster than 64 x 64 on config 3's 4 000 workgroups) and 64 x 64 for
+// small grids (a world-8 strip is 580 workgroups of the tall kind: ONE round on 256 CUs, so the
+// kernel lasts as long as its slowest workgroup's chain, and half the tile halves that chain).
+#define OW_SUBS 8
+#define OW_FN(name) name
+#include "own_tile.inc"
+#undef OW_SUBS
+#undef OW_FN
+#define OW_SUBS 4
+#define OW_FN(name) name##_small
+#include "own_tile.inc"
+#undef OW_SUBS
+#undef OW_FN
+#define OW_TH_TALL (OW_Q * 8)
+#define OW_TH_SMALL (OW_Q * 4)
+// workgroups of the tall kind below which the small tiles are launched (PANO_OWN_SMALL_BELOW: A/B)
+static int own_small_below() {
+    static const int v = getenv("PANO_OWN_SMALL_BELOW") ? atoi(getenv("PANO_OWN_SMALL_BELOW")) : 1536;
+    return v;
 }
 
 // ---- linear_blend / no_blend straight from the frames (fused path) --------------
@@ -1507,10 +1123,14 @@ extern "C" int pano_ownership_cameras(pano_ctx *ctx, const pano_camera *cams, in
     // bit 1 = the round-4 kernel with one level of bounds (A/B, and a second implementation the
     // exactness tests compare with)
     const int prune = ctx->opt[PANO_OPT_OWN_PRUNE];
-    dim3 block(64, 4), grid(ceil_div(xs1 - xs0, 64), ceil_div(H, (prune & 2) ? OWN_TILE_ROWS : OW_TH));
+    const bool small = ceil_div(xs1 - xs0, 64) * ceil_div(H, OW_TH_TALL) < own_small_below();
+    dim3 block(64, 4), grid(ceil_div(xs1 - xs0, 64),
+                            ceil_div(H, (prune & 2) ? OWN_TILE_ROWS : (small ? OW_TH_SMALL : OW_TH_TALL)));
     PANO_TIMED(PK_OWNERSHIP_CAMS, (hipStream_t)stream,
-               hipLaunchKernelGGL((prune & 2) ? ownership_cameras_l1_kernel : ownership_cameras_kernel,
-                                  grid, block, (prune & 2) ? 0 : own_shared_bytes(n),
+               hipLaunchKernelGGL((prune & 2) ? ownership_cameras_l1_kernel
+                                              : (small ? ownership_cameras_kernel_small : ownership_cameras_kernel),
+                                  grid, block,
+                                  (prune & 2) ? 0 : (small ? own_shared_bytes_small(n) : own_shared_bytes(n)),
                                   (hipStream_t)stream, cams, n, H, W, xs0, xs1, sin_t, cos_t,
                                   tan_p, owner, valid, prune & 1, (int32_t *)nullptr, 0,
                                   (uint8_t *)nullptr));
@@ -1683,10 +1303,15 @@ extern "C" int pano_ownership_regions(pano_ctx *ctx, const pano_camera *cams, in
     if (int rc = launch_init_regions(s, regions, n, stride, marks, W)) return rc;
     if (xs0 == xs1) return PANO_OK;
     const int prune = ctx->opt[PANO_OPT_OWN_PRUNE];
-    dim3 block(64, 4), grid(ceil_div(xs1 - xs0, 64), ceil_div(H, (prune & 2) ? OWN_TILE_ROWS : OW_TH));
+    const bool small = ceil_div(xs1 - xs0, 64) * ceil_div(H, OW_TH_TALL) < own_small_below();
+    dim3 block(64, 4), grid(ceil_div(xs1 - xs0, 64),
+                            ceil_div(H, (prune & 2) ? OWN_TILE_ROWS : (small ? OW_TH_SMALL : OW_TH_TALL)));
     PANO_TIMED(PK_OWNERSHIP_CAMS, s,
-               hipLaunchKernelGGL((prune & 2) ? ownership_cameras_l1_kernel : ownership_cameras_kernel,
-                                  grid, block, (prune & 2) ? 0 : own_shared_bytes(n), s, cams, n, H, W, xs0,
+               hipLaunchKernelGGL((prune & 2) ? ownership_cameras_l1_kernel
+                                              : (small ? ownership_cameras_kernel_small : ownership_cameras_kernel),
+                                  grid, block,
+                                  (prune & 2) ? 0 : (small ? own_shared_bytes_small(n) : own_shared_bytes(n)),
+                                  s, cams, n, H, W, xs0,
                                   xs1, sin_t, cos_t, tan_p, owner, valid, prune & 1, regions, stride,
                                   marks));
     PANO_LAUNCH_CHECK("ownership_cameras_kernel");

@@ -43,6 +43,13 @@
 
 #include "common.h"
 
+// The hand-written hazard handling below (s_nop counts behind v_mfma_f32_32x32x16_f16 results
+// read by inline-asm vector instructions, vmcnt values that assume loads and stores retire in
+// order, SDWA / v_fma_mix encodings) is gfx950's: another target must not compile this silently.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "blur_mfma.hip is written for gfx950 (MI355X): its inline-asm wait states are that chip's"
+#endif
+
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 typedef short shortx4 __attribute__((ext_vector_type(4)));
@@ -1127,8 +1134,9 @@ __device__ __forceinline__ void ml_body(const pano_patch &p, const int ch, const
 //     plane for lanes outside A's columns and for tiles nobody wants; only a tile cut by A's
 //     top or bottom row takes the masked path, in the prologue;
 //   * the column pass computes every tile within reach, wanted or not (85 % are; an unwanted
-//     tile's accumulator is never stored); a wave that wants nothing of a band skips both
-//     passes as a whole;
+//     tile's accumulator is never stored); a wave that wants nothing of a band runs both
+//     passes all the same (skipping them, -DMS_SKIP_IDLE, put a branch in front of the block
+//     and measured slower; the switch is kept for A/B only);
 //   * f32 -> (hi, lo) float16 is two instructions per value (v_fma_mixlo/hi_f16: hi =
 //     f16(v s), lo = f16(fma(v, s, -hi)), the same bits as ml_body's (v s) - hi: the
 //     difference is exact in float32), written into packed halves directly;
@@ -1631,11 +1639,17 @@ __device__ __forceinline__ void ms_body(const pano_patch &p, const int ch, const
                             __float_as_uint(sc[q]), q < 16 ? dst : dst_b, MS_STORE_AT,
                             (((q & 15) & 3) + 8 * ((q & 15) >> 2)) * rowstep, MS_STORE_AUX);
             };
+            // how many of the tile's stores fill() has issued in the gaps in front of the commit:
+            // commit_wait's vmcnt leaves exactly those in flight behind the band's loads, so the
+            // count must follow store_gap (the same expression) and the stores must be the
+            // raw_buffer_store_b32 of fill(), one VMEM instruction each
             constexpr int stores_before_commit = [] {
                 int n = 0;
                 for (int q = 0; q < NSTORE; ++q) n += ((2 * q + 1) * G) / (2 * NSTORE) < G_COMMIT ? 1 : 0;
                 return n;
             }();
+            static_assert(stores_before_commit >= 0 && stores_before_commit <= NSTORE,
+                          "the commit's vmcnt counts the stores fill() issued before it");
             if constexpr (!WORK) {
 #pragma unroll
                 for (int g = 0; g < G; ++g) fill(g);
@@ -2293,7 +2307,8 @@ __global__ __launch_bounds__(256) void mb_sort_kernel(const int2 *__restrict__ i
                                                       int *__restrict__ counter, int cap, int scap,
                                                       int wgs_per_item, int slots,
                                                       int2 *__restrict__ sorted,
-                                                      const pano_patch *__restrict__ table, int cm) {
+                                                      const pano_patch *__restrict__ table, int cm,
+                                                      int force_t) {
     __shared__ int s_hist[MB_SORT_BINS];
     __shared__ int s_lmax, s_lsum, s_nirr, s_total;
     const int tid = threadIdx.x;
@@ -2306,14 +2321,25 @@ __global__ __launch_bounds__(256) void mb_sort_kernel(const int2 *__restrict__ i
     // T: the segment length (bands) items are cut to, 0 = nothing is cut.  Items differ in length
     // by a factor of six (13 - 82 bands on config 3): one segment COUNT for all of them (rounds
     // 2 - 4) cut the short items into segments that were mostly lead while the long ones still set
-    // the launch's length; one segment LENGTH gives a long item many segments and a short one none
-    // (a world-8 strip of config 3: the blur 0.138 -> see profiles/r05/notes.md).
+    // the launch's length; one segment LENGTH gives a long item many segments and a short one none.
+    // Which length: the workgroups are dispatched longest first onto `slots` one-per-CU slots, so
+    // a launch lasts as long as that list schedule, and a lower bound (the longest workgroup, the
+    // work per slot) ranks the candidates wrongly exactly where it matters - a few more workgroups
+    // than slots make a second round (a world-8 strip of config 3, PANO_BLUR_SEG_T forced: 29 bands,
+    // the bound's choice, 0.135 ms; 20 or 48 bands 0.100; profiles/r05/blur_seg_t_strip8.txt).
+    // Every candidate therefore gets the histogram of its workgroups' lengths and an estimate of
+    // the schedule from its order statistics l_1 >= l_2 >= ...: one round lasts l_1; two rounds
+    // pair the k-th workgroup of the second with the slot that frees k-th (the shortest of the
+    // first round first): max(l_1, l_slots + l_slots+1, l_2 slots + 1 - W + l_W); more rounds:
+    // the work per slot plus half the shortest workgroup.
     int T = 0, S_irr = 1;
-    constexpr int NCAND = 12;
-    __shared__ int s_segs[NCAND];
+    constexpr int NCAND = 13, HL = 128;                          // candidate 0 = nothing cut
+    __shared__ int s_segs[NCAND], s_est[NCAND];
+    __shared__ unsigned short s_len[NCAND][HL];                  // workgroup lengths (bands + lead), in segments
     if (slots > 0 && n > 0) {                                    // uniform
         if (tid == 0) s_lmax = s_lsum = s_nirr = 0;
         if (tid < NCAND) s_segs[tid] = 0;
+        for (int i = tid; i < NCAND * HL; i += 256) (&s_len[0][0])[i] = 0;
         __syncthreads();
         int lmax = 0, lsum = 0, nirr = 0;
         for (int i = tid; i < n; i += 256) {
@@ -2327,30 +2353,73 @@ __global__ __launch_bounds__(256) void mb_sort_kernel(const int2 *__restrict__ i
         atomicAdd(&s_nirr, nirr);
         __syncthreads();
         const int Lmax = s_lmax, Lsum = s_lsum;
-        // candidate lengths: Lmax / 2 ... Lmax / 8 and a few absolute ones
+        // candidate lengths: none, Lmax / 2 ... Lmax / 8 and a few absolute ones
         auto cand = [&](const int c) {
-            const int t = c < 7 ? (Lmax + c + 1) / (c + 2) : 8 * (c - 5);        // .../2 ... /8, 16 ... 48
+            if (c == 0) return 1 << 20;
+            const int t = c < 8 ? (Lmax + c) / (c + 1) : 8 * (c - 6);            // .../2 ... /8, 16 ... 48
             return max(t, 8);
         };
         for (int c = 0; c < NCAND; ++c) {
             const int t = cand(c);
             int segs = 0;
-            for (int i = tid; i < n; i += 256) segs += min(MB_SEG_MAX, (items[i].y + t - 1) / t);
+            for (int i = tid; i < n; i += 256) {
+                const int len = items[i].y, ns = min(MB_SEG_MAX, (len + t - 1) / t);
+                const int wl = min((len + ns - 1) / ns + MB_SEG_LEAD, HL - 1);
+                segs += ns;
+                atomicAdd((unsigned int *)&s_len[c][wl & ~1], (unsigned int)ns << (16 * (wl & 1)));
+            }
             if (segs) atomicAdd(&s_segs[c], segs);
         }
         __syncthreads();
-        const int base = max(Lmax + MB_SEG_LEAD,
-                             (int)(((long long)Lsum + (long long)n * MB_SEG_LEAD) * wgs_per_item / slots));
+        if (tid < NCAND) {
+            const int c = tid, t = cand(c), segs = s_segs[c];
+            int est = 0x7fffffff;
+            if (c == 0 || (t < Lmax && segs > n && segs <= scap && segs <= n + MB_SEG_SLOTS)) {
+                const int W = segs * wgs_per_item;
+                // order statistics of the workgroup lengths, longest first: l(k), k = 1 .. W
+                const int want[4] = {1, slots, slots + 1, 2 * slots + 1 - W};
+                int got[4] = {0, 0, 0, 0}, lmin = 0, seen = 0;
+                for (int wl = HL - 1; wl >= 0; --wl) {
+                    const int cnt = s_len[c][wl] * wgs_per_item;
+                    if (!cnt) continue;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        if (want[q] > seen && want[q] <= seen + cnt) got[q] = wl;
+                    seen += cnt;
+                    lmin = wl;
+                }
+                const int share = (int)(((long long)Lsum + (long long)segs * MB_SEG_LEAD) *
+                                        wgs_per_item / slots);
+                if (W <= slots)
+                    est = got[0];
+                else if (W <= 2 * slots)
+                    est = max(max(got[0], got[1] + got[2]), max(got[3] + lmin, share));
+                else
+                    est = max(got[0], share + lmin / 2);
+            }
+            s_est[c] = est;
+        }
+        __syncthreads();
+        const int base = s_est[0];
         int best = base;
-        for (int c = 0; c < NCAND; ++c) {
-            const int t = cand(c), segs = s_segs[c];
-            if (t >= Lmax || segs <= n || segs > scap || segs > n + MB_SEG_SLOTS) continue;
-            const int longest = max(t, (Lmax + MB_SEG_MAX - 1) / MB_SEG_MAX) + MB_SEG_LEAD;
-            const int share = (int)(((long long)Lsum + (long long)segs * MB_SEG_LEAD) * wgs_per_item / slots);
-            const int m = max(longest, share);
-            if (m < best && m * 100 <= base * 85) {
+        for (int c = 1; c < NCAND; ++c) {
+            const int m = s_est[c];
+            if (m < best && (long long)m * 100 <= (long long)base * 85) {
                 best = m;
-                T = t;
+                T = cand(c);
+            }
+        }
+        if (force_t) {                                          // (PANO_BLUR_SEG_T: A/B timing)
+            T = 0;
+            if (force_t >= 4) {
+                __syncthreads();
+                if (tid == 0) s_segs[0] = 0;
+                __syncthreads();
+                int segs = 0;
+                for (int i = tid; i < n; i += 256) segs += min(MB_SEG_MAX, (items[i].y + force_t - 1) / force_t);
+                if (segs) atomicAdd(&s_segs[0], segs);
+                __syncthreads();
+                if (s_segs[0] <= scap && s_segs[0] <= n + MB_SEG_SLOTS) T = force_t;   // the list holds them
             }
         }
         // the irregular items' own segment count: as many as the list's spare slots allow
@@ -2515,12 +2584,15 @@ int pano_prepare_blur_mfma(pano_ctx *ctx, const pano_patch *table, int n, int ma
     hipLaunchKernelGGL(mb_items_kernel, dim3(n), dim3(256), 0, stream, table, flags, ctx->item_buf,
                        ctx->item_counter, cap);
     PANO_LAUNCH_CHECK("mb_items_kernel");
+    // (PANO_BLUR_SEG_T = segment length in bands, -1 = no cut: A/B timing of the model's choice)
+    static const int force_t = getenv("PANO_BLUR_SEG_T") ? atoi(getenv("PANO_BLUR_SEG_T")) : 0;
     // 4 channels (x level groups) workgroups per item
     hipLaunchKernelGGL(mb_sort_kernel, dim3(1), dim3(256), 0, stream, ctx->item_buf,
                        ctx->item_counter, cap, mb_sorted_slots(cap), 4,
                        ctx->opt[PANO_OPT_BLUR_SEGMENTS] ? 256 : 0,
                        ctx->item_buf + ctx->item_cap, table,
-                       ctx->opt[PANO_OPT_BLUR_SEGMENTS] ? (ctx->blur_cm > 0 ? ctx->blur_cm : 3) : 0);
+                       ctx->opt[PANO_OPT_BLUR_SEGMENTS] ? (ctx->blur_cm > 0 ? ctx->blur_cm : 3) : 0,
+                       force_t);
     PANO_LAUNCH_CHECK("mb_sort_kernel");
     ctx->prepared_table = table;
     ctx->prepared_n = n;

@@ -957,13 +957,11 @@ class Engine:
         return total
 
     def irregular_tile_share(self, n_levels):
-        """Share of the last blur's active tiles that a kernel other than the lean one blurs.
-        None since ``ms_body`` has its EDGE form (csrc/blur_mfma.hip, ``mb_item_regular``: the
-        items with reflected columns, unaligned windows or low patches were 2 - 15 % of the
-        tiles and ran in ``blur_irregular_kernel``); bench.py still splits the blur's
-        algorithmic bytes by it, so a build with ``-DMB_STREAM_EDGE=0`` reports through
-        ``PANO_IRREGULAR_SHARE``."""
-        return float(os.environ.get("PANO_IRREGULAR_SHARE", "0"))
+        """Share of the last blur's active tiles that a kernel other than the lean one blurs: none
+        since ``ms_body`` has its EDGE form (csrc/blur_mfma.hip, ``mb_item_regular``); bench.py
+        splits the blur's algorithmic bytes by it.  (A ``-DMB_STREAM_EDGE=0`` A/B build runs
+        ``blur_irregular_kernel`` beside the lean one; its share is then the bench's to state.)"""
+        return 0.0
 
     def compose_interior_async(self, owner, shape, strip, interior, cams, plan, luts,
                                want_float=False, mosaic_out=None):

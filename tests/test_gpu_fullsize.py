@@ -556,6 +556,28 @@ def test_cfg3_full_size_strips_equal_whole(eng, world):
             finally:
                 eng.set_option(_lib.OPT_BLUR_SEGMENTS, 1)
             assert torch.equal(plain[:, c0:c1], whole[:, c0:c1]), (world, rank)
+    if world == 8:
+        # trusted layouts at full size (two streams inside the stitch, the bench's plan-cached
+        # figures and the strips' default): the whole mosaic and a strip, three stitches each
+        # through an engine that does not wait, with other pixels in the last one
+        fast = engine.Engine(eng.device).trust_layouts(True)
+        st = pdist.ShardedStitcher(eng, shapes, rots, intrs, levels, 4, world, exchange=None)
+        other = [base[(i + 1) % 4] for i in range(n)]
+        for k in range(3):
+            plan_t = fast.cached_plan(shapes, rots, intrs, True, 10 ** 9)
+            use = other if k == 2 else frames
+            got = fast.multiband_fused(use, plan_t, levels)[0]
+            want = eng.stitch(use, plan, "multiband", levels)[0] if k == 2 else whole
+            assert torch.equal(got, want), k
+        fast.verify_trusted()
+        c0, c1 = st.strip
+        for k in range(3):
+            plan_s = fast.cached_plan(shapes, rots, intrs, True, 10 ** 9, st.table_cols)
+            got = fast.multiband_fused([frames[i] for i in st.my_frames], plan_s, levels,
+                                       frame_ids=st.my_frames, strip=st.strip)[0]
+            assert torch.equal(got[:, c0:c1], whole[:, c0:c1]), k
+        fast.verify_trusted()
+        assert fast.stitch_counts()[0] >= 4 and fast.stitch_counts()[1] == 0
 
 
 def test_cfg4_keypoints_of_a_4k_frame_against_a_windowed_oracle(eng):
