@@ -866,7 +866,8 @@ def main():
         engines = [eng] + [engine.Engine(eng.device) for _ in range(n_lanes - 1)]
         runner = pdist.ShardedStitcher(engines if n_lanes > 1 else eng, shapes, rots, intrs,
                                        n_levels, rank, world, exchange=exchange,
-                                       depth=max(2, n_lanes), cache_plan=cache_plan)
+                                       depth=max(2, n_lanes), cache_plan=cache_plan,
+                                       lane_groups=os.environ.get("PANO_LANE_GROUPS", "shared"))
         frames = upload(0, runner.my_frames)
         serial = dict(on=False)
 

@@ -490,9 +490,10 @@ extern "C" int pano_debug_own_stamps(unsigned long long *out, int reset) {
 #endif
 
 // Two tile heights: 64 x 128 (eight sub-tiles: one camera list, one staging, one pair of bound
-// passes per workgroup - 9 % faster than 64 x 64 on config 3's 4 000 workgroups) and 64 x 64 for
-// small grids (a world-8 strip is 580 workgroups of the tall kind: ONE round on 256 CUs, so the
-// kernel lasts as long as its slowest workgroup's chain, and half the tile halves that chain).
+// passes per workgroup - 9 % faster than 64 x 64 on config 3's 4 000 workgroups), the default on
+// every grid, and 64 x 64, kept as an A/B instance: the idea that a small grid (a world-8 strip is
+// 580 tall workgroups, ONE round on 256 CUs) would gain from shorter workgroups did not hold -
+// strips 0.066 - 0.068 ms either way, config 2 0.058 against 0.065 (profiles/r05/own_small_*.txt).
 #define OW_SUBS 8
 #define OW_FN(name) name
 #include "own_tile.inc"
@@ -507,7 +508,7 @@ extern "C" int pano_debug_own_stamps(unsigned long long *out, int reset) {
 #define OW_TH_SMALL (OW_Q * 4)
 // workgroups of the tall kind below which the small tiles are launched (PANO_OWN_SMALL_BELOW: A/B)
 static int own_small_below() {
-    static const int v = getenv("PANO_OWN_SMALL_BELOW") ? atoi(getenv("PANO_OWN_SMALL_BELOW")) : 1536;
+    static const int v = getenv("PANO_OWN_SMALL_BELOW") ? atoi(getenv("PANO_OWN_SMALL_BELOW")) : 0;
     return v;
 }
 

@@ -2334,15 +2334,35 @@ __global__ __launch_bounds__(256) void mb_sort_kernel(const int2 *__restrict__ i
     // the work per slot plus half the shortest workgroup.
     int T = 0, S_irr = 1;
     constexpr int NCAND = 13, HL = 128;                          // candidate 0 = nothing cut
+    constexpr int MINE = 4;                                      // items a thread keeps in registers
     __shared__ int s_segs[NCAND], s_est[NCAND];
-    __shared__ unsigned short s_len[NCAND][HL];                  // workgroup lengths (bands + lead), in segments
+    __shared__ __align__(16) unsigned short s_len[NCAND][HL];    // workgroup lengths (bands + lead), in segments
+    // (with three rounds of workgroups and more nothing is gained by cutting: the launch is bound by
+    // its work per slot, which segments only add to - and the estimate below would cost a large
+    // launch's sort kernel tens of microseconds for nothing)
+    const bool consider = slots > 0 && n > 0 && !force_t && (long long)n * wgs_per_item < 3ll * slots &&
+                          n <= MINE * 256;
     if (slots > 0 && n > 0) {                                    // uniform
         if (tid == 0) s_lmax = s_lsum = s_nirr = 0;
-        if (tid < NCAND) s_segs[tid] = 0;
-        for (int i = tid; i < NCAND * HL; i += 256) (&s_len[0][0])[i] = 0;
+        if (tid < NCAND) s_segs[tid] = 0, s_est[tid] = 0x7fffffff;
+        for (int i = tid; i < NCAND * HL / 2; i += 256) ((unsigned int *)&s_len[0][0])[i] = 0u;
         __syncthreads();
-        int lmax = 0, lsum = 0, nirr = 0;
-        for (int i = tid; i < n; i += 256) {
+        int lmax = 0, lsum = 0, nirr = 0, mine[MINE];
+        // (static indices only: a `mine[r]` with a running r put the array into scratch memory and
+        // every one of the estimate's 52 reads of it became a trip to memory - 30 us of this kernel)
+#pragma unroll
+        for (int r = 0; r < MINE; ++r) {
+            const int i = tid + 256 * r;
+            mine[r] = 0;
+            if (i < n) {
+                const int2 it = items[i];
+                lmax = max(lmax, it.y);
+                lsum += it.y;
+                nirr += irregular(it) ? 1 : 0;
+                mine[r] = it.y;
+            }
+        }
+        for (int i = tid + 256 * MINE; i < n; i += 256) {
             const int2 it = items[i];
             lmax = max(lmax, it.y);
             lsum += it.y;
@@ -2356,38 +2376,99 @@ __global__ __launch_bounds__(256) void mb_sort_kernel(const int2 *__restrict__ i
         // candidate lengths: none, Lmax / 2 ... Lmax / 8 and a few absolute ones
         auto cand = [&](const int c) {
             if (c == 0) return 1 << 20;
-            const int t = c < 8 ? (Lmax + c) / (c + 1) : 8 * (c - 6);            // .../2 ... /8, 16 ... 48
+            // ~ Lmax / 2 ... Lmax / 8 (multipliers 65536 / (c + 1) + 1: no division), then 16 ... 48
+            const int mul = c == 1 ? 32769 : c == 2 ? 21846 : c == 3 ? 16385 : c == 4 ? 13108
+                          : c == 5 ? 10923 : c == 6 ? 9363 : 8193;
+            const int t = c < 8 ? (int)((unsigned)((Lmax + c) * mul) >> 16) : 8 * (c - 6);
             return max(t, 8);
         };
-        for (int c = 0; c < NCAND; ++c) {
-            const int t = cand(c);
-            int segs = 0;
-            for (int i = tid; i < n; i += 256) {
-                const int len = items[i].y, ns = min(MB_SEG_MAX, (len + t - 1) / t);
-                const int wl = min((len + ns - 1) / ns + MB_SEG_LEAD, HL - 1);
-                segs += ns;
-                atomicAdd((unsigned int *)&s_len[c][wl & ~1], (unsigned int)ns << (16 * (wl & 1)));
+#ifndef SORT_ABL
+#define SORT_ABL 0                  // timing experiments: 1 = no histograms, 2 = no order statistics
+#endif
+        // floor(a / b) for 0 <= a < 2^22, b >= 1 without the integer-division sequence (a dozen of
+        // them per candidate, one behind the other, were 28 us of this kernel): a float estimate
+        // that is off by at most one, put right by two compares
+        auto div_small = [](const int a, const int b, const float rcp_b) {
+            int q = (int)((float)a * rcp_b);
+            q -= q * b > a ? 1 : 0;
+            q += (q + 1) * b <= a ? 1 : 0;
+            return q;
+        };
+        if (consider && !(SORT_ABL & 1)) {
+            const int rounds = (n + 255) >> 8;                           // uniform: the slots of `mine` in use
+#pragma unroll 1
+            for (int c = 0; c < NCAND; ++c) {
+                const int t = cand(c);
+                const float rcp_t = 1.0f / (float)t;
+                int segs = 0;
+#pragma unroll
+                for (int r = 0; r < MINE; ++r) {
+                    if (r >= rounds) break;
+                    const int len = mine[r];
+                    if (len > 0) {
+                        const int ns = min(MB_SEG_MAX, div_small(len + t - 1, t, rcp_t));
+                        const int wl = min(div_small(len + ns - 1, ns, 1.0f / (float)ns) + MB_SEG_LEAD, HL - 1);
+                        segs += ns;
+                        atomicAdd((unsigned int *)&s_len[c][wl & ~1], (unsigned int)ns << (16 * (wl & 1)));
+                    }
+                }
+                // one add per wave
+                for (int off = 32; off > 0; off >>= 1) segs += __shfl_xor(segs, off, 64);
+                if ((tid & 63) == 0 && segs) atomicAdd(&s_segs[c], segs);
             }
-            if (segs) atomicAdd(&s_segs[c], segs);
         }
         __syncthreads();
+        // order statistics of a candidate's workgroup lengths, longest first: l(k), k = 1 .. W.  A
+        // candidate is a group of 16 threads, a thread one chunk of eight bins (one 16-byte LDS read):
+        // the chunks' totals are prefix-summed down from the longest across the group, and a thread
+        // resolves the ranks that fall into its own chunk
+        __shared__ int s_got[NCAND][4], s_lmin[NCAND];
         if (tid < NCAND) {
+            s_got[tid][0] = s_got[tid][1] = s_got[tid][2] = s_got[tid][3] = 0;
+            s_lmin[tid] = HL;
+        }
+        __syncthreads();
+        static_assert(HL == 16 * 8 && NCAND * 16 <= 256, "16 chunks of eight bins per candidate");
+        if (consider && !(SORT_ABL & 2) && tid < NCAND * 16) {
+            const int c = tid >> 4, chunk = 15 - (tid & 15);             // lane 0 of a group: the longest bins
+            const int W = s_segs[c] * wgs_per_item;
+            const uint4 q = *(const uint4 *)&s_len[c][8 * chunk];
+            const unsigned int word[4] = {q.x, q.y, q.z, q.w};
+            int cnt[8], total = 0;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                cnt[e] = (int)((word[e >> 1] >> (16 * (e & 1))) & 0xffffu) * wgs_per_item;
+                total += cnt[e];
+            }
+            int seen = total;                                            // inclusive prefix over the group
+#pragma unroll
+            for (int off = 1; off < 16; off <<= 1) {
+                const int v = __shfl_up(seen, off, 16);
+                if ((tid & 15) >= off) seen += v;
+            }
+            seen -= total;                                               // workgroups longer than this chunk's
+            if (total) {
+                const int want[4] = {1, slots, slots + 1, 2 * slots + 1 - W};
+                int lmin = HL;
+#pragma unroll
+                for (int e = 7; e >= 0; --e) {
+                    if (!cnt[e]) continue;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        if (want[u] > seen && want[u] <= seen + cnt[e]) s_got[c][u] = 8 * chunk + e;
+                    seen += cnt[e];
+                    lmin = 8 * chunk + e;
+                }
+                atomicMin(&s_lmin[c], lmin);
+            }
+        }
+        __syncthreads();
+        if (consider && tid < NCAND) {
             const int c = tid, t = cand(c), segs = s_segs[c];
             int est = 0x7fffffff;
             if (c == 0 || (t < Lmax && segs > n && segs <= scap && segs <= n + MB_SEG_SLOTS)) {
-                const int W = segs * wgs_per_item;
-                // order statistics of the workgroup lengths, longest first: l(k), k = 1 .. W
-                const int want[4] = {1, slots, slots + 1, 2 * slots + 1 - W};
-                int got[4] = {0, 0, 0, 0}, lmin = 0, seen = 0;
-                for (int wl = HL - 1; wl >= 0; --wl) {
-                    const int cnt = s_len[c][wl] * wgs_per_item;
-                    if (!cnt) continue;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        if (want[q] > seen && want[q] <= seen + cnt) got[q] = wl;
-                    seen += cnt;
-                    lmin = wl;
-                }
+                const int W = segs * wgs_per_item, lmin = s_lmin[c];
+                const int *got = s_got[c];
                 const int share = (int)(((long long)Lsum + (long long)segs * MB_SEG_LEAD) *
                                         wgs_per_item / slots);
                 if (W <= slots)
@@ -2402,7 +2483,7 @@ __global__ __launch_bounds__(256) void mb_sort_kernel(const int2 *__restrict__ i
         __syncthreads();
         const int base = s_est[0];
         int best = base;
-        for (int c = 1; c < NCAND; ++c) {
+        for (int c = 1; c < NCAND && consider; ++c) {
             const int m = s_est[c];
             if (m < best && (long long)m * 100 <= (long long)base * 85) {
                 best = m;

@@ -234,23 +234,27 @@ class ShardedStitcher:
 
     def __init__(self, eng, shapes, rots, intrs, n_levels, rank, world, max_resolution=10 ** 9,
                  group=None, exchange="gather", depth=2, cache_plan=True,
-                 force_collective=False):
+                 force_collective=False, lane_groups="shared"):
         # ``eng``: one engine, or a list of them - "lanes": consecutive stitches then alternate
         # between the engines, each on a stream of its own with its own exchange buffers, so
         # that one stitch's kernels cover the other's host round trip (on a column strip of a
         # world-8 run the kernels are 0.45 ms and that round trip plus the launches' gaps 0.1).
-        # Every buffer of a lane is only ever touched in its lane's stream order.  Each lane
-        # exchanges over a process group (communicator) of its own, so that a lane's collective
-        # can only ever pair with the SAME lane's collective on the other ranks.  The lanes are
-        # driven in lock step - ``step`` takes them round-robin, the same on every rank - so every
-        # rank issues the collectives of all communicators in one global order; RCCL still needs
-        # that (device-side collectives of two communicators issued in different orders on
-        # different ranks can deadlock), separate communicators only rule out mis-pairing.  On
-        # gloo, whose collectives do not share a device queue, a test drives the lanes from
-        # skewed threads (tests/test_dist_cpu.py); that says nothing about RCCL.
-        # EVERY rank of the default group must construct the stitcher (``dist.new_group`` is
-        # collective over the default group, also for ranks outside ``group``), in the same
-        # order, and ``close()`` it to give the lane communicators back.
+        # Every buffer of a lane is only ever touched in its lane's stream order.
+        # ``lane_groups``: which communicator a lane's exchange runs on.
+        # * "shared" (default): all lanes use ``group``.  The lanes are driven in lock step -
+        #   ``step`` takes them round-robin from one thread, the same on every rank - so every
+        #   rank issues its collectives in ONE order on ONE communicator, and torch runs them on
+        #   that communicator's own stream in that order (each waits for its lane's stream, the
+        #   lane's stream waits for it in ``collect``): the canonical RCCL usage; nothing of two
+        #   communicators can wait for each other on the device.
+        # * "own": a communicator per lane (``dist.new_group``), so that a lane's collective can
+        #   only pair with the SAME lane's on the other ranks whatever order the lanes are driven
+        #   in (tests/test_dist_cpu.py drives them from skewed threads, on gloo).  On RCCL
+        #   collectives of different communicators run side by side, and the library asks for
+        #   one issue order across ranks all the same; the lock-step order satisfies it, but
+        #   nothing is gained over "shared" while the lanes are driven from one thread.  EVERY
+        #   rank of the default group must then construct the stitcher (``dist.new_group`` is
+        #   collective over it), in the same order, and ``close()`` it to give them back.
         engines = list(eng) if isinstance(eng, (list, tuple)) else [eng]
         self.eng, self.rank, self.world, self.group = engines[0], rank, world, group
         self.shapes, self.rots, self.intrs = shapes, rots, intrs
@@ -283,7 +287,10 @@ class ShardedStitcher:
                 stream = torch.cuda.Stream(use.device)
             # exchange=None: geometry only (emulation of the ranks on one device)
             lane_group = group
-            if exchange and (world > 1 or force_collective) and len(engines) > 1:
+            if lane_groups not in ("shared", "own"):
+                raise ValueError(f"lane_groups {lane_groups!r}: 'shared' or 'own'")
+            if (lane_groups == "own" and exchange and (world > 1 or force_collective)
+                    and len(engines) > 1):
                 import torch.distributed as dist
                 # (collective: every rank builds its lanes in the same order)
                 lane_group = dist.new_group(ranks=(dist.get_process_group_ranks(group)

@@ -41,12 +41,16 @@ def test_strip_exchange_on_device_buffers_through_rccl_at_world_1():
         plan = lanes[0].upload_plan(engine.Plan(shapes, rots, intrs, True, 10 ** 9))
         want = lanes[0].stitch(frames, plan, "multiband", 5)[0].clone()
         torch.cuda.synchronize()
-        for mode in pdist.StripExchange.MODES:
+        for mode, lane_groups in [(m, g) for m in pdist.StripExchange.MODES for g in ("shared", "own")]:
             st = pdist.ShardedStitcher(lanes, shapes, rots, intrs, 5, 0, 1, exchange=mode, depth=2,
-                                       force_collective=True)
+                                       force_collective=True, lane_groups=lane_groups)
             for _, _, ex in st.lanes:
-                assert ex.collective and not ex.host_staged and ex.group is not None
-            assert st.lanes[0][2].group is not st.lanes[1][2].group      # a communicator per lane
+                assert ex.collective and not ex.host_staged
+            if lane_groups == "own":                                     # a communicator per lane
+                assert st.lanes[0][2].group is not None
+                assert st.lanes[0][2].group is not st.lanes[1][2].group
+            else:                                                        # one, the default group's
+                assert st.lanes[0][2].group is None and st.lanes[1][2].group is None
             got = []
             for _ in range(6):                                           # two lanes, depth 2
                 previous = st.step(frames)[1]
@@ -56,7 +60,7 @@ def test_strip_exchange_on_device_buffers_through_rccl_at_world_1():
             torch.cuda.synchronize()
             assert len(got) == 6
             for k, mosaic in enumerate(got):
-                assert torch.equal(mosaic, want), f"{mode}: stitch {k} differs from Engine.stitch"
+                assert torch.equal(mosaic, want), f"{mode} / {lane_groups}: stitch {k} differs from Engine.stitch"
             st.close()
         # the timing reduction and the job description of bench.py on the same backend
         assert pdist.max_over_ranks(1.5, "cuda:0") == 1.5

@@ -179,12 +179,14 @@ def _forced_world1_worker(rank, world, port, result):
         shapes, rots, intrs = _scene()
         shape = engine.Plan(shapes, rots, intrs, True, 10 ** 9).shape
         ok = True
-        for mode in pdist.StripExchange.MODES:
+        for mode, lane_groups in [(m, g) for m in pdist.StripExchange.MODES for g in ("own", "shared")]:
             eng = _HostEngine(shape)
             st = pdist.ShardedStitcher([eng, _HostEngine(shape, eng.clock)], shapes, rots, intrs, 5,
-                                       0, 1, exchange=mode, depth=2, force_collective=True)
-            assert all(ex.collective and ex.group is not None for _, _, ex in st.lanes)
-            assert len(st._lane_groups) == 2
+                                       0, 1, exchange=mode, depth=2, force_collective=True,
+                                       lane_groups=lane_groups)
+            assert all(ex.collective for _, _, ex in st.lanes)
+            assert len(st._lane_groups) == (2 if lane_groups == "own" else 0)
+            assert all((ex.group is not None) == (lane_groups == "own") for _, _, ex in st.lanes)
             got = []
             for _ in range(6):
                 previous = st.step(None)[1]
@@ -282,7 +284,7 @@ def _skewed_lanes_worker(rank, world, port, mode, result):
         shape = engine.Plan(shapes, rots, intrs, True, 10 ** 9).shape
         eng = _HostEngine(shape)
         st = pdist.ShardedStitcher([eng, _HostEngine(shape, eng.clock)], shapes, rots, intrs, 5,
-                                   rank, world, exchange=mode, depth=2)
+                                   rank, world, exchange=mode, depth=2, lane_groups="own")
         groups = [ex.group for _, _, ex in st.lanes]
         assert groups[0] is not groups[1] and None not in groups       # a communicator per lane
         truth = eng.truth
