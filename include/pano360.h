@@ -348,7 +348,9 @@ int pano_multiband_blur(pano_ctx *ctx, const pano_patch *patches, int n, int max
  * colour (to float32 rounding, <= 6e-8 absolute).  interior: dev uint8
  * [ceil(H/B)][ceil(W/B)], B = PANO_INTERIOR_BLOCK, 1 = every pixel of the B x B
  * block is such a pixel (conservative: tested on whole blocks); block_owner: dev
- * int16 workspace, twice that shape.  Only columns [xs0, xs1) of owner are read. */
+ * int16 workspace, twice that shape.  Only columns [xs0, xs1) of owner are read, and only the
+ * blocks that meet those columns are written (one GPU's strip of the mosaic: the rest of
+ * `interior` keeps whatever it held). */
 int pano_interior_map(pano_ctx *ctx, const int16_t *owner, int H, int W, int xs0, int xs1,
                       int radius, int16_t *block_owner, uint8_t *interior);
 

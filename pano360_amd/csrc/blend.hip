@@ -713,10 +713,11 @@ __device__ __forceinline__ uint8_t quant255(float v) { return (uint8_t)(int)(255
 
 __global__ __launch_bounds__(256) void block_owner_kernel(const int16_t *__restrict__ owner,
                                                           int H, int W, int xs0, int xs1,
-                                                          int H8, int W8,
+                                                          int H8, int W8, int blo, int bhi,
                                                           int16_t *__restrict__ bown) {
-    const int bx = blockIdx.x * 64 + threadIdx.x, by = blockIdx.y * 4 + threadIdx.y;
-    if (bx >= W8 || by >= H8) return;
+    // (block columns [blo, bhi) only: a strip's share, grown by the interior test's reach)
+    const int bx = blo + blockIdx.x * 64 + threadIdx.x, by = blockIdx.y * 4 + threadIdx.y;
+    if (bx >= bhi || by >= H8) return;
     const int x0 = bx * IB, y0 = by * IB;
     int o = -2;                                  // -2: mixed, or not inside the strip
     if (x0 >= xs0 && (x0 + IB < W ? x0 + IB : W) <= xs1) {
@@ -778,13 +779,18 @@ __global__ __launch_bounds__(256) void block_owner_kernel(const int16_t *__restr
 __device__ __forceinline__ bool agree(int a, int b) { return a == b || a == -3 || b == -3; }
 
 __global__ __launch_bounds__(256) void interior_tile_kernel(const int16_t *__restrict__ bown,
-                                                            int H8, int W8, int reach,
+                                                            int H8, int W8, int reach, int blo,
+                                                            int bhi, int ilo, int ihi,
                                                             uint8_t *__restrict__ interior) {
     __shared__ int16_t s_own[(IT_H + 2 * IT_REACH_MAX) * (IT_W + 2 * IT_REACH_MAX)];
     __shared__ int16_t s_col[IT_H * (IT_W + 2 * IT_REACH_MAX)];
     __shared__ unsigned long long s_vmask[IT_W + 2 * IT_REACH_MAX];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int bx0 = blockIdx.x * IT_W, by0 = blockIdx.y * IT_H;
+    // block columns [ilo, ihi) are classified (one GPU's strip: the others' blocks are nobody's
+    // business - on a world-8 strip the two map kernels used to walk the whole mosaic's width,
+    // 25 of a strip's 290 us of kernels); block owners exist for [blo, bhi) = that range grown by
+    // the reach, everything else inside the mosaic counts as "not this strip's" (-2)
+    const int bx0 = ilo + blockIdx.x * IT_W, by0 = blockIdx.y * IT_H;
     const int tw = IT_W + 2 * reach, th = IT_H + 2 * reach;          // th <= 56: a column's bits fit a word
     // (rows by wave, columns by lane: an index i = ty * tw + tx split by division cost twenty
     // instructions per element, more than the loads it addressed)
@@ -794,7 +800,9 @@ __global__ __launch_bounds__(256) void interior_tile_kernel(const int16_t *__res
         const bool row_in = y >= 0 && y < H8;
         for (int tx = lane; tx < tw; tx += 64) {
             const int x = bx0 - reach + tx;
-            s_own[ty * tw + tx] = (row_in && x >= 0 && x < W8) ? bown[(size_t)y * W8 + x] : (int16_t)-3;
+            s_own[ty * tw + tx] = (row_in && x >= 0 && x < W8)
+                                      ? (x >= blo && x < bhi ? bown[(size_t)y * W8 + x] : (int16_t)-2)
+                                      : (int16_t)-3;
         }
     }
     __syncthreads();
@@ -827,7 +835,7 @@ __global__ __launch_bounds__(256) void interior_tile_kernel(const int16_t *__res
         const unsigned long long lo = __ballot(lane + 1 < tw && agree(a0, a1));
         const unsigned long long hi = __ballot(lane + 65 < tw && agree(b0, b1));
         const int y = by0 + ry, x = bx0 + lane;
-        if (y >= H8 || x >= W8) continue;
+        if (y >= H8 || x >= ihi) continue;
         const unsigned long long win = lane == 0 ? lo : (lo >> lane) | (hi << (64 - lane));
         const int o = row[lane + reach];
         interior[(size_t)y * W8 + x] = (o >= 0 && (win & full) == full) ? 1 : 0;
@@ -1330,16 +1338,21 @@ extern "C" int pano_interior_map(pano_ctx *ctx, const int16_t *owner, int H, int
     PANO_REQUIRE(H > 0 && W > 0 && radius >= 0, "pano_interior_map: bad argument");
     PANO_REQUIRE(xs0 >= 0 && xs1 <= W && xs0 <= xs1, "pano_interior_map: bad strip [%d, %d)", xs0, xs1);
     const int H8 = ceil_div(H, IB), W8 = ceil_div(W, IB), reach = ceil_div(radius + IB - 1, IB);
-    dim3 block(64, 4), grid(ceil_div(W8, 64), ceil_div(H8, 4));
+    if (xs0 == xs1) return PANO_OK;
+    // the blocks that meet the columns [xs0, xs1) are classified; their owners are needed `reach`
+    // blocks further (blocks that do not lie inside [xs0, xs1) are "not this strip's" either way)
+    const int ilo = xs0 / IB, ihi = ceil_div(xs1, IB);
+    const int blo = ilo - reach > 0 ? ilo - reach : 0, bhi = ihi + reach < W8 ? ihi + reach : W8;
+    dim3 block(64, 4), grid(ceil_div(bhi - blo, 64), ceil_div(H8, 4));
     hipStream_t s = (hipStream_t)stream;
     PANO_TIMED(PK_INTERIOR, s,
                hipLaunchKernelGGL(block_owner_kernel, grid, block, 0, s, owner, H, W, xs0, xs1,
-                                  H8, W8, block_owner));
+                                  H8, W8, blo, bhi, block_owner));
     PANO_LAUNCH_CHECK("block_owner_kernel");
     PANO_REQUIRE(reach <= IT_REACH_MAX, "pano_interior_map: radius %d reaches %d blocks (at most %d)",
                  radius, reach, IT_REACH_MAX);
-    hipLaunchKernelGGL(interior_tile_kernel, dim3(ceil_div(W8, IT_W), ceil_div(H8, IT_H)), dim3(256), 0,
-                       s, block_owner, H8, W8, reach, interior);
+    hipLaunchKernelGGL(interior_tile_kernel, dim3(ceil_div(ihi - ilo, IT_W), ceil_div(H8, IT_H)),
+                       dim3(256), 0, s, block_owner, H8, W8, reach, blo, bhi, ilo, ihi, interior);
     PANO_LAUNCH_CHECK("interior_tile_kernel");
     return PANO_OK;
 }
