@@ -279,7 +279,10 @@ extern "C" int pano_stitch_multiband(pano_ctx *ctx, pano_stitch_args *a, int res
     if (int rc = pano_ctx_side_stream(ctx)) return rc;
     // the second stream pays on large mosaics only (config 3: 1.975 -> 1.945 ms per stitch;
     // config 2, 7.9 MP: 0.527 -> 0.537: the forks and joins cost more than the overlap gives)
-    const bool big = (long long)a->H * (a->own1 - a->own0) >= (1ll << 24);
+    // (PANO_TWO_STREAMS_MIN_PX: A/B timing of the threshold)
+    static const long long min_px = getenv("PANO_TWO_STREAMS_MIN_PX") ? atoll(getenv("PANO_TWO_STREAMS_MIN_PX"))
+                                                                    : (1ll << 24);
+    const bool big = (long long)a->H * (a->own1 - a->own0) >= min_px;
     const bool two_streams = ctx->opt[PANO_OPT_STITCH_STREAMS] != 0 && big;
     const int tile_grid = pano_blur_tile_grid(ctx);
     const int stride = 5 + 2 * a->max_spans;
