@@ -441,3 +441,28 @@ def test_plan_memo_is_keyed_on_every_bit_of_the_cameras():
     for cap in (1400, 1401, 1402):
         small.get(shapes, rots, intrs, True, cap)
     assert len(small) == 2 and small.key(shapes, rots, intrs, True, 1400) not in small.plans
+
+
+def test_bench_reads_the_committed_profiles():
+    """bench.py's `scaling_projection` (the committed strip-floor emulation: worlds 1 and 8, factors
+    from its own milliseconds) and `pmc_traffic` (the newest round's counter summary of the
+    workload, a closing visit's before the earlier ones)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_module", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    proj = bench.scaling_projection("cfg3")
+    assert proj is not None and proj["emulated_on_one_gpu"] and "excluded" in proj["exchange"]
+    ms = proj["ms_per_stitch_and_rank"]
+    assert {"1", "8"} <= set(ms) and ms["8"] < ms["1"]
+    assert abs(proj["factor_vs_world_1"]["8"] - ms["1"] / ms["8"]) < 1e-9
+    assert os.path.exists(os.path.join(ROOT, proj["source"]))
+    assert bench.scaling_projection("no_such_workload") is None
+    traffic, source = bench.pmc_traffic("blur_lean_kernel", "cfg3")
+    assert traffic and traffic > 1e9 and source.startswith("profiles/")
+    rounds = sorted(d for d in os.listdir(os.path.join(ROOT, "profiles")) if d.startswith("r"))
+    newest = [r for r in rounds
+              if any(f.startswith("pmc_traffic") for _, _, fs in os.walk(os.path.join(ROOT, "profiles", r))
+                     for f in fs)][-1]
+    assert source.split("/")[1] == newest
+    assert bench.pmc_traffic("blur_lean_kernel", "no_such_workload") == (None, None)
