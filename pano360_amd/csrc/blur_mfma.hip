@@ -2395,9 +2395,21 @@ __global__ __launch_bounds__(256) void mb_sort_kernel(const int2 *__restrict__ i
             return q;
         };
         if (consider && !(SORT_ABL & 1)) {
-            const int rounds = (n + 255) >> 8;                           // uniform: the slots of `mine` in use
+            // Up to 64 MINE items (a strip, a small scene): every wave holds ALL the items, a lane
+            // MINE of them, and takes every fourth candidate - three or four trips instead of
+            // thirteen, one behind the other.  More items: a thread keeps its own, all candidates.
+            const bool by_wave = n <= 64 * MINE;
+            const int lane = tid & 63, wave = tid >> 6;
+            if (by_wave) {
+#pragma unroll
+                for (int r = 0; r < MINE; ++r) {
+                    const int i = lane + 64 * r;
+                    mine[r] = i < n ? items[i].y : 0;
+                }
+            }
+            const int rounds = by_wave ? (n + 63) >> 6 : (n + 255) >> 8;      // uniform: slots of `mine` in use
 #pragma unroll 1
-            for (int c = 0; c < NCAND; ++c) {
+            for (int c = by_wave ? wave : 0; c < NCAND; c += by_wave ? 4 : 1) {
                 const int t = cand(c);
                 const float rcp_t = 1.0f / (float)t;
                 int segs = 0;
@@ -2414,7 +2426,7 @@ __global__ __launch_bounds__(256) void mb_sort_kernel(const int2 *__restrict__ i
                 }
                 // one add per wave
                 for (int off = 32; off > 0; off >>= 1) segs += __shfl_xor(segs, off, 64);
-                if ((tid & 63) == 0 && segs) atomicAdd(&s_segs[c], segs);
+                if (lane == 0 && segs) atomicAdd(&s_segs[c], segs);
             }
         }
         __syncthreads();
