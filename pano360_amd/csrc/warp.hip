@@ -124,16 +124,6 @@ __global__ __launch_bounds__(256) void warp_windows_kernel(
     // vector instructions - 160 per pixel, 77 % of the issue cycles - not by its loads; the
     // four range tests of the general path and the branches around their modulos were 30 of
     // them).  The decision is per wave, so neither path runs under a partial mask.
-#ifdef WARP_ABL_NOLOAD                          // timing experiment (results wrong): no frame reads
-    if (true) {
-#pragma unroll
-        for (int j = 0; j < WARP_ROWS; ++j)
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-#pragma unroll
-                for (int k = 0; k < 3; ++k) tb[j].v[q][k] = ((uint32_t)(tp[j].x0 + q + k) & 255u) << 2;
-    } else
-#endif
     if (__ballot(!inner) == 0ull) {
 #pragma unroll
         for (int j = 0; j < WARP_ROWS; ++j) tb[j] = load_taps_interior(cam->frame, sw, tp[j]);
@@ -161,21 +151,8 @@ __global__ __launch_bounds__(256) void warp_windows_kernel(
         const uint32_t o = ((uint32_t)y * (uint32_t)p.vpitch + (uint32_t)x) * 4u;
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
-#ifdef WARP_ABL_NOLUT                           // timing experiment (results wrong): no table look-ups
-            const float v = lerp4(__uint_as_float(tb[j].v[0][k]), __uint_as_float(tb[j].v[1][k]),
-                                  __uint_as_float(tb[j].v[2][k]), __uint_as_float(tb[j].v[3][k]), tp[j]);
-#else
-            const float v = lerp4(lut_at(s_lut, tb[j].v[0][k]), lut_at(s_lut, tb[j].v[1][k]),
-                                  lut_at(s_lut, tb[j].v[2][k]), lut_at(s_lut, tb[j].v[3][k]), tp[j]);
-#endif
-#ifdef WARP_ABL_NOSTORE                         // timing experiment (results wrong): (almost) no stores
-            if (v == 12345.0f)
-#endif
-#ifdef WARP_NT_STORE                            // A/B: the planes streamed past the caches
-            __builtin_nontemporal_store(v, (plane_ptr)(out[k] + o));
-#else
-            *(plane_ptr)(out[k] + o) = v;
-#endif
+            *(plane_ptr)(out[k] + o) = lerp4(lut_at(s_lut, tb[j].v[0][k]), lut_at(s_lut, tb[j].v[1][k]),
+                                             lut_at(s_lut, tb[j].v[2][k]), lut_at(s_lut, tb[j].v[3][k]), tp[j]);
         }
     }
 }
