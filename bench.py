@@ -867,7 +867,8 @@ def main():
         runner = pdist.ShardedStitcher(engines if n_lanes > 1 else eng, shapes, rots, intrs,
                                        n_levels, rank, world, exchange=exchange,
                                        depth=max(2, n_lanes), cache_plan=cache_plan,
-                                       lane_groups=os.environ.get("PANO_LANE_GROUPS", "shared"))
+                                       lane_groups=os.environ.get("PANO_LANE_GROUPS", "shared"),
+                                       trust_layouts=os.environ.get("PANO_TRUST_LAYOUT", "1") != "0")
         frames = upload(0, runner.my_frames)
         serial = dict(on=False)
 

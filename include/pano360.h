@@ -187,7 +187,12 @@ int pano_interior_block(void);
  *                         saves is already covered by the side stream's kernels (DESIGN.md
  *                         section 4.14), so the simpler path is the default.  Same results.
  *                         (2 = as 1 with launch bounds the layout is sure to exceed: the
- *                         tests' way into the fallback.) */
+ *                         tests' way into the fallback.)
+ *   PANO_OPT_BLUR_SEG_LEN matrix-core blur, with PANO_OPT_BLUR_SEGMENTS on: 0 (default) = the
+ *                         length of the vertical segments a launch with few work items is cut
+ *                         into comes from the sort kernel's list-schedule estimate; n >= 4 =
+ *                         segments of n bands (32 rows each); -1 = nothing is cut.  Same results
+ *                         bit for bit (A/B of the estimate, and the tests' way to other cuts). */
 typedef struct pano_ctx pano_ctx;
 #define PANO_OPT_BLUR_KERNEL 0
 #define PANO_OPT_OWN_PRUNE 1
@@ -195,7 +200,8 @@ typedef struct pano_ctx pano_ctx;
 #define PANO_OPT_BLUR_LEAN 3
 #define PANO_OPT_STITCH_STREAMS 4
 #define PANO_OPT_STITCH_ASYNC 5
-#define PANO_OPT_COUNT 6
+#define PANO_OPT_BLUR_SEG_LEN 6
+#define PANO_OPT_COUNT 7
 #define PANO_BLUR_MFMA 0
 #define PANO_BLUR_VALU 1
 int pano_ctx_create(int device, void *stream, pano_ctx **out);

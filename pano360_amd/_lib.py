@@ -22,6 +22,7 @@ TAP_PAD = 40
 # pano_ctx options (include/pano360.h)
 OPT_BLUR_KERNEL, OPT_OWN_PRUNE, OPT_BLUR_SEGMENTS, OPT_BLUR_LEAN, OPT_STITCH_STREAMS = 0, 1, 2, 3, 4
 OPT_STITCH_ASYNC = 5
+OPT_BLUR_SEG_LEN = 6
 BLUR_MFMA, BLUR_VALU = 0, 1
 
 

@@ -54,6 +54,7 @@ extern "C" int pano_ctx_create(int device, void *stream, pano_ctx **out) {
     ctx->opt[PANO_OPT_BLUR_LEAN] = 1;
     ctx->opt[PANO_OPT_STITCH_STREAMS] = 1;
     ctx->opt[PANO_OPT_STITCH_ASYNC] = 0;
+    ctx->opt[PANO_OPT_BLUR_SEG_LEN] = 0;
     *out = ctx;
     return PANO_OK;
 }
@@ -140,6 +141,9 @@ extern "C" int pano_ctx_set_option(pano_ctx *ctx, int option, int value) {
         PANO_REQUIRE(value >= 0 && value <= 2, "pano_ctx_set_option: option %d takes 0, 1 or 2", option);
     else if (option == PANO_OPT_OWN_PRUNE)
         PANO_REQUIRE(value >= 0 && value <= 3, "pano_ctx_set_option: option %d takes 0 .. 3", option);
+    else if (option == PANO_OPT_BLUR_SEG_LEN)
+        PANO_REQUIRE(value == -1 || value == 0 || (value >= 4 && value <= 2047),
+                     "pano_ctx_set_option: option %d takes -1, 0 or 4 .. 2047", option);
     else
         PANO_REQUIRE(value == 0 || value == 1, "pano_ctx_set_option: option %d takes 0 or 1", option);
     ctx->opt[option] = value;

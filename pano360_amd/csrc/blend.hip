@@ -489,28 +489,16 @@ extern "C" int pano_debug_own_stamps(unsigned long long *out, int reset) {
 #define OW_STAMP_AT(k) do { } while (0)
 #endif
 
-// Two tile heights: 64 x 128 (eight sub-tiles: one camera list, one staging, one pair of bound
-// passes per workgroup - 9 % faster than 64 x 64 on config 3's 4 000 workgroups), the default on
-// every grid, and 64 x 64, kept as an A/B instance: the idea that a small grid (a world-8 strip is
-// 580 tall workgroups, ONE round on 256 CUs) would gain from shorter workgroups did not hold -
+// The tile is 64 x 128 (eight sub-tiles: one camera list, one staging, one pair of bound passes per
+// workgroup - 9 % faster than 64 x 64 on config 3's 4 000 workgroups, 64 x 256 loses 16 %).  The
+// kernel's text is a parameter of the tile height (own_tile.inc); a 64 x 64 instance for small grids
+// (a world-8 strip is 580 tall workgroups, ONE round on 256 CUs) was measured and gained nothing -
 // strips 0.066 - 0.068 ms either way, config 2 0.058 against 0.065 (profiles/r05/own_small_*.txt).
 #define OW_SUBS 8
 #define OW_FN(name) name
 #include "own_tile.inc"
-#undef OW_SUBS
 #undef OW_FN
-#define OW_SUBS 4
-#define OW_FN(name) name##_small
-#include "own_tile.inc"
-#undef OW_SUBS
-#undef OW_FN
-#define OW_TH_TALL (OW_Q * 8)
-#define OW_TH_SMALL (OW_Q * 4)
-// workgroups of the tall kind below which the small tiles are launched (PANO_OWN_SMALL_BELOW: A/B)
-static int own_small_below() {
-    static const int v = getenv("PANO_OWN_SMALL_BELOW") ? atoi(getenv("PANO_OWN_SMALL_BELOW")) : 0;
-    return v;
-}
+#define OW_TH_TALL (OW_Q * OW_SUBS)
 
 // ---- linear_blend / no_blend straight from the frames (fused path) --------------
 // stitcher.py:160-183 without materialising any patch: per mosaic pixel the
@@ -995,16 +983,6 @@ __global__ __launch_bounds__(256) void multiband_compose_kernel(
         const size_t vo = (size_t)(ay + p.ay0 - p.vy0) * p.vpitch + (ax + p.ax0 - p.vx0);
         const size_t aplane = (size_t)p.ah * p.apitch, ao = (size_t)ay * p.apitch + ax;
         float hi[3], ha = 0.0f;                 // the copy that gets the minus
-#ifdef COMPOSE_ABL_ALIGNED
-        // timing experiment (results wrong): the wave's reads of the blurred copies start on a
-        // 128-byte line (tiles are anchored at multiples of 32 patch columns, which the layout puts
-        // on line boundaries) - its 256 contiguous bytes are then two whole lines instead of parts
-        // of three - to see what the lines fetched twice by neighbouring blocks cost
-        const size_t ao_al = ao - min(ao, (size_t)((xs0 + (int)blockIdx.x * 64 - p.x0) & 31));
-#define COMPOSE_AO ao_al
-#else
-#define COMPOSE_AO ao
-#endif
 #pragma unroll
         for (int c = 0; c < 3; ++c) hi[c] = p.planes[c * vplane + vo];
         if (L == 1) ha = owner[(size_t)y * W + x] == p.index ? 1.0f : 0.0f;   // sharp alpha (:208)
@@ -1012,7 +990,7 @@ __global__ __launch_bounds__(256) void multiband_compose_kernel(
         for (int k = 0; k < L; ++k) {
             float rgb[3], a;
             if (k < L - 1) {
-                const float *b = p.blurred + (size_t)k * 4 * aplane + COMPOSE_AO;
+                const float *b = p.blurred + (size_t)k * 4 * aplane + ao;
                 a = b[3 * aplane];
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
@@ -1132,14 +1110,10 @@ extern "C" int pano_ownership_cameras(pano_ctx *ctx, const pano_camera *cams, in
     // bit 1 = the round-4 kernel with one level of bounds (A/B, and a second implementation the
     // exactness tests compare with)
     const int prune = ctx->opt[PANO_OPT_OWN_PRUNE];
-    const bool small = ceil_div(xs1 - xs0, 64) * ceil_div(H, OW_TH_TALL) < own_small_below();
-    dim3 block(64, 4), grid(ceil_div(xs1 - xs0, 64),
-                            ceil_div(H, (prune & 2) ? OWN_TILE_ROWS : (small ? OW_TH_SMALL : OW_TH_TALL)));
+    dim3 block(64, 4), grid(ceil_div(xs1 - xs0, 64), ceil_div(H, (prune & 2) ? OWN_TILE_ROWS : OW_TH_TALL));
     PANO_TIMED(PK_OWNERSHIP_CAMS, (hipStream_t)stream,
-               hipLaunchKernelGGL((prune & 2) ? ownership_cameras_l1_kernel
-                                              : (small ? ownership_cameras_kernel_small : ownership_cameras_kernel),
-                                  grid, block,
-                                  (prune & 2) ? 0 : (small ? own_shared_bytes_small(n) : own_shared_bytes(n)),
+               hipLaunchKernelGGL((prune & 2) ? ownership_cameras_l1_kernel : ownership_cameras_kernel,
+                                  grid, block, (prune & 2) ? 0 : own_shared_bytes(n),
                                   (hipStream_t)stream, cams, n, H, W, xs0, xs1, sin_t, cos_t,
                                   tan_p, owner, valid, prune & 1, (int32_t *)nullptr, 0,
                                   (uint8_t *)nullptr));
@@ -1312,15 +1286,10 @@ extern "C" int pano_ownership_regions(pano_ctx *ctx, const pano_camera *cams, in
     if (int rc = launch_init_regions(s, regions, n, stride, marks, W)) return rc;
     if (xs0 == xs1) return PANO_OK;
     const int prune = ctx->opt[PANO_OPT_OWN_PRUNE];
-    const bool small = ceil_div(xs1 - xs0, 64) * ceil_div(H, OW_TH_TALL) < own_small_below();
-    dim3 block(64, 4), grid(ceil_div(xs1 - xs0, 64),
-                            ceil_div(H, (prune & 2) ? OWN_TILE_ROWS : (small ? OW_TH_SMALL : OW_TH_TALL)));
+    dim3 block(64, 4), grid(ceil_div(xs1 - xs0, 64), ceil_div(H, (prune & 2) ? OWN_TILE_ROWS : OW_TH_TALL));
     PANO_TIMED(PK_OWNERSHIP_CAMS, s,
-               hipLaunchKernelGGL((prune & 2) ? ownership_cameras_l1_kernel
-                                              : (small ? ownership_cameras_kernel_small : ownership_cameras_kernel),
-                                  grid, block,
-                                  (prune & 2) ? 0 : (small ? own_shared_bytes_small(n) : own_shared_bytes(n)),
-                                  s, cams, n, H, W, xs0,
+               hipLaunchKernelGGL((prune & 2) ? ownership_cameras_l1_kernel : ownership_cameras_kernel,
+                                  grid, block, (prune & 2) ? 0 : own_shared_bytes(n), s, cams, n, H, W, xs0,
                                   xs1, sin_t, cos_t, tan_p, owner, valid, prune & 1, regions, stride,
                                   marks));
     PANO_LAUNCH_CHECK("ownership_cameras_kernel");

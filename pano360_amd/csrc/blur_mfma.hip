@@ -2382,9 +2382,6 @@ __global__ __launch_bounds__(256) void mb_sort_kernel(const int2 *__restrict__ i
             const int t = c < 8 ? (int)((unsigned)((Lmax + c) * mul) >> 16) : 8 * (c - 6);
             return max(t, 8);
         };
-#ifndef SORT_ABL
-#define SORT_ABL 0                  // timing experiments: 1 = no histograms, 2 = no order statistics
-#endif
         // floor(a / b) for 0 <= a < 2^22, b >= 1 without the integer-division sequence (a dozen of
         // them per candidate, one behind the other, were 28 us of this kernel): a float estimate
         // that is off by at most one, put right by two compares
@@ -2394,7 +2391,7 @@ __global__ __launch_bounds__(256) void mb_sort_kernel(const int2 *__restrict__ i
             q += (q + 1) * b <= a ? 1 : 0;
             return q;
         };
-        if (consider && !(SORT_ABL & 1)) {
+        if (consider) {
             // Up to 64 MINE items (a strip, a small scene): every wave holds ALL the items, a lane
             // MINE of them, and takes every fourth candidate - three or four trips instead of
             // thirteen, one behind the other.  More items: a thread keeps its own, all candidates.
@@ -2441,7 +2438,7 @@ __global__ __launch_bounds__(256) void mb_sort_kernel(const int2 *__restrict__ i
         }
         __syncthreads();
         static_assert(HL == 16 * 8 && NCAND * 16 <= 256, "16 chunks of eight bins per candidate");
-        if (consider && !(SORT_ABL & 2) && tid < NCAND * 16) {
+        if (consider && tid < NCAND * 16) {
             const int c = tid >> 4, chunk = 15 - (tid & 15);             // lane 0 of a group: the longest bins
             const int W = s_segs[c] * wgs_per_item;
             const uint4 q = *(const uint4 *)&s_len[c][8 * chunk];
@@ -2502,7 +2499,7 @@ __global__ __launch_bounds__(256) void mb_sort_kernel(const int2 *__restrict__ i
                 T = cand(c);
             }
         }
-        if (force_t) {                                          // (PANO_BLUR_SEG_T: A/B timing)
+        if (force_t) {                                          // (PANO_OPT_BLUR_SEG_LEN)
             T = 0;
             if (force_t >= 4) {
                 __syncthreads();
@@ -2677,8 +2674,8 @@ int pano_prepare_blur_mfma(pano_ctx *ctx, const pano_patch *table, int n, int ma
     hipLaunchKernelGGL(mb_items_kernel, dim3(n), dim3(256), 0, stream, table, flags, ctx->item_buf,
                        ctx->item_counter, cap);
     PANO_LAUNCH_CHECK("mb_items_kernel");
-    // (PANO_BLUR_SEG_T = segment length in bands, -1 = no cut: A/B timing of the model's choice)
-    static const int force_t = getenv("PANO_BLUR_SEG_T") ? atoi(getenv("PANO_BLUR_SEG_T")) : 0;
+    // (option PANO_OPT_BLUR_SEG_LEN: a segment length in bands, -1 = no cut, 0 = the estimate's choice)
+    const int force_t = ctx->opt[PANO_OPT_BLUR_SEG_LEN];
     // 4 channels (x level groups) workgroups per item
     hipLaunchKernelGGL(mb_sort_kernel, dim3(1), dim3(256), 0, stream, ctx->item_buf,
                        ctx->item_counter, cap, mb_sorted_slots(cap), 4,

@@ -1,6 +1,5 @@
 // One multiband stitch per native call: the launch sequence of Engine.multiband_fused
 // (stitcher.py:283-327 without equalize / crop) queued from C++.  No kernel of its own.
-#include <stdlib.h>
 #include <string.h>
 
 #include "common.h"
@@ -279,10 +278,9 @@ extern "C" int pano_stitch_multiband(pano_ctx *ctx, pano_stitch_args *a, int res
     if (int rc = pano_ctx_side_stream(ctx)) return rc;
     // the second stream pays on large mosaics only (config 3: 1.975 -> 1.945 ms per stitch;
     // config 2, 7.9 MP: 0.527 -> 0.537: the forks and joins cost more than the overlap gives)
-    // (PANO_TWO_STREAMS_MIN_PX: A/B timing of the threshold)
-    static const long long min_px = getenv("PANO_TWO_STREAMS_MIN_PX") ? atoll(getenv("PANO_TWO_STREAMS_MIN_PX"))
-                                                                    : (1ll << 24);
-    const bool big = (long long)a->H * (a->own1 - a->own0) >= min_px;
+    // (round 5, with trusted layouts: still nothing below - a world-8 strip 0.363 against 0.362 ms,
+    // config 2 0.50 against 0.444; profiles/r05/visit_p_*.txt)
+    const bool big = (long long)a->H * (a->own1 - a->own0) >= (1ll << 24);
     const bool two_streams = ctx->opt[PANO_OPT_STITCH_STREAMS] != 0 && big;
     const int tile_grid = pano_blur_tile_grid(ctx);
     const int stride = 5 + 2 * a->max_spans;
@@ -335,27 +333,15 @@ extern "C" int pano_stitch_multiband(pano_ctx *ctx, pano_stitch_args *a, int res
             }
         }
         // ownership and, in the same pass, one record per (camera, span of columns it owns):
-        // boxes and column marks from the ownership kernel, the spans' search, its copy to the host
-        // (in one pass on mosaics of 16 MP and more: config 5 16.12 -> 15.99 ms, config 3 even;
-        // on the 8 MP of config 2 the longer ownership kernel costs what the box kernel saved)
-        // (since round 5's ownership kernel the one pass is as fast or faster on every size: config 2
-        // 0.449 / 0.451 ms per stitch, a world-8 strip of config 3 0.321 against 0.331 - the box
-        // kernel's 30 us are a quarter of a strip's ownership; PANO_REGIONS_FUSED = 0: A/B timing)
-        static const char *const fused_env = getenv("PANO_REGIONS_FUSED");
-        const bool fused_regions = fused_env ? fused_env[0] == '1' : true;
-        if (fused_regions) {
-            if (int rc = pano_ownership_regions(ctx, a->cams, a->n, a->H, a->W, a->own0, a->own1,
-                                                a->sin_t, a->cos_t, a->tan_p, a->owner, a->valid,
-                                                a->min_gap, a->max_spans, a->marks, a->regions))
-                return rc;
-        } else {
-            if (int rc = pano_ownership_cameras(ctx, a->cams, a->n, a->H, a->W, a->own0, a->own1,
-                                                a->sin_t, a->cos_t, a->tan_p, a->owner, a->valid))
-                return rc;
-            if (int rc = pano_owned_regions(ctx, a->owner, a->H, a->W, a->own0, a->own1, a->n,
+        // boxes and column marks out of the ownership kernel, then the spans' search.  (Rounds 3 - 4
+        // took the one pass on mosaics of 16 MP and more only; with round 5's ownership kernel it is
+        // as fast or faster on every size - config 2 0.449 / 0.451 ms per stitch, a world-8 strip of
+        // config 3 0.321 against 0.331: the separate box kernel's 30 us were a quarter of a strip's
+        // ownership - profiles/r05/ab_regions_fused_*.txt.)
+        if (int rc = pano_ownership_regions(ctx, a->cams, a->n, a->H, a->W, a->own0, a->own1,
+                                            a->sin_t, a->cos_t, a->tan_p, a->owner, a->valid,
                                             a->min_gap, a->max_spans, a->marks, a->regions))
-                return rc;
-        }
+            return rc;
         // Two small chains depend on the owner map only - the interior map and the region
         // search's tail - and two more on the record table only - the warp and the blur's tile
         // flags and work list: the context's side stream takes one of each pair (the short

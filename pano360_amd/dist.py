@@ -26,8 +26,6 @@ kernels of stitch k + 1; buffers are allocated once and cycled.
 path, no collective): the secondary throughput figure of ``bench.py``.
 """
 
-import os
-
 from . import engine as _eng
 
 
@@ -234,7 +232,7 @@ class ShardedStitcher:
 
     def __init__(self, eng, shapes, rots, intrs, n_levels, rank, world, max_resolution=10 ** 9,
                  group=None, exchange="gather", depth=2, cache_plan=True,
-                 force_collective=False, lane_groups="shared"):
+                 force_collective=False, lane_groups="shared", trust_layouts=None):
         # ``eng``: one engine, or a list of them - "lanes": consecutive stitches then alternate
         # between the engines, each on a stream of its own with its own exchange buffers, so
         # that one stitch's kernels cover the other's host round trip (on a column strip of a
@@ -306,8 +304,10 @@ class ShardedStitcher:
             # with the plan out of the memo a lane's stitch repeats its previous one's Plan
             # object: the engine then queues it with the verified layout and does not wait
             # (Engine.trust_layouts; checked when the mosaic is collected)
-            if cache_plan and exchange and hasattr(use, "trust_layouts"):
-                use.trust_layouts(os.environ.get("PANO_TRUST_LAYOUT", "1") != "0")
+            # (``trust_layouts``: None = whenever the plan comes out of the memo; False = never)
+            if exchange and hasattr(use, "trust_layouts"):
+                use.trust_layouts(bool(cache_plan) if trust_layouts is None
+                                  else bool(trust_layouts and cache_plan))
             self.lanes.append((use, stream, ex))
         self.exchange = self.lanes[0][2]
         self.count = 0

@@ -556,6 +556,14 @@ def test_cfg3_full_size_strips_equal_whole(eng, world):
             finally:
                 eng.set_option(_lib.OPT_BLUR_SEGMENTS, 1)
             assert torch.equal(plain[:, c0:c1], whole[:, c0:c1]), (world, rank)
+            for seg_len in (12, 48):                 # ... and other cuts than the estimate's
+                eng.set_option(_lib.OPT_BLUR_SEG_LEN, seg_len)
+                try:
+                    forced, _, _, _ = eng.multiband_fused([frames[i] for i in st.my_frames], mine,
+                                                          levels, frame_ids=st.my_frames, strip=st.strip)
+                finally:
+                    eng.set_option(_lib.OPT_BLUR_SEG_LEN, 0)
+                assert torch.equal(forced[:, c0:c1], whole[:, c0:c1]), (world, rank, seg_len)
     if world == 8:
         # trusted layouts at full size (two streams inside the stitch, the bench's plan-cached
         # figures and the strips' default): the whole mosaic and a strip, three stitches each
