@@ -118,16 +118,19 @@ def scaling_projection(workload):
     of N; the newest round's file with worlds 1 and 8 wins."""
     import glob
     best = None
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", f"strip_floor_{workload}*.json"))):
+    for path in glob.glob(os.path.join(ROOT, "profiles", "r*", f"strip_floor_{workload}*.json")):
         try:
             with open(path) as fid:
                 entries = json.load(fid)
         except (OSError, ValueError):
             continue
-        for entry in entries if isinstance(entries, list) else []:
+        # (no picking of the best run: the newest round's closing visit - *_final.json - if there
+        # is one, else the round's last file by name; inside a file the entry appended last)
+        for k, entry in enumerate(entries if isinstance(entries, list) else []):
             rows = {int(r["world"]): float(r["ms_per_stitch"]) for r in entry.get("rows", [])}
             if 1 in rows and 8 in rows:
-                key = (os.path.relpath(path, ROOT).split(os.sep)[1], -rows[8])
+                rel = os.path.relpath(path, ROOT).split(os.sep)
+                key = (rel[1], rel[-1].endswith("_final.json"), rel[-1], k)
                 if best is None or key > best[0]:
                     best = (key, path, entry, rows)
     if best is None:
