@@ -126,6 +126,8 @@ __device__ __forceinline__ void iv_axpy(double k, double lo, double hi, double &
     ahi += k >= 0.0 ? k * hi : k * lo;
 }
 
+__device__ __forceinline__ AlphaBound alpha_bound_of(const pano_camera *cam, const double (*v)[2]);
+
 __device__ __forceinline__ AlphaBound alpha_bound(const pano_camera *cam, const double *r) {
     // r = {s_lo, s_hi, t_lo, t_hi, c_lo, c_hi}
     const double *K = cam->proj;
@@ -140,6 +142,41 @@ __device__ __forceinline__ AlphaBound alpha_bound(const pano_camera *cam, const 
         v[row][0] = lo - slack;
         v[row][1] = hi + slack;
     }
+    return alpha_bound_of(cam, v);
+}
+
+// The same bound from the tile's FIRST and LAST column (sa, ca), (sb, cb) instead of the ranges of
+// sin and cos.  A row of K R ray is g(theta) + K1 t with g = K0 sin theta + K2 cos theta; intervals
+// of sin and cos taken as independent overestimate g's range badly where it matters - the depth
+// v_z = cos(theta - theta_0) moves by sin(theta - theta_0) d_theta over a tile, the independent
+// intervals say sin(theta + theta_0) d_theta, and through the divide every per cent of v_z is 15
+// source pixels at the frame's edge, as much as a 16-pixel quarter is wide.  g is a sinusoid of
+// amplitude A <= |K0| + |K2| and theta runs monotonically over the tile's columns, so g stays
+// within A d_theta^2 / 8 of the chord between its end values: [min(ga, gb) - e, max(ga, gb) + e].
+// d_theta follows from the chord of the unit circle between the two columns, 2 sin(d_theta / 2):
+// for chords up to 0.25 (the caller's test; else the ranges above) d_theta <= 1.003 chord.
+// t is independent of theta, so adding K1 [t_lo, t_hi] is exact.  Same slack, same tail.
+__device__ __forceinline__ AlphaBound alpha_bound_ends(const pano_camera *cam, double sa, double ca,
+                                                       double sb, double cb, double t_lo,
+                                                       double t_hi) {
+    const double *K = cam->proj;
+    const double chord2 = (sb - sa) * (sb - sa) + (cb - ca) * (cb - ca);
+    double v[3][2];
+#pragma unroll
+    for (int row = 0; row < 3; ++row) {
+        const double a = K[3 * row + 0], b = K[3 * row + 2];
+        const double ga = a * sa + b * ca, gb = a * sb + b * cb;
+        const double e = (fabs(a) + fabs(b)) * chord2 * 0.1258;
+        double lo = fmin(ga, gb) - e, hi = fmax(ga, gb) + e;
+        iv_axpy(K[3 * row + 1], t_lo, t_hi, lo, hi);
+        const double slack = 1e-9 * (fabs(lo) + fabs(hi) + fabs(ga) + fabs(gb)) + 1e-300;
+        v[row][0] = lo - slack;
+        v[row][1] = hi + slack;
+    }
+    return alpha_bound_of(cam, v);
+}
+
+__device__ __forceinline__ AlphaBound alpha_bound_of(const pano_camera *cam, const double (*v)[2]) {
     AlphaBound out;
     if (v[2][1] <= 0.0) {                    // behind the camera everywhere: mask (stitcher.py:308)
         out.lo = 0.0f;
