@@ -878,15 +878,70 @@ struct InteriorArgs {
     int part;                    // 0 every pixel, 2 only the pixels the interior pass left
 };
 
+// Where an interior pixel's colour table is read: staged in LDS, or in global memory (the
+// per-camera tables of an equalised stitch).
+enum { LUT_LDS = 0, LUT_GLOBAL = 1 };
+
+// One interior pixel of the mosaic: the owner's warped colour, clipped, quantised.
+template <int LUT>
+__device__ __forceinline__ void shade_interior(const pano_camera *cam, const float *__restrict__ table,
+                                               const InteriorArgs &ia, int x, int y, int W,
+                                               uint8_t *__restrict__ mosaic,
+                                               float *__restrict__ mosaic_f32) {
+    // queued before the host has seen the layout's summary (device-side layout): a camera
+    // whose frame is not resident is skipped here and reported by the caller
+    if (!cam->frame) return;
+    const int sw = cam->sw, sh = cam->sh;
+    float fx, fy;
+    map_pixel(cam->proj, table_f64(ia.sin_t, x), table_f64(ia.cos_t, x), table_f64(ia.tan_p, y), sw, sh, fx, fy);
+    // an owned pixel is unmasked; where the whole wave samples away from the frame's last
+    // row and column the taps need no border handling at all
+    Taps tp = tap_base(fx, fy);
+    TapBytes tb;
+    if (__ballot(!taps_interior(tp, sw, sh)) == 0ull) {
+        tb = load_taps_interior(cam->frame, sw, tp);
+    } else {
+        tp.x1 = min(tp.x1, sw - 1);
+        tp.y1 = min(tp.y1, sh - 1);
+        tb = load_taps(cam->frame, sw, tp);
+    }
+    const size_t g = ((size_t)y * W + x) * 3;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        float v = lerp4(lut_at(table, tb.v[0][c]), lut_at(table, tb.v[1][c]),
+                        lut_at(table, tb.v[2][c]), lut_at(table, tb.v[3][c]), tp);
+        v = v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v);
+        if (mosaic_f32) mosaic_f32[g + c] = v;
+        mosaic[g + c] = (uint8_t)(int)(255.0f * v);
+    }
+}
+
+// The interior pixels of a wave nearly always have one owner (a pixel is interior when
+// everything within the blur radius of it has): then the camera record is read through a
+// wave-uniform address - scalar loads of its 9 doubles instead of 64 lanes fetching the same
+// 120 bytes each.  `table`: the LDS copy, or the global table(s) at `stride` floats per camera.
+template <int LUT>
+__device__ __forceinline__ void shade_interior_of(int own, const float *__restrict__ table, int stride,
+                                                  const InteriorArgs &ia, int x, int y, int W,
+                                                  uint8_t *__restrict__ mosaic,
+                                                  float *__restrict__ mosaic_f32) {
+    const int own_u = __builtin_amdgcn_readfirstlane(own);
+    if (__ballot(own != own_u) == 0)
+        shade_interior<LUT>(ia.cams + own_u, table + (size_t)own_u * stride, ia, x, y, W, mosaic, mosaic_f32);
+    else
+        shade_interior<LUT>(ia.cams + own, table + (size_t)own * stride, ia, x, y, W, mosaic, mosaic_f32);
+}
+
 // The interior pixels alone (part 1 of the collapse): they need the owner map and the
-// frames, not the blurred planes, so this runs on a second stream beside the warp and the
-// blur.  Few registers on purpose: its waves fit on a CU next to the blur's workgroup.
-template <bool PERCAM>
+// frames, not the blurred planes, so a caller can run them on a second stream.  (Beside the
+// blur, with no LDS so that its waves fit on a CU next to the blur's workgroup, it costs the blur
+// more than it saves the collapse: profiles/r05/notes.md, section 10.)
+template <int LUT>
 __global__ __launch_bounds__(256) void compose_interior_kernel(
     int H, int W, int xs0, int xs1, const int16_t *__restrict__ owner,
-    uint8_t *__restrict__ mosaic, float *__restrict__ mosaic_f32, InteriorArgs ia) {
-    __shared__ float s_lut[256];
-    if (!PERCAM) {
+    uint8_t *__restrict__ mosaic, float *__restrict__ mosaic_f32, InteriorArgs ia, int lut_stride) {
+    __shared__ float s_lut[LUT == LUT_LDS ? 256 : 1];
+    if (LUT == LUT_LDS) {
         s_lut[threadIdx.y * 64 + threadIdx.x] = ia.lut[threadIdx.y * 64 + threadIdx.x];
         __syncthreads();
     }
@@ -894,26 +949,10 @@ __global__ __launch_bounds__(256) void compose_interior_kernel(
     if (x >= xs1 || y >= H) return;
     if (!ia.interior[(size_t)(y / IB) * ia.W8 + x / IB]) return;
     const int own = owner[(size_t)y * W + x];
-    const pano_camera *cam = ia.cams + own;
-    // queued before the host has checked which frames the strip needs: a camera whose
-    // frame is not resident is skipped here and reported by the caller
-    if (!cam->frame) return;
-    const float *__restrict__ gl = ia.lut + (size_t)own * 256;
-    const int sw = cam->sw, sh = cam->sh;
-    float fx, fy;
-    map_pixel(cam->proj, table_f64(ia.sin_t, x), table_f64(ia.cos_t, x), table_f64(ia.tan_p, y), sw, sh, fx, fy);
-    const Taps tp = make_taps_unmasked(fx, fy, sw, sh);          // an owned pixel is unmasked
-    const TapBytes tb = load_taps(cam->frame, sw, tp);
-    const size_t g = ((size_t)y * W + x) * 3;
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        float v = PERCAM ? lerp4(lut_at(gl, tb.v[0][c]), lut_at(gl, tb.v[1][c]), lut_at(gl, tb.v[2][c]), lut_at(gl, tb.v[3][c]), tp)
-                         : lerp4(lut_at(s_lut, tb.v[0][c]), lut_at(s_lut, tb.v[1][c]), lut_at(s_lut, tb.v[2][c]),
-                                 lut_at(s_lut, tb.v[3][c]), tp);
-        v = v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v);
-        if (mosaic_f32) mosaic_f32[g + c] = v;
-        mosaic[g + c] = (uint8_t)(int)(255.0f * v);
-    }
+    if (LUT == LUT_LDS)
+        shade_interior_of<LUT>(own, s_lut, 0, ia, x, y, W, mosaic, mosaic_f32);
+    else
+        shade_interior_of<LUT>(own, ia.lut, lut_stride, ia, x, y, W, mosaic, mosaic_f32);
 }
 
 #define COMPOSE_MASKS 4            // 256 records through the wave-wide test, more: plain scan
@@ -955,45 +994,10 @@ __global__ __launch_bounds__(256) void multiband_compose_kernel(
         // interior pixel: the mosaic is the owner's warped colour, clipped, quantised
         if (ia.part == 2) return;                // compose_interior_kernel wrote it
         const int own = owner[(size_t)y * W + x];
-        auto shade = [&](const pano_camera *cam, const float *__restrict__ gl) {
-            // queued before the host has seen the layout's summary (device-side layout): a
-            // camera whose frame is not resident is skipped here and reported by the caller
-            if (!cam->frame) return;
-            const int sw = cam->sw, sh = cam->sh;
-            float fx, fy;
-            map_pixel(cam->proj, table_f64(ia.sin_t, x), table_f64(ia.cos_t, x), table_f64(ia.tan_p, y), sw, sh, fx, fy);
-            // an owned pixel is unmasked; where the whole wave samples away from the frame's
-            // last row and column the taps need no border handling at all
-            Taps tp = tap_base(fx, fy);
-            TapBytes tb;
-            if (__ballot(!taps_interior(tp, sw, sh)) == 0ull) {
-                tb = load_taps_interior(cam->frame, sw, tp);
-            } else {
-                tp.x1 = min(tp.x1, sw - 1);
-                tp.y1 = min(tp.y1, sh - 1);
-                tb = load_taps(cam->frame, sw, tp);
-            }
-            const size_t g = ((size_t)y * W + x) * 3;
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                float v = PERCAM ? lerp4(lut_at(gl, tb.v[0][c]), lut_at(gl, tb.v[1][c]), lut_at(gl, tb.v[2][c]),
-                                         lut_at(gl, tb.v[3][c]), tp)
-                                 : lerp4(lut_at(s_lut, tb.v[0][c]), lut_at(s_lut, tb.v[1][c]), lut_at(s_lut, tb.v[2][c]),
-                                         lut_at(s_lut, tb.v[3][c]), tp);
-                v = v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v);
-                if (mosaic_f32) mosaic_f32[g + c] = v;
-                mosaic[g + c] = (uint8_t)(int)(255.0f * v);
-            }
-        };
-        // The interior pixels of a wave nearly always have one owner (a pixel is interior
-        // when everything within the blur radius of it has): then the camera record is read
-        // through a wave-uniform address - scalar loads of its 9 doubles instead of 64 lanes
-        // fetching the same 120 bytes each.
-        const int own_u = __builtin_amdgcn_readfirstlane(own);
-        if (__ballot(own != own_u) == 0)
-            shade(ia.cams + own_u, ia.lut + (size_t)own_u * 256);
+        if (PERCAM)
+            shade_interior_of<LUT_GLOBAL>(own, ia.lut, 256, ia, x, y, W, mosaic, mosaic_f32);
         else
-            shade(ia.cams + own, ia.lut + (size_t)own * 256);
+            shade_interior_of<LUT_LDS>(own, s_lut, 0, ia, x, y, W, mosaic, mosaic_f32);
         return;
     }
     float layer[L][3], wsum[L];
@@ -1394,12 +1398,12 @@ extern "C" int pano_multiband_compose(pano_ctx *ctx, const pano_patch *patches, 
     if (part == 1) {
         if (percam)
             PANO_TIMED(PK_COMPOSE_INTERIOR, s,
-                       hipLaunchKernelGGL(compose_interior_kernel<true>, grid, block, 0, s, H, W,
-                                          xs0, xs1, owner, mosaic, mosaic_f32, ia));
+                       hipLaunchKernelGGL(compose_interior_kernel<LUT_GLOBAL>, grid, block, 0, s, H,
+                                          W, xs0, xs1, owner, mosaic, mosaic_f32, ia, lut_stride));
         else
             PANO_TIMED(PK_COMPOSE_INTERIOR, s,
-                       hipLaunchKernelGGL(compose_interior_kernel<false>, grid, block, 0, s, H, W,
-                                          xs0, xs1, owner, mosaic, mosaic_f32, ia));
+                       hipLaunchKernelGGL(compose_interior_kernel<LUT_LDS>, grid, block, 0, s, H,
+                                          W, xs0, xs1, owner, mosaic, mosaic_f32, ia, lut_stride));
         PANO_LAUNCH_CHECK("compose_interior_kernel");
         return PANO_OK;
     }
