@@ -117,7 +117,7 @@ def scaling_projection(workload):
     world 1, 2, 4, 8 and the factors they project.  A projection from one GPU, not a measurement
     of N; the newest round's file with worlds 1 and 8 wins."""
     import glob
-    best = None
+    best = {}                       # kept geometry? -> the entry to quote
     for path in glob.glob(os.path.join(ROOT, "profiles", "r*", f"strip_floor_{workload}*.json")):
         try:
             with open(path) as fid:
@@ -131,19 +131,30 @@ def scaling_projection(workload):
             if 1 in rows and 8 in rows:
                 rel = os.path.relpath(path, ROOT).split(os.sep)
                 key = (rel[1], rel[-1].endswith("_final.json"), rel[-1], k)
-                if best is None or key > best[0]:
-                    best = (key, path, entry, rows)
-    if best is None:
+                kept = bool(entry.get("kept_geometry"))
+                if kept not in best or key > best[kept][0]:
+                    best[kept] = (key, path, entry, rows)
+    if False not in best:
         return None
-    _, path, entry, rows = best
-    return {"source": os.path.relpath(path, ROOT), "emulated_on_one_gpu": True,
-            "exchange": "excluded (uint8 strips gathered over xGMI behind the next stitch)",
-            "lanes_per_rank": entry.get("lanes"), "plan_from_memo": entry.get("plan_cached"),
-            "trusted_layouts": entry.get("trusted_layouts"),
-            "ms_per_stitch_and_rank": {str(w): rows[w] for w in sorted(rows)},
-            "factor_vs_world_1": {str(w): rows[1] / rows[w] for w in sorted(rows) if w > 1},
-            "note": "slowest of ranks 0, N/2, N-1, each emulated alone on one MI355X; unmeasured on "
-                    "multi-GPU hardware"}
+    _, path, entry, rows = best[False]
+    out = {"source": os.path.relpath(path, ROOT), "emulated_on_one_gpu": True,
+           "exchange": "excluded (uint8 strips gathered over xGMI behind the next stitch)",
+           "lanes_per_rank": entry.get("lanes"), "plan_from_memo": entry.get("plan_cached"),
+           "trusted_layouts": entry.get("trusted_layouts"),
+           "ms_per_stitch_and_rank": {str(w): rows[w] for w in sorted(rows)},
+           "factor_vs_world_1": {str(w): rows[1] / rows[w] for w in sorted(rows) if w > 1},
+           "note": "slowest of ranks 0, N/2, N-1, each emulated alone on one MI355X; unmeasured on "
+                   "multi-GPU hardware"}
+    if True in best:
+        # the same emulation with the geometry kept from stitch to stitch (Engine.keep_geometry:
+        # a fixed rig's owner map, masks, record table and work list are not recomputed; only the
+        # warp, the blur and the collapse run) - factors against ITS OWN world 1
+        _, kpath, _, krows = best[True]
+        out["with_kept_geometry"] = {
+            "source": os.path.relpath(kpath, ROOT),
+            "ms_per_stitch_and_rank": {str(w): krows[w] for w in sorted(krows)},
+            "factor_vs_world_1": {str(w): krows[1] / krows[w] for w in sorted(krows) if w > 1}}
+    return out
 
 
 def measured_traffic(times, steps, workload):
@@ -567,7 +578,7 @@ def secondary_single_gpu(eng, fence):
     from pano360_amd import engine, synth
     out = {}
 
-    def stitches(name, steps, warmup, distinct=None, use=None, cached=False, in_flight=1):
+    def stitches(name, steps, warmup, distinct=None, use=None, cached=False, in_flight=1, kept=False):
         use = use or eng
         cfg = workload(name)
         rots, intrs = synth.make_cameras(cfg["n"], cfg["width"], cfg["height"],
@@ -589,8 +600,10 @@ def secondary_single_gpu(eng, fence):
         state = dict(i=0, serial=False)
         # with the plan out of the memo every stitch repeats the previous one's Plan object: the
         # engine queues it with the verified layout and does not wait (Engine.trust_layouts)
+        # (kept: and re-uses the owner map, masks, record table and work list that stitch left on
+        # the device - Engine.keep_geometry)
         for e, _ in lanes:
-            e.trust_layouts(bool(cached))
+            e.trust_layouts(bool(cached), keep_geometry=bool(cached and kept))
 
         class AllLanes:                      # timing and kernel times over every lane
             def timing(self, on):
@@ -662,6 +675,20 @@ def secondary_single_gpu(eng, fence):
                          "stitch at a time (compare with cfg3_one_in_flight)")
         return entry
     guarded("cfg3_plan_cached", cached)
+
+    def geometry_kept(name, steps, warmup, in_flight):
+        entry = stitches(name, steps, warmup, cached=True, kept=True, in_flight=in_flight)
+        entry["what"] = ("a fixed rig: the plan out of the memo, trusted layouts AND the geometry kept "
+                         "on the device from stitch to stitch (Engine.keep_geometry: owner map, valid "
+                         "mask, interior map, record table, tile flags and the blur's work list are "
+                         "functions of the cameras alone and are not recomputed; the warp, the blur "
+                         "and the collapse run on the new pixels).  The reference recomputes all of it "
+                         "per stitch (stitcher.py:196-204, 276-306) to the same values, as the "
+                         "headline does; mosaics bit-identical "
+                         "(test_kept_geometry_stitches_equal_waiting_ones).  kernel_ms_per_step shows "
+                         "which kernels ran")
+        return entry
+    guarded("cfg3_geometry_kept", lambda: geometry_kept("cfg3", 20, 3, 2))
 
     def with_upload():
         """Config 3 with the frames coming from the HOST every stitch (pinned memory, one copy per
@@ -744,6 +771,7 @@ def secondary_single_gpu(eng, fence):
                          "neither recomputes the geometry nor waits inside the stitch; every kernel runs")
         return entry
     guarded("cfg2_plan_cached", cfg2_cached)
+    guarded("cfg2_geometry_kept", lambda: geometry_kept("cfg2", 40, 4, 1))
 
     def cfg4(detect):
         steps = 16 if detect else 20            # (two frames in flight: a few frames per lane to warm up)
@@ -855,7 +883,7 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    def run_strips(exchange, cache_plan=True):
+    def run_strips(exchange, cache_plan=True, keep_geometry=False):
         """ONE panorama (image set 0) split into column strips, one per rank; the finished
         strips are composed on rank 0 (strong scaling)."""
         # three stitches in flight per rank (PANO_STRIPS_IN_FLIGHT): consecutive stitches go
@@ -871,7 +899,8 @@ def main():
                                        n_levels, rank, world, exchange=exchange,
                                        depth=max(2, n_lanes), cache_plan=cache_plan,
                                        lane_groups=os.environ.get("PANO_LANE_GROUPS", "shared"),
-                                       trust_layouts=os.environ.get("PANO_TRUST_LAYOUT", "1") != "0")
+                                       trust_layouts=os.environ.get("PANO_TRUST_LAYOUT", "1") != "0",
+                                       keep_geometry=keep_geometry)
         frames = upload(0, runner.my_frames)
         serial = dict(on=False)
 
@@ -1217,6 +1246,16 @@ def main():
                              "the headline's strips with the host geometry recomputed every stitch "
                              "(engine.Plan per stitch, as stitcher.py:276-302 does; --no-plan-cache "
                              "makes this the headline)")}
+            # a fixed rig: the geometry kept on the device too (Engine.keep_geometry): the owner
+            # map, masks, record table and work list of a rank's strip are not recomputed
+            e4, p4, _, _, _ = run_strips(args.exchange, cache_plan=True, keep_geometry=True)
+            if rank == 0:
+                out["secondary"]["strips_geometry_kept"] = {
+                    "ms_per_step": e4 / args.steps * 1e3,
+                    "value": p4.patch_pixels / e4 * args.steps / 1e6,
+                    "what": "the strips with plan memo, trusted layouts and the geometry kept on the "
+                            "device from stitch to stitch: each rank runs the warp, the blur and the "
+                            "collapse of its strip only (bit-identical mosaics)"}
         except Exception as err:       # noqa: BLE001
             if dog.cancel() and rank == 0:
                 out["secondary"]["error"] = repr(err)[:300]

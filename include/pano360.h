@@ -644,7 +644,16 @@ typedef struct pano_stitch_args {
                                 * when everything is queued.  out: 2 = it did, 0 = it took the
                                 * waiting path (first stitch of a shape, option off, ...).  Every
                                 * kernel still runs; what is trusted is only that the same cameras
-                                * give the same layout, which pano_stitch_verify checks. */
+                                * give the same layout, which pano_stitch_verify checks.
+                                * in: 3 = the same promise, and the geometry may be KEPT: the owner
+                                * map, valid mask, interior map, record table, tile flags and the
+                                * context's work list are functions of exactly what the caller
+                                * vouches for; when the buffers are the previous stitch's (owner,
+                                * valid, table, interior, tile_flags, need, the arenas, sin_t - same
+                                * pointers) and no other call has entered the context since, only
+                                * the warp, the blur and the collapse are queued: out 4.  Otherwise
+                                * as 1.  The reference recomputes all of it per stitch
+                                * (stitcher.py:276-306, 196-204) - to the same values. */
     pano_layout layout;        /* out */
 } pano_stitch_args;
 int pano_stitch_multiband(pano_ctx *ctx, pano_stitch_args *args, int resume);

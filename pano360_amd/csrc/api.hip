@@ -60,6 +60,8 @@ extern "C" int pano_ctx_create(int device, void *stream, pano_ctx **out) {
 }
 
 int pano_ctx_enter(pano_ctx *ctx) {
+    // any call but the stitch's own may write the buffers a stitch left its geometry in
+    if (!ctx->in_stitch) ctx->geom_valid = false;
     PANO_HIP(hipSetDevice(ctx->device));
     return PANO_OK;
 }

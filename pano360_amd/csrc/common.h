@@ -89,6 +89,7 @@ struct PanoTapSet {                 // one set of Gaussian apertures (pano_multi
 
 struct LayoutSummary;               // layout.h
 
+#define GEOM_BUFS 10
 struct pano_ctx {
     int device;
     hipStream_t stream;
@@ -126,6 +127,10 @@ struct pano_ctx {
     bool lay_prev_verified;         // lay_prev was read back (device summary) or made on the host
     bool trusted_pending;           // a trusted stitch's summary has not been compared yet
     int lay_prev_used_need;
+    // kept geometry (args->trust_layout = 3): the previous stitch of this context went through whole
+    // with these buffers and no other call has entered the context since (pano_ctx_enter clears it)
+    bool geom_valid, in_stitch;
+    const void *geom_bufs[GEOM_BUFS];
     int lay_count[2];               // stitches that went through on the device layout / fell back
     // pano_sift_extrema: the list of scale-space extrema between its two kernels (+ its counter)
     uint32_t *sift_raw;
@@ -147,6 +152,13 @@ int pano_ctx_tap_set_built(pano_ctx *ctx, PanoTapSet *set);
     if (int rc_ = pano_ctx_enter(ctx)) return rc_;                 \
     void *const stream = (void *)(ctx)->stream;                    \
     (void)stream
+
+// An entry point that only READS what a stitch left behind (the crop reads the valid mask): the
+// kept geometry (stitch.hip) survives it.
+#define PANO_ENTER_READONLY(ctx, who)                              \
+    const bool geom_keep_ = (ctx) != nullptr && (ctx)->geom_valid; \
+    PANO_ENTER(ctx, who);                                          \
+    (ctx)->geom_valid = geom_keep_
 
 void pano_timing_edge(pano_ctx *ctx, int kid, hipStream_t stream, bool begin);
 

@@ -227,7 +227,7 @@ __global__ __launch_bounds__(64) void crop_finalize_kernel(const int32_t *__rest
 
 extern "C" int pano_crop_rect(pano_ctx *ctx, const uint8_t *valid, int H, int W, int32_t *heights,
                               int64_t *result) {
-    PANO_ENTER(ctx, "pano_crop_rect");
+    PANO_ENTER_READONLY(ctx, "pano_crop_rect");
     PANO_REQUIRE(valid && heights && result, "pano_crop_rect: null pointer");
     PANO_REQUIRE(H > 0 && W > 0, "pano_crop_rect: bad shape %dx%d", H, W);
     PANO_REQUIRE(W <= CROP_CHUNK * CROP_MAX_CHUNKS, "pano_crop_rect: width %d above %d", W,

@@ -180,8 +180,11 @@ static void stitch_signature(const pano_stitch_args *a, int *sig) {
 // Everything behind the record table: its upload (host layout) or nothing (device layout),
 // the tile flags / warp-need flags, the warp, the blur's work list, the blur, the collapse.
 // `lay`: the layout, or - device layout - the bounds the launches are sized by.
+// `kept`: the tile flags, the warp-need flags and the blur's work list are the previous stitch's
+// (kept geometry): only the warp, the blur and the collapse are queued.
 static int queue_tail(pano_ctx *ctx, pano_stitch_args *a, const pano_layout &lay, bool device_table,
-                      int need_choice, bool two_streams, bool interior, int n_blur, int tile_grid) {
+                      int need_choice, bool two_streams, bool interior, int n_blur, int tile_grid,
+                      bool kept = false) {
     const hipStream_t s = ctx->stream;
     const bool use_blur = n_blur > 0 && lay.n_records > 0;
     const int nr = lay.n_records;
@@ -203,7 +206,10 @@ static int queue_tail(pano_ctx *ctx, pano_stitch_args *a, const pano_layout &lay
     // Warp only what is read: worth it when the rectangles are wide against the blur's reach
     // (8 x 1080p: -4 %; on 32 x 4K nearly every tile is within reach)
     a->used_need = 0;
-    if (interior && tile_grid == 32 && nr && a->tile_flags && a->need) {
+    if (kept) {
+        a->used_need = need_choice == 1;
+        two_streams = false;
+    } else if (interior && tile_grid == 32 && nr && a->tile_flags && a->need) {
         bool on = need_choice == 1;
         if (need_choice < 0) {
             double sum = 0.0;
@@ -239,6 +245,10 @@ static int queue_tail(pano_ctx *ctx, pano_stitch_args *a, const pano_layout &lay
                                    a->used_need ? a->need : nullptr))
         return rc;
     if (two_streams && interior) PANO_HIP(hipStreamWaitEvent(s, ctx->ev_join, 0));
+    if (kept && use_blur) {                      // the work list in the context's buffers is this table's
+        ctx->prepared_table = a->table;
+        ctx->prepared_n = nr;
+    }
     if (n_blur)
         if (int rc = pano_multiband_blur(ctx, a->table, nr, lay.max_aw, lay.max_vh, lay.max_ah,
                                          a->owner, a->W, a->taps, (const int *)a->ntaps, n_blur,
@@ -252,8 +262,30 @@ static int queue_tail(pano_ctx *ctx, pano_stitch_args *a, const pano_layout &lay
                                   a->lut, a->lut_stride, a->mosaic, a->mosaic_f32, 0);
 }
 
+// The buffers a stitch leaves its geometry in (and reads it from when it is kept).
+static void geometry_buffers(const pano_stitch_args *a, const void *out[GEOM_BUFS]) {
+    const void *v[GEOM_BUFS] = {a->owner, a->valid, a->table, a->interior, a->tile_flags, a->need,
+                                a->planes, a->blurred, a->scratch, a->sin_t};
+    for (int k = 0; k < GEOM_BUFS; ++k) out[k] = v[k];
+}
+static void geometry_left(pano_ctx *ctx, const pano_stitch_args *a) {
+    geometry_buffers(a, ctx->geom_bufs);
+    ctx->geom_valid = true;
+}
+
+namespace {
+struct StitchScope {                 // the stitch's own nested calls do not void the kept geometry
+    pano_ctx *ctx;
+    explicit StitchScope(pano_ctx *c) : ctx(c) { ctx->in_stitch = true; }
+    ~StitchScope() { ctx->in_stitch = false; }
+};
+}  // namespace
+
 extern "C" int pano_stitch_multiband(pano_ctx *ctx, pano_stitch_args *a, int resume) {
+    const bool geom_was_valid = ctx && ctx->geom_valid;  // (PANO_ENTER is a foreign call's entry too)
     PANO_ENTER(ctx, "pano_stitch_multiband");
+    ctx->geom_valid = false;
+    StitchScope scope(ctx);
     PANO_REQUIRE(a, "pano_stitch_multiband: null arguments");
     PANO_REQUIRE(a->cams && a->rects && a->sin_t && a->cos_t && a->tan_p && a->lut && a->owner &&
                      a->valid && a->marks && a->regions && a->regions_host && a->records_host &&
@@ -297,12 +329,32 @@ extern "C" int pano_stitch_multiband(pano_ctx *ctx, pano_stitch_args *a, int res
         pano_layout bound = ctx->lay_prev;
         // a trusted stitch (args->trust_layout = 1, see below) needs the verified layout of the
         // same shape; its summary is checked first if one is still pending
-        const bool want_trust = a->trust_layout == 1;
+        const bool want_keep = a->trust_layout == 3;
+        const bool want_trust = a->trust_layout == 1 || want_keep;
         a->trust_layout = 0;
         if (ctx->trusted_pending && !(want_trust && spec))
             if (int rc = pano_stitch_verify(ctx)) return rc;
         const bool trusted = want_trust && spec && ctx->lay_prev_verified &&
                              ctx->opt[PANO_OPT_STITCH_ASYNC] == 1;
+        if (want_keep && trusted && geom_was_valid) {
+            // Kept geometry: the owner map, the valid mask, the interior map, the record table, the
+            // tile flags and the blur's work list are functions of the cameras, rectangles, strip and
+            // resident frames alone - what the caller vouches for - and lie untouched where this
+            // context's previous stitch left them: the frames' pixels go through the warp, the blur
+            // and the collapse, nothing else is queued.
+            const void *bufs[GEOM_BUFS];
+            geometry_buffers(a, bufs);
+            if (memcmp(bufs, ctx->geom_bufs, sizeof(bufs)) == 0) {
+                if (int rc = queue_tail(ctx, a, ctx->lay_prev, true, ctx->lay_prev_used_need, false,
+                                        interior, n_blur, tile_grid, true))
+                    return rc;
+                a->layout = ctx->lay_prev;
+                a->trust_layout = 4;                             // out: geometry kept, nobody waited
+                ctx->geom_valid = true;
+                ++ctx->lay_count[0];
+                return PANO_OK;
+            }
+        }
         if (spec) {
             if (int rc = ensure_layout_buffers(ctx, a->n)) return rc;
             // rectangles and resident flags for the layout kernel: uploaded when they changed,
@@ -400,6 +452,7 @@ extern "C" int pano_stitch_multiband(pano_ctx *ctx, pano_stitch_args *a, int res
                 a->used_need = ctx->lay_prev_used_need;
                 a->trust_layout = 2;                             // out: went through without a wait
                 ctx->trusted_pending = true;
+                geometry_left(ctx, a);
                 ++ctx->lay_count[0];
                 return PANO_OK;
             }
@@ -417,6 +470,7 @@ extern "C" int pano_stitch_multiband(pano_ctx *ctx, pano_stitch_args *a, int res
                 ctx->lay_prev = a->layout;
                 ctx->lay_prev_used_need = a->used_need;
                 ctx->lay_prev_verified = true;
+                geometry_left(ctx, a);
                 ++ctx->lay_count[0];
                 return PANO_OK;
             }
@@ -460,6 +514,7 @@ extern "C" int pano_stitch_multiband(pano_ctx *ctx, pano_stitch_args *a, int res
         ctx->lay_prev_used_need = a->used_need;
         ctx->lay_prev_valid = true;
         ctx->lay_prev_verified = true;       // laid out on the host from this stitch's own regions
+        geometry_left(ctx, a);
     }
     return rc;
 }
@@ -472,7 +527,7 @@ extern "C" int pano_stitch_multiband(pano_ctx *ctx, pano_stitch_args *a, int res
 extern "C" int pano_stitch_verify(pano_ctx *ctx) {
     PANO_REQUIRE(ctx, "pano_stitch_verify: null context");
     if (!ctx->trusted_pending) return PANO_OK;
-    if (int rc = pano_ctx_enter(ctx)) return rc;
+    PANO_HIP(hipSetDevice(ctx->device));                 // (writes no buffer: kept geometry stays)
     PANO_HIP(hipEventSynchronize(ctx->ev_regions));
     ctx->trusted_pending = false;
     const LayoutSummary sum = *ctx->lay_sum_host;
@@ -484,6 +539,7 @@ extern "C" int pano_stitch_verify(pano_ctx *ctx) {
                       sum.max_ah == v.max_ah && sum.missing == 0;
     if (!same) {
         ctx->lay_prev_valid = ctx->lay_prev_verified = false;
+        ctx->geom_valid = false;
         pano_set_error("pano_stitch_verify: a trusted stitch laid out %d records (ok %d, why %d) where "
                        "the verified layout has %d: the cameras were not those of the verified stitch",
                        sum.n_records, sum.ok, sum.why, v.n_records);

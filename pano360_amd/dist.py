@@ -232,7 +232,8 @@ class ShardedStitcher:
 
     def __init__(self, eng, shapes, rots, intrs, n_levels, rank, world, max_resolution=10 ** 9,
                  group=None, exchange="gather", depth=2, cache_plan=True,
-                 force_collective=False, lane_groups="shared", trust_layouts=None):
+                 force_collective=False, lane_groups="shared", trust_layouts=None,
+                 keep_geometry=False):
         # ``eng``: one engine, or a list of them - "lanes": consecutive stitches then alternate
         # between the engines, each on a stream of its own with its own exchange buffers, so
         # that one stitch's kernels cover the other's host round trip (on a column strip of a
@@ -305,9 +306,12 @@ class ShardedStitcher:
             # object: the engine then queues it with the verified layout and does not wait
             # (Engine.trust_layouts; checked when the mosaic is collected)
             # (``trust_layouts``: None = whenever the plan comes out of the memo; False = never)
+            # (``keep_geometry``: a trusted repeat also re-uses the owner map, masks, record table
+            # and work list its lane's previous stitch left on the device - Engine.keep_geometry)
             if exchange and hasattr(use, "trust_layouts"):
                 use.trust_layouts(bool(cache_plan) if trust_layouts is None
-                                  else bool(trust_layouts and cache_plan))
+                                  else bool(trust_layouts and cache_plan),
+                                  keep_geometry=bool(keep_geometry))
             self.lanes.append((use, stream, ex))
         self.exchange = self.lanes[0][2]
         self.count = 0

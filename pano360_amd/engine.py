@@ -742,7 +742,14 @@ class Engine:
         # the layout the device really made.  Off by default: a caller that mutates a Plan in
         # place between stitches must not switch it on.
         self.trust_layout = False
-        self._trusted = None            # (signature, Plan, FusedPatches) of the last verified stitch
+        # ``keep_geometry`` (with trusted stitches): such a repeat also re-uses what the previous
+        # stitch left on the device - owner map, valid mask, interior map, record table, tile
+        # flags, the blur's work list, all functions of the same inputs - and queues the warp, the
+        # blur and the collapse alone (trust_layout = 3).  The owner / valid tensors are then the
+        # SAME tensors from stitch to stitch: read-only for the caller.
+        self.keep_geometry = False
+        self.last_kept_geometry = False
+        self._trusted = None            # (signature, Plan, FusedPatches, owner, valid) of the last verified stitch
 
     def __del__(self):
         ctx, self._ctx = getattr(self, "_ctx", None), None
@@ -1342,8 +1349,6 @@ class Engine:
         max_spans = 4
         ws = self._stitch_workspace(H, W, plan.n, max_spans)
         a = ws["args"]
-        owner = torch.empty((H, W), dtype=torch.int16, device=self.device)
-        valid = torch.empty((H, W), dtype=torch.uint8, device=self.device)
         mosaic = (mosaic_out if mosaic_out is not None else
                   torch.empty((H, W, 3), dtype=torch.uint8, device=self.device))
         fl = (torch.empty((H, W, 3), dtype=torch.float32, device=self.device)
@@ -1358,7 +1363,7 @@ class Engine:
         a.sin_t, a.cos_t, a.tan_p = (ptr(t) for t in plan.dev)
         a.lut, a.lut_stride = lut, lut_stride
         a.taps, a.ntaps = taps.ctypes.data, C.cast(ntaps, C.c_void_p)
-        a.owner, a.valid, a.mosaic, a.mosaic_f32 = ptr(owner), ptr(valid), ptr(mosaic), ptr(fl)
+        a.mosaic, a.mosaic_f32 = ptr(mosaic), ptr(fl)
         a.marks, a.regions, a.regions_host = ptr(ws["marks"]), ptr(ws["regions"]), ptr(ws["regions_host"])
         a.block_owner, a.interior = ptr(ws["bown"]), ptr(ws["interior"])
         a.records_host, a.table, a.cap_records = ptr(ws["records_host"]), ptr(ws["table"]), ws["cap"]
@@ -1372,8 +1377,14 @@ class Engine:
                tuple(sorted(have)), tuple(id(self._arenas.get(k)) for k in ("planes", "blurred", "scratch")),
                id(ws["tiles"]))
         kept = self._trusted
-        a.trust_layout = 1 if (self.trust_layout and kept is not None and kept[0] == sig
-                               and kept[1] is plan) else 0
+        repeat = (self.trust_layout and kept is not None and kept[0] == sig and kept[1] is plan)
+        a.trust_layout = (3 if self.keep_geometry else 1) if repeat else 0
+        if repeat and self.keep_geometry:
+            owner, valid = kept[3], kept[4]         # where the verified stitch left them
+        else:
+            owner = torch.empty((H, W), dtype=torch.int16, device=self.device)
+            valid = torch.empty((H, W), dtype=torch.uint8, device=self.device)
+        a.owner, a.valid = ptr(owner), ptr(valid)
         resume = 0
         a.layout.missing = a.layout.n_records = 0   # (an early failure must not read a previous stitch's)
         while True:
@@ -1402,9 +1413,13 @@ class Engine:
                                      f"{strip[1]}) but are not resident on this device")
             _lib.check(status, "pano_stitch_multiband")
         lay = a.layout
-        if a.trust_layout == 2:
+        if a.trust_layout in (2, 4):
             # queued with the verified layout, nobody waited: the records are the previous stitch's
+            # (4: and so are the owner map, the masks and the work list - nothing was recomputed)
             patches = kept[2]
+            if self.keep_geometry:
+                self._trusted = kept[:3] + (owner, valid)
+            self.last_kept_geometry = a.trust_layout == 4
         else:
             rec = ws["records_host"].numpy().view(PATCH_DTYPE)[:lay.n_records].copy()
             patches = FusedPatches.from_records(
@@ -1414,14 +1429,19 @@ class Engine:
             # stitch that grew one of them is not repeated blindly)
             sig = sig[:-2] + (tuple(id(self._arenas.get(k)) for k in ("planes", "blurred", "scratch")),
                               id(ws["tiles"]))
-            self._trusted = (sig, plan, patches) if self.trust_layout else None
+            self._trusted = ((sig, plan, patches) + ((owner, valid) if self.keep_geometry else (None, None))
+                             if self.trust_layout else None)
+            self.last_kept_geometry = False
         if n_blur:
             self.last_tiles = (patches.table, ws["tiles"] if shortcut else None)
         return mosaic, fl, valid, patches
 
-    def trust_layouts(self, on=True):
-        """Switches trusted stitches on (with the device-side layout they ride on) or off."""
+    def trust_layouts(self, on=True, keep_geometry=False):
+        """Switches trusted stitches on (with the device-side layout they ride on) or off;
+        ``keep_geometry``: repeats also re-use the previous stitch's owner map, masks, record
+        table and work list (see ``__init__``)."""
         self.trust_layout = bool(on)
+        self.keep_geometry = bool(on and keep_geometry)
         self._trusted = None
         self.set_option(_lib.OPT_STITCH_ASYNC, 1 if on else 0)
         return self

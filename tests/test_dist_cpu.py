@@ -169,6 +169,35 @@ def test_exchange_world_1_needs_no_process_group():
         assert torch.equal(st.finish(), eng.truth(1))
 
 
+def test_trusted_layouts_and_kept_geometry_reach_the_lanes_engines():
+    """ShardedStitcher switches its lanes' engines to trusted stitches when the plan comes out of
+    the memo, hands `keep_geometry` through, and checks a trusted lane's layout when it collects
+    that lane's mosaic (Engine.trust_layouts / verify_trusted; the GPU side:
+    test_kept_geometry_stitches_equal_waiting_ones)."""
+    shapes, rots, intrs = _scene()
+    shape = engine.Plan(shapes, rots, intrs, True, 10 ** 9).shape
+
+    class Trusting(_HostEngine):
+        def trust_layouts(self, on=True, keep_geometry=False):
+            self.trust_layout, self.keep_geometry = bool(on), bool(on and keep_geometry)
+            self.calls = getattr(self, "calls", []) + [(bool(on), bool(keep_geometry))]
+
+        def verify_trusted(self):
+            self.verified = getattr(self, "verified", 0) + 1
+
+    for cache_plan, keep, want in [(True, True, (True, True)), (True, False, (True, False)),
+                                   (False, True, (False, False))]:
+        eng = Trusting(shape)
+        lanes = [eng, Trusting(shape, eng.clock)]
+        st = pdist.ShardedStitcher(lanes, shapes, rots, intrs, 5, 0, 1, exchange="gather", depth=2,
+                                   cache_plan=cache_plan, keep_geometry=keep)
+        assert all((e.trust_layout, e.keep_geometry) == want for e in lanes)
+        got = [m.clone() for m in (st.step(None)[1] for _ in range(4)) if m is not None]
+        got.append(st.finish().clone())
+        assert all(torch.equal(m, eng.truth(k)) for k, m in enumerate(got))
+        assert sum(getattr(e, "verified", 0) for e in lanes) == (len(got) if cache_plan else 0)
+
+
 def _forced_world1_worker(rank, world, port, result):
     """One rank, a real (gloo) process group, the collectives FORCED: the very calls of a world-N
     run - `dist.gather` on views of one buffer / `dist.reduce(uint8, SUM)`, `async_op=True`,

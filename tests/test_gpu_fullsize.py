@@ -586,6 +586,27 @@ def test_cfg3_full_size_strips_equal_whole(eng, world):
             assert torch.equal(got[:, c0:c1], whole[:, c0:c1]), k
         fast.verify_trusted()
         assert fast.stitch_counts()[0] >= 4 and fast.stitch_counts()[1] == 0
+        # ... and with the geometry kept (Engine.keep_geometry): the owner map, masks, records and
+        # work list of the first stitch serve the others; new pixels in the second and fourth
+        del fast
+        keeping = engine.Engine(eng.device).trust_layouts(True, keep_geometry=True)
+        want_other = eng.stitch(other, plan, "multiband", levels)[0]
+        kept = 0
+        for k in range(4):
+            plan_t = keeping.cached_plan(shapes, rots, intrs, True, 10 ** 9)
+            got = keeping.multiband_fused(other if k & 1 else frames, plan_t, levels)[0]
+            kept += keeping.last_kept_geometry
+            assert torch.equal(got, want_other if k & 1 else whole), k
+        keeping.verify_trusted()
+        assert kept == 3
+        for k in range(3):
+            plan_s = keeping.cached_plan(shapes, rots, intrs, True, 10 ** 9, st.table_cols)
+            got = keeping.multiband_fused([(other if k & 1 else frames)[i] for i in st.my_frames], plan_s,
+                                          levels, frame_ids=st.my_frames, strip=st.strip)[0]
+            kept += keeping.last_kept_geometry
+            assert torch.equal(got[:, c0:c1], (want_other if k & 1 else whole)[:, c0:c1]), k
+        keeping.verify_trusted()
+        assert kept == 5
 
 
 def test_cfg4_keypoints_of_a_4k_frame_against_a_windowed_oracle(eng):

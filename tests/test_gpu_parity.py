@@ -443,8 +443,8 @@ def test_trusted_stitches_equal_waiting_ones_and_a_broken_promise_is_caught(stri
     rots2, _ = synth.make_cameras(n, w, h, sweep_deg=100.0, jitter=0.004, seed=2)
     other = trusting.upload_plan(engine.Plan(shapes, rots2, intrs, True, 10 ** 9))
     if other.shape == plan_t.shape:
-        sig, _, kept = trusting._trusted
-        trusting._trusted = ((id(other),) + sig[1:], other, kept)
+        sig, _, kept = trusting._trusted[:3]
+        trusting._trusted = ((id(other),) + sig[1:], other, kept) + trusting._trusted[3:]
         trusting.multiband_fused(frames, other, 5, frame_ids=ids, strip=strip)
         with pytest.raises(_lib.PanoError, match="verified"):
             trusting.verify_trusted()
@@ -452,6 +452,56 @@ def test_trusted_stitches_equal_waiting_ones_and_a_broken_promise_is_caught(stri
     got, _, got_valid, _ = trusting.multiband_fused(frames, plan_t, 5, frame_ids=ids, strip=strip)
     torch.cuda.synchronize()
     assert torch.equal(got[:, c0:c1], want[:, c0:c1]) and torch.equal(got_valid[:, c0:c1], want_valid[:, c0:c1])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("strip_case", [False, True])
+def test_kept_geometry_stitches_equal_waiting_ones(strip_case):
+    """Engine.trust_layouts(keep_geometry=True): a repeat of the verified stitch re-uses the owner
+    map, valid mask, interior map, record table, tile flags and work list the previous stitch left
+    on the device (pano_stitch_args.trust_layout = 3 -> 4) and queues the warp, the blur and the
+    collapse alone.  With NEW pixels in the frames every mosaic equals the waiting engine's, float
+    image included; the ownership kernel does not run in a kept stitch; any other call through the
+    context voids the kept geometry (the next stitch recomputes it, then keeps again)."""
+    import torch
+    from pano360_amd import engine, synth
+    n, w, h = 8, 480, 270
+    rots, intrs = synth.make_cameras(n, w, h, sweep_deg=140.0, jitter=0.004, seed=1)
+    shapes = [(h, w)] * n
+    waiting = engine.Engine("cuda:0")
+    keeping = engine.Engine("cuda:0").trust_layouts(True, keep_geometry=True)
+    W = engine.Plan(shapes, rots, intrs, True, 10 ** 9).shape[1]
+    strip = (W // 4 + 3, W // 2 + 1) if strip_case else None
+    c0, c1 = strip if strip else (0, W)
+    ids = list(range(n))
+    took, ran_ownership = [], []
+    for k in range(7):
+        frames = waiting.upload_frames([synth.make_frame(100 * k + i, w, h, "A") for i in range(n)])
+        plan_w = waiting.cached_plan(shapes, rots, intrs, True, 10 ** 9)
+        want, want_f, want_valid, _ = waiting.multiband_fused(frames, plan_w, 5, frame_ids=ids, strip=strip,
+                                                              want_float=True)
+        plan_k = keeping.cached_plan(shapes, rots, intrs, True, 10 ** 9)
+        if k == 4:      # a foreign call on the context: the kept geometry is void
+            keeping.ownership_cameras(plan_k, cams=keeping.camera_table(plan_k, dict(zip(ids, frames))))
+        if k == 2 and not strip_case:      # ... the crop only reads the valid mask: it is not
+            assert keeping.crop_rect(want_valid) == waiting.crop_rect(want_valid)
+        keeping.timing(True)
+        got, got_f, got_valid, patches = keeping.multiband_fused(frames, plan_k, 5, frame_ids=ids, strip=strip,
+                                                                 want_float=True)
+        torch.cuda.synchronize()
+        ran_ownership.append("ownership_cameras_kernel" in keeping.kernel_times())
+        keeping.timing(False)
+        took.append(keeping._stitch_ws[next(iter(keeping._stitch_ws))]["args"].trust_layout)
+        assert took[-1] == (4 if keeping.last_kept_geometry else took[-1])
+        assert torch.equal(got[:, c0:c1], want[:, c0:c1]), (k, took)
+        assert torch.equal(got_f[:, c0:c1], want_f[:, c0:c1]), (k, took)
+        assert torch.equal(got_valid[:, c0:c1], want_valid[:, c0:c1]), (k, took)
+        assert len(patches) > 0
+        keeping.verify_trusted()
+    # the first stitch lays out on the host and leaves its geometry; repeats keep it; the foreign
+    # call before stitch 4 voids it once
+    assert took[0] == 0 and took[1] == 4 and took[3] == 4 and took[4] in (0, 2) and took[6] == 4, took
+    assert ran_ownership == [t != 4 for t in took], (ran_ownership, took)
 
 
 @pytest.mark.parametrize("case", ["sweep", "tilted", "dense", "crowd", "strip"])

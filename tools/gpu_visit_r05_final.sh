@@ -36,6 +36,8 @@ echo "== 2-rank dry run on one GPU through bench.py's own launcher (gloo)"
 PANO_DIST_BACKEND=gloo timeout -k 10 600 python bench.py --gpus 2 --steps 3 --warmup 1 --no-secondary > "$OUT/bench_2rank_selflaunch.json" 2> "$OUT/bench_2rank.err"; cut -c1-700 "$OUT/bench_2rank_selflaunch.json"
 echo "== strip floors, config 3 (three lanes, plan memo, trusted layouts) and config 5 at world 8"
 PANO_PLAN_CACHED=1 PANO_SETS_IN_FLIGHT=3 timeout -k 10 400 python tools/strip_floor.py cfg3 1 2 4 8 --json=$OUT/strip_floor_cfg3_final.json 2>/dev/null | grep "^world" | tee "$OUT/strip_floor_cfg3_final.txt"
+echo "== ... with the geometry kept (Engine.keep_geometry): appended to the same file, flagged kept_geometry"
+PANO_KEEP_GEOMETRY=1 PANO_PLAN_CACHED=1 PANO_SETS_IN_FLIGHT=3 timeout -k 10 400 python tools/strip_floor.py cfg3 1 2 4 8 --json=$OUT/strip_floor_cfg3_final.json 2>/dev/null | grep "^world" | tee "$OUT/strip_floor_cfg3_kept_final.txt"
 PANO_DISTINCT_FRAMES=6 PANO_PLAN_CACHED=1 PANO_SETS_IN_FLIGHT=2 timeout -k 10 900 python tools/strip_floor.py cfg5 1 8 --json=$OUT/strip_floor_cfg5_final.json 2>/dev/null | grep "^world" | tee "$OUT/strip_floor_cfg5_final.txt"
 if grep -l "GPU core dump\|Memory access fault" "$OUT"/*.txt "$OUT"/*.log "$OUT"/*.err 2>/dev/null; then echo "GPU FAULT"; exit 1; fi
 exit 0

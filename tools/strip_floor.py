@@ -30,7 +30,7 @@ for _ in range(max(1, int(os.environ.get("PANO_SETS_IN_FLIGHT", "1"))) - 1):
         LANES.append((engine.Engine(eng.device), _s))
 if os.environ.get("PANO_PLAN_CACHED", "0") != "0" and os.environ.get("PANO_TRUST_LAYOUT", "1") != "0":
     for _e, _ in LANES:      # as ShardedStitcher does with the plan out of the memo
-        _e.trust_layouts(True)
+        _e.trust_layouts(True, keep_geometry=os.environ.get("PANO_KEEP_GEOMETRY", "0") != "0")
 COUNT = [0, False]
 pool = {}
 import gc  # noqa: E402
@@ -39,7 +39,8 @@ gc.freeze()          # the cyclic collector's 37 ms pause would land in one of t
 DISTINCT = int(os.environ.get("PANO_DISTINCT_FRAMES", "0"))    # cfg5: cycle a few 8K frames
 for world in worlds:
     worst = (0.0, None)
-    for rank in sorted({0, world // 2, world - 1}):
+    for rank in (sorted({0, world // 2, world - 1}) if not os.environ.get("PANO_STRIP_RANK")
+                 else [int(os.environ["PANO_STRIP_RANK"])]):
         st = pdist.ShardedStitcher(eng, shapes, rots, intrs, cfg["n_levels"], rank, world,
                                    exchange=None)
         for i in st.my_frames:
@@ -71,6 +72,7 @@ for world in worlds:
         t0 = time.perf_counter()
         for _ in range(20):
             step()
+        host_ms = (time.perf_counter() - t0) / 20 * 1e3     # the host's share: queueing alone
         torch.cuda.synchronize()
         ms = (time.perf_counter() - t0) / 20 * 1e3
         COUNT[1] = True
@@ -82,12 +84,24 @@ for world in worlds:
         kern = sum(v[0] for v in times.values()) / 20
         eng.timing(False)
         if ms > worst[0]:
-            worst = (ms, rank, kern, len(frames), {k: round(v[0] / 20, 3) for k, v in times.items()})
+            worst = (ms, rank, kern, len(frames), {k: round(v[0] / 20, 3) for k, v in times.items()}, host_ms)
     ROWS.append(dict(world=world, rank=worst[1], ms_per_stitch=worst[0], kernel_ms=worst[2],
-                     frames_resident=worst[3], kernels=worst[4]))
+                     frames_resident=worst[3], kernels=worst[4], host_ms_per_stitch=worst[5]))
     sys.stdout.flush()
     print(f"world {world}: slowest of ranks sampled = rank {worst[1]}: {worst[0]:.3f} ms per stitch "
-          f"(timed kernels {worst[2]:.3f} ms, {worst[3]} frames resident) {worst[4]}")
+          f"(host {worst[5]:.3f} ms of it, timed kernels {worst[2]:.3f} ms, {worst[3]} frames resident) {worst[4]}")
+if os.environ.get("PANO_HOST_PROFILE"):
+    # where the host's share goes: the last (world, rank) again under cProfile
+    import cProfile
+    import pstats
+    COUNT[1] = False
+    pr = cProfile.Profile()
+    pr.enable()
+    for _ in range(200):
+        step()
+    pr.disable()
+    torch.cuda.synchronize()
+    pstats.Stats(pr).sort_stats("cumulative").print_stats(28)
 t0 = time.perf_counter()
 for _ in range(50):
     engine.Plan(shapes, rots, intrs, True, 10 ** 9)
@@ -97,6 +111,7 @@ if JSON_OUT:
     entry = dict(config=name, lanes=len(LANES), plan_cached=os.environ.get("PANO_PLAN_CACHED", "0") != "0",
                  stitch_async=os.environ.get("PANO_STITCH_ASYNC", "0"),
                  trusted_layouts=bool(LANES[0][0].trust_layout),
+                 kept_geometry=bool(LANES[0][0].keep_geometry),
                  what="rank r of world N emulated on ONE GPU: its strip's kernels only, no exchange; "
                       "wall ms per stitch of 20 stitches, slowest of ranks 0, N/2, N-1",
                  rows=ROWS)
