@@ -143,8 +143,9 @@ def scaling_projection(workload):
            "trusted_layouts": entry.get("trusted_layouts"),
            "ms_per_stitch_and_rank": {str(w): rows[w] for w in sorted(rows)},
            "factor_vs_world_1": {str(w): rows[1] / rows[w] for w in sorted(rows) if w > 1},
-           "note": "slowest of ranks 0, N/2, N-1, each emulated alone on one MI355X; unmeasured on "
-                   "multi-GPU hardware"}
+           "balanced_strips": entry.get("balanced_strips"),
+           "note": "slowest of the ranks, each emulated alone on one MI355X (what the entry's 'what' "
+                   "says about which ranks); unmeasured on multi-GPU hardware"}
     if True in best:
         # the same emulation with the geometry kept from stitch to stitch (Engine.keep_geometry:
         # a fixed rig's owner map, masks, record table and work list are not recomputed; only the

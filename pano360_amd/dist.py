@@ -75,6 +75,28 @@ def strip_bounds(width, world):
     return [int(round(width * r / world)) for r in range(world + 1)]
 
 
+def balanced_strip_bounds(cost, world, align=8, min_width=64):
+    """Column boundaries that give every rank the same share of ``cost`` (one non-negative
+    number per mosaic column, ``Engine.column_costs``) instead of the same width: cuts at the
+    world-quantiles of the running sum, moved to multiples of ``align`` (the interior block), every
+    strip at least ``min_width`` wide.  Equal widths when the mosaic is too narrow for that."""
+    import numpy as np
+    cost = np.maximum(np.asarray(cost, dtype=np.float64), 0.0)
+    width = len(cost)
+    if world < 1 or width < world * max(min_width, align) or not np.isfinite(cost).all() \
+            or cost.sum() <= 0.0:
+        return strip_bounds(width, max(world, 1))
+    run = np.concatenate([[0.0], np.cumsum(cost)])
+    cuts = np.searchsorted(run, run[-1] * np.arange(1, world) / world, side="left")
+    cuts = [int(round(c / align)) * align for c in cuts]
+    bounds = [0] + cuts + [width]
+    for r in range(1, world):                       # monotone, no strip thinner than min_width
+        bounds[r] = max(bounds[r], bounds[r - 1] + min_width)
+    for r in range(world - 1, 0, -1):
+        bounds[r] = min(bounds[r], bounds[r + 1] - min_width)
+    return bounds
+
+
 def frames_for_strip(rects, strip, margin):
     """Indices of the frames whose patch rectangle intersects the strip grown by
     ``margin`` columns (a superset of what the strip's windows can touch)."""
@@ -233,7 +255,7 @@ class ShardedStitcher:
     def __init__(self, eng, shapes, rots, intrs, n_levels, rank, world, max_resolution=10 ** 9,
                  group=None, exchange="gather", depth=2, cache_plan=True,
                  force_collective=False, lane_groups="shared", trust_layouts=None,
-                 keep_geometry=False):
+                 keep_geometry=False, balance=True):
         # ``eng``: one engine, or a list of them - "lanes": consecutive stitches then alternate
         # between the engines, each on a stream of its own with its own exchange buffers, so
         # that one stitch's kernels cover the other's host round trip (on a column strip of a
@@ -268,7 +290,16 @@ class ShardedStitcher:
         plan = _eng.Plan(shapes, rots, intrs, True, max_resolution)
         radius = max([_eng.gaussian_ksize(s) // 2 for s in _eng.level_sigmas(n_levels)],
                      default=0)
+        # ``balance`` (default): strips of equal WORK - the engine's cost of every column, from the
+        # geometry alone (Engine.column_costs), cut at its quantiles; rank 0's cut is broadcast when
+        # a process group is up, so that every rank uses the same whatever its GPU computed.
+        # Engines without a device (CPU tests) and ``balance=False``: equal widths.
         self.bounds = strip_bounds(plan.shape[1], world)
+        self.balanced = False
+        if balance and world > 1 and hasattr(engines[0], "column_costs"):
+            self.bounds = self._balanced_bounds(engines[0], plan, n_levels, world, group,
+                                                bool(exchange))
+            self.balanced = True
         self.strip = (self.bounds[rank], self.bounds[rank + 1])
         # windows reach one radius past the strip for A's owners and one more for V
         self.my_frames = frames_for_strip(plan.rects, self.strip, 2 * radius)
@@ -316,6 +347,20 @@ class ShardedStitcher:
         self.exchange = self.lanes[0][2]
         self.count = 0
         self.order = []                 # lanes of the stitches whose mosaics are still to come
+
+    @staticmethod
+    def _balanced_bounds(eng, plan, n_levels, world, group, collective):
+        import torch
+        import torch.distributed as dist
+        bounds = balanced_strip_bounds(eng.column_costs(plan, n_levels), world)
+        if collective and dist.is_available() and dist.is_initialized() \
+                and dist.get_world_size(group) == world:
+            staged = dist.get_backend(group) == "gloo"
+            t = torch.tensor(bounds, dtype=torch.int64, device="cpu" if staged else eng.device)
+            dist.broadcast(t, src=dist.get_global_rank(group, 0) if group is not None else 0,
+                           group=group)
+            bounds = [int(v) for v in t.cpu().tolist()]
+        return bounds
 
     @staticmethod
     def _on(stream):
@@ -394,7 +439,8 @@ class ShardedStitcher:
         self.exchange = None
 
 
-def emulate_on_one_device(eng, imgs, rots, intrs, n_levels, world, max_resolution=10 ** 9):
+def emulate_on_one_device(eng, imgs, rots, intrs, n_levels, world, max_resolution=10 ** 9,
+                          balance=True):
     """Run every rank's strip one after the other on a single GPU and compose
     the strips locally - the test double of an N-GPU run."""
     import torch
@@ -402,7 +448,7 @@ def emulate_on_one_device(eng, imgs, rots, intrs, n_levels, world, max_resolutio
     strips, bounds = [], None
     for rank in range(world):
         st = ShardedStitcher(eng, shapes, rots, intrs, n_levels, rank, world, max_resolution,
-                             exchange=None)
+                             exchange=None, balance=balance)
         frames = eng.upload_frames([imgs[i] for i in st.my_frames])
         plan = _eng.Plan(shapes, rots, intrs, True, max_resolution, table_cols=st.table_cols)
         eng.upload_plan(plan)

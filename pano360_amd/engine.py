@@ -941,6 +941,44 @@ class Engine:
                                               _ptr(bown), _ptr(interior)), "pano_interior_map")
         return interior
 
+    # Weights of a column's mosaic pixels (ownership, the collapse's interior pixels), valid pixels
+    # (the warp's windows) and pixels near a seam (the blur's active tiles, the collapse's gathers) in
+    # its cost.  The first two are their kernels' shares of a config-3 stitch (profiles/r05/final);
+    # the third, 0.98 by that count, is calibrated on strips instead: a seam also brings records,
+    # work items and segment leads with it, and world-4 / world-8 splits of config 3 come out level
+    # at 2.5 (profiles/r05/cost_shares_scan_cfg3.txt: slowest rank 0.234 ms against 0.246 at 0.98
+    # and 0.252 at 4, where the end strips become the slow ones)
+    COLUMN_COST_SHARES = (0.27, 0.25, 2.5)
+
+    def column_costs(self, plan, n_levels, shortcut=True):
+        """Relative cost of every mosaic column in a multiband stitch, from the geometry alone (one
+        ownership pass and the interior map of the whole mosaic; no frames): what
+        ``dist.balanced_strip_bounds`` cuts column strips of equal WORK from.  A sweep's first
+        and last cameras own their ends of the mosaic alone - no seam, no blur - so equal-width
+        strips leave the middle ranks a third more than their share (config 3, eight ranks)."""
+        torch = _torch()
+        H, W = plan.shape
+        if not hasattr(plan, "dev"):
+            self.upload_plan(plan)
+        n_blur, radius = self.blur_tables(n_levels)[2:]
+        owner, valid = self.ownership_cameras(plan)
+        a, b, g = self.COLUMN_COST_SHARES
+        if os.environ.get("PANO_COST_SHARES"):                      # (A/B of the model's weights)
+            a, b, g = (float(v) for v in os.environ["PANO_COST_SHARES"].split(","))
+        cost = np.full(W, a / W)
+        per = valid.ne(0).sum(0, dtype=torch.int64).cpu().numpy().astype(np.float64)
+        if per.sum() > 0:
+            cost += b * per / per.sum()
+        if n_blur and shortcut:
+            interior = self.interior_map(owner, radius)
+            near = interior.eq(0).sum(0, dtype=torch.int64).cpu().numpy().astype(np.float64)
+            near = np.repeat(near, self.interior_block)[:W]
+            if near.sum() > 0:
+                cost += g * near / near.sum()
+        elif per.sum() > 0:
+            cost += g * per / per.sum()          # every valid pixel goes through the blur
+        return cost
+
     def active_tile_pixels(self):
         """Pixels of the 32 x 32 tiles the last blur really computed - whole tiles, an upper
         bound - or all of every rectangle A when no tile flags were in use.  Synchronises."""

@@ -198,6 +198,70 @@ def test_trusted_layouts_and_kept_geometry_reach_the_lanes_engines():
         assert sum(getattr(e, "verified", 0) for e in lanes) == (len(got) if cache_plan else 0)
 
 
+def test_balanced_strip_bounds_cut_equal_work():
+    """Strips of equal work: the cuts sit at the quantiles of the column costs (aligned, no strip
+    thinner than the minimum), cover the mosaic, and fall back to equal widths when they cannot."""
+    rng = np.random.default_rng(3)
+    for world in (2, 3, 4, 8):
+        cost = rng.random(13760) + np.where((np.arange(13760) > 3000) & (np.arange(13760) < 11000), 3.0, 0.0)
+        b = pdist.balanced_strip_bounds(cost, world)
+        assert b[0] == 0 and b[-1] == 13760 and len(b) == world + 1
+        assert all(b[r + 1] - b[r] >= 64 for r in range(world)) and all(v % 8 == 0 for v in b[1:-1])
+        work = [cost[b[r]:b[r + 1]].sum() for r in range(world)]
+        assert max(work) / (cost.sum() / world) < 1.01          # (one aligned column either way)
+        even = pdist.strip_bounds(13760, world)
+        assert max(cost[even[r]:even[r + 1]].sum() for r in range(world)) >= max(work)
+    # all the cost in a few columns: the minimum width holds, the order too
+    b = pdist.balanced_strip_bounds(np.r_[np.zeros(5000), np.ones(100), np.zeros(5000)], 4)
+    assert b == sorted(b) and b[0] == 0 and b[-1] == 10100 and min(np.diff(b)) >= 64
+    # too narrow, no cost, nonsense: equal widths
+    assert pdist.balanced_strip_bounds(np.ones(100), 8) == pdist.strip_bounds(100, 8)
+    assert pdist.balanced_strip_bounds(np.zeros(4096), 4) == pdist.strip_bounds(4096, 4)
+    assert pdist.balanced_strip_bounds(np.full(4096, np.nan), 4) == pdist.strip_bounds(4096, 4)
+
+
+def _balanced_worker(rank, world, port, result):
+    """The ranks of a process group take rank 0's cut, whatever their own engine computed."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        shapes, rots, intrs = _scene()
+        shape = engine.Plan(shapes, rots, intrs, True, 10 ** 9).shape
+
+        class Costed(_HostEngine):
+            def column_costs(self, plan, n_levels):
+                cost = np.ones(plan.shape[1])
+                cost[:plan.shape[1] // 3] += 5.0 + rank       # (a rank-dependent answer on purpose)
+                return cost
+
+        eng = Costed(shape)
+        st = pdist.ShardedStitcher(eng, shapes, rots, intrs, 5, rank, world, exchange="gather", depth=2)
+        want = pdist.balanced_strip_bounds(np.where(np.arange(shape[1]) < shape[1] // 3, 6.0, 1.0), world)
+        ok = st.balanced and st.bounds == want and st.bounds != pdist.strip_bounds(shape[1], world)
+        got = []
+        for _ in range(4):
+            previous = st.step(frames=None)[1]
+            if previous is not None:
+                got.append(previous.clone())
+        last = st.finish()
+        if rank == 0:
+            got.append(last.clone())
+            ok = ok and len(got) == 4 and all(torch.equal(m, eng.truth(k)) for k, m in enumerate(got))
+        gathered = [None] * world
+        dist.all_gather_object(gathered, bool(ok))
+        if rank == 0:
+            result.put(all(gathered))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_balanced_strips_over_gloo_take_rank_0s_cut():
+    ctx = mp.get_context("spawn")
+    result = ctx.SimpleQueue()
+    mp.spawn(_balanced_worker, args=(2, _free_port(), result), nprocs=2, join=True)
+    assert result.get() is True
+
+
 def _forced_world1_worker(rank, world, port, result):
     """One rank, a real (gloo) process group, the collectives FORCED: the very calls of a world-N
     run - `dist.gather` on views of one buffer / `dist.reduce(uint8, SUM)`, `async_op=True`,

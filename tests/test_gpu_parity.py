@@ -815,6 +815,15 @@ def test_column_strips_compose_the_single_gpu_mosaic(eng, world):
     strips, bounds = pdist.emulate_on_one_device(eng, imgs, rots, intrs, 5, world)
     assert bounds[-1] == plan.shape[1]
     assert torch.equal(strips, whole)
+    # those were strips of equal work (ShardedStitcher's default: cut at the quantiles of
+    # Engine.column_costs); strips of equal width compose the same mosaic
+    even, even_bounds = pdist.emulate_on_one_device(eng, imgs, rots, intrs, 5, world, balance=False)
+    assert even_bounds == pdist.strip_bounds(plan.shape[1], world) and torch.equal(even, whole)
+    cost = eng.column_costs(plan, 5)
+    assert cost.shape == (plan.shape[1],) and np.isfinite(cost).all() and cost.min() > 0
+    assert bounds == pdist.balanced_strip_bounds(cost, world)
+    work = lambda b: max(cost[b[r]:b[r + 1]].sum() for r in range(world))      # noqa: E731
+    assert work(bounds) <= work(even_bounds) * 1.02
     # the ranks did not all need all frames
     shapes = [im.shape[:2] for im in imgs]
     held = [len(pdist.ShardedStitcher(eng, shapes, rots, intrs, 5, r, world,
