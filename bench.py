@@ -1010,7 +1010,7 @@ def main():
 
     strips = args.mode == "strips" and world > 1
 
-    def build_line(strips, elapsed, plan, patches, times, frames_rank0=None):
+    def build_line(strips, elapsed, plan, patches, times, frames_rank0=None, bounds=None):
         """The JSON line of a measurement (rank 0 only)."""
         sets_per_step = 1 if strips or world == 1 else world
         ms = elapsed / args.steps * 1e3
@@ -1023,6 +1023,9 @@ def main():
                    f"per GPU, frames resident where needed), finished uint8 strips composed on "
                    f"rank 0 over RCCL by {args.exchange}, overlapped with the next stitch; "
                    f"{IN_FLIGHT.get('strips', 1)} consecutive stitches in flight per rank")
+            if bounds is not None:
+                how += ("; strips of equal work (cut at the quantiles of the engine's column costs), "
+                        f"bounds {list(bounds)}")
         elif world > 1:
             how = (f"{world} independent image sets per step, one per GPU (replicas), no "
                    f"data-path collective")
@@ -1217,7 +1220,8 @@ def main():
         os._exit(4)
     out = None
     if rank == 0:
-        out = build_line(True, elapsed, plan, patches, times, len(runner.my_frames))
+        out = build_line(True, elapsed, plan, patches, times, len(runner.my_frames),
+                         runner.bounds if getattr(runner, "balanced", False) else None)
         if fallback is not None:
             out["secondary"] = {"replicas": {
                 "what": f"{world} independent image sets per step, one per GPU, no collective",
