@@ -620,13 +620,25 @@ def secondary_single_gpu(eng, fence):
                         total[kname] = (have[0] + ms_, have[1] + count)
                 return total
 
+        done = []
+
         def step():
-            e, stream = lanes[0 if state["serial"] else state["i"] % len(lanes)]
+            lane = 0 if state["serial"] else state["i"] % len(lanes)
+            e, stream = lanes[lane]
             state["i"] += 1
+            # trusted stitches do not wait inside: the oldest one is waited for (a consumer
+            # collecting its mosaic, ShardedStitcher's depth) before another is queued, so that
+            # max(2, lanes) stitches are in flight and not the whole timed loop, queued in a
+            # millisecond
+            while cached and len(done) >= max(2, len(lanes)):
+                done.pop(0).synchronize()
             with torch.cuda.stream(stream):
                 plan = (e.cached_plan(shapes, rots, intrs, True, NATIVE) if cached
                         else engine.Plan(shapes, rots, intrs, True, NATIVE))
                 mosaic, _, _, patches = e.stitch(frames, plan, "multiband", cfg["n_levels"])
+                if cached:
+                    done.append(torch.cuda.Event())
+                    done[-1].record(stream)
             return plan, mosaic, list(patches)
         for _ in range(3 * len(lanes)):
             step()

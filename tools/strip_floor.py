@@ -57,8 +57,14 @@ for world in worlds:
         # PANO_SETS_IN_FLIGHT=2: consecutive stitches alternate between two engines / streams
         # (timing(True), the per-kernel pass, goes back to one)
         def step():
-            use, stream = LANES[COUNT[0] % len(LANES)] if not COUNT[1] else LANES[0]
+            lane = COUNT[0] % len(LANES) if not COUNT[1] else 0
+            use, stream = LANES[lane]
             COUNT[0] += 1
+            # max(2, lanes) stitches in flight, not more: the oldest is waited for before another is
+            # queued (what collecting its mosaic does in ShardedStitcher.step, depth = max(2, lanes));
+            # a host that queues a trusted stitch in 0.05 ms would otherwise run twenty ahead
+            while len(DONE) >= max(2, len(LANES)):
+                DONE.pop(0).synchronize()
             with torch.cuda.stream(stream):
                 if os.environ.get("PANO_PLAN_CACHED", "0") != "0":
                     plan = use.cached_plan(shapes, rots, intrs, True, 10 ** 9, st.table_cols)
@@ -67,7 +73,10 @@ for world in worlds:
                     use.upload_plan(plan)
                 use.multiband_fused(frames, plan, cfg["n_levels"], frame_ids=st.my_frames,
                                     strip=st.strip, mosaic_out=OUTS[(COUNT[0] - 1) % len(LANES)] if not COUNT[1] else out)
+                DONE.append(torch.cuda.Event())
+                DONE[-1].record(stream)
         OUTS = [out] + [torch.zeros_like(out) for _ in LANES[1:]]
+        DONE = []
         COUNT[1] = False
         for _ in range(3 * len(LANES)):
             step()
