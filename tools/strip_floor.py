@@ -63,8 +63,10 @@ for world in worlds:
             # max(2, lanes) stitches in flight, not more: the oldest is waited for before another is
             # queued (what collecting its mosaic does in ShardedStitcher.step, depth = max(2, lanes));
             # a host that queues a trusted stitch in 0.05 ms would otherwise run twenty ahead
+            t_wait = time.perf_counter()
             while len(DONE) >= max(2, len(LANES)):
                 DONE.pop(0).synchronize()
+            WAITED[0] += time.perf_counter() - t_wait
             with torch.cuda.stream(stream):
                 if os.environ.get("PANO_PLAN_CACHED", "0") != "0":
                     plan = use.cached_plan(shapes, rots, intrs, True, 10 ** 9, st.table_cols)
@@ -77,14 +79,17 @@ for world in worlds:
                 DONE[-1].record(stream)
         OUTS = [out] + [torch.zeros_like(out) for _ in LANES[1:]]
         DONE = []
+        WAITED = [0.0]
         COUNT[1] = False
         for _ in range(3 * len(LANES)):
             step()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
+        WAITED[0] = 0.0
         for _ in range(20):
             step()
-        host_ms = (time.perf_counter() - t0) / 20 * 1e3     # the host's share: queueing alone
+        # the host's share: queueing alone (without its waits for the oldest stitch)
+        host_ms = (time.perf_counter() - t0 - WAITED[0]) / 20 * 1e3
         torch.cuda.synchronize()
         ms = (time.perf_counter() - t0) / 20 * 1e3
         COUNT[1] = True
