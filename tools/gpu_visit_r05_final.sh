@@ -34,10 +34,11 @@ for wl in cfg3 cfg2 cfg5 cfg4; do
 done
 echo "== 2-rank dry run on one GPU through bench.py's own launcher (gloo)"
 PANO_DIST_BACKEND=gloo timeout -k 10 600 python bench.py --gpus 2 --steps 3 --warmup 1 --no-secondary > "$OUT/bench_2rank_selflaunch.json" 2> "$OUT/bench_2rank.err"; cut -c1-700 "$OUT/bench_2rank_selflaunch.json"
-echo "== strip floors, config 3 (three lanes, plan memo, trusted layouts) and config 5 at world 8"
+echo "== strip floors: config 3 (three lanes, plan memo, trusted layouts, strips of equal work, every rank), the same with the geometry kept (appended to the same file, flagged), equal widths for comparison; config 5 at world 8"
 PANO_PLAN_CACHED=1 PANO_SETS_IN_FLIGHT=3 timeout -k 10 400 python tools/strip_floor.py cfg3 1 2 4 8 --json=$OUT/strip_floor_cfg3_final.json 2>/dev/null | grep "^world" | tee "$OUT/strip_floor_cfg3_final.txt"
-echo "== ... with the geometry kept (Engine.keep_geometry): appended to the same file, flagged kept_geometry"
 PANO_KEEP_GEOMETRY=1 PANO_PLAN_CACHED=1 PANO_SETS_IN_FLIGHT=3 timeout -k 10 400 python tools/strip_floor.py cfg3 1 2 4 8 --json=$OUT/strip_floor_cfg3_final.json 2>/dev/null | grep "^world" | tee "$OUT/strip_floor_cfg3_kept_final.txt"
+PANO_STRIP_BALANCE=0 PANO_PLAN_CACHED=1 PANO_SETS_IN_FLIGHT=3 timeout -k 10 400 python tools/strip_floor.py cfg3 1 8 2>/dev/null | grep "^world" | tee "$OUT/strip_floor_cfg3_equal_width.txt"
 PANO_DISTINCT_FRAMES=6 PANO_PLAN_CACHED=1 PANO_SETS_IN_FLIGHT=2 timeout -k 10 900 python tools/strip_floor.py cfg5 1 8 --json=$OUT/strip_floor_cfg5_final.json 2>/dev/null | grep "^world" | tee "$OUT/strip_floor_cfg5_final.txt"
+PANO_KEEP_GEOMETRY=1 PANO_DISTINCT_FRAMES=6 PANO_PLAN_CACHED=1 PANO_SETS_IN_FLIGHT=2 timeout -k 10 900 python tools/strip_floor.py cfg5 1 8 --json=$OUT/strip_floor_cfg5_final.json 2>/dev/null | grep "^world" | tee "$OUT/strip_floor_cfg5_kept_final.txt"
 if grep -l "GPU core dump\|Memory access fault" "$OUT"/*.txt "$OUT"/*.log "$OUT"/*.err 2>/dev/null; then echo "GPU FAULT"; exit 1; fi
 exit 0
