@@ -455,8 +455,8 @@ def test_trusted_stitches_equal_waiting_ones_and_a_broken_promise_is_caught(stri
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("strip_case", [False, True])
-def test_kept_geometry_stitches_equal_waiting_ones(strip_case):
+@pytest.mark.parametrize("strip_case,equalised", [(False, False), (True, False), (False, True)])
+def test_kept_geometry_stitches_equal_waiting_ones(strip_case, equalised):
     """Engine.trust_layouts(keep_geometry=True): a repeat of the verified stitch re-uses the owner
     map, valid mask, interior map, record table, tile flags and work list the previous stitch left
     on the device (pano_stitch_args.trust_layout = 3 -> 4) and queues the warp, the blur and the
@@ -478,8 +478,11 @@ def test_kept_geometry_stitches_equal_waiting_ones(strip_case):
     for k in range(7):
         frames = waiting.upload_frames([synth.make_frame(100 * k + i, w, h, "A") for i in range(n)])
         plan_w = waiting.cached_plan(shapes, rots, intrs, True, 10 ** 9)
+        luts = None
+        if equalised:
+            luts = torch.from_numpy(engine.gain_tables([0.7 + 0.08 * ((i + 3 * k) % 6) for i in range(n)])).to("cuda:0")
         want, want_f, want_valid, _ = waiting.multiband_fused(frames, plan_w, 5, frame_ids=ids, strip=strip,
-                                                              want_float=True)
+                                                              want_float=True, luts=luts)
         plan_k = keeping.cached_plan(shapes, rots, intrs, True, 10 ** 9)
         if k == 4:      # a foreign call on the context: the kept geometry is void
             keeping.ownership_cameras(plan_k, cams=keeping.camera_table(plan_k, dict(zip(ids, frames))))
@@ -487,7 +490,7 @@ def test_kept_geometry_stitches_equal_waiting_ones(strip_case):
             assert keeping.crop_rect(want_valid) == waiting.crop_rect(want_valid)
         keeping.timing(True)
         got, got_f, got_valid, patches = keeping.multiband_fused(frames, plan_k, 5, frame_ids=ids, strip=strip,
-                                                                 want_float=True)
+                                                                 want_float=True, luts=luts)
         torch.cuda.synchronize()
         ran_ownership.append("ownership_cameras_kernel" in keeping.kernel_times())
         keeping.timing(False)
@@ -856,6 +859,19 @@ def test_sharded_stitcher_world_1_equals_stitch(eng):
     got = [st3.step(frames)[1] for _ in range(5)] + [st3.finish()]
     torch.cuda.synchronize()
     assert got[0] is None and all(torch.equal(m, whole) for m in got[1:])
+    # a fixed rig (keep_geometry): the lanes' repeat stitches run warp + blur + collapse only - with
+    # other pixels every step the mosaics are still the whole engine's
+    lanes = [engine.Engine(eng.device), engine.Engine(eng.device)]
+    st4 = pdist.ShardedStitcher(lanes, shapes, rots, intrs, 5, 0, 1, depth=2, keep_geometry=True)
+    want = []
+    for k in range(7):
+        fk = eng.upload_frames([np.roll(im, 7 * k, axis=1) for im in imgs])
+        want.append(eng.stitch(fk, plan, "multiband", 5)[0])
+        m = st4.step(fk)[1]
+        torch.cuda.synchronize()
+        assert (m is None) == (k == 0) and (m is None or torch.equal(m, want[k - 1])), k
+    assert torch.equal(st4.finish(), want[-1])
+    assert all(e.keep_geometry and e.last_kept_geometry for e in lanes)
     with pytest.raises(Exception):       # a needed frame that is not resident
         eng.multiband_fused(eng.upload_frames(imgs[:2]), eng.upload_plan(plan), 5,
                             frame_ids=[0, 1])
