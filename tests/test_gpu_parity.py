@@ -834,6 +834,21 @@ def test_column_strips_compose_the_single_gpu_mosaic(eng, world):
     assert min(held) < len(imgs)
 
 
+@pytest.mark.parametrize("levels", [1, 2, 6])
+def test_balanced_strips_at_other_level_counts(eng, levels):
+    """Strips of equal work with no blur at all (one level: every valid pixel weighs as a seam pixel
+    in the cost), one blur, five: the cut is the engine's, the strips compose the whole mosaic."""
+    import torch
+    from pano360_amd import dist as pdist
+    from pano360_amd import engine, synth
+    imgs, rots, intrs = synth.make_scene(7, 400, 225, sweep_deg=100.0, jitter=0.01, seed=47, kind="A")
+    plan = engine.Plan([im.shape[:2] for im in imgs], rots, intrs, True, 10 ** 9)
+    whole, _, _, _ = eng.stitch(eng.upload_frames(imgs), plan, "multiband", levels)
+    strips, bounds = pdist.emulate_on_one_device(eng, imgs, rots, intrs, levels, 3)
+    assert bounds == pdist.balanced_strip_bounds(eng.column_costs(plan, levels), 3)
+    assert bounds[0] == 0 and bounds[-1] == plan.shape[1] and torch.equal(strips, whole)
+
+
 def test_sharded_stitcher_world_1_equals_stitch(eng):
     import torch
     from pano360_amd import dist as pdist
