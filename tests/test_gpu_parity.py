@@ -507,6 +507,44 @@ def test_kept_geometry_stitches_equal_waiting_ones(strip_case, equalised):
     assert ran_ownership == [t != 4 for t in took], (ran_ownership, took)
 
 
+@pytest.mark.parametrize("seed", range(6))
+def test_kept_geometry_on_random_rigs(seed):
+    """Random rigs (camera count, frame size, sweep, jitter, pyramid levels, whole mosaic or a strip): four
+    stitches with other pixels each through an engine that keeps the geometry equal the waiting
+    engine's, and every one after the first keeps it."""
+    import torch
+    from pano360_amd import engine, synth
+    rng = np.random.default_rng(1000 + seed)
+    n = int(rng.integers(3, 13))
+    w, h = int(rng.integers(20, 60)) * 8, int(rng.integers(12, 40)) * 8
+    levels = int(rng.choice([2, 5, 6]))
+    rots, intrs = synth.make_cameras(n, w, h, sweep_deg=float(rng.uniform(40.0, 200.0)),
+                                     jitter=float(rng.uniform(0.0, 0.02)), seed=seed)
+    shapes = [(h, w)] * n
+    waiting = engine.Engine("cuda:0")
+    keeping = engine.Engine("cuda:0").trust_layouts(True, keep_geometry=True)
+    W = engine.Plan(shapes, rots, intrs, True, 10 ** 9).shape[1]
+    strip = None
+    if rng.random() < 0.5 and W > 300:
+        c0 = int(rng.integers(0, W // 2))
+        strip = (c0, int(rng.integers(c0 + 100, W + 1)))
+    c0, c1 = strip if strip else (0, W)
+    ids = list(range(n))
+    kept = []
+    for k in range(4):
+        frames = waiting.upload_frames([synth.make_frame(50 * k + i, w, h, "AB"[k & 1]) for i in range(n)])
+        want, _, want_valid, _ = waiting.multiband_fused(
+            frames, waiting.cached_plan(shapes, rots, intrs, True, 10 ** 9), levels, frame_ids=ids, strip=strip)
+        got, _, got_valid, _ = keeping.multiband_fused(
+            frames, keeping.cached_plan(shapes, rots, intrs, True, 10 ** 9), levels, frame_ids=ids, strip=strip)
+        torch.cuda.synchronize()
+        kept.append(keeping.last_kept_geometry)
+        assert torch.equal(got[:, c0:c1], want[:, c0:c1]), (seed, k, n, w, h, levels, strip)
+        assert torch.equal(got_valid[:, c0:c1], want_valid[:, c0:c1]), (seed, k)
+    keeping.verify_trusted()
+    assert kept == [False, True, True, True], (seed, kept)
+
+
 @pytest.mark.parametrize("case", ["sweep", "tilted", "dense", "crowd", "strip"])
 def test_ownership_with_regions_equals_the_two_calls(eng, case):
     """pano_ownership_regions (boxes and column marks out of the ownership kernel) against
