@@ -45,7 +45,15 @@ def block_speed(t):
     fill = t.numel() * 4 / timed(lambda: t.fill_(1.0)) / 1e6                      # GB/s
     pages = t[:t.numel() // 1024 * 1024].view(-1, 1024)[:, 0]
     sparse = pages.numel() / timed(lambda: pages.sum()) / 1e3                     # M pages / s
-    return f"fill {fill:6.0f} GB/s, one float per 4 KiB {sparse:6.1f} M pages/s"
+    out = f"fill {fill:6.0f} GB/s, one float per 4 KiB {sparse:6.1f} M pages/s"
+    # the same float of every page in a RANDOM order of pages (4 KiB, 64 KiB, 2 MiB apart): translations
+    for step in (1024, 16384, 524288):
+        rows = t[:t.numel() // step * step].view(-1, step)
+        order = torch.randperm(rows.shape[0], device=t.device)
+        col = rows[:, 0]
+        ms = timed(lambda: col[order].sum())
+        out += f"; random {step * 4 >> 10} KiB pages {rows.shape[0] / ms / 1e3:7.1f} M/s"
+    return out
 
 
 engine.Engine.arena = placed
