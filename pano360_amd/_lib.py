@@ -158,15 +158,17 @@ EXPORTS = tuple(_SIGNATURES)
 
 
 def sources_digest():
-    """sha256 over everything the library is compiled from (csrc/*.hip, *.h, the Makefile,
-    include/pano360.h), names included."""
+    """sha256 over everything the library is compiled from (csrc/*.hip, *.h, *.inc, the Makefile,
+    include/pano360.h), names included.  A package installed without ../include hashes the rest."""
     import hashlib
     src = os.path.join(_HERE, "csrc")
     files = sorted(os.path.join(src, f) for f in os.listdir(src)
-                   if f.endswith((".hip", ".h")) or f == "Makefile")
+                   if f.endswith((".hip", ".h", ".inc")) or f == "Makefile")
     files.append(os.path.join(os.path.dirname(_HERE), "include", "pano360.h"))
     h = hashlib.sha256()
     for path in files:
+        if not os.path.exists(path):
+            continue
         h.update(os.path.basename(path).encode() + b"\0")
         with open(path, "rb") as fid:
             h.update(fid.read())

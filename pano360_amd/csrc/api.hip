@@ -129,6 +129,9 @@ int pano_ctx_side_stream(pano_ctx *ctx) {
 
 extern "C" int pano_ctx_set_stream(pano_ctx *ctx, void *stream) {
     PANO_REQUIRE(ctx, "pano_ctx_set_stream: null context");
+    // what the previous stitch left behind was produced in the OTHER stream's order: a kept-geometry
+    // repeat (stitch.hip) would read its owner map, table and flags with nothing ordering the two
+    if ((hipStream_t)stream != ctx->stream) ctx->geom_valid = false;
     ctx->stream = (hipStream_t)stream;
     return PANO_OK;
 }
@@ -148,9 +151,16 @@ extern "C" int pano_ctx_set_option(pano_ctx *ctx, int option, int value) {
                      "pano_ctx_set_option: option %d takes -1, 0 or 4 .. 2047", option);
     else
         PANO_REQUIRE(value == 0 || value == 1, "pano_ctx_set_option: option %d takes 0 or 1", option);
+    const bool changed = ctx->opt[option] != value;
     ctx->opt[option] = value;
     // tile flags / work lists made for the other tile grid are void
-    ctx->prepared_table = ctx->flags_table = nullptr;
+    ctx->prepared_table = ctx->flags_table = ctx->list_table = nullptr;
+    // ... and so is everything a stitch left for a kept-geometry repeat (stitch.hip): the record
+    // table, the flags and the work list were laid out for the options as they were.  A changed
+    // blur kernel changes the tile grid: the previous layout's bounds are another grid's too.
+    ctx->geom_valid = false;
+    if (changed && option == PANO_OPT_BLUR_KERNEL)
+        ctx->lay_prev_valid = ctx->lay_prev_verified = false;
     return PANO_OK;
 }
 
@@ -250,8 +260,7 @@ static const char *const g_kernel_names[PK_COUNT] = {
     "blend_cameras_kernel", "owned_spans_kernel",
     "block_owner_kernel", "tile_flags_kernel", "overlap_stats_kernel",
     "blur_mfma_kernel", "sift_extrema_kernel", "sift_orient_kernel", "sift_describe_kernel",
-    "compose_interior_kernel", "scale_step_kernel", "knn2_kernel", "blur_lean_kernel", "blur_lean5_kernel",
-    "blur_irregular_kernel"};
+    "compose_interior_kernel", "scale_step_kernel", "knn2_kernel", "blur_lean_kernel", "blur_lean5_kernel"};
 
 void pano_timing_edge(pano_ctx *ctx, int kid, hipStream_t stream, bool begin) {
     hipEvent_t ev;

@@ -31,8 +31,9 @@
 // just received its last contribution is stored.  Tiles are anchored at multiples of 32 in
 // patch coordinates, so a pixel's sum does not depend on how the rectangle A was
 // cut (column strips, windows): results are bit-identical across decompositions.
-// blur_lean_kernel (further down) runs the regular work items through a leaner instruction
-// stream with two band buffers; this kernel keeps the irregular ones.
+// blur_lean_kernel (further down) runs groups of up to four (five) levels with apertures of up to
+// 97 taps through a leaner instruction stream with two band buffers; this kernel keeps the other
+// level groups (two levels per workgroup, apertures above 97 taps, more than one group).
 //
 // Activity: with an interior map only the 32 x 32 tiles that hold a pixel the
 // collapse will gather are produced (flags, one byte per tile).
@@ -66,12 +67,6 @@ typedef const GLOBAL_AS float4u *gcf32x4;
 
 #ifndef MB_SCHED
 #define MB_SCHED 1
-#endif
-#ifndef MB_STREAM
-#define MB_STREAM 1                 // blur_lean_kernel runs ms_body (round 4); 0 = ml_body (round 3)
-#endif
-#ifndef MB_STREAM_EDGE
-#define MB_STREAM_EDGE MB_STREAM    // ms_body takes the items with reflected columns too (EDGE form)
 #endif
 #define MB_XT 64                    // output columns per workgroup: two 32-column tiles
 // halfs per band row: 64 + 2 * 48 + 8.  336 B = 84 dwords, and 84 = 4 * 21 with 21 odd: the 16
@@ -197,13 +192,9 @@ __host__ __device__ static inline bool mb_item_edge(const pano_patch &p, int gx0
     return X0 - 16 * cm < 0 || X0 + 64 + 16 * cm > p.w || (p.vx0 & 3) != 0 ||
            !(((p.vx0 + p.vw) & 3) == 0 || p.vx0 + p.vw == p.w) || p.h < 128;
 }
-// What the lean kernels take: with MB_STREAM_EDGE everything (ms_body's EDGE form loads such an
-// item's bands element by element, at offsets of any number of reflections), and there is no
-// blur_irregular_kernel launch beside them.
-__host__ __device__ static inline bool mb_item_regular(const pano_patch &p, int gx0, int tx0,
-                                                       int cm) {
-    return MB_STREAM_EDGE || !mb_item_edge(p, gx0, tx0, cm);
-}
+// (The lean kernels take such items too: ms_body's EDGE form loads their bands element by
+// element, at offsets of any number of reflections.  Rounds 3 - 4 left them to a general-path
+// kernel beside the lean one: profiles/r06/probes/blur_dead_generations.patch.)
 
 __device__ __forceinline__ MbGeom mb_geom(const pano_patch &p) {
     MbGeom g;
@@ -746,10 +737,9 @@ __global__ __launch_bounds__(MB_THREADS_OF(GROUP), 4 / GROUP) void blur_mfma_ker
 // every step: ~790 instructions per wave and 32-row step for 34 matrix products (counters of
 // rounds 2 and 3), 11 cycles each; the ablations of profiles/r03/notes.md show no unit and no
 // wait to blame, only the length of that stream.  This kernel runs the same arithmetic, tile
-// for tile and product for product (results are bit-identical, tests compare them), on the
-// items where all of that is static - "regular" items, mb_item_regular - and leaves the rest to
-// the kernel above (the host launches both over the same work list; each skips the other's
-// items):
+// for tile and product for product (results are bit-identical, tests compare them), with all of
+// that static or turned into data (ms_body; its EDGE form takes the items with reflected
+// columns, unaligned windows and low patches, mb_item_edge):
 //  * the bands an item steps through are listed once, compacted, in LDS (band index and the
 //    two tile columns' wanted bits in one word): no search for the next wanted band, no
 //    flag words read and re-read inside the step;
@@ -771,35 +761,6 @@ __global__ __launch_bounds__(MB_THREADS_OF(GROUP), 4 / GROUP) void blur_mfma_ker
 #ifndef ML_OVERLAP
 #define ML_OVERLAP 1
 #endif
-
-template <int C, int U>
-__device__ __forceinline__ void ml_colpass(f32x16 (&acc)[2 * ((C + 1) / 2) + 1],
-                                           const half8 (&m_hi)[2], const half8 (&m_lo)[2],
-                                           const half8 *s_ty, const int lane, const unsigned inf) {
-    constexpr int DMAX = (C + 1) / 2, NB = 2 * DMAX + 1;
-    constexpr int Z = C & 1;            // the outermost half-blocks are zero (odd C), not stored
-    f32x16 zero;
-#pragma unroll
-    for (int q = 0; q < 16; ++q) zero[q] = 0.0f;
-#pragma unroll
-    for (int d = -DMAX; d <= DMAX; ++d) {
-        const int k = ((U - d) % NB + NB) % NB;          // tile t - d lives in accumulator k
-        // an unwanted tile is never stored: its products are skipped (wave-uniform; at the
-        // ends of a run and along ragged seams that is a quarter of the column pass)
-        if (!((inf >> (d + 2)) & 1u)) continue;
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            if (Z && ((d == -DMAX && s == 0) || (d == DMAX && s == 1))) continue;
-            const half8 *ty = s_ty + (((d + DMAX) * 2 + s - Z) * 2) * 64 + lane;
-            const half8 t_hi = ty[0], t_lo = ty[64];
-            // the band's first contribution to tile t + DMAX starts its sum
-            const bool first = d == -DMAX && s == Z;
-            acc[k] = __builtin_amdgcn_mfma_f32_32x32x16_f16(t_hi, m_hi[s], first ? zero : acc[k], 0, 0, 0);
-            acc[k] = __builtin_amdgcn_mfma_f32_32x32x16_f16(t_lo, m_hi[s], acc[k], 0, 0, 0);
-            acc[k] = __builtin_amdgcn_mfma_f32_32x32x16_f16(t_hi, m_lo[s], acc[k], 0, 0, 0);
-        }
-    }
-}
 
 // Tile o of this wave's column (accumulator `a`) to its plane.
 // ALWAYS sixteen store instructions: with `wanted` false every one of them gets an offset
@@ -836,283 +797,9 @@ __device__ __forceinline__ void ml_store(const f32x16 &a, const int o, const int
     }
 }
 
-template <int C, bool SHARP>
-__device__ __forceinline__ void ml_body(const pano_patch &p, const int ch, const int out_level,
-                                        const bool live, const half8 *s_tx, const half8 *s_ty,
-                                        const MbShared &sh, const uint32_t *list, const int nlist,
-                                        const int16_t *__restrict__ owner_, const int W,
-                                        const int tx0, const int second) {
-    constexpr int KS = 2 + 2 * C, DMAX = (C + 1) / 2, NB = 2 * DMAX + 1;
-    constexpr int THREADS = MB_THREADS_OF(4), ITS = MB_ITS_OF(4);
-    constexpr unsigned OOB = 0x80000000u;
-    constexpr bool sharp = SHARP;                        // stitcher.py:207-208: the 0 / 1 mask
-    // halfs from band buffer 0 to band buffer 1 (ML_OVERLAP)
-    const int bstride = __builtin_amdgcn_readfirstlane(second);
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, n = lane & 31, h = lane >> 5;
-    const int tile = wv & 1;
-    const MbGeom g = mb_geom(p);
-    const int X0 = g.gx0 + 32 * tx0, px0 = X0 + 32 * tile;
-    const int BW = MB_XT + 32 * sh.CM, CPR = BW >> 2, NCH = 32 * CPR;
-    const int my_lo = g.O0 - DMAX, my_hi = g.O1 + DMAX;
-
-    f32x16 acc[NB];
-    const __amdgpu_buffer_rsrc_t dst = __builtin_amdgcn_make_buffer_rsrc(
-        (void *)(p.blurred + (size_t)(out_level * 4 + ch) * p.ah * p.apitch), 0, p.ah * p.apitch * 4,
-        0x00020000);
-    const gci16 owner = (gci16)owner_;
-
-    // this thread's chunks: band row, LDS slot, and the column part of the address (a chunk
-    // is inside V or outside it as a whole).  Whether chunk `it` exists is wave-uniform: a
-    // band has 512 + 256 CM chunks and 256 threads are four waves.
-    int c_rr[ITS], c_lds[ITS];
-    unsigned c_col[ITS];         // colour: byte offset in a plane row; mask: mosaic column; or OOB
-    bool c_has[ITS];
-#pragma unroll
-    for (int it = 0; it < ITS; ++it) {
-        // (waves 4-7 work on the group's two lightest levels, or on none: they take the larger
-        // share of the band - the chunks beyond the first 1024; 0.722 -> 0.709 ms)
-        const int grp = (tid ^ 256) + THREADS * it;
-        const int rr = grp / CPR, c4 = grp - rr * CPR;
-        c_has[it] = __builtin_amdgcn_readfirstlane(((wv << 6) ^ 256) + THREADS * it) < NCH;
-        const int vc = X0 - 16 * sh.CM + 4 * c4 - p.vx0;     // first column, in V
-        const bool col_ok = vc >= 0 && vc + 4 <= p.vw;
-        c_rr[it] = rr;
-        c_lds[it] = rr * sh.P + 4 * c4;
-        c_col[it] = sharp ? (col_ok ? (unsigned)(p.x0 + p.vx0 + vc) : OOB)
-                          : (col_ok ? (unsigned)vc * 4u : OOB);
-    }
-    // A step fetches the NEXT band right behind its barrier, in front of the previous tile's
-    // sixteen stores (always sixteen: ml_store), and stages it at its end, behind the two matrix
-    // passes.  The wait in front of the staging must cover the loads and NOT the stores behind
-    // them: a store to HBM takes longer than a step to be acknowledged, and waves that wait for
-    // theirs every step are parked 67 % of their cycles (0.89 ms; 0.71 with the stores left in
-    // flight).  The compiler cannot express that - with loads and stores pending on the one
-    // counter it always waits for vmcnt(0) - so the loads are inline asm (invisible to its wait
-    // insertion) and the wait is placed by hand: s_waitcnt vmcnt(16).  The loaded registers
-    // must then not live across a join of the control flow, or the register allocator may copy
-    // them while the loads are in flight (it did, when they lived from one step into the next):
-    // here they are fetched and consumed inside one step.
-    typedef unsigned uint4v __attribute__((ext_vector_type(4)));
-    typedef int int4v __attribute__((ext_vector_type(4)));
-    const unsigned long long src_base =
-        (unsigned long long)(sharp ? p.planes : p.planes + (size_t)ch * p.vh * p.vpitch);
-    int4v rs;                                            // the plane as a buffer descriptor, word by word
-    rs[0] = __builtin_amdgcn_readfirstlane((int)(src_base & 0xffffffffull));
-    rs[1] = __builtin_amdgcn_readfirstlane((int)((src_base >> 32) & 0xffffull));
-    rs[2] = __builtin_amdgcn_readfirstlane(p.vh * p.vpitch * 4);
-    rs[3] = 0x00020000;
-    struct Band {                   // a band in flight: the loads' destination registers
-        uint4v v[ITS];              // colour: one 16-byte load per chunk
-        unsigned e[ITS][4];         // mask: four owner-map entries per chunk
-    };
-    auto fetch = [&](Band &pf, unsigned &pm, const int t) {
-        pm = 0;                                          // mask: bit it = the chunk's samples exist
-#pragma unroll
-        for (int it = 0; it < ITS; ++it) {
-            if (!c_has[it]) continue;                    // wave-uniform
-            const int prow = 32 * t + c_rr[it];
-            const int ry = prow < 0 ? -prow : (prow >= p.h ? 2 * p.h - 2 - prow : prow);
-            const int vr = ry - p.vy0;
-            const bool ok = (unsigned)vr < (unsigned)p.vh && c_col[it] != OOB;
-            if (!sharp) {
-                const unsigned voff = ok ? (unsigned)vr * (unsigned)p.vpitch * 4u + c_col[it] : OOB;
-                asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen"
-                             : "=v"(pf.v[it])
-                             : "v"(voff), "s"(rs)
-                             : "memory");
-            } else {
-                const gci16 at = owner + ((size_t)(unsigned)(p.y0 + (ok ? ry : 0)) * (unsigned)W +
-                                          (ok ? c_col[it] : (unsigned)p.x0));
-                // (straight into the registers the wait below names: a copy of a register
-                // whose load is still in flight copies stale bits)
-                asm volatile("global_load_sshort %0, %4, off\n\t"
-                             "global_load_sshort %1, %4, off offset:2\n\t"
-                             "global_load_sshort %2, %4, off offset:4\n\t"
-                             "global_load_sshort %3, %4, off offset:6"
-                             : "=&v"(pf.e[it][0]), "=&v"(pf.e[it][1]), "=&v"(pf.e[it][2]),
-                               "=&v"(pf.e[it][3])
-                             : "v"(at)
-                             : "memory");
-                pm |= ok ? 1u << it : 0u;
-            }
-        }
-    };
-    // `behind`: sixteen stores were issued behind the loads (they stay in flight)
-    auto commit = [&](Band &pf, const unsigned pm, const int buf, const bool behind) {
-        static_assert(ITS == 3, "the hand-placed waits name three chunks");
-#define ML_WAIT(N)                                                                             \
-    if (sharp)                                                                                 \
-        asm volatile("s_waitcnt vmcnt(" #N ")"                                                 \
-                     : "+v"(pf.e[0][0]), "+v"(pf.e[0][1]), "+v"(pf.e[0][2]), "+v"(pf.e[0][3]), \
-                       "+v"(pf.e[1][0]), "+v"(pf.e[1][1]), "+v"(pf.e[1][2]), "+v"(pf.e[1][3]), \
-                       "+v"(pf.e[2][0]), "+v"(pf.e[2][1]), "+v"(pf.e[2][2]), "+v"(pf.e[2][3])  \
-                     :                                                                         \
-                     : "memory");                                                              \
-    else                                                                                       \
-        asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(pf.v[0]), "+v"(pf.v[1]), "+v"(pf.v[2])::"memory")
-        if (behind) {
-            ML_WAIT(16);
-        } else {
-            ML_WAIT(0);
-        }
-#undef ML_WAIT
-#pragma unroll
-        for (int it = 0; it < ITS; ++it) {
-            if (!c_has[it]) continue;
-            half4 hi, lo;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                float v = sharp ? 0.0f : __uint_as_float(pf.v[it][j]);
-                if (sharp) v = (int)pf.e[it][j] == p.index && ((pm >> it) & 1u) ? 1.0f : 0.0f;
-                _Float16 a, b;
-                split16(v * MB_IN_SCALE, a, b);
-                hi[j] = a;
-                lo[j] = b;
-            }
-            const int at = c_lds[it] + buf;
-            *(half4 *)(sh.hi + at) = hi;
-            if (!sharp) *(half4 *)(sh.lo + at) = lo;     // the mask has no low part
-        }
-    };
-    auto rowpass = [&](f32x16 &mid, const int buf) {
-#pragma unroll
-        for (int q = 0; q < 16; ++q) mid[q] = 0.0f;
-        const int o = buf + n * sh.P + 16 * (sh.CM - C) + 32 * tile + 8 * h;
-        const _Float16 *arow = sh.hi + o, *brow = sh.lo + o;
-        half8 a_hi[2], a_lo[2], b_hi[2], b_lo[2];
-        auto operands = [&](const int s, const int b) {
-            a_hi[b] = *(const half8 *)(arow + 16 * s);
-            b_hi[b] = s_tx[mb_tx_index(KS, lane, s, 0)];
-            b_lo[b] = s_tx[mb_tx_index(KS, lane, s, 1)];
-            if (!sharp) a_lo[b] = *(const half8 *)(brow + 16 * s);
-        };
-        operands(0, 0);
-#pragma unroll
-        for (int s = 0; s < KS; ++s) {
-            const int cur = s & 1;
-            if (s + 1 < KS) operands(s + 1, cur ^ 1);
-            mid = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi[cur], b_hi[cur], mid, 0, 0, 0);
-            mid = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi[cur], b_lo[cur], mid, 0, 0, 0);
-            if (!sharp)
-                mid = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo[cur], b_hi[cur], mid, 0, 0, 0);
-#if MB_SCHED
-            __builtin_amdgcn_sched_group_barrier(0x100, sharp ? 3 : 4, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, sharp ? 2 : 3, 0);
-#endif
-        }
-    };
-    // a list word: band index (16 bits, signed) | tile column 0's wanted bits << 16 | column 1's << 24
-    // (bit d + 2 = tile t - d is wanted, d = -2 .. 2)
-    auto word_at = [&](const int i) -> unsigned {
-        return (unsigned)__builtin_amdgcn_readfirstlane((int)list[i]);
-    };
-    auto band_of = [](const unsigned w) { return (int)(short)(w & 0xffffu); };
-    const unsigned keep = live ? 0x1fu : 0u;
-    auto bits_of = [&](const unsigned w) { return (w >> (16 + 8 * tile)) & keep; };
-
-    if (nlist <= 0) return;                               // uniform
-    // A wanted tile needs every band within DMAX of it, so the listed bands come in RUNS of
-    // consecutive bands and no tile outlives a run.  Inside a run the accumulator of a tile
-    // is given by the tile's position in the run mod NB, and the loop over a run is unrolled
-    // NB times: every step addresses the accumulators statically, with no join of differently
-    // numbered variants behind it (a switch on t mod NB made the compiler move the 80
-    // accumulator registers around at every step: 0.97 ms against 0.89).
-    int i = 0;
-    unsigned word = word_at(0);
-    int prev_o = 0, prev_u = 0;
-    bool prev_store = false;
-    auto store_prev = [&]() {                            // reads the accumulators, writes none
-        switch (prev_u) {
-#define ML_STORE_CASE(UU)                                                                      \
-    case UU:                                                                                   \
-        if constexpr (UU < NB)                                                                 \
-            ml_store(acc[(UU + DMAX + 1) % NB], prev_o, lane, p, dst, px0, prev_store);        \
-        break;
-            ML_STORE_CASE(0) ML_STORE_CASE(1) ML_STORE_CASE(2) ML_STORE_CASE(3) ML_STORE_CASE(4)
-#undef ML_STORE_CASE
-        }
-        prev_store = false;
-    };
-    auto split_mid = [&](const f32x16 &mid, half8 (&m_hi)[2], half8 (&m_lo)[2]) {
-#pragma unroll
-        for (int s = 0; s < 2; ++s)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                _Float16 a, b;
-                split16(mid[8 * s + j] * MB_MID_SCALE, a, b);
-                m_hi[s][j] = a;
-                m_lo[s][j] = b;
-            }
-    };
-    // Band i is staged in the buffer at off_cur (halfs from sh.hi); the step stages band i + 1
-    // in the buffer at off_nxt.  ML_OVERLAP 0: one buffer, two barriers per step.
-    int off_cur = __builtin_amdgcn_readfirstlane(0), off_nxt = ML_OVERLAP ? bstride : off_cur;
-    {
-        Band pf;
-        unsigned pm;
-        fetch(pf, pm, band_of(word));
-        commit(pf, pm, off_cur, false);
-    }
-    // One step with the run position u_c static; false = the run (or the list) ends here.
-    auto step = [&](auto u_c) -> bool {
-        constexpr int U = decltype(u_c)::value;
-        const int t = band_of(word);
-        const unsigned inf = bits_of(word);
-        const bool more = i + 1 < nlist;
-        const unsigned next = more ? word_at(i + 1) : 0u;
-        // (the two offsets swap every step; kept opaque, or the compiler unrolls the run loop
-        // once more to make them constants)
-        off_cur = __builtin_amdgcn_readfirstlane(off_cur);
-        off_nxt = __builtin_amdgcn_readfirstlane(off_nxt);
-        asm volatile("" : "+s"(off_cur), "+s"(off_nxt));
-        lds_barrier();              // band i is whole; nobody reads the other buffer any more
-        Band pf;
-        unsigned pm;
-        fetch(pf, pm, more ? band_of(next) : -100000);   // (no such band: zeros)
-        store_prev();                                    // the tile last step's band completed
-        if (t >= my_lo && t <= my_hi && (inf & (DMAX == 1 ? 0x0eu : 0x1fu))) {
-            f32x16 mid;
-            rowpass(mid, off_cur);
-            half8 m_hi[2], m_lo[2];
-            split_mid(mid, m_hi, m_lo);
-            ml_colpass<C, U>(acc, m_hi, m_lo, s_ty, lane, inf);
-        }
-        if (!ML_OVERLAP) lds_barrier();                  // everybody finished reading the band
-        commit(pf, pm, off_nxt, true);
-        prev_store = (inf >> (DMAX + 2)) & 1u;           // tile t - DMAX is wanted: complete now
-        prev_o = t - DMAX;
-        prev_u = U;
-        word = next;
-        {
-            const int tmp = off_cur;
-            off_cur = off_nxt;
-            off_nxt = tmp;
-        }
-        ++i;
-        return more && band_of(next) == t + 1;
-    };
-    while (i < nlist) {                                  // one run per trip
-        // (nothing of the previous run is alive: say so, else the accumulators are carried
-        // from every exit below to here)
-#pragma unroll
-        for (int k = 0; k < NB; ++k)
-#pragma unroll
-            for (int q = 0; q < 16; ++q) acc[k][q] = 0.0f;
-        for (;;) {
-            if (!step(std::integral_constant<int, 0>{})) break;
-            if (!step(std::integral_constant<int, 1>{})) break;
-            if (!step(std::integral_constant<int, 2>{})) break;
-            if constexpr (NB > 3) {
-                if (!step(std::integral_constant<int, 3>{})) break;
-                if (!step(std::integral_constant<int, 4>{})) break;
-            }
-        }
-        if (prev_store) store_prev();                    // the run's last tile, before the reset
-    }
-}
-
 // =====================================================================================
-// Round 4: the lean step as ONE basic block (MB_STREAM, default on; 0 = ml_body above).
+// Round 4: the lean step as ONE basic block.  (ml_body, round 3's step, is gone from this file:
+// profiles/r06/probes/blur_dead_generations.patch.)
 //
 // ml_body's step is a chain of phases - fetch, store, row pass, split, column pass, commit -
 // each behind wave-uniform branches (chunk exists? tile inside A? tile wanted? band wanted?),
@@ -1143,10 +830,6 @@ __device__ __forceinline__ void ml_body(const pano_patch &p, const int ch, const
 //   * the column pass runs k-half-major (all tiles' first half-blocks, then their second):
 //     the second half of Mid is split under the first half's products.  Each accumulator
 //     still receives its products in ml_body's order: results are bit-identical.
-#ifndef MB_STREAM
-#define MB_STREAM 1
-#endif
-
 // (hi, lo) float16 pairs of floats scaled by the power of two s: hi = f16(v s), lo = f16(v s - hi),
 // two instructions per value (the compiler's own selection takes 3.5: it forms hi a second time
 // for the packed word).  v_fma_mix{lo,hi}_f16 writes one half of its destination and keeps the
@@ -1881,17 +1564,6 @@ __device__ __forceinline__ void lean_kernel_body(
         const int ck = mb_c_of(L.ntaps[l0 + k]);
         sh.CM = ck > sh.CM ? ck : sh.CM;
     }
-    // Not one of ours: blur_irregular_kernel takes it (MB_STREAM; beside this launch, on the
-    // context's side stream).  With the general path inside this kernel - the form of round 3:
-    // a second launch over the whole list cost 0.31 ms of idle workgroups - the kernel's
-    // allocation was the general path's: 220 vector registers against 184, 202 spilled scalars
-    // against 12, and the blur 5 % slower for code that 1 % of the work units run.
-    if (!mb_item_regular(p, g.gx0, tx0, sh.CM)) {                               // uniform
-#if !MB_STREAM
-        mb_general<GROUP>(table, L, tables, owner, W, flags, items, smem, (int)blockIdx.x);
-#endif
-        return;
-    }
     const int n_seg = item.y >> 16, seg = (item.y >> 12) & 15, nty_all = g.O1 - g.O0 + 1;
     const int o_begin = n_seg > 1 ? nty_all * seg / n_seg : 0;
     const int o_end = n_seg > 1 ? nty_all * (seg + 1) / n_seg : nty_all;
@@ -2011,13 +1683,8 @@ __device__ __forceinline__ void lean_kernel_body(
     const int out_level = L.out[level];
     // the second band buffer lies behind the group's tables (the host sized the LDS for it)
     const int second = (mb_fixed_bytes(sh.CM) + rel + 15) / 16 * 8;     // halfs from sh.hi
-#if MB_STREAM
 #define ML_BODY_FN ms_body
-#else
-#define ML_BODY_FN ml_body
-#endif
-#if MB_STREAM
-    const bool edge = MB_STREAM_EDGE && mb_item_edge(p, g.gx0, tx0, sh.CM);             // uniform
+    const bool edge = mb_item_edge(p, g.gx0, tx0, sh.CM);                               // uniform
     if constexpr (FIVE)
     if (lv_b >= 0) {                                     // wave-uniform: levels of 2 and 1 K-steps' reach
         const half8 *s_tx_b = (const half8 *)(smem + my_tx_b), *s_ty_b = (const half8 *)(smem + my_ty_b);
@@ -2047,7 +1714,6 @@ __device__ __forceinline__ void lean_kernel_body(
         }
         return;
     }
-#endif
     switch (c) {                                         // wave-uniform
 #define ML_BODY(CC)                                                                            \
     if (ch == 3)                                                                               \
@@ -2071,7 +1737,6 @@ __global__ __launch_bounds__(MB_THREADS_OF(4), 1) void blur_lean_kernel(
     lean_kernel_body<false>(table, L, tables, owner, W, flags, items, smem);
 }
 
-#if MB_STREAM
 __global__ __launch_bounds__(MB_THREADS_OF(4), 1) void blur_lean5_kernel(
     const pano_patch *__restrict__ table, MbLevels L, const unsigned char *__restrict__ tables,
     const int16_t *__restrict__ owner, int W, const uint8_t *__restrict__ flags,
@@ -2079,65 +1744,6 @@ __global__ __launch_bounds__(MB_THREADS_OF(4), 1) void blur_lean5_kernel(
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     lean_kernel_body<true>(table, L, tables, owner, W, flags, items, smem);
 }
-#endif
-
-#if MB_STREAM
-// The work units blur_lean_kernel / blur_lean5_kernel leave out (mb_item_regular false: bands
-// with reflected columns, ragged windows, short patches), through the general path.  A workgroup
-// takes a contiguous range of `per` (<= 512) units of the sorted list: its threads test one unit
-// each, and the irregular ones - a few dozen of config 3's 1 112 units, every unit of a small
-// scene - are then worked off one after the other by the whole workgroup.  (`per` units per
-// workgroup, unit = workgroup + k x workgroups.)
-template <bool FIVE>
-__global__ __launch_bounds__(MB_THREADS_OF(4), 1) void blur_irregular_kernel(
-    const pano_patch *__restrict__ table, MbLevels L, const unsigned char *__restrict__ tables,
-    const int16_t *__restrict__ owner, int W, const uint8_t *__restrict__ flags,
-    const int2 *__restrict__ items, int n_units, int per) {
-    constexpr int GROUP = 4;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
-    int cm = 1;
-    for (int k = 0; k < (FIVE ? 5 : (L.n < GROUP ? L.n : GROUP)); ++k) {
-        const int ck = mb_c_of(L.ntaps[k]);
-        cm = ck > cm ? ck : cm;
-    }
-    // (strided, not contiguous: the list is sorted by length, so the irregular units of one kind
-    // - the long ones along a patch's left and right edge - are neighbours in it, and a
-    // contiguous range handed one workgroup eight of them: 2.8 ms for config 3's dozen)
-    const int u = (int)blockIdx.x + tid * (int)gridDim.x;
-    bool mine = false;
-    if (tid < per && u < n_units) {
-        const int2 item = items[u >> 2];
-        if (item.x >= 0) {
-            const pano_patch p = table[item.x & 0xffff];
-            const MbGeom g = mb_geom(p);
-            mine = !mb_item_regular(p, g.gx0, item.x >> 16, cm);
-        }
-    }
-    unsigned long long *const s_words = (unsigned long long *)smem;     // [8]: a wave's ballot each
-    const unsigned long long bal = __ballot(mine);
-    if (lane == 0) s_words[wv] = bal;
-    __syncthreads();
-    unsigned long long words[8];
-#pragma unroll
-    for (int w = 0; w < 8; ++w) words[w] = s_words[w];
-    for (int w = 0; w < 8; ++w) {
-        unsigned long long m = words[w];                 // (the same on every thread)
-        while (m) {
-            const int b = __ffsll((long long)m) - 1;
-            m &= m - 1ull;
-            const int unit = __builtin_amdgcn_readfirstlane((int)blockIdx.x + (64 * w + b) * (int)gridDim.x);
-            // the general path takes four levels per workgroup and numbers its work units as
-            // block of 8 pairs x groups + group x 8 + pair: five levels are two of its groups
-            for (int gg = 0; gg < (FIVE ? 2 : 1); ++gg) {
-                __syncthreads();                         // the LDS is the previous unit's (or the ballots')
-                mb_general<GROUP>(table, L, tables, owner, W, flags, items, smem,
-                                  FIVE ? (unit >> 3) * 16 + gg * 8 + (unit & 7) : unit);
-            }
-        }
-    }
-}
-#endif
 
 // One thread per 32 x 32 tile of every record: active = some interior-map block under the
 // tile (cut to A) is not interior.
@@ -2298,11 +1904,6 @@ __global__ __launch_bounds__(256) void mb_items_kernel(const pano_patch *__restr
 #define MB_SEG_MAX 8
 #define MB_SEG_LEAD 8
 #define MB_SEG_SLOTS 192
-// An IRREGULAR item (mb_item_regular false for a group that reaches `cm` k-steps: the pairs along
-// a patch's left and right edge, whose bands hold reflected columns) goes through the general
-// path, at twice the cycles per band, and on the mosaic's outer edges such an item is a whole
-// column of tiles: three items of config 2's 115 were the blur's last 0.17 of 0.19 ms.  They are
-// cut into up to MB_SEG_MAX segments whatever S is.
 __global__ __launch_bounds__(256) void mb_sort_kernel(const int2 *__restrict__ items,
                                                       int *__restrict__ counter, int cap, int scap,
                                                       int wgs_per_item, int slots,
@@ -2310,14 +1911,10 @@ __global__ __launch_bounds__(256) void mb_sort_kernel(const int2 *__restrict__ i
                                                       const pano_patch *__restrict__ table, int cm,
                                                       int force_t) {
     __shared__ int s_hist[MB_SORT_BINS];
-    __shared__ int s_lmax, s_lsum, s_nirr, s_total;
+    __shared__ int s_lmax, s_lsum, s_total;
     const int tid = threadIdx.x;
     const int n = min(*counter, cap);
-    auto irregular = [&](const int2 it) {
-        if (cm <= 0) return false;
-        const pano_patch p = table[it.x & 0xffff];
-        return !mb_item_regular(p, (p.ax0 >> 5) << 5, it.x >> 16, cm);
-    };
+    (void)table, (void)cm;
     // T: the segment length (bands) items are cut to, 0 = nothing is cut.  Items differ in length
     // by a factor of six (13 - 82 bands on config 3): one segment COUNT for all of them (rounds
     // 2 - 4) cut the short items into segments that were mostly lead while the long ones still set
@@ -2332,7 +1929,7 @@ __global__ __launch_bounds__(256) void mb_sort_kernel(const int2 *__restrict__ i
     // pair the k-th workgroup of the second with the slot that frees k-th (the shortest of the
     // first round first): max(l_1, l_slots + l_slots+1, l_2 slots + 1 - W + l_W); more rounds:
     // the work per slot plus half the shortest workgroup.
-    int T = 0, S_irr = 1;
+    int T = 0;
     constexpr int NCAND = 13, HL = 128;                          // candidate 0 = nothing cut
     constexpr int MINE = 4;                                      // items a thread keeps in registers
     __shared__ int s_segs[NCAND], s_est[NCAND];
@@ -2343,11 +1940,11 @@ __global__ __launch_bounds__(256) void mb_sort_kernel(const int2 *__restrict__ i
     const bool consider = slots > 0 && n > 0 && !force_t && (long long)n * wgs_per_item < 3ll * slots &&
                           n <= MINE * 256;
     if (slots > 0 && n > 0) {                                    // uniform
-        if (tid == 0) s_lmax = s_lsum = s_nirr = 0;
+        if (tid == 0) s_lmax = s_lsum = 0;
         if (tid < NCAND) s_segs[tid] = 0, s_est[tid] = 0x7fffffff;
         for (int i = tid; i < NCAND * HL / 2; i += 256) ((unsigned int *)&s_len[0][0])[i] = 0u;
         __syncthreads();
-        int lmax = 0, lsum = 0, nirr = 0, mine[MINE];
+        int lmax = 0, lsum = 0, mine[MINE];
         // (static indices only: a `mine[r]` with a running r put the array into scratch memory and
         // every one of the estimate's 52 reads of it became a trip to memory - 30 us of this kernel)
 #pragma unroll
@@ -2358,7 +1955,6 @@ __global__ __launch_bounds__(256) void mb_sort_kernel(const int2 *__restrict__ i
                 const int2 it = items[i];
                 lmax = max(lmax, it.y);
                 lsum += it.y;
-                nirr += irregular(it) ? 1 : 0;
                 mine[r] = it.y;
             }
         }
@@ -2366,11 +1962,9 @@ __global__ __launch_bounds__(256) void mb_sort_kernel(const int2 *__restrict__ i
             const int2 it = items[i];
             lmax = max(lmax, it.y);
             lsum += it.y;
-            nirr += irregular(it) ? 1 : 0;
         }
         atomicMax(&s_lmax, lmax);
         atomicAdd(&s_lsum, lsum);
-        atomicAdd(&s_nirr, nirr);
         __syncthreads();
         const int Lmax = s_lmax, Lsum = s_lsum;
         // candidate lengths: none, Lmax / 2 ... Lmax / 8 and a few absolute ones
@@ -2512,21 +2106,11 @@ __global__ __launch_bounds__(256) void mb_sort_kernel(const int2 *__restrict__ i
                 if (s_segs[0] <= scap && s_segs[0] <= n + MB_SEG_SLOTS) T = force_t;   // the list holds them
             }
         }
-        // the irregular items' own segment count: as many as the list's spare slots allow
-        // (builds with -DMB_STREAM_EDGE=0 only: the lean step takes every item otherwise)
-        const int n_irr = s_nirr;
-        if (n_irr > 0 && T == 0) {
-            const int spare = min(scap - n, MB_SEG_SLOTS);
-            S_irr = min(MB_SEG_MAX, 1 + max(spare, 0) / n_irr);
-        }
         __syncthreads();
     }
-    // segments of item i: its length over T, or for an irregular one up to S_irr of at least ~10
-    // bands each
+    // segments of item i: its length over T
     auto segments_of = [&](const int2 it) {
-        const int cut = T ? min(MB_SEG_MAX, (it.y + T - 1) / T) : 1;
-        if (S_irr <= cut || !irregular(it)) return cut;
-        return max(cut, min(S_irr, it.y / 10));
+        return T ? min(MB_SEG_MAX, (it.y + T - 1) / T) : 1;
     };
     auto entry = [&](const int2 it, const int seg, const int ns) {
         const int len = ns == 1 ? it.y : (it.y + ns - 1) / ns + 4;
@@ -2684,8 +2268,8 @@ int pano_prepare_blur_mfma(pano_ctx *ctx, const pano_patch *table, int n, int ma
                        ctx->opt[PANO_OPT_BLUR_SEGMENTS] ? (ctx->blur_cm > 0 ? ctx->blur_cm : 3) : 0,
                        force_t);
     PANO_LAUNCH_CHECK("mb_sort_kernel");
-    ctx->prepared_table = table;
-    ctx->prepared_n = n;
+    ctx->prepared_table = ctx->list_table = table;
+    ctx->prepared_n = ctx->list_n = n;
     return PANO_OK;
 }
 
@@ -2697,16 +2281,8 @@ int pano_blur_mfma_opt_in(void) {
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     PANO_HIP(hipFuncSetAttribute((const void *)blur_lean_kernel,
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-#if MB_STREAM
     PANO_HIP(hipFuncSetAttribute((const void *)blur_lean5_kernel,
                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-#if !MB_STREAM_EDGE
-    PANO_HIP(hipFuncSetAttribute((const void *)blur_irregular_kernel<false>,
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    PANO_HIP(hipFuncSetAttribute((const void *)blur_irregular_kernel<true>,
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-#endif
-#endif
     return PANO_OK;
 }
 
@@ -2794,15 +2370,14 @@ static int launch_levels(pano_ctx *ctx, const pano_patch *table, int n, int max_
     int lean = MB_LEAN && ctx->opt[PANO_OPT_BLUR_LEAN] && group == 4 ? 1 : 0;
     // five levels in one group (blur_lean_kernel: the two lightest on one wave pair), when their
     // reaches allow: 1 and 2 K-steps (equal DMAX) for the lightest two
-    const bool five = MB_STREAM && lean && cnt == 5 && mb_c_of(L.ntaps[0]) == 1 &&
+    const bool five = lean && cnt == 5 && mb_c_of(L.ntaps[0]) == 1 &&
                       mb_c_of(L.ntaps[1]) == 2;
     if (cnt > 4 && !five) lean = lean && false;          // (more than one group: the general kernel)
     for (int i = 0; i < cnt; ++i)
         if (L.ntaps[i] < 3) lean = 0;
     int lds_lean = lds;
-    if (MB_STREAM)               // (ms_body stages at most 1280 chunks per band: a reach of 3 K-steps)
-        for (int i = 0; i < cnt; ++i)
-            if (mb_c_of(L.ntaps[i]) > 3) lean = 0;
+    for (int i = 0; i < cnt; ++i)    // (ms_body stages at most 1280 chunks per band: a reach of 3 K-steps)
+        if (mb_c_of(L.ntaps[i]) > 3) lean = 0;
     if (ML_OVERLAP) {            // + the second band buffer, behind the largest group's tables
         lds_lean = 0;
         for (int gidx = 0; gidx < (five ? 1 : ngroups); ++gidx) {
@@ -2816,72 +2391,21 @@ static int launch_levels(pano_ctx *ctx, const pano_patch *table, int n, int max_
         }
         if (lds_lean > 160 * 1024) lean = 0;             // (apertures above 97 taps: the general kernel)
     }
-#if MB_STREAM
     if (lean) {
-        // The irregular work units beside the regular ones: blur_irregular_kernel on the context's
-        // side stream (the two kernels write disjoint tiles), on this stream behind the lean
-        // kernel while kernels are being timed (the events of two streams would span each other).
-        const int n_units = cap * 4;
-        // (about eight units to test per workgroup; a scene whose every unit is irregular - small
-        // patches - then has one or two to work off per workgroup)
-        int wgs = ceil_div(n_units, 8);
-        wgs = wgs < 64 ? 64 : wgs;
-        if (ceil_div(n_units, wgs) > 512) wgs = ceil_div(n_units, 512);
-        const int per = ceil_div(n_units, wgs);
-        // (a small work list - config 2's thousand units - keeps to the one stream: the fork and
-        // the join cost its short blur more than the overlap gives, 0.504 against 0.475 ms per stitch)
-        const bool beside = !MB_STREAM_EDGE && ctx->opt[PANO_OPT_STITCH_STREAMS] != 0 &&
-                            !ctx->timing_on && stream == ctx->stream && n_units >= 4096;
-        hipStream_t other = stream;
-        if (beside) {
-            if (int rc = pano_ctx_side_stream(ctx)) return rc;
-            if (stream != ctx->side) {
-                other = ctx->side;
-                PANO_HIP(hipEventRecord(ctx->ev_fork, stream));
-                PANO_HIP(hipStreamWaitEvent(other, ctx->ev_fork, 0));
-            }
-        }
         if (five) {
             grid = dim3((unsigned)cap * 4, 1, 1);        // one group
             PANO_TIMED(PK_BLUR_LEAN5, stream,
                        hipLaunchKernelGGL(blur_lean5_kernel, grid, dim3(MB_THREADS_OF(4)), lds_lean,
                                           stream, table, L, tables, owner, W, flags, sorted));
             PANO_LAUNCH_CHECK("blur_lean5_kernel");
-#if !MB_STREAM_EDGE
-            PANO_TIMED(PK_BLUR_IRREGULAR, other,
-                       hipLaunchKernelGGL(blur_irregular_kernel<true>, dim3(wgs),
-                                          dim3(MB_THREADS_OF(4)), lds, other, table, L, tables, owner,
-                                          W, flags, sorted, n_units, per));
-#endif
         } else {
             PANO_TIMED(PK_BLUR_LEAN, stream,
                        hipLaunchKernelGGL(blur_lean_kernel, grid, dim3(MB_THREADS_OF(4)), lds_lean,
                                           stream, table, L, tables, owner, W, flags, sorted));
             PANO_LAUNCH_CHECK("blur_lean_kernel");
-#if !MB_STREAM_EDGE
-            PANO_TIMED(PK_BLUR_IRREGULAR, other,
-                       hipLaunchKernelGGL(blur_irregular_kernel<false>, dim3(wgs),
-                                          dim3(MB_THREADS_OF(4)), lds, other, table, L, tables, owner,
-                                          W, flags, sorted, n_units, per));
-#endif
-        }
-        PANO_LAUNCH_CHECK("blur_irregular_kernel");
-        (void)wgs, (void)per;
-        if (other != stream) {
-            PANO_HIP(hipEventRecord(ctx->ev_join, other));
-            PANO_HIP(hipStreamWaitEvent(stream, ctx->ev_join, 0));
         }
         return PANO_OK;
     }
-#else
-    if (lean) {
-        PANO_TIMED(PK_BLUR_LEAN, stream,
-                   hipLaunchKernelGGL(blur_lean_kernel, grid, dim3(MB_THREADS_OF(4)), lds_lean,
-                                      stream, table, L, tables, owner, W, flags, sorted));
-        PANO_LAUNCH_CHECK("blur_lean_kernel");
-        return PANO_OK;
-    }
-#endif
     if (group == 2)
         PANO_TIMED(PK_BLUR_MFMA, stream,
                    hipLaunchKernelGGL(blur_mfma_kernel<2>, grid, dim3(MB_THREADS_OF(2)), lds, stream,
@@ -2922,7 +2446,7 @@ int pano_launch_blur_mfma(pano_ctx *ctx, const pano_patch *table, int n, int max
 #ifndef MB_FIVE_IN_ONE
 #define MB_FIVE_IN_ONE 1
 #endif
-    if (MB_STREAM && narrow && n_blur == 5 && ctx->opt[PANO_OPT_BLUR_LEAN] &&
+    if (narrow && n_blur == 5 && ctx->opt[PANO_OPT_BLUR_LEAN] &&
         mb_c_of(ntaps[0]) == 1 && mb_c_of(ntaps[1]) == 2 && ntaps[0] >= 3 && MB_FIVE_IN_ONE)
         // six pyramid levels: all five Gaussian levels in ONE launch (every band staged once)
         return launch_levels(ctx, table, n, max_aw, owner, W, host_taps, ntaps, 0, 5, rmax, 4, flags);

@@ -67,7 +67,6 @@ enum PanoKernelId {
     PK_KNN2,
     PK_BLUR_LEAN,
     PK_BLUR_LEAN5,
-    PK_BLUR_IRREGULAR,
     PK_COUNT
 };
 // ---- the context (include/pano360.h: pano_ctx) ------------------------------------
@@ -90,6 +89,7 @@ struct PanoTapSet {                 // one set of Gaussian apertures (pano_multi
 struct LayoutSummary;               // layout.h
 
 #define GEOM_BUFS 10
+#define STITCH_SIG 13             // stitch.hip: stitch_signature
 struct pano_ctx {
     int device;
     hipStream_t stream;
@@ -104,6 +104,10 @@ struct pano_ctx {
     int item_cap;
     const pano_patch *prepared_table, *flags_table;
     int prepared_n, flags_n;
+    // whose work list item_buf holds (stays when a blur has consumed `prepared_table`; an option
+    // switch or a re-allocation clears it): what a kept-geometry repeat may re-use
+    const pano_patch *list_table;
+    int list_n;
     std::vector<PanoTapSet> tap_sets;
     uint64_t tick;
     // pano_stitch_multiband: the regions' copy has landed / the record table has left the
@@ -122,7 +126,7 @@ struct pano_ctx {
     std::vector<int32_t> lay_rects_host;
     std::vector<uint8_t> lay_have_host;
     pano_layout lay_prev;
-    int lay_prev_sig[12];
+    int lay_prev_sig[STITCH_SIG];
     bool lay_prev_valid;
     bool lay_prev_verified;         // lay_prev was read back (device summary) or made on the host
     bool trusted_pending;           // a trusted stitch's summary has not been compared yet

@@ -161,10 +161,10 @@ static int ensure_layout_buffers(pano_ctx *ctx, int n) {
     return PANO_OK;
 }
 
-static void stitch_signature(const pano_stitch_args *a, int *sig) {
-    const int v[12] = {a->n, a->H, a->W, a->xs0, a->xs1, a->own0, a->own1, a->n_levels,
-                       a->radius, a->max_spans, a->shortcut, a->min_gap};
-    for (int k = 0; k < 12; ++k) sig[k] = v[k];
+static void stitch_signature(const pano_stitch_args *a, int tile_grid, int *sig) {
+    const int v[STITCH_SIG] = {a->n, a->H, a->W, a->xs0, a->xs1, a->own0, a->own1, a->n_levels,
+                               a->radius, a->max_spans, a->shortcut, a->min_gap, tile_grid};
+    for (int k = 0; k < STITCH_SIG; ++k) sig[k] = v[k];
 }
 
 // Runs `call` with the context targeted at its side stream.
@@ -316,8 +316,8 @@ extern "C" int pano_stitch_multiband(pano_ctx *ctx, pano_stitch_args *a, int res
     const bool two_streams = ctx->opt[PANO_OPT_STITCH_STREAMS] != 0 && big;
     const int tile_grid = pano_blur_tile_grid(ctx);
     const int stride = 5 + 2 * a->max_spans;
-    int sig[12];
-    stitch_signature(a, sig);
+    int sig[STITCH_SIG];
+    stitch_signature(a, tile_grid, sig);
 
     if (!resume) {
         // The layout on the device (option PANO_OPT_STITCH_ASYNC): for the default form of the
@@ -336,7 +336,13 @@ extern "C" int pano_stitch_multiband(pano_ctx *ctx, pano_stitch_args *a, int res
             if (int rc = pano_stitch_verify(ctx)) return rc;
         const bool trusted = want_trust && spec && ctx->lay_prev_verified &&
                              ctx->opt[PANO_OPT_STITCH_ASYNC] == 1;
-        if (want_keep && trusted && geom_was_valid) {
+        // (kept: only on the matrix-core grid - `spec` says so - and only while the work list in
+        // the context's buffers is the one the previous stitch built for this very table: an
+        // option switch voids it, pano_ctx_set_option)
+        const bool list_kept = n_blur == 0 || ctx->lay_prev.n_records == 0 ||
+                               (ctx->item_buf && ctx->list_table == a->table &&
+                                ctx->list_n == ctx->lay_prev.n_records);
+        if (want_keep && trusted && geom_was_valid && tile_grid == 32 && list_kept) {
             // Kept geometry: the owner map, the valid mask, the interior map, the record table, the
             // tile flags and the blur's work list are functions of the cameras, rectangles, strip and
             // resident frames alone - what the caller vouches for - and lie untouched where this

@@ -70,6 +70,56 @@ def describe_job(device="cpu", reduce_device="cpu", group=None):
                 allreduce_expected=world * (world + 1) // 2)
 
 
+def preflight(device="cpu", reduce_device="cpu", group=None, log=None, nbytes=1 << 20):
+    """The first real multi-rank exchange of a job, made cheap to diagnose: a record of who is
+    here (``log``: rank 0's sink, called BEFORE the first collective - world, rank, backend, this
+    rank's device), then the exchange's two collectives on one megabyte each - ``dist.gather`` of
+    uint8 pieces onto rank 0 and ``dist.reduce(sum)`` of a uint8 buffer, the calls
+    ``StripExchange.submit`` makes, on ``reduce_device`` - and their checks.  Returns the record
+    ({"gather_ok", "reduce_ok", "ms"}); raises ``RuntimeError`` when a check fails.  Callers run it
+    under their watchdog: a communicator that cannot move a megabyte hangs HERE."""
+    import time
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return {"world_size": 1, "skipped": "no process group"}
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    if log is not None:
+        import json
+        log("bench preflight " + json.dumps({
+            "stage": "before first collective", "world_size": world, "rank": rank,
+            "backend": dist.get_backend(group), "device": str(device),
+            "exchange_device": str(reduce_device)}))
+    t0 = time.perf_counter()
+    piece = torch.full((nbytes,), rank + 1, dtype=torch.uint8, device=reduce_device)
+    parts = ([torch.empty_like(piece) for _ in range(world)] if rank == 0 else None)
+    dist.gather(piece, parts, dst=0, group=group)
+    gather_ok = True
+    if rank == 0:
+        gather_ok = all(bool((p == r + 1).all().item()) for r, p in enumerate(parts))
+    # disjoint supports, as the strips are: rank r's slice holds r + 1, the sum is the composition
+    buf = torch.zeros(nbytes, dtype=torch.uint8, device=reduce_device)
+    lo, hi = nbytes * rank // world, nbytes * (rank + 1) // world
+    buf[lo:hi] = rank + 1
+    dist.reduce(buf, dst=0, op=dist.ReduceOp.SUM, group=group)
+    reduce_ok = True
+    if rank == 0:
+        want = torch.zeros(nbytes, dtype=torch.uint8, device=reduce_device)
+        for r in range(world):
+            want[nbytes * r // world:nbytes * (r + 1) // world] = r + 1
+        reduce_ok = bool(torch.equal(buf, want))
+    if str(reduce_device).startswith("cuda"):
+        torch.cuda.synchronize()
+    out = {"world_size": world, "bytes": nbytes, "gather_ok": gather_ok, "reduce_ok": reduce_ok,
+           "ms": (time.perf_counter() - t0) * 1e3}
+    if log is not None:
+        import json
+        log("bench preflight " + json.dumps(dict(out, stage="after gather + reduce")))
+    if not (gather_ok and reduce_ok):
+        raise RuntimeError(f"preflight exchange failed: {out}")
+    return out
+
+
 def strip_bounds(width, world):
     """Column boundaries c_0 = 0 <= c_1 <= ... <= c_world = width, equal widths."""
     return [int(round(width * r / world)) for r in range(world + 1)]
@@ -310,6 +360,7 @@ class ShardedStitcher:
         lane_depth = self.depth          # (every lane can hold the whole pipeline: any pattern of lanes)
         self.lanes = []
         self._lane_groups = []
+        self._restore = []
         for i, use in enumerate(engines):
             stream = None
             if i > 0 and str(getattr(use, "device", "cpu")).startswith("cuda"):
@@ -340,6 +391,11 @@ class ShardedStitcher:
             # (``keep_geometry``: a trusted repeat also re-uses the owner map, masks, record table
             # and work list its lane's previous stitch left on the device - Engine.keep_geometry)
             if exchange and hasattr(use, "trust_layouts"):
+                # (what the engine was set to before: close() puts it back)
+                self._restore.append((use, bool(getattr(use, "trust_layout", False)),
+                                      bool(getattr(use, "keep_geometry", False)),
+                                      use.get_option(_eng._lib.OPT_STITCH_ASYNC)
+                                      if hasattr(use, "get_option") else None))
                 use.trust_layouts(bool(cache_plan) if trust_layouts is None
                                   else bool(trust_layouts and cache_plan),
                                   keep_geometry=bool(keep_geometry))
@@ -431,6 +487,13 @@ class ShardedStitcher:
         rank closes its stitcher, in the same order it built it).  The stitcher cannot step
         afterwards."""
         self.finish()
+        # the engines go back to the trust / layout settings they came with: a later direct use
+        # must not stay in trusted mode with nobody calling verify_trusted
+        restore, self._restore = self._restore, []
+        for use, trust, keep, async_opt in restore:
+            use.trust_layouts(trust, keep_geometry=keep)
+            if async_opt is not None:
+                use.set_option(_eng._lib.OPT_STITCH_ASYNC, async_opt)
         groups, self._lane_groups = self._lane_groups, []
         if groups:
             import torch.distributed as dist

@@ -776,6 +776,15 @@ class Engine:
                    "pano_ctx_set_option")
         if option == _lib.OPT_BLUR_KERNEL:
             self.tile_grid = int(self.lib.pano_blur_tile_grid(self._ctx))
+        # an option may change how a stitch is laid out: the verified stitch a trusted repeat
+        # would ride on is not this configuration's (the context voids its side of it too)
+        self._trusted = None
+
+    def get_option(self, option):
+        value = C.c_int(0)
+        _lib.check(self.lib.pano_ctx_get_option(self._ctx, option, C.byref(value)),
+                   "pano_ctx_get_option")
+        return value.value
 
     def stitch_counts(self):
         """(stitches that went through on the device-side layout, attempts that fell back to
@@ -1002,13 +1011,6 @@ class Engine:
             wy = np.minimum(128, int(rec["ah"]) - 128 * np.arange(nty))
             total += int((grid.astype(np.int64) * wy[:, None] * wx[None, :]).sum())
         return total
-
-    def irregular_tile_share(self, n_levels):
-        """Share of the last blur's active tiles that a kernel other than the lean one blurs: none
-        since ``ms_body`` has its EDGE form (csrc/blur_mfma.hip, ``mb_item_regular``); bench.py
-        splits the blur's algorithmic bytes by it.  (A ``-DMB_STREAM_EDGE=0`` A/B build runs
-        ``blur_irregular_kernel`` beside the lean one; its share is then the bench's to state.)"""
-        return 0.0
 
     def compose_interior_async(self, owner, shape, strip, interior, cams, plan, luts,
                                want_float=False, mosaic_out=None):

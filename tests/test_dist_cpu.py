@@ -105,6 +105,14 @@ def _worker(rank, world, port, mode, depth, result, cache_plan=False, lanes=1):
         assert seen["world_size"] == world and seen["backend"] == "gloo"
         assert seen["allreduce_checksum"] == seen["allreduce_expected"] == world * (world + 1) // 2
         assert seen["devices"] == ["cpu"] * world
+        # the bench's pre-flight: who is here (logged before any collective of its own), then one
+        # gather and one uint8 sum-reduce of a small buffer, checked on rank 0
+        said = []
+        pre = pdist.preflight("cpu", "cpu", log=said.append if rank == 0 else None, nbytes=4099)
+        assert pre["world_size"] == world and pre["gather_ok"] and pre["reduce_ok"]
+        if rank == 0:
+            assert len(said) == 2 and "before first collective" in said[0] and len(said[0]) < 1024
+            assert f'"world_size": {world}' in said[0] and '"backend": "gloo"' in said[0]
         # image sets of a stream, dealt out over the ranks: each set exactly once
         mine = torch.zeros(7, dtype=torch.int64)
         mine[pdist.assign_sets(7, rank, world)] = 1
@@ -196,6 +204,10 @@ def test_trusted_layouts_and_kept_geometry_reach_the_lanes_engines():
         got.append(st.finish().clone())
         assert all(torch.equal(m, eng.truth(k)) for k, m in enumerate(got))
         assert sum(getattr(e, "verified", 0) for e in lanes) == (len(got) if cache_plan else 0)
+        # close() hands the engines back as they came: untrusted (a later direct use of the engine
+        # has nobody calling verify_trusted)
+        st.close()
+        assert all((e.trust_layout, e.keep_geometry) == (False, False) for e in lanes)
 
 
 def test_balanced_strip_bounds_cut_equal_work():

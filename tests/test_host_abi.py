@@ -466,3 +466,53 @@ def test_bench_reads_the_committed_profiles():
                      for f in fs)][-1]
     assert source.split("/")[1] == newest
     assert bench.pmc_traffic("blur_lean_kernel", "no_such_workload") == (None, None)
+
+
+def _bench_module():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_module", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    return bench
+
+
+def test_bench_stdout_line_is_compact_and_complete():
+    """The ONE stdout line of bench.py (`compact_line`) stays under 4 KB whatever the whole record
+    holds - round 5's 28 KB line lost its front in the driver's log - parses, and carries the
+    headline, `settings`, `roofline` and `cpu_baseline`; everything else goes to the side file."""
+    import json
+    bench = _bench_module()
+    with open(os.path.join(ROOT, "profiles", "r05", "final", "bench_default.json")) as fid:
+        full = json.load(fid)                       # a whole record as rounds 1 - 5 printed it
+    assert len(json.dumps(full)) > 20000
+    full["settings"] = {"plan": "per_stitch", "lanes": 2, "trusted": False, "keep_geometry": False}
+    full["alt_settings"] = {"plan": "memo", "lanes": 3, "trusted": True, "ms_per_step": 1.4}
+    full["roofline_by_kernel"] = {f"kernel_{k}": {"bound": "hbm", "frac": 0.4, "ms": 0.1, "x": "y" * 99}
+                                  for k in range(14)}
+    line = bench.compact_line(full, os.path.join(ROOT, "gpurun_out", "bench_full_cfg3_n1.json"))
+    assert len(line) < bench.COMPACT_LIMIT and "\n" not in line
+    got = json.loads(line)
+    for key in ("metric", "value", "unit", "value_kind", "processed_MPps", "n_gpus", "steps", "warmup",
+                "ms_per_step", "dtype", "arithmetic", "higher_is_better", "scaling", "vs_baseline",
+                "data", "config", "settings", "roofline", "cpu_baseline", "side_file"):
+        assert key in got, key
+    assert got["value"] == pytest.approx(full["value"], rel=1e-5)
+    assert got["ms_per_step"] == pytest.approx(full["ms_per_step"], rel=1e-5)
+    assert {"kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "blend_frac",
+            "weighted_frac"} <= set(got["roofline"])
+    assert got["roofline"]["frac"] == pytest.approx(full["roofline"]["frac"], rel=1e-5)
+    assert {"value", "unit", "cores", "kind", "sample"} <= set(got["cpu_baseline"])
+    assert len(got["cpu_baseline"]["sample"]) <= 200
+    assert "workload" in got["config"] and "model" not in got["config"]
+    assert got["settings"]["plan"] == "per_stitch" and got["alt_settings"]["plan"] == "memo"
+    assert got["secondary_ms"]["cfg5"] == pytest.approx(full["secondary"]["cfg5"]["ms_per_step"], rel=1e-3)
+    # a record bloated far past anything real still comes out under the limit, headline intact
+    full["secondary"] = {f"entry_{k}": {"ms_per_step": 1.0} for k in range(400)}
+    full["config"]["parallelism"] = "x" * 5000
+    line = bench.compact_line(full, None)
+    got = json.loads(line)
+    assert len(line) < bench.COMPACT_LIMIT
+    assert {"metric", "value", "ms_per_step", "roofline", "cpu_baseline", "settings"} <= set(got)
+    # the error notes of a failed multi-rank run ride on the line
+    full["strips_error"] = "RuntimeError('x')"
+    assert json.loads(bench.compact_line(full, None))["strips_error"] == "RuntimeError('x')"

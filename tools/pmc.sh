@@ -12,7 +12,7 @@ cd /tmp
 run() {  # name, counters...
   name=$1; shift
   timeout 600 rocprofv3 --pmc "$@" --output-format csv -d "$OUT/$name" -- \
-      python3 "$HERE/bench.py" --workload "$WL" --steps 2 --warmup 1 --no-cpu-baseline --no-secondary --busy-seconds 0 ${PMC_EXTRA:-} \
+      python3 "$HERE/bench.py" --workload "$WL" --steps 2 --warmup 1 --no-cpu-baseline --no-secondary --busy-seconds 0 --side-file "$OUT/$name.full.json" ${PMC_EXTRA:-} \
       > "$OUT/$name.log" 2>&1
   echo "pass $name rc=$?"
 }
