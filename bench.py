@@ -389,7 +389,9 @@ def roofline_by_kernel(times, plan, patches, n_levels, steps, px_active, workloa
         if name == "ownership_cameras_kernel":
             issue = ownership_issue_bound(workload)
             if issue is not None:
-                entry.update(bound="valu", frac=issue["issue_ms_per_launch"] * launches / steps / ms,
+                # (the counters' own time base: the share of the launch's SIMD-cycles in which a
+                # vector instruction executed - of the profiled run, committed; not this run's ms)
+                entry.update(bound="valu", frac=issue["valu_busy"],
                              hbm_frac=entry.pop("frac", None), issue=issue)
         out[name] = entry
     return out
@@ -397,10 +399,10 @@ def roofline_by_kernel(times, plan, patches, n_levels, steps, px_active, workloa
 
 def ownership_issue_bound(workload):
     """The committed instruction counters of the ownership kernel on this workload
-    (profiles/<round>/[final/]own_issue_<workload>.json, written by tools/own_issue.py from a
-    --pmc pass: SQ_INSTS_VALU, SQ_ACTIVE_INST_VALU, SQ_BUSY_CYCLES, GRBM_GUI_ACTIVE per launch):
-    the time the kernel's vector instructions need at one instruction per SIMD and cycle on
-    every SIMD of the chip - its issue bound.  None when no such file is committed."""
+    (profiles/<round>/[final/]own_issue_<workload>.json, written by tools/own_issue.py from the
+    --pmc passes: SQ_ACTIVE_INST_VALU, SQ_INSTS_VALU, GRBM_GUI_ACTIVE per launch): `valu_busy` =
+    the share of the kernel's SIMD-cycles in which a vector instruction was executing - its
+    fraction of the issue roof.  The newest round's file wins; None when none is committed."""
     import glob
     found = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "**", f"own_issue_{workload}.json"),
                              recursive=True))
@@ -412,7 +414,7 @@ def ownership_issue_bound(workload):
     except (OSError, ValueError):
         return None
     rec["source"] = os.path.relpath(found[-1], ROOT)
-    return rec if "issue_ms_per_launch" in rec else None
+    return rec if "valu_busy" in rec else None
 
 
 def cpu_baseline(cfg):

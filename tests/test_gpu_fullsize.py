@@ -454,37 +454,42 @@ def test_cfg5_windows_against_oracle(eng, oracle):
     assert all(s[1] > 0 and s[2] >= 2 for s in seen) and seen[2][0] >= 2 and any(s[0] >= 3 for s in seen)
 
 
-@pytest.mark.parametrize("name", ["cfg3", "cfg5"])
-def test_full_size_multiband_windows_against_oracle(eng, oracle, name):
-    """The multiband mosaic of BASELINE configs 3 and 5 AT FULL SIZE against the oracle, on
-    windows.  Every level blurs the ORIGINAL warped patch (stitcher.py:226), so a pixel of the
-    mosaic depends on the patches within the largest Gaussian radius R of it only: the oracle's
-    multiband_blend on the patches cut to a 288 x 288 window (its blur reflecting at the cut)
-    equals the reference's on the whole mosaic on the window shrunk by R from every cut side.
-    Two passes, interior shortcut on:
-    * noise frames (pixel set A, the stress set): uint8 within one level, the stated bound of the
-      multiband path, and at most 0.4 % of a window's values off by that level (measured 0.08 %);
-    * smooth frames (pixel set B, SURVEY 8d's set for the float criterion): the FLOAT mosaic
-      before the uint8 truncation within 1e-4 relative L2 of the oracle's on every window, and the
-      uint8 mosaic within one level."""
+def _seam_windows(owner, S, rng, limit=None):
+    """One S x S window on every SEAM of the mosaic - a pair (a, b) of owners that are horizontal
+    neighbours somewhere - centred on the seam at a seeded random row of its own (drawn among the
+    rows where that pair is adjacent, away from the top and bottom by S / 2 where it can be); with
+    ``limit`` a seeded choice of that many seams.  Also returns the mosaic's total seam length in
+    pixel rows (horizontal owner changes between two valid owners)."""
+    H, W = owner.shape
+    change = (owner[:, 1:] != owner[:, :-1]) & (owner[:, 1:] >= 0) & (owner[:, :-1] >= 0)
+    ys, xs = np.nonzero(change)
+    seam_rows = len(ys)
+    key = owner[ys, xs].astype(np.int64) * 65536 + owner[ys, xs + 1].astype(np.int64)
+    pairs = [int(k) for k in np.unique(key)]
+    if limit is not None and len(pairs) > limit:
+        pairs = [pairs[i] for i in sorted(rng.choice(len(pairs), size=limit, replace=False))]
+    windows = []
+    for k in pairs:
+        at = np.nonzero(key == k)[0]
+        inner = at[(ys[at] >= S // 2) & (ys[at] < H - S // 2)]
+        pick = int(rng.choice(inner if len(inner) else at))
+        r, x = int(ys[pick]), int(xs[pick])
+        y0, x0 = min(max(r - S // 2, 0), H - S), min(max(x - S // 2, 0), W - S)
+        windows.append((y0, y0 + S, x0, x0 + S))
+    return windows, [(k >> 16, k & 65535) for k in pairs], seam_rows
+
+
+def _check_multiband_windows(eng, oracle, name, rots, intrs, w, h, levels, plan, windows):
+    """The fused multiband mosaic (interior shortcut on) against the oracle on ``windows`` of the
+    mosaic, two passes: noise frames (pixel set A) - uint8 within one level, at most 0.4 % of a
+    window's values off by that level; smooth frames (pixel set B, SURVEY 8d's set for the float
+    criterion) - the FLOAT mosaic before the uint8 truncation within 1e-4 relative L2 on every
+    window, uint8 within one level.  Returns the number of mosaic rows compared per window."""
     from pano360_amd import engine, synth
-    cfg = synth.CONFIGS[name]
-    n, w, h, levels = cfg["n"], cfg["width"], cfg["height"], cfg["n_levels"]
-    rots, intrs = synth.make_cameras(n, w, h, sweep_deg=cfg.get("sweep_deg"),
-                                     step_deg=cfg.get("step_deg"))
-    shapes = [(h, w)] * n
-    plan = engine.Plan(shapes, rots, intrs, True, 10 ** 9)
+    n = len(rots)
     H, W = plan.shape
-    owner = eng.ownership_cameras(eng.upload_plan(plan))[0].cpu().numpy()
     R = max(engine.gaussian_ksize(s) // 2 for s in engine.level_sigmas(levels))
-    S = 288
-    seams = np.nonzero(np.diff(owner[H // 2]))[0]
-    mid = int(seams[np.argmin(np.abs(seams - W // 2))])
-    mid = min(max(mid - S // 2, 0), W - S)
-    windows = [(H // 2 - S // 2, H // 2 + S // 2, mid, mid + S),      # a seam in the middle
-               (H // 2, H // 2 + S, W - S, W), (H // 2, H // 2 + S, 0, S),     # both ends
-               (0, S, mid, mid + S), (H - S, H, W - S, W)]                     # top, a corner
-    del owner
+    rows_compared = []
     for kind, distinct in (("A", 4), ("B", 2)):
         host = [synth.make_frame(i, w, h, kind) for i in range(distinct)]
         imgs = [host[i % distinct] for i in range(n)]
@@ -495,9 +500,10 @@ def test_full_size_multiband_windows_against_oracle(eng, oracle, name):
         cache, worst, total, worst_rel = {}, 0, 0, 0.0
         for win in windows:
             wy0, wy1, wx0, wx1 = win
+            S_y, S_x = wy1 - wy0, wx1 - wx0
             _, patches, shape = _oracle_window(oracle, imgs, cache, rots, intrs, True, win)
-            iy0, iy1 = (R if wy0 > 0 else 0), S - (R if wy1 < H else 0)
-            ix0, ix1 = (R if wx0 > 0 else 0), S - (R if wx1 < W else 0)
+            iy0, iy1 = (R if wy0 > 0 else 0), S_y - (R if wy1 < H else 0)
+            ix0, ix1 = (R if wx0 > 0 else 0), S_x - (R if wx1 < W else 0)
             if kind == "B":
                 ref, ref_f = oracle.multiband_blend(patches, shape, levels, return_float=True)
                 got_f = fl[wy0:wy1, wx0:wx1].cpu().numpy()[iy0:iy1, ix0:ix1]
@@ -508,17 +514,102 @@ def test_full_size_multiband_windows_against_oracle(eng, oracle, name):
                 worst_rel = max(worst_rel, rel)
             else:
                 ref = oracle.multiband_blend(patches, shape, levels)
+                rows_compared.append(iy1 - iy0)
             got = mosaic[wy0:wy1, wx0:wx1][iy0:iy1, ix0:ix1].astype(np.int32)
             diff = np.abs(got - ref[iy0:iy1, ix0:ix1].astype(np.int32))
             assert diff.max() <= 1, (kind, win, int(diff.max()), int((diff > 1).sum()))
             assert ref[iy0:iy1, ix0:ix1].max() > 0
             worst = max(worst, float((diff > 0).mean()))
             total += diff.size
-        print(f"{name} full size, multiband windows, pixel set {kind}: {total} values compared, at "
-              f"most {100 * worst:.3f} % of a window differ by one level"
+        print(f"{name} full size, multiband on {len(windows)} windows, pixel set {kind}: {total} values "
+              f"compared, at most {100 * worst:.3f} % of a window differ by one level"
               + (f", float mosaic rel-L2 at most {worst_rel:.2e}" if kind == "B" else ""))
         assert worst < 0.004                    # five times the measured 0.0008
         del mosaic, fl, frames, base, host, imgs, cache
+    return rows_compared
+
+
+@pytest.mark.parametrize("name", ["cfg3", "cfg5"])
+def test_full_size_multiband_windows_against_oracle(eng, oracle, name):
+    """The multiband mosaic of BASELINE configs 3 and 5 AT FULL SIZE against the oracle, on
+    windows.  Every level blurs the ORIGINAL warped patch (stitcher.py:226), so a pixel of the
+    mosaic depends on the patches within the largest Gaussian radius R of it only: the oracle's
+    multiband_blend on the patches cut to a 288 x 288 window (its blur reflecting at the cut)
+    equals the reference's on the whole mosaic on the window shrunk by R from every cut side.
+    Windows: one on EVERY seam of config 3 (31) at a seeded random row, sixteen seams of config 5
+    (seeded choice), plus both ends of the sweep (config 5: the seam-straddling frames), the top
+    and a corner.  Criteria: ``_check_multiband_windows``."""
+    from pano360_amd import engine, synth
+    cfg = synth.CONFIGS[name]
+    n, w, h, levels = cfg["n"], cfg["width"], cfg["height"], cfg["n_levels"]
+    rots, intrs = synth.make_cameras(n, w, h, sweep_deg=cfg.get("sweep_deg"),
+                                     step_deg=cfg.get("step_deg"))
+    shapes = [(h, w)] * n
+    plan = engine.Plan(shapes, rots, intrs, True, 10 ** 9)
+    H, W = plan.shape
+    owner = eng.ownership_cameras(eng.upload_plan(plan))[0].cpu().numpy()
+    S = 288
+    rng = np.random.default_rng(606 + n)
+    windows, pairs, seam_rows = _seam_windows(owner, S, rng, None if name == "cfg3" else 16)
+    assert len(windows) == (31 if name == "cfg3" else 16), len(windows)
+    n_seam_windows = len(windows)
+    mid = min(max(W // 2 - S // 2, 0), W - S)
+    windows += [(H // 2, H // 2 + S, W - S, W), (H // 2, H // 2 + S, 0, S),     # both ends
+                (0, S, mid, mid + S), (H - S, H, W - S, W)]                     # top, a corner
+    del owner
+    rows = _check_multiband_windows(eng, oracle, name, rots, intrs, w, h, levels, plan, windows)
+    print(f"{name}: {n_seam_windows} seam windows, {sum(rows[:n_seam_windows])} of {seam_rows} seam "
+          f"rows compared = {100.0 * sum(rows[:n_seam_windows]) / seam_rows:.2f} % of the seam length")
+
+
+def test_cfg3_jittered_rig_full_size_against_oracle(eng, oracle):
+    """Config 3's cameras with N(0, 0.01 rad) on all three axes (SURVEY 8d's recipe; every other
+    full-size scene is a pure-yaw rig): tilted, uneven seams at FULL size.  Bit-exact: the valid
+    mask of the whole mosaic against the OR of the oracle's inverse-map masks, the crop rectangle,
+    the owner map on a window on every seam (and the corners) against the oracle's argmax.  Then
+    the multiband mosaic on twelve of those seam windows: ``_check_multiband_windows``."""
+    from pano360_amd import engine, synth
+    cfg = synth.CONFIGS["cfg3"]
+    n, w, h, levels = cfg["n"], cfg["width"], cfg["height"], cfg["n_levels"]
+    rots, intrs = synth.make_cameras(n, w, h, sweep_deg=cfg["sweep_deg"], jitter=0.01, seed=3)
+    shapes = [(h, w)] * n
+    plan = eng.upload_plan(engine.Plan(shapes, rots, intrs, True, 10 ** 9))
+    H, W = plan.shape
+    owner_t, valid_t = eng.ownership_cameras(plan)
+    owner, valid = owner_t.cpu().numpy(), valid_t.cpu().numpy().astype(bool)
+    oplan = oracle.Plan(shapes, rots, intrs, True, 10 ** 9)
+    assert oplan.shape == plan.shape and oplan.rects == plan.rects
+    # the rig really is tilted: the patches' top rows differ by tens of pixels
+    tops = [r[0] for r in plan.rects]
+    assert max(tops) - min(tops) >= 20 or max(r[1] for r in plan.rects) - min(r[1] for r in plan.rects) >= 20
+    ref_valid = np.zeros(plan.shape, bool)
+    for proj, rect in zip(oplan.projs, oplan.rects):
+        _, _, mask = oracle.inverse_map(proj, oplan, rect, (h, w))
+        ref_valid[rect[0]:rect[1], rect[2]:rect[3]] |= ~mask
+    assert np.array_equal(valid, ref_valid)
+    assert eng.crop_rect(valid_t) == oracle.crop_rect(ref_valid)
+    S = 288
+    rng = np.random.default_rng(20260)
+    windows, pairs, seam_rows = _seam_windows(owner, S, rng)
+    assert len(windows) >= 31, len(windows)
+    corners = [(0, S, 0, S), (0, S, W - S, W), (H - S, H, 0, S), (H - S, H, W - S, W)]
+    host = [synth.make_frame(i, w, h, "A") for i in range(2)]
+    imgs = [host[i % 2] for i in range(n)]
+    cache, owners_seen = {}, set()
+    for win in windows + corners:
+        wy0, wy1, wx0, wx1 = win
+        _, patches, shape = _oracle_window(oracle, imgs, cache, rots, intrs, True, win)
+        assert np.array_equal(owner[wy0:wy1, wx0:wx1], oracle.ownership(patches, shape)), win
+        assert np.array_equal(valid[wy0:wy1, wx0:wx1], oracle.valid(patches, shape)), win
+        owners_seen.update(np.unique(owner[wy0:wy1, wx0:wx1]).tolist())
+    assert len(owners_seen - {-1}) == n              # every camera owns pixels in some window
+    del cache, host, imgs
+    pick = [windows[i] for i in sorted(rng.choice(len(windows), size=12, replace=False))]
+    rows = _check_multiband_windows(eng, oracle, "cfg3 jittered", rots, intrs, w, h, levels, plan,
+                                    pick + corners[:2])
+    print(f"cfg3 jittered: owner map bit-exact on {len(windows)} seam windows + 4 corners; multiband on "
+          f"12 seam windows, {sum(rows[:12])} of {seam_rows} seam rows = "
+          f"{100.0 * sum(rows[:12]) / seam_rows:.2f} % of the seam length")
 
 
 @pytest.mark.parametrize("world", [8, 5])
