@@ -546,6 +546,13 @@ def run_cfg4(args, eng, rank, world, steps=None, warmup=None, detect=None):
             lanes.append((_engine.Engine(eng.device), s2))
     torch.cuda.synchronize()
 
+    # One native call per frame (features.SiftPipeline -> pano_sift_detect): its ~70 (scale space)
+    # or ~110 (with detection) launches are queued from C++ and, from the second frame of a
+    # workspace on, replayed as ONE HIP graph - queued launch by launch from Python they cost a slow
+    # host more than the GPU (cfg4_detect 3.0 - 6.5 ms per frame by box in rounds 4 - 6).  A
+    # pipeline's three workspaces go round: a frame's result is fetched a frame later.
+    pipes = [features.SiftPipeline(use, h, w, depth=3) for use, _ in lanes]
+
     def step():
         k = state["i"]
         frame = pool[k % len(pool)]
@@ -554,18 +561,16 @@ def run_cfg4(args, eng, rank, world, steps=None, warmup=None, detect=None):
         lane = 0 if state.get("serial") else k % len(lanes)
         use, stream = lanes[lane]
         with torch.cuda.stream(stream):
-            pyr = features.sift_pyramid_device(frame, eng=use)
             if detect:
                 # queued without waiting; the keypoints of the frame this lane took before are
                 # fetched meanwhile
                 key = ("job", lane)
-                job, state[key] = state.get(key), features.sift_detect_async(frame, pyramid=pyr,
-                                                                           eng=use)
+                job, state[key] = state.get(key), pipes[lane].detect(frame)
                 if job is not None:
                     state["kps"] = job.result()[0]
                     state["n_kp"] = len(state["kps"])
-                return pyr, state.get("n_kp")
-        return pyr, None
+                return state[key].pyramid, state.get("n_kp")
+            return pipes[lane].pyramid(frame), None
 
     def fence():
         torch.cuda.synchronize()
@@ -574,7 +579,8 @@ def run_cfg4(args, eng, rank, world, steps=None, warmup=None, detect=None):
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(2):
+    # (every workspace twice: its first frame goes launch by launch, its second is captured)
+    for _ in range(2 * 3 * len(lanes)):
         step()
     fence()
     # (as in main(): the cyclic collector's full pass - tens of ms over all of torch and numpy -
@@ -602,6 +608,7 @@ def run_cfg4(args, eng, rank, world, steps=None, warmup=None, detect=None):
             state["kps"] = job.result()[0]
             state["n_kp"] = n_kp = len(state["kps"])
     SIFT_KPS["last"] = state.get("kps")
+    SIFT_KPS["replaying"] = all(p.replaying for p in pipes)
     return elapsed, pyr, n_kp, times, (w, h)
 
 
@@ -669,7 +676,9 @@ def cfg4_line(args, world, elapsed, pyr, n_kp, times, size):
                   "scale space, keypoints and descriptors are checked against this repo's own NumPy "
                   "restatement of OpenCV's algorithm (oracle/sift_pyramid.py, sift_oracle.py) only",
         "settings": {"frames_in_flight": max(1, int(os.environ.get("PANO_CFG4_STREAMS", "2"))),
-                     "detect": bool(args.detect)},
+                     "detect": bool(args.detect),
+                     # one native call per frame, replayed as a HIP graph (pano_sift_detect)
+                     "graph_replay": bool(SIFT_KPS.get("replaying"))},
         "config": {"workload": f"cfg4: Gaussian / DoG pyramid of {w}x{h} frames (SIFT front end, "
                                f"first octave -1: {gauss[0].shape[2]}x{gauss[0].shape[1]} base, "
                                f"{len(gauss)} octaves, 6 + 5 layers each), one frame per step "

@@ -192,7 +192,11 @@ int pano_interior_block(void);
  *                         length of the vertical segments a launch with few work items is cut
  *                         into comes from the sort kernel's list-schedule estimate; n >= 4 =
  *                         segments of n bands (32 rows each); -1 = nothing is cut.  Same results
- *                         bit for bit (A/B of the estimate, and the tests' way to other cuts). */
+ *                         bit for bit (A/B of the estimate, and the tests' way to other cuts).
+ *   PANO_OPT_SIFT_GRAPH   pano_sift_detect: 1 (default) = a frame's launch sequence is captured
+ *                         into a HIP graph the second time a set of buffers is used and replayed
+ *                         from then on (one hipGraphLaunch per frame instead of ~110 launches);
+ *                         0 = always launch by launch.  Same results bit for bit. */
 typedef struct pano_ctx pano_ctx;
 #define PANO_OPT_BLUR_KERNEL 0
 #define PANO_OPT_OWN_PRUNE 1
@@ -201,7 +205,8 @@ typedef struct pano_ctx pano_ctx;
 #define PANO_OPT_STITCH_STREAMS 4
 #define PANO_OPT_STITCH_ASYNC 5
 #define PANO_OPT_BLUR_SEG_LEN 6
-#define PANO_OPT_COUNT 7
+#define PANO_OPT_SIFT_GRAPH 7
+#define PANO_OPT_COUNT 8
 #define PANO_BLUR_MFMA 0
 #define PANO_BLUR_VALU 1
 int pano_ctx_create(int device, void *stream, pano_ctx **out);
@@ -565,6 +570,42 @@ int pano_sift_describe(pano_ctx *ctx, const float *const *gauss, const int *dims
 size_t pano_sift_sort_work_bytes(int n);
 int pano_sift_sort_unique(pano_ctx *ctx, const pano_sift_keypoint *kpts, int n, const int *n_dev,
                           int first_octave, void *work, pano_sift_keypoint *out, int *n_out);
+
+/* One frame of the detector's front end per call           features.py:192-201 (_detect)
+ * = pano_scale_space, then - with `detect` - pano_sift_extrema for every octave,
+ * pano_sift_orient, pano_sift_sort_unique and pano_sift_describe, in that order on the
+ * context's stream, nothing waited for: the candidate / keypoint / kept counts stay on the
+ * device in counts[0..2] (zeroed here).  Every launch's grid and arguments follow from the
+ * frame size and the buffers alone, so with PANO_OPT_SIFT_GRAPH (default) the sequence is
+ * captured into a HIP graph the second time a set of buffers comes by and replayed afterwards:
+ * `frame_copy` (dev, h * w * 3 bytes, optional) is the frame buffer the graph reads - the
+ * caller's frame is copied into it in front of every replay; without it, or while kernels are
+ * being timed, the sequence is queued launch by launch.  Results are the same either way.
+ * Buffers: as the entry points named above take them; gauss / dog: host arrays of n_octaves
+ * device pointers; gauss_dev / dims_dev: the device arrays pano_sift_orient reads; the result:
+ * cands (the kept keypoints, OpenCV's order), desc, counts[2]. */
+typedef struct pano_sift_args {
+    const uint8_t *frame;      /* dev uint8 [h][w][3]                                   */
+    uint8_t *frame_copy;       /* dev, same size: the graph's own frame buffer, or NULL  */
+    int32_t h, w, n_octaves, n_layers;
+    const float *taps;         /* host: the n_layers + 3 kernels of pano_scale_space     */
+    const int32_t *ntaps;      /* host [n_layers + 3]                                    */
+    float *const *gauss;       /* host [n_octaves] of dev float [n_layers + 3][rows][cols] */
+    float *const *dog;         /* host [n_octaves] of dev float [n_layers + 2][rows][cols] */
+    float *work;               /* dev, 5 h w floats                                      */
+    int32_t detect;            /* 0 = the scale space only                               */
+    float contrast_thr, edge_thr, sigma;
+    int32_t first_octave, max_keypoints;
+    const float *const *gauss_dev;   /* dev [n_octaves]: the pointers of `gauss`         */
+    const int32_t *dims_dev;         /* dev [n_octaves][2]: rows, cols                   */
+    pano_sift_keypoint *cands, *kpts;   /* dev [max_keypoints] each                      */
+    int32_t *counts;           /* dev int32 [3]: candidates, keypoints, kept             */
+    void *sort_work;           /* dev, pano_sift_sort_work_bytes(max_keypoints)          */
+    float *desc;               /* dev float [max_keypoints][128]                         */
+} pano_sift_args;
+int pano_sift_detect(pano_ctx *ctx, const pano_sift_args *args);
+/* 1 when the most recently used set of buffers of pano_sift_detect is replayed as a graph */
+int pano_sift_detect_replaying(const pano_ctx *ctx);
 
 /* The two nearest rows of `train` for every row of `query` (Euclidean), the search behind
  * flann_matching                                                  features.py:222-232

@@ -23,6 +23,7 @@ TAP_PAD = 40
 OPT_BLUR_KERNEL, OPT_OWN_PRUNE, OPT_BLUR_SEGMENTS, OPT_BLUR_LEAN, OPT_STITCH_STREAMS = 0, 1, 2, 3, 4
 OPT_STITCH_ASYNC = 5
 OPT_BLUR_SEG_LEN = 6
+OPT_SIFT_GRAPH = 7
 BLUR_MFMA, BLUR_VALU = 0, 1
 
 
@@ -47,6 +48,19 @@ class Layout(C.Structure):
                 ("scratch_floats", C.c_int64), ("n_records", C.c_int32), ("n_tiles", C.c_int32),
                 ("max_vw", C.c_int32), ("max_vh", C.c_int32), ("max_aw", C.c_int32),
                 ("max_ah", C.c_int32), ("missing", C.c_int32)]
+
+
+class SiftArgs(C.Structure):
+    """``pano_sift_args`` of include/pano360.h."""
+    _fields_ = [("frame", C.c_void_p), ("frame_copy", C.c_void_p),
+                ("h", C.c_int32), ("w", C.c_int32), ("n_octaves", C.c_int32), ("n_layers", C.c_int32),
+                ("taps", C.c_void_p), ("ntaps", C.c_void_p), ("gauss", C.c_void_p),
+                ("dog", C.c_void_p), ("work", C.c_void_p), ("detect", C.c_int32),
+                ("contrast_thr", C.c_float), ("edge_thr", C.c_float), ("sigma", C.c_float),
+                ("first_octave", C.c_int32), ("max_keypoints", C.c_int32),
+                ("gauss_dev", C.c_void_p), ("dims_dev", C.c_void_p), ("cands", C.c_void_p),
+                ("kpts", C.c_void_p), ("counts", C.c_void_p), ("sort_work", C.c_void_p),
+                ("desc", C.c_void_p)]
 
 
 class StitchArgs(C.Structure):
@@ -150,6 +164,8 @@ _SIGNATURES = {
     "pano_sift_sort_unique": (_i, [_vp, _vp, _i, _vp, _i, _vp, _vp, _vp]),
     "pano_knn2_work_bytes": (C.c_size_t, [_i, _i, _i]),
     "pano_knn2": (_i, [_vp, _vp, _i, _vp, _i, _i, C.c_float, _vp, _vp, _vp, _vp]),
+    "pano_sift_detect": (_i, [_vp, _vp]),
+    "pano_sift_detect_replaying": (_i, [_vp]),
     "pano_stitch_multiband": (_i, [_vp, _vp, _i]),
     "pano_stitch_counts": (_i, [_vp, _vp, _vp]),
     "pano_stitch_verify": (_i, [_vp]),

@@ -55,6 +55,7 @@ extern "C" int pano_ctx_create(int device, void *stream, pano_ctx **out) {
     ctx->opt[PANO_OPT_STITCH_STREAMS] = 1;
     ctx->opt[PANO_OPT_STITCH_ASYNC] = 0;
     ctx->opt[PANO_OPT_BLUR_SEG_LEN] = 0;
+    ctx->opt[PANO_OPT_SIFT_GRAPH] = 1;
     *out = ctx;
     return PANO_OK;
 }
@@ -99,6 +100,7 @@ extern "C" int pano_ctx_destroy(pano_ctx *ctx) {
     if (ctx->item_buf) (void)hipFree(ctx->item_buf);
     if (ctx->item_counter) (void)hipFree(ctx->item_counter);
     if (ctx->sift_raw) (void)hipFree(ctx->sift_raw);
+    pano_sift_graphs_free(ctx);
     if (ctx->lay_sum_host) (void)hipHostFree(ctx->lay_sum_host);
     if (ctx->lay_rects_dev) (void)hipFree(ctx->lay_rects_dev);
     if (ctx->lay_have_dev) (void)hipFree(ctx->lay_have_dev);

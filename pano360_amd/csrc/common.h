@@ -87,6 +87,12 @@ struct PanoTapSet {                 // one set of Gaussian apertures (pano_multi
 };
 
 struct LayoutSummary;               // layout.h
+struct PanoSiftGraph {               // detect.hip: one captured launch sequence of pano_sift_detect
+    uint64_t key;                   // hash of sizes, switches, buffer addresses, tap values
+    hipGraphExec_t exec;            // null: not captured (yet, or the capture failed)
+    int seen;                       // 0 new, 1 ran launch by launch once, 2 capture attempted
+    uint64_t used;                  // last use (eviction order)
+};
 
 #define GEOM_BUFS 10
 #define STITCH_SIG 13             // stitch.hip: stitch_signature
@@ -139,9 +145,12 @@ struct pano_ctx {
     // pano_sift_extrema: the list of scale-space extrema between its two kernels (+ its counter)
     uint32_t *sift_raw;
     size_t sift_raw_cap;
+    // pano_sift_detect: the captured launch sequences, one per set of buffers (detect.hip)
+    std::vector<PanoSiftGraph> sift_graphs;
 };
 
 int pano_ctx_enter(pano_ctx *ctx);
+void pano_sift_graphs_free(pano_ctx *ctx);   // detect.hip
 int pano_ctx_side_stream(pano_ctx *ctx);     // makes ctx->side and the fork / join events
 // Device copy of a host tap table set (and, with `tables`, its matrix-core operand tables'
 // buffer, `table_bytes` long, `*fresh` = it was just allocated and must be filled).

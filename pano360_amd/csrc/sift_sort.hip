@@ -9,13 +9,17 @@
 //
 // On the host this was np.lexsort over six keys: 54 of the 69 ms of a 4K frame's
 // detectAndCompute (135 k keypoints).  Here: ONE stable radix sort of (64-bit key, index)
-// pairs on the two leading keys, x and y - rocPRIM's device radix sort through hipCUB, the
-// library sort for a plain sort - and a kernel that orders the short runs of keypoints sharing
+// pairs on the two leading keys, x and y - rocPRIM's device radix sort, called directly (the
+// ROCm library primitive for a plain key-value sort; rounds 3 - 5 went through the hipCUB
+// compatibility layer) - and a kernel that orders the short runs of keypoints sharing
 // a position by the other four keys (a stable insertion sort per run: the same order as six
 // stable least-significant-key-first passes, which is what round 2 ran - a hundred launches
 // per frame, 0.6 ms of launch latency); hand-written kernels around them build the
 // order-preserving integer keys, flag the duplicates and compact the survivors.
-#include <hipcub/hipcub.hpp>
+#include <string.h>
+
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
 
 #include "common.h"
 
@@ -126,8 +130,8 @@ SortLayout sort_layout(int n) {
     uint64_t *k64 = nullptr;
     uint32_t *ku = nullptr;
     int *iu = nullptr;
-    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, sort_bytes, k64, k64, ku, ku, n);   // size queries
-    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, iu, iu, n);
+    (void)rocprim::radix_sort_pairs(nullptr, sort_bytes, k64, k64, ku, ku, (size_t)n, 0u, 64u);   // size queries
+    (void)rocprim::exclusive_scan(nullptr, scan_bytes, iu, iu, 0, (size_t)n, rocprim::plus<int>());
     L.temp_bytes = ((sort_bytes > scan_bytes ? sort_bytes : scan_bytes) + 255) & ~(size_t)255;
     const size_t arr = ((size_t)n * 4 + 255) & ~(size_t)255;
     L.keys_a = L.temp_bytes;                            // 64-bit keys: two arrays' worth each
@@ -167,15 +171,15 @@ extern "C" int pano_sift_sort_unique(pano_ctx *ctx, const pano_sift_keypoint *kp
     PANO_LAUNCH_CHECK("sift_keys_kernel");
     {
         size_t temp = L.temp_bytes;
-        PANO_HIP(hipcub::DeviceRadixSort::SortPairs(base, temp, keys_a, keys_b, idx_b, idx_a, n, 0,
-                                                    64, s));
+        PANO_HIP(rocprim::radix_sort_pairs(base, temp, keys_a, keys_b, idx_b, idx_a, (size_t)n, 0u,
+                                           64u, s));
     }
     hipLaunchKernelGGL(sift_runs_kernel, grid, block, 0, s, kpts, keys_b, n, idx_a);
     PANO_LAUNCH_CHECK("sift_runs_kernel");
     hipLaunchKernelGGL(sift_flags_kernel, grid, block, 0, s, kpts, idx_a, n, n_dev, flags);
     PANO_LAUNCH_CHECK("sift_flags_kernel");
     size_t temp = L.temp_bytes;
-    PANO_HIP(hipcub::DeviceScan::ExclusiveSum(base, temp, flags, pos, n, s));
+    PANO_HIP(rocprim::exclusive_scan(base, temp, flags, pos, 0, (size_t)n, rocprim::plus<int>(), s));
     const float scale = first_octave < 0 ? 1.0f / (float)(1 << -first_octave)
                                          : (float)(1 << first_octave);
     hipLaunchKernelGGL(sift_compact_kernel, grid, block, 0, s, kpts, idx_a, flags, pos, n,

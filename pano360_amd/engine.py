@@ -729,6 +729,8 @@ class Engine:
             self.set_option(_lib.OPT_STITCH_STREAMS, 0)
         if os.environ.get("PANO_STITCH_ASYNC", "0") == "1":         # (A/B timing)
             self.set_option(_lib.OPT_STITCH_ASYNC, 1)
+        if os.environ.get("PANO_SIFT_GRAPH", "1") == "0":           # (A/B timing: launch by launch)
+            self.set_option(_lib.OPT_SIFT_GRAPH, 0)
         if os.environ.get("PANO_BLUR_SEG_T"):                       # (A/B timing of the segments' length)
             self.set_option(_lib.OPT_BLUR_SEG_LEN, int(os.environ["PANO_BLUR_SEG_T"]))
         self._stitch_ws = {}

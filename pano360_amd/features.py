@@ -291,6 +291,117 @@ class SiftDetection:
         return self._out
 
 
+class SiftPipeline:
+    """Frames of ONE size through the detector's front end on one engine, a native call per frame
+    (``pano_sift_detect``: scale space, extrema, orientations, OpenCV's order, descriptors - about
+    110 launches - queued from C++ and, from the second frame of a set of buffers on, replayed as
+    ONE HIP graph).  A graph holds addresses, so every buffer of a frame - the pyramid, the
+    keypoint lists, the descriptors - lives in one of ``depth`` workspaces used in turn: what
+    ``pyramid()`` / ``detect()`` hand back stays valid until ``depth`` more frames have been queued
+    on this pipeline (take a detection's ``result()`` before that)."""
+
+    def __init__(self, eng, h, w, depth=3, max_keypoints=1 << 18, n_octaves=None,
+                 sigma=SIFT_SIGMA, layers=SIFT_LAYERS):
+        import torch
+        self.eng, self.h, self.w, self.depth = eng, int(h), int(w), max(int(depth), 1)
+        self.max_keypoints, self.layers, self.sigma = int(max_keypoints), layers, sigma
+        if n_octaves is None:
+            n_octaves = sift_octaves(self.h, self.w)
+        sig_diff = float(np.sqrt(max(np.float32(sigma) ** 2 - np.float32(SIFT_INIT_SIGMA) ** 2 * 4,
+                                     np.float32(0.01))))
+        kernels = [_step_taps(s) for s in [sig_diff] + sift_sigmas(sigma, layers)[1:]]
+        self.taps = np.ascontiguousarray(np.concatenate(kernels), np.float32)
+        self.ntaps = (C.c_int * len(kernels))(*[len(k) for k in kernels])
+        self.dims, rows, cols = [], 2 * self.h, 2 * self.w
+        for _ in range(n_octaves):
+            self.dims.append((rows, cols))
+            if min(rows, cols) < 2:         # buildGaussianPyramid would halve it to nothing
+                break
+            rows, cols = rows // 2, cols // 2
+        self.slots, self.next = [], 0
+        self._torch = torch
+
+    def _slot(self):
+        """The next workspace in turn (made on first use: 2.3 GB for a 4K frame)."""
+        torch, eng, dev = self._torch, self.eng, self.eng.device
+        k = self.next % self.depth
+        self.next += 1
+        if k < len(self.slots):
+            return self.slots[k]
+        f32 = dict(dtype=torch.float32, device=dev)
+        ws = {}
+        ws["gauss"] = [torch.empty((self.layers + 3, r, c), **f32) for r, c in self.dims]
+        ws["dog"] = [torch.empty((self.layers + 2, r, c), **f32) for r, c in self.dims]
+        ws["work"] = torch.empty(5 * self.h * self.w, **f32)
+        ws["frame"] = torch.empty((self.h, self.w, 3), dtype=torch.uint8, device=dev)
+        n = self.max_keypoints
+        ws["cands"] = torch.empty(n * 32, dtype=torch.uint8, device=dev)
+        ws["kpts"] = torch.empty(n * 32, dtype=torch.uint8, device=dev)
+        ws["counts"] = torch.zeros(3, dtype=torch.int32, device=dev)
+        ws["sort"] = torch.empty(int(eng.lib.pano_sift_sort_work_bytes(n)), dtype=torch.uint8,
+                                 device=dev)
+        ws["desc"] = torch.empty((n, 128), **f32)
+        ws["gptr_host"] = (C.c_void_p * len(self.dims))(*[g.data_ptr() for g in ws["gauss"]])
+        ws["dptr_host"] = (C.c_void_p * len(self.dims))(*[d.data_ptr() for d in ws["dog"]])
+        ws["dims_dev"] = torch.tensor([v for d in self.dims for v in d], dtype=torch.int32).to(dev)
+        ws["gptr_dev"] = torch.tensor([g.data_ptr() for g in ws["gauss"]], dtype=torch.int64).to(dev)
+        a = _lib.SiftArgs()
+        a.frame_copy = ws["frame"].data_ptr()
+        a.h, a.w, a.n_octaves, a.n_layers = self.h, self.w, len(self.dims), self.layers
+        a.taps, a.ntaps = self.taps.ctypes.data, C.cast(self.ntaps, C.c_void_p)
+        a.gauss, a.dog = C.cast(ws["gptr_host"], C.c_void_p), C.cast(ws["dptr_host"], C.c_void_p)
+        a.work = ws["work"].data_ptr()
+        a.contrast_thr, a.edge_thr, a.sigma = SIFT_CONTRAST, SIFT_EDGE, self.sigma
+        a.first_octave, a.max_keypoints = SIFT_FIRST_OCTAVE, n
+        a.gauss_dev, a.dims_dev = ws["gptr_dev"].data_ptr(), ws["dims_dev"].data_ptr()
+        a.cands, a.kpts = ws["cands"].data_ptr(), ws["kpts"].data_ptr()
+        a.counts, a.sort_work, a.desc = (ws["counts"].data_ptr(), ws["sort"].data_ptr(),
+                                         ws["desc"].data_ptr())
+        ws["args"] = a
+        self.slots.append(ws)
+        return ws
+
+    def _queue(self, frame, detect):
+        if tuple(frame.shape) != (self.h, self.w, 3) or not frame.is_contiguous():
+            raise ValueError(f"SiftPipeline of {self.h} x {self.w} frames got {tuple(frame.shape)}")
+        ws = self._slot()
+        a = ws["args"]
+        a.frame, a.detect = frame.data_ptr(), 1 if detect else 0
+        _lib.check(self.eng.lib.pano_sift_detect(self.eng.ctx(), C.byref(a)), "pano_sift_detect")
+        ws["last_frame"] = frame            # (queued kernels read it)
+        return ws
+
+    @property
+    def replaying(self):
+        """True once the frames of the workspace used last go out as one graph launch."""
+        return bool(self.eng.lib.pano_sift_detect_replaying(self.eng._ctx))
+
+    def pyramid(self, frame):
+        """(gauss, dog) of ``sift_pyramid_device``, in this pipeline's buffers."""
+        ws = self._queue(frame, False)
+        return ws["gauss"], ws["dog"]
+
+    def detect(self, frame):
+        """A queued ``detectAndCompute``: ``SiftDetection`` (``result()`` waits)."""
+        ws = self._queue(frame, True)
+        det = SiftDetection(ws["counts"], ws["cands"], ws["desc"], self.max_keypoints, (ws,), self.eng)
+        det.pyramid = (ws["gauss"], ws["dog"])
+        return det
+
+
+def _pipeline_for(eng, h, w, max_keypoints):
+    """The engine's pipeline for frames of this size (a few sizes are kept)."""
+    kept = getattr(eng, "_sift_pipelines", None)
+    if kept is None:
+        kept = eng._sift_pipelines = {}
+    key = (int(h), int(w), int(max_keypoints))
+    if key not in kept:
+        if len(kept) >= 2:
+            kept.pop(next(iter(kept)))
+        kept[key] = SiftPipeline(eng, h, w, depth=3, max_keypoints=max_keypoints)
+    return kept[key]
+
+
 def sift_detect_async(frame, max_keypoints=1 << 18, pyramid=None, eng=None):
     """detectAndCompute of a uint8 BGR frame on the device, queued without a single wait: the
     candidate and keypoint counts stay on the device (``n_dev`` of ``pano_sift_sort_unique`` /
@@ -300,7 +411,12 @@ def sift_detect_async(frame, max_keypoints=1 << 18, pyramid=None, eng=None):
     import torch
     eng = eng or _eng.engine()
     lib = eng.lib
-    gauss, dog = pyramid if pyramid is not None else sift_pyramid_device(frame, eng=eng)
+    if pyramid is None:
+        # the whole frame in one native call (a HIP graph from the second frame of a workspace on);
+        # the result lives in the engine's pipeline of this frame size: valid for three frames
+        h, w = (int(v) for v in frame.shape[:2])
+        return _pipeline_for(eng, h, w, max_keypoints).detect(frame.contiguous())
+    gauss, dog = pyramid
     dev = eng.device
     dims_host = np.array([v for g in gauss for v in g.shape[1:]], np.int32)
     gptr_host = np.array([g.data_ptr() for g in gauss], np.int64)

@@ -1158,6 +1158,71 @@ def test_sift_keypoints_and_descriptors_match_oracle(eng, kind, seed):
     assert abs(kp[0].pt[0] - got2["x"][0]) < 1e-6 and kp[0].octave == got2["octave"][0]
 
 
+def test_sift_pipeline_graph_replay_equals_launch_by_launch(eng):
+    """``features.SiftPipeline`` - one native call per frame (``pano_sift_detect``), captured into
+    a HIP graph the second time a workspace is used and replayed afterwards - against the entry
+    points called one by one from Python (``sift_pyramid_device`` + ``sift_detect_async`` on that
+    pyramid): the scale space bit for bit, the keypoints bit for bit in position, size, response and
+    octave (angles and descriptors to the summation order of their LDS atomics, as between any two
+    runs).  Three frames go round two workspaces four times: every workspace sees a launch-by-launch
+    frame, a captured one and replays; then once more with graphs switched off."""
+    import torch
+    from pano360_amd import _lib, engine, features, synth
+    w, h = 320, 200
+    imgs = [synth.make_frame(70 + i, w, h, "B") for i in range(3)]
+    frames = eng.upload_frames(imgs)
+    want = []
+    for frame in frames:
+        pyr = features.sift_pyramid_device(frame, eng=eng)
+        kps, desc = features.sift_detect_async(frame, pyramid=pyr, eng=eng).result()
+        want.append((pyr, kps, desc.cpu().numpy()))
+    assert all(len(wk) > 50 for _, wk, _ in want)
+
+    def same(det, ref):
+        (g_ref, d_ref), kps_ref, desc_ref = ref
+        kps, desc = det.result()
+        gauss, dog = det.pyramid
+        assert all(torch.equal(a, b) for a, b in zip(gauss, g_ref))
+        assert all(torch.equal(a, b) for a, b in zip(dog, d_ref))
+        assert len(kps) == len(kps_ref)
+        for key in ("x", "y", "size", "response", "octave", "r", "c"):
+            assert np.array_equal(kps[key], kps_ref[key]), key
+        dang = np.abs(kps["angle"] - kps_ref["angle"])
+        assert np.minimum(dang, 360 - dang).max() <= 0.01
+        diff = np.abs(desc.cpu().numpy() - desc_ref)
+        assert diff.max() <= 2 and (diff > 0).mean() < 0.02
+
+    use = engine.Engine(eng.device)
+    stream = torch.cuda.Stream(eng.device)
+    with torch.cuda.stream(stream):
+        pipe = features.SiftPipeline(use, h, w, depth=2, max_keypoints=1 << 14)
+        for k in range(12):
+            same(pipe.detect(frames[k % 3]), want[k % 3])
+            if k == 1:
+                assert not pipe.replaying              # both workspaces have run launch by launch only
+        assert pipe.replaying
+        # the scale space alone goes through the same call (its own graph: `detect` is in the key)
+        for k in range(6):
+            gauss, dog = pipe.pyramid(frames[k % 3])
+            assert all(torch.equal(a, b) for a, b in zip(gauss, want[k % 3][0][0]))
+            assert all(torch.equal(a, b) for a, b in zip(dog, want[k % 3][0][1]))
+        # graphs off: launch by launch every time, same results
+        use.set_option(_lib.OPT_SIFT_GRAPH, 0)
+        plain = features.SiftPipeline(use, h, w, depth=2, max_keypoints=1 << 14)
+        for k in range(5):
+            same(plain.detect(frames[k % 3]), want[k % 3])
+        # on the legacy default stream too (captured on a stream of the library's own)
+    use.set_option(_lib.OPT_SIFT_GRAPH, 1)
+    torch.cuda.synchronize()
+    pipe0 = features.SiftPipeline(use, h, w, depth=1, max_keypoints=1 << 14)
+    for k in range(4):
+        same(pipe0.detect(frames[k % 3]), want[k % 3])
+    assert pipe0.replaying
+    # the reference-facing entry point rides on the engine's pipeline
+    kps, desc = features.sift_detect_device(frames[0], eng=use)
+    assert len(kps) == len(want[0][1]) and np.array_equal(kps["x"], want[0][1]["x"])
+
+
 def test_exhaustive_two_nearest_neighbour_matching(eng):
     """flann_matching (features.py:222-232) as an exact search: every match the ratio
     test keeps equals the brute-force answer; the same frame matched against a shifted

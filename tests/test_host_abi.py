@@ -33,15 +33,24 @@ def test_library_exports_every_declared_symbol():
             fid.write('#include <stdio.h>\n#include "pano360.h"\nint main(void){'
                       'printf("%zu %zu %zu %zu %zu %zu", sizeof(pano_patch), sizeof(pano_camera), '
                       'sizeof(pano_pair), sizeof(pano_stitch_args), sizeof(pano_layout), '
-                      '__builtin_offsetof(pano_stitch_args, layout));return 0;}')
+                      '__builtin_offsetof(pano_stitch_args, layout));'
+                      'printf(" %zu %zu %zu %zu %zu", sizeof(pano_sift_args), '
+                      '__builtin_offsetof(pano_sift_args, detect), '
+                      '__builtin_offsetof(pano_sift_args, first_octave), '
+                      '__builtin_offsetof(pano_sift_args, gauss_dev), '
+                      '__builtin_offsetof(pano_sift_args, desc));return 0;}')
         exe = os.path.join(tmp, "sz")
         subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), src, "-o", exe])
         sizes = [int(v) for v in subprocess.check_output([exe]).split()]
     assert sizes[:3] == [ctypes.sizeof(_lib.Patch), ctypes.sizeof(_lib.Camera),
                          ctypes.sizeof(_lib.Pair)] == [96, 120, 80]
     # the argument record of pano_stitch_multiband, field for field
-    assert sizes[3:] == [ctypes.sizeof(_lib.StitchArgs), ctypes.sizeof(_lib.Layout),
-                         _lib.StitchArgs.layout.offset]
+    assert sizes[3:6] == [ctypes.sizeof(_lib.StitchArgs), ctypes.sizeof(_lib.Layout),
+                          _lib.StitchArgs.layout.offset]
+    # ... and of pano_sift_detect
+    A = _lib.SiftArgs
+    assert sizes[6:] == [ctypes.sizeof(A), A.detect.offset, A.first_octave.offset,
+                         A.gauss_dev.offset, A.desc.offset]
 
 
 def test_header_constants_match_binding():

@@ -13,7 +13,7 @@ mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd /tmp
 timeout -k 10 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_$WL" -- \
-    python3 "$HERE/bench.py" --workload "$WL" --steps "$STEPS" --warmup 5 --no-cpu-baseline --no-secondary --busy-seconds 0 --side-file "$OUT/bench_${WL}_profiled_full.json" \
+    python3 "$HERE/bench.py" --workload "$WL" --steps "$STEPS" --warmup 5 --no-cpu-baseline --no-secondary --busy-seconds 0 --side-file "$OUT/bench_${WL}_profiled_full.json" ${BENCH_EXTRA:-} \
     > "$OUT/bench_${WL}_profiled.json" 2> "$OUT/rocprof_$WL.log"
 echo "rocprof rc=$?"
 cd "$HERE"
