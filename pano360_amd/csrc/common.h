@@ -151,6 +151,7 @@ struct pano_ctx {
 
 int pano_ctx_enter(pano_ctx *ctx);
 void pano_sift_graphs_free(pano_ctx *ctx);   // detect.hip
+int pano_zero_i32(hipStream_t s, int *p, int n);   // detect.hip: p[0 .. n) = 0, as a kernel
 int pano_ctx_side_stream(pano_ctx *ctx);     // makes ctx->side and the fork / join events
 // Device copy of a host tap table set (and, with `tables`, its matrix-core operand tables'
 // buffer, `table_bytes` long, `*fresh` = it was just allocated and must be filled).

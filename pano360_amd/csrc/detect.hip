@@ -1,17 +1,31 @@
 // One frame of the SIFT front end per native call, replayed as a HIP graph.
 //   reference: features.py:192-201 (cv2.xfeatures2d.SIFT_create().detectAndCompute; PARITY
 //   UNPINNED - OpenCV is not under /root/reference, see include/pano360.h).
-// No kernel of its own: pano_scale_space, pano_sift_extrema per octave, pano_sift_orient,
-// pano_sift_sort_unique and pano_sift_describe in that order on the context's stream - about
-// 110 dependent launches for a 4K frame, of which the last eight octaves are a few workgroups
-// each.  Queued launch by launch they cost the HOST more than the GPU (3.0 ms of kernels took
+// pano_scale_space, pano_sift_extrema per octave, pano_sift_orient, pano_sift_sort_unique and
+// pano_sift_describe in that order on the context's stream - about 110 dependent launches for a
+// 4K frame, of which the last eight octaves are a few workgroups each.  Queued launch by launch they cost the HOST more than the GPU (3.0 ms of kernels took
 // 4.8 - 6.5 ms per frame on slower hosts, profiles/r06/notes.md); every grid and every argument
 // is fixed by the frame size and the buffers alone - the candidate and keypoint counts stay on
-// the device - so the sequence is captured ONCE per set of buffers (hipStreamBeginCapture,
-// thread-local mode) and replayed with one hipGraphLaunch per frame.
+// the device - so the sequence up to the orientations (~100 launches) is captured ONCE per set of
+// buffers (hipStreamBeginCapture, thread-local mode) and replayed with one hipGraphLaunch per
+// frame; the sort and the descriptors follow launch by launch.
 #include <string.h>
 
 #include "common.h"
+
+// Counters are zeroed by a kernel, not by hipMemsetAsync: the captured sequence holds nothing but
+// kernel nodes of this library, in stream order.  (The first graph of this sequence, with memset
+// nodes and rocPRIM's launches inside, ended in a fault of the orientation kernel on a stale
+// keypoint list - profiles/r06/notes.md; which of the two was to blame was not pursued.)
+__global__ __launch_bounds__(64) void zero_i32_kernel(int *__restrict__ p, int n) {
+    for (int i = threadIdx.x; i < n; i += 64) p[i] = 0;
+}
+
+int pano_zero_i32(hipStream_t s, int *p, int n) {
+    hipLaunchKernelGGL(zero_i32_kernel, dim3(1), dim3(64), 0, s, p, n);
+    PANO_LAUNCH_CHECK("zero_i32_kernel");
+    return PANO_OK;
+}
 
 static uint64_t fnv(uint64_t h, const void *p, size_t bytes) {
     const unsigned char *b = (const unsigned char *)p;
@@ -38,14 +52,17 @@ static uint64_t detect_key(const pano_sift_args *a, const uint8_t *frame) {
     return fnv(h, a->taps, floats * sizeof(float));
 }
 
-// The launch sequence of one frame on ctx->stream.
-static int queue_frame(pano_ctx *ctx, const pano_sift_args *a, const uint8_t *frame) {
+// The launch sequence of one frame on ctx->stream, in two parts.  The front - scale space, extrema,
+// orientations: ~100 launches of this library's own kernels - is what a graph replays; the back -
+// the keypoint sort (rocPRIM, which sizes and zeroes its own state) and the descriptors, a dozen
+// launches - is always queued launch by launch behind it.
+static int queue_front(pano_ctx *ctx, const pano_sift_args *a, const uint8_t *frame) {
     const hipStream_t s = ctx->stream;
     if (int rc = pano_scale_space(ctx, frame, a->h, a->w, a->n_octaves, a->n_layers, a->taps,
                                   a->ntaps, a->gauss, a->dog, a->work))
         return rc;
     if (!a->detect) return PANO_OK;
-    PANO_HIP(hipMemsetAsync(a->counts, 0, 3 * sizeof(int), s));
+    if (int rc = pano_zero_i32(s, a->counts, 3)) return rc;
     int rows = 2 * a->h, cols = 2 * a->w;
     for (int o = 0; o < a->n_octaves; ++o) {
         if (int rc = pano_sift_extrema(ctx, a->dog[o], rows, cols, o, a->n_layers, a->contrast_thr,
@@ -54,9 +71,12 @@ static int queue_frame(pano_ctx *ctx, const pano_sift_args *a, const uint8_t *fr
         rows /= 2;
         cols /= 2;
     }
-    if (int rc = pano_sift_orient(ctx, a->gauss_dev, a->dims_dev, a->n_layers, a->cands, a->counts,
-                                  a->max_keypoints, a->kpts, a->counts + 1, a->max_keypoints))
-        return rc;
+    return pano_sift_orient(ctx, a->gauss_dev, a->dims_dev, a->n_layers, a->cands, a->counts,
+                            a->max_keypoints, a->kpts, a->counts + 1, a->max_keypoints);
+}
+
+static int queue_back(pano_ctx *ctx, const pano_sift_args *a) {
+    if (!a->detect) return PANO_OK;
     // OpenCV's order and duplicate removal, the first-octave adjustment; `cands` is free again
     // and takes the result
     if (int rc = pano_sift_sort_unique(ctx, a->kpts, a->max_keypoints, a->counts + 1, a->first_octave,
@@ -64,6 +84,11 @@ static int queue_frame(pano_ctx *ctx, const pano_sift_args *a, const uint8_t *fr
         return rc;
     return pano_sift_describe(ctx, a->gauss_dev, a->dims_dev, a->first_octave, a->cands,
                               a->max_keypoints, a->counts + 2, a->desc);
+}
+
+static int queue_frame(pano_ctx *ctx, const pano_sift_args *a, const uint8_t *frame) {
+    if (int rc = queue_front(ctx, a, frame)) return rc;
+    return queue_back(ctx, a);
 }
 
 void pano_sift_graphs_free(pano_ctx *ctx) {
@@ -125,7 +150,7 @@ extern "C" int pano_sift_detect(pano_ctx *ctx, const pano_sift_args *a) {
             hipError_t e = hipStreamBeginCapture(cap, hipStreamCaptureModeThreadLocal);
             if (e == hipSuccess) {
                 ctx->stream = cap;
-                const int rc = queue_frame(ctx, a, a->frame_copy);
+                const int rc = queue_front(ctx, a, a->frame_copy);
                 ctx->stream = s;
                 e = hipStreamEndCapture(cap, &graph);                // (always: leaves capture mode)
                 if (rc != PANO_OK || e != hipSuccess || !graph) {
@@ -145,7 +170,7 @@ extern "C" int pano_sift_detect(pano_ctx *ctx, const pano_sift_args *a) {
     if (!slot->exec) return queue_frame(ctx, a, a->frame);           // no graph: launch by launch
     PANO_HIP(hipMemcpyAsync(a->frame_copy, a->frame, frame_bytes, hipMemcpyDeviceToDevice, s));
     PANO_HIP(hipGraphLaunch(slot->exec, s));
-    return PANO_OK;
+    return queue_back(ctx, a);
 }
 
 // 0 = no graph yet for the most recently used set of buffers, 1 = replaying

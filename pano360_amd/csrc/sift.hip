@@ -669,7 +669,7 @@ extern "C" int pano_sift_extrema(pano_ctx *ctx, const float *dog, int rows, int 
             ctx->sift_raw_cap = cap;
         }
         int *raw_count = (int *)(ctx->sift_raw + ctx->sift_raw_cap);
-        PANO_HIP(hipMemsetAsync(raw_count, 0, sizeof(int), s));
+        if (int rc = pano_zero_i32(s, raw_count, 1)) return rc;   // (a kernel: graph-safe, detect.hip)
         int seg_rows = 96;
         while (seg_rows > 12 && (long)ceil_div(cols - 2 * SIFT_BORDER, 62) *
                                     ceil_div(rows - 2 * SIFT_BORDER, seg_rows) < SIFT_SCAN_WAVES)

@@ -343,8 +343,15 @@ class SiftPipeline:
         ws["desc"] = torch.empty((n, 128), **f32)
         ws["gptr_host"] = (C.c_void_p * len(self.dims))(*[g.data_ptr() for g in ws["gauss"]])
         ws["dptr_host"] = (C.c_void_p * len(self.dims))(*[d.data_ptr() for d in ws["dog"]])
-        ws["dims_dev"] = torch.tensor([v for d in self.dims for v in d], dtype=torch.int32).to(dev)
-        ws["gptr_dev"] = torch.tensor([g.data_ptr() for g in ws["gauss"]], dtype=torch.int64).to(dev)
+        # 256 entries each - one per value of a keypoint's octave byte, zeros beyond the pyramid:
+        # a keypoint record that is not this frame's (octave byte 255 after the first-octave
+        # adjustment) then finds an empty plane and samples nothing instead of a wild address
+        dims_tab = np.zeros((256, 2), np.int32)
+        dims_tab[:len(self.dims)] = self.dims
+        gptr_tab = np.zeros(256, np.int64)
+        gptr_tab[:len(self.dims)] = [g.data_ptr() for g in ws["gauss"]]
+        ws["dims_dev"] = torch.from_numpy(dims_tab.reshape(-1)).to(dev)
+        ws["gptr_dev"] = torch.from_numpy(gptr_tab).to(dev)
         a = _lib.SiftArgs()
         a.frame_copy = ws["frame"].data_ptr()
         a.h, a.w, a.n_octaves, a.n_layers = self.h, self.w, len(self.dims), self.layers
