@@ -285,7 +285,7 @@ def measured_traffic(times, steps, workload):
 BLUR_KERNELS = ("blur_lean_kernel", "blur_lean5_kernel", "blur_mfma_kernel")
 
 
-def algorithmic_bytes(plan, patches, n_levels, px_active, times=None):
+def algorithmic_bytes(plan, patches, n_levels, px_active, times=None, gathered=None):
     """Algorithmic HBM bytes per step of each big kernel: every logical
     array the kernel consumes or produces counted once, on the pixels this run really
     processed (windows V / rectangles A / active tiles), not on the reference's P."""
@@ -314,8 +314,12 @@ def algorithmic_bytes(plan, patches, n_levels, px_active, times=None):
         # no pixel data read: owner (2 B) + valid (1 B) written per mosaic pixel
         "ownership_cameras_kernel": 3.0 * M,
         "owned_boxes_kernel": 2.0 * M,
-        # warped colour + L-1 blurred RGBA per gathered pixel; owner/valid read, u8 out
-        "multiband_compose_kernel": (12.0 + 16.0 * (n_levels - 1)) * px_cols + 6.0 * M,
+        # what the collapse gathers per (record, pixel) by the pixel's level class
+        # (Engine.gather_bytes: planes + all copies on class 0, copy j - 1's colour and the copies
+        # above on class j, nothing on interior pixels); owner / valid read, u8 out.  Rounds 2 - 5
+        # counted (12 + 16 (L - 1)) bytes on every pixel of an active blur tile, an upper bound
+        "multiband_compose_kernel": (gathered if gathered is not None else
+                                     (12.0 + 16.0 * (n_levels - 1)) * px_cols) + 6.0 * M,
         # the float32 vector-ALU form (Engine(blur="valu")): the row pass reads the planes and
         # the owner map over V and writes L-1 RGBA row-pass images (V rows x A columns), the
         # column pass reads those and writes the blurred copies over A
@@ -324,12 +328,12 @@ def algorithmic_bytes(plan, patches, n_levels, px_active, times=None):
     }, dict(px_warp=px_warp, px_cols=px_cols, px_rows=px_rows)
 
 
-def roofline_for(times, plan, patches, n_levels, steps, px_active, workload=None):
+def roofline_for(times, plan, patches, n_levels, steps, px_active, workload=None, gathered=None):
     """Roofline entry of the kernel with the largest share of the timed region, plus the
     time-weighted fraction over the three kernels that move the pixels (warp, blur,
     collapse)."""
     from pano360_amd import engine
-    per_step, px = algorithmic_bytes(plan, patches, n_levels, px_active, times)
+    per_step, px = algorithmic_bytes(plan, patches, n_levels, px_active, times, gathered)
     name = max(times, key=lambda k: times[k][0])
     total_ms, launches = times[name]
     avg_s = total_ms / launches * 1e-3
@@ -369,12 +373,12 @@ def roofline_for(times, plan, patches, n_levels, steps, px_active, workload=None
     return out
 
 
-def roofline_by_kernel(times, plan, patches, n_levels, steps, px_active, workload=None):
+def roofline_by_kernel(times, plan, patches, n_levels, steps, px_active, workload=None, gathered=None):
     """Every timed kernel of a stitch against ITS roof: the pixel movers against the HBM peak
     (algorithmic bytes / event time), the ownership kernel against the vector ALU's issue rate -
     its counter traffic is 1.05 x its 0.1 GB of algorithmic bytes and it sits at 0.09 of the HBM
     peak: HBM is not its roof (`ownership_issue_bound`)."""
-    per_step, _ = algorithmic_bytes(plan, patches, n_levels, px_active, times)
+    per_step, _ = algorithmic_bytes(plan, patches, n_levels, px_active, times, gathered)
     out = {}
     for name, (total_ms, launches) in sorted(times.items()):
         ms = total_ms / steps
@@ -824,7 +828,8 @@ def secondary_single_gpu(eng, fence, other_setting=None):
             "kernel_ms_per_step": {k_: v[0] / steps for k_, v in sorted(times.items())},
             "instrumented_ms_per_step": INSTRUMENTED.get("seconds", 0.0) / steps * 1e3,
             "roofline": roofline_for(times, plan, patches, cfg["n_levels"], steps,
-                                     use.active_tile_pixels(), name),
+                                     use.active_tile_pixels(), name,
+                                     use.gather_bytes(plan.shape, cfg["n_levels"])),
         }
         del pool, frames
         for e, _ in lanes:
@@ -1251,6 +1256,7 @@ def main():
         warped = sum((p.window[1] - p.window[0]) * (p.window[3] - p.window[2]) for p in patches)
         blurred = sum((p.area[1] - p.area[0]) * (p.area[3] - p.area[2]) for p in patches)
         timed_kernel_ms = sum(v[0] for v in times.values()) / args.steps
+        gathered = eng.gather_bytes(plan.shape, n_levels)       # this rank's last stitch
         out = {
             "metric": "blended megapixels/sec (multiband)",
             "value": sets_per_step * P / (ms * 1e-3) / 1e6,
@@ -1340,10 +1346,12 @@ def main():
                           "x launches per step, this rank's kernels"})(
                 measured_traffic(times, args.steps, args.workload) if world == 1 else None),
             "roofline": roofline_for(times, plan, patches, n_levels, args.steps,
-                                     eng.active_tile_pixels(), args.workload),
+                                     eng.active_tile_pixels(), args.workload, gathered),
         }
         out["roofline_by_kernel"] = roofline_by_kernel(times, plan, patches, n_levels, args.steps,
-                                                       eng.active_tile_pixels(), args.workload)
+                                                       eng.active_tile_pixels(), args.workload,
+                                                       gathered)
+        out["collapse_gather_GB"] = None if gathered is None else gathered / 1e9
         projection = scaling_projection(args.workload)
         if projection is not None:
             out["scaling_projection"] = projection

@@ -196,7 +196,11 @@ int pano_interior_block(void);
  *   PANO_OPT_SIFT_GRAPH   pano_sift_detect: 1 (default) = a frame's launch sequence is captured
  *                         into a HIP graph the second time a set of buffers is used and replayed
  *                         from then on (one hipGraphLaunch per frame instead of ~110 launches);
- *                         0 = always launch by launch.  Same results bit for bit. */
+ *                         0 = always launch by launch.  Same results bit for bit.
+ *   PANO_OPT_LEVEL_CLASSES  pano_multiband_compose / pano_stitch_multiband: 1 (default) = the
+ *                         collapse uses the level classes it is handed (pano_interior_classes);
+ *                         0 = it gathers every copy on every pixel that is not interior, as rounds
+ *                         1 - 5 did (A/B; the mosaics agree to float32 rounding). */
 typedef struct pano_ctx pano_ctx;
 #define PANO_OPT_BLUR_KERNEL 0
 #define PANO_OPT_OWN_PRUNE 1
@@ -206,7 +210,8 @@ typedef struct pano_ctx pano_ctx;
 #define PANO_OPT_STITCH_ASYNC 5
 #define PANO_OPT_BLUR_SEG_LEN 6
 #define PANO_OPT_SIFT_GRAPH 7
-#define PANO_OPT_COUNT 8
+#define PANO_OPT_LEVEL_CLASSES 8
+#define PANO_OPT_COUNT 9
 #define PANO_BLUR_MFMA 0
 #define PANO_BLUR_VALU 1
 int pano_ctx_create(int device, void *stream, pano_ctx **out);
@@ -364,6 +369,17 @@ int pano_multiband_blur(pano_ctx *ctx, const pano_patch *patches, int n, int max
  * `interior` keeps whatever it held). */
 int pano_interior_map(pano_ctx *ctx, const int16_t *owner, int H, int W, int xs0, int xs1,
                       int radius, int16_t *block_owner, uint8_t *interior);
+/* The same test level by level (round 6).  radii: host int [n_radii], the Gaussian radii of the
+ * levels, ascending (stitcher.py:218: the apertures grow with the level); classes: dev uint8, the
+ * interior map's shape: the number of leading levels k whose (2 radii[k] + 1)^2 window around the
+ * block holds one owner (0 .. n_radii; interior = the map at radii[n_radii - 1] = class n_radii).
+ * For a pixel of class j >= 1 the levels below j telescope to  I - G_{j-1} I  of the owner alone:
+ * pano_multiband_compose then gathers, of every record over the pixel, the colour of copy j - 1
+ * and the copies j and up only - not the copies below, not alpha j - 1, and the warped planes of
+ * the owner's record only (same result to float32 rounding, as for the interior pixels). */
+int pano_interior_classes(pano_ctx *ctx, const int16_t *owner, int H, int W, int xs0, int xs1,
+                          const int *radii, int n_radii, int16_t *block_owner, uint8_t *interior,
+                          uint8_t *classes);
 
 /* Host side of the fused path: the record table from the owned regions
  * (no reference counterpart; the arithmetic of "Windows" above).  regions: host copy
@@ -394,6 +410,8 @@ int pano_layout_place(pano_patch *records, int n_records, void *planes, void *bl
  * frame (cams[owner].frame) is sampled there exactly as the warp samples it,
  * which needs cams, the trig tables and the colour tables (all NULL
  * otherwise).
+ * classes (optional, with interior): the level classes of pano_interior_classes - a pixel
+ * of class j >= 1 gathers the copies j - 1 and up only (see there).
  * part: 0 = every pixel of the strip; 1 = the interior pixels only - they depend
  * on the owner map and the frames, not on the patches (patches / valid may be
  * NULL), so this part can be queued on another stream beside the warp and the
@@ -401,9 +419,10 @@ int pano_layout_place(pano_patch *records, int n_records, void *planes, void *bl
 int pano_multiband_compose(pano_ctx *ctx, const pano_patch *patches, int n, int H, int W,
                            int xs0, int xs1, int n_levels, const int16_t *owner,
                            const uint8_t *valid, const uint8_t *interior,
-                           const pano_camera *cams, const double *sin_t,
-                           const double *cos_t, const double *tan_p, const float *lut,
-                           int lut_stride, uint8_t *mosaic, float *mosaic_f32, int part);
+                           const uint8_t *classes, const pano_camera *cams,
+                           const double *sin_t, const double *cos_t, const double *tan_p,
+                           const float *lut, int lut_stride, uint8_t *mosaic,
+                           float *mosaic_f32, int part);
 
 /* linear_blend (linear != 0) or no_blend (linear == 0) of the mosaic columns
  * [xs0, xs1) straight from the frames         stitcher.py:160-183 + :300-317
@@ -695,6 +714,8 @@ typedef struct pano_stitch_args {
                                 * the warp, the blur and the collapse are queued: out 4.  Otherwise
                                 * as 1.  The reference recomputes all of it per stitch
                                 * (stitcher.py:276-306, 196-204) - to the same values. */
+    uint8_t *classes;          /* dev workspace of pano_interior_classes (the interior map's shape),
+                                * or NULL: no level classes */
     pano_layout layout;        /* out */
 } pano_stitch_args;
 int pano_stitch_multiband(pano_ctx *ctx, pano_stitch_args *args, int resume);

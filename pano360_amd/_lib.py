@@ -24,6 +24,7 @@ OPT_BLUR_KERNEL, OPT_OWN_PRUNE, OPT_BLUR_SEGMENTS, OPT_BLUR_LEAN, OPT_STITCH_STR
 OPT_STITCH_ASYNC = 5
 OPT_BLUR_SEG_LEN = 6
 OPT_SIFT_GRAPH = 7
+OPT_LEVEL_CLASSES = 8
 BLUR_MFMA, BLUR_VALU = 0, 1
 
 
@@ -74,7 +75,7 @@ class StitchArgs(C.Structure):
             "n", "H", "W", "xs0", "xs1", "own0", "own1", "lut_stride", "n_levels", "radius",
             "shortcut", "warp_need", "max_spans", "min_gap", "cap_records", "cap_tiles",
             "used_need", "trust_layout")]
-        + [("layout", Layout)])
+        + [("classes", C.c_void_p), ("layout", Layout)])
 
 
 EINVAL = -1     # PANO_EINVAL
@@ -132,7 +133,8 @@ _SIGNATURES = {
     "pano_layout_windows": (_i, [_i, _vp, _i, _i, _vp, _vp, _i, _i, _i, _i, _vp, _i, _vp]),
     "pano_layout_place": (_i, [_vp, _i, _vp, _vp, _vp]),
     "pano_interior_map": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
-    "pano_multiband_compose": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp,
+    "pano_interior_classes": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp]),
+    "pano_multiband_compose": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp,
                                     _vp, _vp, _vp, _i, _vp, _vp, _i]),
     "pano_blend_cameras": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp,
                                 _vp]),

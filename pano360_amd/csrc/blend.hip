@@ -803,10 +803,22 @@ __global__ __launch_bounds__(256) void block_owner_kernel(const int16_t *__restr
 #define IT_REACH_MAX 20
 __device__ __forceinline__ bool agree(int a, int b) { return a == b || a == -3 || b == -3; }
 
+// Level classes (round 6): the same test at SEVERAL reaches - one per Gaussian level, ascending,
+// the last one `reach` - on the one staged tile: a block's class is the number of leading levels
+// whose window holds one owner (`classes`, optional; interior = the class is the number of levels).
+// The collapse gathers, for a pixel of class j >= 1, only the copies of the levels j - 1 and up
+// (multiband_compose_kernel).
+struct LevelReaches {
+    int n;
+    int reach[PANO_MAX_LEVELS];
+};
+
 __global__ __launch_bounds__(256) void interior_tile_kernel(const int16_t *__restrict__ bown,
                                                             int H8, int W8, int reach, int blo,
                                                             int bhi, int ilo, int ihi,
-                                                            uint8_t *__restrict__ interior) {
+                                                            uint8_t *__restrict__ interior,
+                                                            LevelReaches lv,
+                                                            uint8_t *__restrict__ classes) {
     __shared__ int16_t s_own[(IT_H + 2 * IT_REACH_MAX) * (IT_W + 2 * IT_REACH_MAX)];
     __shared__ int16_t s_col[IT_H * (IT_W + 2 * IT_REACH_MAX)];
     __shared__ unsigned long long s_vmask[IT_W + 2 * IT_REACH_MAX];
@@ -844,26 +856,46 @@ __global__ __launch_bounds__(256) void interior_tile_kernel(const int16_t *__res
         s_vmask[tx] = m;
     }
     __syncthreads();
-    const unsigned long long full = (1ull << (2 * reach)) - 1ull;     // 2 reach <= 40 pairs
-    for (int ry = wave; ry < IT_H; ry += 4)
-        for (int tx = lane; tx < tw; tx += 64) {
-            const int o = s_own[(ry + reach) * tw + tx];
-            const bool same = ((s_vmask[tx] >> ry) & full) == full;
-            s_col[ry * tw + tx] = (int16_t)(o >= 0 && !same ? -2 : o);  // -3 stays -3
+    // one pass of both window tests per level, smallest reach first; a level counts while every
+    // level before it passed (the reaches ascend, so the tests are nested anyway)
+    int cls[IT_H / 4];
+#pragma unroll
+    for (int r = 0; r < IT_H / 4; ++r) cls[r] = 0;
+    const int nlv = classes ? lv.n : 1;
+    for (int q = 0; q < nlv; ++q) {
+        const int rq = classes ? lv.reach[q] : reach, off = reach - rq;
+        const unsigned long long full = (1ull << (2 * rq)) - 1ull;       // 2 reach <= 40 pairs
+        for (int ry = wave; ry < IT_H; ry += 4)
+            for (int tx = lane; tx < tw; tx += 64) {
+                const int o = s_own[(ry + reach) * tw + tx];
+                const bool same = ((s_vmask[tx] >> (ry + off)) & full) == full;
+                s_col[ry * tw + tx] = (int16_t)(o >= 0 && !same ? -2 : o);  // -3 stays -3
+            }
+        __syncthreads();
+        // along the rows of that: a row's pairs as two ballots, a pixel's window as a shift
+#pragma unroll
+        for (int r = 0; r < IT_H / 4; ++r) {
+            const int ry = wave + 4 * r;
+            const int16_t *row = s_col + ry * tw;
+            const int a0 = row[lane], a1 = row[min(lane + 1, tw - 1)];
+            const int b0 = row[min(lane + 64, tw - 1)], b1 = row[min(lane + 65, tw - 1)];
+            const unsigned long long lo = __ballot(lane + 1 < tw && agree(a0, a1));
+            const unsigned long long hi = __ballot(lane + 65 < tw && agree(b0, b1));
+            const int sh = lane + off;                   // first pair of this lane's window
+            const unsigned long long win = sh == 0 ? lo
+                                           : sh < 64 ? (lo >> sh) | (hi << (64 - sh))
+                                                     : hi >> (sh - 64);
+            const int o = row[lane + reach];
+            if (o >= 0 && (win & full) == full && cls[r] == q) cls[r] = q + 1;
         }
-    __syncthreads();
-    // along the rows of that: a row's pairs as two ballots, a pixel's window as a shift
-    for (int ry = wave; ry < IT_H; ry += 4) {
-        const int16_t *row = s_col + ry * tw;
-        const int a0 = row[lane], a1 = row[min(lane + 1, tw - 1)];
-        const int b0 = row[min(lane + 64, tw - 1)], b1 = row[min(lane + 65, tw - 1)];
-        const unsigned long long lo = __ballot(lane + 1 < tw && agree(a0, a1));
-        const unsigned long long hi = __ballot(lane + 65 < tw && agree(b0, b1));
-        const int y = by0 + ry, x = bx0 + lane;
+        __syncthreads();                                 // s_col is the next level's
+    }
+#pragma unroll
+    for (int r = 0; r < IT_H / 4; ++r) {
+        const int y = by0 + wave + 4 * r, x = bx0 + lane;
         if (y >= H8 || x >= ihi) continue;
-        const unsigned long long win = lane == 0 ? lo : (lo >> lane) | (hi << (64 - lane));
-        const int o = row[lane + reach];
-        interior[(size_t)y * W8 + x] = (o >= 0 && (win & full) == full) ? 1 : 0;
+        interior[(size_t)y * W8 + x] = cls[r] == nlv ? 1 : 0;
+        if (classes) classes[(size_t)y * W8 + x] = (uint8_t)cls[r];
     }
 }
 
@@ -876,6 +908,7 @@ struct InteriorArgs {
     const double *sin_t, *cos_t, *tan_p;
     const float *lut;            // [256], or [n][256] when PERCAM
     int part;                    // 0 every pixel, 2 only the pixels the interior pass left
+    const uint8_t *classes;      // [H8][W8] level classes (interior_tile_kernel), NULL = all class 0
 };
 
 // Where an interior pixel's colour table is read: staged in LDS, or in global memory (the
@@ -1003,6 +1036,15 @@ __global__ __launch_bounds__(256) void multiband_compose_kernel(
     float layer[L][3], wsum[L];
 #pragma unroll
     for (int k = 0; k < L; ++k) layer[k][0] = layer[k][1] = layer[k][2] = wsum[k] = 0.0f;
+    // The pixel's level class j (0 .. L - 2 here): within the reach of the levels k < j everything
+    // is the owner's, so for those levels the owner's blurred alpha is the full tap sum, every
+    // other record's an exact zero, and  sum_{k<j} band_k  telescopes to  I - G_{j-1} I  of the
+    // owner alone (the interior shortcut's argument, level by level).  Such a pixel needs, of
+    // every record, the colour of copy j - 1 and the copies j .. L - 2 - not the copies below,
+    // not alpha j - 1, and the warped planes of the owner's record only.
+    const int j = L > 1 && ia.classes ? (int)ia.classes[(size_t)(y / IB) * ia.W8 + x / IB] : 0;
+    const int own_px = j > 0 ? (int)owner[(size_t)y * W + x] : -1;
+    float base[3] = {0.0f, 0.0f, 0.0f};          // I - G_{j-1} I of the owner (class j >= 1)
 
     // records in index order (the reference's summation order): the set bits, or all of them
     int m = 0;
@@ -1024,11 +1066,22 @@ __global__ __launch_bounds__(256) void multiband_compose_kernel(
         const size_t vo = (size_t)(ay + p.ay0 - p.vy0) * p.vpitch + (ax + p.ax0 - p.vx0);
         const size_t aplane = (size_t)p.ah * p.apitch, ao = (size_t)ay * p.apitch + ax;
         float hi[3], ha = 0.0f;                 // the copy that gets the minus
+        if (j == 0) {
 #pragma unroll
-        for (int c = 0; c < 3; ++c) hi[c] = p.planes[c * vplane + vo];
+            for (int c = 0; c < 3; ++c) hi[c] = p.planes[c * vplane + vo];
+        } else {
+            const float *b = p.blurred + (size_t)(j - 1) * 4 * aplane + ao;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) hi[c] = b[c * aplane];
+            if (p.index == own_px) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) base[c] = p.planes[c * vplane + vo] - hi[c];
+            }
+        }
         if (L == 1) ha = owner[(size_t)y * W + x] == p.index ? 1.0f : 0.0f;   // sharp alpha (:208)
 #pragma unroll
         for (int k = 0; k < L; ++k) {
+            if (k < j) continue;                 // telescoped into `base`
             float rgb[3], a;
             if (k < L - 1) {
                 const float *b = p.blurred + (size_t)k * 4 * aplane + ao;
@@ -1051,9 +1104,10 @@ __global__ __launch_bounds__(256) void multiband_compose_kernel(
         }
     }
     const bool ok = valid[(size_t)y * W + x] != 0;
-    float out[3] = {0.0f, 0.0f, 0.0f};
+    float out[3] = {ok ? base[0] : 0.0f, ok ? base[1] : 0.0f, ok ? base[2] : 0.0f};
 #pragma unroll
     for (int k = 0; k < L; ++k) {
+        if (k < j) continue;
         const float ws = wsum[k] == 0.0f ? 1.0f : wsum[k];                         // :237
 #pragma unroll
         for (int c = 0; c < 3; ++c)
@@ -1341,13 +1395,22 @@ extern "C" int pano_ownership_regions(pano_ctx *ctx, const pano_camera *cams, in
     return PANO_OK;
 }
 
-extern "C" int pano_interior_map(pano_ctx *ctx, const int16_t *owner, int H, int W, int xs0,
-                                 int xs1, int radius, int16_t *block_owner, uint8_t *interior) {
-    PANO_ENTER(ctx, "pano_interior_map");
-    PANO_REQUIRE(owner && block_owner && interior, "pano_interior_map: null pointer");
-    PANO_REQUIRE(H > 0 && W > 0 && radius >= 0, "pano_interior_map: bad argument");
-    PANO_REQUIRE(xs0 >= 0 && xs1 <= W && xs0 <= xs1, "pano_interior_map: bad strip [%d, %d)", xs0, xs1);
-    const int H8 = ceil_div(H, IB), W8 = ceil_div(W, IB), reach = ceil_div(radius + IB - 1, IB);
+static int interior_map_launch(pano_ctx *ctx, const int16_t *owner, int H, int W, int xs0, int xs1,
+                               const int *radii, int n_radii, int16_t *block_owner,
+                               uint8_t *interior, uint8_t *classes, const char *who) {
+    void *const stream = (void *)ctx->stream;
+    PANO_REQUIRE(owner && block_owner && interior && radii, "%s: null pointer", who);
+    PANO_REQUIRE(H > 0 && W > 0 && n_radii >= 1 && n_radii < PANO_MAX_LEVELS, "%s: bad argument", who);
+    PANO_REQUIRE(xs0 >= 0 && xs1 <= W && xs0 <= xs1, "%s: bad strip [%d, %d)", who, xs0, xs1);
+    LevelReaches lv = {};
+    lv.n = n_radii;
+    for (int k = 0; k < n_radii; ++k) {
+        PANO_REQUIRE(radii[k] >= 0 && (k == 0 || radii[k] >= radii[k - 1]),
+                     "%s: radii must ascend (level %d: %d)", who, k, radii[k]);
+        lv.reach[k] = ceil_div(radii[k] + IB - 1, IB);
+    }
+    const int radius = radii[n_radii - 1];
+    const int H8 = ceil_div(H, IB), W8 = ceil_div(W, IB), reach = lv.reach[n_radii - 1];
     if (xs0 == xs1) return PANO_OK;
     // the blocks that meet the columns [xs0, xs1) are classified; their owners are needed `reach`
     // blocks further (blocks that do not lie inside [xs0, xs1) are "not this strip's" either way)
@@ -1359,18 +1422,36 @@ extern "C" int pano_interior_map(pano_ctx *ctx, const int16_t *owner, int H, int
                hipLaunchKernelGGL(block_owner_kernel, grid, block, 0, s, owner, H, W, xs0, xs1,
                                   H8, W8, blo, bhi, block_owner));
     PANO_LAUNCH_CHECK("block_owner_kernel");
-    PANO_REQUIRE(reach <= IT_REACH_MAX, "pano_interior_map: radius %d reaches %d blocks (at most %d)",
-                 radius, reach, IT_REACH_MAX);
+    PANO_REQUIRE(reach <= IT_REACH_MAX, "%s: radius %d reaches %d blocks (at most %d)", who, radius,
+                 reach, IT_REACH_MAX);
     hipLaunchKernelGGL(interior_tile_kernel, dim3(ceil_div(ihi - ilo, IT_W), ceil_div(H8, IT_H)),
-                       dim3(256), 0, s, block_owner, H8, W8, reach, blo, bhi, ilo, ihi, interior);
+                       dim3(256), 0, s, block_owner, H8, W8, reach, blo, bhi, ilo, ihi, interior, lv,
+                       classes);
     PANO_LAUNCH_CHECK("interior_tile_kernel");
     return PANO_OK;
+}
+
+extern "C" int pano_interior_map(pano_ctx *ctx, const int16_t *owner, int H, int W, int xs0,
+                                 int xs1, int radius, int16_t *block_owner, uint8_t *interior) {
+    PANO_ENTER(ctx, "pano_interior_map");
+    return interior_map_launch(ctx, owner, H, W, xs0, xs1, &radius, 1, block_owner, interior, nullptr,
+                               "pano_interior_map");
+}
+
+extern "C" int pano_interior_classes(pano_ctx *ctx, const int16_t *owner, int H, int W, int xs0,
+                                     int xs1, const int *radii, int n_radii, int16_t *block_owner,
+                                     uint8_t *interior, uint8_t *classes) {
+    PANO_ENTER(ctx, "pano_interior_classes");
+    PANO_REQUIRE(classes, "pano_interior_classes: null pointer");
+    return interior_map_launch(ctx, owner, H, W, xs0, xs1, radii, n_radii, block_owner, interior,
+                               classes, "pano_interior_classes");
 }
 
 extern "C" int pano_multiband_compose(pano_ctx *ctx, const pano_patch *patches, int n, int H,
                                       int W, int xs0, int xs1, int n_levels, const int16_t *owner,
                                       const uint8_t *valid, const uint8_t *interior,
-                                      const pano_camera *cams, const double *sin_t,
+                                      const uint8_t *classes, const pano_camera *cams,
+                                      const double *sin_t,
                                       const double *cos_t, const double *tan_p, const float *lut,
                                       int lut_stride, uint8_t *mosaic, float *mosaic_f32,
                                       int part) {
@@ -1391,7 +1472,9 @@ extern "C" int pano_multiband_compose(pano_ctx *ctx, const pano_patch *patches, 
                  "pano_multiband_compose: lut_stride %d (0 = shared table, 256 = per camera)",
                  lut_stride);
     if (xs0 == xs1) return PANO_OK;
-    InteriorArgs ia = {interior, ceil_div(W, IB), cams, sin_t, cos_t, tan_p, lut, part};
+    PANO_REQUIRE(!classes || interior, "pano_multiband_compose: level classes without the interior map");
+    InteriorArgs ia = {interior, ceil_div(W, IB), cams, sin_t, cos_t, tan_p, lut, part,
+                       ctx->opt[PANO_OPT_LEVEL_CLASSES] ? classes : nullptr};
     const bool percam = interior && lut_stride != 0;
     dim3 block(64, 4), grid(ceil_div(xs1 - xs0, 64), ceil_div(H, 4));
     hipStream_t s = (hipStream_t)stream;

@@ -94,7 +94,7 @@ struct PanoSiftGraph {               // detect.hip: one captured launch sequence
     uint64_t used;                  // last use (eviction order)
 };
 
-#define GEOM_BUFS 10
+#define GEOM_BUFS 11
 #define STITCH_SIG 13             // stitch.hip: stitch_signature
 struct pano_ctx {
     int device;

@@ -167,6 +167,32 @@ static void stitch_signature(const pano_stitch_args *a, int tile_grid, int *sig)
     for (int k = 0; k < STITCH_SIG; ++k) sig[k] = v[k];
 }
 
+// The interior map of a stitch - with the level classes beside it when the caller gave a buffer
+// for them (radii of the levels: half their apertures, ascending as stitcher.py:218 makes them).
+static int stitch_interior_map(pano_ctx *ctx, const pano_stitch_args *a, int n_blur) {
+    if (a->classes && n_blur > 0) {
+        int radii[PANO_MAX_LEVELS];
+        bool ascending = true;
+        for (int k = 0; k < n_blur; ++k) {
+            radii[k] = a->ntaps[k] / 2;
+            if (k && radii[k] < radii[k - 1]) ascending = false;
+        }
+        if (ascending && radii[n_blur - 1] == a->radius)
+            return pano_interior_classes(ctx, a->owner, a->H, a->W, a->own0, a->own1, radii, n_blur,
+                                         a->block_owner, a->interior, a->classes);
+    }
+    return pano_interior_map(ctx, a->owner, a->H, a->W, a->own0, a->own1, a->radius, a->block_owner,
+                             a->interior);
+}
+
+// Do this stitch's classes hold (the buffer was given and stitch_interior_map filled it)?
+static bool stitch_has_classes(const pano_stitch_args *a, int n_blur) {
+    if (!a->classes || n_blur <= 0) return false;
+    for (int k = 0; k < n_blur; ++k)
+        if (k && a->ntaps[k] / 2 < a->ntaps[k - 1] / 2) return false;
+    return a->ntaps[n_blur - 1] / 2 == a->radius;
+}
+
 // Runs `call` with the context targeted at its side stream.
 #define ON_SIDE(ctx, call)                  \
     do {                                    \
@@ -257,6 +283,7 @@ static int queue_tail(pano_ctx *ctx, pano_stitch_args *a, const pano_layout &lay
             return rc;
     return pano_multiband_compose(ctx, a->table, nr, a->H, a->W, a->xs0, a->xs1, a->n_levels,
                                   a->owner, a->valid, interior ? a->interior : nullptr,
+                                  interior && stitch_has_classes(a, n_blur) ? a->classes : nullptr,
                                   interior ? a->cams : nullptr, interior ? a->sin_t : nullptr,
                                   interior ? a->cos_t : nullptr, interior ? a->tan_p : nullptr,
                                   a->lut, a->lut_stride, a->mosaic, a->mosaic_f32, 0);
@@ -265,7 +292,7 @@ static int queue_tail(pano_ctx *ctx, pano_stitch_args *a, const pano_layout &lay
 // The buffers a stitch leaves its geometry in (and reads it from when it is kept).
 static void geometry_buffers(const pano_stitch_args *a, const void *out[GEOM_BUFS]) {
     const void *v[GEOM_BUFS] = {a->owner, a->valid, a->table, a->interior, a->tile_flags, a->need,
-                                a->planes, a->blurred, a->scratch, a->sin_t};
+                                a->planes, a->blurred, a->scratch, a->sin_t, a->classes};
     for (int k = 0; k < GEOM_BUFS; ++k) out[k] = v[k];
 }
 static void geometry_left(pano_ctx *ctx, const pano_stitch_args *a) {
@@ -409,8 +436,7 @@ extern "C" int pano_stitch_multiband(pano_ctx *ctx, pano_stitch_args *a, int res
         if (forked && interior) {
             PANO_HIP(hipEventRecord(ctx->ev_fork, s));
             PANO_HIP(hipStreamWaitEvent(ctx->side, ctx->ev_fork, 0));
-            ON_SIDE(ctx, pano_interior_map(ctx, a->owner, a->H, a->W, a->own0, a->own1, a->radius,
-                                           a->block_owner, a->interior));
+            ON_SIDE(ctx, stitch_interior_map(ctx, a, n_blur));
         }
         bool interior_queued = forked && interior;
         if (spec) {
@@ -439,9 +465,7 @@ extern "C" int pano_stitch_multiband(pano_ctx *ctx, pano_stitch_args *a, int res
                 PANO_HIP(hipEventRecord(ctx->ev_copy, ctx->side));
             }
             if (interior && !interior_queued) {
-                if (int rc = pano_interior_map(ctx, a->owner, a->H, a->W, a->own0, a->own1,
-                                               a->radius, a->block_owner, a->interior))
-                    return rc;
+                if (int rc = stitch_interior_map(ctx, a, n_blur)) return rc;
                 interior_queued = true;
             }
             if (int rc = queue_tail(ctx, a, bound, true, ctx->lay_prev_used_need, two_streams, interior,
@@ -493,9 +517,7 @@ extern "C" int pano_stitch_multiband(pano_ctx *ctx, pano_stitch_args *a, int res
         // the interior map needs the owner map only: queued before the wait, it keeps the GPU
         // busy while the host lays out the windows
         if (interior && !interior_queued)
-            if (int rc = pano_interior_map(ctx, a->owner, a->H, a->W, a->own0, a->own1, a->radius,
-                                           a->block_owner, a->interior))
-                return rc;
+            if (int rc = stitch_interior_map(ctx, a, n_blur)) return rc;
         PANO_HIP(hipEventSynchronize(ctx->ev_regions));          // the one wait of a stitch
         if (ctx->upload_pending) {                               // records_host may be in use
             PANO_HIP(hipEventSynchronize(ctx->ev_upload));

@@ -729,6 +729,8 @@ class Engine:
             self.set_option(_lib.OPT_STITCH_STREAMS, 0)
         if os.environ.get("PANO_STITCH_ASYNC", "0") == "1":         # (A/B timing)
             self.set_option(_lib.OPT_STITCH_ASYNC, 1)
+        if os.environ.get("PANO_LEVEL_CLASSES", "1") == "0":        # (A/B: every copy on every seam pixel)
+            self.set_option(_lib.OPT_LEVEL_CLASSES, 0)
         if os.environ.get("PANO_SIFT_GRAPH", "1") == "0":           # (A/B timing: launch by launch)
             self.set_option(_lib.OPT_SIFT_GRAPH, 0)
         if os.environ.get("PANO_BLUR_SEG_T"):                       # (A/B timing of the segments' length)
@@ -952,6 +954,29 @@ class Engine:
                                               _ptr(bown), _ptr(interior)), "pano_interior_map")
         return interior
 
+    def interior_classes(self, owner, radii, strip=None):
+        """(interior map at radii[-1], level classes): uint8 [ceil(H/B)][ceil(W/B)] each.  A block's
+        class is the number of leading levels whose Gaussian radius (``radii``, ascending) finds
+        one owner around every pixel of the block; class len(radii) = interior.  The collapse
+        gathers, on a pixel of class j >= 1, only the blurred copies j - 1 and up."""
+        torch = _torch()
+        H, W = owner.shape
+        c0, c1 = strip if strip is not None else (0, W)
+        ib = self.interior_block
+        shape8 = ((H + ib - 1) // ib, (W + ib - 1) // ib)
+        bown = torch.empty((2,) + shape8, dtype=torch.int16, device=self.device)
+        interior = torch.empty(shape8, dtype=torch.uint8, device=self.device)
+        classes = torch.empty(shape8, dtype=torch.uint8, device=self.device)
+        arr = (C.c_int * len(radii))(*[int(r) for r in radii])
+        _lib.check(self.lib.pano_interior_classes(self.ctx(), _ptr(owner), H, W, c0, c1, arr,
+                                                  len(radii), _ptr(bown), _ptr(interior),
+                                                  _ptr(classes)), "pano_interior_classes")
+        return interior, classes
+
+    def level_radii(self, n_levels):
+        """Gaussian radii of the n_levels - 1 blurred levels (half their apertures)."""
+        return [gaussian_ksize(s) // 2 for s in level_sigmas(n_levels)]
+
     # Weights of a column's mosaic pixels (ownership, the collapse's interior pixels), valid pixels
     # (the warp's windows) and pixels near a seam (the blur's active tiles, the collapse's gathers) in
     # its cost.  The first two are their kernels' shares of a config-3 stitch (profiles/r05/final);
@@ -1014,6 +1039,44 @@ class Engine:
             total += int((grid.astype(np.int64) * wy[:, None] * wx[None, :]).sum())
         return total
 
+    def gather_bytes(self, shape, n_levels):
+        """Algorithmic bytes the last fused stitch's collapse gathers from the warped planes and the
+        blurred copies: over every record's rectangle A, a pixel of class 0 takes the planes (12 B)
+        and all n_levels - 1 copies (16 B each), a pixel of class j >= 1 the colour of copy j - 1
+        (12 B) and the copies j and up - plus the owner's planes (12 B) once per such pixel - and an
+        interior pixel nothing (``multiband_compose_kernel``).  Without level classes (option off,
+        no shortcut) every pixel that is not interior counts as class 0.  None before a stitch.
+        Synchronises (reporting only)."""
+        torch = _torch()
+        table, flags = getattr(self, "last_tiles", (None, None))
+        classes = getattr(self, "last_classes", None)
+        if table is None:
+            return None
+        H, W = shape
+        nb = n_levels - 1
+        host = table.host
+        if classes is None or flags is None:
+            return float((host["ah"].astype(np.int64) * host["aw"]).sum()) * (12 + 16 * nb)
+        if not self.get_option(_lib.OPT_LEVEL_CLASSES):
+            classes = torch.where(classes >= nb, classes, torch.zeros_like(classes))
+        ib = self.interior_block
+        px = classes.repeat_interleave(ib, 0).repeat_interleave(ib, 1)[:H, :W]
+        per_class = torch.tensor([12 + 16 * nb] + [12 + 16 * (nb - j) for j in range(1, nb)] + [0],
+                                 dtype=torch.float64, device=self.device)
+        total = torch.zeros((), dtype=torch.float64, device=self.device)
+        for rec in host:
+            aw, ah = int(rec["aw"]), int(rec["ah"])
+            if aw <= 0 or ah <= 0:
+                continue
+            y0, x0 = int(rec["y0"]) + int(rec["ay0"]), int(rec["x0"]) + int(rec["ax0"])
+            sub = px[max(y0, 0):min(y0 + ah, H), max(x0, 0):min(x0 + aw, W)]
+            if sub.numel():
+                counts = torch.bincount(sub.reshape(-1).long(), minlength=nb + 1)[:nb + 1]
+                total += (counts.double() * per_class).sum()
+        # the owner's planes on the pixels of the classes in between, once each
+        mid = ((px > 0) & (px < nb)).sum().double() * 12.0
+        return float((total + mid).item())
+
     def compose_interior_async(self, owner, shape, strip, interior, cams, plan, luts,
                                want_float=False, mosaic_out=None):
         """Part 1 of the collapse - the interior pixels, which need the owner map and
@@ -1034,7 +1097,7 @@ class Engine:
                 t.record_stream(self.side)
         _lib.check(self.lib.pano_multiband_compose(
             self.ctx(self.side), None, 0, H, W, strip[0], strip[1], 1, _ptr(owner), None,
-            _ptr(interior), _ptr(cams),
+            _ptr(interior), None, _ptr(cams),
             _ptr(plan.dev[0]), _ptr(plan.dev[1]), _ptr(plan.dev[2]), *self._lut_args(luts),
             _ptr(mosaic), _ptr(fl), 1),
             "pano_multiband_compose")
@@ -1064,7 +1127,7 @@ class Engine:
 
     def blur_and_compose(self, table, owner, valid, shape, n_levels, want_float=False,
                          strip=None, interior=None, cams=None, plan=None, luts=None, out=None,
-                         prepared=None, mosaic_out=None):
+                         prepared=None, mosaic_out=None, classes=None):
         """All Gaussian levels of all patches (n_levels launches), then the gather
         over the mosaic columns ``strip`` (default: all of them).  With an
         ``interior`` map, blur tiles and gathers are skipped where the result is
@@ -1098,7 +1161,8 @@ class Engine:
         tabs = plan.dev if interior is not None else (None, None, None)
         _lib.check(self.lib.pano_multiband_compose(
             self.ctx(), table.ptr, table.n, H, W, c0, c1, n_levels, _ptr(owner), _ptr(valid),
-            _ptr(interior), _ptr(cams) if interior is not None else None, _ptr(tabs[0]),
+            _ptr(interior), _ptr(classes) if interior is not None else None,
+            _ptr(cams) if interior is not None else None, _ptr(tabs[0]),
             _ptr(tabs[1]), _ptr(tabs[2]), *self._lut_args(luts), _ptr(mosaic), _ptr(fl),
             part), "pano_multiband_compose")
         if out is not None:
@@ -1309,7 +1373,9 @@ class Engine:
         # The interior map needs the owner map only: queued first, it keeps the GPU busy
         # while the host waits for the regions and lays out the windows.
         regions = self.owned_regions_async(owner, plan.n, ext, 2 * radius + 2)
-        interior = self.interior_map(owner, radius, ext) if shortcut and n_blur else None
+        interior = classes = None
+        if shortcut and n_blur:
+            interior, classes = self.interior_classes(owner, self.level_radii(n_levels), ext)
         # The interior pixels of the mosaic need nothing but the owner map: queued now, on
         # the side stream, they fill the GPU while the host waits for the regions and lays
         # out the windows, and run beside the warp.  (Queued behind the warp instead they
@@ -1352,7 +1418,9 @@ class Engine:
             _ptr(plan.dev[1]), _ptr(plan.dev[2]), *self._lut_args(luts), _ptr(need)), "pano_warp_windows")
         mosaic, fl = self.blur_and_compose(table, owner, valid, plan.shape, n_levels,
                                            want_float, (c0, c1), interior, cams, plan, luts,
-                                           out=early, prepared=prepared, mosaic_out=mosaic_out)
+                                           out=early, prepared=prepared, mosaic_out=mosaic_out,
+                                           classes=classes)
+        self.last_classes = classes
         return mosaic, fl, valid, patches
 
     def _stitch_workspace(self, H, W, n, max_spans):
@@ -1374,6 +1442,8 @@ class Engine:
                 regions_host=torch.empty((n, stride), dtype=torch.int32).pin_memory(),
                 bown=torch.empty((2,) + shape8, dtype=torch.int16, device=dev),
                 interior=torch.empty(shape8, dtype=torch.uint8, device=dev),
+                # (zeros: blocks outside the strip a rank works on stay class 0 for gather_bytes)
+                classes=torch.zeros(shape8, dtype=torch.uint8, device=dev),
                 records_host=torch.empty(cap * PATCH_DTYPE.itemsize, dtype=torch.uint8).pin_memory(),
                 table=torch.empty(cap * PATCH_DTYPE.itemsize, dtype=torch.uint8, device=dev),
                 cap=cap, tiles=None, need=None, cap_tiles=0, have=np.zeros(n, np.uint8),
@@ -1408,6 +1478,7 @@ class Engine:
         a.mosaic, a.mosaic_f32 = ptr(mosaic), ptr(fl)
         a.marks, a.regions, a.regions_host = ptr(ws["marks"]), ptr(ws["regions"]), ptr(ws["regions_host"])
         a.block_owner, a.interior = ptr(ws["bown"]), ptr(ws["interior"])
+        a.classes = ptr(ws["classes"])
         a.records_host, a.table, a.cap_records = ptr(ws["records_host"]), ptr(ws["table"]), ws["cap"]
         a.n, a.H, a.W = plan.n, H, W
         a.xs0, a.xs1, a.own0, a.own1 = strip[0], strip[1], ext[0], ext[1]
@@ -1476,6 +1547,7 @@ class Engine:
             self.last_kept_geometry = False
         if n_blur:
             self.last_tiles = (patches.table, ws["tiles"] if shortcut else None)
+        self.last_classes = ws["classes"] if shortcut and n_blur else None
         return mosaic, fl, valid, patches
 
     def trust_layouts(self, on=True, keep_geometry=False):

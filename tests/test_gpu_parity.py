@@ -791,7 +791,12 @@ def test_interior_shortcut(eng, oracle, kind):
     assert 0.2 < frac < 0.8                         # both branches are exercised
     ib = eng.interior_block
     big = interior.repeat_interleave(ib, 0).repeat_interleave(ib, 1)[:plan.shape[0], :plan.shape[1]]
-    assert torch.equal(m1[~big], m2[~big])          # untouched outside the interior
+    # untouched where no level's window holds a single owner (class 0: every copy is gathered as the
+    # full blend gathers it); the classes in between move by float32 rounding like the interior
+    _, classes = eng.interior_classes(owner, eng.level_radii(5))
+    c0 = (classes == 0).repeat_interleave(ib, 0).repeat_interleave(ib, 1)[:plan.shape[0], :plan.shape[1]]
+    assert 0.05 < c0.float().mean().item() < 0.6
+    assert torch.equal(m1[c0], m2[c0]) and torch.equal(f1[c0], f2[c0])
     # the interior test is conservative: every pixel of an interior block has one
     # owner over the whole (2R+1)^2 window
     own = owner.cpu().numpy().astype(np.int32)
@@ -800,6 +805,93 @@ def test_interior_shortcut(eng, oracle, kind):
            (maximum_filter(own, size=87, mode="nearest") == own) & (own >= 0)
     assert same[big.cpu().numpy()].all()
     ref_u8, ref_f = oracle.stitch(imgs, rots, intrs, "multiband", 5, max_resolution=10 ** 9,
+                                  return_float=True)
+    assert rel_l2(f1.cpu().numpy(), ref_f) <= REL_TOL
+    assert np.abs(m1.cpu().numpy().astype(int) - ref_u8.astype(int)).max() <= 1
+
+
+@pytest.mark.parametrize("levels", [5, 6, 3])
+def test_level_classes_of_the_interior_map(eng, levels):
+    """``pano_interior_classes``: a block's class = the number of leading levels whose Gaussian
+    radius finds one owner around every pixel of the block.  Against the one-radius map run once per
+    level (their sum), against a brute-force window test (conservative: class > k implies a
+    single-owner (2 r_k + 1)^2 window), nested, and the same on a column strip."""
+    from scipy.ndimage import maximum_filter, minimum_filter
+    from pano360_amd import engine, synth
+    _, rots, intrs = synth.make_scene(7, 640, 360, sweep_deg=60.0, jitter=0.012, seed=91, kind="A")
+    plan = eng.upload_plan(engine.Plan([(360, 640)] * 7, rots, intrs, True, 10 ** 9))
+    owner, _ = eng.ownership_cameras(plan)
+    radii = eng.level_radii(levels)
+    assert radii == sorted(radii) and len(radii) == levels - 1
+    interior, classes = eng.interior_classes(owner, radii)
+    stack = sum(eng.interior_map(owner, r).int() for r in radii)
+    assert torch_equal(classes.int(), stack)
+    assert torch_equal(interior, eng.interior_map(owner, radii[-1]))
+    assert torch_equal(interior.bool(), classes == len(radii))
+    hist = [int((classes == j).sum().item()) for j in range(levels)]
+    assert all(v > 0 for v in hist), hist          # every class occurs
+    own = owner.cpu().numpy().astype(np.int32)
+    ib = eng.interior_block
+    H, W = own.shape
+    big = classes.cpu().numpy().repeat(ib, 0).repeat(ib, 1)[:H, :W]
+    for k, r in enumerate(radii):
+        size = 2 * r + 1
+        same = (minimum_filter(own, size=size, mode="nearest") == own) & \
+               (maximum_filter(own, size=size, mode="nearest") == own) & (own >= 0)
+        assert same[big > k].all(), (k, r)
+    # a strip classifies its blocks as the whole mosaic does
+    c0, c1 = 4 * (W // 8), 4 * (W // 8) + 256
+    margin = ib * ((radii[-1] + 2 * ib - 2) // ib) + ib - 1
+    ext = (max(c0 - margin, 0), min(c1 + margin, W))
+    owner_s, _ = eng.ownership_cameras(plan, strip=ext)
+    _, cls_s = eng.interior_classes(owner_s, radii, ext)
+    b0, b1 = (c0 + ib - 1) // ib, c1 // ib
+    assert torch_equal(cls_s[:, b0:b1], classes[:, b0:b1])
+
+
+def torch_equal(a, b):
+    import torch
+    return torch.equal(a, b)
+
+
+@pytest.mark.parametrize("levels,kind", [(5, "A"), (6, "B"), (3, "A")])
+def test_collapse_with_level_classes(eng, oracle, levels, kind):
+    """The collapse gathers, on a pixel of class j >= 1, the colour of copy j - 1 and the copies
+    j and up only (the levels below telescope to the owner's I - G_{j-1} I): against the collapse
+    that gathers every copy (option PANO_OPT_LEVEL_CLASSES = 0, rounds 1 - 5) the float mosaic moves
+    by float32 rounding, uint8 by at most one level, class-0 pixels not at all; against the oracle
+    it stays inside the stated bars.  The launch-by-launch path and the native call agree bit for
+    bit, and so do column strips."""
+    import torch
+    from pano360_amd import _lib, dist as pdist, engine, synth
+    imgs, rots, intrs = synth.make_scene(6, 640, 360, sweep_deg=50.0, jitter=0.01, seed=33, kind=kind)
+    shapes = [im.shape[:2] for im in imgs]
+    plan = engine.Plan(shapes, rots, intrs, True, 10 ** 9)
+    frames = eng.upload_frames(imgs)
+    m1, f1, v1, _ = eng.stitch(frames, plan, "multiband", levels, want_float=True)
+    classes = eng.last_classes.clone()
+    plain = engine.Engine(eng.device)
+    plain.set_option(_lib.OPT_LEVEL_CLASSES, 0)
+    m0, f0, v0, _ = plain.stitch(frames, plan, "multiband", levels, want_float=True)
+    assert torch.equal(v1, v0)
+    assert (f1 - f0).abs().max().item() <= 2.5e-7
+    assert (m1.int() - m0.int()).abs().max().item() <= 1
+    ib = eng.interior_block
+    H, W = plan.shape
+    px = classes.repeat_interleave(ib, 0).repeat_interleave(ib, 1)[:H, :W]
+    assert torch.equal(m1[px == 0], m0[px == 0]) and torch.equal(f1[px == 0], f0[px == 0])
+    moved = (f1 != f0).any(dim=2)
+    mid = (px > 0) & (px < levels - 1)
+    assert mid.float().mean().item() > 0.03 and moved[mid].any()      # the new branch really ran
+    # launch by launch from Python = the native call
+    loose = engine.Engine(eng.device)
+    loose.native_stitch = False
+    m2, f2, _, _ = loose.stitch(frames, plan, "multiband", levels, want_float=True)
+    assert torch.equal(m2, m1) and torch.equal(f2.view(torch.int32), f1.view(torch.int32))
+    # column strips compose the same mosaic
+    strips, _ = pdist.emulate_on_one_device(eng, imgs, rots, intrs, levels, 3)
+    assert torch.equal(strips, m1)
+    ref_u8, ref_f = oracle.stitch(imgs, rots, intrs, "multiband", levels, max_resolution=10 ** 9,
                                   return_float=True)
     assert rel_l2(f1.cpu().numpy(), ref_f) <= REL_TOL
     assert np.abs(m1.cpu().numpy().astype(int) - ref_u8.astype(int)).max() <= 1
