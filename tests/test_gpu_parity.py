@@ -880,9 +880,12 @@ def test_collapse_with_level_classes(eng, oracle, levels, kind):
     H, W = plan.shape
     px = classes.repeat_interleave(ib, 0).repeat_interleave(ib, 1)[:H, :W]
     assert torch.equal(m1[px == 0], m0[px == 0]) and torch.equal(f1[px == 0], f0[px == 0])
-    moved = (f1 != f0).any(dim=2)
+    # the classes in between exist and save the collapse bytes (where a level's tap sum is exactly
+    # 1 the two collapses even agree bit for bit: (x 1) / 1 = x)
     mid = (px > 0) & (px < levels - 1)
-    assert mid.float().mean().item() > 0.03 and moved[mid].any()      # the new branch really ran
+    assert mid.float().mean().item() > 0.03
+    with_classes, without = eng.gather_bytes(plan.shape, levels), plain.gather_bytes(plan.shape, levels)
+    assert 0.5 * without < with_classes < 0.97 * without, (with_classes, without)
     # launch by launch from Python = the native call
     loose = engine.Engine(eng.device)
     loose.native_stitch = False
