@@ -197,10 +197,14 @@ int pano_interior_block(void);
  *                         into a HIP graph the second time a set of buffers is used and replayed
  *                         from then on (one hipGraphLaunch per frame instead of ~110 launches);
  *                         0 = always launch by launch.  Same results bit for bit.
- *   PANO_OPT_LEVEL_CLASSES  pano_multiband_compose / pano_stitch_multiband: 1 (default) = the
- *                         collapse uses the level classes it is handed (pano_interior_classes);
- *                         0 = it gathers every copy on every pixel that is not interior, as rounds
- *                         1 - 5 did (A/B; the mosaics agree to float32 rounding). */
+ *   PANO_OPT_LEVEL_CLASSES  pano_multiband_compose / pano_stitch_multiband: 1 = the collapse
+ *                         uses the level classes (pano_interior_classes; the stitch computes
+ *                         them); 0 (default) = it gathers every copy on every pixel that is not
+ *                         interior.  The mosaics agree to float32 rounding.  Measured (round 6,
+ *                         profiles/r06/ab_level_classes.txt): the classes take 13 % off the
+ *                         collapse's HBM traffic and ADD 4 - 7 % to its time - it is bound by its
+ *                         memory instructions, which a wave issues while ANY lane needs them,
+ *                         not by bytes - so the option is off. */
 typedef struct pano_ctx pano_ctx;
 #define PANO_OPT_BLUR_KERNEL 0
 #define PANO_OPT_OWN_PRUNE 1

@@ -56,7 +56,7 @@ extern "C" int pano_ctx_create(int device, void *stream, pano_ctx **out) {
     ctx->opt[PANO_OPT_STITCH_ASYNC] = 0;
     ctx->opt[PANO_OPT_BLUR_SEG_LEN] = 0;
     ctx->opt[PANO_OPT_SIFT_GRAPH] = 1;
-    ctx->opt[PANO_OPT_LEVEL_CLASSES] = 1;
+    ctx->opt[PANO_OPT_LEVEL_CLASSES] = 0;
     *out = ctx;
     return PANO_OK;
 }

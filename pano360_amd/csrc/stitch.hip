@@ -22,7 +22,8 @@ __global__ __launch_bounds__(LAY_THREADS) void layout_windows_kernel(
     int n_blur, int grid32, float *planes, float *blurred, float *scratch, long cap_planes,
     long cap_blurred, long cap_scratch, int cap_tiles, int want_tiles, int b_nr, int b_vw,
     int b_vh, int b_aw, int b_ah, pano_patch *__restrict__ table,
-    LayoutSummary *__restrict__ summary) {
+    LayoutSummary *__restrict__ summary, LayoutSummary expect, int check_expect,
+    int *__restrict__ sticky) {
     __shared__ long s_planes[LAY_THREADS], s_blurred[LAY_THREADS], s_scratch[LAY_THREADS];
     __shared__ int s_tiles[LAY_THREADS], s_slot[LAY_THREADS];
     __shared__ long s_run[4];                       // planes, blurred, scratch, tiles so far
@@ -140,12 +141,25 @@ __global__ __launch_bounds__(LAY_THREADS) void layout_windows_kernel(
         out.why = why;
         out.pad = 0;
         *summary = out;
+        // a trusted stitch: ITS layout against the verified one it was queued with, kept in a
+        // sticky word - the one summary slot is overwritten by the next stitch's kernel, and a
+        // broken promise in the middle of a run of trusted stitches must not be lost with it
+        if (check_expect &&
+            !(out.ok && out.planes_floats == expect.planes_floats &&
+              out.blurred_floats == expect.blurred_floats && out.scratch_floats == expect.scratch_floats &&
+              out.n_records == expect.n_records && out.n_tiles == expect.n_tiles &&
+              out.max_vw == expect.max_vw && out.max_vh == expect.max_vh && out.max_aw == expect.max_aw &&
+              out.max_ah == expect.max_ah && out.missing == 0))
+            *(volatile int *)sticky = 1;
     }
 }
 
 static int ensure_layout_buffers(pano_ctx *ctx, int n) {
-    if (!ctx->lay_sum_host)
-        PANO_HIP(hipHostMalloc((void **)&ctx->lay_sum_host, sizeof(LayoutSummary), hipHostMallocDefault));
+    if (!ctx->lay_sum_host) {
+        // (the summary, then the sticky mismatch word of the trusted stitches)
+        PANO_HIP(hipHostMalloc((void **)&ctx->lay_sum_host, sizeof(LayoutSummary) + 64, hipHostMallocDefault));
+        memset(ctx->lay_sum_host, 0, sizeof(LayoutSummary) + 64);
+    }
     if (n > ctx->lay_cap_n) {
         PANO_HIP(hipStreamSynchronize(ctx->stream));            // a queued kernel may still read them
         if (ctx->lay_rects_dev) PANO_HIP(hipFree(ctx->lay_rects_dev));
@@ -161,6 +175,19 @@ static int ensure_layout_buffers(pano_ctx *ctx, int n) {
     return PANO_OK;
 }
 
+// The verified layout as the layout kernel compares it, and the sticky word behind the summary.
+static LayoutSummary layout_expectation(const pano_layout &v) {
+    LayoutSummary e = {};
+    e.planes_floats = v.planes_floats, e.blurred_floats = v.blurred_floats;
+    e.scratch_floats = v.scratch_floats;
+    e.n_records = v.n_records, e.n_tiles = v.n_tiles;
+    e.max_vw = v.max_vw, e.max_vh = v.max_vh, e.max_aw = v.max_aw, e.max_ah = v.max_ah;
+    return e;
+}
+static int *layout_sticky(pano_ctx *ctx) {
+    return (int *)((unsigned char *)ctx->lay_sum_host + sizeof(LayoutSummary));
+}
+
 static void stitch_signature(const pano_stitch_args *a, int tile_grid, int *sig) {
     const int v[STITCH_SIG] = {a->n, a->H, a->W, a->xs0, a->xs1, a->own0, a->own1, a->n_levels,
                                a->radius, a->max_spans, a->shortcut, a->min_gap, tile_grid};
@@ -170,7 +197,7 @@ static void stitch_signature(const pano_stitch_args *a, int tile_grid, int *sig)
 // The interior map of a stitch - with the level classes beside it when the caller gave a buffer
 // for them (radii of the levels: half their apertures, ascending as stitcher.py:218 makes them).
 static int stitch_interior_map(pano_ctx *ctx, const pano_stitch_args *a, int n_blur) {
-    if (a->classes && n_blur > 0) {
+    if (a->classes && n_blur > 0 && ctx->opt[PANO_OPT_LEVEL_CLASSES]) {
         int radii[PANO_MAX_LEVELS];
         bool ascending = true;
         for (int k = 0; k < n_blur; ++k) {
@@ -186,8 +213,8 @@ static int stitch_interior_map(pano_ctx *ctx, const pano_stitch_args *a, int n_b
 }
 
 // Do this stitch's classes hold (the buffer was given and stitch_interior_map filled it)?
-static bool stitch_has_classes(const pano_stitch_args *a, int n_blur) {
-    if (!a->classes || n_blur <= 0) return false;
+static bool stitch_has_classes(const pano_ctx *ctx, const pano_stitch_args *a, int n_blur) {
+    if (!a->classes || n_blur <= 0 || !ctx->opt[PANO_OPT_LEVEL_CLASSES]) return false;
     for (int k = 0; k < n_blur; ++k)
         if (k && a->ntaps[k] / 2 < a->ntaps[k - 1] / 2) return false;
     return a->ntaps[n_blur - 1] / 2 == a->radius;
@@ -283,7 +310,7 @@ static int queue_tail(pano_ctx *ctx, pano_stitch_args *a, const pano_layout &lay
             return rc;
     return pano_multiband_compose(ctx, a->table, nr, a->H, a->W, a->xs0, a->xs1, a->n_levels,
                                   a->owner, a->valid, interior ? a->interior : nullptr,
-                                  interior && stitch_has_classes(a, n_blur) ? a->classes : nullptr,
+                                  interior && stitch_has_classes(ctx, a, n_blur) ? a->classes : nullptr,
                                   interior ? a->cams : nullptr, interior ? a->sin_t : nullptr,
                                   interior ? a->cos_t : nullptr, interior ? a->tan_p : nullptr,
                                   a->lut, a->lut_stride, a->mosaic, a->mosaic_f32, 0);
@@ -452,7 +479,8 @@ extern "C" int pano_stitch_multiband(pano_ctx *ctx, pano_stitch_args *a, int res
                                (long)a->planes_floats, (long)a->blurred_floats,
                                (long)a->scratch_floats, a->cap_tiles, 1, bound.n_records,
                                bound.max_vw, bound.max_vh, bound.max_aw, bound.max_ah, a->table,
-                               ctx->lay_sum_host);
+                               ctx->lay_sum_host, layout_expectation(ctx->lay_prev), trusted ? 1 : 0,
+                               layout_sticky(ctx));
             PANO_LAUNCH_CHECK("layout_windows_kernel");
             // the summary goes straight into pinned host memory; the caller's copy of the records
             // leaves through the side stream: nothing stands between this kernel and the warp
@@ -560,7 +588,9 @@ extern "C" int pano_stitch_verify(pano_ctx *ctx) {
     ctx->trusted_pending = false;
     const LayoutSummary sum = *ctx->lay_sum_host;
     const pano_layout &v = ctx->lay_prev;
-    const bool same = sum.ok && sum.planes_floats == v.planes_floats &&
+    // (the last trusted stitch's summary, and the sticky word every trusted stitch before it left)
+    const int sticky = __atomic_exchange_n(layout_sticky(ctx), 0, __ATOMIC_SEQ_CST);
+    const bool same = !sticky && sum.ok && sum.planes_floats == v.planes_floats &&
                       sum.blurred_floats == v.blurred_floats && sum.scratch_floats == v.scratch_floats &&
                       sum.n_records == v.n_records && sum.n_tiles == v.n_tiles &&
                       sum.max_vw == v.max_vw && sum.max_vh == v.max_vh && sum.max_aw == v.max_aw &&
@@ -568,9 +598,10 @@ extern "C" int pano_stitch_verify(pano_ctx *ctx) {
     if (!same) {
         ctx->lay_prev_valid = ctx->lay_prev_verified = false;
         ctx->geom_valid = false;
-        pano_set_error("pano_stitch_verify: a trusted stitch laid out %d records (ok %d, why %d) where "
-                       "the verified layout has %d: the cameras were not those of the verified stitch",
-                       sum.n_records, sum.ok, sum.why, v.n_records);
+        pano_set_error("pano_stitch_verify: a trusted stitch laid out %d records (ok %d, why %d, an "
+                       "earlier one differed: %d) where the verified layout has %d: the cameras were "
+                       "not those of the verified stitch",
+                       sum.n_records, sum.ok, sum.why, sticky, v.n_records);
         return PANO_EINVAL;
     }
     return PANO_OK;

@@ -729,8 +729,8 @@ class Engine:
             self.set_option(_lib.OPT_STITCH_STREAMS, 0)
         if os.environ.get("PANO_STITCH_ASYNC", "0") == "1":         # (A/B timing)
             self.set_option(_lib.OPT_STITCH_ASYNC, 1)
-        if os.environ.get("PANO_LEVEL_CLASSES", "1") == "0":        # (A/B: every copy on every seam pixel)
-            self.set_option(_lib.OPT_LEVEL_CLASSES, 0)
+        if os.environ.get("PANO_LEVEL_CLASSES", "0") == "1":        # (A/B: the collapse by level classes)
+            self.set_option(_lib.OPT_LEVEL_CLASSES, 1)
         if os.environ.get("PANO_SIFT_GRAPH", "1") == "0":           # (A/B timing: launch by launch)
             self.set_option(_lib.OPT_SIFT_GRAPH, 0)
         if os.environ.get("PANO_BLUR_SEG_T"):                       # (A/B timing of the segments' length)
@@ -1055,10 +1055,11 @@ class Engine:
         H, W = shape
         nb = n_levels - 1
         host = table.host
-        if classes is None or flags is None:
+        interior = getattr(self, "last_interior", None)
+        if flags is None or (classes is None and interior is None):
             return float((host["ah"].astype(np.int64) * host["aw"]).sum()) * (12 + 16 * nb)
-        if not self.get_option(_lib.OPT_LEVEL_CLASSES):
-            classes = torch.where(classes >= nb, classes, torch.zeros_like(classes))
+        if classes is None:                  # no level classes: a pixel is interior (class nb) or class 0
+            classes = interior * nb
         ib = self.interior_block
         px = classes.repeat_interleave(ib, 0).repeat_interleave(ib, 1)[:H, :W]
         per_class = torch.tensor([12 + 16 * nb] + [12 + 16 * (nb - j) for j in range(1, nb)] + [0],
@@ -1375,7 +1376,10 @@ class Engine:
         regions = self.owned_regions_async(owner, plan.n, ext, 2 * radius + 2)
         interior = classes = None
         if shortcut and n_blur:
-            interior, classes = self.interior_classes(owner, self.level_radii(n_levels), ext)
+            if self.get_option(_lib.OPT_LEVEL_CLASSES):
+                interior, classes = self.interior_classes(owner, self.level_radii(n_levels), ext)
+            else:
+                interior = self.interior_map(owner, radius, ext)
         # The interior pixels of the mosaic need nothing but the owner map: queued now, on
         # the side stream, they fill the GPU while the host waits for the regions and lays
         # out the windows, and run beside the warp.  (Queued behind the warp instead they
@@ -1420,7 +1424,7 @@ class Engine:
                                            want_float, (c0, c1), interior, cams, plan, luts,
                                            out=early, prepared=prepared, mosaic_out=mosaic_out,
                                            classes=classes)
-        self.last_classes = classes
+        self.last_classes, self.last_interior = classes, interior
         return mosaic, fl, valid, patches
 
     def _stitch_workspace(self, H, W, n, max_spans):
@@ -1441,8 +1445,8 @@ class Engine:
                 regions=torch.empty((n, stride), dtype=torch.int32, device=dev),
                 regions_host=torch.empty((n, stride), dtype=torch.int32).pin_memory(),
                 bown=torch.empty((2,) + shape8, dtype=torch.int16, device=dev),
-                interior=torch.empty(shape8, dtype=torch.uint8, device=dev),
                 # (zeros: blocks outside the strip a rank works on stay class 0 for gather_bytes)
+                interior=torch.zeros(shape8, dtype=torch.uint8, device=dev),
                 classes=torch.zeros(shape8, dtype=torch.uint8, device=dev),
                 records_host=torch.empty(cap * PATCH_DTYPE.itemsize, dtype=torch.uint8).pin_memory(),
                 table=torch.empty(cap * PATCH_DTYPE.itemsize, dtype=torch.uint8, device=dev),
@@ -1547,7 +1551,9 @@ class Engine:
             self.last_kept_geometry = False
         if n_blur:
             self.last_tiles = (patches.table, ws["tiles"] if shortcut else None)
-        self.last_classes = ws["classes"] if shortcut and n_blur else None
+        self.last_classes = (ws["classes"] if shortcut and n_blur
+                             and self.get_option(_lib.OPT_LEVEL_CLASSES) else None)
+        self.last_interior = ws["interior"] if shortcut and n_blur else None
         return mosaic, fl, valid, patches
 
     def trust_layouts(self, on=True, keep_geometry=False):

@@ -446,6 +446,14 @@ def test_trusted_stitches_equal_waiting_ones_and_a_broken_promise_is_caught(stri
         sig, _, kept = trusting._trusted[:3]
         trusting._trusted = ((id(other),) + sig[1:], other, kept) + trusting._trusted[3:]
         trusting.multiband_fused(frames, other, 5, frame_ids=ids, strip=strip)
+        if strip_case:
+            # ... and a GOOD trusted stitch behind the bad one, before anybody verifies: the one
+            # summary slot now holds the good stitch's layout, the bad one's lives on in the sticky
+            # word its layout kernel set (a void mosaic must not pass because a later one is fine)
+            sig, _, kept = trusting._trusted[:3]
+            trusting._trusted = ((id(plan_t),) + sig[1:], plan_t, kept) + trusting._trusted[3:]
+            trusting.multiband_fused(frames, plan_t, 5, frame_ids=ids, strip=strip)
+            assert trusting._stitch_ws[next(iter(trusting._stitch_ws))]["args"].trust_layout == 2
         with pytest.raises(_lib.PanoError, match="verified"):
             trusting.verify_trusted()
     # ... after which the engine lays out from scratch and is right again
@@ -791,12 +799,7 @@ def test_interior_shortcut(eng, oracle, kind):
     assert 0.2 < frac < 0.8                         # both branches are exercised
     ib = eng.interior_block
     big = interior.repeat_interleave(ib, 0).repeat_interleave(ib, 1)[:plan.shape[0], :plan.shape[1]]
-    # untouched where no level's window holds a single owner (class 0: every copy is gathered as the
-    # full blend gathers it); the classes in between move by float32 rounding like the interior
-    _, classes = eng.interior_classes(owner, eng.level_radii(5))
-    c0 = (classes == 0).repeat_interleave(ib, 0).repeat_interleave(ib, 1)[:plan.shape[0], :plan.shape[1]]
-    assert 0.05 < c0.float().mean().item() < 0.6
-    assert torch.equal(m1[c0], m2[c0]) and torch.equal(f1[c0], f2[c0])
+    assert torch.equal(m1[~big], m2[~big])          # untouched outside the interior
     # the interior test is conservative: every pixel of an interior block has one
     # owner over the whole (2R+1)^2 window
     own = owner.cpu().numpy().astype(np.int32)
@@ -861,18 +864,22 @@ def test_collapse_with_level_classes(eng, oracle, levels, kind):
     that gathers every copy (option PANO_OPT_LEVEL_CLASSES = 0, rounds 1 - 5) the float mosaic moves
     by float32 rounding, uint8 by at most one level, class-0 pixels not at all; against the oracle
     it stays inside the stated bars.  The launch-by-launch path and the native call agree bit for
-    bit, and so do column strips."""
+    bit, and so do column strips.  (The option is OFF by default: it takes 13 % off the collapse's
+    traffic and adds 4 - 7 % to its time, profiles/r06/ab_level_classes.txt.)"""
     import torch
     from pano360_amd import _lib, dist as pdist, engine, synth
     imgs, rots, intrs = synth.make_scene(6, 640, 360, sweep_deg=50.0, jitter=0.01, seed=33, kind=kind)
     shapes = [im.shape[:2] for im in imgs]
     plan = engine.Plan(shapes, rots, intrs, True, 10 ** 9)
     frames = eng.upload_frames(imgs)
-    m1, f1, v1, _ = eng.stitch(frames, plan, "multiband", levels, want_float=True)
-    classes = eng.last_classes.clone()
-    plain = engine.Engine(eng.device)
-    plain.set_option(_lib.OPT_LEVEL_CLASSES, 0)
+    on = engine.Engine(eng.device)
+    on.set_option(_lib.OPT_LEVEL_CLASSES, 1)
+    m1, f1, v1, _ = on.stitch(frames, plan, "multiband", levels, want_float=True)
+    classes = on.last_classes.clone()
+    plain = eng                                     # the default: no level classes
+    assert plain.get_option(_lib.OPT_LEVEL_CLASSES) == 0
     m0, f0, v0, _ = plain.stitch(frames, plan, "multiband", levels, want_float=True)
+    assert plain.last_classes is None
     assert torch.equal(v1, v0)
     assert (f1 - f0).abs().max().item() <= 2.5e-7
     assert (m1.int() - m0.int()).abs().max().item() <= 1
@@ -884,15 +891,16 @@ def test_collapse_with_level_classes(eng, oracle, levels, kind):
     # 1 the two collapses even agree bit for bit: (x 1) / 1 = x)
     mid = (px > 0) & (px < levels - 1)
     assert mid.float().mean().item() > 0.03
-    with_classes, without = eng.gather_bytes(plan.shape, levels), plain.gather_bytes(plan.shape, levels)
+    with_classes, without = on.gather_bytes(plan.shape, levels), plain.gather_bytes(plan.shape, levels)
     assert 0.5 * without < with_classes < 0.97 * without, (with_classes, without)
     # launch by launch from Python = the native call
     loose = engine.Engine(eng.device)
+    loose.set_option(_lib.OPT_LEVEL_CLASSES, 1)
     loose.native_stitch = False
     m2, f2, _, _ = loose.stitch(frames, plan, "multiband", levels, want_float=True)
     assert torch.equal(m2, m1) and torch.equal(f2.view(torch.int32), f1.view(torch.int32))
     # column strips compose the same mosaic
-    strips, _ = pdist.emulate_on_one_device(eng, imgs, rots, intrs, levels, 3)
+    strips, _ = pdist.emulate_on_one_device(on, imgs, rots, intrs, levels, 3)
     assert torch.equal(strips, m1)
     ref_u8, ref_f = oracle.stitch(imgs, rots, intrs, "multiband", levels, max_resolution=10 ** 9,
                                   return_float=True)
