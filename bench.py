@@ -83,7 +83,7 @@ def compact_line(full, side_file=None):
     out["roofline"] = {k: _num(roof[k]) for k in
                        ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic",
                         "traffic_source", "avg_launch_ms", "launches", "blend_frac",
-                        "weighted_frac", "frac_range") if k in roof}
+                        "blend_frac_tile_count", "weighted_frac", "frac_range") if k in roof}
     by_kernel = full.get("roofline_by_kernel")
     if by_kernel:
         out["roofline_by_kernel"] = {
@@ -320,6 +320,8 @@ def algorithmic_bytes(plan, patches, n_levels, px_active, times=None, gathered=N
         # counted (12 + 16 (L - 1)) bytes on every pixel of an active blur tile, an upper bound
         "multiband_compose_kernel": (gathered if gathered is not None else
                                      (12.0 + 16.0 * (n_levels - 1)) * px_cols) + 6.0 * M,
+        # (rounds 2 - 5's count, kept beside it for continuity: `blend_frac_tile_count`)
+        "multiband_compose_kernel/tile_count": (12.0 + 16.0 * (n_levels - 1)) * px_cols + 6.0 * M,
         # the float32 vector-ALU form (Engine(blur="valu")): the row pass reads the planes and
         # the owner map over V and writes L-1 RGBA row-pass images (V rows x A columns), the
         # column pass reads those and writes the blurred copies over A
@@ -348,11 +350,12 @@ def roofline_for(times, plan, patches, n_levels, steps, px_active, workload=None
         out["note"] = ("split-float16 Toeplitz products on the matrix cores (3 MFMAs per "
                        "float32-accurate product); %.1f TFLOP/s of useful float32-equivalent "
                        "FMA work" % (flop / launches / avg_s / 1e12))
-    def together(names, note):
+    def together(names, note, tile_count=False):
         have = [k for k in names if k in times and k in per_step]
         if not have:
             return None
-        bytes_sum = sum(per_step[k] for k in have) * steps
+        count = lambda k: per_step.get(k + "/tile_count", per_step[k]) if tile_count else per_step[k]  # noqa: E731
+        bytes_sum = sum(count(k) for k in have) * steps
         secs = sum(times[k][0] for k in have) * 1e-3
         return dict(kernels=have, achieved=bytes_sum / secs / 1e9,
                     frac=bytes_sum / secs / 1e9 / HBM_PEAK_GBPS, ms_per_step=secs / steps * 1e3,
@@ -370,6 +373,15 @@ def roofline_for(times, plan, patches, n_levels, steps, px_active, workload=None
     if agg:
         out["multiband_blend"] = agg
         out["blend_frac"] = agg["frac"]          # (a scalar beside `frac`: north_star's >= 0.40)
+        # Round 6 counts the collapse's bytes on the (record, pixel) pairs it really gathers
+        # (Engine.gather_bytes: seam pixels, 4 x 4 blocks); rounds 2 - 5 counted every pixel of an
+        # active 32 x 32 blur tile - the pixels the blur WRITES copies on - as gathered, which
+        # credits the collapse with reads it does not make.  The old figure, for continuity:
+        old = together(BLUR_KERNELS + ("blur_rows_kernel", "blur_cols_kernel", "multiband_compose_kernel"),
+                       "as `multiband_blend`, the collapse's gathers counted on every pixel of an active "
+                       "blur tile (rounds 2 - 5's count; an upper bound of what it reads)", True)
+        out["multiband_blend_tile_count"] = old
+        out["blend_frac_tile_count"] = old["frac"]
     return out
 
 

@@ -469,10 +469,17 @@ def test_bench_reads_the_committed_profiles():
     assert bench.scaling_projection("no_such_workload") is None
     traffic, source = bench.pmc_traffic("blur_lean_kernel", "cfg3")
     assert traffic and traffic > 1e9 and source.startswith("profiles/")
+    import glob
+    import json
     rounds = sorted(d for d in os.listdir(os.path.join(ROOT, "profiles")) if d.startswith("r"))
-    newest = [r for r in rounds
-              if any(f.startswith("pmc_traffic") for _, _, fs in os.walk(os.path.join(ROOT, "profiles", r))
-                     for f in fs)][-1]
+
+    def has_cfg3(r):                                # a counter summary OF THIS WORKLOAD in the round
+        for path in glob.glob(os.path.join(ROOT, "profiles", r, "**", "pmc_traffic*.json"), recursive=True):
+            with open(path) as fid:
+                if json.load(fid).get("workload") == "cfg3":
+                    return True
+        return False
+    newest = [r for r in rounds if has_cfg3(r)][-1]
     assert source.split("/")[1] == newest
     assert bench.pmc_traffic("blur_lean_kernel", "no_such_workload") == (None, None)
 
