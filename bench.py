@@ -83,7 +83,10 @@ def compact_line(full, side_file=None):
     out["roofline"] = {k: _num(roof[k]) for k in
                        ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic",
                         "traffic_source", "avg_launch_ms", "launches", "blend_frac",
-                        "blend_frac_tile_count", "weighted_frac", "frac_range") if k in roof}
+                        "blend_frac_tile_count", "weighted_frac") if k in roof}
+    if isinstance(roof.get("frac_range"), dict):         # [min, max, processes]: the side file says where from
+        fr = roof["frac_range"]
+        out["roofline"]["frac_range"] = [_num(fr["min"], 4), _num(fr["max"], 4), fr["n"]]
     by_kernel = full.get("roofline_by_kernel")
     if by_kernel:
         out["roofline_by_kernel"] = {
@@ -350,6 +353,9 @@ def roofline_for(times, plan, patches, n_levels, steps, px_active, workload=None
         out["note"] = ("split-float16 Toeplitz products on the matrix cores (3 MFMAs per "
                        "float32-accurate product); %.1f TFLOP/s of useful float32-equivalent "
                        "FMA work" % (flop / launches / avg_s / 1e12))
+    rng = frac_range(name, workload)
+    if rng is not None:
+        out["frac_range"] = rng
     def together(names, note, tile_count=False):
         have = [k for k in names if k in times and k in per_step]
         if not have:
@@ -431,6 +437,25 @@ def ownership_issue_bound(workload):
         return None
     rec["source"] = os.path.relpath(found[-1], ROOT)
     return rec if "valu_busy" in rec else None
+
+
+def frac_range(kernel, workload):
+    """The committed range of `roofline.frac` of this kernel on this workload over fresh processes
+    (profiles/<round>/frac_range_<workload>.json; the newest round wins): a process allocates its
+    arenas once, and round 5 saw the blur's time move by 15 % with the physical pages it got."""
+    import glob
+    found = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", f"frac_range_{workload}.json")))
+    if not found:
+        return None
+    try:
+        with open(found[-1]) as fid:
+            rec = json.load(fid)
+    except (OSError, ValueError):
+        return None
+    if rec.get("kernel") != kernel:
+        return None
+    return {"min": rec["min"], "max": rec["max"], "n": rec["n"],
+            "source": os.path.relpath(found[-1], ROOT)}
 
 
 def cpu_baseline(cfg):
