@@ -204,7 +204,11 @@ int pano_interior_block(void);
  *                         profiles/r06/ab_level_classes.txt): the classes take 13 % off the
  *                         collapse's HBM traffic and ADD 4 - 7 % to its time - it is bound by its
  *                         memory instructions, which a wave issues while ANY lane needs them,
- *                         not by bytes - so the option is off. */
+ *                         not by bytes - so the option is off.
+ *   PANO_OPT_COMPOSE_COMPACT  pano_multiband_compose with an interior map: 1 = a 64 x 4 tile of the
+ *                         mosaic that holds seam and interior pixels hands the seam pixels to its
+ *                         first threads and the interior ones to its last, so that a wave runs one
+ *                         of the two paths; 0 = a thread keeps its pixel.  Same mosaic bit for bit. */
 typedef struct pano_ctx pano_ctx;
 #define PANO_OPT_BLUR_KERNEL 0
 #define PANO_OPT_OWN_PRUNE 1
@@ -215,7 +219,8 @@ typedef struct pano_ctx pano_ctx;
 #define PANO_OPT_BLUR_SEG_LEN 6
 #define PANO_OPT_SIFT_GRAPH 7
 #define PANO_OPT_LEVEL_CLASSES 8
-#define PANO_OPT_COUNT 9
+#define PANO_OPT_COMPOSE_COMPACT 9
+#define PANO_OPT_COUNT 10
 #define PANO_BLUR_MFMA 0
 #define PANO_BLUR_VALU 1
 int pano_ctx_create(int device, void *stream, pano_ctx **out);
