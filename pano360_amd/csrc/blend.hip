@@ -1008,7 +1008,11 @@ __device__ __forceinline__ int nth_set_bit(unsigned long long m, int n) {
 }
 
 #define COMPOSE_MASKS 4            // 256 records through the wave-wide test, more: plain scan
-template <int L, bool PERCAM>
+// CLS: the gathers follow the pixels' level classes (ia.classes; option PANO_OPT_LEVEL_CLASSES).  A
+// template parameter, not a test of the pointer: with the class a run-time value in every pixel's
+// band loop the kernel was 12 - 20 % slower even where every class is 0 (0.49 -> 0.55 - 0.61 ms on
+// config 3, visits a / e - g of round 6).
+template <int L, bool PERCAM, bool CLS>
 __global__ __launch_bounds__(256) void multiband_compose_kernel(
     const pano_patch *__restrict__ patches, int n, int H, int W, int xs0, int xs1,
     const int16_t *__restrict__ owner, const uint8_t *__restrict__ valid,
@@ -1106,8 +1110,8 @@ __global__ __launch_bounds__(256) void multiband_compose_kernel(
     // owner alone (the interior shortcut's argument, level by level).  Such a pixel needs, of
     // every record, the colour of copy j - 1 and the copies j .. L - 2 - not the copies below,
     // not alpha j - 1, and the warped planes of the owner's record only.
-    const int j = L > 1 && ia.classes ? (int)ia.classes[(size_t)(y / IB) * ia.W8 + x / IB] : 0;
-    const int own_px = j > 0 ? (int)owner[(size_t)y * W + x] : -1;
+    const int j = CLS && L > 1 ? (int)ia.classes[(size_t)(y / IB) * ia.W8 + x / IB] : 0;
+    const int own_px = CLS && j > 0 ? (int)owner[(size_t)y * W + x] : -1;
     float base[3] = {0.0f, 0.0f, 0.0f};          // I - G_{j-1} I of the owner (class j >= 1)
 
     // records in index order (the reference's summation order): the set bits, or all of them
@@ -1130,7 +1134,7 @@ __global__ __launch_bounds__(256) void multiband_compose_kernel(
         const size_t vo = (size_t)(ay + p.ay0 - p.vy0) * p.vpitch + (ax + p.ax0 - p.vx0);
         const size_t aplane = (size_t)p.ah * p.apitch, ao = (size_t)ay * p.apitch + ax;
         float hi[3], ha = 0.0f;                 // the copy that gets the minus
-        if (j == 0) {
+        if (!CLS || j == 0) {
 #pragma unroll
             for (int c = 0; c < 3; ++c) hi[c] = p.planes[c * vplane + vo];
         } else {
@@ -1145,7 +1149,7 @@ __global__ __launch_bounds__(256) void multiband_compose_kernel(
         if (L == 1) ha = owner[(size_t)y * W + x] == p.index ? 1.0f : 0.0f;   // sharp alpha (:208)
 #pragma unroll
         for (int k = 0; k < L; ++k) {
-            if (k < j) continue;                 // telescoped into `base`
+            if (CLS && k < j) continue;          // telescoped into `base`
             float rgb[3], a;
             if (k < L - 1) {
                 const float *b = p.blurred + (size_t)k * 4 * aplane + ao;
@@ -1168,10 +1172,10 @@ __global__ __launch_bounds__(256) void multiband_compose_kernel(
         }
     }
     const bool ok = valid[(size_t)y * W + x] != 0;
-    float out[3] = {ok ? base[0] : 0.0f, ok ? base[1] : 0.0f, ok ? base[2] : 0.0f};
+    float out[3] = {CLS && ok ? base[0] : 0.0f, CLS && ok ? base[1] : 0.0f, CLS && ok ? base[2] : 0.0f};
 #pragma unroll
     for (int k = 0; k < L; ++k) {
-        if (k < j) continue;
+        if (CLS && k < j) continue;
         const float ws = wsum[k] == 0.0f ? 1.0f : wsum[k];                         // :237
 #pragma unroll
         for (int c = 0; c < 3; ++c)
@@ -1555,22 +1559,23 @@ extern "C" int pano_multiband_compose(pano_ctx *ctx, const pano_patch *patches, 
         PANO_LAUNCH_CHECK("compose_interior_kernel");
         return PANO_OK;
     }
+#define COMPOSE_AS(L, PC, CL)                                                            \
+    PANO_TIMED(PK_COMPOSE, s,                                                           \
+               hipLaunchKernelGGL((multiband_compose_kernel<L, PC, CL>), grid, block, 0, s, \
+                                  patches, n, H, W, xs0, xs1, owner, valid, mosaic,     \
+                                  mosaic_f32, ia))
 #define COMPOSE(L)                                                                      \
     case L:                                                                             \
-        if (percam)                                                                     \
-            PANO_TIMED(PK_COMPOSE, s,                                                   \
-                       hipLaunchKernelGGL((multiband_compose_kernel<L, true>), grid,    \
-                                          block, 0, s, patches, n, H, W, xs0, xs1,      \
-                                          owner, valid, mosaic, mosaic_f32, ia));       \
-        else                                                                            \
-            PANO_TIMED(PK_COMPOSE, s,                                                   \
-                       hipLaunchKernelGGL((multiband_compose_kernel<L, false>), grid,   \
-                                          block, 0, s, patches, n, H, W, xs0, xs1,      \
-                                          owner, valid, mosaic, mosaic_f32, ia));       \
+        if (ia.classes && L > 1) {                                                      \
+            if (percam) COMPOSE_AS(L, true, true); else COMPOSE_AS(L, false, true);     \
+        } else {                                                                        \
+            if (percam) COMPOSE_AS(L, true, false); else COMPOSE_AS(L, false, false);   \
+        }                                                                               \
         break;
     switch (n_levels) {
         COMPOSE(1) COMPOSE(2) COMPOSE(3) COMPOSE(4) COMPOSE(5) COMPOSE(6) COMPOSE(7) COMPOSE(8)
     }
+#undef COMPOSE_AS
 #undef COMPOSE
     PANO_LAUNCH_CHECK("multiband_compose_kernel");
     return PANO_OK;
