@@ -202,13 +202,9 @@ int pano_interior_block(void);
  *                         them); 0 (default) = it gathers every copy on every pixel that is not
  *                         interior.  The mosaics agree to float32 rounding.  Measured (round 6,
  *                         profiles/r06/ab_level_classes.txt): the classes take 13 % off the
- *                         collapse's HBM traffic and ADD 4 - 7 % to its time - it is bound by its
+ *                         collapse's HBM traffic and ADD 15 - 19 % to its time - it is bound by its
  *                         memory instructions, which a wave issues while ANY lane needs them,
- *                         not by bytes - so the option is off.
- *   PANO_OPT_COMPOSE_COMPACT  pano_multiband_compose with an interior map: 1 = a 64 x 4 tile of the
- *                         mosaic that holds seam and interior pixels hands the seam pixels to its
- *                         first threads and the interior ones to its last, so that a wave runs one
- *                         of the two paths; 0 = a thread keeps its pixel.  Same mosaic bit for bit. */
+ *                         not by bytes - so the option is off. */
 typedef struct pano_ctx pano_ctx;
 #define PANO_OPT_BLUR_KERNEL 0
 #define PANO_OPT_OWN_PRUNE 1

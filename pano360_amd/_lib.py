@@ -25,7 +25,6 @@ OPT_STITCH_ASYNC = 5
 OPT_BLUR_SEG_LEN = 6
 OPT_SIFT_GRAPH = 7
 OPT_LEVEL_CLASSES = 8
-OPT_COMPOSE_COMPACT = 9
 BLUR_MFMA, BLUR_VALU = 0, 1
 
 

@@ -909,7 +909,6 @@ struct InteriorArgs {
     const float *lut;            // [256], or [n][256] when PERCAM
     int part;                    // 0 every pixel, 2 only the pixels the interior pass left
     const uint8_t *classes;      // [H8][W8] level classes (interior_tile_kernel), NULL = all class 0
-    int compact;                 // multiband_compose_kernel: a mixed tile's pixels sorted by kind
 };
 
 // Where an interior pixel's colour table is read: staged in LDS, or in global memory (the
@@ -989,24 +988,6 @@ __global__ __launch_bounds__(256) void compose_interior_kernel(
         shade_interior_of<LUT>(own, ia.lut, lut_stride, ia, x, y, W, mosaic, mosaic_f32);
 }
 
-// Position of the n-th set bit of m (n < popcount(m)): six halvings.
-__device__ __forceinline__ int nth_set_bit(unsigned long long m, int n) {
-    int pos = 0;
-#pragma unroll
-    for (int s = 32; s >= 1; s >>= 1) {
-        const unsigned long long low = m & ((1ull << s) - 1ull);
-        const int c = __popcll(low);
-        if (n >= c) {
-            n -= c;
-            m >>= s;
-            pos += s;
-        } else {
-            m = low;
-        }
-    }
-    return pos;
-}
-
 #define COMPOSE_MASKS 4            // 256 records through the wave-wide test, more: plain scan
 // CLS: the gathers follow the pixels' level classes (ia.classes; option PANO_OPT_LEVEL_CLASSES).  A
 // template parameter, not a test of the pointer: with the class a run-time value in every pixel's
@@ -1018,55 +999,13 @@ __global__ __launch_bounds__(256) void multiband_compose_kernel(
     const int16_t *__restrict__ owner, const uint8_t *__restrict__ valid,
     uint8_t *__restrict__ mosaic, float *__restrict__ mosaic_f32, InteriorArgs ia) {
     __shared__ float s_lut[256];
-    __shared__ unsigned long long s_kind[2][4];          // [seam, interior][wave]: the tile's pixels by kind
-    int x = xs0 + blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
-    bool inside = x < xs1 && y < H;
-    bool is_interior = inside && ia.interior && ia.interior[(size_t)(y / IB) * ia.W8 + x / IB];
-    // Compaction (ia.compact): a 64 x 4 tile that holds seam AND interior pixels - the tiles along a
-    // band's edges, most of the tiles a band touches - hands its seam pixels to its first threads
-    // and its interior pixels to its last ones, row by row, so that a wave runs ONE of the two paths
-    // (at most one wave of the tile both) instead of all four waves running both, each for a part
-    // of its lanes: a wave's pass through the gathers costs the same for ten lanes as for sixty-four.
-    // Same pixels, same arithmetic per pixel: the mosaic does not change by a bit.
-    const bool compact = ia.compact != 0 && ia.interior != nullptr;                  // uniform
-    if (compact) {
-        const unsigned long long sm = __ballot(inside && !is_interior), im = __ballot(is_interior);
-        if (threadIdx.x == 0) s_kind[0][threadIdx.y] = sm, s_kind[1][threadIdx.y] = im;
+    if (ia.interior && !PERCAM) {
+        s_lut[threadIdx.y * 64 + threadIdx.x] = ia.lut[threadIdx.y * 64 + threadIdx.x];
+        __syncthreads();
     }
-    if (ia.interior && !PERCAM) s_lut[threadIdx.y * 64 + threadIdx.x] = ia.lut[threadIdx.y * 64 + threadIdx.x];
-    if ((ia.interior && !PERCAM) || compact) __syncthreads();
-    bool tile_rows = false;                              // candidate records over the tile's four rows
-    if (compact) {
-        unsigned long long sm[4], im[4];
-        int ns = 0, ni = 0;
-#pragma unroll
-        for (int w = 0; w < 4; ++w) {
-            sm[w] = s_kind[0][w], im[w] = s_kind[1][w];
-            ns += __popcll(sm[w]), ni += __popcll(im[w]);
-        }
-        if (ns != 0 && ni != 0) {                        // a mixed tile (uniform over the workgroup)
-            const int t = threadIdx.y * 64 + threadIdx.x;
-            const bool seam_lane = t < ns, int_lane = t >= 256 - ni;
-            inside = seam_lane || int_lane;
-            is_interior = int_lane;
-            tile_rows = true;
-            if (inside) {
-                int k = seam_lane ? t : t - (256 - ni);
-                int w = 0;
-#pragma unroll
-                for (int q = 0; q < 3; ++q) {
-                    const int c = __popcll(seam_lane ? sm[q] : im[q]);
-                    if (w == q && k >= c) k -= c, w = q + 1;
-                }
-                const unsigned long long mask = seam_lane ? sm[0] : im[0];
-                unsigned long long mw = mask;
-#pragma unroll
-                for (int q = 1; q < 4; ++q) mw = w == q ? (seam_lane ? sm[q] : im[q]) : mw;
-                x = xs0 + blockIdx.x * 64 + nth_set_bit(mw, k);
-                y = blockIdx.y * 4 + w;
-            }
-        }
-    }
+    const int x = xs0 + blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+    const bool inside = x < xs1 && y < H;
+    const bool is_interior = inside && ia.interior && ia.interior[(size_t)(y / IB) * ia.W8 + x / IB];
     // A wave with a seam pixel first finds, with all its lanes (lane l tests record l), the
     // records whose rectangle A meets its 64 pixels of row y: the seam pixels then walk the two
     // or three set bits instead of testing all n records one scalar load at a time.  No
@@ -1075,9 +1014,6 @@ __global__ __launch_bounds__(256) void multiband_compose_kernel(
     const bool masked = n <= 64 * COMPOSE_MASKS && __ballot(inside && !is_interior) != 0;
     if (masked) {
         const int wx0 = xs0 + blockIdx.x * 64, wx1 = min(wx0 + 64, xs1);
-        // (a compacted wave holds pixels of several of the tile's rows: records over any of them)
-        const int ry0 = tile_rows ? (int)blockIdx.y * 4 : (int)(blockIdx.y * 4 + threadIdx.y);
-        const int ry1 = tile_rows ? ry0 + 3 : ry0;
 #pragma unroll
         for (int m = 0; m < COMPOSE_MASKS; ++m) {
             const int i = 64 * m + (int)threadIdx.x;
@@ -1085,7 +1021,7 @@ __global__ __launch_bounds__(256) void multiband_compose_kernel(
             if (i < n) {
                 const pano_patch *q = patches + i;
                 const int ax = q->x0 + q->ax0, ay = q->y0 + q->ay0;
-                hit = ax < wx1 && ax + q->aw > wx0 && ay <= ry1 && ry0 < ay + q->ah;
+                hit = ax < wx1 && ax + q->aw > wx0 && ay <= y && y < ay + q->ah;
             }
             cand[m] = __ballot(hit);
         }
@@ -1542,8 +1478,7 @@ extern "C" int pano_multiband_compose(pano_ctx *ctx, const pano_patch *patches, 
     if (xs0 == xs1) return PANO_OK;
     PANO_REQUIRE(!classes || interior, "pano_multiband_compose: level classes without the interior map");
     InteriorArgs ia = {interior, ceil_div(W, IB), cams, sin_t, cos_t, tan_p, lut, part,
-                       ctx->opt[PANO_OPT_LEVEL_CLASSES] ? classes : nullptr,
-                       ctx->opt[PANO_OPT_COMPOSE_COMPACT]};
+                       ctx->opt[PANO_OPT_LEVEL_CLASSES] ? classes : nullptr};
     const bool percam = interior && lut_stride != 0;
     dim3 block(64, 4), grid(ceil_div(xs1 - xs0, 64), ceil_div(H, 4));
     hipStream_t s = (hipStream_t)stream;

@@ -729,8 +729,6 @@ class Engine:
             self.set_option(_lib.OPT_STITCH_STREAMS, 0)
         if os.environ.get("PANO_STITCH_ASYNC", "0") == "1":         # (A/B timing)
             self.set_option(_lib.OPT_STITCH_ASYNC, 1)
-        if os.environ.get("PANO_COMPOSE_COMPACT"):                  # (A/B: the collapse's tiles sorted by kind)
-            self.set_option(_lib.OPT_COMPOSE_COMPACT, int(os.environ["PANO_COMPOSE_COMPACT"]))
         if os.environ.get("PANO_LEVEL_CLASSES", "0") == "1":        # (A/B: the collapse by level classes)
             self.set_option(_lib.OPT_LEVEL_CLASSES, 1)
         if os.environ.get("PANO_SIFT_GRAPH", "1") == "0":           # (A/B timing: launch by launch)

@@ -908,42 +908,6 @@ def test_collapse_with_level_classes(eng, oracle, levels, kind):
     assert np.abs(m1.cpu().numpy().astype(int) - ref_u8.astype(int)).max() <= 1
 
 
-@pytest.mark.parametrize("levels,equalised", [(5, False), (6, False), (5, True), (1, False)])
-def test_collapse_tiles_sorted_by_kind_change_no_bit(eng, levels, equalised):
-    """PANO_OPT_COMPOSE_COMPACT: a 64 x 4 tile of the mosaic with seam AND interior pixels hands its
-    seam pixels to its first threads and its interior pixels to its last ones (a wave then runs one
-    of the collapse's two paths).  The pixels and their arithmetic are the same: mosaic, float mosaic
-    and valid mask agree bit for bit with the option off - whole mosaic, column strips, per-camera
-    colour tables, one level (no blur at all), and the interior part on its own (part 1 / 2)."""
-    import torch
-    from pano360_amd import _lib, dist as pdist, engine, synth
-    imgs, rots, intrs = synth.make_scene(7, 512, 300, sweep_deg=65.0, jitter=0.012, seed=57, kind="A")
-    shapes = [im.shape[:2] for im in imgs]
-    plan = engine.Plan(shapes, rots, intrs, True, 10 ** 9)
-    frames = eng.upload_frames(imgs)
-    a, b = engine.Engine(eng.device), engine.Engine(eng.device)
-    a.set_option(_lib.OPT_COMPOSE_COMPACT, 0)
-    b.set_option(_lib.OPT_COMPOSE_COMPACT, 1)
-    luts = None
-    if equalised:
-        luts = a.equalize_gains(frames, rots, intrs)[3]
-    m0, f0, v0, _ = a.stitch(frames, plan, "multiband", levels, want_float=True, luts=luts)
-    m1, f1, v1, _ = b.stitch(frames, plan, "multiband", levels, want_float=True, luts=luts)
-    assert torch.equal(m0, m1) and torch.equal(v0, v1)
-    assert torch.equal(f0.view(torch.int32), f1.view(torch.int32))
-    assert int(m0.max()) > 0
-    if levels > 1 and not equalised:
-        s0, _ = pdist.emulate_on_one_device(a, imgs, rots, intrs, levels, 3)
-        s1, _ = pdist.emulate_on_one_device(b, imgs, rots, intrs, levels, 3)
-        assert torch.equal(s0, m0) and torch.equal(s1, m0)
-        # the two-part collapse (interior pixels on the side stream)
-        c = engine.Engine(eng.device, side_stream=1)
-        c.set_option(_lib.OPT_COMPOSE_COMPACT, 1)
-        m2, f2, _, _ = c.stitch(frames, plan, "multiband", levels, want_float=True)
-        torch.cuda.synchronize()
-        assert torch.equal(m2, m0) and torch.equal(f2.view(torch.int32), f0.view(torch.int32))
-
-
 def test_closed_360_sweep_with_seam_straddling_frames(eng, oracle):
     """BASELINE config 5 in miniature: a closed 360 degree sweep.  Frames that
     straddle the +-pi seam get full-width patches (the reference has no
