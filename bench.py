@@ -732,9 +732,13 @@ def cfg4_line(args, world, elapsed, pyr, n_kp, times, size):
                                   "small octaves are a chain of few-workgroup launches)"},
         "kernel_ms_per_step": {k: v[0] / args.steps for k, v in sorted(times.items())},
         "instrumented_ms_per_step": INSTRUMENTED.get("seconds", 0.0) / args.steps * 1e3,
-        "instrumentation": "ms_per_step / value: K steps with no instrumentation inside; "
-                           "kernel_ms_per_step and roofline: the same K steps once more with HIP "
-                           "events around every launch (instrumented_ms_per_step), rank 0",
+        "instrumentation": "ms_per_step / value: K steps with no instrumentation inside, two frames in "
+                           "flight, graph replay; kernel_ms_per_step: the same K steps once more ONE "
+                           "frame at a time, launch by launch, with HIP events around every launch "
+                           "(29 % of overhead on a frame's seventy launches: its kernels' times add up "
+                           "to MORE than ms_per_step and are no evidence for the roofline - that is "
+                           "the step time's; per-kernel durations: profiles/*/cfg4_*_kernel_stats_steady.txt, "
+                           "rocprofv3)",
     }
     if n_kp is not None:
         out["config"]["keypoints_per_frame"] = n_kp
