@@ -1326,6 +1326,34 @@ def test_sift_pipeline_graph_replay_equals_launch_by_launch(eng):
     assert len(kps) == len(want[0][1]) and np.array_equal(kps["x"], want[0][1]["x"])
 
 
+def test_sift_graphs_are_evicted_and_recaptured(eng):
+    """A context keeps at most eight captured launch sequences (least recently used leaves): eleven
+    pipelines of different frame sizes on one engine, each run into its replay, then the first one
+    again - its graph is gone, it runs launch by launch, is captured again and replays - with the
+    same keypoints every time."""
+    import torch
+    from pano360_amd import engine, features, synth
+    use = engine.Engine(eng.device)
+    stream = torch.cuda.Stream(eng.device)
+    sizes = [(96 + 8 * k, 128 + 16 * k) for k in range(11)]
+    with torch.cuda.stream(stream):
+        pipes, first = [], []
+        for h, w in sizes:
+            frame = use.upload_frames([synth.make_frame(h + w, w, h, "B")])[0]
+            pipe = features.SiftPipeline(use, h, w, depth=1, max_keypoints=1 << 12)
+            got = [pipe.detect(frame).result()[0] for _ in range(3)]
+            assert pipe.replaying and len(got[0]) > 0
+            assert all(np.array_equal(g["x"], got[0]["x"]) and np.array_equal(g["octave"], got[0]["octave"])
+                       for g in got[1:])
+            pipes.append((pipe, frame))
+            first.append(got[0])
+        pipe, frame = pipes[0]                      # evicted by the ninth pipeline's graph
+        again = [pipe.detect(frame).result()[0] for _ in range(3)]
+        assert pipe.replaying
+        assert all(np.array_equal(g["x"], first[0]["x"]) for g in again)
+    torch.cuda.synchronize()
+
+
 def test_exhaustive_two_nearest_neighbour_matching(eng):
     """flann_matching (features.py:222-232) as an exact search: every match the ratio
     test keeps equals the brute-force answer; the same frame matched against a shifted
