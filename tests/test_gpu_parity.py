@@ -1326,6 +1326,24 @@ def test_sift_pipeline_graph_replay_equals_launch_by_launch(eng):
     assert len(kps) == len(want[0][1]) and np.array_equal(kps["x"], want[0][1]["x"])
 
 
+@pytest.mark.parametrize("h,w", [(33, 47), (16, 16), (9, 200), (64, 65), (12, 11)])
+def test_sift_native_call_on_small_and_odd_frames(eng, h, w):
+    """``pano_sift_detect`` on frames whose pyramid ends early, whose octaves are odd-sized or
+    narrower than the extrema search's border: the same keypoints as the entry points called one by
+    one (none at all on the smallest), through the eager frame, the captured one and a replay."""
+    from pano360_amd import features, synth
+    frame = eng.upload_frames([synth.make_frame(h * 1000 + w, w, h, "B")])[0]
+    pyr = features.sift_pyramid_device(frame, eng=eng)
+    want, _ = features.sift_detect_async(frame, pyramid=pyr, eng=eng).result()
+    pipe = features.SiftPipeline(eng, h, w, depth=1, max_keypoints=1 << 12)
+    for _ in range(3):
+        det = pipe.detect(frame)
+        got, desc = det.result()
+        assert len(got) == len(want) and desc.shape == (len(want), 128)
+        assert np.array_equal(got["x"], want["x"]) and np.array_equal(got["octave"], want["octave"])
+        assert all(a.shape == b.shape for a, b in zip(det.pyramid[0], pyr[0]))
+
+
 def test_sift_graphs_are_evicted_and_recaptured(eng):
     """A context keeps at most eight captured launch sequences (least recently used leaves): eleven
     pipelines of different frame sizes on one engine, each run into its replay, then the first one
