@@ -144,6 +144,9 @@ def emit(full, workload=None, world=1):
     except OSError as err:                       # a read-only tree: the line still goes out
         print(f"bench.py: side file not written: {err}", file=sys.stderr)
         path = None
+    if os.environ.get("PANO_BENCH_FULL_LINE") == "1":   # (tools/ab_*.sh: the whole record as the line)
+        print(json.dumps(full), flush=True)
+        return
     print(compact_line(full, path), flush=True)
 
 

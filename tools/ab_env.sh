@@ -1,5 +1,6 @@
 #!/bin/bash
 # A/B of an environment switch on a bench workload, alternating: tools/ab_env.sh WORKLOAD REPS VAR VALUE_A VALUE_B
+export PANO_BENCH_FULL_LINE=1   # the whole record on stdout (bench.py prints a compact line otherwise)
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 WL=$1; REPS=$2; VAR=$3; shift; shift; shift
 for r in $(seq "$REPS"); do

@@ -1,6 +1,7 @@
 #!/bin/bash
 # A/B of library builds on a bench workload, alternating, REPS rounds of 20 stitches each:
 #   tools/ab_libs.sh WORKLOAD REPS NAME1 NAME2 ...     (NAME = base | a build/variants/ name)
+export PANO_BENCH_FULL_LINE=1   # the whole record on stdout (bench.py prints a compact line otherwise)
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 WL=$1; REPS=$2; shift; shift
 mkdir -p gpurun_out/ab; LOG=gpurun_out/ab/log_$WL.txt; : > "$LOG"
@@ -10,7 +11,7 @@ for r in $(seq "$REPS"); do
     PANO_LIB=$LIB timeout -k 10 300 python bench.py --workload "$WL" --steps 20 --warmup 3 --no-cpu-baseline --no-secondary 2>gpurun_out/ab/err_$v.txt | python -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1]); k=d['kernel_ms_per_step']
-print('$v', d['ms_per_step'], k.get('blur_mfma_kernel', 0) + k.get('blur_lean_kernel', 0) + k.get('blur_lean5_kernel', 0), k.get('blur_irregular_kernel', 0), k.get('multiband_compose_kernel', 0), k.get('warp_windows_kernel', 0), k.get('ownership_cameras_kernel', 0), k.get('owned_boxes_kernel', 0) + k.get('owned_spans_kernel', 0), d.get('ms_per_stitch_one_in_flight') or 0)" >> "$LOG" || echo "$v FAILED" >> "$LOG"
+print('$v', d['ms_per_step'], k.get('blur_mfma_kernel', 0) + k.get('blur_lean_kernel', 0) + k.get('blur_lean5_kernel', 0), 0.0, k.get('multiband_compose_kernel', 0), k.get('warp_windows_kernel', 0), k.get('ownership_cameras_kernel', 0), k.get('owned_boxes_kernel', 0) + k.get('owned_spans_kernel', 0), d.get('ms_per_stitch_one_in_flight') or 0)" >> "$LOG" || echo "$v FAILED" >> "$LOG"
   done
 done
 python - "$LOG" <<'P'

@@ -1,6 +1,7 @@
 #!/bin/bash
 # fast loop: the GPU parity tests (optionally -k filter), then one cfg3 bench line
 set -u
+export PANO_BENCH_FULL_LINE=1   # the whole record on stdout (bench.py prints a compact line otherwise)
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 OUT=gpurun_out/${1:-q}
 mkdir -p "$OUT"

@@ -3,6 +3,7 @@
 # Everything lands in gpurun_out/<tag>/ (merged back into the repo by gpurun).
 #   tools/gpu_round.sh <tag> [quick]
 set -u
+export PANO_BENCH_FULL_LINE=1   # the whole record on stdout (bench.py prints a compact line otherwise)
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 OUT=gpurun_out/${1:-r03}
 MODE=${2:-full}
