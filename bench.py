@@ -112,6 +112,10 @@ def compact_line(full, side_file=None):
             k: (_num(v["ms_per_step"], 4) if isinstance(v, dict) and "ms_per_step" in v
                 else _short(v.get("error", "?") if isinstance(v, dict) else v, 80))
             for k, v in sec.items()}
+        # ... and their dominant kernels' roofline fractions
+        out["secondary_frac"] = {
+            k: _num(v["roofline"]["frac"], 3) for k, v in sec.items()
+            if isinstance(v, dict) and isinstance(v.get("roofline"), dict) and "frac" in v["roofline"]}
     for k in ("fallback", "strips_error", "secondary_error", "scaling_note"):
         if k in full:
             out[k] = _short(full[k], 200)
@@ -119,7 +123,7 @@ def compact_line(full, side_file=None):
         out["side_file"] = os.path.relpath(side_file, ROOT)
     line = json.dumps(out)
     # never over the limit: shed the optional parts, largest first
-    for drop in ("secondary_ms", "roofline_by_kernel", "alt_settings", "comm"):
+    for drop in ("secondary_frac", "secondary_ms", "roofline_by_kernel", "alt_settings", "comm"):
         if len(line) < COMPACT_LIMIT:
             break
         out.pop(drop, None)
