@@ -721,8 +721,10 @@ def cfg4_line(args, world, elapsed, pyr, n_kp, times, size):
         "data": "synthetic",
         # (missing 3) what this workload's results are checked against
         "parity": "unpinned: cv2's SIFT is not in /root/reference and no OpenCV is installed; the "
-                  "scale space, keypoints and descriptors are checked against this repo's own NumPy "
-                  "restatement of OpenCV's algorithm (oracle/sift_pyramid.py, sift_oracle.py) only",
+                  "scale space is checked against this repo's NumPy restatement of OpenCV's algorithm "
+                  "(oracle/sift_pyramid.py, itself cross-checked against SciPy / torch / Pillow: "
+                  "tests/test_oracle_golden.py), keypoints and descriptors against oracle/sift_oracle.py "
+                  "only (no independent implementation installed)",
         "settings": {"frames_in_flight": max(1, int(os.environ.get("PANO_CFG4_STREAMS", "2"))),
                      "detect": bool(args.detect),
                      # one native call per frame, replayed as a HIP graph (pano_sift_detect)

@@ -14,6 +14,15 @@ first octave -1):
   buildDoGPyramid    : differences of neighbouring layers
 
 It checks ``pano360_amd.features.sift_pyramid`` (HIP) in tests/.
+
+Third-party cross-checks of THIS file (tests/test_oracle_golden.py, round 6; implementations
+not written for this repo): ``gray_u8`` within one level of Pillow's 'L' conversion (and BGR, not
+RGB); ``resize_up2`` = scipy.ndimage.zoom(order=1, grid_mode=True, mode='nearest') = torch's
+bilinear interpolate(align_corners=False) to 1e-4 of 255; ``decimate2`` = torch's nearest
+interpolate, exactly; every Gaussian layer = scipy's correlate1d with float64 taps of the
+aperture rule, 'mirror' borders, the sigma schedule recomputed, to 2e-4; layer i = ONE Gaussian
+of total sigma 1.6 * 2^(i/3) on the doubled image (the schedule's defining property) to 0.05.
+The keypoint / descriptor stages (oracle/sift_oracle.py) have no such counterpart installed.
 """
 import numpy as np
 

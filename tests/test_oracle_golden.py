@@ -395,3 +395,103 @@ def test_shim_pyr_down_against_scipy_correlate1d(shape):
     assert got.shape == want.shape
     if min(shape) > 2:                          # (one reflection: what both definitions share)
         assert np.abs(got - want).max() <= 1e-6
+
+
+# ---- the SIFT scale space's restatement (oracle/sift_pyramid.py) against third parties -------------
+# OpenCV's SIFT is not pinned by the reference and not installed: the keypoint and descriptor
+# stages stay unpinned.  The SCALE SPACE, though, is made of operations that libraries not written
+# for this repo implement too - a grey conversion (Pillow), a 2 x bilinear resize (SciPy, torch), a
+# nearest-neighbour decimation (torch), separable Gaussian filters (SciPy) - and of a sigma schedule
+# whose defining property can be checked directly (layer i of an octave has the total sigma
+# 1.6 * 2^(i/3) of the octave's base resolution).
+def test_sift_grey_conversion_against_pillow():
+    """cv2.cvtColor(BGR2GRAY) on uint8: 14-bit fixed-point Rec. 601 weights on B, G, R in that
+    order.  Pillow's 'L' conversion uses the same weights in 16-bit fixed point: within one level,
+    and the channel order is BGR (swapping R and B moves it by tens of levels)."""
+    import sift_pyramid as sp
+    from PIL import Image
+    rng = np.random.default_rng(21)
+    bgr = rng.integers(0, 256, (64, 80, 3), dtype=np.uint8)
+    got = sp.gray_u8(bgr)
+    want = np.asarray(Image.fromarray(bgr[..., ::-1].copy(), "RGB").convert("L"), np.float32)
+    assert np.abs(got - want).max() <= 1.0
+    assert np.abs(sp.gray_u8(bgr[..., ::-1]) - want).max() > 20.0
+
+
+@pytest.mark.parametrize("shape", [(31, 45), (64, 64), (9, 120)])
+def test_sift_upsampling_against_scipy_zoom_and_torch_interpolate(shape):
+    """resize(img, (2w, 2h), INTER_LINEAR): output pixel i samples the input at (i + 0.5) / 2 - 0.5,
+    clamped at the borders = scipy.ndimage.zoom(order=1, grid_mode=True, mode='nearest') =
+    torch's interpolate(mode='bilinear', align_corners=False)."""
+    import sift_pyramid as sp
+    import torch
+    from scipy import ndimage
+    rng = np.random.default_rng(22)
+    img = (_smooth_image(rng, *shape) * 255).astype(np.float32)
+    got = sp.resize_up2(img)
+    assert got.shape == (2 * shape[0], 2 * shape[1])
+    want = ndimage.zoom(img.astype(np.float64), 2, order=1, mode="nearest", grid_mode=True)
+    assert np.abs(got - want).max() <= 1e-4                     # values up to 255
+    want_t = torch.nn.functional.interpolate(torch.from_numpy(img.astype(np.float64))[None, None],
+                                             scale_factor=2, mode="bilinear", align_corners=False)[0, 0]
+    assert np.abs(got - want_t.numpy()).max() <= 1e-4
+
+
+@pytest.mark.parametrize("shape", [(64, 48), (37, 53), (5, 121)])
+def test_sift_decimation_against_torch_nearest(shape):
+    """resize(img, (w // 2, h // 2), INTER_NEAREST): source index floor(dst * src / dst_size) =
+    torch's interpolate(mode='nearest')."""
+    import sift_pyramid as sp
+    import torch
+    rng = np.random.default_rng(23)
+    img = rng.random(shape).astype(np.float32)
+    got = sp.decimate2(img)
+    want = torch.nn.functional.interpolate(torch.from_numpy(img)[None, None],
+                                           size=(shape[0] // 2, shape[1] // 2), mode="nearest")[0, 0].numpy()
+    assert np.array_equal(got, want)
+
+
+def test_sift_scale_space_layers_against_scipy():
+    """Every Gaussian layer of the restated scale space against SciPy: layer i = the previous layer
+    filtered with the float64 taps of cv2.GaussianBlur's rule (aperture cvRound(8 sigma + 1) | 1,
+    REFLECT_101 = 'mirror'), the sigmas from buildGaussianPyramid's schedule recomputed here; the
+    next octave's base = every second pixel of layer 3; DoG = differences.  Then the schedule's
+    defining property: layer i has the TOTAL sigma 1.6 * 2^(i/3) - it agrees with ONE wide Gaussian
+    of that sigma (scipy.ndimage.gaussian_filter, truncated far out) applied to the doubled grey
+    image of nominal sigma 1.0, away from the border and up to what the 4-sigma apertures cut off."""
+    import sift_pyramid as sp
+    from scipy import ndimage
+    rng = np.random.default_rng(24)
+    bgr = (np.stack([_smooth_image(rng, 96, 128) for _ in range(3)], axis=-1) * 255).astype(np.uint8)
+    gauss, dog = sp.sift_pyramid(bgr)
+    assert len(gauss) == sp.n_octaves(96, 128) == 7 and all(len(o) == 6 for o in gauss)
+
+    def blur64(img, sigma):
+        ksize = int(round(sigma * 8 + 1)) | 1
+        x = np.arange(ksize, dtype=np.float64) - (ksize - 1) / 2
+        taps = np.exp(-x * x / (2 * sigma * sigma))
+        taps /= taps.sum()
+        out = ndimage.correlate1d(img, taps, axis=1, mode="mirror")
+        return ndimage.correlate1d(out, taps, axis=0, mode="mirror")
+    k = 2.0 ** (1.0 / 3)
+    total = [1.6 * k ** i for i in range(6)]
+    steps = [np.sqrt(1.6 ** 2 - 1.0)] + [np.sqrt(total[i] ** 2 - total[i - 1] ** 2) for i in range(1, 6)]
+    assert np.allclose(steps[1:], sp.sigmas()[1:], rtol=1e-12)
+    base = ndimage.zoom(sp.gray_u8(bgr).astype(np.float64), 2, order=1, mode="nearest", grid_mode=True)
+    prev = blur64(base, steps[0])
+    for o in range(3):                                   # (the small octaves reflect more than once)
+        if o:
+            prev = np.asarray(gauss[o - 1][3], np.float64)[::2, ::2]
+            assert np.array_equal(gauss[o][0], gauss[o - 1][3][::2, ::2])
+        assert np.abs(gauss[o][0] - prev).max() <= 2e-4
+        for i in range(1, 6):
+            want = blur64(np.asarray(gauss[o][i - 1], np.float64), steps[i])
+            assert np.abs(gauss[o][i] - want).max() <= 2e-4, (o, i)
+            assert np.array_equal(dog[o][i - 1], gauss[o][i] - gauss[o][i - 1])
+    # total sigmas of the first octave: one wide Gaussian on the doubled image (nominal sigma 1.0)
+    for i in range(6):
+        wide = ndimage.gaussian_filter(base, np.sqrt(total[i] ** 2 - 1.0), mode="mirror", truncate=8.0)
+        err = np.abs(np.asarray(gauss[0][i], np.float64) - wide)[24:-24, 24:-24].max()
+        assert err <= 0.05, (i, err)                     # of 255: the chained 4-sigma apertures' tails
+    # ... and across octaves: layer 3 has twice the base sigma, so the next octave starts at 1.6 again
+    assert abs(total[3] - 3.2) < 1e-12
