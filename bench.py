@@ -724,7 +724,8 @@ def cfg4_line(args, world, elapsed, pyr, n_kp, times, size):
                   "scale space is checked against this repo's NumPy restatement of OpenCV's algorithm "
                   "(oracle/sift_pyramid.py, itself cross-checked against SciPy / torch / Pillow: "
                   "tests/test_oracle_golden.py), keypoints and descriptors against oracle/sift_oracle.py "
-                  "only (no independent implementation installed)",
+                  "and against known answers (blob positions and scales in closed form, a ramp's "
+                  "direction, a quarter turn); no independent SIFT is installed",
         "settings": {"frames_in_flight": max(1, int(os.environ.get("PANO_CFG4_STREAMS", "2"))),
                      "detect": bool(args.detect),
                      # one native call per frame, replayed as a HIP graph (pano_sift_detect)

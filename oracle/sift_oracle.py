@@ -24,6 +24,15 @@ defaults the reference uses (nfeatures 0, 3 octave layers, contrast threshold
 libm one (OpenCV's table-driven ``exp32f`` agrees to ~1e-7).  Everything is
 float32 where OpenCV computes in float.  It checks ``pano360_amd.features``
 (HIP) in tests/; loops are plain Python, so keep images small.
+
+Known answers (round 6; tests/test_oracle_golden.py::test_sift_oracle_known_answers, and the same
+checks on the HIP kernels: tests/test_gpu_parity.py::test_sift_kernels_known_answers) - what can be
+known about the keypoint stages without OpenCV: a Gaussian blob of standard deviation s is found at
+its centre (+ 0.25 px on both axes: the doubled first octave's pixel-centre alignment) with
+size / 2 = s / sqrt(k), k = 2^(1/3) - the closed-form maximum over scale of the difference of
+Gaussians, labelled with the lower scale of the pair; a weak blob on a strong linear ramp gets the
+ramp's direction as its angle (to 4 degrees: 36 bins + the parabola); a quarter turn of the image
+turns the keypoints and leaves their descriptors alone (median distance 0 of norm 512).
 """
 import numpy as np
 

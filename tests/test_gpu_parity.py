@@ -1344,6 +1344,26 @@ def test_sift_native_call_on_small_and_odd_frames(eng, h, w):
         assert all(a.shape == b.shape for a, b in zip(det.pyramid[0], pyr[0]))
 
 
+def test_sift_kernels_known_answers(eng):
+    """The HIP detector (``features.sift_detect_device``: scale space, extrema, orientations,
+    descriptors) against what is known without OpenCV or any restatement of it - the checks of
+    tests/test_oracle_golden.py, where the oracle passes them too: Gaussian blobs are found at their
+    centres (+ 0.25 px: the doubled first octave) with size / 2 = s / sqrt(k), the closed-form
+    maximum of the difference of Gaussians in scale; a weak blob on a strong linear ramp gets the
+    ramp's direction as its angle; a quarter turn of the image turns the keypoints and leaves their
+    descriptors alone."""
+    from test_oracle_golden import (SIFT_BLOBS, _blob_scene, check_blob_keypoints, check_ramp_orientation,
+                                    check_rot90)
+    from pano360_amd import features
+
+    def detect(bgr, with_desc=False):
+        kps, desc = features.sift_detect_device(eng.upload_frames([np.ascontiguousarray(bgr)])[0], eng=eng)
+        return (kps, desc.cpu().numpy()) if with_desc else kps
+    check_blob_keypoints(detect(_blob_scene(SIFT_BLOBS)))
+    check_ramp_orientation(detect)
+    check_rot90(detect)
+
+
 def test_sift_graphs_are_evicted_and_recaptured(eng):
     """A context keeps at most eight captured launch sequences (least recently used leaves): eleven
     pipelines of different frame sizes on one engine, each run into its replay, then the first one

@@ -495,3 +495,92 @@ def test_sift_scale_space_layers_against_scipy():
         assert err <= 0.05, (i, err)                     # of 255: the chained 4-sigma apertures' tails
     # ... and across octaves: layer 3 has twice the base sigma, so the next octave starts at 1.6 again
     assert abs(total[3] - 3.2) < 1e-12
+
+
+# ---- known answers for the keypoint stages (no third-party SIFT is installed) ---------------------
+def _blob_scene(blobs, size=128, ramp=0.0, phi_deg=0.0, base=128.0):
+    """uint8 BGR image (three equal channels): Gaussian blobs (cx, cy, std, amplitude) on a linear
+    ramp of `ramp` levels per pixel along the direction phi (image coordinates, y down)."""
+    yy, xx = np.mgrid[:size, :size].astype(np.float64)
+    img = np.full((size, size), base)
+    for cx, cy, s, a in blobs:
+        img += a * np.exp(-((xx - cx) ** 2 + (yy - cy) ** 2) / (2 * s * s))
+    p = np.deg2rad(phi_deg)
+    img += ramp * ((xx - size / 2) * np.cos(p) + (yy - size / 2) * np.sin(p))
+    u8 = np.clip(np.rint(img), 0, 255).astype(np.uint8)
+    return np.stack([u8] * 3, axis=-1)
+
+
+SIFT_BLOBS = [(40.3, 38.7, 3.0, +90.0), (88.6, 40.2, 5.0, -90.0), (64.0, 92.5, 8.0, +90.0)]
+SIFT_K = 2.0 ** (1.0 / 3.0)
+
+
+def check_blob_keypoints(kps, blobs=SIFT_BLOBS):
+    """A Gaussian blob of standard deviation s is, at scale sigma, a Gaussian of variance s^2 +
+    sigma^2 and amplitude ~ s^2 / (s^2 + sigma^2); the difference of the scales k sigma and sigma is
+    extremal where d/dv [1 / (s^2 + k^2 v) - 1 / (s^2 + v)] = 0, v = sigma^2, i.e. at
+    sigma* = s / sqrt(k) - and SIFT labels the extremum with the LOWER scale of the pair, so the
+    keypoint's size / 2 is s / sqrt(k) = 0.891 s (k = 2^(1/3); a little less for small s: the
+    image's nominal blur of 0.5 px).  Its position is the blob's centre + 0.25 px on both axes:
+    OpenCV doubles the image with pixel-CENTRE alignment and halves the coordinates afterwards."""
+    for cx, cy, s, _ in blobs:
+        best = min(kps, key=lambda k: (float(k["x"]) - cx - 0.25) ** 2 + (float(k["y"]) - cy - 0.25) ** 2)
+        assert abs(float(best["x"]) - cx - 0.25) <= 0.06 and abs(float(best["y"]) - cy - 0.25) <= 0.06, (cx, cy)
+        ratio = float(best["size"]) / 2.0 / s
+        assert 0.98 / np.sqrt(SIFT_K) <= ratio <= 1.005 / np.sqrt(SIFT_K), (s, ratio)
+
+
+def check_ramp_orientation(detect):
+    """One weak blob (so that there IS an extremum) on a strong linear ramp: the gradient field around
+    the keypoint is the ramp's constant gradient plus the blob's radial one, which cancels over the
+    orientation window - the keypoint's angle is the ramp's direction (OpenCV's angle runs clockwise
+    on the screen, y down: 360 - atan2(up - down, right - left))."""
+    for phi in (30.0, 135.0, 250.0, 0.0, 90.0):
+        kps = detect(_blob_scene([(64.0, 60.0, 8.0, 30.0)], ramp=1.0, phi_deg=phi))
+        near = [k for k in kps if (float(k["x"]) - 64.25) ** 2 + (float(k["y"]) - 60.25) ** 2 < 0.25]
+        assert len(near) == 1, (phi, len(near))
+        diff = abs((float(near[0]["angle"]) - phi + 180.0) % 360.0 - 180.0)
+        assert diff <= 4.0, (phi, float(near[0]["angle"]))
+
+
+def check_rot90(detect, seed=5, size=96):
+    """Turning the image by 90 degrees turns the keypoints with it and leaves the descriptors alone
+    (each is computed in its keypoint's own frame).  The detector's + 0.25 px offset does not turn:
+    positions agree to 0.8 px."""
+    from scipy import ndimage
+    rng = np.random.default_rng(seed)
+    base = ndimage.gaussian_filter(rng.random((size, size)), 2.0)
+    base = ((base - base.min()) / (base.max() - base.min()) * 255).astype(np.uint8)
+    k0, d0 = detect(np.stack([base] * 3, -1), True)
+    turned = np.rot90(base).copy()                       # new[i, j] = old[j, W - 1 - i]
+    k1, d1 = detect(np.stack([turned] * 3, -1), True)
+    assert len(k0) > 100 and abs(len(k0) - len(k1)) <= 0.1 * len(k0)
+    dist, dang = [], []
+    for i, k in enumerate(k0):
+        xp, yp = float(k["y"]), size - 1 - float(k["x"])
+        js = [j for j, q in enumerate(k1)
+              if (float(q["x"]) - xp) ** 2 + (float(q["y"]) - yp) ** 2 < 0.64
+              and abs(float(q["size"]) - float(k["size"])) < 0.2 * float(k["size"])]
+        if js:
+            dist.append(min(float(np.linalg.norm(d0[i] - d1[j])) for j in js))
+            dang.append(min(abs((float(k1[j]["angle"]) - (float(k["angle"]) - 90.0) + 180.0) % 360.0 - 180.0)
+                            for j in js))
+    assert len(dist) >= 0.9 * len(k0)
+    assert np.median(dist) <= 10.0 and np.percentile(dist, 90) <= 110.0      # descriptors have norm 512
+    assert np.median(dang) <= 0.5
+
+
+def _oracle_detect(bgr, with_desc=False):
+    import sift_oracle as so
+    import sift_pyramid as sp
+    gauss, dog = sp.sift_pyramid(bgr)
+    kps, des = so.detect_and_compute(gauss, dog)
+    return (kps, des) if with_desc else kps
+
+
+def test_sift_oracle_known_answers():
+    """The keypoint stages' restatement (oracle/sift_oracle.py) against what can be known without
+    OpenCV: blobs' positions and scales in closed form, a ramp's direction, a quarter turn."""
+    check_blob_keypoints(_oracle_detect(_blob_scene(SIFT_BLOBS)))
+    check_ramp_orientation(_oracle_detect)
+    check_rot90(_oracle_detect)
