@@ -21,6 +21,15 @@ NumPy itself (stitcher.py:73-157, 160-327, 340-369) is exercised for real.
 Written vectorised NumPy, float32 arithmetic with one rounding per operation
 (no FMA), so that the independent C restatement in ``pano_oracle.c`` can be
 checked against it bit for bit.
+
+Third-party cross-checks of this file (tests/test_oracle_golden.py; implementations not
+written for this repo): ``remap`` = scipy.ndimage.map_coordinates(order=1, mode='reflect') =
+torch's grid_sample; ``GaussianBlur`` and ``pyrDown`` = scipy's correlate1d ('mirror'); round 6:
+``resize`` within one level of scipy.ndimage.zoom(order=1, grid_mode=True) and torch's bilinear
+interpolate, its 2 : 1 case = torch's avg_pool2d; ``warpPerspective`` = map_coordinates at
+M^-1 (x, y, 1); ``pyrUp`` = zero-stuffing + correlate1d([1 4 6 4 1] / 8) away from the borders.
+They pin interpolation conventions, apertures, border rules and separability - not OpenCV's
+bit-level rounding, which stays as documented here.
 """
 import numpy as np
 

@@ -584,3 +584,94 @@ def test_sift_oracle_known_answers():
     check_blob_keypoints(_oracle_detect(_blob_scene(SIFT_BLOBS)))
     check_ramp_orientation(_oracle_detect)
     check_rot90(_oracle_detect)
+
+
+# ---- the remaining restated OpenCV calls against third parties (round 6) ---------------------------
+@pytest.mark.parametrize("shrink", [1.5, 2.5, 3.0, 4.0])
+def test_shim_resize_against_scipy_zoom_and_torch(shrink):
+    """cv2.resize(img, None, fx=1/shrink, fy=1/shrink) on uint8 (stitcher.py:419-420): bilinear at
+    source coordinate (d + 0.5) * shrink - 0.5, no antialiasing, 11-bit fixed-point coefficients:
+    within one level of the float bilinear of scipy.ndimage.zoom(order=1, grid_mode=True) and of
+    torch's interpolate(bilinear, align_corners=False) at the same output size."""
+    import cv2_shim as cv
+    import torch
+    from scipy import ndimage
+    rng = np.random.default_rng(31)
+    h, w = int(36 * shrink), int(50 * shrink)            # sizes the factor divides: every check runs
+    img = (_smooth_image(rng, h, w, 3) * 255).astype(np.uint8)
+    got = cv.resize(img, None, fx=1 / shrink, fy=1 / shrink).astype(np.float64)
+    assert got.shape[:2] == (36, 50)
+    t = torch.from_numpy(img.astype(np.float64)).permute(2, 0, 1)[None]
+    want_t = torch.nn.functional.interpolate(t, size=(36, 50), mode="bilinear", align_corners=False)
+    assert np.abs(got - want_t[0].permute(1, 2, 0).numpy()).max() <= 1.0
+    want = np.stack([ndimage.zoom(img[..., c].astype(np.float64), 1 / shrink, order=1, mode="nearest",
+                                  grid_mode=True) for c in range(3)], axis=-1)
+    assert want.shape == got.shape and np.abs(got - want).max() <= 1.0
+    # (and the two third parties agree with each other far below a level)
+    assert np.abs(want - want_t[0].permute(1, 2, 0).numpy()).max() <= 1e-6
+
+
+def test_shim_resize_half_is_the_area_mean_of_torch():
+    """An exact 2 : 1 reduction goes through OpenCV's area path: rounded 2 x 2 box means =
+    torch's avg_pool2d, rounded half up."""
+    import cv2_shim as cv
+    import torch
+    rng = np.random.default_rng(32)
+    img = rng.integers(0, 256, (40, 56, 3), dtype=np.uint8)
+    got = cv.resize(img, None, fx=0.5, fy=0.5)
+    mean = torch.nn.functional.avg_pool2d(torch.from_numpy(img.astype(np.float64)).permute(2, 0, 1)[None], 2)
+    want = np.floor(mean[0].permute(1, 2, 0).numpy() + 0.5)
+    assert np.array_equal(got, want.astype(np.uint8))
+
+
+def test_shim_warp_perspective_against_scipy_map_coordinates():
+    """cv2.warpPerspective(INTER_LINEAR, BORDER_TRANSPARENT) (stitcher.py:56-57): destination pixel
+    (x, y) samples the source at M^-1 (x, y, 1), bilinear, and is written only when all four taps
+    lie inside the source.  With a matrix whose inverse lands on the 1 / 32-pixel grid (a shift by
+    multiples of 1/32 and a scale of 1/2) the fixed-point coordinates are exact: equal to SciPy's
+    map_coordinates(order=1) to 1e-6 where written, zeros elsewhere; with a general homography the
+    coordinates are rounded to 1/32 px: within the image's gradient times that step."""
+    import cv2_shim as cv
+    from scipy import ndimage
+    rng = np.random.default_rng(33)
+    h, w = 60, 84
+    src = _smooth_image(rng, h, w, 4)
+    gy, gx = np.gradient(src.astype(np.float64), axis=(0, 1))
+    slope = float(np.sqrt(gx ** 2 + gy ** 2).max())
+    for M, exact in ((np.array([[2.0, 0, 7.0 / 16], [0, 2.0, -5.0 / 16], [0, 0, 1.0]]), True),
+                     (np.array([[0.95, 0.08, 3.3], [-0.06, 1.04, -2.1], [2e-4, -1e-4, 1.0]]), False)):
+        dsize = (100, 72)
+        got = cv.warpPerspective(src, M, dsize, flags=cv.INTER_LINEAR, borderMode=cv.BORDER_TRANSPARENT)
+        inv = np.linalg.inv(M)
+        ys, xs = np.mgrid[:dsize[1], :dsize[0]].astype(np.float64)
+        den = inv[2, 0] * xs + inv[2, 1] * ys + inv[2, 2]
+        sx = (inv[0, 0] * xs + inv[0, 1] * ys + inv[0, 2]) / den
+        sy = (inv[1, 0] * xs + inv[1, 1] * ys + inv[1, 2]) / den
+        inside = (sx >= 0) & (sx < w - 1) & (sy >= 0) & (sy < h - 1)
+        edge = (np.abs(sx) < 0.05) | (np.abs(sx - (w - 1)) < 0.05) | (np.abs(sy) < 0.05) | \
+               (np.abs(sy - (h - 1)) < 0.05)           # (a rounded coordinate may fall on the other side)
+        for ch in range(4):
+            want = ndimage.map_coordinates(src[..., ch].astype(np.float64), [sy, sx], order=1,
+                                           mode="constant", cval=0.0)
+            tol = 1e-6 if exact else slope * (np.sqrt(2.0) / 64) + 1e-6
+            ok = inside & ~edge
+            assert np.abs(got[..., ch][ok] - want[ok]).max() <= tol, (exact, ch)
+        assert np.all(got[~inside & ~edge] == 0)
+        assert inside.mean() > 0.3
+
+
+def test_shim_pyr_up_against_scipy():
+    """cv2.pyrUp (blend.py:127-134): the source zero-stuffed to twice its size and filtered with
+    [1 4 6 4 1] / 8 per axis - away from the borders (whose closed forms are OpenCV's own) equal to
+    SciPy's correlate1d on the zero-stuffed image."""
+    import cv2_shim as cv
+    from scipy import ndimage
+    rng = np.random.default_rng(34)
+    img = _smooth_image(rng, 33, 47)
+    got = cv.pyrUp(img)
+    stuffed = np.zeros((66, 94))
+    stuffed[0::2, 0::2] = img
+    taps = np.array([1, 4, 6, 4, 1], np.float64) / 8
+    want = ndimage.correlate1d(ndimage.correlate1d(stuffed, taps, axis=1, mode="constant"), taps, axis=0,
+                               mode="constant")
+    assert np.abs(got[2:-2, 2:-2] - want[2:-2, 2:-2]).max() <= 1e-6
