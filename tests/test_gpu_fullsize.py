@@ -805,3 +805,79 @@ def test_sift_sort_unique_on_device_equals_the_host_lexsort(eng, n):
         got_sub = out[:len(sub) * 32].cpu().numpy().view(features.KP_DTYPE)
         assert np.array_equal(got_sub["angle"], sub["angle"])
         assert np.array_equal(got_sub["y"], sub["y"] * np.float32(0.5))
+
+
+def _analytic_texture(theta, phi, ch):
+    """A smooth panorama in closed form, one of three channels: values in [0.15, 0.85], features of
+    0.1 - 0.3 rad (hundreds of pixels at 4K)."""
+    import torch
+    a, b, c, d, p = [(41.0, 17.0, 23.0, 31.0, 0.3), (29.0, 23.0, 37.0, 19.0, 1.1),
+                     (35.0, 13.0, 27.0, 43.0, 2.0)][ch]
+    return 0.5 + 0.2 * torch.sin(a * theta + p) * torch.cos(b * phi) + 0.15 * torch.cos(c * theta - d * phi)
+
+
+@pytest.mark.parametrize("name,jitter", [("cfg3", 0.0), ("cfg3", 0.01), ("cfg5", 0.0)])
+def test_analytic_panorama_is_reproduced_everywhere(eng, name, jitter):
+    """A known answer for the WHOLE mosaic of config 3 (all 31 seams from top to bottom; pure-yaw and
+    jittered rig) and of config 5 (120 x 8K, the closed sweep: T is 2 pi-periodic): the frames are
+    renderings of one analytic panorama T(theta, phi) - pixel (u, v) of camera i looks along
+    R_i^T K^-1 (u - w/2, v - h/2, 1), the reference's conventions (bundle_adj.py:28-29,
+    stitcher.py:119, 310) - so every patch agrees with every other on their overlaps and the
+    multiband mosaic must be T itself at (theta_x, phi_y) = (x, y) * resolution + low
+    (stitcher.py:301-302), whatever the ownership, the seams and the levels do: within two uint8
+    levels (the frames' own quantisation, one truncation) on every valid pixel farther than the
+    largest blur radius from the border of the covered area (there the blend mixes in
+    BORDER_REFLECT content by design).  No oracle, no restatement: geometry and blend against
+    ground truth, pure-yaw and jittered rig."""
+    import torch
+    from pano360_amd import engine, synth
+    cfg = synth.CONFIGS[name]
+    n, w, h, levels = cfg["n"], cfg["width"], cfg["height"], cfg["n_levels"]
+    rots, intrs = synth.make_cameras(n, w, h, sweep_deg=cfg.get("sweep_deg"), step_deg=cfg.get("step_deg"),
+                                     jitter=jitter, seed=9)
+    dev = eng.device
+    vv, uu = torch.meshgrid(torch.arange(h, dtype=torch.float64, device=dev),
+                            torch.arange(w, dtype=torch.float64, device=dev), indexing="ij")
+    pix = torch.stack([uu - w / 2, vv - h / 2, torch.ones_like(uu)], dim=0).reshape(3, -1)
+    frames = []
+    for i in range(n):
+        hom = torch.from_numpy(rots[i].T.dot(np.linalg.inv(intrs[i]))).to(dev)        # pixel -> ray
+        ray = hom @ pix
+        theta = torch.atan2(ray[0], ray[2])
+        phi = torch.atan2(ray[1], torch.sqrt(ray[0] ** 2 + ray[2] ** 2))
+        img = torch.stack([_analytic_texture(theta, phi, ch) for ch in range(3)], dim=-1)
+        frames.append(torch.round(img * 255.0).clamp(0, 255).to(torch.uint8).reshape(h, w, 3).contiguous())
+        del ray, theta, phi, img
+    plan = engine.Plan([(h, w)] * n, rots, intrs, True, 10 ** 9)
+    mosaic, _, valid, _ = eng.stitch(frames, plan, "multiband", levels)
+    H, W = plan.shape
+    theta = torch.arange(W, dtype=torch.float64, device=dev) * plan.resolution[0] + plan.low[0]
+    phi = torch.arange(H, dtype=torch.float64, device=dev) * plan.resolution[1] + plan.low[1]
+    want = [(_analytic_texture(theta[None, :], phi[:, None], ch) * 255.0).float() for ch in range(3)]
+    # valid and farther than R (+ the multiband padding) from anything invalid: erosion by max-pooling
+    R = max(engine.gaussian_ksize(s) // 2 for s in engine.level_sigmas(levels)) + 12
+    bad = (valid == 0).float()[None, None]
+    near_bad = torch.nn.functional.max_pool2d(bad, 2 * R + 1, stride=1, padding=R)[0, 0] > 0
+    core = ~near_bad
+    # (the mosaic's own outer border counts as invalid beyond it)
+    core[:R] = core[-R:] = False
+    core[:, :R] = core[:, -R:] = False
+    share = core.float().mean().item()
+    assert share > 0.55, share
+    del bad, near_bad
+
+    def worst(img):                                      # (channel by channel: 228 MP at config 5)
+        mx, total = 0.0, 0.0
+        for ch in range(3):
+            d = (img[..., ch].float() - want[ch]).abs()[core]
+            mx, total = max(mx, d.max().item()), total + d.sum().item()
+        return mx, total / (3.0 * core.sum().item())
+    mx, mean = worst(mosaic)
+    print(f"analytic panorama, {name}, jitter {jitter}: {int(core.sum().item()) / 1e6:.1f} MP compared "
+          f"({100 * share:.0f} % of the mosaic), max |mosaic - T| {mx:.2f} levels, mean {mean:.3f}")
+    assert mx <= 2.0 and mean <= 0.8
+    # ... and the same through the linear and the paste blenders (unpadded plan)
+    plan_u = engine.Plan([(h, w)] * n, rots, intrs, False, 10 ** 9)
+    assert plan_u.shape == plan.shape
+    for blend in ("linear", "none"):
+        assert worst(eng.stitch(frames, plan_u, blend)[0])[0] <= 2.0, blend
